@@ -1,0 +1,33 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+@pytest.fixture(scope='session')
+def dev():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip('no HIP device')
+    return torch.device('cuda:0')
+
+
+@pytest.fixture(scope='session')
+def assets():
+    from oracle import synth
+    return synth.make_assets(0)
+
+
+@pytest.fixture(scope='session')
+def state_dict(assets):
+    from oracle import synth
+    return synth.make_state_dict(0, assets)

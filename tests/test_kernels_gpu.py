@@ -1,0 +1,160 @@
+"""Per-kernel parity of the HIP library against plain fp32 torch on the same inputs (runs on the MI355X box)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return ((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize('M,N,K', [(392, 768, 768), (128, 128, 64), (12544, 2304, 768), (300, 3072, 768), (392, 768, 3072)])
+@pytest.mark.parametrize('glds', [True, False])
+def test_gemm_bf16(dev, M, N, K, glds):
+    from whmr_amd import _lib as L
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).bfloat16()
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    ref = F.gelu(a.float() @ w.float().t() + bias) + res
+    out = torch.empty(M, N, device=dev)
+    L.gemm(a.to(dev), w.to(dev), out, bias=bias.to(dev), residual=res.to(dev), act=L.ACT_GELU, glds=glds)
+    assert _rel(out.cpu(), ref) < 2e-5 * math.sqrt(K) / 8 + 1e-5
+    # bf16 output, no epilogue extras; asymmetric operands catch transposed C writes
+    out2 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    L.gemm(a.to(dev), w.to(dev), out2, glds=glds)
+    assert _rel(out2.float().cpu(), a.float() @ w.float().t()) < 1e-2
+
+
+def test_gemm_bf16_rowmod_residual(dev):
+    from whmr_amd import _lib as L
+    g = torch.Generator().manual_seed(3)
+    M, N, K, R = 392, 768, 768, 196
+    a = torch.randn(M, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).bfloat16()
+    pos = torch.randn(R, N, generator=g)
+    out = torch.empty(M, N, device=dev)
+    L.gemm(a.to(dev), w.to(dev), out, residual=pos.to(dev), res_row_mod=R)
+    ref = a.float() @ w.float().t() + pos.repeat(M // R, 1)
+    assert _rel(out.cpu(), ref) < 1e-4
+
+
+@pytest.mark.parametrize('M,N,K', [(64, 1024, 2250), (2, 216, 1024), (64, 3, 1024), (392, 768, 768), (320, 648, 216), (77, 130, 33)])
+def test_gemm_f32(dev, M, N, K):
+    from whmr_amd import _lib as L
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    out = torch.empty(M, N, device=dev)
+    L.gemm(a.to(dev), w.to(dev), out, bias=bias.to(dev), residual=res.to(dev))
+    ref = (a.double() @ w.double().t() + bias + res).float()
+    assert _rel(out.cpu(), ref) < 2e-6
+
+
+def _conv_case(dev, dtype, tol):
+    """implicit GEMM: Conv2d k7 s3 (Tz head conv, whmr.py:419) on an NHWC image"""
+    from whmr_amd import _lib as L
+    g = torch.Generator().manual_seed(11)
+    B, Cin, IH, IW, Cout, KH, KW, S = 2, 64, 23, 20, 128, 7, 7, 3
+    x = torch.randn(B, Cin, IH, IW, generator=g)
+    w = torch.randn(Cout, Cin, KH, KW, generator=g) / math.sqrt(Cin * KH * KW)
+    if dtype == torch.bfloat16:
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    ref = F.conv2d(x, w, stride=S)                                       # [B, Cout, OH, OW]
+    OH, OW = ref.shape[2:]
+    xn = x.permute(0, 2, 3, 1).contiguous().to(dtype).to(dev)             # NHWC
+    w2 = w.permute(0, 2, 3, 1).reshape(Cout, KH * KW * Cin).contiguous().to(dtype).to(dev)
+    out = torch.empty(B, OH, OW, Cout, device=dev)
+    L.gemm(xn, w2, out.view(-1, Cout), conv=dict(IH=IH, IW=IW, Cin=Cin, OH=OH, OW=OW, KW=KW, SH=S, SW=S, PH=0, PW=0))
+    assert _rel(out.permute(0, 3, 1, 2).cpu(), ref) < tol
+
+
+def test_conv_gather_bf16(dev):
+    _conv_case(dev, torch.bfloat16, 2e-5)
+
+
+def test_conv_gather_f32(dev):
+    _conv_case(dev, torch.float32, 2e-6)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_deconv_phases(dev, dtype):
+    """ConvTranspose2d(k4,s2,p1) as 4 sub-pixel 2x2 convs with scatter stores (whmr.py:488-498)"""
+    from whmr_amd import _lib as L
+    g = torch.Generator().manual_seed(5)
+    B, Cin, H, W, Cout = 2, 64, 6, 5, 128
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cin, Cout, 4, 4, generator=g) / math.sqrt(Cin * 4)
+    if dtype == torch.bfloat16:
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    ref = F.relu(F.conv_transpose2d(x, w, stride=2, padding=1))
+    xn = x.permute(0, 2, 3, 1).contiguous().to(dtype).to(dev)
+    out = torch.zeros(B, 2 * H, 2 * W, Cout, device=dev)
+    for py in range(2):
+        for px in range(2):
+            # taps a,b in {0,1}: iy = y + py - 1 + a, ky = 3 - py - 2a
+            wp = torch.stack([torch.stack([w[:, :, 3 - py - 2 * a, 3 - px - 2 * b] for b in range(2)], 0)
+                              for a in range(2)], 0)                     # [a, b, Cin, Cout]
+            w2 = wp.permute(3, 0, 1, 2).reshape(Cout, 4 * Cin).contiguous().to(dtype).to(dev)
+            L.gemm(xn, w2, out, act=L.ACT_RELU,
+                   conv=dict(IH=H, IW=W, Cin=Cin, OH=H, OW=W, KW=2, SH=1, SW=1, PH=1 - py, PW=1 - px),
+                   scatter=dict(c_off=(py * 2 * W + px) * Cout, osb=4 * H * W * Cout, osy=2 * 2 * W * Cout, osx=2 * Cout))
+    assert _rel(out.permute(0, 3, 1, 2).cpu(), ref) < (2e-5 if dtype == torch.bfloat16 else 2e-6)
+
+
+@pytest.mark.parametrize('C', [768, 216, 1024])
+@pytest.mark.parametrize('bf16', [False, True])
+def test_layernorm(dev, C, bf16):
+    from whmr_amd import _lib as L
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(391, C, generator=g) * 3 + 0.5
+    w, b = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    out = torch.empty(391, C, device=dev, dtype=torch.bfloat16 if bf16 else torch.float32)
+    L.layernorm(x.to(dev), w.to(dev), b.to(dev), out, 1e-6)
+    ref = F.layer_norm(x, (C,), w, b, 1e-6)
+    assert _rel(out.float().cpu(), ref) < (1e-2 if bf16 else 2e-6)
+
+
+@pytest.mark.parametrize('N', [196, 192, 5, 37])
+def test_attention_bf16(dev, N):
+    from whmr_amd import _lib as L
+    g = torch.Generator().manual_seed(N)
+    B, H, d = 3, 12, 64
+    qkv = (torch.randn(B, N, 3, H, d, generator=g) * 1.5).bfloat16()
+    q, k, v = qkv.float().permute(2, 0, 3, 1, 4)
+    ref = ((q * d ** -0.5) @ k.transpose(-2, -1)).softmax(-1) @ v
+    ref = ref.transpose(1, 2).reshape(B, N, H * d)
+    out = torch.empty(B, N, H * d, device=dev, dtype=torch.bfloat16)
+    L.attention(qkv.to(dev).view(B, N, 3 * H * d), out, B, N, H, d, d ** -0.5)
+    assert _rel(out.float().cpu(), ref) < 2e-2
+
+
+@pytest.mark.parametrize('N,H,d', [(196, 12, 64), (5, 2, 108), (192, 12, 64), (70, 3, 32)])
+def test_attention_f32(dev, N, H, d):
+    from whmr_amd import _lib as L
+    g = torch.Generator().manual_seed(N + d)
+    B = 2
+    qkv = torch.randn(B, N, 3, H, d, generator=g) * 1.5
+    q, k, v = qkv.permute(2, 0, 3, 1, 4)
+    ref = ((q * d ** -0.5) @ k.transpose(-2, -1)).softmax(-1) @ v
+    ref = ref.transpose(1, 2).reshape(B, N, H * d)
+    out = torch.empty(B, N, H * d, device=dev)
+    L.attention(qkv.to(dev).view(B, N, 3 * H * d), out, B, N, H, d, d ** -0.5)
+    assert _rel(out.cpu(), ref) < 5e-6
+
+
+def test_patch_im2col(dev):
+    from whmr_amd import _lib as L
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 3, 64, 80, generator=g)[:, :, :, 8:-8]             # sliced view like demo/tester.py:152
+    out = torch.empty(2 * 4 * 4, 768, device=dev)
+    L.patch_im2col(x.to(dev)[:, :, :, :], out, 16, 2)
+    ref = F.unfold(x, 16, padding=2, stride=16).transpose(1, 2).reshape(-1, 768)
+    assert torch.equal(out.cpu(), ref)

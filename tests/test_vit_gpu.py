@@ -1,0 +1,59 @@
+"""ViTPose backbone on the MI355X vs the CPU oracle and the committed reference fixtures."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return ((a.double() - b.double()).abs().max() / b.double().abs().max()).item()
+
+
+def _build(sd, prefix, img_size, numerics, dev):
+    from whmr_amd.models.pose_vit import ViT
+    m = ViT(img_size=img_size, patch_size=16, embed_dim=768, depth=12, num_heads=12, ratio=1, mlp_ratio=4,
+            qkv_bias=True, drop_path_rate=0.3, numerics=numerics)
+    m.load_state_dict({k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}, strict=True)
+    return m.to(dev).eval()
+
+
+def test_vit_256x192_fp32_matches_reference_fixture(dev, state_dict):
+    g = np.load(os.path.join(GOLDEN, 'whmr_b2.npz'))
+    m = _build(state_dict, 'feature_extractor.backbone.', (256, 192), 'fp32', dev)
+    out = m(torch.from_numpy(g['in_x']).to(dev))
+    assert out.shape == (2, 768, 16, 12)
+    assert _rel(out.cpu(), torch.from_numpy(g['s_feat'])) < 1e-4
+
+
+def test_vit_224_fp32_and_bf16(dev):
+    from oracle import synth
+    from oracle.vit import vit_forward
+    g = np.load(os.path.join(GOLDEN, 'vit224_b2.npz'))
+    sd = synth.make_vit_state(1, (224, 224))
+    x = torch.from_numpy(g['x'])
+    ref = torch.from_numpy(g['s_feat'])
+    assert _rel(vit_forward(sd, x), ref) < 1e-5                       # oracle still reproduces the reference fixture
+    out = _build(sd, '', (224, 224), 'fp32', dev)(x.to(dev))
+    assert _rel(out.cpu(), ref) < 1e-4
+    out16 = _build(sd, '', (224, 224), 'bf16', dev)(x.to(dev))
+    err = _rel(out16.cpu(), ref)
+    print('bf16 ViT max-rel error vs fp32 reference: %.3e' % err)
+    assert err < 5e-2
+
+
+def test_vit_full_size_properties(dev):
+    """BASELINE batch-64 size: per-image independence (batch of 64 == the same images run in two halves)."""
+    from oracle import synth
+    sd = synth.make_vit_state(1, (224, 224))
+    m = _build(sd, '', (224, 224), 'bf16', dev)
+    x = synth.make_inputs(64, 3, (224, 224))['x'].to(dev)
+    full = m(x).clone()
+    a = m(x[:32]).clone()
+    b = m(x[32:]).clone()
+    assert torch.equal(full, torch.cat([a, b]))
+    assert torch.isfinite(full).all()

@@ -1,0 +1,166 @@
+"""ctypes binding of libwhmr_hip.so (C ABI: include/whmr_hip.h) + thin tensor-level wrappers.
+
+PyTorch is used only for device memory and the current HIP stream.  There is NO fallback: if the shared
+library is missing, or a tensor is not on a HIP device, these functions raise.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libwhmr_hip.so')
+_lib = None
+
+
+class WhmrGemm(C.Structure):
+    _fields_ = [('A', C.c_void_p), ('W', C.c_void_p), ('C', C.c_void_p),
+                ('bias', C.c_void_p), ('residual', C.c_void_p), ('zeros', C.c_void_p),
+                ('M', C.c_int32), ('N', C.c_int32), ('K', C.c_int32),
+                ('lda', C.c_int32), ('ldc', C.c_int32), ('ldr', C.c_int32),
+                ('res_row_mod', C.c_int32), ('act', C.c_int32), ('out_bf16', C.c_int32), ('a_mode', C.c_int32),
+                ('IH', C.c_int32), ('IW', C.c_int32), ('Cin', C.c_int32), ('OH', C.c_int32), ('OW', C.c_int32),
+                ('KW', C.c_int32), ('SH', C.c_int32), ('SW', C.c_int32), ('PH', C.c_int32), ('PW', C.c_int32),
+                ('c_mode', C.c_int32),
+                ('c_off', C.c_int64), ('osb', C.c_int64), ('osy', C.c_int64), ('osx', C.c_int64)]
+
+
+_P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_long
+_SIGS = {
+    'whmr_gemm_bf16': [C.POINTER(WhmrGemm), _I, _P],
+    'whmr_gemm_f32': [C.POINTER(WhmrGemm), _I, _P],
+    'whmr_layernorm': [_P, _P, _P, _P, _I, _I, _F, _I, _P],
+    'whmr_patch_im2col': [_P, _P, _I, _I, _I, _I, _I, _I, _L, _L, _L, _L, _I, _P],
+    'whmr_cast_f32_bf16': [_P, _P, _L, _P],
+    'whmr_attention': [_P, _P, _I, _I, _I, _I, _F, _I, _P],
+}
+EXPORTS = tuple(_SIGS)
+
+
+def lib():
+    """Load the HIP library (once).  Raises if it has not been built -- there is no CPU path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError('%s not found: build it with `python -m whmr_amd.build` (hipcc, gfx950). '
+                              'The W-HMR hot path has no non-HIP fallback.' % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, args in _SIGS.items():
+            fn = getattr(l, name)
+            fn.argtypes = args
+            fn.restype = C.c_int
+        _lib = l
+    return _lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _check(err, what):
+    if err != 0:
+        raise RuntimeError('%s failed: hipError %d' % (what, err))
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('whmr_amd kernels need HIP device tensors (got %s); there is no CPU fallback' % t.device)
+
+
+_zeros = {}
+
+
+def zero_page(device):
+    z = _zeros.get(device)
+    if z is None:
+        z = _zeros[device] = torch.zeros(1024, dtype=torch.uint8, device=device)
+    return z
+
+
+ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+
+
+def gemm(a, w, out, bias=None, residual=None, res_row_mod=0, act=ACT_NONE, conv=None, scatter=None, M=None,
+         lda=None, glds=True):
+    """out = act(a . w^T + bias) + residual.  a/w dtype selects the kernel (bf16 MFMA or exact-fp32 MFMA).
+
+    conv = dict(IH, IW, Cin, OH, OW, KW, SH, SW, PH, PW): a is an NHWC image [B, IH, IW, Cin], rows are output pixels.
+    scatter = dict(c_off, osb, osy, osx): row (b, oy, ox) is written at that offset of ``out`` (needs conv dims).
+    """
+    _dev(a, w, out, bias, residual)
+    assert a.dtype == w.dtype and a.dtype in (torch.bfloat16, torch.float32)
+    assert a.is_contiguous() or lda is not None
+    assert w.is_contiguous() and w.dim() == 2
+    N, K = w.shape
+    p = WhmrGemm()
+    p.A, p.W, p.C = a.data_ptr(), w.data_ptr(), out.data_ptr()
+    p.bias = bias.data_ptr() if bias is not None else None
+    p.residual = residual.data_ptr() if residual is not None else None
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() == N
+    if residual is not None:
+        assert residual.dtype == torch.float32 and residual.stride(-1) == 1
+        p.ldr = residual.stride(-2)
+    p.res_row_mod = res_row_mod
+    p.act = act
+    assert out.dtype in (torch.bfloat16, torch.float32)
+    p.out_bf16 = int(out.dtype == torch.bfloat16)
+    if conv is not None:
+        p.a_mode = 1
+        for k in ('IH', 'IW', 'Cin', 'OH', 'OW', 'KW', 'SH', 'SW', 'PH', 'PW'):
+            setattr(p, k, conv[k])
+        B = a.shape[0]
+        p.M = B * conv['OH'] * conv['OW'] if M is None else M
+        assert K % conv['Cin'] == 0
+        p.zeros = zero_page(a.device).data_ptr()
+    else:
+        p.M = (a.numel() // a.shape[-1]) if M is None else M
+        p.lda = a.stride(-2) if lda is None else lda
+        assert a.shape[-1] == K
+    p.N, p.K = N, K
+    if scatter is not None:
+        p.c_mode = 1
+        for k in ('c_off', 'osb', 'osy', 'osx'):
+            setattr(p, k, scatter[k])
+    else:
+        p.ldc = out.stride(-2) if out.dim() >= 2 else N
+    fn = lib().whmr_gemm_bf16 if a.dtype == torch.bfloat16 else lib().whmr_gemm_f32
+    _check(fn(C.byref(p), 0 if glds else 1, _stream()), 'whmr_gemm')
+    return out
+
+
+def layernorm(x, weight, bias, out, eps):
+    _dev(x, weight, bias, out)
+    assert x.dtype == torch.float32 and x.is_contiguous() and out.is_contiguous()
+    Cdim = x.shape[-1]
+    _check(lib().whmr_layernorm(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), out.data_ptr(), x.numel() // Cdim,
+                                Cdim, eps, int(out.dtype == torch.bfloat16), _stream()), 'whmr_layernorm')
+    return out
+
+
+def patch_im2col(x, out, patch, pad):
+    _dev(x, out)
+    assert x.dtype == torch.float32 and x.dim() == 4
+    B, Cin, H, W = x.shape
+    sb, sc, sh, sw = x.stride()
+    _check(lib().whmr_patch_im2col(x.data_ptr(), out.data_ptr(), B, Cin, H, W, patch, pad, sb, sc, sh, sw,
+                                   int(out.dtype == torch.bfloat16), _stream()), 'whmr_patch_im2col')
+    return out
+
+
+def cast_bf16(src):
+    _dev(src)
+    src = src.contiguous()
+    assert src.dtype == torch.float32
+    dst = torch.empty(src.shape, dtype=torch.bfloat16, device=src.device)
+    _check(lib().whmr_cast_f32_bf16(src.data_ptr(), dst.data_ptr(), src.numel(), _stream()), 'whmr_cast_f32_bf16')
+    return dst
+
+
+def attention(qkv, out, B, N, H, d, scale):
+    _dev(qkv, out)
+    assert qkv.is_contiguous() and out.is_contiguous() and qkv.dtype == out.dtype
+    _check(lib().whmr_attention(qkv.data_ptr(), out.data_ptr(), B, N, H, d, scale,
+                                int(qkv.dtype == torch.bfloat16), _stream()), 'whmr_attention')
+    return out

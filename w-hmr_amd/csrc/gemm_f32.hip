@@ -1,0 +1,132 @@
+// fp32 MFMA GEMM / implicit-GEMM (parity path + skinny regressor GEMMs):  C = epilogue(A[M,K] . W[N,K]^T)
+//
+// Exact-f32 arithmetic on v_mfma_f32_32x32x2_f32 (bitwise an fmaf chain over k; no reduced precision on gfx950),
+// so the result differs from the reference's CPU sgemm only by summation order.  Any M, N, K (all masked).
+// Used for: every GEMM of the fp32 "parity" mode of the ViT / deconv path, and always for the regressor stages
+// (whmr.py:118-126: fc1 -> fc2 -> decpose/decshape/deccam), Global_Orient_Regressor (whmr.py:295-301), the Tz
+// head linears (whmr.py:425-430), the second Tz conv (whmr.py:420) -- M = batch, weight-streaming bound.
+//
+// 64x64x16 block tile, 4 waves (2x2), one 32x32 accumulator per wave, register-staged LDS (rows padded to 17
+// dwords: conflict-free ds_read_b32 fragment reads).  Same descriptor / gather / scatter modes as the bf16 kernel.
+#include "common.h"
+#include "gemm_params.h"
+
+#define FBM 64
+#define FBN 64
+#define FBK 16
+#define FLD 17
+
+template <bool GATHER>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const whmr_gemm p) {
+    __shared__ float sA[FBM * FLD];
+    __shared__ float sB[FBN * FLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_n = (p.N + FBN - 1) / FBN;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    const int m0 = tm * FBM, n0 = tn * FBN;
+    const float* __restrict__ A = (const float*)p.A;
+    const float* __restrict__ W = (const float*)p.W;
+
+    // staging: thread -> (row = tid>>2, 4 consecutive k = (tid&3)*4)
+    const int srow = tid >> 2, sk = (tid & 3) * 4;
+    const int am = m0 + srow, bn = n0 + srow;
+    const bool a_ok = am < p.M, b_ok = bn < p.N;
+    int ay = 0, ax = 0;
+    const float* a_base = A;
+    if (a_ok) {
+        if constexpr (GATHER) {
+            const int ohw = p.OH * p.OW;
+            const int b = am / ohw, rem = am - b * ohw;
+            const int oy = rem / p.OW, ox = rem - oy * p.OW;
+            ay = oy * p.SH - p.PH;
+            ax = ox * p.SW - p.PW;
+            a_base = A + (size_t)b * p.IH * p.IW * p.Cin;
+        } else {
+            a_base = A + (size_t)am * p.lda;
+        }
+    }
+    const float* b_base = W + (size_t)(b_ok ? bn : 0) * p.K;
+
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    f32x16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    for (int k0 = 0; k0 < p.K; k0 += FBK) {
+        float av[4], bw[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = k0 + sk + e;
+            float a = 0.f, b = 0.f;
+            if (k < p.K) {
+                if (a_ok) {
+                    if constexpr (GATHER) {
+                        const int tap = k / p.Cin, ci = k - tap * p.Cin;
+                        const int ky = tap / p.KW, kx = tap - ky * p.KW;
+                        const int iy = ay + ky, ix = ax + kx;
+                        if ((unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW)
+                            a = a_base[((size_t)iy * p.IW + ix) * p.Cin + ci];
+                    } else {
+                        a = a_base[k];
+                    }
+                }
+                if (b_ok) b = b_base[k];
+            }
+            av[e] = a; bw[e] = b;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            sA[srow * FLD + sk + e] = av[e];
+            sB[srow * FLD + sk + e] = bw[e];
+        }
+        __syncthreads();
+        // A operand: lane l holds A[i = l&31][k = l>>5]; B operand: B[k = l>>5][j = l&31]
+#pragma unroll
+        for (int kk = 0; kk < FBK; kk += 2) {
+            const float a = sA[(wm * 32 + l31) * FLD + kk + hi];
+            const float b = sB[(wn * 32 + l31) * FLD + kk + hi];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+    }
+
+    const int n = n0 + wn * 32 + l31;
+    if (n >= p.N) return;
+    const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (m >= p.M) continue;
+        float v = acc[r] + bv;
+        if (p.act == 1) v = gelu_erf(v);
+        else if (p.act == 2) v = fmaxf(v, 0.f);
+        if (p.residual) {
+            const int rr = p.res_row_mod > 0 ? m % p.res_row_mod : m;
+            v += p.residual[(size_t)rr * p.ldr + n];
+        }
+        size_t off;
+        if (p.c_mode == 1) {
+            const int ohw = p.OH * p.OW;
+            const int b = m / ohw, rem = m - b * ohw;
+            const int oy = rem / p.OW, ox = rem - oy * p.OW;
+            off = (size_t)(p.c_off + b * p.osb + oy * p.osy + ox * p.osx) + n;
+        } else {
+            off = (size_t)m * p.ldc + n;
+        }
+        if (p.out_bf16) ((bf16_t*)p.C)[off] = f32_to_bf16(v);
+        else ((float*)p.C)[off] = v;
+    }
+}
+
+extern "C" int whmr_gemm_f32(const whmr_gemm* pp, int flags, void* stream) {
+    (void)flags;
+    const whmr_gemm& p = *pp;
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0) return (int)hipErrorInvalidValue;
+    const int tiles = ((p.M + FBM - 1) / FBM) * ((p.N + FBN - 1) / FBN);
+    hipStream_t st = (hipStream_t)stream;
+    if (p.a_mode == 1) hipLaunchKernelGGL(gemm_f32_kernel<true>, dim3(tiles), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(gemm_f32_kernel<false>, dim3(tiles), dim3(256), 0, st, p);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}

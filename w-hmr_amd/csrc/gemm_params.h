@@ -1,0 +1,22 @@
+// GEMM / implicit-GEMM descriptor shared by the bf16 (MFMA 32x32x16) and fp32 (MFMA 32x32x2) kernels.
+// Mirrors `struct whmr_gemm` in include/whmr_hip.h (plain C layout; filled by the host through ctypes).
+#pragma once
+#include <stdint.h>
+
+struct whmr_gemm {
+    const void* A;          // activations: plain [M, lda] or NHWC image for a_mode = 1
+    const void* W;          // weights [N, K], K contiguous (nn.Linear layout / conv weight re-ordered (co, ky, kx, ci))
+    void* C;                // output, fp32 or bf16 (out_bf16)
+    const float* bias;      // [N] or null
+    const float* residual;  // fp32, row stride ldr, or null; added after the activation
+    const void* zeros;      // >= 256 B of zeros (gather padding source); required when a_mode = 1
+    int32_t M, N, K;
+    int32_t lda, ldc, ldr;
+    int32_t res_row_mod;    // > 0: residual row = m % res_row_mod (pos-embed broadcast, vit.py:320)
+    int32_t act;            // 0 none, 1 exact-erf GELU, 2 ReLU
+    int32_t out_bf16;       // 1: C is bf16, 0: fp32
+    int32_t a_mode;         // 0 plain, 1 conv gather: row m = (b, oy, ox), k = (ky, kx, ci)
+    int32_t IH, IW, Cin, OH, OW, KW, SH, SW, PH, PW;   // iy = oy*SH + ky - PH, ix = ox*SW + kx - PW
+    int32_t c_mode;         // 0 plain rows (m*ldc), 1 spatial scatter: c_off + b*osb + oy*osy + ox*osx
+    int64_t c_off, osb, osy, osx;
+};

@@ -1,0 +1,129 @@
+// Memory-bound helpers of the ViT path: LayerNorm and the patch-embed im2col.
+//   whmr_layernorm   <- nn.LayerNorm(eps=1e-6) at vit.py:125,133,212,242 (and eps=1e-5 inside the timm Block, whmr.py:423)
+//   whmr_patch_im2col <- the gather half of PatchEmbed's Conv2d(k16, s16, pad 2) at vit.py:157,161 (GEMM half: gemm_*.hip)
+#include "common.h"
+
+// One wave per row; the row is held in registers (C <= 64*4*MAXV), two-pass mean / variance in fp32 like ATen's CPU kernel.
+template <typename TOUT, int MAXV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                        const float* __restrict__ b, TOUT* __restrict__ y,
+                                                        int rows, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * C;
+    const int nv = C >> 2;            // float4 per row
+    float4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c4 = lane + 64 * i;
+        if (c4 < nv) {
+            v[i] = *(const float4*)(xr + c4 * 4);
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c4 = lane + 64 * i;
+        if (c4 < nv) {
+            const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+            q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+    TOUT* yr = y + (size_t)row * C;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c4 = lane + 64 * i;
+        if (c4 < nv) {
+            const float4 gg = *(const float4*)(g + c4 * 4), bb = *(const float4*)(b + c4 * 4);
+            const float o0 = (v[i].x - mean) * rstd * gg.x + bb.x, o1 = (v[i].y - mean) * rstd * gg.y + bb.y;
+            const float o2 = (v[i].z - mean) * rstd * gg.z + bb.z, o3 = (v[i].w - mean) * rstd * gg.w + bb.w;
+            if constexpr (sizeof(TOUT) == 4) {
+                *(float4*)(yr + c4 * 4) = make_float4(o0, o1, o2, o3);
+            } else {
+                *(uint2*)(yr + c4 * 4) = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
+            }
+        }
+    }
+}
+
+extern "C" int whmr_layernorm(const float* x, const float* gamma, const float* beta, void* y, int rows, int C,
+                              float eps, int out_bf16, void* stream) {
+    if (rows <= 0 || C <= 0 || (C & 3) || C > 64 * 4 * 8) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((rows + 3) / 4), block(256);
+    const bool small = C <= 64 * 4 * 3;
+    if (out_bf16) {
+        if (small) hipLaunchKernelGGL((layernorm_kernel<bf16_t, 3>), grid, block, 0, st, x, gamma, beta, (bf16_t*)y, rows, C, eps);
+        else hipLaunchKernelGGL((layernorm_kernel<bf16_t, 8>), grid, block, 0, st, x, gamma, beta, (bf16_t*)y, rows, C, eps);
+    } else {
+        if (small) hipLaunchKernelGGL((layernorm_kernel<float, 3>), grid, block, 0, st, x, gamma, beta, (float*)y, rows, C, eps);
+        else hipLaunchKernelGGL((layernorm_kernel<float, 8>), grid, block, 0, st, x, gamma, beta, (float*)y, rows, C, eps);
+    }
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+// x: NCHW fp32 with arbitrary strides (the demo passes a sliced view, demo/tester.py:152) ->
+// cols [B*Hp*Wp, Cin*P*P] (k = ci*P*P + ky*P + kx, i.e. the flattened conv weight order), zero padded borders.
+template <typename TOUT>
+__global__ __launch_bounds__(256) void patch_im2col_kernel(const float* __restrict__ x, TOUT* __restrict__ cols,
+                                                           int B, int Cin, int H, int W, int P, int pad, int Hp, int Wp,
+                                                           long sb, long sc, long sh, long sw) {
+    // one thread per (patch row m, ci, ky): copies P contiguous kx
+    const long total = (long)B * Hp * Wp * Cin * P;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int ky = idx % P;
+    long t = idx / P;
+    const int ci = t % Cin;
+    const long m = t / Cin;
+    const int px = m % Wp;
+    const int py = (m / Wp) % Hp;
+    const int b = m / ((long)Wp * Hp);
+    const int iy = py * P - pad + ky;
+    TOUT* dst = cols + ((size_t)m * Cin + ci) * P * P + ky * P;
+    const bool rowok = (unsigned)iy < (unsigned)H;
+    const float* src = x + b * sb + ci * sc + (long)iy * sh;
+    for (int kx = 0; kx < P; ++kx) {
+        const int ix = px * P - pad + kx;
+        const float v = (rowok && (unsigned)ix < (unsigned)W) ? src[(long)ix * sw] : 0.f;
+        io<TOUT>::st(dst + kx, v);
+    }
+}
+
+extern "C" int whmr_patch_im2col(const float* x, void* cols, int B, int Cin, int H, int W, int P, int pad,
+                                 long sb, long sc, long sh, long sw, int out_bf16, void* stream) {
+    const int Hp = (H + 2 * pad - P) / P + 1, Wp = (W + 2 * pad - P) / P + 1;
+    const long total = (long)B * Hp * Wp * Cin * P;
+    if (total <= 0) return (int)hipErrorInvalidValue;
+    dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (out_bf16) hipLaunchKernelGGL(patch_im2col_kernel<bf16_t>, grid, block, 0, st, x, (bf16_t*)cols, B, Cin, H, W, P, pad, Hp, Wp, sb, sc, sh, sw);
+    else hipLaunchKernelGGL(patch_im2col_kernel<float>, grid, block, 0, st, x, (float*)cols, B, Cin, H, W, P, pad, Hp, Wp, sb, sc, sh, sw);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+// dst = (T)src, elementwise fp32 -> bf16 (weight preparation / activation casts that are not fused anywhere)
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n) {
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        const float4 v = *(const float4*)(src + i);
+        *(uint2*)(dst + i) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+    } else {
+        for (long j = i; j < n; ++j) dst[j] = f32_to_bf16(src[j]);
+    }
+}
+
+extern "C" int whmr_cast_f32_bf16(const float* src, void* dst, long n, void* stream) {
+    if (n <= 0) return (int)hipErrorInvalidValue;
+    if (((uintptr_t)src & 15) || ((uintptr_t)dst & 7)) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)((n / 4 + 256) / 256)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}

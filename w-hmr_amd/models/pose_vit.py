@@ -1,0 +1,181 @@
+"""ViTPose backbone on MI355X -- same module surface as the reference, HIP kernels inside.
+
+Mirrors models/pose_vit.py:8-23 (``VitPose`` with child ``.backbone``, ``get_vitpose_encoder``) and the
+``ViT`` of models/ViTPose/mmpose/models/backbones/vit.py:200-341: identical constructor arguments for the
+parts W-HMR uses, identical ``state_dict`` keys, ``forward(x) -> [B, C, Hp, Wp]``.
+
+Forward (inference) = 1 im2col + 1 + 12*4 GEMM launches + 25 LayerNorms + 12 attention launches, all from
+libwhmr_hip.so.  ``numerics``: 'bf16' (default; bf16 MFMA operands, fp32 accumulate, fp32 residual stream)
+or 'fp32' (exact-f32 MFMA everywhere: the 1e-4 parity mode of BASELINE.json).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+
+
+def _pair(v):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+
+
+class _Holder(nn.Module):
+    """Parameter container (keeps reference key names; compute is driven by ViT.forward)."""
+
+
+def _linear_params(m, name, out_f, in_f, bias=True):
+    lin = _Holder()
+    lin.weight = nn.Parameter(torch.empty(out_f, in_f))
+    nn.init.trunc_normal_(lin.weight, std=.02)
+    if bias:
+        lin.bias = nn.Parameter(torch.zeros(out_f))
+    else:
+        lin.register_parameter('bias', None)
+    setattr(m, name, lin)
+
+
+def _ln_params(m, name, dim):
+    ln = _Holder()
+    ln.weight = nn.Parameter(torch.ones(dim))
+    ln.bias = nn.Parameter(torch.zeros(dim))
+    setattr(m, name, ln)
+
+
+class ViT(nn.Module):
+    """vit.py:200-341 (plain ViT, pos-embed with an unused cls slot, pre-LN blocks eps 1e-6, last_norm)."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=80, embed_dim=768, depth=12, num_heads=12,
+                 mlp_ratio=4., qkv_bias=False, qk_scale=None, drop_rate=0., attn_drop_rate=0., drop_path_rate=0.,
+                 hybrid_backbone=None, norm_layer=None, use_checkpoint=False, frozen_stages=-1, ratio=1,
+                 last_norm=True, patch_padding='pad', freeze_attn=False, freeze_ffn=False, numerics='bf16'):
+        super().__init__()
+        assert hybrid_backbone is None and ratio == 1 and last_norm, 'only the configuration W-HMR uses is built'
+        img_size, ps = _pair(img_size), _pair(patch_size)
+        assert ps[0] == ps[1]
+        self.img_size, self.patch_size = img_size, ps[0]
+        self.embed_dim = self.num_features = embed_dim
+        self.depth, self.num_heads = depth, num_heads
+        self.scale = qk_scale or (embed_dim // num_heads) ** -0.5
+        self.numerics = numerics
+        self.patch_pad = 4 + 2 * (ratio // 2 - 1)                       # vit.py:157 -> 2
+        num_patches = (img_size[0] // ps[0]) * (img_size[1] // ps[1])
+        self.patch_embed = _Holder()
+        self.patch_embed.proj = _Holder()
+        self.patch_embed.proj.weight = nn.Parameter(torch.empty(embed_dim, in_chans, ps[0], ps[1]))
+        nn.init.kaiming_uniform_(self.patch_embed.proj.weight, a=math.sqrt(5))
+        self.patch_embed.proj.bias = nn.Parameter(torch.zeros(embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, num_patches + 1, embed_dim))
+        nn.init.trunc_normal_(self.pos_embed, std=.02)
+        hidden = int(embed_dim * mlp_ratio)
+        self.blocks = nn.ModuleList()
+        for _ in range(depth):
+            blk = _Holder()
+            _ln_params(blk, 'norm1', embed_dim)
+            blk.attn = _Holder()
+            _linear_params(blk.attn, 'qkv', 3 * embed_dim, embed_dim, qkv_bias)
+            _linear_params(blk.attn, 'proj', embed_dim, embed_dim)
+            _ln_params(blk, 'norm2', embed_dim)
+            blk.mlp = _Holder()
+            _linear_params(blk.mlp, 'fc1', hidden, embed_dim)
+            _linear_params(blk.mlp, 'fc2', embed_dim, hidden)
+            self.blocks.append(blk)
+        _ln_params(self, 'last_norm', embed_dim)
+        self._wcache = {}
+        self._ws = {}
+
+    # ------------------------------------------------------------------ weight / workspace caches
+    def _w(self, p, shape=None):
+        """Operand copy of a weight in the compute dtype (bf16 copies are re-made when the parameter changes)."""
+        if self.numerics == 'fp32':
+            w = p.detach()
+            return w.reshape(shape) if shape is not None else w
+        key = id(p)
+        ent = self._wcache.get(key)
+        if ent is None or ent[0] != p._version or ent[1].device != p.device:
+            w = L.cast_bf16(p.detach())
+            ent = (p._version, w.reshape(shape) if shape is not None else w)
+            self._wcache[key] = ent
+        return ent[1]
+
+    def _buf(self, name, shape, dtype, device):
+        key = (name, tuple(shape), dtype, device)
+        t = self._ws.get(key)
+        if t is None:
+            t = self._ws[key] = torch.empty(shape, dtype=dtype, device=device)
+        return t
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward_tokens(self, x):
+        """x [B,3,H,W] fp32 (any strides) -> (tokens [B*N, C] fp32 after last_norm, (B, Hp, Wp))."""
+        if not x.is_cuda:
+            raise RuntimeError('whmr_amd.ViT runs on a HIP device only (no CPU fallback)')
+        B, Cin, H, W = x.shape
+        P, pad, D = self.patch_size, self.patch_pad, self.embed_dim
+        Hp, Wp = (H + 2 * pad - P) // P + 1, (W + 2 * pad - P) // P + 1
+        N, M = Hp * Wp, B * Hp * Wp
+        assert N + 1 == self.pos_embed.shape[1], 'input size does not match pos_embed (vit.py:231)'
+        dt = torch.float32 if self.numerics == 'fp32' else torch.bfloat16
+        dev = x.device
+        cols = self._buf('cols', (M, Cin * P * P), dt, dev)
+        L.patch_im2col(x.float(), cols, P, pad)
+        pos = self._buf('pos', (N, D), torch.float32, dev)
+        torch.add(self.pos_embed[0, 1:], self.pos_embed[0, :1], out=pos)              # vit.py:320
+        t = self._buf('t', (M, D), torch.float32, dev)
+        L.gemm(cols, self._w(self.patch_embed.proj.weight, (D, Cin * P * P)), t, bias=self.patch_embed.proj.bias,
+               residual=pos, res_row_mod=N)
+        h = self._buf('h', (M, D), dt, dev)
+        qkv = self._buf('qkv', (M, 3 * D), dt, dev)
+        att = self._buf('att', (M, D), dt, dev)
+        hid = self._buf('hid', (M, self.blocks[0].mlp.fc1.weight.shape[0]), dt, dev) if self.depth else None
+        for blk in self.blocks:
+            L.layernorm(t, blk.norm1.weight, blk.norm1.bias, h, 1e-6)
+            L.gemm(h, self._w(blk.attn.qkv.weight), qkv, bias=blk.attn.qkv.bias)
+            L.attention(qkv, att, B, N, self.num_heads, D // self.num_heads, self.scale)
+            L.gemm(att, self._w(blk.attn.proj.weight), t, bias=blk.attn.proj.bias, residual=t)
+            L.layernorm(t, blk.norm2.weight, blk.norm2.bias, h, 1e-6)
+            L.gemm(h, self._w(blk.mlp.fc1.weight), hid, bias=blk.mlp.fc1.bias, act=L.ACT_GELU)
+            L.gemm(hid, self._w(blk.mlp.fc2.weight), t, bias=blk.mlp.fc2.bias, residual=t)
+        out = self._buf('out', (M, D), torch.float32, dev)
+        L.layernorm(t, self.last_norm.weight, self.last_norm.bias, out, 1e-6)
+        return out, (B, Hp, Wp)
+
+    def forward_features(self, x):
+        tok, (B, Hp, Wp) = self.forward_tokens(x)
+        # vit.py:330 returns NCHW; the tokens already are NHWC, so hand back the NCHW *view* (channels-last memory).
+        return tok.view(B, Hp, Wp, self.embed_dim).permute(0, 3, 1, 2)
+
+    def forward(self, x):
+        return self.forward_features(x)
+
+
+class VitPose(nn.Module):
+    """models/pose_vit.py:8-15."""
+
+    def __init__(self, config):
+        super().__init__()
+        cfg = dict(config['backbone'] if isinstance(config, dict) else config.backbone)
+        cfg.pop('type', None)
+        self.backbone = ViT(**cfg)
+
+    def forward(self, x):
+        return self.backbone(x)
+
+
+# models/ViTPose/configs/body/2d_kpt_sview_rgb_img/topdown_heatmap/coco/ViTPose_base_coco_256x192.py:170-182
+VITPOSE_BASE_256x192 = dict(img_size=(256, 192), patch_size=16, embed_dim=768, depth=12, num_heads=12, ratio=1,
+                            use_checkpoint=False, mlp_ratio=4, qkv_bias=True, drop_path_rate=0.3)
+# .../ViTPose_large_coco_256x192.py:46-58
+VITPOSE_LARGE_256x192 = dict(img_size=(256, 192), patch_size=16, embed_dim=1024, depth=24, num_heads=16, ratio=1,
+                             use_checkpoint=False, mlp_ratio=4, qkv_bias=True, drop_path_rate=0.5)
+
+
+def get_vitpose_encoder(cfg=None, pretrained='data/pretrained_model/vitpose-b-multi-coco.pth', numerics='bf16'):
+    """models/pose_vit.py:17-23.  Loads the ViTPose checkpoint when it exists (strict=False like the reference)."""
+    import os
+    model = VitPose(dict(backbone=dict(VITPOSE_BASE_256x192, numerics=numerics)))
+    if pretrained and os.path.exists(pretrained):
+        ckpt = torch.load(pretrained, map_location='cpu')
+        model.load_state_dict(ckpt['state_dict'], strict=False)
+    return model
