@@ -1,0 +1,137 @@
+"""Benchmark of the W-HMR hot path on MI355X.  Contract: see the task brief / DESIGN.md "Measurement".
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload vit224|vit256x192|whmr] [--no-cpu]
+
+A step = one forward of the hot path over one batch of 64 synthetic crops per GPU (inputs resident in HBM).
+N=1 default workload = BASELINE.json configs[1]: ViT-B/16 backbone only, 224x224, batch 64, bf16 MFMA.
+For N>1 launch under torch.distributed.run (one rank per GPU, RCCL); the path shards by image with no data-path
+collective (replicas, weak scaling), so only the timing barrier / max-reduce use the communicator.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+VIT_FLOP_PER_IMG = {'vit224': 34.94e9, 'vit256x192': 34.20e9}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=64)
+    ap.add_argument('--workload', default='vit224')
+    ap.add_argument('--numerics', default='bf16')
+    ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
+    return ap.parse_args()
+
+
+def build_workload(args, dev):
+    from oracle import synth                       # synthetic weights / inputs only (generator, not a compute path)
+    from whmr_amd.models.pose_vit import ViT
+    if args.workload in ('vit224', 'vit256x192'):
+        size = (224, 224) if args.workload == 'vit224' else (256, 192)
+        sd = synth.make_vit_state(1, size)
+        m = ViT(img_size=size, patch_size=16, embed_dim=768, depth=12, num_heads=12, ratio=1, mlp_ratio=4,
+                qkv_bias=True, drop_path_rate=0.3, numerics=args.numerics)
+        m.load_state_dict(sd, strict=True)
+        m = m.to(dev).eval()
+        x = synth.make_inputs(args.batch, 7, size)['x'].to(dev)
+        return (lambda: m(x)), sd, x, size
+    raise SystemExit('unknown workload %s' % args.workload)
+
+
+def cpu_baseline(sd, x_cpu, size):
+    """Oracle (pure-PyTorch fp32 restatement of the reference ViT) on the host cores, bounded sample."""
+    from oracle.vit import vit_forward
+    torch.set_num_threads(os.cpu_count() or 1)
+    with torch.no_grad():
+        vit_forward(sd, x_cpu[:4])                         # warm-up
+        n = x_cpu.shape[0]
+        t0 = time.perf_counter()
+        vit_forward(sd, x_cpu)
+        dt = time.perf_counter() - t0
+    return {'value': n / dt, 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': 'oracle.vit.vit_forward fp32, one batch of %d %dx%d crops, 1 pass (%.1f s)' % (n, size[0], size[1], dt)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a HIP device: the hot path has no CPU fallback')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)
+
+    from whmr_amd import _lib as L
+    step, sd, x, size = build_workload(args, dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        # dominant-kernel timing: one instrumented step, HIP events around every GEMM launch on the launch stream
+        L.PROFILE = []
+        step()
+        torch.cuda.synchronize()
+        prof, L.PROFILE = L.PROFILE, None
+    tmax = torch.tensor([dt], device=dev)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = tmax.item()
+
+    gemm = [(f, e0.elapsed_time(e1) * 1e-3) for (name, f, e0, e1) in prof if name == 'gemm_bf16']
+    n_launch = max(len(gemm), 1)
+    flops_per_launch = sum(f for f, _ in gemm) / n_launch
+    avg_s = sum(t for _, t in gemm) / n_launch
+    achieved = flops_per_launch / avg_s / 1e12 if gemm else 0.0
+    peak = 2500.0                                                     # dense bf16 MFMA, MI355X_MICROARCH.md
+    if rank == 0:
+        res = {
+            'metric': 'images/sec ViT-B 224^2 batch-64 fwd', 'value': world * args.batch * args.steps / dt,
+            'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': args.numerics, 'data': 'synthetic',
+            'config': {'workload': 'ViT-B/16 backbone forward (%s), %dx%d crops, batch %d per GPU, random-init weights'
+                                   % (args.workload, size[0], size[1], args.batch),
+                       'global_batch': world * args.batch, 'parallelism': 'replicas x%d (no data-path collective)' % world},
+            'model_tflops': VIT_FLOP_PER_IMG[args.workload] * world * args.batch * args.steps / dt / 1e12,
+            'roofline': {'bound': 'mfma', 'kernel': 'gemm_bf16_kernel (all %d launches of one step)' % len(gemm),
+                         'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
+                         'flops_per_launch': flops_per_launch, 'avg_launch_us': avg_s * 1e6, 'traffic': None},
+        }
+        if not args.no_cpu and world == 1:
+            res['cpu_baseline'] = cpu_baseline(sd, x.cpu(), size)
+        else:
+            res['cpu_baseline'] = None
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -79,6 +79,7 @@ def zero_page(device):
 
 
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+PROFILE = None        # bench.py sets this to a list: (kernel, flops, start_event, end_event) per GEMM launch
 
 
 def gemm(a, w, out, bias=None, residual=None, res_row_mod=0, act=ACT_NONE, conv=None, scatter=None, M=None,
@@ -126,6 +127,13 @@ def gemm(a, w, out, bias=None, residual=None, res_row_mod=0, act=ACT_NONE, conv=
     else:
         p.ldc = out.stride(-2) if out.dim() >= 2 else N
     fn = lib().whmr_gemm_bf16 if a.dtype == torch.bfloat16 else lib().whmr_gemm_f32
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _check(fn(C.byref(p), 0 if glds else 1, _stream()), 'whmr_gemm')
+        e1.record()
+        PROFILE.append(('gemm_bf16' if a.dtype == torch.bfloat16 else 'gemm_f32', 2.0 * p.M * p.N * p.K, e0, e1))
+        return out
     _check(fn(C.byref(p), 0 if glds else 1, _stream()), 'whmr_gemm')
     return out
 
