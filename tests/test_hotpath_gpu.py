@@ -1,0 +1,179 @@
+"""Geometry / SMPL LBS / MAF sampler kernels and the full W-HMR forward on the MI355X vs the oracle + reference fixtures."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+@pytest.fixture(scope='module')
+def geo():
+    return {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLDEN, 'geometry.npz')).items()}
+
+
+def test_geometry_matches_reference_fixture(dev, geo):
+    """every utils.geometry function against the outputs of the reference's own utils/geometry.py (edge cases included)"""
+    from whmr_amd.utils import geometry as G
+    d = lambda k: geo['in_' + k].to(dev)
+    assert _rel(G.rot6d_to_rotmat(d('r6')), geo['out_r6_to_R']) < 1e-5
+    assert _rel(G.unbiased_gram_schmidt(d('m33')), geo['out_gs']) < 1e-5
+    assert _rel(G.batch_rodrigues(d('aa_in')), geo['out_rod']) < 1e-5
+    aa = G.rotation_matrix_to_angle_axis(d('R')).cpu()
+    ref = geo['out_aa']
+    # 180-degree rotations sit on a branch cut (sign of the axis is ill-conditioned): compare as rotations there
+    big = ref.norm(dim=1) > 3.1
+    assert _rel(aa[~big], ref[~big]) < 1e-4
+    from oracle.geometry import batch_rodrigues
+    assert (batch_rodrigues(aa[big]) - batch_rodrigues(ref[big])).abs().max() < 1e-3
+    assert _rel(G.projection(d('pts'), d('cam')), geo['out_proj']) < 1e-5
+    eye = torch.eye(3, device=dev).unsqueeze(0).expand(4, -1, -1)
+    assert _rel(G.perspective_projection(d('pts'), eye, d('tr'), d('fl'), d('cc')), geo['out_persp']) < 1e-5
+    assert _rel(G.perspective_projection(d('pts'), eye[:1], d('tr'), d('fl'), d('cc')), geo['out_persp']) < 1e-5
+    w, h = torch.full((4,), 1280., device=dev), torch.full((4,), 720., device=dev)
+    assert _rel(G.convert_pare_to_full_img_cam(d('cam'), d('fl'), d('cc'), w, h, Tz=d('tr')[:, 2]), geo['out_full_cam']) < 1e-6
+    assert torch.equal(G.rotmat_to_rot6d(d('R')).cpu(), geo['out_rot6d'])
+
+
+def test_maf_sampler_matches_reference_fixture(dev, geo, state_dict):
+    """grid_sample (zero padding, exact texels, out-of-range points) + point MLP vs the reference MAF_Extractor"""
+    from whmr_amd.models.maf_extractor import MAF_Extractor
+    ext = MAF_Extractor()
+    ext.load_state_dict({k[len('maf_extractor.1.'):]: v for k, v in state_dict.items() if k.startswith('maf_extractor.1.')})
+    ext = ext.to(dev)
+    fmap, pts = geo['in_maf_fmap'].to(dev), geo['in_maf_pts'].to(dev)
+    y, pf = ext.sampling(pts, fmap)                                   # NCHW strides
+    assert _rel(pf, geo['out_maf_pf']) < 1e-5
+    assert _rel(y, geo['out_maf_y']) < 1e-5
+    y2, _ = ext.sampling(pts, fmap.contiguous(memory_format=torch.channels_last))     # NHWC strides
+    assert torch.equal(y2, y)
+    y3, _ = ext.sampling(pts, fmap.bfloat16().float())                # bf16 feature map path
+    y4, _ = ext.sampling(pts, fmap.bfloat16())
+    assert torch.equal(y3, y4)
+    assert _rel(ext.reduce_dim(geo['out_maf_pf'].to(dev)), geo['out_maf_y']) < 1e-5
+
+
+@pytest.mark.parametrize('B', [1, 2, 13, 64])
+def test_smpl_lbs_vs_oracle(dev, assets, B):
+    from oracle import geometry as OG
+    from oracle import smpl as OS
+    from whmr_amd.models.smpl import SMPL
+    g = torch.Generator().manual_seed(B)
+    betas = torch.randn(B, 10, generator=g)
+    rot = OG.batch_rodrigues(torch.randn(B * 24, 3, generator=g) * 0.7).view(B, 24, 3, 3)
+    v_ref, j_ref = OS.smpl_forward(betas, rot, assets['smpl'])
+    m = SMPL(arrays=assets['smpl'], marker_ids=assets['ssm']).to(dev)
+    out = m(betas=betas.to(dev), body_pose=rot[:, 1:].to(dev), global_orient=rot[:, :1].to(dev), pose2rot=False)
+    assert out.vertices.shape == (B, 6890, 3) and out.joints.shape == (B, 49, 3)
+    assert _rel(out.vertices, v_ref) < 1e-5
+    assert _rel(out.joints, j_ref) < 1e-5
+    # raw (non-orthonormal) 3x3 blocks + in-kernel Gram-Schmidt, angle-axis, SMPL joints, markers (Regressor path)
+    raw = rot + 0.05 * torch.randn(B, 24, 3, 3, generator=g)
+    gs = OG.unbiased_gram_schmidt(raw)
+    v2, _ = OS.smpl_forward(betas, gs, assets['smpl'])
+    o2 = m.run(betas.to(dev), raw.to(dev), gram_schmidt=True, want_aa=True, want_smpl_joints=True, want_markers=True)
+    assert _rel(o2.rotmat, gs) < 1e-5
+    assert _rel(o2.vertices, v2) < 1e-5
+    assert _rel(o2.pose_aa, OG.rotation_matrix_to_angle_axis(gs.reshape(-1, 3, 3)).reshape(B, 72)) < 1e-4
+    sj = OS.vertex_joint_selector(v2, torch.einsum('bik,ji->bjk', v2, assets['smpl']['J_regressor']))
+    assert _rel(o2.smpl_joints, sj) < 1e-5
+    assert _rel(o2.markers, v2[:, assets['ssm']]) < 1e-6
+
+
+def test_smpl_known_answers(dev, assets):
+    """analytic checks that do not depend on any restatement: identity pose => T + S.beta; a rotation of the root
+    joint alone => rigid rotation of the whole shaped mesh about the root joint"""
+    from whmr_amd.models.smpl import SMPL
+    from oracle import geometry as OG
+    s = assets['smpl']
+    m = SMPL(arrays=s).to(dev)
+    betas = torch.tensor([[0.5, -1.0, 0.3, 0, 0, 0, 0, 0.2, 0, -0.4]])
+    eye = torch.eye(3).expand(1, 24, 3, 3)
+    v_shaped = s['v_template'] + torch.einsum('l,mkl->mk', betas[0], s['shapedirs'])
+    out = m.run(betas.to(dev), eye.contiguous().to(dev))
+    assert _rel(out.vertices[0], v_shaped) < 1e-6
+    R = OG.batch_rodrigues(torch.tensor([[0.3, -0.8, 0.5]]))[0]
+    rot = eye.clone()
+    rot[0, 0] = R
+    J0 = (s['J_regressor'] @ v_shaped)[0]
+    # pose feature excludes the root joint, so the pose blend shapes stay zero and the body turns rigidly about J0
+    expect = (v_shaped - J0) @ R.t() + J0
+    out = m.run(betas.to(dev), rot.to(dev))
+    assert _rel(out.vertices[0], expect) < 1e-5
+
+
+def _load_model(assets, state_dict, numerics, dev):
+    from whmr_amd.models import whmr_net
+    m = whmr_net(None, assets=assets, numerics=numerics)
+    res = m.load_state_dict(state_dict, strict=False)
+    assert not res.unexpected_keys and all('.smpl.' in k for k in res.missing_keys)
+    return m.to(dev).eval()
+
+
+@pytest.fixture(scope='module')
+def gold():
+    return {k: v for k, v in np.load(os.path.join(GOLDEN, 'whmr_b2.npz')).items()}
+
+
+def _inputs(gold, dev):
+    t = lambda k: torch.from_numpy(gold['in_' + k]).to(dev)
+    return dict(x=t('x'), meta_masks=None, center=t('center'), scale=t('scale'), bbox_height=t('bbox_height'),
+                orig_shape=t('orig_shape'), bbox_info=t('bbox_info'), is_train=False, J_regressor=None, full_x=t('full_x'))
+
+
+def test_whmr_forward_fp32_matches_reference_fixture(dev, assets, state_dict, gold):
+    """north_star parity gate: pose/shape/cam, 6890x3 vertices, projected 2-D joints within 1e-4 rel (fp32 mode)"""
+    m = _load_model(assets, state_dict, 'fp32', dev)
+    out = m(**_inputs(gold, dev))
+    assert set(out) == {'local_smpl_vertices', 'smpl_vertices', 'pred_cam_t', 'focal_length', 'cam_rotmat',
+                        'render_rotmat', 'shape', 'global_pose', 'local_pose'}
+    for k, v in out.items():
+        err = _rel(v, gold['out_' + k])
+        print('%-22s max-rel %.2e' % (k, err))
+        assert err < 1e-4, k
+    (tr, feats) = m(**_inputs(gold, dev), view='train')
+    assert len(tr['smpl_out']) == 4 and len(feats) == 4
+    assert _rel(feats[0], gold['s_feat']) < 1e-4
+    for i in range(3):
+        flat = feats[i + 1].contiguous().reshape(-1).cpu()
+        assert _rel(flat[torch.from_numpy(gold['fmap%d_idx' % i])], gold['fmap%d_val' % i]) < 1e-4
+        so = tr['smpl_out'][i + 1]
+        for k in ('theta', 'verts', 'kp_2d', 'kp_2d_w', 'kp_3d', 'rotmat', 'pred_cam_t', 'focal_length', 'pose'):
+            err = _rel(so[k], gold['iter%d_%s' % (i, k)])
+            assert err < 1e-4, (i, k, err)
+        assert so['sub_verts'].shape == (2, 1723, 3) and so['temp_verts'].shape == (2, 431, 3)
+    ev, _ = m(**_inputs(gold, dev), view='eval')
+    assert _rel(ev['global_output']['global_verts'], gold['out_smpl_vertices']) < 1e-4
+    # cam_rotmat given / no full image: the released reference raises NameError here; we define it
+    kw = _inputs(gold, dev)
+    kw['full_x'] = None
+    o2 = m(**kw, cam_rotmat=torch.from_numpy(gold['out_cam_rotmat']).to(dev))
+    assert _rel(o2['smpl_vertices'], gold['out_smpl_vertices']) < 1e-4
+    assert torch.equal(o2['render_rotmat'], o2['cam_rotmat'])
+
+
+def test_whmr_forward_bf16_error_report(dev, assets, state_dict, gold):
+    m = _load_model(assets, state_dict, 'bf16', dev)
+    out = m(**_inputs(gold, dev))
+    errs = {k: _rel(v, gold['out_' + k]) for k, v in out.items()}
+    print('bf16 perf-mode error vs fp32 reference:', {k: '%.2e' % e for k, e in errs.items()})
+    assert errs['smpl_vertices'] < 5e-2 and errs['local_pose'] < 1e-1
+    assert all(torch.isfinite(v).all() for v in out.values())
+
+
+def test_whmr_batch_independence(dev, assets, state_dict, gold):
+    """size-independent property: every image is processed independently -> batch of 6 == 3 x batch of 2"""
+    m = _load_model(assets, state_dict, 'fp32', dev)
+    kw = _inputs(gold, dev)
+    rep = {k: (torch.cat([v] * 3) if torch.is_tensor(v) else v) for k, v in kw.items()}
+    a, b = m(**kw), m(**rep)
+    for k in a:
+        assert torch.allclose(b[k][:2], a[k], rtol=1e-5, atol=1e-6) and torch.allclose(b[k][4:], a[k], rtol=1e-5, atol=1e-6)

@@ -25,6 +25,19 @@ class WhmrGemm(C.Structure):
                 ('c_off', C.c_int64), ('osb', C.c_int64), ('osy', C.c_int64), ('osx', C.c_int64)]
 
 
+class WhmrSmplModel(C.Structure):
+    _fields_ = [('v_template', C.c_void_p), ('shapedirs', C.c_void_p), ('posedirs', C.c_void_p),
+                ('lbs_weights', C.c_void_p), ('J_template', C.c_void_p), ('J_shapedirs', C.c_void_p),
+                ('J_regressor', C.c_void_p), ('J_regressor_extra', C.c_void_p), ('parents', C.c_void_p),
+                ('extra_vertex_ids', C.c_void_p), ('joint_map', C.c_void_p), ('marker_ids', C.c_void_p),
+                ('n_markers', C.c_int32)]
+
+
+class WhmrMafWeights(C.Structure):
+    _fields_ = [('w0t', C.c_void_p), ('b0', C.c_void_p), ('w1t', C.c_void_p), ('b1', C.c_void_p),
+                ('w2t', C.c_void_p), ('b2', C.c_void_p)]
+
+
 _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_long
 _SIGS = {
     'whmr_gemm_bf16': [C.POINTER(WhmrGemm), _I, _P],
@@ -33,6 +46,15 @@ _SIGS = {
     'whmr_patch_im2col': [_P, _P, _I, _I, _I, _I, _I, _I, _L, _L, _L, _L, _I, _P],
     'whmr_cast_f32_bf16': [_P, _P, _L, _P],
     'whmr_attention': [_P, _P, _I, _I, _I, _I, _F, _I, _P],
+    'whmr_rot_to_mat': [_P, _P, _I, _I, _P],
+    'whmr_mat_to_aa': [_P, _P, _I, _P],
+    'whmr_perspective': [_P, _P, _I, _P, _P, _I, _P, _P, _F, _P, _I, _I, _P],
+    'whmr_weak_projection': [_P, _P, _P, _I, _I, _F, _F, _F, _P],
+    'whmr_smpl_pose_chain': [C.POINTER(WhmrSmplModel), _P, _P, _I, _I, _P, _P, _P, _P, _P, _P],
+    'whmr_smpl_skin': [C.POINTER(WhmrSmplModel), _P, _P, _P, _I, _P, _P],
+    'whmr_smpl_joints': [C.POINTER(WhmrSmplModel), _P, _P, _I, _P, _P, _P, _P],
+    'whmr_maf_sample': [_P, _I, _L, _L, _L, _L, _I, _I, _P, _P, _P, _F, _F, _F, C.POINTER(WhmrMafWeights), _I, _I, _P, _L, _P, _P],
+    'whmr_tz_tail': [_P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _F, _P, _P],
 }
 EXPORTS = tuple(_SIGS)
 
@@ -171,4 +193,112 @@ def attention(qkv, out, B, N, H, d, scale):
     assert qkv.is_contiguous() and out.is_contiguous() and qkv.dtype == out.dtype
     _check(lib().whmr_attention(qkv.data_ptr(), out.data_ptr(), B, N, H, d, scale,
                                 int(qkv.dtype == torch.bfloat16), _stream()), 'whmr_attention')
+    return out
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+def _f32c(t):
+    assert t.dtype == torch.float32 and t.is_contiguous(), 'expected a contiguous fp32 tensor'
+    return t
+
+
+ROT6D, GRAM_SCHMIDT, RODRIGUES = 0, 1, 2
+
+
+def rot_to_mat(x, mode):
+    """x [n, 6|9|3] -> [n, 3, 3]  (rot6d_to_rotmat / unbiased_gram_schmidt / batch_rodrigues)."""
+    _dev(x)
+    x = _f32c(x.contiguous())
+    n = x.numel() // (6, 9, 3)[mode]
+    out = torch.empty(n, 3, 3, dtype=torch.float32, device=x.device)
+    _check(lib().whmr_rot_to_mat(x.data_ptr(), out.data_ptr(), n, mode, _stream()), 'whmr_rot_to_mat')
+    return out
+
+
+def mat_to_aa(R):
+    _dev(R)
+    R = _f32c(R.contiguous())
+    n = R.numel() // 9
+    out = torch.empty(n, 3, dtype=torch.float32, device=R.device)
+    _check(lib().whmr_mat_to_aa(R.data_ptr(), out.data_ptr(), n, _stream()), 'whmr_mat_to_aa')
+    return out
+
+
+def perspective(points, rotation, translation, focal, center, post_div=None, post_shift=0.0):
+    """perspective_projection (+ optional out / post_div[b] + post_shift).  focal: tensor [B] or python float."""
+    _dev(points, rotation, translation, center, post_div)
+    points = _f32c(points.contiguous())
+    B, P = points.shape[0], points.shape[1]
+    if not torch.is_tensor(focal):
+        focal = torch.full((1,), float(focal), dtype=torch.float32, device=points.device)
+    focal = _f32c(focal.contiguous())
+    assert focal.numel() in (1, B)
+    fstride = 1 if focal.numel() == B else 0
+    rstride = 0
+    if rotation is not None:
+        rotation = _f32c(rotation.contiguous())
+        assert rotation.shape[0] in (1, B)
+        rstride = 9 if rotation.shape[0] == B else 0
+    out = torch.empty(B, P, 2, dtype=torch.float32, device=points.device)
+    _check(lib().whmr_perspective(points.data_ptr(), _ptr(rotation), rstride, _f32c(translation.contiguous()).data_ptr(),
+                                  focal.data_ptr(), fstride, _ptr(center.contiguous() if center is not None else None),
+                                  _ptr(post_div.contiguous() if post_div is not None else None), post_shift,
+                                  out.data_ptr(), B, P, _stream()), 'whmr_perspective')
+    return out
+
+
+def weak_projection(points, cam, focal=1000.0, res_w=256.0, res_h=256.0):
+    _dev(points, cam)
+    points, cam = _f32c(points.contiguous()), _f32c(cam.contiguous())
+    B, P = points.shape[0], points.shape[1]
+    out = torch.empty(B, P, 2, dtype=torch.float32, device=points.device)
+    _check(lib().whmr_weak_projection(points.data_ptr(), cam.data_ptr(), out.data_ptr(), B, P, focal, res_w, res_h,
+                                      _stream()), 'whmr_weak_projection')
+    return out
+
+
+def smpl_pose_chain(model, pose9, betas, do_gs, rotmat, aa, A, posed_joints, pose_feat):
+    B = betas.shape[0]
+    _check(lib().whmr_smpl_pose_chain(C.byref(model), _f32c(pose9).data_ptr(), _f32c(betas).data_ptr(), B, int(do_gs),
+                                      _ptr(rotmat), _ptr(aa), A.data_ptr(), _ptr(posed_joints), _ptr(pose_feat),
+                                      _stream()), 'whmr_smpl_pose_chain')
+
+
+def smpl_skin(model, betas, pose_feat, A, verts):
+    _check(lib().whmr_smpl_skin(C.byref(model), betas.data_ptr(), pose_feat.data_ptr(), A.data_ptr(), betas.shape[0],
+                                verts.data_ptr(), _stream()), 'whmr_smpl_skin')
+
+
+def smpl_joints(model, verts, posed_joints, joints49, smpl_joints45, markers):
+    _check(lib().whmr_smpl_joints(C.byref(model), verts.data_ptr(), _ptr(posed_joints), verts.shape[0], _ptr(joints49),
+                                  _ptr(smpl_joints45), _ptr(markers), _stream()), 'whmr_smpl_joints')
+
+
+def maf_sample(fmap_nchw, weights, out, pts2d=None, pts3d=None, cam=None, point_feat=None, focal=1000.0, res_w=256.0,
+               res_h=256.0):
+    """fmap_nchw: logical [B, 256, H, W] tensor of any strides (channels-last memory makes the gather coalesced);
+    with no points given, a [B, 256, P] tensor of already-sampled features (MLP only).  out: [B, >= 32*P] rows."""
+    _dev(fmap_nchw, out, pts2d, pts3d, cam, point_feat)
+    assert fmap_nchw.shape[1] == 256 and fmap_nchw.dtype in (torch.float32, torch.bfloat16)
+    if pts2d is None and pts3d is None:
+        B, _, P = fmap_nchw.shape
+        (sb, sc, sx), sy, H, W = fmap_nchw.stride(), 0, 1, P
+    else:
+        B, _, H, W = fmap_nchw.shape
+        sb, sc, sy, sx = fmap_nchw.stride()
+        P = (pts2d if pts2d is not None else pts3d).shape[1]
+    assert out.dtype == torch.float32 and out.stride(-1) == 1
+    _check(lib().whmr_maf_sample(fmap_nchw.data_ptr(), int(fmap_nchw.dtype == torch.bfloat16), sb, sc, sy, sx, H, W,
+                                 _ptr(pts2d), _ptr(pts3d), _ptr(cam), focal, res_w, res_h, C.byref(weights), B, P,
+                                 out.data_ptr(), out.stride(0), _ptr(point_feat), _stream()), 'whmr_maf_sample')
+    return out
+
+
+def tz_tail(tok, w0, b0, w1, b1, bn4, eps, out):
+    B, T, D = tok.shape
+    _check(lib().whmr_tz_tail(_f32c(tok).data_ptr(), B, T, D, w0.data_ptr(), b0.data_ptr(), w0.shape[0], w1.data_ptr(),
+                              b1.data_ptr(), bn4.data_ptr(), eps, out.data_ptr(), _stream()), 'whmr_tz_tail')
     return out

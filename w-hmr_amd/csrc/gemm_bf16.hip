@@ -34,7 +34,7 @@ template <int OUT_BF16, int ACT, bool GATHER, bool GLDS>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const whmr_gemm p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tiles_n = p.N / BN;
+    const int tiles_n = (p.N + BN - 1) / BN;
     const int tiles_m = (p.M + BM - 1) / BM;
     const int lid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
     const int tm = lid / tiles_n, tn = lid % tiles_n;
@@ -65,7 +65,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const whmr_gemm p) {
         } else {
             a_src[i] = A + (size_t)m * p.lda + lc[i] * 8;
         }
-        b_src[i] = W + (size_t)(n0 + row) * p.K + lc[i] * 8;
+        int nr = n0 + row;
+        if (nr > p.N - 1) nr = p.N - 1;             // N tail: clamp the load, mask the store
+        b_src[i] = W + (size_t)nr * p.K + lc[i] * 8;
     }
 
     auto stage = [&](int kt, int s) {
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const whmr_gemm p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         ncol[j] = n0 + wn * 64 + j * 32 + l31;
-        bv[j] = p.bias ? p.bias[ncol[j]] : 0.f;
+        bv[j] = (p.bias && ncol[j] < p.N) ? p.bias[ncol[j]] : 0.f;
     }
     const float* __restrict__ res = p.residual;
 #pragma unroll
@@ -170,6 +172,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const whmr_gemm p) {
             if (res) rrow = (size_t)(p.res_row_mod > 0 ? m % p.res_row_mod : m) * p.ldr;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
+                if (ncol[j] >= p.N) continue;
                 float v = acc[i][j][r] + bv[j];
                 if (ACT == 1) v = gelu_erf(v);
                 if (ACT == 2) v = fmaxf(v, 0.f);
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const whmr_gemm p) {
 
 template <int OUT_BF16, int ACT, bool GATHER>
 static int launch(const whmr_gemm& p, hipStream_t st, bool glds) {
-    const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     if (glds) hipLaunchKernelGGL((gemm_bf16_kernel<OUT_BF16, ACT, GATHER, true>), dim3(tiles), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((gemm_bf16_kernel<OUT_BF16, ACT, GATHER, false>), dim3(tiles), dim3(256), 0, st, p);
     WHMR_CHECK_LAUNCH();
@@ -204,7 +207,7 @@ static int launch_act(const whmr_gemm& p, hipStream_t st, bool glds) {
 extern "C" int whmr_gemm_bf16(const whmr_gemm* pp, int flags, void* stream) {
     const whmr_gemm& p = *pp;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return (int)hipErrorInvalidValue;
-    if (p.N % BN || p.K % BK) return (int)hipErrorInvalidValue;
+    if (p.K % BK) return (int)hipErrorInvalidValue;
     if (p.a_mode == 1 && (p.Cin % BK || !p.zeros)) return (int)hipErrorInvalidValue;
     if (p.a_mode == 0 && (p.lda % 8)) return (int)hipErrorInvalidValue;
     const bool glds = !(flags & 1);

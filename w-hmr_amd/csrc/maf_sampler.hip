@@ -1,0 +1,205 @@
+// Mesh-aligned feature sampler: (projection ->) bilinear gather -> 3-layer point MLP, one fused launch per iteration.
+//
+// Replaces MAF_Extractor.forward / .sampling / .reduce_dim (models/maf_extractor.py:126-143,103-124,75-101):
+//   p2d = projection(p3d, cam)                              (utils/geometry.py:289-307, only when p3d is given)
+//   f   = grid_sample(fmap, p2d, bilinear, zeros padding, align_corners=True)     [256 channels per point]
+//   y   = relu(W2 . [leaky(W1 . [leaky(W0 f + b0); f] + b1); f] + b2)             leaky slope 0.01
+//   out[b, c*P + p] = y[c]   (channel-major flatten, maf_extractor.py:100)
+// The feature map is addressed with explicit element strides, so both the NHWC maps produced by this library's
+// deconv GEMMs (256 contiguous channels per texel: the gather is 1 KiB-coalesced) and a caller's NCHW tensor work.
+// Block = 128 threads = PT points of one image; features and activations live in LDS; weights are pre-transposed
+// to [in][out] on the host so every weight read is coalesced and L2-resident (66 K floats).
+#include "common.h"
+
+#define CF 256
+#define PT 8
+
+struct whmr_maf_weights {
+    const float* w0t; const float* b0;   // [256][128], [128]
+    const float* w1t; const float* b1;   // [384][64],  [64]     input order: [y0 (128) | f (256)]
+    const float* w2t; const float* b2;   // [320][32],  [32]     input order: [y1 (64)  | f (256)]
+};
+
+template <typename TF>
+__global__ __launch_bounds__(128) void maf_sample_kernel(const TF* __restrict__ fmap, long sb, long sc, long sy, long sx,
+                                                         int H, int W, const float* __restrict__ pts2d,
+                                                         const float* __restrict__ pts3d, const float* __restrict__ cam,
+                                                         float focal, float res_w, float res_h,
+                                                         const whmr_maf_weights wts, int P, float* __restrict__ out,
+                                                         long out_stride, float* __restrict__ point_feat) {
+    __shared__ float sF[PT][CF];
+    __shared__ float sY0[PT][128];
+    __shared__ float sY1[PT][64];
+    __shared__ float sXY[PT][2];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y, p0 = blockIdx.x * PT;
+    const int np = min(PT, P - p0);
+
+    const bool direct = !pts2d && !pts3d;      // reduce_dim() on already-sampled features [B,256,P] (sx = point stride)
+    if (tid < PT) {
+        float x = 0.f, y = 0.f;
+        if (tid < np && !direct) {
+            const int p = p0 + tid;
+            if (pts3d) {
+                const float s = cam[3 * b], tx = cam[3 * b + 1], ty = cam[3 * b + 2];
+                const float tz = 2 * focal / (res_h * s + 1e-9f);
+                const float* q = pts3d + ((size_t)b * P + p) * 3;
+                const float z = q[2] + tz;
+                x = (focal * ((q[0] + tx) / z)) / (res_w / 2.f);
+                y = (focal * ((q[1] + ty) / z)) / (res_h / 2.f);
+            } else {
+                x = pts2d[((size_t)b * P + p) * 2];
+                y = pts2d[((size_t)b * P + p) * 2 + 1];
+            }
+        }
+        sXY[tid][0] = x; sXY[tid][1] = y;
+    }
+    __syncthreads();
+
+    // ---- bilinear gather (ATen grid_sampler_2d, align_corners=True, zeros padding)
+    const TF* fb = fmap + (size_t)b * sb;
+    for (int pp = 0; pp < np && direct; ++pp) {
+        sF[pp][tid] = io<TF>::ld(fb + (size_t)tid * sc + (size_t)(p0 + pp) * sx);
+        sF[pp][tid + 128] = io<TF>::ld(fb + (size_t)(tid + 128) * sc + (size_t)(p0 + pp) * sx);
+    }
+    for (int pp = 0; pp < np && !direct; ++pp) {
+        const float ix = ((sXY[pp][0] + 1.f) / 2.f) * (float)(W - 1);
+        const float iy = ((sXY[pp][1] + 1.f) / 2.f) * (float)(H - 1);
+        const float fx0 = floorf(ix), fy0 = floorf(iy);
+        const int x0 = (int)fx0, y0 = (int)fy0, x1 = x0 + 1, y1 = y0 + 1;
+        const float wnw = ((fx0 + 1.f) - ix) * ((fy0 + 1.f) - iy), wne = (ix - fx0) * ((fy0 + 1.f) - iy);
+        const float wsw = ((fx0 + 1.f) - ix) * (iy - fy0), wse = (ix - fx0) * (iy - fy0);
+        const bool okx0 = (unsigned)x0 < (unsigned)W, okx1 = (unsigned)x1 < (unsigned)W;
+        const bool oky0 = (unsigned)y0 < (unsigned)H, oky1 = (unsigned)y1 < (unsigned)H;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c = tid + 128 * h;
+            const TF* fc = fb + (size_t)c * sc;
+            float v = 0.f;
+            if (oky0 && okx0) v += io<TF>::ld(fc + y0 * sy + x0 * sx) * wnw;
+            if (oky0 && okx1) v += io<TF>::ld(fc + y0 * sy + x1 * sx) * wne;
+            if (oky1 && okx0) v += io<TF>::ld(fc + y1 * sy + x0 * sx) * wsw;
+            if (oky1 && okx1) v += io<TF>::ld(fc + y1 * sy + x1 * sx) * wse;
+            sF[pp][c] = v;
+            if (point_feat) point_feat[((size_t)b * CF + c) * P + p0 + pp] = v;
+        }
+    }
+    for (int pp = np; pp < PT; ++pp) { sF[pp][tid] = 0.f; sF[pp][tid + 128] = 0.f; }
+    __syncthreads();
+
+    // ---- layer 0: 256 -> 128, thread = output channel, all PT points
+    {
+        float acc[PT];
+        const float bv = wts.b0[tid];
+#pragma unroll
+        for (int pp = 0; pp < PT; ++pp) acc[pp] = bv;
+        for (int i = 0; i < CF; ++i) {
+            const float w = wts.w0t[i * 128 + tid];
+#pragma unroll
+            for (int pp = 0; pp < PT; ++pp) acc[pp] = fmaf(w, sF[pp][i], acc[pp]);
+        }
+#pragma unroll
+        for (int pp = 0; pp < PT; ++pp) sY0[pp][tid] = acc[pp] > 0.f ? acc[pp] : 0.01f * acc[pp];
+    }
+    __syncthreads();
+    // ---- layer 1: [128 | 256] -> 64, thread = (output channel, half of the points)
+    {
+        const int o = tid & 63, hp = (tid >> 6) * (PT / 2);
+        float acc[PT / 2];
+        const float bv = wts.b1[o];
+#pragma unroll
+        for (int q = 0; q < PT / 2; ++q) acc[q] = bv;
+        for (int i = 0; i < 128; ++i) {
+            const float w = wts.w1t[i * 64 + o];
+#pragma unroll
+            for (int q = 0; q < PT / 2; ++q) acc[q] = fmaf(w, sY0[hp + q][i], acc[q]);
+        }
+        for (int i = 0; i < CF; ++i) {
+            const float w = wts.w1t[(128 + i) * 64 + o];
+#pragma unroll
+            for (int q = 0; q < PT / 2; ++q) acc[q] = fmaf(w, sF[hp + q][i], acc[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < PT / 2; ++q) sY1[hp + q][o] = acc[q] > 0.f ? acc[q] : 0.01f * acc[q];
+    }
+    __syncthreads();
+    // ---- layer 2: [64 | 256] -> 32, thread = (output channel, quarter of the points); ReLU; channel-major store
+    {
+        const int o = tid & 31, qp = (tid >> 5) * (PT / 4);
+        float acc[PT / 4];
+        const float bv = wts.b2[o];
+#pragma unroll
+        for (int q = 0; q < PT / 4; ++q) acc[q] = bv;
+        for (int i = 0; i < 64; ++i) {
+            const float w = wts.w2t[i * 32 + o];
+#pragma unroll
+            for (int q = 0; q < PT / 4; ++q) acc[q] = fmaf(w, sY1[qp + q][i], acc[q]);
+        }
+        for (int i = 0; i < CF; ++i) {
+            const float w = wts.w2t[(64 + i) * 32 + o];
+#pragma unroll
+            for (int q = 0; q < PT / 4; ++q) acc[q] = fmaf(w, sF[qp + q][i], acc[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < PT / 4; ++q) {
+            const int p = p0 + qp + q;
+            if (p < P) out[(size_t)b * out_stride + (size_t)o * P + p] = fmaxf(acc[q], 0.f);
+        }
+    }
+}
+
+// fmap_bf16: element type of the feature map.  pts2d XOR (pts3d, cam) selects the sampling points; with neither, fmap is
+// an already-sampled [B,256,P] feature tensor (strides sb, sc, sx) and only the MLP runs (MAF_Extractor.reduce_dim).
+// out row b starts at out + b*out_stride (>= 32*P), so the result can land inside the regressor's input buffer.
+extern "C" int whmr_maf_sample(const void* fmap, int fmap_bf16, long sb, long sc, long sy, long sx, int H, int W,
+                               const float* pts2d, const float* pts3d, const float* cam, float focal, float res_w,
+                               float res_h, const whmr_maf_weights* w, int B, int P, float* out, long out_stride,
+                               float* point_feat, void* stream) {
+    if (B <= 0 || P <= 0 || (pts2d && pts3d) || (pts3d && !cam) || out_stride < 32L * P) return (int)hipErrorInvalidValue;
+    dim3 grid((P + PT - 1) / PT, B), block(128);
+    hipStream_t st = (hipStream_t)stream;
+    if (fmap_bf16) hipLaunchKernelGGL(maf_sample_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)fmap, sb, sc, sy, sx, H, W,
+                                      pts2d, pts3d, cam, focal, res_w, res_h, *w, P, out, out_stride, point_feat);
+    else hipLaunchKernelGGL(maf_sample_kernel<float>, grid, block, 0, st, (const float*)fmap, sb, sc, sy, sx, H, W, pts2d,
+                            pts3d, cam, focal, res_w, res_h, *w, P, out, out_stride, point_feat);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+// Tail of the Tz head (whmr.py:574-577): tokens [B,5,216] -> transpose/AvgPool1d(5) = mean over the 5 tokens ->
+// Linear(216,12) -> Linear(12,1) -> BatchNorm1d(1) (eval) -> sigmoid -> * 10.
+__global__ __launch_bounds__(64) void tz_tail_kernel(const float* __restrict__ tok, int T, int D, const float* __restrict__ w0,
+                                                     const float* __restrict__ b0, int Hd, const float* __restrict__ w1,
+                                                     const float* __restrict__ b1, const float* __restrict__ bn /*w,b,mean,var*/,
+                                                     float bn_eps, float* __restrict__ tz) {
+    __shared__ float sm[1024];
+    __shared__ float sh[64];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    for (int d = lane; d < D; d += 64) {
+        float s = 0.f;
+        for (int t = 0; t < T; ++t) s += tok[((size_t)b * T + t) * D + d];
+        sm[d] = s / (float)T;
+    }
+    __syncthreads();
+    if (lane < Hd) {
+        float a = 0.f;
+        for (int d = 0; d < D; ++d) a = fmaf(sm[d], w0[lane * D + d], a);
+        sh[lane] = a + b0[lane];
+    }
+    __syncthreads();
+    if (lane == 0) {
+        float a = 0.f;
+        for (int j = 0; j < Hd; ++j) a = fmaf(sh[j], w1[j], a);
+        a += b1[0];
+        a = (a - bn[2]) / sqrtf(bn[3] + bn_eps) * bn[0] + bn[1];
+        tz[b] = 10.0f * (1.0f / (1.0f + expf(-a)));
+    }
+}
+
+extern "C" int whmr_tz_tail(const float* tok, int B, int T, int D, const float* w0, const float* b0, int Hd, const float* w1,
+                            const float* b1, const float* bn4, float bn_eps, float* tz, void* stream) {
+    if (B <= 0 || D > 1024 || Hd > 64) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(tz_tail_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, tok, T, D, w0, b0, Hd, w1, b1, bn4, bn_eps, tz);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,261 @@
+// SMPL forward (linear blend skinning) for W-HMR on gfx950, fp32.
+//
+// Replaces pare.models.SMPL.forward(pose2rot=False) (smplx==0.1.28 lbs) as called at models/whmr.py:132-137,227-232,
+// 641-644, plus the surrounding small ops of Regressor.forward: unbiased_gram_schmidt (whmr.py:129-130),
+// rotation_matrix_to_angle_axis (whmr.py:174), vertex_joint_selector / J_regressor (whmr.py:186-187), markers
+// (whmr.py:184).  In-tree spec of the math: models/smpl_webuser/lbs.py:27-80, verts.py:39-67, models/smpl.py:61-83.
+//
+// Three launches per SMPL call:
+//   1. smpl_pose_chain : per image, one wave -- (optional Gram-Schmidt) -> rotmats, angle-axis, joint locations
+//      J = J_template + J_shapedirs.beta (= Jreg.(T + S.beta), regressor folded into the constants once), the 24-joint
+//      kinematic chain and the rest-pose-removed skinning transforms A[24][3x4], pose feature (R[1:] - I).
+//   2. smpl_skin       : vertex-parallel, HBM/L2-bound -- v_shaped, + posedirs^T.pose_feature (the 17 MB operand is
+//      read coalesced, once per block for BT images), T = sum_j w_vj A_j, v = T [v_posed; 1].
+//   3. smpl_joints     : per image -- extra-joint regressors over the skinned mesh, vertex picks, JOINT_MAP gather.
+#include "geometry_dev.h"
+
+#define NV 6890
+#define NJ 24
+#define NPF 207
+
+struct whmr_smpl_model {
+    const float* v_template;     // [6890,3]
+    const float* shapedirs;      // [6890,3,10]
+    const float* posedirs;       // [207, 20670]  (smplx layout)
+    const float* lbs_weights;    // [6890,24]
+    const float* J_template;     // [24,3]      = J_regressor . v_template
+    const float* J_shapedirs;    // [24,3,10]   = J_regressor . shapedirs
+    const float* J_regressor;    // [24,6890]   (whmr.py:186 smpl_joints; may be null if never requested)
+    const float* J_regressor_extra;  // [9,6890]
+    const int32_t* parents;      // [24]
+    const int32_t* extra_vertex_ids; // [21]
+    const int32_t* joint_map;    // [49] into the 54-joint superset
+    const int32_t* marker_ids;   // [n_markers]
+    int32_t n_markers;
+};
+
+__global__ __launch_bounds__(64) void smpl_pose_chain_kernel(const whmr_smpl_model m, const float* __restrict__ pose9,
+                                                             const float* __restrict__ betas, int do_gs,
+                                                             float* __restrict__ rotmat, float* __restrict__ aa,
+                                                             float* __restrict__ A, float* __restrict__ posed_joints,
+                                                             float* __restrict__ pose_feat) {
+    __shared__ float sR[NJ][9];
+    __shared__ float sJ[NJ][3];
+    __shared__ float sG[NJ][12];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (lane < NJ) {
+        float r[9], o[9];
+        for (int k = 0; k < 9; ++k) r[k] = pose9[((size_t)b * NJ + lane) * 9 + k];
+        if (do_gs) gram_schmidt9(r, o); else for (int k = 0; k < 9; ++k) o[k] = r[k];
+        for (int k = 0; k < 9; ++k) { sR[lane][k] = o[k]; if (rotmat) rotmat[((size_t)b * NJ + lane) * 9 + k] = o[k]; }
+        if (aa) { float a3[3]; rotmat_to_aa3(o, a3); for (int k = 0; k < 3; ++k) aa[(size_t)b * 72 + lane * 3 + k] = a3[k]; }
+        if (lane >= 1 && pose_feat) {
+            for (int k = 0; k < 9; ++k)
+                pose_feat[(size_t)b * NPF + (lane - 1) * 9 + k] = o[k] - ((k == 0 || k == 4 || k == 8) ? 1.f : 0.f);
+        }
+        // joint locations of the shaped rest mesh
+        for (int c = 0; c < 3; ++c) {
+            float acc = 0.f;
+            for (int l = 0; l < 10; ++l) acc = fmaf(m.J_shapedirs[(lane * 3 + c) * 10 + l], betas[(size_t)b * 10 + l], acc);
+            sJ[lane][c] = m.J_template[lane * 3 + c] + acc;
+        }
+    }
+    __syncthreads();
+    // kinematic chain: G_0 = [R_0 | J_0], G_i = G_parent . [R_i | J_i - J_parent]   (lbs.py:41-49); lanes 0..11 own one entry
+    const int row = lane / 4, col = lane % 4;
+    if (lane < 12) sG[0][lane] = (col < 3) ? sR[0][row * 3 + col] : sJ[0][row];
+    __syncthreads();
+    for (int i = 1; i < NJ; ++i) {
+        const int p = m.parents[i];
+        if (lane < 12) {
+            const float g0 = sG[p][row * 4 + 0], g1 = sG[p][row * 4 + 1], g2 = sG[p][row * 4 + 2], g3 = sG[p][row * 4 + 3];
+            float v;
+            if (col < 3) v = g0 * sR[i][col] + g1 * sR[i][3 + col] + g2 * sR[i][6 + col];
+            else v = g0 * (sJ[i][0] - sJ[p][0]) + g1 * (sJ[i][1] - sJ[p][1]) + g2 * (sJ[i][2] - sJ[p][2]) + g3;
+            sG[i][lane] = v;
+        }
+        __syncthreads();
+    }
+    // A_i = G_i with translation  t_i - G_i[:, :3] . J_i   (lbs.py:51-55)
+    for (int e = lane; e < NJ * 12; e += 64) {
+        const int j = e / 12, k = e % 12, r = k / 4, c = k % 4;
+        float v = sG[j][k];
+        if (c == 3) {
+            v = v - (sG[j][r * 4] * sJ[j][0] + sG[j][r * 4 + 1] * sJ[j][1] + sG[j][r * 4 + 2] * sJ[j][2]);
+            if (posed_joints) posed_joints[((size_t)b * NJ + j) * 3 + r] = sG[j][k];
+        }
+        A[(size_t)b * NJ * 12 + e] = v;
+    }
+}
+
+template <int BT>
+__global__ __launch_bounds__(128) void smpl_skin_kernel(const whmr_smpl_model m, const float* __restrict__ betas,
+                                                        const float* __restrict__ pose_feat, const float* __restrict__ A,
+                                                        int B, float* __restrict__ verts) {
+    __shared__ float sPF[NPF][BT];          // [k][b]: one ds_read_b128 pair fetches all BT coefficients of step k
+    __shared__ float sBeta[10][BT];
+    __shared__ __attribute__((aligned(16))) float sA[BT][NJ * 12];
+    const int tid = threadIdx.x;
+    const int b0 = blockIdx.y * BT;
+    const int v = blockIdx.x * 128 + tid;
+    for (int e = tid; e < NPF * BT; e += 128) {
+        const int k = e / BT, bb = e % BT;
+        sPF[k][bb] = (b0 + bb < B) ? pose_feat[(size_t)(b0 + bb) * NPF + k] : 0.f;
+    }
+    for (int e = tid; e < 10 * BT; e += 128) {
+        const int k = e / BT, bb = e % BT;
+        sBeta[k][bb] = (b0 + bb < B) ? betas[(size_t)(b0 + bb) * 10 + k] : 0.f;
+    }
+    for (int e = tid; e < BT * NJ * 12; e += 128) {
+        const int bb = e / (NJ * 12);
+        sA[bb][e % (NJ * 12)] = (b0 + bb < B) ? A[(size_t)(b0 + bb) * NJ * 12 + (e % (NJ * 12))] : 0.f;
+    }
+    __syncthreads();
+    if (v >= NV) return;
+
+    float acc[BT][3];
+    {   // v_shaped = T + S . beta   (verts.py:46-48)
+        const float t0 = m.v_template[3 * v], t1 = m.v_template[3 * v + 1], t2 = m.v_template[3 * v + 2];
+        float s[30];
+        const float* sd = m.shapedirs + (size_t)v * 30;
+#pragma unroll
+        for (int k = 0; k < 30; ++k) s[k] = sd[k];
+#pragma unroll
+        for (int bb = 0; bb < BT; ++bb) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int l = 0; l < 10; ++l) {
+                const float be = sBeta[l][bb];
+                a0 = fmaf(s[l], be, a0); a1 = fmaf(s[10 + l], be, a1); a2 = fmaf(s[20 + l], be, a2);
+            }
+            acc[bb][0] = t0 + a0; acc[bb][1] = t1 + a1; acc[bb][2] = t2 + a2;
+        }
+    }
+    {   // v_posed = v_shaped + posedirs^T . pose_feature   (verts.py:51-53); separate accumulator like the reference's matmul-then-add
+        float po[BT][3];
+#pragma unroll
+        for (int bb = 0; bb < BT; ++bb) po[bb][0] = po[bb][1] = po[bb][2] = 0.f;
+        const float* pd = m.posedirs + 3 * v;
+#pragma unroll 3
+        for (int k = 0; k < NPF; ++k) {
+            const float p0 = pd[(size_t)k * (NV * 3)], p1 = pd[(size_t)k * (NV * 3) + 1], p2 = pd[(size_t)k * (NV * 3) + 2];
+#pragma unroll
+            for (int bb = 0; bb < BT; ++bb) {
+                const float f = sPF[k][bb];
+                po[bb][0] = fmaf(f, p0, po[bb][0]); po[bb][1] = fmaf(f, p1, po[bb][1]); po[bb][2] = fmaf(f, p2, po[bb][2]);
+            }
+        }
+#pragma unroll
+        for (int bb = 0; bb < BT; ++bb) { acc[bb][0] += po[bb][0]; acc[bb][1] += po[bb][1]; acc[bb][2] += po[bb][2]; }
+    }
+    // skinning: T = sum_j w_j A_j ; v = T [v_posed; 1]   (lbs.py:67-77)
+    float w[NJ];
+    const float* wr = m.lbs_weights + (size_t)v * NJ;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) w[j] = wr[j];
+#pragma unroll
+    for (int bb = 0; bb < BT; ++bb) {
+        if (b0 + bb >= B) break;
+        float T[12];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) T[e] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const float4* a4 = (const float4*)&sA[bb][j * 12];
+            const float4 r0 = a4[0], r1 = a4[1], r2 = a4[2];
+            T[0] = fmaf(w[j], r0.x, T[0]); T[1] = fmaf(w[j], r0.y, T[1]); T[2] = fmaf(w[j], r0.z, T[2]); T[3] = fmaf(w[j], r0.w, T[3]);
+            T[4] = fmaf(w[j], r1.x, T[4]); T[5] = fmaf(w[j], r1.y, T[5]); T[6] = fmaf(w[j], r1.z, T[6]); T[7] = fmaf(w[j], r1.w, T[7]);
+            T[8] = fmaf(w[j], r2.x, T[8]); T[9] = fmaf(w[j], r2.y, T[9]); T[10] = fmaf(w[j], r2.z, T[10]); T[11] = fmaf(w[j], r2.w, T[11]);
+        }
+        const float x = acc[bb][0], y = acc[bb][1], z = acc[bb][2];
+        float* o = verts + ((size_t)(b0 + bb) * NV + v) * 3;
+        o[0] = T[0] * x + T[1] * y + T[2] * z + T[3];
+        o[1] = T[4] * x + T[5] * y + T[6] * z + T[7];
+        o[2] = T[8] * x + T[9] * y + T[10] * z + T[11];
+    }
+}
+
+// Per image: regress rows of `reg` ([R,6890], dense like the reference's buffers) over the mesh -> [R,3].
+__device__ __forceinline__ void regress_rows(const float* __restrict__ reg, int R, const float* __restrict__ vb,
+                                             float* __restrict__ sOut /*[R][3] shared*/, float* sRed /*[4][3]*/) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int r = 0; r < R; ++r) {
+        const float* rr = reg + (size_t)r * NV;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        for (int v = tid; v < NV; v += 256) {
+            const float wv = rr[v];
+            if (wv != 0.f) {     // the real regressors are >99 % zeros; skipping exact zeros does not change the sum
+                a0 = fmaf(wv, vb[3 * v], a0); a1 = fmaf(wv, vb[3 * v + 1], a1); a2 = fmaf(wv, vb[3 * v + 2], a2);
+            }
+        }
+        a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
+        if (lane == 0) { sRed[wave * 3] = a0; sRed[wave * 3 + 1] = a1; sRed[wave * 3 + 2] = a2; }
+        __syncthreads();
+        if (tid < 3) sOut[r * 3 + tid] = sRed[tid] + sRed[3 + tid] + sRed[6 + tid] + sRed[9 + tid];
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void smpl_joints_kernel(const whmr_smpl_model m, const float* __restrict__ verts,
+                                                          const float* __restrict__ posed_joints,
+                                                          float* __restrict__ joints49, float* __restrict__ smpl_joints45,
+                                                          float* __restrict__ markers) {
+    __shared__ float sExtra[9 * 3];
+    __shared__ float sJ24[24 * 3];
+    __shared__ float sRed[12];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* vb = verts + (size_t)b * NV * 3;
+    if (joints49) {
+        regress_rows(m.J_regressor_extra, 9, vb, sExtra, sRed);
+        // 54-joint superset: 24 posed SMPL joints, 21 picked vertices, 9 regressed (models/smpl.py:61-83), then JOINT_MAP
+        if (tid < 49 * 3) {
+            const int j = tid / 3, c = tid % 3;
+            const int s = m.joint_map[j];
+            float v;
+            if (s < 24) v = posed_joints[((size_t)b * NJ + s) * 3 + c];
+            else if (s < 45) v = vb[3 * m.extra_vertex_ids[s - 24] + c];
+            else v = sExtra[(s - 45) * 3 + c];
+            joints49[((size_t)b * 49 + j) * 3 + c] = v;
+        }
+    }
+    if (smpl_joints45) {     // whmr.py:186-187: J_regressor over the POSED mesh + vertex_joint_selector
+        regress_rows(m.J_regressor, 24, vb, sJ24, sRed);
+        if (tid < 45 * 3) {
+            const int j = tid / 3, c = tid % 3;
+            smpl_joints45[((size_t)b * 45 + j) * 3 + c] = j < 24 ? sJ24[j * 3 + c] : vb[3 * m.extra_vertex_ids[j - 24] + c];
+        }
+    }
+    if (markers) {           // whmr.py:184
+        for (int e = tid; e < m.n_markers * 3; e += 256)
+            markers[((size_t)b * m.n_markers) * 3 + e] = vb[3 * m.marker_ids[e / 3] + e % 3];
+    }
+}
+
+extern "C" int whmr_smpl_pose_chain(const whmr_smpl_model* m, const float* pose9, const float* betas, int B, int do_gs,
+                                    float* rotmat, float* aa, float* A, float* posed_joints, float* pose_feat, void* stream) {
+    if (B <= 0 || !A) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(smpl_pose_chain_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, *m, pose9, betas, do_gs, rotmat, aa, A,
+                       posed_joints, pose_feat);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int whmr_smpl_skin(const whmr_smpl_model* m, const float* betas, const float* pose_feat, const float* A, int B,
+                              float* verts, void* stream) {
+    if (B <= 0) return (int)hipErrorInvalidValue;
+    constexpr int BT = 8;
+    hipLaunchKernelGGL(smpl_skin_kernel<BT>, dim3((NV + 127) / 128, (B + BT - 1) / BT), dim3(128), 0, (hipStream_t)stream, *m,
+                       betas, pose_feat, A, B, verts);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int whmr_smpl_joints(const whmr_smpl_model* m, const float* verts, const float* posed_joints, int B,
+                                float* joints49, float* smpl_joints45, float* markers, void* stream) {
+    if (B <= 0) return (int)hipErrorInvalidValue;
+    if (smpl_joints45 && !m->J_regressor) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(smpl_joints_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, *m, verts, posed_joints, joints49,
+                       smpl_joints45, markers);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,126 @@
+"""SMPL body model on MI355X: the object W-HMR calls as ``self.smpl(betas=, body_pose=, global_orient=, pose2rot=False)``.
+
+Stands in for ``pare.models.SMPL`` (pare==0.1 wrapping smplx==0.1.28; commented twin at models/smpl.py:61-83 of the
+reference): same call signature, output with ``.vertices`` [B,6890,3] and ``.joints`` [B,49,3], ``.faces``.
+Buffers use the smplx names (v_template, shapedirs, posedirs [207,20670], J_regressor, lbs_weights, parents,
+faces_tensor, J_regressor_extra) so a reference checkpoint's ``regressor.N.smpl.*`` keys load.
+"""
+import os
+import pickle
+from collections import namedtuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+from ..core import constants as K
+
+SMPL_MODEL_DIR = 'data/smpl'
+SMPL_MEAN_PARAMS = 'data/smpl_mean_params.npz'
+JOINT_REGRESSOR_TRAIN_EXTRA = 'data/J_regressor_extra.npy'
+H36M_TO_J17 = K.H36M_TO_J17
+H36M_TO_J14 = K.H36M_TO_J14
+
+ModelOutput = namedtuple('ModelOutput', ['vertices', 'joints', 'smpl_joints', 'rotmat', 'pose_aa', 'markers'])
+
+
+def _np(a):
+    import scipy.sparse
+    return np.asarray(a.todense() if scipy.sparse.issparse(a) else a, dtype=np.float32)
+
+
+def load_smpl_arrays(model_dir=SMPL_MODEL_DIR, extra=JOINT_REGRESSOR_TRAIN_EXTRA):
+    """Read the licensed SMPL_NEUTRAL.pkl + J_regressor_extra.npy when present (never shipped with this repo)."""
+    with open(os.path.join(model_dir, 'SMPL_NEUTRAL.pkl'), 'rb') as f:
+        d = pickle.load(f, encoding='latin1')
+    nv = d['v_template'].shape[0]
+    return {'v_template': torch.from_numpy(_np(d['v_template'])), 'shapedirs': torch.from_numpy(_np(d['shapedirs'])[:, :, :10]),
+            'posedirs': torch.from_numpy(_np(d['posedirs']).reshape(nv * 3, -1).T.copy()),
+            'J_regressor': torch.from_numpy(_np(d['J_regressor'])), 'lbs_weights': torch.from_numpy(_np(d['weights'])),
+            'J_regressor_extra': torch.from_numpy(np.load(extra).astype(np.float32)),
+            'faces': torch.from_numpy(np.asarray(d['f'], dtype=np.int64))}
+
+
+class SMPL(nn.Module):
+    NUM_VERTS, NUM_JOINTS = 6890, 24
+
+    def __init__(self, model_path=SMPL_MODEL_DIR, arrays=None, marker_ids=None, **kwargs):
+        super().__init__()
+        a = arrays if arrays is not None else load_smpl_arrays(model_path)
+        for k in ('v_template', 'shapedirs', 'posedirs', 'J_regressor', 'lbs_weights', 'J_regressor_extra'):
+            self.register_buffer(k, a[k].float().contiguous().clone())
+        faces = a.get('faces', torch.zeros(1, 3, dtype=torch.int64))
+        self.register_buffer('faces_tensor', faces.long())
+        self.register_buffer('parents', torch.tensor(K.SMPL_PARENTS, dtype=torch.long))
+        self.register_buffer('extra_joints_idxs', torch.tensor(K.EXTRA_VERTEX_IDS, dtype=torch.long))
+        self.register_buffer('joint_map', torch.tensor(K.JOINT_MAP_49, dtype=torch.long))
+        ids = marker_ids if marker_ids is not None else torch.zeros(0, dtype=torch.long)
+        self.marker_ids = torch.as_tensor(ids, dtype=torch.long)
+        self._dev_cache = None
+
+    @property
+    def faces(self):
+        return self.faces_tensor.cpu().numpy()
+
+    # ---- device-side constants (folded joint regressors, int32 index tables) -- built once per device / buffer version
+    def _model(self):
+        dev = self.v_template.device
+        ver = (dev, self.v_template._version, self.shapedirs._version, self.J_regressor._version, self.posedirs.data_ptr())
+        if self._dev_cache is None or self._dev_cache[0] != ver:
+            i32 = lambda t: t.to(device=dev, dtype=torch.int32).contiguous()
+            # J = Jreg . (T + S beta) = (Jreg . T) + (Jreg . S) beta: fold the 24x6890 regressor into 24x3(+x10) constants
+            Jreg64 = self.J_regressor.double()
+            keep = {'J_template': (Jreg64 @ self.v_template.double()).float().contiguous(),
+                    'J_shapedirs': torch.einsum('jv,vcl->jcl', Jreg64, self.shapedirs.double()).float().contiguous(),
+                    'parents': i32(self.parents), 'extra': i32(self.extra_joints_idxs), 'jmap': i32(self.joint_map),
+                    'markers': i32(self.marker_ids)}
+            m = L.WhmrSmplModel()
+            m.v_template, m.shapedirs = self.v_template.data_ptr(), self.shapedirs.data_ptr()
+            m.posedirs, m.lbs_weights = self.posedirs.data_ptr(), self.lbs_weights.data_ptr()
+            m.J_template, m.J_shapedirs = keep['J_template'].data_ptr(), keep['J_shapedirs'].data_ptr()
+            m.J_regressor, m.J_regressor_extra = self.J_regressor.data_ptr(), self.J_regressor_extra.data_ptr()
+            m.parents, m.extra_vertex_ids = keep['parents'].data_ptr(), keep['extra'].data_ptr()
+            m.joint_map, m.marker_ids = keep['jmap'].data_ptr(), keep['markers'].data_ptr() if keep['markers'].numel() else None
+            m.n_markers = int(keep['markers'].numel())
+            self._dev_cache = (ver, m, keep)
+        return self._dev_cache[1]
+
+    @torch.no_grad()
+    def run(self, betas, rotmats, gram_schmidt=False, want_aa=False, want_smpl_joints=False, want_markers=False):
+        """betas [B,10], rotmats [B,24,3,3] (raw 3x3 blocks when gram_schmidt=True) -> ModelOutput."""
+        if not betas.is_cuda:
+            raise RuntimeError('whmr_amd.SMPL runs on a HIP device only (no CPU fallback)')
+        B, dev = betas.shape[0], betas.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        m = self._model()
+        betas = betas.float().contiguous()
+        pose9 = rotmats.reshape(B, 24, 9).float().contiguous()
+        rot = torch.empty(B, 24, 3, 3, **f32)
+        aa = torch.empty(B, 72, **f32) if want_aa else None
+        A = torch.empty(B, 24, 12, **f32)
+        pj = torch.empty(B, 24, 3, **f32)
+        pf = torch.empty(B, 207, **f32)
+        L.smpl_pose_chain(m, pose9, betas, gram_schmidt, rot, aa, A, pj, pf)
+        verts = torch.empty(B, self.NUM_VERTS, 3, **f32)
+        L.smpl_skin(m, betas, pf, A, verts)
+        joints = torch.empty(B, 49, 3, **f32)
+        sj = torch.empty(B, 45, 3, **f32) if want_smpl_joints else None
+        mk = torch.empty(B, m.n_markers, 3, **f32) if (want_markers and m.n_markers) else None
+        L.smpl_joints(m, verts, pj, joints, sj, mk)
+        return ModelOutput(verts, joints, sj, rot, aa, mk)
+
+    def forward(self, betas=None, body_pose=None, global_orient=None, pose2rot=False, **kwargs):
+        """pare.models.SMPL.forward call shape (whmr.py:132-137).  pose2rot=True takes axis-angle [B,69] / [B,3]."""
+        if pose2rot:
+            from ..utils.geometry import batch_rodrigues
+            B = betas.shape[0]
+            full = torch.cat([global_orient.reshape(B, -1), body_pose.reshape(B, -1)], dim=1).reshape(-1, 3)
+            rot = batch_rodrigues(full).reshape(B, 24, 3, 3)
+        else:
+            rot = torch.cat([global_orient.reshape(-1, 1, 3, 3), body_pose.reshape(-1, 23, 3, 3)], dim=1)
+        return self.run(betas, rot)
+
+
+def get_smpl_faces():
+    return SMPL(SMPL_MODEL_DIR).faces

@@ -1,0 +1,476 @@
+"""W-HMR on MI355X: the reference's ``WHMR`` / ``whmr_net`` module surface over libwhmr_hip.so.
+
+Mirrors models/whmr.py of yw0208/W-HMR: ``Regressor`` (:42-269), ``Global_Orient_Regressor`` (:272-305), ``WHMR`` (:308-678),
+``whmr_net`` (:681-687) -- same constructor role, same ``forward(x, meta_masks, center, scale, bbox_height, orig_shape,
+bbox_info, is_train=False, J_regressor=None, full_x=None, cam_rotmat=None)`` and the same ``state_dict`` keys
+(SURVEY App. B).  Differences, all deliberate and documented in DESIGN.md:
+  * three return views: ``view='vis'`` (released default, the 9-tensor vis_dict), ``'train'``
+    ((out_list, vis_feat_list)), ``'eval'`` (({'global_output': ...}, None)); select per call or via ``self.return_view``;
+  * ``full_x=None`` / ``cam_rotmat=...`` work (the release raises NameError): render_rotmat := cam_rotmat;
+  * inference only this round (is_train=True raises): Dropout/DropPath are identity, BN uses running stats;
+  * ``numerics``: 'bf16' (MFMA bf16 operands for ViT / deconv / Tz conv; everything after the feature maps is fp32)
+    or 'fp32' (exact-f32 MFMA everywhere; the 1e-4 parity mode).
+Every tensor op on the hot path is a kernel of this repo; the camera-calibration ResNet-50 stays on PyTorch-ROCm
+ and a few O(batch)-sized scalar expressions (focal length, camera translation) are tensor arithmetic.
+"""
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+from ..core.cfgs import cfg
+from ..core.constants import H36M_TO_J14
+from ..utils.geometry import (convert_pare_to_full_img_cam, rot6d_to_rotmat, rotation_matrix_to_angle_axis,
+                              unbiased_gram_schmidt)
+from .cam_model import CameraRegressorNetwork, batch_euler2matrix, convert_preds_to_angles
+from .maf_extractor import MAF_Extractor
+from .pose_vit import _Holder, _linear_params, _ln_params, get_vitpose_encoder
+from .smpl import SMPL, SMPL_MEAN_PARAMS, load_smpl_arrays
+
+BN_MOMENTUM = 0.1
+SMPL_Marker = 'data/smpl/smpl_ssm.npy'
+MESH_DOWNSAMPLING = 'data/mesh_downsampling.npz'
+
+
+def _cpu_rot6d_to_rotmat(x):
+    """geometry.py:243-257 on the host, for constructor-time buffers only (whmr.py:64-65,284-286)."""
+    x = x.reshape(-1, 3, 2)
+    a1, a2 = x[:, :, 0], x[:, :, 1]
+    b1 = a1 / a1.norm(dim=1, keepdim=True).clamp_min(1e-12)
+    u = a2 - (b1 * a2).sum(-1, keepdim=True) * b1
+    b2 = u / u.norm(dim=1, keepdim=True).clamp_min(1e-12)
+    return torch.stack((b1, b2, torch.linalg.cross(b1, b2, dim=-1)), dim=-1)
+
+
+def load_assets(smpl_mean_params=SMPL_MEAN_PARAMS):
+    """The reference's data files (whmr.py:62-100; never shipped here): SMPL pkl, mean params, markers, down-sampling."""
+    import scipy.sparse
+    mp = np.load(smpl_mean_params)
+    g = np.load(MESH_DOWNSAMPLING, allow_pickle=True, encoding='latin1')
+    D = [torch.from_numpy(np.asarray(scipy.sparse.coo_matrix(d).todense(), dtype=np.float32)) for d in g['D']]
+    return {'smpl': load_smpl_arrays(), 'ssm': torch.from_numpy(np.load(SMPL_Marker).astype(np.int64)),
+            'Dmap0': D[0], 'Dmap1': D[1], 'mean_params': {k: mp[k] for k in ('pose', 'shape', 'cam')}}
+
+
+def h36m_joints(verts, J_regressor):
+    """whmr.py:176-180 / :647-651: J_regressor [17,6890] . verts, LSP-14 subset, pelvis-centred (fp32 GEMM kernel)."""
+    B = verts.shape[0]
+    J = J_regressor.float().to(verts.device).contiguous()
+    vt = verts.permute(0, 2, 1).reshape(B * 3, -1).contiguous()
+    jj = torch.empty(J.shape[0], B * 3, dtype=torch.float32, device=verts.device)
+    L.gemm(J, vt, jj)
+    jj = jj.view(J.shape[0], B, 3).permute(1, 0, 2)
+    return jj[:, H36M_TO_J14] - jj[:, [0]]
+
+
+class _Cache:
+    """Derived device-side operands (folded / re-ordered / cast weights), rebuilt when a source tensor changes."""
+
+    def __init__(self):
+        self.d = {}
+
+    def get(self, key, srcs, fn):
+        ver = tuple((t.device, t._version, t.data_ptr()) for t in srcs)
+        ent = self.d.get(key)
+        if ent is None or ent[0] != ver:
+            ent = self.d[key] = (ver, fn())
+        return ent[1]
+
+
+class Regressor(nn.Module):
+    """whmr.py:42-269.  fc1 -> fc2 (no nonlinearity) -> decpose/decshape/deccam residual heads -> SMPL -> projections."""
+
+    def __init__(self, feat_dim, smpl_mean_params, smpl=None, assets=None):
+        super().__init__()
+        npose = 24 * 9
+        self.fc1 = nn.Linear(feat_dim + npose + 13 + 5, 1024)
+        self.drop1 = nn.Dropout()
+        self.fc2 = nn.Linear(1024, 1024)
+        self.drop2 = nn.Dropout()
+        self.decpose = nn.Linear(1024, npose)
+        self.decshape = nn.Linear(1024, 10)
+        self.deccam = nn.Linear(1024, 3)
+        for m in (self.decpose, self.decshape, self.deccam):
+            nn.init.xavier_uniform_(m.weight, gain=0.01)
+        self.smpl = smpl
+        mp = assets['mean_params']
+        init_pose = _cpu_rot6d_to_rotmat(torch.from_numpy(np.asarray(mp['pose'], dtype=np.float32)).reshape(1, 24, 6)).reshape(1, -1)
+        self.register_buffer('init_pose', init_pose)
+        self.register_buffer('init_shape', torch.from_numpy(np.asarray(mp['shape'], dtype=np.float32)).unsqueeze(0))
+        self.register_buffer('init_cam', torch.from_numpy(np.asarray(mp['cam'], dtype=np.float32)).unsqueeze(0))
+        self.register_buffer('Dmap0', assets['Dmap0'].float().clone())      # dense, like whmr.py:95-98
+        self.register_buffer('Dmap1', assets['Dmap1'].float().clone())
+        self.ssm = np.asarray(assets['ssm'])
+        self._cache = _Cache()
+
+    def _heads(self):
+        ws = [self.decpose.weight, self.decshape.weight, self.deccam.weight, self.decpose.bias, self.decshape.bias, self.deccam.bias]
+        return self._cache.get('heads', ws, lambda: (torch.cat([w.detach() for w in ws[:3]], 0).contiguous(),
+                                                     torch.cat([b.detach() for b in ws[3:]], 0).contiguous()))
+
+    def _downsample(self, verts):
+        """whmr.py:182-183 (train view only): dense Dmap0 / Dmap1 products on the fp32 GEMM kernel."""
+        B = verts.shape[0]
+        vt = verts.permute(0, 2, 1).reshape(B * 3, -1).contiguous()                  # [3B, 6890]
+        sub = torch.empty(self.Dmap0.shape[0], B * 3, dtype=torch.float32, device=verts.device)
+        L.gemm(self.Dmap0, vt, sub)
+        st = sub.t().contiguous()                                                      # [3B, 1723]
+        tmp = torch.empty(self.Dmap1.shape[0], B * 3, dtype=torch.float32, device=verts.device)
+        L.gemm(self.Dmap1, st, tmp)
+        n0, n1 = self.Dmap0.shape[0], self.Dmap1.shape[0]
+        return sub.view(n0, B, 3).permute(1, 0, 2).contiguous(), tmp.view(n1, B, 3).permute(1, 0, 2).contiguous()
+
+    def _outputs(self, out, pose_flat, shape, cam, scale, J_regressor, with_aux, Tz=None, orig_shape=None, center=None,
+                 bbox_height=None):
+        verts, joints = out.vertices, out.joints
+        B = verts.shape[0]
+        kp_2d = L.weak_projection(joints, cam.contiguous(), 1000.0, float(cfg.IMG_RES.WIDTH), float(cfg.IMG_RES.HEIGHT))
+        d = {'theta': torch.cat([cam, shape, out.pose_aa], dim=1), 'verts': verts, 'kp_2d': kp_2d, 'kp_3d': joints,
+             'smpl_kp_3d': out.smpl_joints, 'rotmat': out.rotmat, 'pred_cam': cam, 'pred_shape': shape,
+             'pred_pose': pose_flat, 'pose': out.pose_aa, 'pelvis': out.smpl_joints[:, :1] if out.smpl_joints is not None else None,
+             'markers': out.markers}
+        if Tz is not None:
+            s = cam[:, 0]
+            focal = s * bbox_height * Tz / 2.                                        # whmr.py:147-149
+            cam_center = orig_shape[:, [1, 0]] / 2.
+            cam_t = convert_pare_to_full_img_cam(cam, bbox_height, center, orig_shape[:, 1], orig_shape[:, 0], Tz=Tz)
+            kp_w = L.perspective(joints, None, cam_t.contiguous(), focal.contiguous(), cam_center.contiguous(),
+                                 post_div=cam_center.contiguous(), post_shift=-1.0)   # whmr.py:165-173
+            d.update(kp_2d_w=kp_w, pred_cam_t=cam_t, scale=scale, focal_length=focal)
+        if J_regressor is not None:                                                   # whmr.py:176-180
+            d['kp_3d'] = h36m_joints(verts, J_regressor)
+        if with_aux:
+            d['sub_verts'], d['temp_verts'] = self._downsample(verts)
+        return d
+
+    @torch.no_grad()
+    def forward(self, x, bbox_info, Tz, orig_shape, center, scale, bbox_height, init_pose=None, init_shape=None,
+                init_cam=None, is_train=False, n_iter=1, J_regressor=None, with_aux=True, xc=None):
+        """x [B, feat] (or pre-filled xc buffer [B, feat+5+229] whose first ``feat`` columns hold x) -> (dict, body_feat)."""
+        if is_train:
+            raise NotImplementedError('whmr_amd is inference-only this round (backward kernels: SURVEY 7 step 7)')
+        B = bbox_info.shape[0]
+        dev = bbox_info.device
+        F = self.fc1.in_features - 229 - 5
+        if xc is None:
+            xc = torch.empty(B, F + 5 + 229, dtype=torch.float32, device=dev)
+            xc[:, :F] = x
+        pose = (self.init_pose.expand(B, -1) if init_pose is None else init_pose).reshape(B, -1)
+        shape = self.init_shape.expand(B, -1) if init_shape is None else init_shape
+        cam = self.init_cam.expand(B, -1) if init_cam is None else init_cam
+        xc[:, F:F + 5] = bbox_info                                                    # whmr.py:105
+        xc[:, F + 5:F + 221] = pose                                                   # whmr.py:119
+        xc[:, F + 221:F + 231] = shape
+        xc[:, F + 231:] = cam
+        h1 = torch.empty(B, 1024, dtype=torch.float32, device=dev)
+        h2 = torch.empty(B, 1024, dtype=torch.float32, device=dev)
+        new = torch.empty(B, 229, dtype=torch.float32, device=dev)
+        wh, bh = self._heads()
+        for _ in range(n_iter):
+            L.gemm(xc, self.fc1.weight.detach(), h1, bias=self.fc1.bias.detach())
+            L.gemm(h1, self.fc2.weight.detach(), h2, bias=self.fc2.bias.detach())
+            L.gemm(h2, wh, new, bias=bh, residual=xc[:, F + 5:])                      # whmr.py:124-126 (+ residual state)
+            if n_iter > 1:
+                xc[:, F + 5:] = new
+        pose, shape, cam = new[:, :216].contiguous(), new[:, 216:226].contiguous(), new[:, 226:].contiguous()
+        out = self.smpl.run(shape, pose.view(B, 24, 3, 3), gram_schmidt=True, want_aa=True, want_smpl_joints=True,
+                            want_markers=True)                                        # whmr.py:128-137,174,184-187
+        d = self._outputs(out, pose, shape, cam, scale, J_regressor, with_aux, Tz, orig_shape, center, bbox_height)
+        return d, xc[:, :F + 5]
+
+    @torch.no_grad()
+    def forward_init(self, x, init_pose=None, init_shape=None, init_cam=None, n_iter=1, J_regressor=None, with_aux=True):
+        """whmr.py:211-269: the mean-pose mesh (no Gram-Schmidt, rotmats = init_pose as stored)."""
+        B = x.shape[0]
+        pose = (self.init_pose.expand(B, -1) if init_pose is None else init_pose).contiguous()
+        shape = (self.init_shape.expand(B, -1) if init_shape is None else init_shape).contiguous()
+        cam = (self.init_cam.expand(B, -1) if init_cam is None else init_cam).contiguous()
+        out = self.smpl.run(shape, pose.view(B, 24, 3, 3), gram_schmidt=False, want_aa=True, want_smpl_joints=True,
+                            want_markers=True)
+        return self._outputs(out, pose, shape, cam, None, J_regressor, with_aux)
+
+
+class Global_Orient_Regressor(nn.Module):
+    """whmr.py:272-305.  In eval the three 'iterations' are identical (local_orient is never fed back): one pass."""
+
+    def __init__(self, smpl_mean_params=None, assets=None):
+        super().__init__()
+        self.fc1 = nn.Linear(2149 + 6 + 9, 2048)
+        self.drop1 = nn.Dropout()
+        self.fc2 = nn.Linear(2048, 2048)
+        self.drop2 = nn.Dropout()
+        self.decrot = nn.Linear(2048, 9)
+        nn.init.xavier_uniform_(self.decrot.weight, gain=0.01)
+        mp = assets['mean_params']
+        init_pose = _cpu_rot6d_to_rotmat(torch.from_numpy(np.asarray(mp['pose'], dtype=np.float32)).reshape(1, 24, 6)).reshape(1, 24, 9)
+        self.register_buffer('init_pose', init_pose[:, 0])
+
+    @torch.no_grad()
+    def forward(self, x, cam_rotmat, local_orient, is_train=False):
+        if is_train:
+            raise NotImplementedError('inference-only this round')
+        B, dev = x.shape[0], x.device
+        xc = torch.empty(B, 2149 + 6 + 9, dtype=torch.float32, device=dev)
+        xc[:, :2149] = x
+        xc[:, 2149:2155] = cam_rotmat[:, :, :2].reshape(B, 6)                          # rotmat_to_rot6d, geometry.py:275-286
+        xc[:, 2155:] = local_orient.reshape(B, 9)
+        h1 = torch.empty(B, 2048, dtype=torch.float32, device=dev)
+        h2 = torch.empty(B, 2048, dtype=torch.float32, device=dev)
+        r = torch.empty(B, 9, dtype=torch.float32, device=dev)
+        L.gemm(xc, self.fc1.weight.detach(), h1, bias=self.fc1.bias.detach())
+        L.gemm(h1, self.fc2.weight.detach(), h2, bias=self.fc2.bias.detach())
+        L.gemm(h2, self.decrot.weight.detach(), r, bias=self.decrot.bias.detach(), residual=xc[:, 2155:])
+        return unbiased_gram_schmidt(r.reshape(-1, 1, 3, 3))
+
+
+class IUV_predict_layer(nn.Module):
+    """Parameter container of models/iuv_predictor.py:71-91 (dp_head).  Its output is discarded by the released
+    forward (whmr.py:656-658,663-678), so no inference view evaluates it; kept for state_dict parity."""
+
+    def __init__(self, feat_dim=256, final_cov_k=3, part_out_dim=25):
+        super().__init__()
+        pad = 1 if final_cov_k == 3 else 0
+        self.predict_u = nn.Conv2d(feat_dim, 25, final_cov_k, 1, pad)
+        self.predict_v = nn.Conv2d(feat_dim, 25, final_cov_k, 1, pad)
+        self.predict_ann_index = nn.Conv2d(feat_dim, 15, final_cov_k, 1, pad)
+        self.predict_uv_index = nn.Conv2d(feat_dim, 25, final_cov_k, 1, pad)
+
+
+class WHMR(nn.Module):
+    """whmr.py:308-678 (vitpose branch)."""
+
+    def __init__(self, smpl_mean_params=SMPL_MEAN_PARAMS, pretrained=True, assets=None, numerics='bf16',
+                 return_view='vis', cam_ckpt='data/pretrained_model/camcalib_sa_biased_l2.ckpt'):
+        super().__init__()
+        assert cfg.MODEL.PyMAF.BACKBONE == 'vitpose', 'only the vitpose branch is on the hot path (SURVEY 2.1)'
+        assert cfg.MODEL.PyMAF.N_ITER == 3
+        if assets is None:
+            assets = load_assets(smpl_mean_params)
+        self.numerics = numerics
+        self.return_view = return_view
+        self.feature_extractor = get_vitpose_encoder(cfg, numerics=numerics)
+        self.inplanes = 768
+        self.deconv_with_bias = cfg.RES_MODEL.DECONV_WITH_BIAS
+        self.deconv_layers = self._make_deconv_layer(cfg.RES_MODEL.NUM_DECONV_LAYERS, cfg.RES_MODEL.NUM_DECONV_FILTERS,
+                                                     cfg.RES_MODEL.NUM_DECONV_KERNELS)
+        dmap = torch.matmul(assets['Dmap1'].float(), assets['Dmap0'].float())
+        self.maf_extractor = nn.ModuleList([MAF_Extractor(Dmap=dmap.clone()) for _ in range(cfg.MODEL.PyMAF.N_ITER)])
+        ma_feat_len = 67 * cfg.MODEL.PyMAF.MLP_DIM[-1]
+        xv, yv = torch.meshgrid([torch.linspace(-1, 1, 7), torch.linspace(-1, 1, 9)], indexing='ij')   # whmr.py:341-347
+        self.register_buffer('points_grid', torch.stack([xv.reshape(-1), yv.reshape(-1)]).unsqueeze(0))
+        grid_feat_len = 7 * 9 * cfg.MODEL.PyMAF.MLP_DIM[-1]
+        smpl = SMPL(arrays=assets['smpl'], marker_ids=assets['ssm'])                  # one instance, shared (3 key prefixes)
+        self.regressor = nn.ModuleList([Regressor(grid_feat_len if i == 0 else ma_feat_len, smpl_mean_params, smpl, assets)
+                                        for i in range(3)])
+        self.transformer = nn.ModuleList()                                            # dead in the reference (whmr.py:362-394)
+        if cfg.MODEL.PyMAF.AUX_SUPV_ON:
+            self.dp_head = IUV_predict_layer(feat_dim=256)
+        self.conv = nn.Sequential(nn.Conv2d(256, 64, 7, 3, 0, bias=False), nn.Conv2d(64, 5, 7, 2, 0, bias=False))
+        td = _Holder()                                                                # timm Block(dim=216, heads=2) names
+        _ln_params(td, 'norm1', 216)
+        td.attn = _Holder()
+        _linear_params(td.attn, 'qkv', 648, 216, bias=False)
+        _linear_params(td.attn, 'proj', 216, 216)
+        _ln_params(td, 'norm2', 216)
+        td.mlp = _Holder()
+        _linear_params(td.mlp, 'fc1', 864, 216)
+        _linear_params(td.mlp, 'fc2', 216, 864)
+        self.transformer_decoder = td
+        self.avgpool = nn.AvgPool1d(kernel_size=5)
+        self.est_Tz = nn.Sequential(nn.Linear(18 * 12, 12), nn.Linear(12, 1), nn.BatchNorm1d(1), nn.Sigmoid())
+        self.cam_model = CameraRegressorNetwork(backbone='resnet50', num_fc_layers=1, num_fc_channels=1024)
+        if pretrained and cam_ckpt and os.path.exists(cam_ckpt):
+            sd = torch.load(cam_ckpt, map_location='cpu')['state_dict']
+            self.cam_model.load_state_dict({k.replace('model.', '', 1): v for k, v in sd.items()}, strict=True)
+        self.global_orient = Global_Orient_Regressor(smpl_mean_params, assets)
+        self._cache = _Cache()
+        self._init_cache = None
+        self.eval()
+
+    def _make_deconv_layer(self, num_layers, num_filters, num_kernels):
+        """whmr.py:459-501: parameter containers for 3x (ConvTranspose2d k4 s2 p1, BatchNorm2d, ReLU)."""
+        assert num_layers == len(num_filters) == len(num_kernels)
+        layers = []
+        for i in range(num_layers):
+            assert num_kernels[i] == 4, 'the sub-pixel GEMM decomposition is built for kernel 4 / stride 2 / pad 1'
+            layers += [nn.ConvTranspose2d(self.inplanes, num_filters[i], 4, 2, 1, 0, bias=self.deconv_with_bias),
+                       nn.BatchNorm2d(num_filters[i], momentum=BN_MOMENTUM), nn.ReLU(inplace=True)]
+            self.inplanes = num_filters[i]
+        return nn.Sequential(*layers)
+
+    # ------------------------------------------------------------------ derived operands
+    @property
+    def _dt(self):
+        return torch.float32 if self.numerics == 'fp32' else torch.bfloat16
+
+    def _deconv_operands(self, i):
+        """4 sub-pixel phase matrices [Cout, 4*Cin] (k = (a, b, ci)) with the eval BatchNorm scale folded in, + shift."""
+        ct, bn = self.deconv_layers[3 * i], self.deconv_layers[3 * i + 1]
+        srcs = [ct.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var] + ([ct.bias] if ct.bias is not None else [])
+
+        def build():
+            w = ct.weight.detach().float()                                            # [Cin, Cout, 4, 4]
+            s = bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)
+            t = bn.bias.detach() - bn.running_mean * s
+            if ct.bias is not None:
+                t = t + ct.bias.detach() * s
+            phases = []
+            for py in range(2):
+                for px in range(2):
+                    taps = [w[:, :, 3 - py - 2 * a, 3 - px - 2 * b] for a in range(2) for b in range(2)]   # each [Cin, Cout]
+                    wp = torch.stack(taps, 0).permute(2, 0, 1).reshape(w.shape[1], -1) * s[:, None]
+                    phases.append(wp.contiguous().to(self._dt) if self._dt == torch.float32 else L.cast_bf16(wp.contiguous()))
+            return phases, t.float().contiguous()
+        return self._cache.get(('deconv', i, self.numerics), srcs, build)
+
+    def _tz_operands(self):
+        c0, c1 = self.conv[0].weight, self.conv[1].weight
+
+        def build():
+            w0 = c0.detach().permute(0, 2, 3, 1).reshape(c0.shape[0], -1).contiguous()     # [64, (ky,kx,ci)]
+            w0 = w0 if self._dt == torch.float32 else L.cast_bf16(w0)
+            w1 = c1.detach().permute(0, 2, 3, 1).reshape(c1.shape[0], -1).contiguous()     # [5, (ky,kx,ci)] fp32 always
+            bn = self.est_Tz[2]
+            bn4 = torch.stack([bn.weight.detach()[0], bn.bias.detach()[0], bn.running_mean[0], bn.running_var[0]]).float().contiguous()
+            return w0, w1, bn4
+        bn = self.est_Tz[2]
+        return self._cache.get(('tz', self.numerics), [c0, c1, bn.weight, bn.bias, bn.running_mean, bn.running_var], build)
+
+    # ------------------------------------------------------------------ stages
+    def _deconv(self, i, x_nhwc):
+        B, H, W, Cin = x_nhwc.shape
+        phases, shift = self._deconv_operands(i)
+        Cout = phases[0].shape[0]
+        out = torch.empty(B, 2 * H, 2 * W, Cout, dtype=self._dt, device=x_nhwc.device)
+        for py in range(2):
+            for px in range(2):
+                L.gemm(x_nhwc, phases[py * 2 + px], out, bias=shift, act=L.ACT_RELU,
+                       conv=dict(IH=H, IW=W, Cin=Cin, OH=H, OW=W, KW=2, SH=1, SW=1, PH=1 - py, PW=1 - px),
+                       scatter=dict(c_off=(py * 2 * W + px) * Cout, osb=4 * H * W * Cout, osy=4 * W * Cout, osx=2 * Cout))
+        return out
+
+    def _tz_head(self, f_nhwc):
+        """whmr.py:567-577."""
+        B, H, W, C = f_nhwc.shape
+        dev = f_nhwc.device
+        w0, w1, bn4 = self._tz_operands()
+        H1, W1 = (H - 7) // 3 + 1, (W - 7) // 3 + 1
+        y0 = torch.empty(B, H1, W1, 64, dtype=torch.float32, device=dev)
+        L.gemm(f_nhwc, w0, y0.view(-1, 64), conv=dict(IH=H, IW=W, Cin=C, OH=H1, OW=W1, KW=7, SH=3, SW=3, PH=0, PW=0))
+        H2, W2 = (H1 - 7) // 2 + 1, (W1 - 7) // 2 + 1
+        y1 = torch.empty(B, H2 * W2, 5, dtype=torch.float32, device=dev)
+        L.gemm(y0, w1, y1.view(-1, 5), conv=dict(IH=H1, IW=W1, Cin=64, OH=H2, OW=W2, KW=7, SH=2, SW=2, PH=0, PW=0))
+        D = H2 * W2
+        t = y1.transpose(1, 2).contiguous().view(B * 5, D)                            # reshape(B, 5, -1) of the NCHW map
+        td = self.transformer_decoder
+        h = torch.empty_like(t)
+        qkv = torch.empty(B * 5, 3 * D, dtype=torch.float32, device=dev)
+        att = torch.empty_like(t)
+        hid = torch.empty(B * 5, td.mlp.fc1.weight.shape[0], dtype=torch.float32, device=dev)
+        L.layernorm(t, td.norm1.weight, td.norm1.bias, h, 1e-5)
+        L.gemm(h, td.attn.qkv.weight.detach(), qkv, bias=td.attn.qkv.bias)
+        L.attention(qkv, att, B, 5, 2, D // 2, (D // 2) ** -0.5)
+        L.gemm(att, td.attn.proj.weight.detach(), t, bias=td.attn.proj.bias.detach(), residual=t)
+        L.layernorm(t, td.norm2.weight, td.norm2.bias, h, 1e-5)
+        L.gemm(h, td.mlp.fc1.weight.detach(), hid, bias=td.mlp.fc1.bias.detach(), act=L.ACT_GELU)
+        L.gemm(hid, td.mlp.fc2.weight.detach(), t, bias=td.mlp.fc2.bias.detach(), residual=t)
+        tz = torch.empty(B, dtype=torch.float32, device=dev)
+        L.tz_tail(t.view(B, 5, D), self.est_Tz[0].weight.detach(), self.est_Tz[0].bias.detach(), self.est_Tz[1].weight.detach(),
+                  self.est_Tz[1].bias.detach(), bn4, self.est_Tz[2].eps, tz)
+        return tz
+
+    def _init_mesh(self, B, J_regressor, with_aux):
+        """whmr.py:548-550 recomputes a constant every call: computed once at batch 1 and expanded."""
+        reg = self.regressor[0]
+        expand = lambda d: {k: (v.expand(B, *v.shape[1:]) if torch.is_tensor(v) else v) for k, v in d.items()}
+        x1 = torch.empty(1, 1, device=self.points_grid.device)
+        if J_regressor is not None:
+            return expand(reg.forward_init(x1, J_regressor=J_regressor, with_aux=with_aux))
+        key = (reg.init_pose.device, reg.init_pose._version, reg.init_shape._version, reg.init_cam._version, with_aux)
+        if self._init_cache is None or self._init_cache[0] != key:
+            self._init_cache = (key, reg.forward_init(x1, with_aux=with_aux))
+        return expand(self._init_cache[1])
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward(self, x, meta_masks=None, center=None, scale=None, bbox_height=None, orig_shape=None, bbox_info=None,
+                is_train=False, J_regressor=None, full_x=None, cam_rotmat=None, view=None):
+        if is_train:
+            raise NotImplementedError('whmr_amd is inference-only this round (backward kernels: SURVEY 7 step 7)')
+        if not x.is_cuda:
+            raise RuntimeError('whmr_amd.WHMR runs on a HIP device only (no CPU fallback)')
+        view = view or self.return_view
+        with_aux = view == 'train'
+        B, dev = x.shape[0], x.device
+        render_rotmat = None
+        if cam_rotmat is None:                                                        # whmr.py:509-524
+            if full_x is not None:
+                pred, _ = self.cam_model(full_x)
+                _, pitch, roll = convert_preds_to_angles(*pred, loss_type='softargmax_l2')
+                pitch, roll = pitch.unsqueeze(-1), roll.unsqueeze(-1)
+                zeros = torch.zeros((B, 1), device=dev)
+                cam_rotmat = batch_euler2matrix(torch.cat([pitch, zeros, roll], dim=1).float())
+                render_rotmat = batch_euler2matrix(torch.cat([-pitch, zeros, roll], dim=1).float())
+            else:
+                cam_rotmat = torch.eye(3, device=dev).unsqueeze(0).expand(B, -1, -1).float()
+        if render_rotmat is None:
+            render_rotmat = cam_rotmat
+
+        # backbone (tokens are NHWC already) -> deconv pyramid in NHWC
+        vit = self.feature_extractor.backbone
+        tok, (_, Hp, Wp) = vit.forward_tokens(x)
+        s_feat = tok.view(B, Hp, Wp, vit.embed_dim)
+        f = s_feat if self._dt == torch.float32 else L.cast_bf16(s_feat)
+        fmaps = []
+        for i in range(3):
+            f = self._deconv(i, f)
+            fmaps.append(f)
+            self.maf_extractor[i].im_feat = f.permute(0, 3, 1, 2)                     # logical NCHW view (whmr.py:564)
+        Tz = self._tz_head(fmaps[-1])
+
+        smpl_output = self._init_mesh(B, J_regressor, with_aux)
+        outs = [smpl_output]
+        body_feat = None
+        center, scale, bbox_height = center.float(), scale.float(), bbox_height.float()
+        orig_shape, bbox_info = orig_shape.float(), bbox_info.float().contiguous()
+        for i in range(3):                                                            # whmr.py:580-627
+            reg, ext = self.regressor[i], self.maf_extractor[i]
+            cam, shp, pose = smpl_output['pred_cam'], smpl_output['pred_shape'], smpl_output['rotmat']
+            ext.cam = cam
+            F = reg.fc1.in_features - 234
+            xc = torch.empty(B, F + 234, dtype=torch.float32, device=dev)
+            if i == 0:
+                pts = self.points_grid.expand(B, -1, -1).transpose(1, 2).contiguous()
+                ext.sampling(pts, out=xc, want_point_feat=False)
+            else:
+                ext(smpl_output['markers'].contiguous(), cam=cam.contiguous(), out=xc, want_point_feat=False)
+            smpl_output, body_feat = reg(None, bbox_info, Tz, orig_shape, center, scale, bbox_height, pose, shp, cam,
+                                         is_train=False, n_iter=1, J_regressor=J_regressor, with_aux=with_aux, xc=xc)
+            outs.append(smpl_output)
+
+        g_rot = self.global_orient(body_feat, cam_rotmat, smpl_output['rotmat'][:, 0], False)     # whmr.py:630-654
+        g_aa = rotation_matrix_to_angle_axis(g_rot.reshape(-1, 3, 3)).reshape(-1, 3)
+        g_pose = torch.cat([g_aa, smpl_output['pose'][:, 3:]], dim=1)
+        g_rotmat = torch.cat([g_rot, smpl_output['rotmat'][:, 1:]], dim=1)
+        g = self.regressor[0].smpl.run(smpl_output['pred_shape'], g_rotmat)
+        g_joints = g.joints
+        if J_regressor is not None:
+            g_joints = h36m_joints(g.vertices, J_regressor)
+        g_out = {'global_pose': g_pose, 'global_shape': smpl_output['pred_shape'], 'global_rotmat': g_rotmat,
+                 'global_kp_3d': g_joints, 'global_verts': g.vertices}
+        if view == 'eval':
+            return {'global_output': g_out}, None
+        if view == 'train':
+            vis_feat = [s_feat.permute(0, 3, 1, 2)] + [m.permute(0, 3, 1, 2) for m in fmaps]
+            return {'smpl_out': outs, 'dp_out': [], 'dpth_out': [], 'global_output': g_out}, vis_feat
+        return {'local_smpl_vertices': smpl_output['verts'], 'smpl_vertices': g.vertices,
+                'pred_cam_t': smpl_output['pred_cam_t'], 'focal_length': smpl_output['focal_length'],
+                'cam_rotmat': cam_rotmat, 'render_rotmat': render_rotmat, 'shape': smpl_output['pred_shape'],
+                'global_pose': g_pose, 'local_pose': smpl_output['pose']}
+
+
+def whmr_net(smpl_mean_params, pretrained=True, **kwargs):
+    """models/whmr.py:681-687."""
+    return WHMR(smpl_mean_params, pretrained, **kwargs)
