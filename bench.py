@@ -63,6 +63,25 @@ def cpu_baseline(sd, x_cpu, size):
             'sample': 'oracle.vit.vit_forward fp32, one batch of %d %dx%d crops, 1 pass (%.1f s)' % (n, size[0], size[1], dt)}
 
 
+def reduce_max_time(dt, dist, dev):
+    """max over ranks of the timed region (the slowest rank defines the step time)"""
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t.item()
+
+
+def aggregate_value(world, batch, steps, dt):
+    """whole-job images/sec: every rank processes its own `batch` images per step (weak scaling, no collective)"""
+    return world * batch * steps / dt
+
+
+def shard_batch(global_batch, world, rank):
+    """contiguous per-rank slice [lo, hi) of a global batch (partition = contiguous batch slices)"""
+    per = global_batch // world
+    return [rank * per, (rank + 1) * per]
+
+
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -99,10 +118,7 @@ def main():
         step()
         torch.cuda.synchronize()
         prof, L.PROFILE = L.PROFILE, None
-    tmax = torch.tensor([dt], device=dev)
-    if dist is not None:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = tmax.item()
+    dt = reduce_max_time(dt, dist, dev)
 
     gemm = [(f, e0.elapsed_time(e1) * 1e-3) for (name, f, e0, e1) in prof if name == 'gemm_bf16']
     n_launch = max(len(gemm), 1)
@@ -112,7 +128,7 @@ def main():
     peak = 2500.0                                                     # dense bf16 MFMA, MI355X_MICROARCH.md
     if rank == 0:
         res = {
-            'metric': 'images/sec ViT-B 224^2 batch-64 fwd', 'value': world * args.batch * args.steps / dt,
+            'metric': 'images/sec ViT-B 224^2 batch-64 fwd', 'value': aggregate_value(world, args.batch, args.steps, dt),
             'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': args.numerics, 'data': 'synthetic',

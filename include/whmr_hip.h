@@ -36,7 +36,7 @@ struct whmr_gemm {
     int64_t c_off, osb, osy, osx;
 };
 
-/* bf16 MFMA GEMM (v_mfma_f32_32x32x16_bf16, fp32 accumulate).  Needs N % 128 == 0, K % 64 == 0.
+/* bf16 MFMA GEMM (v_mfma_f32_32x32x16_bf16, fp32 accumulate).  Needs K % 64 == 0 (and Cin % 64 == 0 for a_mode 1).
  * Replaces nn.Linear at vit.py:93,96 (qkv, proj), vit.py:66-68 (fc1, fc2), Conv2d at vit.py:157 (after
  * whmr_patch_im2col), ConvTranspose2d+BN+ReLU at whmr.py:488-498 and Conv2d at whmr.py:419.
  * flags bit0: stage through registers instead of global_load_lds. */
@@ -61,6 +61,70 @@ int whmr_cast_f32_bf16(const float* src, void* dst, long n, void* stream);
 /* softmax(scale * Q K^T) V per (image, head) on qkv [B, N, 3, H, d] -> out [B, N, H*d].  vit.py:102-111.
  * is_bf16 = 1: MFMA kernel (d == 64, N <= 256); 0: fp32 kernel (N <= 256, any d). */
 int whmr_attention(const void* qkv, void* out, int B, int N, int H, int d, float scale, int is_bf16, void* stream);
+
+/* ---- rotation / projection helpers: utils/geometry.py ------------------------------------------------------------ */
+/* mode 0: rot6d_to_rotmat (geometry.py:243-257, in [n,6]); 1: unbiased_gram_schmidt (:260-272, in [n,9]);
+ * 2: batch_rodrigues (:14-27, in [n,3]).  out [n,9] row-major. */
+int whmr_rot_to_mat(const float* in, float* out, int n, int mode, void* stream);
+/* rotation_matrix_to_angle_axis (geometry.py:54-83 via :160-240 and :86-136): [n,9] -> [n,3], NaN -> 0. */
+int whmr_mat_to_aa(const float* in, float* out, int n, void* stream);
+/* perspective_projection (geometry.py:310-341).  rot may be null (identity) or batch-1 (rot_bstride 0, else 9);
+ * focal per image (focal_bstride 1) or one scalar (0); center / post_div may be null.
+ * out = K (R p + t) / z  [ / post_div[b] + post_shift ]  (the latter = whmr.py:173). */
+int whmr_perspective(const float* pts, const float* rot, int rot_bstride, const float* trans, const float* focal,
+                     int focal_bstride, const float* center, const float* post_div, float post_shift, float* out,
+                     int B, int P, void* stream);
+/* projection (geometry.py:289-307): weak-perspective camera [B,3] -> [-1,1] crop coordinates. */
+int whmr_weak_projection(const float* pts, const float* cam, float* out, int B, int P, float focal, float res_w,
+                         float res_h, void* stream);
+
+/* ---- SMPL forward: pare.models.SMPL / smplx lbs as called at whmr.py:132-137,227-232,641-644 ---------------------- */
+struct whmr_smpl_model {
+    const float* v_template;         /* [6890,3] */
+    const float* shapedirs;          /* [6890,3,10] */
+    const float* posedirs;           /* [207,20670] (smplx layout) */
+    const float* lbs_weights;        /* [6890,24] */
+    const float* J_template;         /* [24,3]    = J_regressor . v_template  (folded once on the host) */
+    const float* J_shapedirs;        /* [24,3,10] = J_regressor . shapedirs */
+    const float* J_regressor;        /* [24,6890] (for smpl_joints45; may be null) */
+    const float* J_regressor_extra;  /* [9,6890] */
+    const int32_t* parents;          /* [24] */
+    const int32_t* extra_vertex_ids; /* [21] VertexJointSelector picks */
+    const int32_t* joint_map;        /* [49] into the 54-joint superset (core/constants.py:16-92) */
+    const int32_t* marker_ids;       /* [n_markers] (data/smpl/smpl_ssm.npy, whmr.py:100,184) */
+    int32_t n_markers;
+};
+/* pose9 [B,24,9] (+ optional unbiased Gram-Schmidt, whmr.py:129-130) -> rotmat [B,24,9], angle-axis [B,72] (whmr.py:174),
+ * skinning transforms A [B,24,12], posed joints [B,24,3], pose feature [B,207].  Null outputs are skipped (A required). */
+int whmr_smpl_pose_chain(const struct whmr_smpl_model* m, const float* pose9, const float* betas, int B, int do_gs,
+                         float* rotmat, float* aa, float* A, float* posed_joints, float* pose_feat, void* stream);
+/* blend shapes + pose-corrective offsets + linear blend skinning -> verts [B,6890,3]. */
+int whmr_smpl_skin(const struct whmr_smpl_model* m, const float* betas, const float* pose_feat, const float* A, int B,
+                   float* verts, void* stream);
+/* joints49 [B,49,3] (24 posed + 21 vertex picks + 9 regressed, JOINT_MAP), optional smpl_joints45 [B,45,3]
+ * (whmr.py:186-187) and markers [B,n_markers,3] (whmr.py:184). */
+int whmr_smpl_joints(const struct whmr_smpl_model* m, const float* verts, const float* posed_joints, int B,
+                     float* joints49, float* smpl_joints45, float* markers, void* stream);
+
+/* ---- MAF sampler: models/maf_extractor.py:75-143 ------------------------------------------------------------------ */
+struct whmr_maf_weights {
+    const float* w0t; const float* b0;   /* conv0 transposed [256][128], bias [128] */
+    const float* w1t; const float* b1;   /* conv1 transposed [384][64]  (inputs: y0 | raw feature) */
+    const float* w2t; const float* b2;   /* conv2 transposed [320][32]  (inputs: y1 | raw feature) */
+};
+/* (weak-perspective projection of pts3d with cam ->) bilinear grid_sample(align_corners=True, zero padding) of 256
+ * channels at P points -> 3-layer point MLP -> out[b*out_stride + c*P + p].  fmap is addressed by element strides
+ * (sb, sc, sy, sx), fp32 or bf16.  With neither pts2d nor pts3d, fmap is [B,256,P] pre-sampled features (reduce_dim).
+ * point_feat (nullable) receives the raw sampled features [B,256,P]. */
+int whmr_maf_sample(const void* fmap, int fmap_bf16, long sb, long sc, long sy, long sx, int H, int W,
+                    const float* pts2d, const float* pts3d, const float* cam, float focal, float res_w, float res_h,
+                    const struct whmr_maf_weights* w, int B, int P, float* out, long out_stride, float* point_feat,
+                    void* stream);
+
+/* Tz-head tail (whmr.py:574-577): tokens [B,T,D] -> mean over T -> Linear(D,Hd) -> Linear(Hd,1) -> BatchNorm1d(1) eval
+ * (bn4 = weight, bias, running_mean, running_var) -> sigmoid -> x10. */
+int whmr_tz_tail(const float* tok, int B, int T, int D, const float* w0, const float* b0, int Hd, const float* w1,
+                 const float* b1, const float* bn4, float bn_eps, float* tz, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,101 @@
+"""CPU suite: C-ABI library exports, host-side module logic, config object, loud failure without a GPU, gloo sharding."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    import __graft_entry__ as ge
+    ge.build()
+    from whmr_amd import _lib as L
+    lib = ctypes.CDLL(L.LIB_PATH)
+    hdr = open(os.path.join(ROOT, 'include', 'whmr_hip.h')).read()
+    declared = set(re.findall(r'^\s*int\s+(whmr_\w+)\s*\(', hdr, flags=re.M))
+    assert declared and declared == set(L.EXPORTS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+
+
+def test_product_path_never_imports_the_oracle():
+    for dp, _, files in os.walk(os.path.join(ROOT, 'w-hmr_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle', src, flags=re.M), os.path.join(dp, f)
+
+
+def test_no_cpu_fallback(assets, state_dict):
+    from whmr_amd.models import whmr_net
+    from whmr_amd.models.pose_vit import ViT
+    from whmr_amd.utils import geometry as G
+    with pytest.raises(RuntimeError):
+        ViT(img_size=(256, 192), depth=1, qkv_bias=True)(torch.zeros(1, 3, 256, 192))
+    with pytest.raises(RuntimeError):
+        G.batch_rodrigues(torch.zeros(2, 3))
+    m = whmr_net(None, assets=assets)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 3, 256, 192))
+    with pytest.raises(NotImplementedError):
+        m(torch.zeros(1, 3, 256, 192), is_train=True)
+
+
+def test_state_dict_contract(assets, state_dict):
+    """every own-code key of the reference state_dict exists with the right shape, strict on our side"""
+    from whmr_amd.models import whmr_net
+    m = whmr_net(None, assets=assets)
+    own = m.state_dict()
+    for k, v in state_dict.items():
+        assert k in own and tuple(own[k].shape) == tuple(v.shape), k
+    extra = [k for k in own if k not in state_dict]
+    assert all('.smpl.' in k for k in extra), extra                  # third-party (smplx) buffer names only
+    res = m.load_state_dict(state_dict, strict=False)
+    assert not res.unexpected_keys
+    assert torch.equal(m.points_grid, state_dict['points_grid'])
+    assert torch.allclose(m.regressor[1].init_pose, state_dict['regressor.1.init_pose'], atol=1e-7)
+    assert tuple(m.feature_extractor.backbone.pos_embed.shape) == (1, 193, 768)
+
+
+def test_cfg_object():
+    from whmr_amd.core.cfgs import CfgNode, cfg
+    assert cfg.MODEL.PyMAF.MLP_DIM == [256, 128, 64, 32] and cfg.IMG_RES.WIDTH == 256 and cfg.TRAIN.STAGE == 2
+    c = cfg.clone()
+    c.merge_from_list(['TRAIN.BATCH_SIZE', '8', 'MODEL.PyMAF.AUX_SUPV_ON', 'False'])
+    assert c.TRAIN.BATCH_SIZE == 8 and c.MODEL.PyMAF.AUX_SUPV_ON is False and cfg.TRAIN.BATCH_SIZE == 64
+    assert isinstance(CfgNode({'a': {'b': 1}}).a, CfgNode)
+    assert 'PyMAF' in c.dump()
+
+
+def test_gemm_wrapper_rejects_host_tensors():
+    from whmr_amd import _lib as L
+    with pytest.raises(RuntimeError):
+        L.gemm(torch.zeros(4, 64), torch.zeros(128, 64), torch.zeros(4, 128))
+
+
+def test_bench_sharding_two_ranks_gloo(tmp_path):
+    """N>1 path of bench.py (rank/world bookkeeping, barrier, max-over-ranks, whole-job aggregate) on CPU/gloo, world 2"""
+    code = r'''
+import os, sys, json, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+import bench
+dist.init_process_group('gloo')
+t = bench.reduce_max_time(0.5 + dist.get_rank(), dist, torch.device('cpu'))
+v = bench.aggregate_value(dist.get_world_size(), 64, 10, t)
+if dist.get_rank() == 0:
+    print(json.dumps({'t': t, 'v': v, 'shard': bench.shard_batch(256, dist.get_world_size(), 1)}))
+dist.destroy_process_group()
+''' % ROOT
+    script = tmp_path / 'w.py'
+    script.write_text(code)
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+                        '127.0.0.1', '--master-port', '29533', str(script)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    import json
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert out['t'] == 1.5 and abs(out['v'] - 2 * 64 * 10 / 1.5) < 1e-9 and out['shard'] == [128, 256]

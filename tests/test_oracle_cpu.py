@@ -1,0 +1,113 @@
+"""CPU suite: the oracle against the committed reference fixtures + analytic known answers (no GPU needed)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+
+def _rel(a, b):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def test_synthetic_weights_are_reproducible(state_dict):
+    """the fixtures were produced with these weights: any drift of the generator would silently unpin parity"""
+    g = np.load(os.path.join(GOLDEN, 'whmr_b2.npz'))
+    for k, s in zip(g['weight_keys'], g['weight_sums']):
+        assert abs(state_dict[str(k)].double().sum().item() - s) <= 1e-9 * max(1.0, abs(s)), k
+
+
+def test_oracle_whmr_forward_matches_reference_fixture(assets, state_dict):
+    from oracle import whmr as OW
+    g = np.load(os.path.join(GOLDEN, 'whmr_b2.npz'))
+    t = lambda k: torch.from_numpy(g['in_' + k])
+    taps = {}
+    with torch.no_grad():
+        out = OW.whmr_forward(state_dict, assets, t('x'), t('center'), t('scale'), t('bbox_height'), t('orig_shape'),
+                              t('bbox_info'), full_x=t('full_x'), taps=taps)
+    for k, v in out.items():
+        assert _rel(v, g['out_' + k]) < 1e-5, k
+    assert _rel(taps['s_feat0'], g['s_feat']) < 1e-5
+    assert _rel(taps['Tz'], g['Tz']) < 1e-5
+    for i in range(3):
+        assert _rel(taps['ref_feature'][i], g['ref_feature%d' % i]) < 1e-5
+        fm = taps['fmaps'][i]
+        assert _rel(fm.reshape(-1)[torch.from_numpy(g['fmap%d_idx' % i])], g['fmap%d_val' % i]) < 1e-5
+        assert abs(fm.double().sum().item() - g['fmap%d_sum' % i][0]) < 1e-3 * g['fmap%d_sum' % i][1]
+
+
+def test_oracle_vit224_matches_reference_fixture():
+    from oracle import synth
+    from oracle.vit import vit_forward
+    g = np.load(os.path.join(GOLDEN, 'vit224_b2.npz'))
+    with torch.no_grad():
+        out = vit_forward(synth.make_vit_state(1, (224, 224)), torch.from_numpy(g['x']))
+    assert out.shape == (2, 768, 14, 14)
+    assert _rel(out, g['s_feat']) < 1e-5
+
+
+def test_oracle_geometry_matches_reference_fixture():
+    from oracle import geometry as OG
+    g = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLDEN, 'geometry.npz')).items()}
+    assert _rel(OG.rotation_matrix_to_angle_axis(g['in_R']), g['out_aa']) < 1e-6
+    assert _rel(OG.batch_rodrigues(g['in_aa_in']), g['out_rod']) < 1e-6
+    assert _rel(OG.rot6d_to_rotmat(g['in_r6']), g['out_r6_to_R']) < 1e-6
+    assert _rel(OG.unbiased_gram_schmidt(g['in_m33']), g['out_gs']) < 1e-6
+    assert _rel(OG.projection(g['in_pts'], g['in_cam']), g['out_proj']) < 1e-6
+    assert _rel(OG.perspective_projection(g['in_pts'], torch.eye(3).unsqueeze(0), g['in_tr'], g['in_fl'], g['in_cc']),
+                g['out_persp']) < 1e-6
+
+
+def test_geometry_known_answers():
+    from oracle import geometry as OG
+    gen = torch.Generator().manual_seed(0)
+    R = OG.rot6d_to_rotmat(torch.randn(32, 6, generator=gen))
+    eye = torch.eye(3).expand(32, 3, 3)
+    assert torch.allclose(R @ R.transpose(1, 2), eye, atol=1e-5) and torch.allclose(torch.linalg.det(R), torch.ones(32), atol=1e-5)
+    G = OG.unbiased_gram_schmidt(torch.randn(4, 8, 3, 3, generator=gen)).reshape(-1, 3, 3)
+    assert torch.allclose(G @ G.transpose(1, 2), torch.eye(3).expand(32, 3, 3), atol=1e-5)
+    aa = torch.randn(32, 3, generator=gen) * 0.8
+    assert torch.allclose(OG.rotation_matrix_to_angle_axis(OG.batch_rodrigues(aa)), aa, atol=1e-4)   # round trip
+    assert torch.allclose(OG.batch_rodrigues(torch.zeros(1, 3)), torch.eye(3).unsqueeze(0), atol=1e-6)
+
+
+def test_smpl_known_answers(assets):
+    """pins the un-vendored SMPL arithmetic analytically: identity pose, rigid root rotation, single-joint rotation"""
+    from oracle import geometry as OG
+    from oracle import smpl as OS
+    s = assets['smpl']
+    betas = torch.tensor([[0.4, -0.7, 0.2, 0, 0, 0.1, 0, 0, -0.3, 0.5]])
+    eye = torch.eye(3).expand(1, 24, 3, 3).clone()
+    v_shaped = s['v_template'] + torch.einsum('l,mkl->mk', betas[0], s['shapedirs'])
+    v, j = OS.lbs(betas, eye, s)
+    J = s['J_regressor'] @ v_shaped
+    assert _rel(v[0], v_shaped) < 1e-6 and _rel(j[0], J) < 1e-6
+    R = OG.batch_rodrigues(torch.tensor([[0.2, 0.9, -0.4]]))[0]
+    rot = eye.clone()
+    rot[0, 0] = R
+    v, j = OS.lbs(betas, rot, s)
+    assert _rel(v[0], (v_shaped - J[0]) @ R.t() + J[0]) < 1e-5
+    assert _rel(j[0], (J - J[0]) @ R.t() + J[0]) < 1e-5
+    # rotate a leaf joint (23): joints not below it stay put
+    rot = eye.clone()
+    rot[0, 23] = R
+    _, j = OS.lbs(betas, rot, s)
+    assert _rel(j[0], J) < 1e-6
+    verts, j49 = OS.smpl_forward(betas, eye, s)
+    assert j49.shape == (1, 49, 3)
+    assert torch.equal(j49[0, 0], verts[0, 332])                      # 'OP Nose' = picked vertex 332
+    assert _rel(j49[0, 8], J[0]) < 1e-6                               # 'OP MidHip' = SMPL joint 0
+
+
+def test_maf_known_answers(state_dict):
+    """grid_sample at integer texel coordinates returns the exact texel; far outside the map -> zeros (padding)"""
+    from oracle import whmr as OW
+    fmap = torch.randn(1, 256, 5, 4, generator=torch.Generator().manual_seed(1))
+    pts = torch.tensor([[[-1.0, -1.0], [1.0, 1.0], [-1.0 + 2 * 2 / 3, -1.0 + 2 * 3 / 4], [3.0, 3.0]]])
+    _, pf = OW.maf_sampling(state_dict, pts, fmap, 'maf_extractor.0.')
+    assert torch.allclose(pf[0, :, 0], fmap[0, :, 0, 0], atol=1e-6) and torch.allclose(pf[0, :, 1], fmap[0, :, 4, 3], atol=1e-6)
+    assert torch.allclose(pf[0, :, 2], fmap[0, :, 3, 2], atol=1e-5)
+    assert (pf[0, :, 3] == 0).all()
