@@ -142,24 +142,46 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const whmr_gemm p) {
         __syncthreads();
     }
 
-    // ---- epilogue: bias -> activation -> residual -> store (C/D map: col = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5))
+    // ---- epilogue.  Accumulators (C/D map: col = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5)) get bias + activation in
+    // registers, are transposed through the now-idle LDS (two 64-row passes, fp32, rows padded to 132 dwords), and
+    // leave as whole 512-B rows: 16-B residual loads and 16-B (fp32) / 8-B (bf16) stores, fully coalesced.
+    constexpr int CLD = BN + 4;
+    float* sC = (float*)smem;                    // 64 x 132 fp32 = 33 KiB
     float bv[2];
-    int ncol[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        ncol[j] = n0 + wn * 64 + j * 32 + l31;
-        bv[j] = (p.bias && ncol[j] < p.N) ? p.bias[ncol[j]] : 0.f;
+        const int n = n0 + wn * 64 + j * 32 + l31;
+        bv[j] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
     }
     const float* __restrict__ res = p.residual;
+    bool spatial = false;
+    if constexpr (GATHER) spatial = (p.c_mode == 1);
+    const int c4 = (tid & 31) * 4;               // this thread's 4 consecutive columns in the tile
+    const int rsub = tid >> 5;                   // row within an 8-row group
+    const bool vec_ok = (n0 + BN <= p.N) && ((p.ldc & 3) == 0 || spatial) && (!res || (p.ldr & 3) == 0);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int pass = 0; pass < 2; ++pass) {
+        if (wm == pass) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float v = acc[i][j][r] + bv[j];
+                        if (ACT == 1) v = gelu_fast(v);
+                        if (ACT == 2) v = fmaxf(v, 0.f);
+                        sC[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * CLD + wn * 64 + j * 32 + l31] = v;
+                    }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int lr = it * 8 + rsub;                       // row inside this 64-row pass
+            const int m = m0 + pass * 64 + lr;
             if (m >= p.M) continue;
+            float4 v = *(const float4*)(sC + lr * CLD + c4);
             size_t crow;
-            bool spatial = false;
-            if constexpr (GATHER) spatial = (p.c_mode == 1);
             if (spatial) {
                 const int ohw = p.OH * p.OW;
                 const int b = m / ohw, rem = m - b * ohw;
@@ -168,19 +190,29 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const whmr_gemm p) {
             } else {
                 crow = (size_t)m * p.ldc;
             }
-            size_t rrow = 0;
-            if (res) rrow = (size_t)(p.res_row_mod > 0 ? m % p.res_row_mod : m) * p.ldr;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                if (ncol[j] >= p.N) continue;
-                float v = acc[i][j][r] + bv[j];
-                if (ACT == 1) v = gelu_erf(v);
-                if (ACT == 2) v = fmaxf(v, 0.f);
-                if (res) v += res[rrow + ncol[j]];
-                if (OUT_BF16) ((bf16_t*)p.C)[crow + ncol[j]] = f32_to_bf16(v);
-                else ((float*)p.C)[crow + ncol[j]] = v;
+            const int n = n0 + c4;
+            if (vec_ok) {
+                if (res) {
+                    const size_t rrow = (size_t)(p.res_row_mod > 0 ? m % p.res_row_mod : m) * p.ldr;
+                    const float4 rv = *(const float4*)(res + rrow + n);
+                    v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                }
+                if (OUT_BF16) *(uint2*)((bf16_t*)p.C + crow + n) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+                else *(float4*)((float*)p.C + crow + n) = v;
+            } else {
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+                size_t rrow = 0;
+                if (res) rrow = (size_t)(p.res_row_mod > 0 ? m % p.res_row_mod : m) * p.ldr;
+                for (int e = 0; e < 4; ++e) {
+                    if (n + e >= p.N) break;
+                    float o = vv[e];
+                    if (res) o += res[rrow + n + e];
+                    if (OUT_BF16) ((bf16_t*)p.C)[crow + n + e] = f32_to_bf16(o);
+                    else ((float*)p.C)[crow + n + e] = o;
+                }
             }
         }
+        __syncthreads();
     }
 }
 

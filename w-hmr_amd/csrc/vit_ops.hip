@@ -70,38 +70,32 @@ extern "C" int whmr_layernorm(const float* x, const float* gamma, const float* b
 
 // x: NCHW fp32 with arbitrary strides (the demo passes a sliced view, demo/tester.py:152) ->
 // cols [B*Hp*Wp, Cin*P*P] (k = ci*P*P + ky*P + kx, i.e. the flattened conv weight order), zero padded borders.
+// One thread per output element: consecutive lanes walk kx, so both the image reads and the patch-row writes coalesce.
 template <typename TOUT>
 __global__ __launch_bounds__(256) void patch_im2col_kernel(const float* __restrict__ x, TOUT* __restrict__ cols,
                                                            int B, int Cin, int H, int W, int P, int pad, int Hp, int Wp,
                                                            long sb, long sc, long sh, long sw) {
-    // one thread per (patch row m, ci, ky): copies P contiguous kx
-    const long total = (long)B * Hp * Wp * Cin * P;
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int ky = idx % P;
-    long t = idx / P;
-    const int ci = t % Cin;
-    const long m = t / Cin;
-    const int px = m % Wp;
-    const int py = (m / Wp) % Hp;
-    const int b = m / ((long)Wp * Hp);
-    const int iy = py * P - pad + ky;
-    TOUT* dst = cols + ((size_t)m * Cin + ci) * P * P + ky * P;
-    const bool rowok = (unsigned)iy < (unsigned)H;
-    const float* src = x + b * sb + ci * sc + (long)iy * sh;
-    for (int kx = 0; kx < P; ++kx) {
-        const int ix = px * P - pad + kx;
-        const float v = (rowok && (unsigned)ix < (unsigned)W) ? src[(long)ix * sw] : 0.f;
-        io<TOUT>::st(dst + kx, v);
+    const int K = Cin * P * P;
+    const long total = (long)B * Hp * Wp * K;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(idx % K);
+        const long m = idx / K;
+        const int kx = k % P, ky = (k / P) % P, ci = k / (P * P);
+        const int px = (int)(m % Wp), py = (int)((m / Wp) % Hp), b = (int)(m / ((long)Wp * Hp));
+        const int iy = py * P - pad + ky, ix = px * P - pad + kx;
+        float v = 0.f;
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = x[b * sb + ci * sc + (long)iy * sh + (long)ix * sw];
+        io<TOUT>::st(cols + idx, v);
     }
 }
 
 extern "C" int whmr_patch_im2col(const float* x, void* cols, int B, int Cin, int H, int W, int P, int pad,
                                  long sb, long sc, long sh, long sw, int out_bf16, void* stream) {
     const int Hp = (H + 2 * pad - P) / P + 1, Wp = (W + 2 * pad - P) / P + 1;
-    const long total = (long)B * Hp * Wp * Cin * P;
+    const long total = (long)B * Hp * Wp * Cin * P * P;
     if (total <= 0) return (int)hipErrorInvalidValue;
-    dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    const long nb = (total + 255) / 256;
+    dim3 grid((unsigned)(nb < 16384 ? nb : 16384)), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (out_bf16) hipLaunchKernelGGL(patch_im2col_kernel<bf16_t>, grid, block, 0, st, x, (bf16_t*)cols, B, Cin, H, W, P, pad, Hp, Wp, sb, sc, sh, sw);
     else hipLaunchKernelGGL(patch_im2col_kernel<float>, grid, block, 0, st, x, (float*)cols, B, Cin, H, W, P, pad, Hp, Wp, sb, sc, sh, sw);
