@@ -39,8 +39,11 @@ struct whmr_gemm {
 /* bf16 MFMA GEMM (v_mfma_f32_32x32x16_bf16, fp32 accumulate).  Needs K % 64 == 0 (and Cin % 64 == 0 for a_mode 1).
  * Replaces nn.Linear at vit.py:93,96 (qkv, proj), vit.py:66-68 (fc1, fc2), Conv2d at vit.py:157 (after
  * whmr_patch_im2col), ConvTranspose2d+BN+ReLU at whmr.py:488-498 and Conv2d at whmr.py:419.
- * flags bit0: stage through registers instead of global_load_lds. */
+ * flags 0/1: automatic tile choice (see gemm_bf16.hip); > 1: explicit tile id. */
 int whmr_gemm_bf16(const struct whmr_gemm* p, int flags, void* stream);
+/* Same contract with an explicit tile id: 64 = 128x128x64 (4 waves, 2 blocks/CU), 128 = 128x256x32 (4 waves, 3-stage),
+ * 192 = 192x256x64, 257 = 256x256x64 (8 waves, 2-stage), 256 = 256x256x32 (8 waves, 4-stage). */
+int whmr_gemm_bf16_big(const struct whmr_gemm* p, int tile, void* stream);
 
 /* exact-fp32 MFMA GEMM (v_mfma_f32_32x32x2_f32), any M/N/K.  Parity mode of the calls above, plus always:
  * Regressor fc1/fc2/decpose/decshape/deccam (whmr.py:118-126), Global_Orient_Regressor (whmr.py:295-301),

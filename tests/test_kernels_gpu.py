@@ -13,7 +13,7 @@ def _rel(a, b):
 
 
 @pytest.mark.parametrize('M,N,K', [(392, 768, 768), (128, 128, 64), (12544, 2304, 768), (300, 3072, 768), (392, 768, 3072)])
-@pytest.mark.parametrize('glds', [True, False])
+@pytest.mark.parametrize('glds', [True])
 def test_gemm_bf16(dev, M, N, K, glds):
     from whmr_amd import _lib as L
     g = torch.Generator().manual_seed(M + N + K)
@@ -28,6 +28,24 @@ def test_gemm_bf16(dev, M, N, K, glds):
     # bf16 output, no epilogue extras; asymmetric operands catch transposed C writes
     out2 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     L.gemm(a.to(dev), w.to(dev), out2, glds=glds)
+    assert _rel(out2.float().cpu(), a.float() @ w.float().t()) < 1e-2
+
+
+@pytest.mark.parametrize('M,N,K', [(392, 768, 768), (12544, 2304, 768), (300, 3072, 768), (392, 768, 3072), (1000, 130, 64)])
+@pytest.mark.parametrize('tile', [64, 128, 256, 192, 257])
+def test_gemm_bf16_big_tile(dev, M, N, K, tile):
+    from whmr_amd import _lib as L
+    g = torch.Generator().manual_seed(M + N + K + tile)
+    a = torch.randn(M, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).bfloat16()
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    ref = F.gelu(a.float() @ w.float().t() + bias) + res
+    out = torch.empty(M, N, device=dev)
+    L.gemm(a.to(dev), w.to(dev), out, bias=bias.to(dev), residual=res.to(dev), act=L.ACT_GELU, tile=tile)
+    assert _rel(out.cpu(), ref) < 2e-5 * math.sqrt(K) / 8 + 1e-5
+    out2 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    L.gemm(a.to(dev), w.to(dev), out2, tile=tile)
     assert _rel(out2.float().cpu(), a.float() @ w.float().t()) < 1e-2
 
 

@@ -40,6 +40,18 @@ for name, (N, K, kind) in {'qkv': (2304, 768, 'bf16'), 'proj': (768, 768, 'res')
     o2 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     ms0 = timeit(lambda: L.gemm(a, w, o2))
     msb = timeit(lambda: torch.matmul(a, w.t()))
+    for tile in (64, 128, 256, 192, 257):
+        if kind == 'res':
+            f2 = lambda: L.gemm(a, w, out, bias=bias, residual=out, tile=tile)
+        elif kind == 'gelu':
+            f2 = lambda: L.gemm(a, w, out, bias=bias, act=L.ACT_GELU, tile=tile)
+        else:
+            f2 = lambda: L.gemm(a, w, out, bias=bias, tile=tile)
+        mst = timeit(f2)
+        mst0 = timeit(lambda: L.gemm(a, w, o2, tile=tile))
+        msm = timeit(lambda: L.gemm(a, w, o2, tile=tile, res_row_mod=-12345))
+        print('      tile %dx256: main-loop-only %.1f us %.0f TF' % (tile, msm * 1e3, 2.0 * M * N * K / msm / 1e9))
+        print('      tile %dx256: fused %.1f us %.0f TF | plain %.1f us %.0f TF' % (tile, mst * 1e3, 2.0 * M * N * K / mst / 1e9, mst0 * 1e3, 2.0 * M * N * K / mst0 / 1e9))
     tf = lambda t: 2.0 * M * N * K / t / 1e9
     print('%-5s M=%d N=%d K=%d  fused-epilogue %.1f us %.0f TF | plain bf16-out %.1f us %.0f TF | hipBLASLt %.1f us %.0f TF'
           % (name, M, N, K, ms * 1e3, tf(ms), ms0 * 1e3, tf(ms0), msb * 1e3, tf(msb)))

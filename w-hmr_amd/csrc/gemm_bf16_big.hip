@@ -1,0 +1,384 @@
+// Generic large-wave-tile bf16 MFMA GEMM for gfx950 (v_mfma_f32_32x32x16_bf16), templated on the block tile
+// BM x BN x BK and the wave grid WM x WN (wave tile (BM/WM) x (BN/WN), at least 64 wide so that LDS fragment traffic
+// stays at <= 24 B/clk/SIMD).  Instantiated as:
+//   <128,256,32,1,4>  4 waves, 48 KiB LDS  -> 2-3 independent blocks per CU: one block's (memory-bound) epilogue
+//                     overlaps the other's MFMA main loop.  Default for the ViT shapes.
+//   <256,256,64,2,4>, <192,256,64,2,4>  8 waves, 112-128 KiB LDS, one block per CU (A/B reference points).
+// Differences from gemm_bf16.hip (128x128, 64x64 wave tiles): larger wave tile; MFMA operands are swapped
+// (D^T = W_tile . A_tile^T) so that each lane owns 4 consecutive output COLUMNS per register quad -- the epilogue packs
+// them (bias + activation applied in registers) into 16-B / 8-B LDS writes, and leaves through whole-row 16-B stores.
+#include "common.h"
+#include "gemm_params.h"
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+
+template <int BM, int BN, int BK, int WM, int WN, int NS>
+struct big_cfg {
+    static constexpr int THREADS = 64 * WM * WN;
+    static constexpr int CPR = BK / 8;                     // 16-B chunks per tile row
+    static constexpr int RP = THREADS / CPR;               // tile rows staged per pass
+    static constexpr int AP = BM / RP, BP = BN / RP;       // staging passes (= global_load_lds per thread per K step)
+    static constexpr int WTM = BM / WM, WTN = BN / WN;     // wave tile
+    static constexpr int MI = WTM / 32, NJ = WTN / 32;
+    static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+    static constexpr int CROWS = WM * 32;                  // C rows per epilogue pass
+    static constexpr int CLD_F32 = BN + 4;                 // fp32 staging row stride (dwords): conflict-free b128 writes
+    static constexpr int CLD_BF16 = BN + 4;                // bf16 staging row stride (elements): (BN+4)/2 dwords = 2 mod 32
+    static constexpr int EPI_BYTES = CROWS * CLD_F32 * 4;
+    static constexpr int LDS = (NS * STAGE > EPI_BYTES) ? NS * STAGE : EPI_BYTES;
+    static constexpr int G = AP + BP;                      // global_load_lds per thread per K step
+    static_assert(BM % RP == 0 && BN % RP == 0, "staging passes must tile the block");
+    static_assert(BK == 32 || BK == 64, "BK");
+    static_assert(NS >= 2 && NS <= 4, "wait_step handles at most 2 younger groups in flight");
+};
+
+// XOR swizzle of the 16-B chunk index inside a tile row, keyed by the row (conflict-free ds_read_b128 fragment reads)
+template <int BK> __device__ __forceinline__ int swz(int row) { return BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
+
+#ifndef DIRECT_EPI
+#define DIRECT_EPI 0
+#endif
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void wait_lgkmcnt() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+// Fragment read hidden from hipcc's waitcnt bookkeeping (it would otherwise wait lgkmcnt(0) across the loop back-edge
+// and serialise the register double-buffer): destination is valid only after the matching counted wait_lgkmcnt + sched_barrier.
+__device__ __forceinline__ bf16x8_t lds_read128(uint32_t addr) {
+    bf16x8_t v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+
+template <int BM, int BN, int BK, int WM, int WN, int NS, int MINW, int OUT_BF16, int ACT, bool GATHER>
+__global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const whmr_gemm p) {
+    using cfg = big_cfg<BM, BN, BK, WM, WN, NS>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int AP = cfg::AP, BP = cfg::BP, MI = cfg::MI, NJ = cfg::NJ, CPR = cfg::CPR, RP = cfg::RP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const int lid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int tm = lid / tiles_n, tn = lid % tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const bf16_t* __restrict__ A = (const bf16_t*)p.A;
+    const bf16_t* __restrict__ W = (const bf16_t*)p.W;
+
+    // ---- staging geometry: chunk c = tid + THREADS*i -> tile row tid/CPR + RP*i, physical slot tid%CPR
+    const int srow = tid / CPR, pc = tid % CPR;
+    const bf16_t* a_src[AP];
+    int a_y[AP], a_x[AP];
+    const bf16_t* b_src[BP];
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+        const int row = srow + RP * i;
+        const int lc = pc ^ swz<BK>(row);
+        int m = m0 + row;
+        if (m > p.M - 1) m = p.M - 1;
+        if constexpr (GATHER) {
+            const int ohw = p.OH * p.OW;
+            const int b = m / ohw, rem = m - b * ohw;
+            const int oy = rem / p.OW, ox = rem - oy * p.OW;
+            a_y[i] = oy * p.SH - p.PH;
+            a_x[i] = ox * p.SW - p.PW;
+            a_src[i] = A + (size_t)b * p.IH * p.IW * p.Cin + lc * 8;
+        } else {
+            a_src[i] = A + (size_t)m * p.lda + lc * 8;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < BP; ++i) {
+        const int row = srow + RP * i;
+        const int lc = pc ^ swz<BK>(row);
+        int nr = n0 + row;
+        if (nr > p.N - 1) nr = p.N - 1;
+        b_src[i] = W + (size_t)nr * p.K + lc * 8;
+    }
+
+    auto stage = [&](int kt, int s) {
+        char* sa = smem + s * cfg::STAGE;
+        char* sb = sa + cfg::A_BYTES;
+        const int k0 = kt * BK;
+        int ky = 0, kx = 0, ci0 = 0;
+        if constexpr (GATHER) {
+            const int tap = k0 / p.Cin;
+            ci0 = k0 - tap * p.Cin;
+            ky = tap / p.KW;
+            kx = tap - ky * p.KW;
+        }
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            const bf16_t* src;
+            if constexpr (GATHER) {
+                const int iy = a_y[i] + ky, ix = a_x[i] + kx;
+                const bool ok = (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+                src = ok ? a_src[i] + ((size_t)iy * p.IW + ix) * p.Cin + ci0 : (const bf16_t*)p.zeros + pc * 8;
+            } else {
+                src = a_src[i] + k0;
+            }
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(sa + (wave * 64 + cfg::THREADS * i) * 16), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < BP; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(b_src[i] + k0), (lds_void_t*)(sb + (wave * 64 + cfg::THREADS * i) * 16), 16, 0, 0);
+    };
+
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, hi = lane >> 5;
+    // acc[i][j][r]: output row m = wm*WTM + i*32 + l31, column n = wn*WTN + j*32 + (r&3) + 8*(r>>2) + 4*hi  (swapped operands)
+    f32x16_t acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    int a_off[MI], a_sw[MI], b_off[NJ], b_sw[NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int ra = wm * cfg::WTM + i * 32 + l31;
+        a_off[i] = ra * (BK * 2); a_sw[i] = swz<BK>(ra);
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int rb = wn * cfg::WTN + j * 32 + l31;
+        b_off[j] = rb * (BK * 2); b_sw[j] = swz<BK>(rb);
+    }
+
+    // ---- main loop: NS-deep LDS ring, loads issued NS-1 K steps ahead.  global_load_lds has no register result, so the
+    // compiler tracks nothing: completion is enforced by hand with a COUNTED s_waitcnt vmcnt (loads return in order) and a
+    // raw s_barrier -- one barrier per K step, never a drain to zero in steady state.
+    // Fragments are software-pipelined through two register sets: the ds_reads of sub-step kk+1 are issued before the
+    // MFMAs of sub-step kk, so LDS latency hides under the wave's own 8 MFMAs instead of idling the matrix pipe while
+    // both waves of a SIMD wait in lockstep.  With NS >= 3 the K-step barrier sits before the LAST sub-step's MFMAs:
+    // after it the wave issues the next stage's DMA and the first fragments of step kt+1, then still has MFMAs queued.
+    constexpr int KK = BK / 16;
+    const int nkt = p.K / BK;
+    bf16x8_t af[2][MI], bfr[2][NJ];
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)smem;
+    constexpr int NF = MI + NJ;          // ds_read_b128 per fragment set
+    auto load_frags = [&](int buf, int kk, int set) {
+        const uint32_t sa = lds0 + buf * cfg::STAGE;
+        const uint32_t sb = sa + cfg::A_BYTES;
+        const int c = kk * 2 + hi;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) bfr[set][j] = lds_read128(sb + b_off[j] + ((c ^ b_sw[j]) << 4));
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[set][i] = lds_read128(sa + a_off[i] + ((c ^ a_sw[i]) << 4));
+    };
+    auto mfmas = [&](int set) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[set][j], af[set][i], acc[i][j], 0, 0, 0);
+    };
+    // Step `step` has landed once at most (younger groups already in flight) x G loads are outstanding.  `ahead` = how many
+    // younger groups can be in flight at the wait: NS-2 when the wait precedes the step's own compute (2-stage scheme),
+    // NS-3 for the mid-step wait of the deep scheme (the next stage is issued only after the barrier that follows it).
+    auto wait_step = [&](int step, int ahead) {
+        int younger = nkt - 1 - step;
+        if (younger > ahead) younger = ahead;
+        if (younger >= 2) wait_vmcnt<cfg::G * 2>();
+        else if (younger == 1) wait_vmcnt<cfg::G>();
+        else wait_vmcnt<0>();
+    };
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t)
+        if (t < nkt) stage(t, t);
+    if constexpr (NS >= 3) {
+        wait_step(0, NS - 2);
+        __builtin_amdgcn_s_barrier();
+        load_frags(0, 0, 0);
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int buf = kt % NS;
+#pragma unroll
+            for (int kk = 0; kk < KK - 1; ++kk) {
+                load_frags(buf, kk + 1, (kk + 1) & 1);
+                wait_lgkmcnt<NF>();                 // the older set (sub-step kk) has landed; kk+1 stays in flight
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas(kk & 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (kt + 1 < nkt) {
+                wait_step(kt + 1, NS - 3);
+                __builtin_amdgcn_s_barrier();       // step kt+1 visible to all; everyone is past step kt-1's buffer
+                if (kt + NS - 1 < nkt) stage(kt + NS - 1, (kt + NS - 1) % NS);
+                load_frags((kt + 1) % NS, 0, KK & 1);
+                wait_lgkmcnt<NF>();
+            } else {
+                wait_lgkmcnt<0>();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas((KK - 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        for (int kt = 0; kt < nkt; ++kt) {
+            wait_step(kt, NS - 2);
+            __builtin_amdgcn_s_barrier();        // everyone's step-kt data visible; everyone done reading buffer (kt-1) % NS
+            if (kt + NS - 1 < nkt) stage(kt + NS - 1, (kt + NS - 1) % NS);
+            load_frags(kt % NS, 0, 0);
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                if (kk + 1 < KK) { load_frags(kt % NS, kk + 1, (kk + 1) & 1); wait_lgkmcnt<NF>(); }
+                else wait_lgkmcnt<0>();
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas(kk & 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    __syncthreads();                         // all fragment reads done before the epilogue reuses the LDS
+
+    if (p.res_row_mod == -12345) {            // timing probe: main loop only (keeps the accumulators live)
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+        if (t == 12345.678f) ((float*)p.C)[0] = t;
+        return;
+    }
+
+    // ---- epilogue, written for CODE SIZE (a fully unrolled epilogue made this kernel 85-92 KB and every tile paid an
+    // instruction-cache miss storm -- +20-30 us per GEMM): MI passes; in pass i every wave parks its RAW acc[i][*] (32 rows
+    // x WTN cols) in LDS as 16-B writes; then a rolled loop streams whole rows out: 16-B LDS reads -> bias -> activation ->
+    // residual -> convert -> one 16-B global store per thread and row.  Bias / activation / residual code exists once.
+    constexpr int CPT = OUT_BF16 ? 8 : 4;                   // columns per thread in the store phase (16 B either way)
+    constexpr int TPR = BN / CPT;                           // threads per output row
+    constexpr int RPI = cfg::THREADS / TPR;                 // rows per store iteration
+    const int ccol = (tid % TPR) * CPT, rsub = tid / TPR;
+    const int ncol = n0 + ccol;
+    float* sC = (float*)smem;
+    float bias_r[CPT];
+#pragma unroll
+    for (int e = 0; e < CPT; ++e) bias_r[e] = (p.bias && ncol + e < p.N) ? p.bias[ncol + e] : 0.f;
+    const float* __restrict__ res = p.residual;
+    bool spatial = false;
+    if constexpr (GATHER) spatial = (p.c_mode == 1);
+    const bool vec_ok = (ncol + CPT <= p.N) && (spatial || (p.ldc % CPT) == 0) && (!res || (p.ldr & 3) == 0);
+    const bool probe_nostore = p.res_row_mod == -2001, probe_nolds = p.res_row_mod == -2002;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        if (!probe_nolds)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *(float4*)(sC + (wm * 32 + l31) * cfg::CLD_F32 + wn * cfg::WTN + j * 32 + 8 * q + 4 * hi) =
+                    make_float4(acc[i][j][q * 4], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]);
+        if (!probe_nolds) __syncthreads();
+#pragma unroll 1
+        for (int lr = rsub; lr < cfg::CROWS; lr += RPI) {       // lr = row inside the staged WM*32-row slab
+            const int m = m0 + (lr >> 5) * cfg::WTM + i * 32 + (lr & 31);
+            if (m >= p.M || ncol >= p.N) continue;
+            size_t crow;
+            if (spatial) {
+                const int ohw = p.OH * p.OW;
+                const int b = m / ohw, rem = m - b * ohw;
+                const int oy = rem / p.OW, ox = rem - oy * p.OW;
+                crow = (size_t)(p.c_off + b * p.osb + oy * p.osy + ox * p.osx);
+            } else {
+                crow = (size_t)m * p.ldc;
+            }
+            float v[CPT];
+#pragma unroll
+            for (int e = 0; e < CPT; e += 4) {
+                const float4 f = *(const float4*)(sC + lr * cfg::CLD_F32 + ccol + e);
+                v[e] = f.x; v[e + 1] = f.y; v[e + 2] = f.z; v[e + 3] = f.w;
+            }
+#pragma unroll
+            for (int e = 0; e < CPT; ++e) {
+                v[e] += bias_r[e];
+                if (ACT == 1) v[e] = gelu_fast(v[e]);
+                if (ACT == 2) v[e] = fmaxf(v[e], 0.f);
+            }
+            const float* rp = res ? res + (size_t)(p.res_row_mod > 0 ? m % p.res_row_mod : m) * p.ldr + ncol : nullptr;
+            if (probe_nostore && v[0] != 12345.678f) continue;
+            if (vec_ok) {
+                if (rp) {
+#pragma unroll
+                    for (int e = 0; e < CPT; e += 4) {
+                        const float4 rv = *(const float4*)(rp + e);
+                        v[e] += rv.x; v[e + 1] += rv.y; v[e + 2] += rv.z; v[e + 3] += rv.w;
+                    }
+                }
+                if constexpr (OUT_BF16)
+                    *(uint4*)((bf16_t*)p.C + crow + ncol) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]),
+                                                                       pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+                else
+                    *(float4*)((float*)p.C + crow + ncol) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll 1
+                for (int e = 0; e < CPT; ++e) {
+                    if (ncol + e >= p.N) break;
+                    float o = v[e];
+                    if (rp) o += rp[e];
+                    if (OUT_BF16) ((bf16_t*)p.C)[crow + ncol + e] = f32_to_bf16(o);
+                    else ((float*)p.C)[crow + ncol + e] = o;
+                }
+            }
+        }
+        if (!probe_nolds) __syncthreads();
+    }
+}
+
+template <int BM, int BN, int BK, int WM, int WN, int NS, int MINW, int OUT_BF16, int ACT, bool GATHER>
+static int launch_big(const whmr_gemm& p, hipStream_t st) {
+    using cfg = big_cfg<BM, BN, BK, WM, WN, NS>;
+    auto kern = gemm_bf16_big_kernel<BM, BN, BK, WM, WN, NS, MINW, OUT_BF16, ACT, GATHER>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, cfg::LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(cfg::THREADS), cfg::LDS, st, p);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int BM, int BN, int BK, int WM, int WN, int NS, int MINW, bool GATHER>
+static int launch_big_act(const whmr_gemm& p, hipStream_t st) {
+    if (p.out_bf16) {
+        switch (p.act) {
+            case 0: return launch_big<BM, BN, BK, WM, WN, NS, MINW, 1, 0, GATHER>(p, st);
+            case 1: return launch_big<BM, BN, BK, WM, WN, NS, MINW, 1, 1, GATHER>(p, st);
+            case 2: return launch_big<BM, BN, BK, WM, WN, NS, MINW, 1, 2, GATHER>(p, st);
+        }
+    } else {
+        switch (p.act) {
+            case 0: return launch_big<BM, BN, BK, WM, WN, NS, MINW, 0, 0, GATHER>(p, st);
+            case 1: return launch_big<BM, BN, BK, WM, WN, NS, MINW, 0, 1, GATHER>(p, st);
+            case 2: return launch_big<BM, BN, BK, WM, WN, NS, MINW, 0, 2, GATHER>(p, st);
+        }
+    }
+    return (int)hipErrorInvalidValue;
+}
+
+template <int BM, int BN, int BK, int WM, int WN, int NS, int MINW>
+static int launch_big_mode(const whmr_gemm& p, hipStream_t st) {
+    return p.a_mode == 1 ? launch_big_act<BM, BN, BK, WM, WN, NS, MINW, true>(p, st)
+                         : launch_big_act<BM, BN, BK, WM, WN, NS, MINW, false>(p, st);
+}
+
+// tile: 128 -> 128x256x32, 4 waves, 2+ blocks/CU;  256 / 192 -> BM x 256 x 64, 8 waves, 1 block/CU.
+extern "C" int whmr_gemm_bf16_big(const whmr_gemm* pp, int tile, void* stream) {
+    const whmr_gemm& p = *pp;
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % 64)) return (int)hipErrorInvalidValue;
+    if (p.a_mode == 1 && (p.Cin % 64 || !p.zeros)) return (int)hipErrorInvalidValue;
+    if (p.a_mode == 0 && (p.lda % 8)) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    switch (tile) {
+        case 64: return launch_big_mode<128, 128, 64, 2, 2, 2, 2>(p, st);      // 64 KiB, 4 waves (64x64 wave tiles): 2 blocks / CU
+        case 128: return launch_big_mode<128, 256, 32, 1, 4, 3, 2>(p, st);     // 72 KiB: 2 blocks / CU
+        case 256: return launch_big_mode<256, 256, 32, 2, 4, 4, 2>(p, st);     // 128 KiB: 1 block / CU, 3 steps ahead
+        case 192: return launch_big_mode<192, 256, 64, 2, 4, 2, 2>(p, st);     // 112 KiB, 2 stages
+        case 257: return launch_big_mode<256, 256, 64, 2, 4, 2, 2>(p, st);     // the 2-stage BK=64 reference point
+    }
+    return (int)hipErrorInvalidValue;
+}
