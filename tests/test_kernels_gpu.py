@@ -24,7 +24,8 @@ def test_gemm_bf16(dev, M, N, K, glds):
     ref = F.gelu(a.float() @ w.float().t() + bias) + res
     out = torch.empty(M, N, device=dev)
     L.gemm(a.to(dev), w.to(dev), out, bias=bias.to(dev), residual=res.to(dev), act=L.ACT_GELU, glds=glds)
-    assert _rel(out.cpu(), ref) < 2e-5 * math.sqrt(K) / 8 + 1e-5
+    # the bf16-path GELU is the tanh form (|err| <= 4.8e-4 abs vs erf, below bf16 output resolution; common.h)
+    assert _rel(out.cpu(), ref) < 2e-4
     # bf16 output, no epilogue extras; asymmetric operands catch transposed C writes
     out2 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     L.gemm(a.to(dev), w.to(dev), out2, glds=glds)
@@ -43,7 +44,10 @@ def test_gemm_bf16_big_tile(dev, M, N, K, tile):
     ref = F.gelu(a.float() @ w.float().t() + bias) + res
     out = torch.empty(M, N, device=dev)
     L.gemm(a.to(dev), w.to(dev), out, bias=bias.to(dev), residual=res.to(dev), act=L.ACT_GELU, tile=tile)
-    assert _rel(out.cpu(), ref) < 2e-5 * math.sqrt(K) / 8 + 1e-5
+    assert _rel(out.cpu(), ref) < 2e-4
+    out1 = torch.empty(M, N, device=dev)
+    L.gemm(a.to(dev), w.to(dev), out1, bias=bias.to(dev), residual=res.to(dev), tile=tile)       # exact epilogue ops only
+    assert _rel(out1.cpu(), a.float() @ w.float().t() + bias + res) < 2e-5 * math.sqrt(K) / 8 + 1e-5
     out2 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     L.gemm(a.to(dev), w.to(dev), out2, tile=tile)
     assert _rel(out2.float().cpu(), a.float() @ w.float().t()) < 1e-2

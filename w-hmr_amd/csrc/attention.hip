@@ -14,7 +14,8 @@
 
 template <int NKT>
 __global__ __launch_bounds__(NKT * 64) void attention_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                                   int N, int H, float scale) {
+                                                                   int N, int H, float scale_in) {
+    float scale = scale_in;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NPAD = NKT * 32;
     constexpr int VS = NPAD + 4;                 // Vt row stride (elements): dword stride = 2*odd -> conflict-free b64 reads
@@ -26,13 +27,17 @@ __global__ __launch_bounds__(NKT * 64) void attention_bf16_kernel(const bf16_t* 
     const int C = H * 64, ld = 3 * C;
     const bf16_t* base = qkv + (size_t)b * N * ld + h * 64;
 
+    int probe = 0;
+    if (scale < 0.f) { probe = (int)(-scale); scale = 0.125f; }
     // ---- stage K (swizzled) and V (transposed) into LDS
+    if (probe != 1)
     for (int c = tid; c < NPAD * 8; c += NKT * 64) {
         const int key = c >> 3, ch = c & 7;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (key < N) v = *(const uint4*)(base + (size_t)key * ld + C + ch * 8);
         *(uint4*)(Ks + key * 128 + ((ch ^ ((key >> 1) & 7)) << 4)) = v;
     }
+    if (probe != 1)
     for (int c = tid; c < (NPAD / 2) * 8; c += NKT * 64) {
         const int kp = c >> 3, ch = c & 7;
         const int k0 = 2 * kp;
@@ -57,6 +62,7 @@ __global__ __launch_bounds__(NKT * 64) void attention_bf16_kernel(const bf16_t* 
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const bf16x8_t*)(base + (size_t)qrow * ld + kk * 16 + hi * 8);
     __syncthreads();
+    if (probe == 2) { if (qf[0][0] == 12345) out[0] = 1; return; }
 
     // ---- S^T = K . Q^T : acc[kt][r] = S[q = l31][key = kt*32 + (r&3) + 8*(r>>2) + 4*hi]
     f32x16_t s[NKT];

@@ -13,17 +13,17 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
-// round-to-nearest-even, NaN preserved (same rule as torch's float->bfloat16 cast)
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
+// fp32 -> bf16, round-to-nearest-even with NaN preserved: the native __bf16 conversion lowers to the gfx950 hardware
+// instruction (v_cvt_pk_bf16_f32, two values per issue) -- same rounding rule as torch's float -> bfloat16 cast.
+typedef __bf16 bf16x2_native_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_native_t __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    const bf16x2_native_t v = __builtin_convertvector((f32x2_native_t){lo, hi}, bf16x2_native_t);
+    return __builtin_bit_cast(uint32_t, v);
 }
+
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
