@@ -64,23 +64,27 @@ __global__ __launch_bounds__(NKT * 64) void attention_bf16_kernel(const bf16_t* 
     __syncthreads();
     if (probe == 2) { if (qf[0][0] == 12345) out[0] = 1; return; }
 
-    // ---- S^T = K . Q^T : acc[kt][r] = S[q = l31][key = kt*32 + (r&3) + 8*(r>>2) + 4*hi]
+    // ---- S^T = K . Q^T : s[kt][r] = S[q = l31][key = kt*32 + (r&3) + 8*(r>>2) + 4*hi].  kk is the OUTER loop so that
+    // consecutive MFMAs hit different accumulators (7 independent chains) instead of one dependent chain per tile.
     f32x16_t s[NKT];
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
+    for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
-        const int key = kt * 32 + l31;
-        const char* krow = Ks + key * 128;
-        const int sw = (key >> 1) & 7;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const bf16x8_t kf = *(const bf16x8_t*)(krow + (((kk * 2 + hi) ^ sw) << 4));
-            s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[kt], 0, 0, 0);
+    for (int kk = 0; kk < 4; ++kk) {
+        bf16x8_t kf[NKT];
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            const int key = kt * 32 + l31;
+            kf[kt] = *(const bf16x8_t*)(Ks + key * 128 + (((kk * 2 + hi) ^ ((key >> 1) & 7)) << 4));
         }
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt], qf[kk], s[kt], 0, 0, 0);
     }
 
-    // ---- softmax over keys (in-lane over kt, r; one exchange with the other half-wave)
+    // ---- softmax over keys (in-lane over kt, r; one exchange with the other half-wave).  Only the last key tile can
+    // hold padded keys; the scale is folded into the exp2 argument (scale > 0, so the max commutes with it).
     const float sc = scale * LOG2E;
     float mx = -INFINITY;
 #pragma unroll
@@ -88,17 +92,16 @@ __global__ __launch_bounds__(NKT * 64) void attention_bf16_kernel(const bf16_t* 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            const float t = key < N ? s[kt][r] * sc : -INFINITY;
-            s[kt][r] = t;
-            mx = fmaxf(mx, t);
+            if (kt == NKT - 1 && key >= N) s[kt][r] = -INFINITY;
+            mx = fmaxf(mx, s[kt][r]);
         }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * sc;
     float sum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float e = __builtin_amdgcn_exp2f(s[kt][r] - mx);
+            const float e = __builtin_amdgcn_exp2f(fmaf(s[kt][r], sc, -mx));
             s[kt][r] = e;
             sum += e;
         }
