@@ -40,7 +40,7 @@ for name, (N, K, kind) in {'qkv': (2304, 768, 'bf16'), 'proj': (768, 768, 'res')
     o2 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     ms0 = timeit(lambda: L.gemm(a, w, o2))
     msb = timeit(lambda: torch.matmul(a, w.t()))
-    for tile in (64, 128, 256, 192, 257):
+    for tile in (64, 192, 257, 320):
         if kind == 'res':
             f2 = lambda: L.gemm(a, w, out, bias=bias, residual=out, tile=tile)
         elif kind == 'gelu':

@@ -20,7 +20,7 @@ extern "C" int whmr_gemm_bf16(const whmr_gemm* pp, int flags, void* stream) {
     const whmr_gemm& p = *pp;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % 64)) return (int)hipErrorInvalidValue;
     if (flags > 1) return whmr_gemm_bf16_big(pp, flags, stream);          // explicit tile id (A/B tests)
-    static const tile_cfg cands[] = {{257, 256, 256, 1}, {192, 192, 256, 1}, {128, 128, 256, 2}, {64, 128, 128, 2}};
+    static const tile_cfg cands[] = {{320, 320, 256, 1}, {257, 256, 256, 1}, {192, 192, 256, 1}, {128, 128, 256, 2}, {64, 128, 128, 2}};
     long best_cost = -1;
     int best = 64;
     for (const tile_cfg& c : cands) {

@@ -378,7 +378,8 @@ extern "C" int whmr_gemm_bf16_big(const whmr_gemm* pp, int tile, void* stream) {
         case 128: return launch_big_mode<128, 256, 32, 1, 4, 3, 2>(p, st);     // 72 KiB: 2 blocks / CU
         case 256: return launch_big_mode<256, 256, 32, 2, 4, 4, 2>(p, st);     // 128 KiB: 1 block / CU, 3 steps ahead
         case 192: return launch_big_mode<192, 256, 64, 2, 4, 2, 2>(p, st);     // 112 KiB, 2 stages
-        case 257: return launch_big_mode<256, 256, 64, 2, 4, 2, 2>(p, st);     // the 2-stage BK=64 reference point
+        case 257: return launch_big_mode<256, 256, 64, 2, 4, 2, 2>(p, st);     // 128 KiB, 2 stages
+        case 320: return launch_big_mode<320, 256, 64, 2, 4, 2, 2>(p, st);     // 144 KiB, 2 stages, 160x64 wave tiles
     }
     return (int)hipErrorInvalidValue;
 }
