@@ -34,6 +34,8 @@ struct whmr_gemm {
     int32_t IH, IW, Cin, OH, OW, KW, SH, SW, PH, PW;
     int32_t c_mode;
     int64_t c_off, osb, osy, osx;
+    void* workspace;        /* optional split-K scratch (fp32 kernel): splits*M*N floats; null = no split */
+    int64_t workspace_bytes;
 };
 
 /* bf16 MFMA GEMM (v_mfma_f32_32x32x16_bf16, fp32 accumulate).  Needs K % 64 == 0 (and Cin % 64 == 0 for a_mode 1).
@@ -106,8 +108,10 @@ int whmr_smpl_skin(const struct whmr_smpl_model* m, const float* betas, const fl
                    float* verts, void* stream);
 /* joints49 [B,49,3] (24 posed + 21 vertex picks + 9 regressed, JOINT_MAP), optional smpl_joints45 [B,45,3]
  * (whmr.py:186-187) and markers [B,n_markers,3] (whmr.py:184). */
+/* scratch: >= B*33*3 floats of workspace.  When smpl_joints45 is requested, J_regressor_extra and J_regressor must be one
+ * contiguous [33,6890] buffer (extra rows first). */
 int whmr_smpl_joints(const struct whmr_smpl_model* m, const float* verts, const float* posed_joints, int B,
-                     float* joints49, float* smpl_joints45, float* markers, void* stream);
+                     float* joints49, float* smpl_joints45, float* markers, float* scratch, void* stream);
 
 /* ---- MAF sampler: models/maf_extractor.py:75-143 ------------------------------------------------------------------ */
 struct whmr_maf_weights {

@@ -22,7 +22,8 @@ class WhmrGemm(C.Structure):
                 ('IH', C.c_int32), ('IW', C.c_int32), ('Cin', C.c_int32), ('OH', C.c_int32), ('OW', C.c_int32),
                 ('KW', C.c_int32), ('SH', C.c_int32), ('SW', C.c_int32), ('PH', C.c_int32), ('PW', C.c_int32),
                 ('c_mode', C.c_int32),
-                ('c_off', C.c_int64), ('osb', C.c_int64), ('osy', C.c_int64), ('osx', C.c_int64)]
+                ('c_off', C.c_int64), ('osb', C.c_int64), ('osy', C.c_int64), ('osx', C.c_int64),
+                ('workspace', C.c_void_p), ('workspace_bytes', C.c_int64)]
 
 
 class WhmrSmplModel(C.Structure):
@@ -53,7 +54,7 @@ _SIGS = {
     'whmr_weak_projection': [_P, _P, _P, _I, _I, _F, _F, _F, _P],
     'whmr_smpl_pose_chain': [C.POINTER(WhmrSmplModel), _P, _P, _I, _I, _P, _P, _P, _P, _P, _P],
     'whmr_smpl_skin': [C.POINTER(WhmrSmplModel), _P, _P, _P, _I, _P, _P],
-    'whmr_smpl_joints': [C.POINTER(WhmrSmplModel), _P, _P, _I, _P, _P, _P, _P],
+    'whmr_smpl_joints': [C.POINTER(WhmrSmplModel), _P, _P, _I, _P, _P, _P, _P, _P],
     'whmr_maf_sample': [_P, _I, _L, _L, _L, _L, _I, _I, _P, _P, _P, _F, _F, _F, C.POINTER(WhmrMafWeights), _I, _I, _P, _L, _P, _P],
     'whmr_tz_tail': [_P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _F, _P, _P],
 }
@@ -92,6 +93,15 @@ def _dev(*ts):
 
 
 _zeros = {}
+_splitk_ws = {}
+
+
+def splitk_workspace(device):
+    """Per-device scratch for the fp32 split-K partial sums (16 MiB covers 16 splits of a 64 x 2048 output 2x over)."""
+    w = _splitk_ws.get(device)
+    if w is None:
+        w = _splitk_ws[device] = torch.empty(16 << 20, dtype=torch.uint8, device=device)
+    return w
 
 
 def zero_page(device):
@@ -150,6 +160,9 @@ def gemm(a, w, out, bias=None, residual=None, res_row_mod=0, act=ACT_NONE, conv=
     else:
         p.ldc = out.stride(-2) if out.dim() >= 2 else N
     fn = lib().whmr_gemm_bf16 if a.dtype == torch.bfloat16 else lib().whmr_gemm_f32
+    if a.dtype == torch.float32 and conv is None and scatter is None:
+        ws = splitk_workspace(a.device)
+        p.workspace, p.workspace_bytes = ws.data_ptr(), ws.numel()
     if tile is not None:                    # explicit tile id (A/B tests), see gemm_bf16_big.hip
         assert a.dtype == torch.bfloat16
         _check(lib().whmr_gemm_bf16_big(C.byref(p), int(tile), _stream()), 'whmr_gemm_bf16_big')
@@ -278,8 +291,9 @@ def smpl_skin(model, betas, pose_feat, A, verts):
 
 
 def smpl_joints(model, verts, posed_joints, joints49, smpl_joints45, markers):
+    scratch = torch.empty(verts.shape[0] * 33 * 3, dtype=torch.float32, device=verts.device)
     _check(lib().whmr_smpl_joints(C.byref(model), verts.data_ptr(), _ptr(posed_joints), verts.shape[0], _ptr(joints49),
-                                  _ptr(smpl_joints45), _ptr(markers), _stream()), 'whmr_smpl_joints')
+                                  _ptr(smpl_joints45), _ptr(markers), scratch.data_ptr(), _stream()), 'whmr_smpl_joints')
 
 
 def maf_sample(fmap_nchw, weights, out, pts2d=None, pts3d=None, cam=None, point_feat=None, focal=1000.0, res_w=256.0,

@@ -6,7 +6,7 @@
 //
 // All candidate tiles run the same kernel template; what differs is how well the tile grid fills the 256 CUs.
 // Cost model (matches the measured ordering on the ViT-B shapes, profiles/): a launch takes
-//     rounds x (blocks co-resident per CU) x BM x BN,   rounds = ceil(tiles / (256 CUs x blocks per CU))
+//     rounds x (blocks co-resident per CU) x BM x BN x eff,   rounds = ceil(tiles / (256 CUs x blocks per CU))
 // because co-resident blocks share the CU's matrix pipes.  Examples at M = 12544: N = 768 -> 192x256 (198 tiles, one
 // round of 3/4-size tiles); N = 2304 -> 256x256 (441 tiles, 2 rounds); N = 3072 -> 128x128 (2352 tiles, 4.6 -> 5 rounds).
 #include "common.h"
@@ -14,20 +14,21 @@
 
 extern "C" int whmr_gemm_bf16_big(const whmr_gemm* pp, int tile, void* stream);
 
-struct tile_cfg { int id, bm, bn, per_cu; };
+struct tile_cfg { int id, bm, bn, per_cu, eff_pct; };   // eff_pct: measured main-loop cost per tile area, relative to 256x256
 
 extern "C" int whmr_gemm_bf16(const whmr_gemm* pp, int flags, void* stream) {
     const whmr_gemm& p = *pp;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % 64)) return (int)hipErrorInvalidValue;
     if (flags > 1) return whmr_gemm_bf16_big(pp, flags, stream);          // explicit tile id (A/B tests)
-    static const tile_cfg cands[] = {{320, 320, 256, 1}, {257, 256, 256, 1}, {192, 192, 256, 1}, {128, 128, 256, 2}, {64, 128, 128, 2}};
+    static const tile_cfg cands[] = {{320, 320, 256, 1, 100}, {257, 256, 256, 1, 100}, {192, 192, 256, 1, 100},
+                                     {128, 128, 256, 2, 120}, {64, 128, 128, 2, 125}, {65, 128, 64, 3, 150}};
     long best_cost = -1;
     int best = 64;
     for (const tile_cfg& c : cands) {
         const long tiles = (long)((p.M + c.bm - 1) / c.bm) * ((p.N + c.bn - 1) / c.bn);
         const long slots = 256L * c.per_cu;
         const long rounds = (tiles + slots - 1) / slots;
-        const long cost = rounds * c.per_cu * c.bm * c.bn;
+        const long cost = rounds * c.per_cu * c.bm * c.bn * c.eff_pct;
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = c.id; }
     }
     return whmr_gemm_bf16_big(pp, best, stream);

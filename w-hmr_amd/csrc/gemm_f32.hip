@@ -16,8 +16,8 @@
 #define FBK 16
 #define FLD 17
 
-template <bool GATHER>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const whmr_gemm p) {
+template <bool GATHER, bool SPLIT>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const whmr_gemm p, int k_per_split) {
     __shared__ float sA[FBM * FLD];
     __shared__ float sB[FBN * FLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -53,13 +53,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const whmr_gemm p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-    for (int k0 = 0; k0 < p.K; k0 += FBK) {
+    const int k_begin = SPLIT ? blockIdx.y * k_per_split : 0;
+    const int k_end = SPLIT ? min(p.K, k_begin + k_per_split) : p.K;
+    for (int k0 = k_begin; k0 < k_end; k0 += FBK) {
         float av[4], bw[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int k = k0 + sk + e;
             float a = 0.f, b = 0.f;
-            if (k < p.K) {
+            if (k < k_end) {
                 if (a_ok) {
                     if constexpr (GATHER) {
                         const int tap = k / p.Cin, ci = k - tap * p.Cin;
@@ -93,6 +95,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const whmr_gemm p) {
 
     const int n = n0 + wn * 32 + l31;
     if (n >= p.N) return;
+    if constexpr (SPLIT) {           // raw partial sums; bias / activation / residual happen in splitk_reduce_kernel
+        float* ws = (float*)p.workspace + (size_t)blockIdx.y * p.M * p.N;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (m < p.M) ws[(size_t)m * p.N + n] = acc[r];
+        }
+        return;
+    }
     const float bv = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -119,14 +130,49 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const whmr_gemm p) {
     }
 }
 
+// Sum the split-K partials in a fixed order (deterministic), then the usual epilogue.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const whmr_gemm p, int splits) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)p.M * p.N) return;
+    const int m = (int)(idx / p.N), n = (int)(idx - (long)m * p.N);
+    const float* ws = (const float*)p.workspace + idx;
+    float v = 0.f;
+    for (int s = 0; s < splits; ++s) v += ws[(size_t)s * p.M * p.N];
+    if (p.bias) v += p.bias[n];
+    if (p.act == 1) v = gelu_erf(v);
+    else if (p.act == 2) v = fmaxf(v, 0.f);
+    if (p.residual) v += p.residual[(size_t)(p.res_row_mod > 0 ? m % p.res_row_mod : m) * p.ldr + n];
+    const size_t off = (size_t)m * p.ldc + n;
+    if (p.out_bf16) ((bf16_t*)p.C)[off] = f32_to_bf16(v);
+    else ((float*)p.C)[off] = v;
+}
+
 extern "C" int whmr_gemm_f32(const whmr_gemm* pp, int flags, void* stream) {
     (void)flags;
     const whmr_gemm& p = *pp;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return (int)hipErrorInvalidValue;
     const int tiles = ((p.M + FBM - 1) / FBM) * ((p.N + FBN - 1) / FBN);
     hipStream_t st = (hipStream_t)stream;
-    if (p.a_mode == 1) hipLaunchKernelGGL(gemm_f32_kernel<true>, dim3(tiles), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(gemm_f32_kernel<false>, dim3(tiles), dim3(256), 0, st, p);
+    // Skinny shapes (M = batch: regressor / global-orient / Tz linears) leave most CUs idle and are weight-streaming bound:
+    // split K across blocks so that ~2 blocks per CU stream the weight matrix concurrently.
+    int splits = 1;
+    if (p.a_mode == 0 && p.c_mode == 0 && p.workspace && tiles < 128 && p.K >= 512) {
+        splits = (384 + tiles - 1) / tiles;
+        if (splits > p.K / 128) splits = p.K / 128;
+        if (splits > 32) splits = 32;
+        while (splits > 1 && (int64_t)splits * p.M * p.N * 4 > p.workspace_bytes) --splits;
+    }
+    if (splits > 1) {
+        int kps = (p.K + splits - 1) / splits;
+        kps = (kps + FBK - 1) / FBK * FBK;
+        splits = (p.K + kps - 1) / kps;
+        hipLaunchKernelGGL((gemm_f32_kernel<false, true>), dim3(tiles, splits), dim3(256), 0, st, p, kps);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((long)p.M * p.N + 255) / 256)), dim3(256), 0, st, p, splits);
+    } else if (p.a_mode == 1) {
+        hipLaunchKernelGGL((gemm_f32_kernel<true, false>), dim3(tiles), dim3(256), 0, st, p, 0);
+    } else {
+        hipLaunchKernelGGL((gemm_f32_kernel<false, false>), dim3(tiles), dim3(256), 0, st, p, 0);
+    }
     WHMR_CHECK_LAUNCH();
     return 0;
 }

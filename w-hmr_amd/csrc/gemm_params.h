@@ -19,4 +19,6 @@ struct whmr_gemm {
     int32_t IH, IW, Cin, OH, OW, KW, SH, SW, PH, PW;   // iy = oy*SH + ky - PH, ix = ox*SW + kx - PW
     int32_t c_mode;         // 0 plain rows (m*ldc), 1 spatial scatter: c_off + b*osb + oy*osy + ox*osx
     int64_t c_off, osb, osy, osx;
+    void* workspace;        // optional scratch for split-K partial sums (fp32 kernel, skinny shapes); may be null
+    int64_t workspace_bytes;
 };

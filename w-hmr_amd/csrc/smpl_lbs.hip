@@ -175,57 +175,49 @@ __global__ __launch_bounds__(128) void smpl_skin_kernel(const whmr_smpl_model m,
     }
 }
 
-// Per image: regress rows of `reg` ([R,6890], dense like the reference's buffers) over the mesh -> [R,3].
-__device__ __forceinline__ void regress_rows(const float* __restrict__ reg, int R, const float* __restrict__ vb,
-                                             float* __restrict__ sOut /*[R][3] shared*/, float* sRed /*[4][3]*/) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int r = 0; r < R; ++r) {
-        const float* rr = reg + (size_t)r * NV;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-        for (int v = tid; v < NV; v += 256) {
-            const float wv = rr[v];
-            if (wv != 0.f) {     // the real regressors are >99 % zeros; skipping exact zeros does not change the sum
-                a0 = fmaf(wv, vb[3 * v], a0); a1 = fmaf(wv, vb[3 * v + 1], a1); a2 = fmaf(wv, vb[3 * v + 2], a2);
-            }
-        }
-        a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
-        if (lane == 0) { sRed[wave * 3] = a0; sRed[wave * 3 + 1] = a1; sRed[wave * 3 + 2] = a2; }
-        __syncthreads();
-        if (tid < 3) sOut[r * 3 + tid] = sRed[tid] + sRed[3 + tid] + sRed[6 + tid] + sRed[9 + tid];
-        __syncthreads();
+// Regress `R` rows of a dense [R,6890] matrix over every image's skinned mesh: one WAVE per (image, row) -- 33 rows x B
+// images give thousands of independent waves instead of one block per image walking the rows serially.
+// out[(b*R + r)*3 + c] = sum_v reg[r][v] * verts[b][v][c].  Exact zeros are skipped (the real regressors are >99 % zeros).
+__global__ __launch_bounds__(256) void smpl_regress_kernel(const float* __restrict__ reg, int R, const float* __restrict__ verts,
+                                                           int B, float* __restrict__ out) {
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (w >= B * R) return;
+    const int b = w / R, r = w - b * R;
+    const float* rr = reg + (size_t)r * NV;
+    const float* vb = verts + (size_t)b * NV * 3;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int v = lane; v < NV; v += 64) {
+        const float wv = rr[v];
+        if (wv != 0.f) { a0 = fmaf(wv, vb[3 * v], a0); a1 = fmaf(wv, vb[3 * v + 1], a1); a2 = fmaf(wv, vb[3 * v + 2], a2); }
     }
+    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
+    if (lane == 0) { out[(size_t)w * 3] = a0; out[(size_t)w * 3 + 1] = a1; out[(size_t)w * 3 + 2] = a2; }
 }
 
+// Gather stage: 54-joint superset (24 posed SMPL joints, 21 picked vertices, 9 regressed; models/smpl.py:61-83) -> JOINT_MAP
+// -> joints49; whmr.py:186-187 smpl_joints45 (J_regressor over the POSED mesh + vertex_joint_selector); markers (whmr.py:184).
+// `regd` = [B, 9 (+24)] x 3 rows from smpl_regress_kernel (extra first, then J_regressor when requested).
 __global__ __launch_bounds__(256) void smpl_joints_kernel(const whmr_smpl_model m, const float* __restrict__ verts,
-                                                          const float* __restrict__ posed_joints,
-                                                          float* __restrict__ joints49, float* __restrict__ smpl_joints45,
+                                                          const float* __restrict__ posed_joints, const float* __restrict__ regd,
+                                                          int R, float* __restrict__ joints49, float* __restrict__ smpl_joints45,
                                                           float* __restrict__ markers) {
-    __shared__ float sExtra[9 * 3];
-    __shared__ float sJ24[24 * 3];
-    __shared__ float sRed[12];
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* vb = verts + (size_t)b * NV * 3;
-    if (joints49) {
-        regress_rows(m.J_regressor_extra, 9, vb, sExtra, sRed);
-        // 54-joint superset: 24 posed SMPL joints, 21 picked vertices, 9 regressed (models/smpl.py:61-83), then JOINT_MAP
-        if (tid < 49 * 3) {
-            const int j = tid / 3, c = tid % 3;
-            const int s = m.joint_map[j];
-            float v;
-            if (s < 24) v = posed_joints[((size_t)b * NJ + s) * 3 + c];
-            else if (s < 45) v = vb[3 * m.extra_vertex_ids[s - 24] + c];
-            else v = sExtra[(s - 45) * 3 + c];
-            joints49[((size_t)b * 49 + j) * 3 + c] = v;
-        }
+    const float* rb = regd + (size_t)b * R * 3;
+    if (joints49 && tid < 49 * 3) {
+        const int j = tid / 3, c = tid % 3;
+        const int s = m.joint_map[j];
+        float v;
+        if (s < 24) v = posed_joints[((size_t)b * NJ + s) * 3 + c];
+        else if (s < 45) v = vb[3 * m.extra_vertex_ids[s - 24] + c];
+        else v = rb[(s - 45) * 3 + c];
+        joints49[((size_t)b * 49 + j) * 3 + c] = v;
     }
-    if (smpl_joints45) {     // whmr.py:186-187: J_regressor over the POSED mesh + vertex_joint_selector
-        regress_rows(m.J_regressor, 24, vb, sJ24, sRed);
-        if (tid < 45 * 3) {
-            const int j = tid / 3, c = tid % 3;
-            smpl_joints45[((size_t)b * 45 + j) * 3 + c] = j < 24 ? sJ24[j * 3 + c] : vb[3 * m.extra_vertex_ids[j - 24] + c];
-        }
+    if (smpl_joints45 && tid < 45 * 3) {
+        const int j = tid / 3, c = tid % 3;
+        smpl_joints45[((size_t)b * 45 + j) * 3 + c] = j < 24 ? rb[(9 + j) * 3 + c] : vb[3 * m.extra_vertex_ids[j - 24] + c];
     }
-    if (markers) {           // whmr.py:184
+    if (markers) {
         for (int e = tid; e < m.n_markers * 3; e += 256)
             markers[((size_t)b * m.n_markers) * 3 + e] = vb[3 * m.marker_ids[e / 3] + e % 3];
     }
@@ -250,11 +242,17 @@ extern "C" int whmr_smpl_skin(const whmr_smpl_model* m, const float* betas, cons
     return 0;
 }
 
+// scratch: >= B*33*3 floats of device workspace (regressed rows).  J_regressor_extra and J_regressor must be ONE contiguous
+// [33,6890] buffer (extra rows first) when smpl_joints45 is requested; the host wrapper builds it once.
 extern "C" int whmr_smpl_joints(const whmr_smpl_model* m, const float* verts, const float* posed_joints, int B,
-                                float* joints49, float* smpl_joints45, float* markers, void* stream) {
-    if (B <= 0) return (int)hipErrorInvalidValue;
+                                float* joints49, float* smpl_joints45, float* markers, float* scratch, void* stream) {
+    if (B <= 0 || !scratch) return (int)hipErrorInvalidValue;
     if (smpl_joints45 && !m->J_regressor) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(smpl_joints_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, *m, verts, posed_joints, joints49,
+    const int R = smpl_joints45 ? 33 : 9;
+    if (smpl_joints45 && m->J_regressor != m->J_regressor_extra + 9 * NV) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(smpl_regress_kernel, dim3((B * R + 3) / 4), dim3(256), 0, st, m->J_regressor_extra, R, verts, B, scratch);
+    hipLaunchKernelGGL(smpl_joints_kernel, dim3(B), dim3(256), 0, st, *m, verts, posed_joints, scratch, R, joints49,
                        smpl_joints45, markers);
     WHMR_CHECK_LAUNCH();
     return 0;

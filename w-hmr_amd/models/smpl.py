@@ -66,12 +66,14 @@ class SMPL(nn.Module):
     # ---- device-side constants (folded joint regressors, int32 index tables) -- built once per device / buffer version
     def _model(self):
         dev = self.v_template.device
-        ver = (dev, self.v_template._version, self.shapedirs._version, self.J_regressor._version, self.posedirs.data_ptr())
+        ver = (dev,) + tuple((t._version, t.data_ptr()) for t in (self.v_template, self.shapedirs, self.posedirs, self.lbs_weights,
+                                                                  self.J_regressor, self.J_regressor_extra))
         if self._dev_cache is None or self._dev_cache[0] != ver:
             i32 = lambda t: t.to(device=dev, dtype=torch.int32).contiguous()
             # J = Jreg . (T + S beta) = (Jreg . T) + (Jreg . S) beta: fold the 24x6890 regressor into 24x3(+x10) constants
             Jreg64 = self.J_regressor.double()
-            keep = {'J_template': (Jreg64 @ self.v_template.double()).float().contiguous(),
+            keep = {'regs': torch.cat([self.J_regressor_extra, self.J_regressor], 0).contiguous(),   # [9 + 24, 6890]
+                    'J_template': (Jreg64 @ self.v_template.double()).float().contiguous(),
                     'J_shapedirs': torch.einsum('jv,vcl->jcl', Jreg64, self.shapedirs.double()).float().contiguous(),
                     'parents': i32(self.parents), 'extra': i32(self.extra_joints_idxs), 'jmap': i32(self.joint_map),
                     'markers': i32(self.marker_ids)}
@@ -79,7 +81,8 @@ class SMPL(nn.Module):
             m.v_template, m.shapedirs = self.v_template.data_ptr(), self.shapedirs.data_ptr()
             m.posedirs, m.lbs_weights = self.posedirs.data_ptr(), self.lbs_weights.data_ptr()
             m.J_template, m.J_shapedirs = keep['J_template'].data_ptr(), keep['J_shapedirs'].data_ptr()
-            m.J_regressor, m.J_regressor_extra = self.J_regressor.data_ptr(), self.J_regressor_extra.data_ptr()
+            m.J_regressor_extra = keep['regs'].data_ptr()
+            m.J_regressor = keep['regs'].data_ptr() + 9 * self.NUM_VERTS * 4
             m.parents, m.extra_vertex_ids = keep['parents'].data_ptr(), keep['extra'].data_ptr()
             m.joint_map, m.marker_ids = keep['jmap'].data_ptr(), keep['markers'].data_ptr() if keep['markers'].numel() else None
             m.n_markers = int(keep['markers'].numel())
