@@ -50,17 +50,43 @@ def build_workload(args, dev):
 
 
 def cpu_baseline(sd, x_cpu, size):
-    """Oracle (pure-PyTorch fp32 restatement of the reference ViT) on the host cores, bounded sample."""
+    """Oracle (pure-PyTorch fp32 restatement of the reference ViT) on the host cores, bounded sample (~10-20 s).
+
+    The box exposes 256 logical CPUs but the container's usable share is much smaller (more threads run slower), so a
+    short sweep on 8 images picks the thread count, then the same batch-64 workload is timed at that setting.
+    """
     from oracle.vit import vit_forward
-    torch.set_num_threads(os.cpu_count() or 1)
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    best = None
     with torch.no_grad():
-        vit_forward(sd, x_cpu[:4])                         # warm-up
+        for th in sorted({min(t, ncpu) for t in (8, 16, 32, 64)}):
+            torch.set_num_threads(th)
+            vit_forward(sd, x_cpu[:2])
+            t0 = time.perf_counter()
+            vit_forward(sd, x_cpu[:8])
+            dt = time.perf_counter() - t0
+            if best is None or dt < best[1]:
+                best = (th, dt)
+        torch.set_num_threads(best[0])
         n = x_cpu.shape[0]
-        t0 = time.perf_counter()
-        vit_forward(sd, x_cpu)
-        dt = time.perf_counter() - t0
-    return {'value': n / dt, 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': 'oracle.vit.vit_forward fp32, one batch of %d %dx%d crops, 1 pass (%.1f s)' % (n, size[0], size[1], dt)}
+        reps, t0 = 0, time.perf_counter()
+        while reps < 1 or (time.perf_counter() - t0 < 10.0 and reps < 8):
+            vit_forward(sd, x_cpu)
+            reps += 1
+        dt = (time.perf_counter() - t0) / reps
+    return {'value': n / dt, 'unit': 'images/sec', 'cores': best[0], 'kind': 'port',
+            'sample': 'oracle.vit.vit_forward fp32 (CPU restatement of the reference ViT), %d pass(es) over one batch of %d '
+                      '%dx%d crops (%.1f s each), torch threads = %d (best of a short sweep; %d logical CPUs visible)'
+                      % (reps, n, size[0], size[1], dt, best[0], ncpu)}
+
+
+def gemm_traffic():
+    """HBM bytes per GEMM launch from the committed rocprofv3 --pmc pass of this same command (profiles/), or None."""
+    path = os.path.join(ROOT, 'profiles', 'r01_vit224_gemm_traffic.json')
+    if os.path.exists(path):
+        with open(path) as f:
+            return json.load(f)
+    return None
 
 
 def reduce_max_time(dt, dist, dev):
@@ -121,6 +147,7 @@ def main():
     dt = reduce_max_time(dt, dist, dev)
 
     gemm = [(f, e0.elapsed_time(e1) * 1e-3) for (name, f, e0, e1) in prof if name == 'gemm_bf16']
+    traffic = gemm_traffic()
     n_launch = max(len(gemm), 1)
     flops_per_launch = sum(f for f, _ in gemm) / n_launch
     avg_s = sum(t for _, t in gemm) / n_launch
@@ -136,9 +163,11 @@ def main():
                                    % (args.workload, size[0], size[1], args.batch),
                        'global_batch': world * args.batch, 'parallelism': 'replicas x%d (no data-path collective)' % world},
             'model_tflops': VIT_FLOP_PER_IMG[args.workload] * world * args.batch * args.steps / dt / 1e12,
-            'roofline': {'bound': 'mfma', 'kernel': 'gemm_bf16_kernel (all %d launches of one step)' % len(gemm),
+            'roofline': {'bound': 'mfma', 'kernel': 'gemm_bf16_big_kernel (all %d GEMM launches of one step)' % len(gemm),
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
-                         'flops_per_launch': flops_per_launch, 'avg_launch_us': avg_s * 1e6, 'traffic': None},
+                         'flops_per_launch': flops_per_launch, 'avg_launch_us': avg_s * 1e6,
+                         'traffic': traffic['bytes_per_launch'] if traffic else None,
+                         'traffic_note': traffic['note'] if traffic else 'no PMC pass committed'},
         }
         if not args.no_cpu and world == 1:
             res['cpu_baseline'] = cpu_baseline(sd, x.cpu(), size)
