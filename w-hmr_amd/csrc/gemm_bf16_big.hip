@@ -250,6 +250,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
     constexpr int CPT = OUT_BF16 ? 8 : 4;                   // columns per thread in the store phase (16 B either way)
     constexpr int TPR = BN / CPT;                           // threads per output row
     constexpr int RPI = cfg::THREADS / TPR;                 // rows per store iteration
+    constexpr int NIT = cfg::CROWS / RPI;                   // store iterations per pass
     const int ccol = (tid % TPR) * CPT, rsub = tid / TPR;
     const int ncol = n0 + ccol;
     float* sC = (float*)smem;
@@ -260,20 +261,83 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
     bool spatial = false;
     if constexpr (GATHER) spatial = (p.c_mode == 1);
     const bool vec_ok = (ncol + CPT <= p.N) && (spatial || (p.ldc % CPT) == 0) && (!res || (p.ldr & 3) == 0);
-    const bool probe_nostore = p.res_row_mod == -2001, probe_nolds = p.res_row_mod == -2002;
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        if (!probe_nolds)
+    // LDS-only barrier: the global stores of a pass must NOT be drained at the pass barrier (a __syncthreads() would wait
+    // vmcnt(0), i.e. a full HBM write round trip per pass); only this wave's LDS traffic has to be complete.
+    auto lds_barrier = [&]() { wait_lgkmcnt<0>(); __builtin_amdgcn_s_barrier(); };
+    auto row_of = [&](int i, int it) { const int lr = it * RPI + rsub; return m0 + (lr >> 5) * cfg::WTM + i * 32 + (lr & 31); };
+    auto res_ptr = [&](int m) { return res + (size_t)(p.res_row_mod > 0 ? m % p.res_row_mod : m) * p.ldr + ncol; };
+    auto stage_pass = [&](int i) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 *(float4*)(sC + (wm * 32 + l31) * cfg::CLD_F32 + wn * cfg::WTN + j * 32 + 8 * q + 4 * hi) =
                     make_float4(acc[i][j][q * 4], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]);
-        if (!probe_nolds) __syncthreads();
+    };
+    auto load_row = [&](int lr, float* v) {
+#pragma unroll
+        for (int e = 0; e < CPT; e += 4) {
+            const float4 f = *(const float4*)(sC + lr * cfg::CLD_F32 + ccol + e);
+            v[e] = f.x + bias_r[e]; v[e + 1] = f.y + bias_r[e + 1]; v[e + 2] = f.z + bias_r[e + 2]; v[e + 3] = f.w + bias_r[e + 3];
+        }
+#pragma unroll
+        for (int e = 0; e < CPT; ++e) {
+            if (ACT == 1) v[e] = gelu_fast(v[e]);
+            if (ACT == 2) v[e] = fmaxf(v[e], 0.f);
+        }
+    };
+    auto store_vec = [&](size_t off, const float* v) {
+        if constexpr (OUT_BF16)
+            *(uint4*)((bf16_t*)p.C + off) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]),
+                                                       pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+        else
+            *(float4*)((float*)p.C + off) = make_float4(v[0], v[1], v[2], v[3]);
+    };
+
+    if constexpr (!GATHER && MI <= 4) {
+        if (res && vec_ok) {
+            // ---- fast residual path (proj / fc2 / patch-embed): all residual rows of a pass are prefetched one pass ahead,
+            // NIT independent 16-B loads in flight per thread instead of one exposed HBM round trip per row.
+            float4 rv[NIT][CPT / 4];
+            auto prefetch_res = [&](int i) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int m = row_of(i, it);
+#pragma unroll
+                    for (int e = 0; e < CPT / 4; ++e)
+                        rv[it][e] = (m < p.M) ? *(const float4*)(res_ptr(m) + 4 * e) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            };
+            prefetch_res(0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                stage_pass(i);
+                lds_barrier();
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int m = row_of(i, it);
+                    float v[CPT];
+                    load_row(it * RPI + rsub, v);
+#pragma unroll
+                    for (int e = 0; e < CPT / 4; ++e) {
+                        v[4 * e] += rv[it][e].x; v[4 * e + 1] += rv[it][e].y; v[4 * e + 2] += rv[it][e].z; v[4 * e + 3] += rv[it][e].w;
+                    }
+                    if (m < p.M) store_vec((size_t)m * p.ldc + ncol, v);
+                }
+                lds_barrier();                                   // slab consumed: the next pass may overwrite it
+                if (i + 1 < MI) prefetch_res(i + 1);
+            }
+            return;
+        }
+    }
+    // ---- generic path (no residual, conv scatter, N tail): rolled store loop, code exists once
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        stage_pass(i);
+        lds_barrier();
 #pragma unroll 1
-        for (int lr = rsub; lr < cfg::CROWS; lr += RPI) {       // lr = row inside the staged WM*32-row slab
-            const int m = m0 + (lr >> 5) * cfg::WTM + i * 32 + (lr & 31);
+        for (int it = 0; it < NIT; ++it) {
+            const int m = row_of(i, it);
             if (m >= p.M || ncol >= p.N) continue;
             size_t crow;
             if (spatial) {
@@ -285,32 +349,17 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
                 crow = (size_t)m * p.ldc;
             }
             float v[CPT];
-#pragma unroll
-            for (int e = 0; e < CPT; e += 4) {
-                const float4 f = *(const float4*)(sC + lr * cfg::CLD_F32 + ccol + e);
-                v[e] = f.x; v[e + 1] = f.y; v[e + 2] = f.z; v[e + 3] = f.w;
-            }
-#pragma unroll
-            for (int e = 0; e < CPT; ++e) {
-                v[e] += bias_r[e];
-                if (ACT == 1) v[e] = gelu_fast(v[e]);
-                if (ACT == 2) v[e] = fmaxf(v[e], 0.f);
-            }
-            const float* rp = res ? res + (size_t)(p.res_row_mod > 0 ? m % p.res_row_mod : m) * p.ldr + ncol : nullptr;
-            if (probe_nostore && v[0] != 12345.678f) continue;
+            load_row(it * RPI + rsub, v);
+            const float* rp = res ? res_ptr(m) : nullptr;
             if (vec_ok) {
                 if (rp) {
 #pragma unroll
                     for (int e = 0; e < CPT; e += 4) {
-                        const float4 rv = *(const float4*)(rp + e);
-                        v[e] += rv.x; v[e + 1] += rv.y; v[e + 2] += rv.z; v[e + 3] += rv.w;
+                        const float4 r4 = *(const float4*)(rp + e);
+                        v[e] += r4.x; v[e + 1] += r4.y; v[e + 2] += r4.z; v[e + 3] += r4.w;
                     }
                 }
-                if constexpr (OUT_BF16)
-                    *(uint4*)((bf16_t*)p.C + crow + ncol) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]),
-                                                                       pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
-                else
-                    *(float4*)((float*)p.C + crow + ncol) = make_float4(v[0], v[1], v[2], v[3]);
+                store_vec(crow + ncol, v);
             } else {
 #pragma unroll 1
                 for (int e = 0; e < CPT; ++e) {
@@ -322,7 +371,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
                 }
             }
         }
-        if (!probe_nolds) __syncthreads();
+        lds_barrier();
     }
 }
 
