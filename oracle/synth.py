@@ -208,6 +208,23 @@ def make_state_dict(seed=0, assets=None, img_size=(256, 192), with_cam_model=Tru
     return sd
 
 
+def make_hmr_state(seed=0, assets=None):
+    """HMR (models/hmr.py:164-213) weights: torchvision-style R50 trunk + fc1/fc2/decpose/decshape/deccam + init buffers."""
+    assets = assets if assets is not None else make_assets(seed)
+    sd = {}
+    _resnet50(sd, seed + 100, '')
+    _linear(sd, seed, 'fc1', 1024, 2048 + 144 + 13)
+    _linear(sd, seed, 'fc2', 1024, 1024)
+    _linear(sd, seed, 'decpose', 144, 1024, xavier_gain=0.01)
+    _linear(sd, seed, 'decshape', 10, 1024, xavier_gain=0.01)
+    _linear(sd, seed, 'deccam', 3, 1024, xavier_gain=0.01)
+    mp = assets['mean_params']
+    sd['init_pose'] = torch.from_numpy(mp['pose']).unsqueeze(0)
+    sd['init_shape'] = torch.from_numpy(mp['shape']).unsqueeze(0)
+    sd['init_cam'] = torch.from_numpy(mp['cam']).unsqueeze(0)
+    return sd
+
+
 # ----------------------------------------------------------------------------- inputs
 def make_inputs(B, seed=0, img_size=(256, 192), full_size=None):
     """Synthetic crops + bbox metadata (bbox_info per demo/tester.py:136-145)."""

@@ -379,6 +379,24 @@ def main():
         chk('vit224', vit_forward(vsd, xin), ref)
     np.savez_compressed(os.path.join(HERE, 'vit224_b2.npz'), x=xin.numpy(), s_feat=ref.numpy())
 
+    # ---- BASELINE config #1: HMR (R50 trunk + iterative regressor), 1 x 224 x 224, CPU
+    import models.hmr as RH
+    from oracle.hmr import hmr_forward
+    hsd = synth.make_hmr_state(0, ASSETS)
+    hnet = RH.HMR(RH.Bottleneck, [3, 4, 6, 3], 'data/smpl_mean_params.npz')
+    res = hnet.load_state_dict(hsd, strict=True)
+    hnet.eval()
+    xh = synth.make_inputs(1, 11, (224, 224))['x']
+    with torch.no_grad():
+        rot_r, shape_r, cam_r = hnet(xh)
+        rot_m, shape_m, cam_m = hmr_forward(hsd, xh)
+        vr = OS.smpl_forward(shape_r, rot_r, ASSETS['smpl'])[0]
+    chk('hmr.rotmat', rot_m, rot_r)
+    chk('hmr.shape', shape_m, shape_r)
+    chk('hmr.cam', cam_m, cam_r)
+    np.savez_compressed(os.path.join(HERE, 'hmr_b1.npz'), x=xh.numpy(), rotmat=rot_r.numpy(), shape=shape_r.numpy(),
+                        cam=cam_r.numpy(), verts=vr.numpy())
+
     # ---- geometry helpers on edge cases
     gen = torch.Generator().manual_seed(0)
     R = OG.batch_rodrigues(torch.randn(64, 3, generator=gen) * 1.5)

@@ -177,3 +177,20 @@ def test_whmr_batch_independence(dev, assets, state_dict, gold):
     a, b = m(**kw), m(**rep)
     for k in a:
         assert torch.allclose(b[k][:2], a[k], rtol=1e-5, atol=1e-6) and torch.allclose(b[k][4:], a[k], rtol=1e-5, atol=1e-6)
+
+
+def test_config1_hmr_plumbing_matches_reference_fixture(dev, assets):
+    """BASELINE config #1: R50 trunk + HMR iterative regressor (6-D pose state) + SMPL forward, 1 x 224 x 224"""
+    from oracle import synth
+    from whmr_amd.models import hmr
+    from whmr_amd.models.smpl import SMPL
+    g = np.load(os.path.join(GOLDEN, 'hmr_b1.npz'))
+    m = hmr(None, assets=assets)
+    m.load_state_dict(synth.make_hmr_state(0, assets), strict=True)
+    m = m.to(dev).eval()
+    rot, shape, cam = m(torch.from_numpy(g['x']).to(dev))
+    assert rot.shape == (1, 24, 3, 3)
+    assert _rel(rot, g['rotmat']) < 1e-4 and _rel(shape, g['shape']) < 1e-4 and _rel(cam, g['cam']) < 1e-4
+    smpl = SMPL(arrays=assets['smpl']).to(dev)
+    out = smpl(betas=shape, body_pose=rot[:, 1:], global_orient=rot[:, :1], pose2rot=False)
+    assert _rel(out.vertices, g['verts']) < 1e-4

@@ -111,3 +111,19 @@ def test_maf_known_answers(state_dict):
     assert torch.allclose(pf[0, :, 0], fmap[0, :, 0, 0], atol=1e-6) and torch.allclose(pf[0, :, 1], fmap[0, :, 4, 3], atol=1e-6)
     assert torch.allclose(pf[0, :, 2], fmap[0, :, 3, 2], atol=1e-5)
     assert (pf[0, :, 3] == 0).all()
+
+
+def test_oracle_config1_hmr_matches_reference_fixture(assets):
+    """BASELINE config #1 (the reference's own CPU-runnable case): pose_resnet/HMR R50 + regressor + SMPL, 1 x 224 x 224"""
+    from oracle import smpl as OS
+    from oracle import synth
+    from oracle.hmr import hmr_forward, pose_resnet_global
+    g = np.load(os.path.join(GOLDEN, 'hmr_b1.npz'))
+    sd = synth.make_hmr_state(0, assets)
+    x = torch.from_numpy(g['x'])
+    with torch.no_grad():
+        rot, shape, cam = hmr_forward(sd, x)
+        f, gf = pose_resnet_global(sd, x)
+    assert f.shape == (1, 2048, 7, 7) and gf.shape == (1, 2048)
+    assert _rel(rot, g['rotmat']) < 1e-5 and _rel(shape, g['shape']) < 1e-5 and _rel(cam, g['cam']) < 1e-5
+    assert _rel(OS.smpl_forward(shape, rot, assets['smpl'])[0], g['verts']) < 1e-5
