@@ -36,6 +36,10 @@ struct whmr_gemm {
     int64_t c_off, osb, osy, osx;
     void* workspace;        /* optional split-K scratch (fp32 kernel): splits*M*N floats; null = no split */
     int64_t workspace_bytes;
+    /* all 4 sub-pixel phases of ConvTranspose2d(k4,s2,p1) in one launch (bf16 kernel, a_mode = c_mode = 1, n_phase = 4):
+     * phase = 2*py + px: W += phase*phase_w_stride; PH -= py; PW -= px; c_off += py*phase_cy + px*phase_cx. */
+    int32_t n_phase, pad_;
+    int64_t phase_w_stride, phase_cy, phase_cx;
 };
 
 /* bf16 MFMA GEMM (v_mfma_f32_32x32x16_bf16, fp32 accumulate).  Needs K % 64 == 0 (and Cin % 64 == 0 for a_mode 1).

@@ -131,6 +131,29 @@ def test_deconv_phases(dev, dtype):
     assert _rel(out.permute(0, 3, 1, 2).cpu(), ref) < (2e-5 if dtype == torch.bfloat16 else 2e-6)
 
 
+def test_deconv_phases_batched_launch(dev):
+    """the 4 sub-pixel phases in ONE launch (n_phase = 4) == ConvTranspose2d(k4,s2,p1) + ReLU"""
+    from whmr_amd import _lib as L
+    g = torch.Generator().manual_seed(6)
+    B, Cin, H, W, Cout = 3, 128, 7, 5, 256
+    x = (torch.randn(B, Cin, H, W, generator=g)).bfloat16().float()
+    w = (torch.randn(Cin, Cout, 4, 4, generator=g) / math.sqrt(Cin * 4)).bfloat16().float()
+    shift = torch.randn(Cout, generator=g)
+    ref = F.relu(F.conv_transpose2d(x, w, stride=2, padding=1) + shift[None, :, None, None])
+    xn = x.permute(0, 2, 3, 1).contiguous().bfloat16().to(dev)
+    ph = []
+    for py in range(2):
+        for px in range(2):
+            taps = [w[:, :, 3 - py - 2 * a, 3 - px - 2 * b] for a in range(2) for b in range(2)]
+            ph.append(torch.stack(taps, 0).permute(2, 0, 1).reshape(Cout, -1))
+    wst = torch.stack(ph, 0).contiguous().bfloat16().to(dev)
+    out = torch.zeros(B, 2 * H, 2 * W, Cout, device=dev)
+    L.gemm(xn, wst, out, bias=shift.to(dev), act=L.ACT_RELU,
+           conv=dict(IH=H, IW=W, Cin=Cin, OH=H, OW=W, KW=2, SH=1, SW=1, PH=1, PW=1),
+           scatter=dict(c_off=0, osb=4 * H * W * Cout, osy=4 * W * Cout, osx=2 * Cout), phases=dict(cy=2 * W * Cout, cx=Cout))
+    assert _rel(out.permute(0, 3, 1, 2).cpu(), ref) < 2e-5
+
+
 @pytest.mark.parametrize('C', [768, 216, 1024])
 @pytest.mark.parametrize('bf16', [False, True])
 def test_layernorm(dev, C, bf16):

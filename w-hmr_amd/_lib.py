@@ -23,7 +23,9 @@ class WhmrGemm(C.Structure):
                 ('KW', C.c_int32), ('SH', C.c_int32), ('SW', C.c_int32), ('PH', C.c_int32), ('PW', C.c_int32),
                 ('c_mode', C.c_int32),
                 ('c_off', C.c_int64), ('osb', C.c_int64), ('osy', C.c_int64), ('osx', C.c_int64),
-                ('workspace', C.c_void_p), ('workspace_bytes', C.c_int64)]
+                ('workspace', C.c_void_p), ('workspace_bytes', C.c_int64),
+                ('n_phase', C.c_int32), ('pad_', C.c_int32),
+                ('phase_w_stride', C.c_int64), ('phase_cy', C.c_int64), ('phase_cx', C.c_int64)]
 
 
 class WhmrSmplModel(C.Structure):
@@ -116,7 +118,7 @@ PROFILE = None        # bench.py sets this to a list: (kernel, flops, start_even
 
 
 def gemm(a, w, out, bias=None, residual=None, res_row_mod=0, act=ACT_NONE, conv=None, scatter=None, M=None,
-         lda=None, glds=True, tile=None):
+         lda=None, glds=True, tile=None, phases=None):
     """out = act(a . w^T + bias) + residual.  a/w dtype selects the kernel (bf16 MFMA or exact-fp32 MFMA).
 
     conv = dict(IH, IW, Cin, OH, OW, KW, SH, SW, PH, PW): a is an NHWC image [B, IH, IW, Cin], rows are output pixels.
@@ -125,8 +127,8 @@ def gemm(a, w, out, bias=None, residual=None, res_row_mod=0, act=ACT_NONE, conv=
     _dev(a, w, out, bias, residual)
     assert a.dtype == w.dtype and a.dtype in (torch.bfloat16, torch.float32)
     assert a.is_contiguous() or lda is not None
-    assert w.is_contiguous() and w.dim() == 2
-    N, K = w.shape
+    assert w.is_contiguous() and w.dim() == (3 if phases else 2)
+    N, K = w.shape[-2:]
     p = WhmrGemm()
     p.A, p.W, p.C = a.data_ptr(), w.data_ptr(), out.data_ptr()
     p.bias = bias.data_ptr() if bias is not None else None
@@ -153,6 +155,9 @@ def gemm(a, w, out, bias=None, residual=None, res_row_mod=0, act=ACT_NONE, conv=
         p.lda = a.stride(-2) if lda is None else lda
         assert a.shape[-1] == K
     p.N, p.K = N, K
+    if phases is not None:                  # dict(cy, cx): 4 stacked phase matrices w[4, N, K] (sub-pixel deconv)
+        assert a.dtype == torch.bfloat16 and conv is not None and scatter is not None and w.shape[0] == 4
+        p.n_phase, p.phase_w_stride, p.phase_cy, p.phase_cx = 4, N * K, phases['cy'], phases['cx']
     if scatter is not None:
         p.c_mode = 1
         for k in ('c_off', 'osb', 'osy', 'osx'):
@@ -172,7 +177,7 @@ def gemm(a, w, out, bias=None, residual=None, res_row_mod=0, act=ACT_NONE, conv=
         e0.record()
         _check(fn(C.byref(p), 0 if glds else 1, _stream()), 'whmr_gemm')
         e1.record()
-        PROFILE.append(('gemm_bf16' if a.dtype == torch.bfloat16 else 'gemm_f32', 2.0 * p.M * p.N * p.K, e0, e1))
+        PROFILE.append(('gemm_bf16' if a.dtype == torch.bfloat16 else 'gemm_f32', 2.0 * p.M * p.N * p.K * max(1, p.n_phase), e0, e1))
         return out
     _check(fn(C.byref(p), 0 if glds else 1, _stream()), 'whmr_gemm')
     return out

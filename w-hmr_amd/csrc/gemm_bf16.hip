@@ -19,13 +19,14 @@ struct tile_cfg { int id, bm, bn, per_cu, eff_pct; };   // eff_pct: measured mai
 extern "C" int whmr_gemm_bf16(const whmr_gemm* pp, int flags, void* stream) {
     const whmr_gemm& p = *pp;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % 64)) return (int)hipErrorInvalidValue;
+    if (p.n_phase > 1 && (p.n_phase != 4 || p.a_mode != 1 || p.c_mode != 1)) return (int)hipErrorInvalidValue;
     if (flags > 1) return whmr_gemm_bf16_big(pp, flags, stream);          // explicit tile id (A/B tests)
     static const tile_cfg cands[] = {{320, 320, 256, 1, 100}, {257, 256, 256, 1, 100}, {192, 192, 256, 1, 100},
                                      {128, 128, 256, 2, 120}, {64, 128, 128, 2, 125}, {65, 128, 64, 3, 150}};
     long best_cost = -1;
     int best = 64;
     for (const tile_cfg& c : cands) {
-        const long tiles = (long)((p.M + c.bm - 1) / c.bm) * ((p.N + c.bn - 1) / c.bn);
+        const long tiles = (long)((p.M + c.bm - 1) / c.bm) * ((p.N + c.bn - 1) / c.bn) * (p.n_phase > 1 ? p.n_phase : 1);
         const long slots = 256L * c.per_cu;
         const long rounds = (tiles + slots - 1) / slots;
         const long cost = rounds * c.per_cu * c.bm * c.bn * c.eff_pct;

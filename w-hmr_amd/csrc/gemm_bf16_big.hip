@@ -62,6 +62,16 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
     const int m0 = tm * BM, n0 = tn * BN;
     const bf16_t* __restrict__ A = (const bf16_t*)p.A;
     const bf16_t* __restrict__ W = (const bf16_t*)p.W;
+    int PH = p.PH, PW = p.PW;
+    int64_t c_off = p.c_off;
+    if constexpr (GATHER) {
+        if (p.n_phase > 1) {                  // sub-pixel deconv phase of this block (gemm_params.h)
+            const int py = blockIdx.y >> 1, px = blockIdx.y & 1;
+            W += (size_t)blockIdx.y * p.phase_w_stride;
+            PH -= py; PW -= px;
+            c_off += py * p.phase_cy + px * p.phase_cx;
+        }
+    }
 
     // ---- staging geometry: chunk c = tid + THREADS*i -> tile row tid/CPR + RP*i, physical slot tid%CPR
     const int srow = tid / CPR, pc = tid % CPR;
@@ -78,8 +88,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
             const int ohw = p.OH * p.OW;
             const int b = m / ohw, rem = m - b * ohw;
             const int oy = rem / p.OW, ox = rem - oy * p.OW;
-            a_y[i] = oy * p.SH - p.PH;
-            a_x[i] = ox * p.SW - p.PW;
+            a_y[i] = oy * p.SH - PH;
+            a_x[i] = ox * p.SW - PW;
             a_src[i] = A + (size_t)b * p.IH * p.IW * p.Cin + lc * 8;
         } else {
             a_src[i] = A + (size_t)m * p.lda + lc * 8;
@@ -344,7 +354,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
                 const int ohw = p.OH * p.OW;
                 const int b = m / ohw, rem = m - b * ohw;
                 const int oy = rem / p.OW, ox = rem - oy * p.OW;
-                crow = (size_t)(p.c_off + b * p.osb + oy * p.osy + ox * p.osx);
+                crow = (size_t)(c_off + b * p.osb + oy * p.osy + ox * p.osx);
             } else {
                 crow = (size_t)m * p.ldc;
             }
@@ -386,7 +396,7 @@ static int launch_big(const whmr_gemm& p, hipStream_t st) {
         attr_done = true;
     }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(cfg::THREADS), cfg::LDS, st, p);
+    hipLaunchKernelGGL(kern, dim3(tiles, GATHER && p.n_phase > 1 ? p.n_phase : 1), dim3(cfg::THREADS), cfg::LDS, st, p);
     WHMR_CHECK_LAUNCH();
     return 0;
 }

@@ -21,4 +21,8 @@ struct whmr_gemm {
     int64_t c_off, osb, osy, osx;
     void* workspace;        // optional scratch for split-K partial sums (fp32 kernel, skinny shapes); may be null
     int64_t workspace_bytes;
+    // Sub-pixel phases of ConvTranspose2d(k4, s2, p1) in ONE launch (bf16 kernel, a_mode = c_mode = 1): n_phase = 4,
+    // phase = blockIdx.y = 2*py + px:  W += phase*phase_w_stride;  PH -= py;  PW -= px;  c_off += py*phase_cy + px*phase_cx.
+    int32_t n_phase, pad_;
+    int64_t phase_w_stride, phase_cy, phase_cx;
 };

@@ -321,8 +321,10 @@ class WHMR(nn.Module):
                 for px in range(2):
                     taps = [w[:, :, 3 - py - 2 * a, 3 - px - 2 * b] for a in range(2) for b in range(2)]   # each [Cin, Cout]
                     wp = torch.stack(taps, 0).permute(2, 0, 1).reshape(w.shape[1], -1) * s[:, None]
-                    phases.append(wp.contiguous().to(self._dt) if self._dt == torch.float32 else L.cast_bf16(wp.contiguous()))
-            return phases, t.float().contiguous()
+                    phases.append(wp.contiguous())
+            if self._dt == torch.float32:
+                return phases, t.float().contiguous()
+            return L.cast_bf16(torch.stack(phases, 0).contiguous()), t.float().contiguous()        # [4, Cout, 4*Cin]
         return self._cache.get(('deconv', i, self.numerics), srcs, build)
 
     def _tz_operands(self):
@@ -345,6 +347,12 @@ class WHMR(nn.Module):
         phases, shift = self._deconv_operands(i)
         Cout = phases[0].shape[0]
         out = torch.empty(B, 2 * H, 2 * W, Cout, dtype=self._dt, device=x_nhwc.device)
+        if self._dt != torch.float32:          # all 4 sub-pixel phases in one launch (4x the tiles to fill the CUs)
+            L.gemm(x_nhwc, phases, out, bias=shift, act=L.ACT_RELU,
+                   conv=dict(IH=H, IW=W, Cin=Cin, OH=H, OW=W, KW=2, SH=1, SW=1, PH=1, PW=1),
+                   scatter=dict(c_off=0, osb=4 * H * W * Cout, osy=4 * W * Cout, osx=2 * Cout),
+                   phases=dict(cy=2 * W * Cout, cx=Cout))
+            return out
         for py in range(2):
             for px in range(2):
                 L.gemm(x_nhwc, phases[py * 2 + px], out, bias=shift, act=L.ACT_RELU,
