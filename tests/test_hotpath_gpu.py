@@ -194,3 +194,22 @@ def test_config1_hmr_plumbing_matches_reference_fixture(dev, assets):
     smpl = SMPL(arrays=assets['smpl']).to(dev)
     out = smpl(betas=shape, body_pose=rot[:, 1:], global_orient=rot[:, :1], pose2rot=False)
     assert _rel(out.vertices, g['verts']) < 1e-4
+
+
+def test_whmr_hip_graph_replay_matches_eager(dev, assets, state_dict, gold):
+    """the whole forward (ViT + deconvs + 3-iteration loop, ~330 launches) captured once and replayed as a HIP graph"""
+    from whmr_amd.graph import GraphedForward
+    m = _load_model(assets, state_dict, 'fp32', dev)
+    kw = _inputs(gold, dev)
+    args = (kw['x'], None, kw['center'], kw['scale'], kw['bbox_height'], kw['orig_shape'], kw['bbox_info'])
+    eager = {k: v.clone() for k, v in m(*args, full_x=kw['full_x']).items()}
+    fast = GraphedForward(m, *args, full_x=kw['full_x'])
+    out = fast(*args, full_x=kw['full_x'])
+    for k in eager:
+        assert torch.allclose(out[k], eager[k], rtol=1e-5, atol=1e-6), k
+    # new inputs through the same graph
+    x2 = kw['x'].flip(0).contiguous()
+    out2 = {k: v.clone() for k, v in fast(x2, None, kw['center'].flip(0), kw['scale'].flip(0), kw['bbox_height'].flip(0),
+                                          kw['orig_shape'].flip(0), kw['bbox_info'].flip(0), full_x=kw['full_x'].flip(0)).items()}
+    for k in eager:
+        assert torch.allclose(out2[k], eager[k].flip(0), rtol=1e-4, atol=1e-5), k

@@ -24,3 +24,16 @@ for name, kw in (('no full_x (cam_rotmat = I)', {}),):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     print('WHMR forward B=%d %s: %.2f ms  %.0f img/s' % (B, name, dt * 1e3, B / dt))
+from whmr_amd.graph import GraphedForward
+for b in (1, 8, B):
+    a2 = tuple(t[:b].contiguous() if torch.is_tensor(t) else t for t in args)
+    for _ in range(3): m(*a2)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps): m(*a2)
+    torch.cuda.synchronize(); te = (time.perf_counter() - t0) / steps
+    fast = GraphedForward(m, *a2)
+    for _ in range(3): fast(*a2)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps): fast(*a2)
+    torch.cuda.synchronize(); tg = (time.perf_counter() - t0) / steps
+    print('B=%d: eager %.2f ms (%.0f img/s) | HIP graph %.2f ms (%.0f img/s)' % (b, te * 1e3, b / te, tg * 1e3, b / tg))

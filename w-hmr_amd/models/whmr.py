@@ -54,6 +54,9 @@ def load_assets(smpl_mean_params=SMPL_MEAN_PARAMS):
             'Dmap0': D[0], 'Dmap1': D[1], 'mean_params': {k: mp[k] for k in ('pose', 'shape', 'cam')}}
 
 
+_H36M_IDX = {}
+
+
 def h36m_joints(verts, J_regressor):
     """whmr.py:176-180 / :647-651: J_regressor [17,6890] . verts, LSP-14 subset, pelvis-centred (fp32 GEMM kernel)."""
     B = verts.shape[0]
@@ -62,7 +65,10 @@ def h36m_joints(verts, J_regressor):
     jj = torch.empty(J.shape[0], B * 3, dtype=torch.float32, device=verts.device)
     L.gemm(J, vt, jj)
     jj = jj.view(J.shape[0], B, 3).permute(1, 0, 2)
-    return jj[:, H36M_TO_J14] - jj[:, [0]]
+    idx = _H36M_IDX.get(verts.device)
+    if idx is None:
+        idx = _H36M_IDX[verts.device] = torch.tensor(H36M_TO_J14, dtype=torch.long, device=verts.device)
+    return jj.index_select(1, idx) - jj[:, :1]
 
 
 class _Cache:
@@ -134,7 +140,7 @@ class Regressor(nn.Module):
         if Tz is not None:
             s = cam[:, 0]
             focal = s * bbox_height * Tz / 2.                                        # whmr.py:147-149
-            cam_center = orig_shape[:, [1, 0]] / 2.
+            cam_center = orig_shape.flip(1) / 2.                                     # (W, H) / 2; no host-side index tensor
             cam_t = convert_pare_to_full_img_cam(cam, bbox_height, center, orig_shape[:, 1], orig_shape[:, 0], Tz=Tz)
             kp_w = L.perspective(joints, None, cam_t.contiguous(), focal.contiguous(), cam_center.contiguous(),
                                  post_div=cam_center.contiguous(), post_shift=-1.0)   # whmr.py:165-173
