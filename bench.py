@@ -19,7 +19,11 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-VIT_FLOP_PER_IMG = {'vit224': 34.94e9, 'vit256x192': 34.20e9}
+VIT_FLOP_PER_IMG = {'vit224': 34.94e9, 'vit256x192': 34.20e9, 'whmr': 34.20e9 + 9.26e9 + 1.98e9}
+METRIC = {'vit224': 'images/sec ViT-B 224^2 batch-64 fwd', 'vit256x192': 'images/sec ViT-B 256x192 batch-64 fwd',
+          'whmr': 'images/sec full W-HMR fwd (ViT-B + 3-iter MAF loop + orientation) batch-64'}
+WORKLOAD = {'vit224': 'ViT-B/16 backbone forward', 'vit256x192': 'ViT-B/16 backbone forward',
+            'whmr': 'full W-HMR forward (ViT-B + deconv pyramid + Tz head + 3-iteration MAF/regressor/SMPL loop + global orientation)'}
 
 
 def parse():
@@ -46,6 +50,18 @@ def build_workload(args, dev):
         m = m.to(dev).eval()
         x = synth.make_inputs(args.batch, 7, size)['x'].to(dev)
         return (lambda: m(x)), sd, x, size
+    if args.workload == 'whmr':
+        # BASELINE configs[2]: full W-HMR forward (ViT-B + deconvs + Tz head + 3-iteration MAF/regressor/SMPL loop +
+        # global orientation), 256x192 crops, camera rotation given (the cam_model ResNet-50 is not a hot-path kernel row)
+        from whmr_amd.models import whmr_net
+        assets = synth.make_assets(0)
+        sd = synth.make_state_dict(0, assets)
+        m = whmr_net(None, assets=assets, numerics=args.numerics)
+        m.load_state_dict(sd, strict=False)
+        m = m.to(dev).eval()
+        inp = {k: v.to(dev) for k, v in synth.make_inputs(args.batch, 7).items()}
+        a = (inp['x'], None, inp['center'], inp['scale'], inp['bbox_height'], inp['orig_shape'], inp['bbox_info'])
+        return (lambda: m(*a)), None, inp['x'], (256, 192)
     raise SystemExit('unknown workload %s' % args.workload)
 
 
@@ -147,7 +163,7 @@ def main():
     dt = reduce_max_time(dt, dist, dev)
 
     gemm = [(f, e0.elapsed_time(e1) * 1e-3) for (name, f, e0, e1) in prof if name == 'gemm_bf16']
-    traffic = gemm_traffic()
+    traffic = gemm_traffic() if args.workload == 'vit224' else None
     n_launch = max(len(gemm), 1)
     flops_per_launch = sum(f for f, _ in gemm) / n_launch
     avg_s = sum(t for _, t in gemm) / n_launch
@@ -155,12 +171,12 @@ def main():
     peak = 2500.0                                                     # dense bf16 MFMA, MI355X_MICROARCH.md
     if rank == 0:
         res = {
-            'metric': 'images/sec ViT-B 224^2 batch-64 fwd', 'value': aggregate_value(world, args.batch, args.steps, dt),
+            'metric': METRIC[args.workload], 'value': aggregate_value(world, args.batch, args.steps, dt),
             'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': args.numerics, 'data': 'synthetic',
-            'config': {'workload': 'ViT-B/16 backbone forward (%s), %dx%d crops, batch %d per GPU, random-init weights'
-                                   % (args.workload, size[0], size[1], args.batch),
+            'config': {'workload': '%s (%s), %dx%d crops, batch %d per GPU, random-init weights'
+                                   % (WORKLOAD[args.workload], args.workload, size[0], size[1], args.batch),
                        'global_batch': world * args.batch, 'parallelism': 'replicas x%d (no data-path collective)' % world},
             'model_tflops': VIT_FLOP_PER_IMG[args.workload] * world * args.batch * args.steps / dt / 1e12,
             'roofline': {'bound': 'mfma', 'kernel': 'gemm_bf16_big_kernel (all %d GEMM launches of one step)' % len(gemm),
@@ -169,7 +185,7 @@ def main():
                          'traffic': traffic['bytes_per_launch'] if traffic else None,
                          'traffic_note': traffic['note'] if traffic else 'no PMC pass committed'},
         }
-        if not args.no_cpu and world == 1:
+        if not args.no_cpu and world == 1 and sd is not None:
             res['cpu_baseline'] = cpu_baseline(sd, x.cpu(), size)
         else:
             res['cpu_baseline'] = None
