@@ -19,10 +19,11 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-VIT_FLOP_PER_IMG = {'vit224': 34.94e9, 'vit256x192': 34.20e9, 'whmr': 34.20e9 + 9.26e9 + 1.98e9}
+VIT_FLOP_PER_IMG = {'vit224': 34.94e9, 'vit256x192': 34.20e9, 'vitl256x192': 119.9e9, 'whmr': 34.20e9 + 9.26e9 + 1.98e9}
 METRIC = {'vit224': 'images/sec ViT-B 224^2 batch-64 fwd', 'vit256x192': 'images/sec ViT-B 256x192 batch-64 fwd',
+          'vitl256x192': 'images/sec ViT-L 256x192 fwd',
           'whmr': 'images/sec full W-HMR fwd (ViT-B + 3-iter MAF loop + orientation) batch-64'}
-WORKLOAD = {'vit224': 'ViT-B/16 backbone forward', 'vit256x192': 'ViT-B/16 backbone forward',
+WORKLOAD = {'vit224': 'ViT-B/16 backbone forward', 'vit256x192': 'ViT-B/16 backbone forward', 'vitl256x192': 'ViT-L/16 backbone forward',
             'whmr': 'full W-HMR forward (ViT-B + deconv pyramid + Tz head + 3-iteration MAF/regressor/SMPL loop + global orientation)'}
 
 
@@ -41,10 +42,12 @@ def parse():
 def build_workload(args, dev):
     from oracle import synth                       # synthetic weights / inputs only (generator, not a compute path)
     from whmr_amd.models.pose_vit import ViT
-    if args.workload in ('vit224', 'vit256x192'):
+    if args.workload in ('vit224', 'vit256x192', 'vitl256x192'):
         size = (224, 224) if args.workload == 'vit224' else (256, 192)
-        sd = synth.make_vit_state(1, size)
-        m = ViT(img_size=size, patch_size=16, embed_dim=768, depth=12, num_heads=12, ratio=1, mlp_ratio=4,
+        large = args.workload == 'vitl256x192'                  # BASELINE configs[4] backbone: ViT-L/16, dim 1024, depth 24
+        dim, depth, heads = (1024, 24, 16) if large else (768, 12, 12)
+        sd = synth.make_vit_state(1, size, embed_dim=dim, depth=depth)
+        m = ViT(img_size=size, patch_size=16, embed_dim=dim, depth=depth, num_heads=heads, ratio=1, mlp_ratio=4,
                 qkv_bias=True, drop_path_rate=0.3, numerics=args.numerics)
         m.load_state_dict(sd, strict=True)
         m = m.to(dev).eval()
@@ -65,7 +68,7 @@ def build_workload(args, dev):
     raise SystemExit('unknown workload %s' % args.workload)
 
 
-def cpu_baseline(sd, x_cpu, size):
+def cpu_baseline(sd, x_cpu, size, heads=12):
     """Oracle (pure-PyTorch fp32 restatement of the reference ViT) on the host cores, bounded sample (~10-20 s).
 
     The box exposes 256 logical CPUs but the container's usable share is much smaller (more threads run slower), so a
@@ -77,9 +80,9 @@ def cpu_baseline(sd, x_cpu, size):
     with torch.no_grad():
         for th in sorted({min(t, ncpu) for t in (8, 16, 32, 64)}):
             torch.set_num_threads(th)
-            vit_forward(sd, x_cpu[:2])
+            vit_forward(sd, x_cpu[:2], num_heads=heads)
             t0 = time.perf_counter()
-            vit_forward(sd, x_cpu[:8])
+            vit_forward(sd, x_cpu[:8], num_heads=heads)
             dt = time.perf_counter() - t0
             if best is None or dt < best[1]:
                 best = (th, dt)
@@ -87,7 +90,7 @@ def cpu_baseline(sd, x_cpu, size):
         n = x_cpu.shape[0]
         reps, t0 = 0, time.perf_counter()
         while reps < 1 or (time.perf_counter() - t0 < 10.0 and reps < 8):
-            vit_forward(sd, x_cpu)
+            vit_forward(sd, x_cpu, num_heads=heads)
             reps += 1
         dt = (time.perf_counter() - t0) / reps
     return {'value': n / dt, 'unit': 'images/sec', 'cores': best[0], 'kind': 'port',
@@ -186,7 +189,7 @@ def main():
                          'traffic_note': traffic['note'] if traffic else 'no PMC pass committed'},
         }
         if not args.no_cpu and world == 1 and sd is not None:
-            res['cpu_baseline'] = cpu_baseline(sd, x.cpu(), size)
+            res['cpu_baseline'] = cpu_baseline(sd, x.cpu(), size, 16 if args.workload == 'vitl256x192' else 12)
         else:
             res['cpu_baseline'] = None
         print(json.dumps(res), flush=True)

@@ -158,6 +158,11 @@ def test_whmr_forward_fp32_matches_reference_fixture(dev, assets, state_dict, go
     o2 = m(**kw, cam_rotmat=torch.from_numpy(gold['out_cam_rotmat']).to(dev))
     assert _rel(o2['smpl_vertices'], gold['out_smpl_vertices']) < 1e-4
     assert torch.equal(o2['render_rotmat'], o2['cam_rotmat'])
+    # one full image shared by every person crop (batch-1 full_x is broadcast; the ResNet-50 runs once)
+    kw = _inputs(gold, dev)
+    kw['full_x'] = kw['full_x'][:1]
+    o3 = m(**kw)
+    assert torch.allclose(o3['cam_rotmat'][1], o3['cam_rotmat'][0]) and _rel(o3['cam_rotmat'][:1], gold['out_cam_rotmat'][:1]) < 1e-4
 
 
 def test_whmr_forward_bf16_error_report(dev, assets, state_dict, gold):

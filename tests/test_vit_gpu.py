@@ -57,3 +57,20 @@ def test_vit_full_size_properties(dev):
     b = m(x[32:]).clone()
     assert torch.equal(full, torch.cat([a, b]))
     assert torch.isfinite(full).all()
+
+
+def test_vit_large_256x192_matches_oracle(dev):
+    """BASELINE config #5 backbone (ViT-L/16: dim 1024, 16 heads; depth cut to 2 to keep the oracle fast), fp32 + bf16"""
+    from oracle import synth
+    from oracle.vit import vit_forward
+    from whmr_amd.models.pose_vit import ViT
+    sd = synth.make_vit_state(3, (256, 192), embed_dim=1024, depth=2)
+    x = synth.make_inputs(3, 9, (256, 192))['x']
+    ref = vit_forward(sd, x, num_heads=16)
+    for numerics, tol in (('fp32', 1e-4), ('bf16', 5e-2)):
+        m = ViT(img_size=(256, 192), patch_size=16, embed_dim=1024, depth=2, num_heads=16, ratio=1, mlp_ratio=4,
+                qkv_bias=True, drop_path_rate=0.5, numerics=numerics)
+        m.load_state_dict(sd, strict=True)
+        out = m.to(dev).eval()(x.to(dev))
+        assert out.shape == (3, 1024, 16, 12)
+        assert _rel(out.cpu(), ref) < tol, numerics

@@ -422,8 +422,12 @@ class WHMR(nn.Module):
         render_rotmat = None
         if cam_rotmat is None:                                                        # whmr.py:509-524
             if full_x is not None:
+                # demo/tester.py:161 replicates the full image once per person; a batch-1 full_x is accepted here and its
+                # camera prediction broadcast (identical result, the ~80 GFLOP ResNet-50 runs once per image -- SURVEY 8f N1)
                 pred, _ = self.cam_model(full_x)
                 _, pitch, roll = convert_preds_to_angles(*pred, loss_type='softargmax_l2')
+                if pitch.shape[0] == 1 and B > 1:
+                    pitch, roll = pitch.expand(B), roll.expand(B)
                 pitch, roll = pitch.unsqueeze(-1), roll.unsqueeze(-1)
                 zeros = torch.zeros((B, 1), device=dev)
                 cam_rotmat = batch_euler2matrix(torch.cat([pitch, zeros, roll], dim=1).float())
