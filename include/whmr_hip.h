@@ -105,17 +105,27 @@ struct whmr_smpl_model {
 };
 /* pose9 [B,24,9] (+ optional unbiased Gram-Schmidt, whmr.py:129-130) -> rotmat [B,24,9], angle-axis [B,72] (whmr.py:174),
  * skinning transforms A [B,24,12], posed joints [B,24,3], pose feature [B,207].  Null outputs are skipped (A required). */
-int whmr_smpl_pose_chain(const struct whmr_smpl_model* m, const float* pose9, const float* betas, int B, int do_gs,
-                         float* rotmat, float* aa, float* A, float* posed_joints, float* pose_feat, void* stream);
-/* blend shapes + pose-corrective offsets + linear blend skinning -> verts [B,6890,3]. */
-int whmr_smpl_skin(const struct whmr_smpl_model* m, const float* betas, const float* pose_feat, const float* A, int B,
-                   float* verts, void* stream);
+/* pose_stride / beta_stride: row strides in elements (the operands may be column slices of a [.., 216|10|3] state buffer). */
+int whmr_smpl_pose_chain(const struct whmr_smpl_model* m, const float* pose9, long pose_stride, const float* betas,
+                         long beta_stride, int B, int do_gs, float* rotmat, float* aa, float* A, float* posed_joints,
+                         float* pose_feat, void* stream);
+/* blend shapes + pose-corrective offsets + linear blend skinning -> verts [B,6890,3].  pose_off (nullable) = [B,20670]
+ * pose_feat . posedirs precomputed by whmr_gemm_f32; null = computed in the kernel. */
+int whmr_smpl_skin(const struct whmr_smpl_model* m, const float* betas, long beta_stride, const float* pose_feat, const float* A,
+                   const float* pose_off, int B, float* verts, void* stream);
 /* joints49 [B,49,3] (24 posed + 21 vertex picks + 9 regressed, JOINT_MAP), optional smpl_joints45 [B,45,3]
  * (whmr.py:186-187) and markers [B,n_markers,3] (whmr.py:184). */
 /* scratch: >= B*33*3 floats of workspace.  When smpl_joints45 is requested, J_regressor_extra and J_regressor must be one
  * contiguous [33,6890] buffer (extra rows first). */
 int whmr_smpl_joints(const struct whmr_smpl_model* m, const float* verts, const float* posed_joints, int B,
                      float* joints49, float* smpl_joints45, float* markers, float* scratch, void* stream);
+
+/* Tail of Regressor.forward (whmr.py:142-174,190) fused: state row = [pose(216) | shape(10) | cam(3)] (row stride
+ * state_stride) -> theta [B,85], kp_2d [B,49,2] (geometry.py:289-307), focal = s*h*Tz/2 [B] (whmr.py:147-149), cam_t [B,3]
+ * (geometry.py:139-157), kp_2d_w [B,49,2] = perspective(joints, cam_t, focal, centre)/centre - 1 (whmr.py:165-173). */
+int whmr_regressor_post(const float* state, long state_stride, const float* aa, const float* joints49, const float* Tz,
+                        const float* bbox_h, const float* center, const float* orig_shape, int B, float focal0, float res_w,
+                        float res_h, float* theta, float* kp2d, float* kp2d_w, float* cam_t, float* focal, void* stream);
 
 /* ---- MAF sampler: models/maf_extractor.py:75-143 ------------------------------------------------------------------ */
 struct whmr_maf_weights {

@@ -54,8 +54,9 @@ _SIGS = {
     'whmr_mat_to_aa': [_P, _P, _I, _P],
     'whmr_perspective': [_P, _P, _I, _P, _P, _I, _P, _P, _F, _P, _I, _I, _P],
     'whmr_weak_projection': [_P, _P, _P, _I, _I, _F, _F, _F, _P],
-    'whmr_smpl_pose_chain': [C.POINTER(WhmrSmplModel), _P, _P, _I, _I, _P, _P, _P, _P, _P, _P],
-    'whmr_smpl_skin': [C.POINTER(WhmrSmplModel), _P, _P, _P, _I, _P, _P],
+    'whmr_smpl_pose_chain': [C.POINTER(WhmrSmplModel), _P, _L, _P, _L, _I, _I, _P, _P, _P, _P, _P, _P],
+    'whmr_regressor_post': [_P, _L, _P, _P, _P, _P, _P, _P, _I, _F, _F, _F, _P, _P, _P, _P, _P, _P],
+    'whmr_smpl_skin': [C.POINTER(WhmrSmplModel), _P, _L, _P, _P, _P, _I, _P, _P],
     'whmr_smpl_joints': [C.POINTER(WhmrSmplModel), _P, _P, _I, _P, _P, _P, _P, _P],
     'whmr_maf_sample': [_P, _I, _L, _L, _L, _L, _I, _I, _P, _P, _P, _F, _F, _F, C.POINTER(WhmrMafWeights), _I, _I, _P, _L, _P, _P],
     'whmr_tz_tail': [_P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _F, _P, _P],
@@ -283,16 +284,40 @@ def weak_projection(points, cam, focal=1000.0, res_w=256.0, res_h=256.0):
     return out
 
 
+def _rows(t, width):
+    """pointer + row stride of a [B, width] fp32 matrix whose rows are contiguous (it may be a column slice)"""
+    assert t.dtype == torch.float32 and t.dim() == 2 and t.shape[1] == width and (t.stride(1) == 1 or width == 1)
+    return t.data_ptr(), t.stride(0)
+
+
 def smpl_pose_chain(model, pose9, betas, do_gs, rotmat, aa, A, posed_joints, pose_feat):
+    """pose9 [B,216] and betas [B,10]: rows contiguous, any row stride (slices of the regressor state buffer are fine)"""
     B = betas.shape[0]
-    _check(lib().whmr_smpl_pose_chain(C.byref(model), _f32c(pose9).data_ptr(), _f32c(betas).data_ptr(), B, int(do_gs),
-                                      _ptr(rotmat), _ptr(aa), A.data_ptr(), _ptr(posed_joints), _ptr(pose_feat),
-                                      _stream()), 'whmr_smpl_pose_chain')
+    pp, ps = _rows(pose9, 216)
+    bp, bs = _rows(betas, 10)
+    _check(lib().whmr_smpl_pose_chain(C.byref(model), pp, ps, bp, bs, B, int(do_gs), _ptr(rotmat), _ptr(aa), A.data_ptr(),
+                                      _ptr(posed_joints), _ptr(pose_feat), _stream()), 'whmr_smpl_pose_chain')
 
 
-def smpl_skin(model, betas, pose_feat, A, verts):
-    _check(lib().whmr_smpl_skin(C.byref(model), betas.data_ptr(), pose_feat.data_ptr(), A.data_ptr(), betas.shape[0],
-                                verts.data_ptr(), _stream()), 'whmr_smpl_skin')
+def smpl_skin(model, betas, pose_feat, A, verts, pose_off=None):
+    bp, bs = _rows(betas, 10)
+    _check(lib().whmr_smpl_skin(C.byref(model), bp, bs, pose_feat.data_ptr(), A.data_ptr(), _ptr(pose_off),
+                                betas.shape[0], verts.data_ptr(), _stream()), 'whmr_smpl_skin')
+
+
+def regressor_post(state, aa, joints49, Tz, bbox_h, center, orig_shape, focal0=1000.0, res_w=256.0, res_h=256.0):
+    """state [B,229] = [pose | shape | cam] rows (any row stride) -> theta, kp_2d, kp_2d_w, cam_t, focal (one launch)"""
+    _dev(state, aa, joints49, Tz, bbox_h, center, orig_shape)
+    B = state.shape[0]
+    sp, ss = _rows(state, 229)
+    f32 = dict(dtype=torch.float32, device=state.device)
+    theta, kp, kpw = torch.empty(B, 85, **f32), torch.empty(B, 49, 2, **f32), torch.empty(B, 49, 2, **f32)
+    cam_t, focal = torch.empty(B, 3, **f32), torch.empty(B, **f32)
+    _check(lib().whmr_regressor_post(sp, ss, _f32c(aa).data_ptr(), _f32c(joints49).data_ptr(), _f32c(Tz).data_ptr(),
+                                     _f32c(bbox_h).data_ptr(), _f32c(center).data_ptr(), _f32c(orig_shape).data_ptr(), B,
+                                     focal0, res_w, res_h, theta.data_ptr(), kp.data_ptr(), kpw.data_ptr(), cam_t.data_ptr(),
+                                     focal.data_ptr(), _stream()), 'whmr_regressor_post')
+    return theta, kp, kpw, cam_t, focal
 
 
 def smpl_joints(model, verts, posed_joints, joints49, smpl_joints45, markers):

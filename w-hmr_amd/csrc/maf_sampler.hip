@@ -27,9 +27,10 @@ __global__ __launch_bounds__(128) void maf_sample_kernel(const TF* __restrict__ 
                                                          float focal, float res_w, float res_h,
                                                          const whmr_maf_weights wts, int P, float* __restrict__ out,
                                                          long out_stride, float* __restrict__ point_feat) {
-    __shared__ float sF[PT][CF];
-    __shared__ float sY0[PT][128];
-    __shared__ float sY1[PT][64];
+    // point-minor layouts: one ds_read_b128 fetches a channel's value for 4 points
+    __shared__ __attribute__((aligned(16))) float sF[CF][PT];
+    __shared__ __attribute__((aligned(16))) float sY0[128][PT];
+    __shared__ __attribute__((aligned(16))) float sY1[64][PT];
     __shared__ float sXY[PT][2];
     const int tid = threadIdx.x;
     const int b = blockIdx.y, p0 = blockIdx.x * PT;
@@ -59,8 +60,8 @@ __global__ __launch_bounds__(128) void maf_sample_kernel(const TF* __restrict__ 
     // ---- bilinear gather (ATen grid_sampler_2d, align_corners=True, zeros padding)
     const TF* fb = fmap + (size_t)b * sb;
     for (int pp = 0; pp < np && direct; ++pp) {
-        sF[pp][tid] = io<TF>::ld(fb + (size_t)tid * sc + (size_t)(p0 + pp) * sx);
-        sF[pp][tid + 128] = io<TF>::ld(fb + (size_t)(tid + 128) * sc + (size_t)(p0 + pp) * sx);
+        sF[tid][pp] = io<TF>::ld(fb + (size_t)tid * sc + (size_t)(p0 + pp) * sx);
+        sF[tid + 128][pp] = io<TF>::ld(fb + (size_t)(tid + 128) * sc + (size_t)(p0 + pp) * sx);
     }
     for (int pp = 0; pp < np && !direct; ++pp) {
         const float ix = ((sXY[pp][0] + 1.f) / 2.f) * (float)(W - 1);
@@ -80,66 +81,68 @@ __global__ __launch_bounds__(128) void maf_sample_kernel(const TF* __restrict__ 
             if (oky0 && okx1) v += io<TF>::ld(fc + y0 * sy + x1 * sx) * wne;
             if (oky1 && okx0) v += io<TF>::ld(fc + y1 * sy + x0 * sx) * wsw;
             if (oky1 && okx1) v += io<TF>::ld(fc + y1 * sy + x1 * sx) * wse;
-            sF[pp][c] = v;
+            sF[c][pp] = v;
             if (point_feat) point_feat[((size_t)b * CF + c) * P + p0 + pp] = v;
         }
     }
-    for (int pp = np; pp < PT; ++pp) { sF[pp][tid] = 0.f; sF[pp][tid + 128] = 0.f; }
+    for (int pp = np; pp < PT; ++pp) { sF[tid][pp] = 0.f; sF[tid + 128][pp] = 0.f; }
     __syncthreads();
 
-    // ---- layer 0: 256 -> 128, thread = output channel, all PT points
-    {
+    // ---- point MLP.  acc[q] += sum_i W^T[i][o] * in[i][pbase + q]: the weights of 8 consecutive inputs are fetched as 8
+    // independent (coalesced, L2-resident) loads before any FMA -- one exposed load latency per 8 inputs instead of one per
+    // input -- and the activations come from LDS as 16-B / 8-B broadcast-free reads (point-minor layout).
+    auto layer = [&](const float* __restrict__ wt, int ld, int o, int n_in, const float (*in)[PT], int pbase, auto& acc) {
+        constexpr int NP = sizeof(acc) / sizeof(float);
+        for (int i = 0; i < n_in; i += 8) {
+            float w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w[u] = wt[(size_t)(i + u) * ld + o];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if constexpr (NP == 8) {
+                    const float4 a = *(const float4*)&in[i + u][0], c = *(const float4*)&in[i + u][4];
+                    acc[0] = fmaf(w[u], a.x, acc[0]); acc[1] = fmaf(w[u], a.y, acc[1]); acc[2] = fmaf(w[u], a.z, acc[2]); acc[3] = fmaf(w[u], a.w, acc[3]);
+                    acc[4] = fmaf(w[u], c.x, acc[4]); acc[5] = fmaf(w[u], c.y, acc[5]); acc[6] = fmaf(w[u], c.z, acc[6]); acc[7] = fmaf(w[u], c.w, acc[7]);
+                } else if constexpr (NP == 4) {
+                    const float4 a = *(const float4*)&in[i + u][pbase];
+                    acc[0] = fmaf(w[u], a.x, acc[0]); acc[1] = fmaf(w[u], a.y, acc[1]); acc[2] = fmaf(w[u], a.z, acc[2]); acc[3] = fmaf(w[u], a.w, acc[3]);
+                } else {
+                    const float2 a = *(const float2*)&in[i + u][pbase];
+                    acc[0] = fmaf(w[u], a.x, acc[0]); acc[1] = fmaf(w[u], a.y, acc[1]);
+                }
+            }
+        }
+    };
+    {   // layer 0: 256 -> 128, thread = output channel, all PT points
         float acc[PT];
         const float bv = wts.b0[tid];
 #pragma unroll
         for (int pp = 0; pp < PT; ++pp) acc[pp] = bv;
-        for (int i = 0; i < CF; ++i) {
-            const float w = wts.w0t[i * 128 + tid];
+        layer(wts.w0t, 128, tid, CF, sF, 0, acc);
 #pragma unroll
-            for (int pp = 0; pp < PT; ++pp) acc[pp] = fmaf(w, sF[pp][i], acc[pp]);
-        }
-#pragma unroll
-        for (int pp = 0; pp < PT; ++pp) sY0[pp][tid] = acc[pp] > 0.f ? acc[pp] : 0.01f * acc[pp];
+        for (int pp = 0; pp < PT; ++pp) sY0[tid][pp] = acc[pp] > 0.f ? acc[pp] : 0.01f * acc[pp];
     }
     __syncthreads();
-    // ---- layer 1: [128 | 256] -> 64, thread = (output channel, half of the points)
-    {
+    {   // layer 1: [128 | 256] -> 64, thread = (output channel, half of the points)
         const int o = tid & 63, hp = (tid >> 6) * (PT / 2);
         float acc[PT / 2];
         const float bv = wts.b1[o];
 #pragma unroll
         for (int q = 0; q < PT / 2; ++q) acc[q] = bv;
-        for (int i = 0; i < 128; ++i) {
-            const float w = wts.w1t[i * 64 + o];
+        layer(wts.w1t, 64, o, 128, sY0, hp, acc);
+        layer(wts.w1t + 128 * 64, 64, o, CF, sF, hp, acc);
 #pragma unroll
-            for (int q = 0; q < PT / 2; ++q) acc[q] = fmaf(w, sY0[hp + q][i], acc[q]);
-        }
-        for (int i = 0; i < CF; ++i) {
-            const float w = wts.w1t[(128 + i) * 64 + o];
-#pragma unroll
-            for (int q = 0; q < PT / 2; ++q) acc[q] = fmaf(w, sF[hp + q][i], acc[q]);
-        }
-#pragma unroll
-        for (int q = 0; q < PT / 2; ++q) sY1[hp + q][o] = acc[q] > 0.f ? acc[q] : 0.01f * acc[q];
+        for (int q = 0; q < PT / 2; ++q) sY1[o][hp + q] = acc[q] > 0.f ? acc[q] : 0.01f * acc[q];
     }
     __syncthreads();
-    // ---- layer 2: [64 | 256] -> 32, thread = (output channel, quarter of the points); ReLU; channel-major store
-    {
+    {   // layer 2: [64 | 256] -> 32, thread = (output channel, quarter of the points); ReLU; channel-major store
         const int o = tid & 31, qp = (tid >> 5) * (PT / 4);
         float acc[PT / 4];
         const float bv = wts.b2[o];
 #pragma unroll
         for (int q = 0; q < PT / 4; ++q) acc[q] = bv;
-        for (int i = 0; i < 64; ++i) {
-            const float w = wts.w2t[i * 32 + o];
-#pragma unroll
-            for (int q = 0; q < PT / 4; ++q) acc[q] = fmaf(w, sY1[qp + q][i], acc[q]);
-        }
-        for (int i = 0; i < CF; ++i) {
-            const float w = wts.w2t[(64 + i) * 32 + o];
-#pragma unroll
-            for (int q = 0; q < PT / 4; ++q) acc[q] = fmaf(w, sF[qp + q][i], acc[q]);
-        }
+        layer(wts.w2t, 32, o, 64, sY1, qp, acc);
+        layer(wts.w2t + 64 * 32, 32, o, CF, sF, qp, acc);
 #pragma unroll
         for (int q = 0; q < PT / 4; ++q) {
             const int p = p0 + qp + q;

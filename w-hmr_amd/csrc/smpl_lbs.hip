@@ -34,8 +34,8 @@ struct whmr_smpl_model {
     int32_t n_markers;
 };
 
-__global__ __launch_bounds__(64) void smpl_pose_chain_kernel(const whmr_smpl_model m, const float* __restrict__ pose9,
-                                                             const float* __restrict__ betas, int do_gs,
+__global__ __launch_bounds__(64) void smpl_pose_chain_kernel(const whmr_smpl_model m, const float* __restrict__ pose9, long pose_stride,
+                                                             const float* __restrict__ betas, long beta_stride, int do_gs,
                                                              float* __restrict__ rotmat, float* __restrict__ aa,
                                                              float* __restrict__ A, float* __restrict__ posed_joints,
                                                              float* __restrict__ pose_feat) {
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(64) void smpl_pose_chain_kernel(const whmr_smpl_mod
     const int b = blockIdx.x, lane = threadIdx.x;
     if (lane < NJ) {
         float r[9], o[9];
-        for (int k = 0; k < 9; ++k) r[k] = pose9[((size_t)b * NJ + lane) * 9 + k];
+        for (int k = 0; k < 9; ++k) r[k] = pose9[(size_t)b * pose_stride + lane * 9 + k];
         if (do_gs) gram_schmidt9(r, o); else for (int k = 0; k < 9; ++k) o[k] = r[k];
         for (int k = 0; k < 9; ++k) { sR[lane][k] = o[k]; if (rotmat) rotmat[((size_t)b * NJ + lane) * 9 + k] = o[k]; }
         if (aa) { float a3[3]; rotmat_to_aa3(o, a3); for (int k = 0; k < 3; ++k) aa[(size_t)b * 72 + lane * 3 + k] = a3[k]; }
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(64) void smpl_pose_chain_kernel(const whmr_smpl_mod
         // joint locations of the shaped rest mesh
         for (int c = 0; c < 3; ++c) {
             float acc = 0.f;
-            for (int l = 0; l < 10; ++l) acc = fmaf(m.J_shapedirs[(lane * 3 + c) * 10 + l], betas[(size_t)b * 10 + l], acc);
+            for (int l = 0; l < 10; ++l) acc = fmaf(m.J_shapedirs[(lane * 3 + c) * 10 + l], betas[(size_t)b * beta_stride + l], acc);
             sJ[lane][c] = m.J_template[lane * 3 + c] + acc;
         }
     }
@@ -89,9 +89,9 @@ __global__ __launch_bounds__(64) void smpl_pose_chain_kernel(const whmr_smpl_mod
 }
 
 template <int BT>
-__global__ __launch_bounds__(128) void smpl_skin_kernel(const whmr_smpl_model m, const float* __restrict__ betas,
+__global__ __launch_bounds__(128) void smpl_skin_kernel(const whmr_smpl_model m, const float* __restrict__ betas, long beta_stride,
                                                         const float* __restrict__ pose_feat, const float* __restrict__ A,
-                                                        int B, float* __restrict__ verts) {
+                                                        const float* __restrict__ pose_off, int B, float* __restrict__ verts) {
     __shared__ float sPF[NPF][BT];          // [k][b]: one ds_read_b128 pair fetches all BT coefficients of step k
     __shared__ float sBeta[10][BT];
     __shared__ __attribute__((aligned(16))) float sA[BT][NJ * 12];
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(128) void smpl_skin_kernel(const whmr_smpl_model m,
     }
     for (int e = tid; e < 10 * BT; e += 128) {
         const int k = e / BT, bb = e % BT;
-        sBeta[k][bb] = (b0 + bb < B) ? betas[(size_t)(b0 + bb) * 10 + k] : 0.f;
+        sBeta[k][bb] = (b0 + bb < B) ? betas[(size_t)(b0 + bb) * beta_stride + k] : 0.f;
     }
     for (int e = tid; e < BT * NJ * 12; e += 128) {
         const int bb = e / (NJ * 12);
@@ -131,7 +131,15 @@ __global__ __launch_bounds__(128) void smpl_skin_kernel(const whmr_smpl_model m,
             acc[bb][0] = t0 + a0; acc[bb][1] = t1 + a1; acc[bb][2] = t2 + a2;
         }
     }
-    {   // v_posed = v_shaped + posedirs^T . pose_feature   (verts.py:51-53); separate accumulator like the reference's matmul-then-add
+    if (pose_off) {   // pose-corrective offsets precomputed as one [B,207] x [207,20670] GEMM (whmr_gemm_f32): coalesced 12-B reads
+#pragma unroll
+        for (int bb = 0; bb < BT; ++bb) {
+            if (b0 + bb < B) {
+                const float* po = pose_off + ((size_t)(b0 + bb) * NV + v) * 3;
+                acc[bb][0] += po[0]; acc[bb][1] += po[1]; acc[bb][2] += po[2];
+            }
+        }
+    } else {   // v_posed = v_shaped + posedirs^T . pose_feature   (verts.py:51-53); separate accumulator like the reference's matmul-then-add
         float po[BT][3];
 #pragma unroll
         for (int bb = 0; bb < BT; ++bb) po[bb][0] = po[bb][1] = po[bb][2] = 0.f;
@@ -223,21 +231,26 @@ __global__ __launch_bounds__(256) void smpl_joints_kernel(const whmr_smpl_model 
     }
 }
 
-extern "C" int whmr_smpl_pose_chain(const whmr_smpl_model* m, const float* pose9, const float* betas, int B, int do_gs,
-                                    float* rotmat, float* aa, float* A, float* posed_joints, float* pose_feat, void* stream) {
+// pose_stride / beta_stride: row strides (elements) of pose9 [B,216] and betas [B,10] -- they may be column slices of the
+// regressor state buffer [.., pose(216) | shape(10) | cam(3)].
+extern "C" int whmr_smpl_pose_chain(const whmr_smpl_model* m, const float* pose9, long pose_stride, const float* betas,
+                                    long beta_stride, int B, int do_gs, float* rotmat, float* aa, float* A, float* posed_joints,
+                                    float* pose_feat, void* stream) {
     if (B <= 0 || !A) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(smpl_pose_chain_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, *m, pose9, betas, do_gs, rotmat, aa, A,
-                       posed_joints, pose_feat);
+    hipLaunchKernelGGL(smpl_pose_chain_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, *m, pose9, pose_stride, betas, beta_stride,
+                       do_gs, rotmat, aa, A, posed_joints, pose_feat);
     WHMR_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int whmr_smpl_skin(const whmr_smpl_model* m, const float* betas, const float* pose_feat, const float* A, int B,
-                              float* verts, void* stream) {
+// pose_off (nullable): [B, 20670] = pose_feat . posedirs computed by the caller with whmr_gemm_f32 (the 17 MB operand is then
+// streamed once by an MFMA GEMM instead of once per 8-image block of this kernel); null = compute it here.
+extern "C" int whmr_smpl_skin(const whmr_smpl_model* m, const float* betas, long beta_stride, const float* pose_feat, const float* A,
+                              const float* pose_off, int B, float* verts, void* stream) {
     if (B <= 0) return (int)hipErrorInvalidValue;
     constexpr int BT = 8;
     hipLaunchKernelGGL(smpl_skin_kernel<BT>, dim3((NV + 127) / 128, (B + BT - 1) / BT), dim3(128), 0, (hipStream_t)stream, *m,
-                       betas, pose_feat, A, B, verts);
+                       betas, beta_stride, pose_feat, A, pose_off, B, verts);
     WHMR_CHECK_LAUNCH();
     return 0;
 }
@@ -254,6 +267,54 @@ extern "C" int whmr_smpl_joints(const whmr_smpl_model* m, const float* verts, co
     hipLaunchKernelGGL(smpl_regress_kernel, dim3((B * R + 3) / 4), dim3(256), 0, st, m->J_regressor_extra, R, verts, B, scratch);
     hipLaunchKernelGGL(smpl_joints_kernel, dim3(B), dim3(256), 0, st, *m, verts, posed_joints, scratch, R, joints49,
                        smpl_joints45, markers);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+// Tail of Regressor.forward (whmr.py:142-174) in one launch per batch: weak-perspective key points (geometry.py:289-307),
+// focal length s*h*Tz/2 (whmr.py:147-149), full-image camera translation (geometry.py:139-157), perspective key points in the
+// full image normalised by the image centre (whmr.py:165-173) and theta = [cam | shape | angle-axis] (whmr.py:190).
+// state rows hold [... pose(216) | shape(10) | cam(3)]; `state` points at the pose column, row stride state_stride.
+__global__ __launch_bounds__(64) void regressor_post_kernel(const float* __restrict__ state, long state_stride,
+                                                            const float* __restrict__ aa, const float* __restrict__ joints49,
+                                                            const float* __restrict__ Tz, const float* __restrict__ bbox_h,
+                                                            const float* __restrict__ center, const float* __restrict__ orig_shape,
+                                                            float focal0, float res_w, float res_h, float* __restrict__ theta,
+                                                            float* __restrict__ kp2d, float* __restrict__ kp2d_w,
+                                                            float* __restrict__ cam_t_out, float* __restrict__ focal_out) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const float* st = state + (size_t)b * state_stride;
+    const float s = st[226], tx = st[227], ty = st[228];
+    const float h = bbox_h[b], tz = Tz[b];
+    const float focal = s * h * tz / 2.f;
+    const float H = orig_shape[2 * b], W = orig_shape[2 * b + 1];
+    const float ctx = tx + 2.f * (center[2 * b] - W / 2.f) / (s * h);
+    const float cty = ty + 2.f * (center[2 * b + 1] - H / 2.f) / (s * h);
+    if (lane == 0) {
+        cam_t_out[3 * b] = ctx; cam_t_out[3 * b + 1] = cty; cam_t_out[3 * b + 2] = tz;
+        focal_out[b] = focal;
+    }
+    for (int e = lane; e < 85; e += 64) theta[(size_t)b * 85 + e] = e < 3 ? st[226 + e] : (e < 13 ? st[216 + e - 3] : aa[(size_t)b * 72 + e - 13]);
+    const float tzw = 2.f * focal0 / (res_h * s + 1e-9f);
+    const float cxw = W / 2.f, cyw = H / 2.f;
+    for (int j = lane; j < 49; j += 64) {
+        const float* q = joints49 + ((size_t)b * 49 + j) * 3;
+        const float x = q[0], y = q[1], z = q[2];
+        const float zw = z + tzw;
+        kp2d[((size_t)b * 49 + j) * 2] = (focal0 * ((x + tx) / zw)) / (res_w / 2.f);
+        kp2d[((size_t)b * 49 + j) * 2 + 1] = (focal0 * ((y + ty) / zw)) / (res_h / 2.f);
+        const float zf = z + tz;
+        kp2d_w[((size_t)b * 49 + j) * 2] = (focal * ((x + ctx) / zf) + cxw) / cxw - 1.f;
+        kp2d_w[((size_t)b * 49 + j) * 2 + 1] = (focal * ((y + cty) / zf) + cyw) / cyw - 1.f;
+    }
+}
+
+extern "C" int whmr_regressor_post(const float* state, long state_stride, const float* aa, const float* joints49, const float* Tz,
+                                   const float* bbox_h, const float* center, const float* orig_shape, int B, float focal0, float res_w,
+                                   float res_h, float* theta, float* kp2d, float* kp2d_w, float* cam_t, float* focal, void* stream) {
+    if (B <= 0) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(regressor_post_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, state, state_stride, aa, joints49, Tz, bbox_h,
+                       center, orig_shape, focal0, res_w, res_h, theta, kp2d, kp2d_w, cam_t, focal);
     WHMR_CHECK_LAUNCH();
     return 0;
 }

@@ -73,6 +73,7 @@ class SMPL(nn.Module):
             # J = Jreg . (T + S beta) = (Jreg . T) + (Jreg . S) beta: fold the 24x6890 regressor into 24x3(+x10) constants
             Jreg64 = self.J_regressor.double()
             keep = {'regs': torch.cat([self.J_regressor_extra, self.J_regressor], 0).contiguous(),   # [9 + 24, 6890]
+                    'posedirs_t': self.posedirs.t().contiguous(),                                     # [20670, 207]: GEMM weight layout
                     'J_template': (Jreg64 @ self.v_template.double()).float().contiguous(),
                     'J_shapedirs': torch.einsum('jv,vcl->jcl', Jreg64, self.shapedirs.double()).float().contiguous(),
                     'parents': i32(self.parents), 'extra': i32(self.extra_joints_idxs), 'jmap': i32(self.joint_map),
@@ -97,16 +98,21 @@ class SMPL(nn.Module):
         B, dev = betas.shape[0], betas.device
         f32 = dict(dtype=torch.float32, device=dev)
         m = self._model()
-        betas = betas.float().contiguous()
-        pose9 = rotmats.reshape(B, 24, 9).float().contiguous()
+        # rows may be column slices of the regressor state buffer: only the innermost dimension has to be dense
+        betas = betas if (betas.dtype == torch.float32 and betas.stride(-1) == 1) else betas.float().contiguous()
+        pose9 = rotmats if rotmats.dim() == 2 else rotmats.reshape(B, 216)
+        pose9 = pose9 if (pose9.dtype == torch.float32 and pose9.stride(-1) == 1) else pose9.float().contiguous()
         rot = torch.empty(B, 24, 3, 3, **f32)
         aa = torch.empty(B, 72, **f32) if want_aa else None
         A = torch.empty(B, 24, 12, **f32)
         pj = torch.empty(B, 24, 3, **f32)
         pf = torch.empty(B, 207, **f32)
         L.smpl_pose_chain(m, pose9, betas, gram_schmidt, rot, aa, A, pj, pf)
+        # pose-corrective offsets: one fp32 MFMA GEMM [B,207] x [207,20670] (verts.py:51-53), then blend + skin
+        pose_off = torch.empty(B, self.NUM_VERTS * 3, **f32)
+        L.gemm(pf, self._dev_cache[2]['posedirs_t'], pose_off)
         verts = torch.empty(B, self.NUM_VERTS, 3, **f32)
-        L.smpl_skin(m, betas, pf, A, verts)
+        L.smpl_skin(m, betas, pf, A, verts, pose_off)
         joints = torch.empty(B, 49, 3, **f32)
         sj = torch.empty(B, 45, 3, **f32) if want_smpl_joints else None
         mk = torch.empty(B, m.n_markers, 3, **f32) if (want_markers and m.n_markers) else None

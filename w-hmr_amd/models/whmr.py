@@ -128,23 +128,20 @@ class Regressor(nn.Module):
         n0, n1 = self.Dmap0.shape[0], self.Dmap1.shape[0]
         return sub.view(n0, B, 3).permute(1, 0, 2).contiguous(), tmp.view(n1, B, 3).permute(1, 0, 2).contiguous()
 
-    def _outputs(self, out, pose_flat, shape, cam, scale, J_regressor, with_aux, Tz=None, orig_shape=None, center=None,
-                 bbox_height=None):
+    def _outputs(self, out, state, scale, J_regressor, with_aux, Tz=None, orig_shape=None, center=None, bbox_height=None):
+        """state [B,229] = [pose(216) | shape(10) | cam(3)] rows (possibly a strided view).  whmr.py:139-209."""
         verts, joints = out.vertices, out.joints
-        B = verts.shape[0]
-        kp_2d = L.weak_projection(joints, cam.contiguous(), 1000.0, float(cfg.IMG_RES.WIDTH), float(cfg.IMG_RES.HEIGHT))
-        d = {'theta': torch.cat([cam, shape, out.pose_aa], dim=1), 'verts': verts, 'kp_2d': kp_2d, 'kp_3d': joints,
-             'smpl_kp_3d': out.smpl_joints, 'rotmat': out.rotmat, 'pred_cam': cam, 'pred_shape': shape,
-             'pred_pose': pose_flat, 'pose': out.pose_aa, 'pelvis': out.smpl_joints[:, :1] if out.smpl_joints is not None else None,
-             'markers': out.markers}
-        if Tz is not None:
-            s = cam[:, 0]
-            focal = s * bbox_height * Tz / 2.                                        # whmr.py:147-149
-            cam_center = orig_shape.flip(1) / 2.                                     # (W, H) / 2; no host-side index tensor
-            cam_t = convert_pare_to_full_img_cam(cam, bbox_height, center, orig_shape[:, 1], orig_shape[:, 0], Tz=Tz)
-            kp_w = L.perspective(joints, None, cam_t.contiguous(), focal.contiguous(), cam_center.contiguous(),
-                                 post_div=cam_center.contiguous(), post_shift=-1.0)   # whmr.py:165-173
-            d.update(kp_2d_w=kp_w, pred_cam_t=cam_t, scale=scale, focal_length=focal)
+        pose_flat, shape, cam = state[:, :216], state[:, 216:226], state[:, 226:]
+        d = {'verts': verts, 'kp_3d': joints, 'smpl_kp_3d': out.smpl_joints, 'rotmat': out.rotmat, 'pred_cam': cam,
+             'pred_shape': shape, 'pred_pose': pose_flat, 'pose': out.pose_aa,
+             'pelvis': out.smpl_joints[:, :1] if out.smpl_joints is not None else None, 'markers': out.markers}
+        if Tz is not None:      # one fused launch: theta, kp_2d, focal (whmr.py:147-149), cam_t, kp_2d_w (whmr.py:165-173)
+            theta, kp_2d, kp_w, cam_t, focal = L.regressor_post(state, out.pose_aa, joints, Tz, bbox_height, center, orig_shape,
+                                                                1000.0, float(cfg.IMG_RES.WIDTH), float(cfg.IMG_RES.HEIGHT))
+            d.update(theta=theta, kp_2d=kp_2d, kp_2d_w=kp_w, pred_cam_t=cam_t, scale=scale, focal_length=focal)
+        else:
+            d['theta'] = torch.cat([cam, shape, out.pose_aa], dim=1)
+            d['kp_2d'] = L.weak_projection(joints, cam.contiguous(), 1000.0, float(cfg.IMG_RES.WIDTH), float(cfg.IMG_RES.HEIGHT))
         if J_regressor is not None:                                                   # whmr.py:176-180
             d['kp_3d'] = h36m_joints(verts, J_regressor)
         if with_aux:
@@ -180,22 +177,21 @@ class Regressor(nn.Module):
             L.gemm(h2, wh, new, bias=bh, residual=xc[:, F + 5:])                      # whmr.py:124-126 (+ residual state)
             if n_iter > 1:
                 xc[:, F + 5:] = new
-        pose, shape, cam = new[:, :216].contiguous(), new[:, 216:226].contiguous(), new[:, 226:].contiguous()
-        out = self.smpl.run(shape, pose.view(B, 24, 3, 3), gram_schmidt=True, want_aa=True, want_smpl_joints=True,
+        out = self.smpl.run(new[:, 216:226], new[:, :216], gram_schmidt=True, want_aa=True, want_smpl_joints=True,
                             want_markers=True)                                        # whmr.py:128-137,174,184-187
-        d = self._outputs(out, pose, shape, cam, scale, J_regressor, with_aux, Tz, orig_shape, center, bbox_height)
+        d = self._outputs(out, new, scale, J_regressor, with_aux, Tz, orig_shape, center, bbox_height)
         return d, xc[:, :F + 5]
 
     @torch.no_grad()
     def forward_init(self, x, init_pose=None, init_shape=None, init_cam=None, n_iter=1, J_regressor=None, with_aux=True):
         """whmr.py:211-269: the mean-pose mesh (no Gram-Schmidt, rotmats = init_pose as stored)."""
         B = x.shape[0]
-        pose = (self.init_pose.expand(B, -1) if init_pose is None else init_pose).contiguous()
-        shape = (self.init_shape.expand(B, -1) if init_shape is None else init_shape).contiguous()
-        cam = (self.init_cam.expand(B, -1) if init_cam is None else init_cam).contiguous()
-        out = self.smpl.run(shape, pose.view(B, 24, 3, 3), gram_schmidt=False, want_aa=True, want_smpl_joints=True,
+        state = torch.cat([self.init_pose.expand(B, -1) if init_pose is None else init_pose.reshape(B, -1),
+                           self.init_shape.expand(B, -1) if init_shape is None else init_shape,
+                           self.init_cam.expand(B, -1) if init_cam is None else init_cam], dim=1).float().contiguous()
+        out = self.smpl.run(state[:, 216:226], state[:, :216], gram_schmidt=False, want_aa=True, want_smpl_joints=True,
                             want_markers=True)
-        return self._outputs(out, pose, shape, cam, None, J_regressor, with_aux)
+        return self._outputs(out, state, None, J_regressor, with_aux)
 
 
 class Global_Orient_Regressor(nn.Module):
@@ -452,8 +448,8 @@ class WHMR(nn.Module):
         smpl_output = self._init_mesh(B, J_regressor, with_aux)
         outs = [smpl_output]
         body_feat = None
-        center, scale, bbox_height = center.float(), scale.float(), bbox_height.float()
-        orig_shape, bbox_info = orig_shape.float(), bbox_info.float().contiguous()
+        center, scale, bbox_height = center.float().contiguous(), scale.float(), bbox_height.float().contiguous()
+        orig_shape, bbox_info = orig_shape.float().contiguous(), bbox_info.float().contiguous()
         for i in range(3):                                                            # whmr.py:580-627
             reg, ext = self.regressor[i], self.maf_extractor[i]
             cam, shp, pose = smpl_output['pred_cam'], smpl_output['pred_shape'], smpl_output['rotmat']
