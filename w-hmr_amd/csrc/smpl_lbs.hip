@@ -194,9 +194,15 @@ __global__ __launch_bounds__(256) void smpl_regress_kernel(const float* __restri
     const float* rr = reg + (size_t)r * NV;
     const float* vb = verts + (size_t)b * NV * 3;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-    for (int v = lane; v < NV; v += 64) {
-        const float wv = rr[v];
-        if (wv != 0.f) { a0 = fmaf(wv, vb[3 * v], a0); a1 = fmaf(wv, vb[3 * v + 1], a1); a2 = fmaf(wv, vb[3 * v + 2], a2); }
+    for (int v0 = lane; v0 < NV; v0 += 64 * 9) {          // 9 independent coalesced weight loads in flight per lane
+        float wv[9];
+#pragma unroll
+        for (int u = 0; u < 9; ++u) { const int v = v0 + 64 * u; wv[u] = v < NV ? rr[v] : 0.f; }
+#pragma unroll
+        for (int u = 0; u < 9; ++u) {
+            const int v = v0 + 64 * u;
+            if (wv[u] != 0.f) { a0 = fmaf(wv[u], vb[3 * v], a0); a1 = fmaf(wv[u], vb[3 * v + 1], a1); a2 = fmaf(wv[u], vb[3 * v + 2], a2); }
+        }
     }
     a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
     if (lane == 0) { out[(size_t)w * 3] = a0; out[(size_t)w * 3 + 1] = a1; out[(size_t)w * 3 + 2] = a2; }
