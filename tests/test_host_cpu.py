@@ -62,6 +62,21 @@ def test_state_dict_contract(assets, state_dict):
     assert tuple(m.feature_extractor.backbone.pos_embed.shape) == (1, 193, 768)
 
 
+def test_reference_checkpoint_adapter(assets, state_dict):
+    from whmr_amd.models import whmr_net
+    from whmr_amd.models.whmr import load_reference_state_dict
+    m = whmr_net(None, assets=assets)
+    ckpt = dict(state_dict)
+    ckpt['regressor.0.vertex_joint_selector.extra_joints_idxs'] = torch.zeros(21, dtype=torch.long)   # smplx-internal key
+    ckpt['regressor.1.smpl.betas'] = torch.zeros(1, 10)
+    missing, unexpected, skipped = load_reference_state_dict(m, ckpt, verbose=False)
+    assert not unexpected and len(skipped) == 2 and all('.smpl.' in k for k in missing)
+    bad = dict(state_dict)
+    bad['regressor.0.fc1.weight'] = torch.zeros(3, 3)
+    with pytest.raises(KeyError):
+        load_reference_state_dict(m, bad, verbose=False)
+
+
 def test_cfg_object():
     from whmr_amd.core.cfgs import CfgNode, cfg
     assert cfg.MODEL.PyMAF.MLP_DIM == [256, 128, 64, 32] and cfg.IMG_RES.WIDTH == 256 and cfg.TRAIN.STAGE == 2

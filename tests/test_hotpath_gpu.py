@@ -218,3 +218,31 @@ def test_whmr_hip_graph_replay_matches_eager(dev, assets, state_dict, gold):
                                           kw['orig_shape'].flip(0), kw['bbox_info'].flip(0), full_x=kw['full_x'].flip(0)).items()}
     for k in eager:
         assert torch.allclose(out2[k], eager[k].flip(0), rtol=1e-4, atol=1e-5), k
+
+
+def test_whmr_eval_view_with_h36m_regressor_and_sliced_input(dev, assets, state_dict):
+    """evaluate/eval.py:178-185 call shape: J_regressor given, eval view; crop passed as the non-contiguous slice
+    inp[:, :, :, 32:-32] (demo/tester.py:152); batch of 1 and of 3 (odd sizes)"""
+    from oracle import synth
+    from oracle import whmr as OW
+    m = _load_model(assets, state_dict, 'fp32', dev)
+    Jh = torch.zeros(17, 6890)
+    g = torch.Generator().manual_seed(4)
+    for j in range(17):
+        idx = torch.randperm(6890, generator=g)[:20]
+        Jh[j, idx] = torch.rand(20, generator=g)
+        Jh[j] /= Jh[j].sum()
+    for B in (1, 3):
+        inp = synth.make_inputs(B, 20 + B)
+        wide = torch.zeros(B, 3, 256, 256)
+        wide[:, :, :, 32:-32] = inp['x']
+        x_view = wide.to(dev)[:, :, :, 32:-32]
+        assert not x_view.is_contiguous()
+        with torch.no_grad():
+            ref, _ = OW.whmr_forward(state_dict, assets, inp['x'], inp['center'], inp['scale'], inp['bbox_height'],
+                                     inp['orig_shape'], inp['bbox_info'], J_regressor=Jh, view='eval')
+        out, _ = m(x_view, None, inp['center'].to(dev), inp['scale'].to(dev), inp['bbox_height'].to(dev),
+                   inp['orig_shape'].to(dev), inp['bbox_info'].to(dev), is_train=False, J_regressor=Jh.to(dev), view='eval')
+        for k in ('global_pose', 'global_shape', 'global_rotmat', 'global_kp_3d', 'global_verts'):
+            assert _rel(out['global_output'][k], ref['global_output'][k]) < 1e-4, (B, k)
+        assert out['global_output']['global_kp_3d'].shape == (B, 14, 3)

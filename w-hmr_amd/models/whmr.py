@@ -486,6 +486,32 @@ class WHMR(nn.Module):
                 'global_pose': g_pose, 'local_pose': smpl_output['pose']}
 
 
+def load_reference_state_dict(model, state_dict, verbose=True):
+    """Load a reference checkpoint's ``ckpt['model']`` (demo/tester.py:64-65, utils/saver.py:26-64) into ``model``.
+
+    Own-code keys are identical and are loaded strictly.  Keys that belong to third-party classes in the
+    reference (``regressor.N.smpl.*`` from smplx, ``regressor.N.vertex_joint_selector.*``) are matched by name where this
+    package has the same buffer and otherwise reported, never silently dropped.  Returns (missing, unexpected, skipped).
+    """
+    own = model.state_dict()
+    load, skipped = {}, []
+    for k, v in state_dict.items():
+        if k in own and tuple(own[k].shape) == tuple(v.shape):
+            load[k] = v
+        elif '.vertex_joint_selector.' in k or '.smpl.' in k or k.startswith('transformer.'):
+            skipped.append(k)                      # smplx / pare internals without a counterpart (e.g. betas, faces_tensor variants)
+        else:
+            raise KeyError('reference key %s %s has no counterpart of that shape' % (k, tuple(v.shape)))
+    res = model.load_state_dict(load, strict=False)
+    missing = [k for k in res.missing_keys if '.smpl.' not in k]
+    if missing:
+        raise KeyError('own-code keys missing from the checkpoint: %s' % missing[:8])
+    if verbose:
+        print('loaded %d tensors; %d third-party keys skipped; %d smpl buffers kept from the SMPL model file'
+              % (len(load), len(skipped), len(res.missing_keys)))
+    return res.missing_keys, res.unexpected_keys, skipped
+
+
 def whmr_net(smpl_mean_params, pretrained=True, **kwargs):
     """models/whmr.py:681-687."""
     return WHMR(smpl_mean_params, pretrained, **kwargs)
