@@ -34,12 +34,14 @@ struct whmr_gemm {
     int32_t IH, IW, Cin, OH, OW, KW, SH, SW, PH, PW;
     int32_t c_mode;
     int64_t c_off, osb, osy, osx;
-    void* workspace;        /* optional split-K scratch (fp32 kernel): splits*M*N floats; null = no split */
+    void* workspace;        /* optional split-K scratch: splits*M*N floats; null = no split */
     int64_t workspace_bytes;
     /* all 4 sub-pixel phases of ConvTranspose2d(k4,s2,p1) in one launch (bf16 kernel, a_mode = c_mode = 1, n_phase = 4):
      * phase = 2*py + px: W += phase*phase_w_stride; PH -= py; PW -= px; c_off += py*phase_cy + px*phase_cx. */
-    int32_t n_phase, pad_;
+    int32_t n_phase;
+    int32_t epi_flags;      /* bit 0: residual is bf16 (else fp32); bit 1: residual is added BEFORE the activation (ResNet blocks) */
     int64_t phase_w_stride, phase_cy, phase_cx;
+    int64_t split_k;        /* internal (set by the bf16 launcher, pass 0): K elements per split-K slice, blockIdx.z = slice */
 };
 
 /* bf16 MFMA GEMM (v_mfma_f32_32x32x16_bf16, fp32 accumulate).  Needs K % 64 == 0 (and Cin % 64 == 0 for a_mode 1).
@@ -141,6 +143,15 @@ int whmr_maf_sample(const void* fmap, int fmap_bf16, long sb, long sc, long sy, 
                     const float* pts2d, const float* pts3d, const float* cam, float focal, float res_w, float res_h,
                     const struct whmr_maf_weights* w, int B, int P, float* out, long out_stride, float* point_feat,
                     void* stream);
+
+/* ---- NHWC helpers for the camera-calibration ResNet-50 on the implicit-GEMM kernel (models/cam_model.py:24-81) */
+/* NCHW fp32 image (element strides) -> cols [B*OH*OW, Kpad] bf16, k = (ci, ky, kx), zero padded (stem conv 7x7 s2 p3). */
+int whmr_conv_im2col(const float* x, void* cols, int B, int Cin, int H, int W, int KH, int KW, int S, int pad, int Kpad,
+                     long sb, long sc, long sh, long sw, void* stream);
+/* MaxPool2d(k, s, pad) on NHWC, bf16 (C % 8 == 0) or fp32. */
+int whmr_maxpool_nhwc(const void* x, void* y, int B, int H, int W, int C, int k, int s, int pad, int is_bf16, void* stream);
+/* AdaptiveAvgPool2d((1,1)) on NHWC bf16 / fp32 -> [B, C] fp32 (C % 64 == 0). */
+int whmr_avgpool_nhwc(const void* x, float* y, int B, int HW, int C, int is_bf16, void* stream);
 
 /* Tz-head tail (whmr.py:574-577): tokens [B,T,D] -> mean over T -> Linear(D,Hd) -> Linear(Hd,1) -> BatchNorm1d(1) eval
  * (bn4 = weight, bias, running_mean, running_var) -> sigmoid -> x10. */

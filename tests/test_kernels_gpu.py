@@ -203,3 +203,114 @@ def test_patch_im2col(dev):
     L.patch_im2col(x.to(dev)[:, :, :, :], out, 16, 2)
     ref = F.unfold(x, 16, padding=2, stride=16).transpose(1, 2).reshape(-1, 768)
     assert torch.equal(out.cpu(), ref)
+
+
+@pytest.mark.parametrize('tile', [None, 64, 65, 128, 257])
+@pytest.mark.parametrize('out_bf16', [True, False])
+def test_gemm_bf16_skip_before_relu(dev, tile, out_bf16):
+    """ResNet bottleneck epilogue: relu(a.w^T + bias + skip) with a bf16 skip tensor (epi_flags bits 0|1)."""
+    from whmr_amd import _lib as L
+    g = torch.Generator().manual_seed(11)
+    M, N, K = 1000, 256, 64
+    a = torch.randn(M, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).bfloat16()
+    bias = torch.randn(N, generator=g)
+    skip = torch.randn(M, N, generator=g).bfloat16()
+    ref = F.relu(a.float() @ w.float().t() + bias + skip.float())
+    out = torch.empty(M, N, device=dev, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    L.gemm(a.to(dev), w.to(dev), out, bias=bias.to(dev), residual=skip.to(dev), act=L.ACT_RELU, res_first=True, tile=tile)
+    assert _rel(out.float().cpu(), ref) < (1e-2 if out_bf16 else 1e-5)
+    # fp32 skip, added before the activation
+    out2 = torch.empty(M, N, device=dev)
+    L.gemm(a.to(dev), w.to(dev), out2, bias=bias.to(dev), residual=skip.float().to(dev), act=L.ACT_RELU, res_first=True, tile=tile)
+    assert _rel(out2.cpu(), ref) < 1e-5
+
+
+def test_gemm_f32_skip_before_relu(dev):
+    from whmr_amd import _lib as L
+    g = torch.Generator().manual_seed(12)
+    M, N, K = 333, 200, 96
+    a, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K)
+    bias, skip = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    out = torch.empty(M, N, device=dev)
+    L.gemm(a.to(dev), w.to(dev), out, bias=bias.to(dev), residual=skip.to(dev), act=L.ACT_RELU, res_first=True)
+    assert _rel(out.cpu(), F.relu(a @ w.t() + bias + skip)) < 5e-6
+
+
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float32])
+def test_nhwc_pools_and_stem_im2col(dev, dt):
+    from whmr_amd import _lib as L
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(2, 64, 37, 45, generator=g).to(dt)
+    xn = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    ref = F.max_pool2d(x.float(), 3, 2, 1).permute(0, 2, 3, 1)
+    assert torch.equal(L.maxpool_nhwc(xn, 3, 2, 1).float().cpu(), ref)
+    assert _rel(L.avgpool_nhwc(xn).cpu(), x.float().mean(dim=(2, 3))) < 2e-6
+    if dt == torch.float32:
+        img = torch.randn(2, 3, 50, 71, generator=g)
+        cols, OH, OW = L.conv_im2col(img.to(dev)[:, :, 1:, 2:], 7, 7, 2, 3, 192)          # strided view in, like a cropped frame
+        ref = F.unfold(img[:, :, 1:, 2:], 7, padding=3, stride=2).transpose(1, 2).reshape(-1, 147)
+        assert (OH, OW) == (25, 35)
+        assert torch.equal(cols[:, :147].float().cpu(), ref.bfloat16().float()) and not cols[:, 147:].any()
+
+
+@pytest.mark.parametrize('numerics,tol', [('fp32', 1e-4), ('bf16', 4e-2)])
+def test_cam_model_resnet50(dev, numerics, tol):
+    """the HIP NHWC ResNet-50 of cam_model against the same module's plain-PyTorch forward."""
+    from oracle import synth
+    from whmr_amd.models.cam_model import CameraRegressorNetwork
+    sd = synth.make_state_dict(0, synth.make_assets(0))
+    m = CameraRegressorNetwork()
+    m.load_state_dict({k[len('cam_model.'):]: v for k, v in sd.items() if k.startswith('cam_model.')}, strict=True)
+    m.numerics = numerics
+    m = m.to(dev).eval()
+    x = torch.randn(2, 3, 160, 224, generator=torch.Generator().manual_seed(5)).to(dev)
+    with torch.no_grad():
+        ref, rfeat = m.forward_torch(x)
+    out, feat = m(x)
+    assert _rel(feat, rfeat) < tol
+    for o, r in zip(out, ref):
+        assert o.shape == r.shape and _rel(o, r) < tol
+    m.train()
+    with pytest.raises(RuntimeError):
+        m(x)
+
+
+@pytest.mark.parametrize('out_bf16', [True, False])
+def test_gemm_bf16_split_k(dev, out_bf16):
+    """Few-tile deep-K shapes take the split-K route (gemm_bf16.hip); same epilogue semantics, deterministic."""
+    from whmr_amd import _lib as L
+    g = torch.Generator().manual_seed(21)
+    M, N, K = 475, 512, 4608
+    a = torch.randn(M, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).bfloat16()
+    bias = torch.randn(N, generator=g)
+    skip = torch.randn(M, N, generator=g).bfloat16()
+    ref = F.relu(a.float() @ w.float().t() + bias + skip.float())
+    out = torch.empty(M, N, device=dev, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    L.gemm(a.to(dev), w.to(dev), out, bias=bias.to(dev), residual=skip.to(dev), act=L.ACT_RELU, res_first=True)
+    assert _rel(out.float().cpu(), ref) < (1e-2 if out_bf16 else 2e-5)
+    out_b = torch.empty_like(out)
+    L.gemm(a.to(dev), w.to(dev), out_b, bias=bias.to(dev), residual=skip.to(dev), act=L.ACT_RELU, res_first=True)
+    assert torch.equal(out, out_b)
+    # the unsplit kernel (explicit tile) agrees to fp32 summation-order noise
+    out_t = torch.empty(M, N, device=dev)
+    out_s = torch.empty(M, N, device=dev)
+    L.gemm(a.to(dev), w.to(dev), out_t, bias=bias.to(dev), tile=65)
+    L.gemm(a.to(dev), w.to(dev), out_s, bias=bias.to(dev))
+    assert _rel(out_s, out_t) < 1e-5
+
+
+def test_conv3x3_bf16_split_k(dev):
+    """ResNet layer4 3x3 conv on one 600x800 frame: implicit GEMM M = 475, K = 4608 through the split-K route."""
+    from whmr_amd import _lib as L
+    g = torch.Generator().manual_seed(22)
+    B, H, W, Cin, Cout = 1, 19, 25, 512, 512
+    x = torch.randn(B, Cin, H, W, generator=g).bfloat16()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)).bfloat16()
+    bias = torch.randn(Cout, generator=g)
+    ref = F.relu(F.conv2d(x.float(), w.float(), bias, stride=1, padding=1)).permute(0, 2, 3, 1)
+    out = torch.empty(B, H, W, Cout, device=dev)
+    L.gemm(x.permute(0, 2, 3, 1).contiguous().to(dev), w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to(dev), out,
+           bias=bias.to(dev), act=L.ACT_RELU, conv=dict(IH=H, IW=W, Cin=Cin, OH=H, OW=W, KW=3, SH=1, SW=1, PH=1, PW=1))
+    assert _rel(out.cpu(), ref) < 2e-5

@@ -24,8 +24,8 @@ class WhmrGemm(C.Structure):
                 ('c_mode', C.c_int32),
                 ('c_off', C.c_int64), ('osb', C.c_int64), ('osy', C.c_int64), ('osx', C.c_int64),
                 ('workspace', C.c_void_p), ('workspace_bytes', C.c_int64),
-                ('n_phase', C.c_int32), ('pad_', C.c_int32),
-                ('phase_w_stride', C.c_int64), ('phase_cy', C.c_int64), ('phase_cx', C.c_int64)]
+                ('n_phase', C.c_int32), ('epi_flags', C.c_int32),
+                ('phase_w_stride', C.c_int64), ('phase_cy', C.c_int64), ('phase_cx', C.c_int64), ('split_k', C.c_int64)]
 
 
 class WhmrSmplModel(C.Structure):
@@ -60,6 +60,9 @@ _SIGS = {
     'whmr_smpl_joints': [C.POINTER(WhmrSmplModel), _P, _P, _I, _P, _P, _P, _P, _P],
     'whmr_maf_sample': [_P, _I, _L, _L, _L, _L, _I, _I, _P, _P, _P, _F, _F, _F, C.POINTER(WhmrMafWeights), _I, _I, _P, _L, _P, _P],
     'whmr_tz_tail': [_P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _F, _P, _P],
+    'whmr_conv_im2col': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _L, _L, _L, _P],
+    'whmr_maxpool_nhwc': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    'whmr_avgpool_nhwc': [_P, _P, _I, _I, _I, _I, _P],
 }
 EXPORTS = tuple(_SIGS)
 
@@ -100,10 +103,10 @@ _splitk_ws = {}
 
 
 def splitk_workspace(device):
-    """Per-device scratch for the fp32 split-K partial sums (16 MiB covers 16 splits of a 64 x 2048 output 2x over)."""
+    """Per-device scratch for split-K partial sums (fp32 skinny GEMMs; bf16 GEMMs with too few tiles to fill 256 CUs)."""
     w = _splitk_ws.get(device)
     if w is None:
-        w = _splitk_ws[device] = torch.empty(16 << 20, dtype=torch.uint8, device=device)
+        w = _splitk_ws[device] = torch.empty(64 << 20, dtype=torch.uint8, device=device)
     return w
 
 
@@ -119,7 +122,7 @@ PROFILE = None        # bench.py sets this to a list: (kernel, flops, start_even
 
 
 def gemm(a, w, out, bias=None, residual=None, res_row_mod=0, act=ACT_NONE, conv=None, scatter=None, M=None,
-         lda=None, glds=True, tile=None, phases=None):
+         lda=None, glds=True, tile=None, phases=None, res_first=False):
     """out = act(a . w^T + bias) + residual.  a/w dtype selects the kernel (bf16 MFMA or exact-fp32 MFMA).
 
     conv = dict(IH, IW, Cin, OH, OW, KW, SH, SW, PH, PW): a is an NHWC image [B, IH, IW, Cin], rows are output pixels.
@@ -137,8 +140,10 @@ def gemm(a, w, out, bias=None, residual=None, res_row_mod=0, act=ACT_NONE, conv=
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() == N
     if residual is not None:
-        assert residual.dtype == torch.float32 and residual.stride(-1) == 1
+        assert residual.dtype in (torch.float32, torch.bfloat16) and residual.stride(-1) == 1
         p.ldr = residual.stride(-2)
+        p.epi_flags = (1 if residual.dtype == torch.bfloat16 else 0) | (2 if res_first else 0)
+        assert residual.dtype == torch.float32 or a.dtype == torch.bfloat16, 'bf16 residuals exist in the bf16 kernel only'
     p.res_row_mod = res_row_mod
     p.act = act
     assert out.dtype in (torch.bfloat16, torch.float32)
@@ -166,7 +171,7 @@ def gemm(a, w, out, bias=None, residual=None, res_row_mod=0, act=ACT_NONE, conv=
     else:
         p.ldc = out.stride(-2) if out.dim() >= 2 else N
     fn = lib().whmr_gemm_bf16 if a.dtype == torch.bfloat16 else lib().whmr_gemm_f32
-    if a.dtype == torch.float32 and conv is None and scatter is None:
+    if scatter is None and phases is None and (a.dtype == torch.bfloat16 or conv is None):
         ws = splitk_workspace(a.device)
         p.workspace, p.workspace_bytes = ws.data_ptr(), ws.numel()
     if tile is not None:                    # explicit tile id (A/B tests), see gemm_bf16_big.hip
@@ -351,3 +356,36 @@ def tz_tail(tok, w0, b0, w1, b1, bn4, eps, out):
     _check(lib().whmr_tz_tail(_f32c(tok).data_ptr(), B, T, D, w0.data_ptr(), b0.data_ptr(), w0.shape[0], w1.data_ptr(),
                               b1.data_ptr(), bn4.data_ptr(), eps, out.data_ptr(), _stream()), 'whmr_tz_tail')
     return out
+
+
+def conv_im2col(x, KH, KW, S, pad, Kpad):
+    """NCHW fp32 -> cols [B*OH*OW, Kpad] bf16 (stem conv); returns (cols, OH, OW)"""
+    _dev(x)
+    B, Cin, H, W = x.shape
+    OH, OW = (H + 2 * pad - KH) // S + 1, (W + 2 * pad - KW) // S + 1
+    cols = torch.empty(B * OH * OW, Kpad, dtype=torch.bfloat16, device=x.device)
+    sb, sc, sh, sw = x.stride()
+    _check(lib().whmr_conv_im2col(x.data_ptr(), cols.data_ptr(), B, Cin, H, W, KH, KW, S, pad, Kpad, sb, sc, sh, sw, _stream()),
+           'whmr_conv_im2col')
+    return cols, OH, OW
+
+
+def maxpool_nhwc(x, k, s, pad):
+    _dev(x)
+    assert x.dtype in (torch.bfloat16, torch.float32) and x.is_contiguous()
+    B, H, W, Cc = x.shape
+    OH, OW = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+    y = torch.empty(B, OH, OW, Cc, dtype=x.dtype, device=x.device)
+    _check(lib().whmr_maxpool_nhwc(x.data_ptr(), y.data_ptr(), B, H, W, Cc, k, s, pad, int(x.dtype == torch.bfloat16), _stream()),
+           'whmr_maxpool_nhwc')
+    return y
+
+
+def avgpool_nhwc(x):
+    _dev(x)
+    assert x.dtype in (torch.bfloat16, torch.float32) and x.is_contiguous()
+    B, H, W, Cc = x.shape
+    y = torch.empty(B, Cc, dtype=torch.float32, device=x.device)
+    _check(lib().whmr_avgpool_nhwc(x.data_ptr(), y.data_ptr(), B, H * W, Cc, int(x.dtype == torch.bfloat16), _stream()),
+           'whmr_avgpool_nhwc')
+    return y

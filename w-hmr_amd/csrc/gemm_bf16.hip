@@ -14,6 +14,41 @@
 
 extern "C" int whmr_gemm_bf16_big(const whmr_gemm* pp, int tile, void* stream);
 
+// Deterministic split-K epilogue: sum the slices in a fixed order, then bias / skip / activation / convert (4 columns per thread).
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const whmr_gemm p, int splits) {
+    const int n4 = p.N >> 2;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)p.M * n4) return;
+    const int m = (int)(idx / n4), n = (int)(idx - (long)m * n4) * 4;
+    const float* ws = (const float*)p.workspace + (size_t)m * p.N + n;
+    float4 a = *(const float4*)ws;
+    for (int s = 1; s < splits; ++s) {
+        const float4 b = *(const float4*)(ws + (size_t)s * p.M * p.N);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    float v[4] = {a.x, a.y, a.z, a.w};
+    if (p.bias) {
+        const float4 b = *(const float4*)(p.bias + n);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    }
+    float r[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.residual) {
+        const size_t roff = (size_t)(p.res_row_mod > 0 ? m % p.res_row_mod : m) * p.ldr + n;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = (p.epi_flags & 1) ? bf16_to_f32(((const bf16_t*)p.residual)[roff + e]) : p.residual[roff + e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (p.epi_flags & 2) v[e] += r[e];
+        if (p.act == 1) v[e] = gelu_fast(v[e]);
+        else if (p.act == 2) v[e] = fmaxf(v[e], 0.f);
+        if (!(p.epi_flags & 2)) v[e] += r[e];
+    }
+    const size_t off = (size_t)m * p.ldc + n;
+    if (p.out_bf16) *(uint2*)((bf16_t*)p.C + off) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+    else *(float4*)((float*)p.C + off) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
 struct tile_cfg { int id, bm, bn, per_cu, eff_pct; };   // eff_pct: measured main-loop cost per tile area, relative to 256x256
 
 extern "C" int whmr_gemm_bf16(const whmr_gemm* pp, int flags, void* stream) {
@@ -23,14 +58,37 @@ extern "C" int whmr_gemm_bf16(const whmr_gemm* pp, int flags, void* stream) {
     if (flags > 1) return whmr_gemm_bf16_big(pp, flags, stream);          // explicit tile id (A/B tests)
     static const tile_cfg cands[] = {{320, 320, 256, 1, 100}, {257, 256, 256, 1, 100}, {192, 192, 256, 1, 100},
                                      {128, 128, 256, 2, 120}, {64, 128, 128, 2, 125}, {65, 128, 64, 3, 150}};
-    long best_cost = -1;
-    int best = 64;
+    long best_cost = -1, best_tiles = 0;
+    const tile_cfg* best = &cands[4];
     for (const tile_cfg& c : cands) {
         const long tiles = (long)((p.M + c.bm - 1) / c.bm) * ((p.N + c.bn - 1) / c.bn) * (p.n_phase > 1 ? p.n_phase : 1);
         const long slots = 256L * c.per_cu;
         const long rounds = (tiles + slots - 1) / slots;
         const long cost = rounds * c.per_cu * c.bm * c.bn * c.eff_pct;
-        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = c.id; }
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = &c; best_tiles = tiles; }
     }
-    return whmr_gemm_bf16_big(pp, best, stream);
+    // Few tiles and a deep K (ResNet layer3/4 convs on one frame, ViT at batch 1): every block walks K alone, one exposed
+    // HBM round trip per K step on a mostly idle chip.  Slice K over blockIdx.z so that the co-resident slots are full;
+    // partial sums go to the fp32 workspace, splitk_epilogue_kernel finishes (fixed summation order: deterministic).
+    const long slots = 256L * best->per_cu;
+    if (p.workspace && p.n_phase <= 1 && p.c_mode == 0 && best->bm <= 128 && best_tiles * 2 <= slots && p.K >= 512 &&
+        !(p.N & 3) && !(p.ldc & 3) && !(p.ldr & 3)) {
+        long splits = slots / best_tiles;
+        if (splits > p.K / 256) splits = p.K / 256;
+        while (splits > 1 && splits * p.M * p.N * 4 > p.workspace_bytes) --splits;
+        if (splits > 1) {
+            long kps = ((p.K / 64 + splits - 1) / splits) * 64;
+            splits = (p.K + kps - 1) / kps;
+            whmr_gemm q = p;
+            q.C = p.workspace; q.out_bf16 = 0; q.act = 0; q.bias = nullptr; q.residual = nullptr; q.epi_flags = 0; q.ldc = p.N;
+            q.split_k = kps;
+            const int rc = whmr_gemm_bf16_big(&q, best->id, stream);
+            if (rc) return rc;
+            hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)(((long)p.M * (p.N >> 2) + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p,
+                               (int)splits);
+            WHMR_CHECK_LAUNCH();
+            return 0;
+        }
+    }
+    return whmr_gemm_bf16_big(pp, best->id, stream);
 }

@@ -104,10 +104,13 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
         b_src[i] = W + (size_t)nr * p.K + lc * 8;
     }
 
+    // split-K slice of this block (whmr_gemm_bf16 sets split_k for few-tile, deep-K shapes): raw fp32 partial sums go to
+    // workspace slice blockIdx.z; bias / skip / activation happen in splitk_epilogue_kernel.
+    const int k_first = p.split_k ? (int)(blockIdx.z * p.split_k) : 0;
     auto stage = [&](int kt, int s) {
         char* sa = smem + s * cfg::STAGE;
         char* sb = sa + cfg::A_BYTES;
-        const int k0 = kt * BK;
+        const int k0 = k_first + kt * BK;
         int ky = 0, kx = 0, ci0 = 0;
         if constexpr (GATHER) {
             const int tap = k0 / p.Cin;
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
     // both waves of a SIMD wait in lockstep.  With NS >= 3 the K-step barrier sits before the LAST sub-step's MFMAs:
     // after it the wave issues the next stage's DMA and the first fragments of step kt+1, then still has MFMAs queued.
     constexpr int KK = BK / 16;
-    const int nkt = p.K / BK;
+    const int nkt = (p.split_k ? min((int)p.split_k, p.K - k_first) : p.K) / BK;
     bf16x8_t af[2][MI], bfr[2][NJ];
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)smem;
     constexpr int NF = MI + NJ;          // ds_read_b128 per fragment set
@@ -264,13 +267,14 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
     const int ccol = (tid % TPR) * CPT, rsub = tid / TPR;
     const int ncol = n0 + ccol;
     float* sC = (float*)smem;
+    void* const Cout = p.split_k ? (void*)((float*)p.C + (size_t)blockIdx.z * p.M * p.N) : p.C;
     float bias_r[CPT];
 #pragma unroll
     for (int e = 0; e < CPT; ++e) bias_r[e] = (p.bias && ncol + e < p.N) ? p.bias[ncol + e] : 0.f;
     const float* __restrict__ res = p.residual;
     bool spatial = false;
     if constexpr (GATHER) spatial = (p.c_mode == 1);
-    const bool vec_ok = (ncol + CPT <= p.N) && (spatial || (p.ldc % CPT) == 0) && (!res || (p.ldr & 3) == 0);
+    const bool vec_ok = (ncol + CPT <= p.N) && (spatial || (p.ldc % CPT) == 0);
     // LDS-only barrier: the global stores of a pass must NOT be drained at the pass barrier (a __syncthreads() would wait
     // vmcnt(0), i.e. a full HBM write round trip per pass); only this wave's LDS traffic has to be complete.
     auto lds_barrier = [&]() { wait_lgkmcnt<0>(); __builtin_amdgcn_s_barrier(); };
@@ -284,38 +288,48 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
                 *(float4*)(sC + (wm * 32 + l31) * cfg::CLD_F32 + wn * cfg::WTN + j * 32 + 8 * q + 4 * hi) =
                     make_float4(acc[i][j][q * 4], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]);
     };
-    auto load_row = [&](int lr, float* v) {
+    auto load_raw = [&](int lr, float* v) {          // accumulator + bias
 #pragma unroll
         for (int e = 0; e < CPT; e += 4) {
             const float4 f = *(const float4*)(sC + lr * cfg::CLD_F32 + ccol + e);
             v[e] = f.x + bias_r[e]; v[e + 1] = f.y + bias_r[e + 1]; v[e + 2] = f.z + bias_r[e + 2]; v[e + 3] = f.w + bias_r[e + 3];
         }
+    };
+    auto activate = [&](float* v) {
 #pragma unroll
         for (int e = 0; e < CPT; ++e) {
             if (ACT == 1) v[e] = gelu_fast(v[e]);
             if (ACT == 2) v[e] = fmaxf(v[e], 0.f);
         }
     };
+    const bool res_bf16 = p.epi_flags & 1, res_first = p.epi_flags & 2;   // ResNet-style epilogue: act(acc + bias + bf16 skip)
     auto store_vec = [&](size_t off, const float* v) {
         if constexpr (OUT_BF16)
-            *(uint4*)((bf16_t*)p.C + off) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]),
+            *(uint4*)((bf16_t*)Cout + off) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]),
                                                        pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
         else
-            *(float4*)((float*)p.C + off) = make_float4(v[0], v[1], v[2], v[3]);
+            *(float4*)((float*)Cout + off) = make_float4(v[0], v[1], v[2], v[3]);
     };
 
     if constexpr (!GATHER && MI <= 4) {
-        if (res && vec_ok) {
-            // ---- fast residual path (proj / fc2 / patch-embed): all residual rows of a pass are prefetched one pass ahead,
-            // NIT independent 16-B loads in flight per thread instead of one exposed HBM round trip per row.
-            float4 rv[NIT][CPT / 4];
+        if (res && vec_ok && (p.ldr % (res_bf16 ? CPT : 4)) == 0) {
+            // ---- fast residual path (proj / fc2 / patch-embed; ResNet conv3 + bf16 skip): all residual rows of a pass are
+            // prefetched one pass ahead, NIT independent 16-B loads in flight per thread instead of one exposed HBM round
+            // trip per row.  rv holds raw bits: CPT fp32 values (CPT/4 x 16 B) or CPT bf16 values (first CPT*2 bytes).
+            uint4 rv[NIT][CPT / 4];
             auto prefetch_res = [&](int i) {
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
                     const int m = row_of(i, it);
+                    if (res_bf16) {
+                        const bf16_t* rp = (const bf16_t*)p.residual + (size_t)(p.res_row_mod > 0 ? m % p.res_row_mod : m) * p.ldr + ncol;
+                        if constexpr (CPT == 8) rv[it][0] = (m < p.M) ? *(const uint4*)rp : make_uint4(0, 0, 0, 0);
+                        else { const uint2 r = (m < p.M) ? *(const uint2*)rp : make_uint2(0, 0); rv[it][0].x = r.x; rv[it][0].y = r.y; }
+                    } else {
 #pragma unroll
-                    for (int e = 0; e < CPT / 4; ++e)
-                        rv[it][e] = (m < p.M) ? *(const float4*)(res_ptr(m) + 4 * e) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        for (int e = 0; e < CPT / 4; ++e)
+                            rv[it][e] = (m < p.M) ? *(const uint4*)(res_ptr(m) + 4 * e) : make_uint4(0, 0, 0, 0);
+                    }
                 }
             };
             prefetch_res(0);
@@ -327,11 +341,20 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
                 for (int it = 0; it < NIT; ++it) {
                     const int m = row_of(i, it);
                     float v[CPT];
-                    load_row(it * RPI + rsub, v);
+                    load_raw(it * RPI + rsub, v);
+                    if (!res_first) activate(v);
+                    if (res_bf16) {
+                        const uint32_t w[4] = {rv[it][0].x, rv[it][0].y, rv[it][0].z, rv[it][0].w};
 #pragma unroll
-                    for (int e = 0; e < CPT / 4; ++e) {
-                        v[4 * e] += rv[it][e].x; v[4 * e + 1] += rv[it][e].y; v[4 * e + 2] += rv[it][e].z; v[4 * e + 3] += rv[it][e].w;
+                        for (int e = 0; e < CPT / 2; ++e) { v[2 * e] += __uint_as_float(w[e] << 16); v[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u); }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < CPT / 4; ++e) {
+                            v[4 * e] += __uint_as_float(rv[it][e].x); v[4 * e + 1] += __uint_as_float(rv[it][e].y);
+                            v[4 * e + 2] += __uint_as_float(rv[it][e].z); v[4 * e + 3] += __uint_as_float(rv[it][e].w);
+                        }
                     }
+                    if (res_first) activate(v);
                     if (m < p.M) store_vec((size_t)m * p.ldc + ncol, v);
                 }
                 lds_barrier();                                   // slab consumed: the next pass may overwrite it
@@ -359,25 +382,33 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
                 crow = (size_t)m * p.ldc;
             }
             float v[CPT];
-            load_row(it * RPI + rsub, v);
-            const float* rp = res ? res_ptr(m) : nullptr;
-            if (vec_ok) {
-                if (rp) {
+            load_raw(it * RPI + rsub, v);
+            if (!res_first) activate(v);
+            if (res) {                              // fp32 or bf16 skip tensor, added after (ViT) or before (ResNet) the activation
+                const size_t roff = (size_t)(p.res_row_mod > 0 ? m % p.res_row_mod : m) * p.ldr + ncol;
+                if (res_bf16 && vec_ok && (p.ldr % CPT) == 0) {          // one 16-B (8-B) load of CPT bf16 skip values
+                    uint32_t w[CPT / 2];
+                    if constexpr (CPT == 8) { const uint4 r = *(const uint4*)((const bf16_t*)p.residual + roff); w[0] = r.x; w[1] = r.y; w[2] = r.z; w[3] = r.w; }
+                    else { const uint2 r = *(const uint2*)((const bf16_t*)p.residual + roff); w[0] = r.x; w[1] = r.y; }
 #pragma unroll
-                    for (int e = 0; e < CPT; e += 4) {
-                        const float4 r4 = *(const float4*)(rp + e);
-                        v[e] += r4.x; v[e + 1] += r4.y; v[e + 2] += r4.z; v[e + 3] += r4.w;
+                    for (int e = 0; e < CPT / 2; ++e) { v[2 * e] += __uint_as_float(w[e] << 16); v[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u); }
+                } else {
+#pragma unroll 1
+                    for (int e = 0; e < CPT; ++e) {
+                        if (ncol + e >= p.N) break;
+                        v[e] += res_bf16 ? bf16_to_f32(((const bf16_t*)p.residual)[roff + e]) : res[roff + e];
                     }
                 }
+            }
+            if (res_first) activate(v);
+            if (vec_ok) {
                 store_vec(crow + ncol, v);
             } else {
 #pragma unroll 1
                 for (int e = 0; e < CPT; ++e) {
                     if (ncol + e >= p.N) break;
-                    float o = v[e];
-                    if (rp) o += rp[e];
-                    if (OUT_BF16) ((bf16_t*)p.C)[crow + ncol + e] = f32_to_bf16(o);
-                    else ((float*)p.C)[crow + ncol + e] = o;
+                    if (OUT_BF16) ((bf16_t*)Cout)[crow + ncol + e] = f32_to_bf16(v[e]);
+                    else ((float*)Cout)[crow + ncol + e] = v[e];
                 }
             }
         }
@@ -396,7 +427,7 @@ static int launch_big(const whmr_gemm& p, hipStream_t st) {
         attr_done = true;
     }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    hipLaunchKernelGGL(kern, dim3(tiles, GATHER && p.n_phase > 1 ? p.n_phase : 1), dim3(cfg::THREADS), cfg::LDS, st, p);
+    hipLaunchKernelGGL(kern, dim3(tiles, GATHER && p.n_phase > 1 ? p.n_phase : 1, p.split_k ? (unsigned)((p.K + p.split_k - 1) / p.split_k) : 1), dim3(cfg::THREADS), cfg::LDS, st, p);
     WHMR_CHECK_LAUNCH();
     return 0;
 }

@@ -110,12 +110,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const whmr_gemm p, int k_
         const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
         if (m >= p.M) continue;
         float v = acc[r] + bv;
-        if (p.act == 1) v = gelu_erf(v);
-        else if (p.act == 2) v = fmaxf(v, 0.f);
+        float rv = 0.f;
         if (p.residual) {
             const int rr = p.res_row_mod > 0 ? m % p.res_row_mod : m;
-            v += p.residual[(size_t)rr * p.ldr + n];
+            rv = p.residual[(size_t)rr * p.ldr + n];
         }
+        if (p.epi_flags & 2) v += rv;                 // ResNet bottleneck: skip added before the ReLU
+        if (p.act == 1) v = gelu_erf(v);
+        else if (p.act == 2) v = fmaxf(v, 0.f);
+        if (!(p.epi_flags & 2)) v += rv;
         size_t off;
         if (p.c_mode == 1) {
             const int ohw = p.OH * p.OW;
@@ -139,9 +142,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const whmr_gemm p, i
     float v = 0.f;
     for (int s = 0; s < splits; ++s) v += ws[(size_t)s * p.M * p.N];
     if (p.bias) v += p.bias[n];
+    const float rv = p.residual ? p.residual[(size_t)(p.res_row_mod > 0 ? m % p.res_row_mod : m) * p.ldr + n] : 0.f;
+    if (p.epi_flags & 2) v += rv;
     if (p.act == 1) v = gelu_erf(v);
     else if (p.act == 2) v = fmaxf(v, 0.f);
-    if (p.residual) v += p.residual[(size_t)(p.res_row_mod > 0 ? m % p.res_row_mod : m) * p.ldr + n];
+    if (!(p.epi_flags & 2)) v += rv;
     const size_t off = (size_t)m * p.ldc + n;
     if (p.out_bf16) ((bf16_t*)p.C)[off] = f32_to_bf16(v);
     else ((float*)p.C)[off] = v;

@@ -19,10 +19,12 @@ struct whmr_gemm {
     int32_t IH, IW, Cin, OH, OW, KW, SH, SW, PH, PW;   // iy = oy*SH + ky - PH, ix = ox*SW + kx - PW
     int32_t c_mode;         // 0 plain rows (m*ldc), 1 spatial scatter: c_off + b*osb + oy*osy + ox*osx
     int64_t c_off, osb, osy, osx;
-    void* workspace;        // optional scratch for split-K partial sums (fp32 kernel, skinny shapes); may be null
+    void* workspace;        // optional scratch for split-K partial sums (skinny / few-tile shapes); may be null
     int64_t workspace_bytes;
     // Sub-pixel phases of ConvTranspose2d(k4, s2, p1) in ONE launch (bf16 kernel, a_mode = c_mode = 1): n_phase = 4,
     // phase = blockIdx.y = 2*py + px:  W += phase*phase_w_stride;  PH -= py;  PW -= px;  c_off += py*phase_cy + px*phase_cx.
-    int32_t n_phase, pad_;
+    int32_t n_phase;
+    int32_t epi_flags;      /* bit 0: residual is bf16 (else fp32); bit 1: residual is added BEFORE the activation (ResNet blocks) */
     int64_t phase_w_stride, phase_cy, phase_cx;
+    int64_t split_k;        /* internal (set by the bf16 launcher, pass 0): K elements per split-K slice, blockIdx.z = slice */
 };

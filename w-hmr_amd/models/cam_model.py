@@ -1,13 +1,25 @@
-"""Camera-calibration head (models/cam_model.py:24-81 + utils/cam_utils.py:114-145 of the reference).
+"""Camera-calibration head (models/cam_model.py:24-81 + utils/cam_utils.py:114-145 of the reference) -- SURVEY 8(f) N1.
 
-Not a hand-written-kernel component this round: SURVEY 2.1 row 7 / 8(f) N1 keep the ResNet-50 on PyTorch-ROCm (MIOpen
-convolutions on the same HIP device).  Module/parameter names follow torchvision's ResNet so that
-``cam_model.backbone.*`` checkpoint keys load.  The tiny post-processing (softargmax over 256 bins -> angles ->
-euler -> rotation matrix) is a handful of [B,256] tensor ops.
+Module/parameter names follow torchvision's ResNet so that ``cam_model.backbone.*`` checkpoint keys load.  On a HIP
+device ``CameraRegressorNetwork.forward`` runs the ResNet-50 on libwhmr_hip.so: activations NHWC, eval-mode BatchNorm
+folded into the conv weights, every conv an (implicit-)GEMM on the same MFMA kernels as the ViT --
+
+    stem 7x7 s2   im2col (k = ci,ky,kx; K 147 -> 192) + GEMM + ReLU        [bf16]   /  NHWC gather GEMM          [fp32]
+    max-pool      whmr_maxpool_nhwc
+    bottleneck    1x1 GEMM+ReLU -> 3x3 gather GEMM+ReLU -> 1x1 GEMM + skip (added BEFORE the ReLU, epi_flags bit 1);
+                  projection skip = 1x1 (strided) gather GEMM
+    head          whmr_avgpool_nhwc -> one [768,2048] fp32 GEMM for the three fc layers
+
+``numerics``: 'bf16' (bf16 operands/activations, fp32 accumulate) or 'fp32' (exact-f32 MFMA: the 1e-4 parity mode).
+The nn.Module tree (``ResNet50.forward`` etc.) is plain PyTorch and is what tests compare against; the HIP path never
+calls it.  The post-processing (softargmax over 256 bins -> angles -> euler -> rotation matrix) is a handful of
+[B,256] tensor ops.
 """
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from .. import _lib as L
 
 VFOV_RANGE = (0.2617, 2.1)        # utils/cam_utils.py:56
 PITCH_RANGE = (-0.6, 0.6)         # utils/cam_utils.py:38
@@ -75,9 +87,94 @@ class CameraRegressorNetwork(nn.Module):
             nn.init.constant_(fc.bias, 0)
             setattr(self, n, fc)
 
-    def forward(self, images):
+        self.numerics = 'bf16'
+        self._prep = None
+
+    # ------------------------------------------------------------------ reference-shaped PyTorch forward (test oracle for the HIP path)
+    def forward_torch(self, images):
         x = torch.flatten(self.avgpool(self.backbone(images)), 1)
         return [self.fc_vfov(x), self.fc_pitch(x), self.fc_roll(x)], x
+
+    # ------------------------------------------------------------------ HIP path
+    def _versions(self):
+        return tuple(t._version for t in list(self.parameters()) + list(self.buffers())) + (self.numerics, str(self.fc_vfov.weight.device))
+
+    def _prepare(self):
+        """Fold BN into the conv weights, lay them out [N, (ky, kx, ci)] in the compute dtype (cached until a tensor changes)."""
+        key = self._versions()
+        if self._prep is not None and self._prep['key'] == key:
+            return self._prep
+        dt = torch.float32 if self.numerics == 'fp32' else torch.bfloat16
+
+        def fold(conv, bn, stem_cols=False):
+            s = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach().float()
+            w = conv.weight.detach().float() * s[:, None, None, None]
+            b = (bn.bias - bn.running_mean * s).detach().float().contiguous()
+            if stem_cols:                                          # im2col column order (ci, ky, kx), K padded to 192
+                w = F.pad(w.reshape(w.shape[0], -1), (0, 192 - w[0].numel()))
+            else:
+                w = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
+            return w.to(dt).contiguous(), b
+
+        bb = self.backbone
+        prep = {'key': key, 'stem': fold(bb.conv1, bb.bn1, stem_cols=(dt == torch.bfloat16)), 'blocks': []}
+        for li in range(1, 5):
+            for blk in getattr(bb, 'layer%d' % li):
+                prep['blocks'].append(dict(c1=fold(blk.conv1, blk.bn1), c2=fold(blk.conv2, blk.bn2), c3=fold(blk.conv3, blk.bn3),
+                                           stride=blk.conv2.stride[0],
+                                           down=fold(blk.downsample[0], blk.downsample[1]) if blk.downsample is not None else None))
+        prep['fc_w'] = torch.cat([self.fc_vfov.weight, self.fc_pitch.weight, self.fc_roll.weight], 0).detach().float().contiguous()
+        prep['fc_b'] = torch.cat([self.fc_vfov.bias, self.fc_pitch.bias, self.fc_roll.bias], 0).detach().float().contiguous()
+        self._prep = prep
+        return prep
+
+    @torch.no_grad()
+    def forward(self, images):
+        if not images.is_cuda:
+            raise RuntimeError('whmr_amd.CameraRegressorNetwork runs on a HIP device only (no CPU fallback)')
+        if self.training:
+            raise RuntimeError('the HIP ResNet-50 folds eval-mode BatchNorm; call .eval() (the reference freezes cam_model, whmr.py:507)')
+        P = self._prepare()
+        dt = torch.float32 if self.numerics == 'fp32' else torch.bfloat16
+        dev = images.device
+        B, _, H, W = images.shape
+        w, b = P['stem']
+        if dt == torch.bfloat16:
+            cols, OH, OW = L.conv_im2col(images.float(), 7, 7, 2, 3, 192)
+            x = torch.empty(B, OH, OW, 64, dtype=dt, device=dev)
+            L.gemm(cols, w, x, bias=b, act=L.ACT_RELU)
+        else:
+            OH, OW = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+            x = torch.empty(B, OH, OW, 64, dtype=dt, device=dev)
+            L.gemm(images.float().permute(0, 2, 3, 1).contiguous(), w, x, bias=b, act=L.ACT_RELU,
+                   conv=dict(IH=H, IW=W, Cin=3, OH=OH, OW=OW, KW=7, SH=2, SW=2, PH=3, PW=3))
+        x = L.maxpool_nhwc(x, 3, 2, 1)
+        for blk in P['blocks']:
+            _, IH, IW, Cin = x.shape
+            s = blk['stride']
+            OH, OW = (IH - 1) // s + 1, (IW - 1) // s + 1
+            planes = blk['c1'][0].shape[0]
+            y1 = torch.empty(B, IH, IW, planes, dtype=dt, device=dev)
+            L.gemm(x, blk['c1'][0], y1, bias=blk['c1'][1], act=L.ACT_RELU)
+            y2 = torch.empty(B, OH, OW, planes, dtype=dt, device=dev)
+            L.gemm(y1, blk['c2'][0], y2, bias=blk['c2'][1], act=L.ACT_RELU,
+                   conv=dict(IH=IH, IW=IW, Cin=planes, OH=OH, OW=OW, KW=3, SH=s, SW=s, PH=1, PW=1))
+            if blk['down'] is None:
+                skip = x
+            else:
+                skip = torch.empty(B, OH, OW, planes * 4, dtype=dt, device=dev)
+                if s == 1:
+                    L.gemm(x, blk['down'][0], skip, bias=blk['down'][1])
+                else:
+                    L.gemm(x, blk['down'][0], skip, bias=blk['down'][1],
+                           conv=dict(IH=IH, IW=IW, Cin=Cin, OH=OH, OW=OW, KW=1, SH=s, SW=s, PH=0, PW=0))
+            x = torch.empty(B, OH, OW, planes * 4, dtype=dt, device=dev)
+            L.gemm(y2, blk['c3'][0], x, bias=blk['c3'][1], act=L.ACT_RELU, residual=skip.view(-1, planes * 4), res_first=True)
+        feat = L.avgpool_nhwc(x)
+        logits = torch.empty(B, P['fc_w'].shape[0], dtype=torch.float32, device=dev)
+        L.gemm(feat, P['fc_w'], logits, bias=P['fc_b'])
+        n = self.num_out_channels
+        return [logits[:, :n], logits[:, n:2 * n], logits[:, 2 * n:]], feat
 
 
 def softargmax1d(logits):

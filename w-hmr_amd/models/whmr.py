@@ -283,6 +283,7 @@ class WHMR(nn.Module):
         self.avgpool = nn.AvgPool1d(kernel_size=5)
         self.est_Tz = nn.Sequential(nn.Linear(18 * 12, 12), nn.Linear(12, 1), nn.BatchNorm1d(1), nn.Sigmoid())
         self.cam_model = CameraRegressorNetwork(backbone='resnet50', num_fc_layers=1, num_fc_channels=1024)
+        self.cam_model.numerics = numerics
         if pretrained and cam_ckpt and os.path.exists(cam_ckpt):
             sd = torch.load(cam_ckpt, map_location='cpu')['state_dict']
             self.cam_model.load_state_dict({k.replace('model.', '', 1): v for k, v in sd.items()}, strict=True)
