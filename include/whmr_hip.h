@@ -52,6 +52,8 @@ int whmr_gemm_bf16(const struct whmr_gemm* p, int flags, void* stream);
 /* Same contract with an explicit tile id: 64 = 128x128x64 (4 waves, 2 blocks/CU), 128 = 128x256x32 (4 waves, 3-stage),
  * 192 = 192x256x64, 257 = 256x256x64 (8 waves, 2-stage), 256 = 256x256x32 (8 waves, 4-stage). */
 int whmr_gemm_bf16_big(const struct whmr_gemm* p, int tile, void* stream);
+/* Same, K sliced over `splits` blocks per tile (fp32 partial sums in p->workspace, deterministic epilogue pass). */
+int whmr_gemm_bf16_split(const struct whmr_gemm* p, int tile, int splits, void* stream);
 
 /* exact-fp32 MFMA GEMM (v_mfma_f32_32x32x2_f32), any M/N/K.  Parity mode of the calls above, plus always:
  * Regressor fc1/fc2/decpose/decshape/deccam (whmr.py:118-126), Global_Orient_Regressor (whmr.py:295-301),
@@ -145,7 +147,8 @@ int whmr_maf_sample(const void* fmap, int fmap_bf16, long sb, long sc, long sy, 
                     void* stream);
 
 /* ---- NHWC helpers for the camera-calibration ResNet-50 on the implicit-GEMM kernel (models/cam_model.py:24-81) */
-/* NCHW fp32 image (element strides) -> cols [B*OH*OW, Kpad] bf16, k = (ci, ky, kx), zero padded (stem conv 7x7 s2 p3). */
+/* NCHW fp32 image (element strides) -> cols [B*OH*OW, Kpad] bf16, k = (ci*KH + ky)*8 + kx (kx padded to 8, KW <= 8),
+ * zero padded to Kpad (stem conv 7x7 s2 p3: Kpad = 192). */
 int whmr_conv_im2col(const float* x, void* cols, int B, int Cin, int H, int W, int KH, int KW, int S, int pad, int Kpad,
                      long sb, long sc, long sh, long sw, void* stream);
 /* MaxPool2d(k, s, pad) on NHWC, bf16 (C % 8 == 0) or fp32. */

@@ -249,9 +249,10 @@ def test_nhwc_pools_and_stem_im2col(dev, dt):
     if dt == torch.float32:
         img = torch.randn(2, 3, 50, 71, generator=g)
         cols, OH, OW = L.conv_im2col(img.to(dev)[:, :, 1:, 2:], 7, 7, 2, 3, 192)          # strided view in, like a cropped frame
-        ref = F.unfold(img[:, :, 1:, 2:], 7, padding=3, stride=2).transpose(1, 2).reshape(-1, 147)
+        ref = F.unfold(img[:, :, 1:, 2:], 7, padding=3, stride=2).transpose(1, 2).reshape(-1, 21, 7)      # (ci*7 + ky, kx)
         assert (OH, OW) == (25, 35)
-        assert torch.equal(cols[:, :147].float().cpu(), ref.bfloat16().float()) and not cols[:, 147:].any()
+        got = cols.float().cpu().view(-1, 24, 8)
+        assert torch.equal(got[:, :21, :7], ref.bfloat16().float()) and not got[:, 21:].any() and not got[:, :, 7].any()
 
 
 @pytest.mark.parametrize('numerics,tol', [('fp32', 1e-4), ('bf16', 4e-2)])

@@ -46,6 +46,7 @@ _SIGS = {
     'whmr_gemm_bf16': [C.POINTER(WhmrGemm), _I, _P],
     'whmr_gemm_f32': [C.POINTER(WhmrGemm), _I, _P],
     'whmr_gemm_bf16_big': [C.POINTER(WhmrGemm), _I, _P],
+    'whmr_gemm_bf16_split': [C.POINTER(WhmrGemm), _I, _I, _P],
     'whmr_layernorm': [_P, _P, _P, _P, _I, _I, _F, _I, _P],
     'whmr_patch_im2col': [_P, _P, _I, _I, _I, _I, _I, _I, _L, _L, _L, _L, _I, _P],
     'whmr_cast_f32_bf16': [_P, _P, _L, _P],
@@ -122,7 +123,7 @@ PROFILE = None        # bench.py sets this to a list: (kernel, flops, start_even
 
 
 def gemm(a, w, out, bias=None, residual=None, res_row_mod=0, act=ACT_NONE, conv=None, scatter=None, M=None,
-         lda=None, glds=True, tile=None, phases=None, res_first=False):
+         lda=None, glds=True, tile=None, phases=None, res_first=False, splits=None):
     """out = act(a . w^T + bias) + residual.  a/w dtype selects the kernel (bf16 MFMA or exact-fp32 MFMA).
 
     conv = dict(IH, IW, Cin, OH, OW, KW, SH, SW, PH, PW): a is an NHWC image [B, IH, IW, Cin], rows are output pixels.
@@ -176,6 +177,9 @@ def gemm(a, w, out, bias=None, residual=None, res_row_mod=0, act=ACT_NONE, conv=
         p.workspace, p.workspace_bytes = ws.data_ptr(), ws.numel()
     if tile is not None:                    # explicit tile id (A/B tests), see gemm_bf16_big.hip
         assert a.dtype == torch.bfloat16
+        if splits and splits > 1:
+            _check(lib().whmr_gemm_bf16_split(C.byref(p), int(tile), int(splits), _stream()), 'whmr_gemm_bf16_split')
+            return out
         _check(lib().whmr_gemm_bf16_big(C.byref(p), int(tile), _stream()), 'whmr_gemm_bf16_big')
         return out
     if PROFILE is not None:

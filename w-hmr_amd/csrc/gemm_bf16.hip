@@ -6,8 +6,8 @@
 //
 // All candidate tiles run the same kernel template; what differs is how well the tile grid fills the 256 CUs.
 // Cost model (matches the measured ordering on the ViT-B shapes, profiles/): a launch takes
-//     rounds x (blocks co-resident per CU) x BM x BN x eff,   rounds = ceil(tiles / (256 CUs x blocks per CU))
-// because co-resident blocks share the CU's matrix pipes.  Examples at M = 12544: N = 768 -> 192x256 (198 tiles, one
+//     (full rounds x blocks co-resident per CU + blocks per CU of the last partial round) x BM x BN x eff,
+// a round = 256 CUs x blocks per CU tiles, because co-resident blocks share the CU's matrix pipes.  Examples at M = 12544: N = 768 -> 192x256 (198 tiles, one
 // round of 3/4-size tiles); N = 2304 -> 256x256 (441 tiles, 2 rounds); N = 3072 -> 128x128 (2352 tiles, 4.6 -> 5 rounds).
 #include "common.h"
 #include "gemm_params.h"
@@ -51,6 +51,27 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const whmr_gemm p,
 
 struct tile_cfg { int id, bm, bn, per_cu, eff_pct; };   // eff_pct: measured main-loop cost per tile area, relative to 256x256
 
+// Explicit tile + split-K count (A/B tests; the chooser below calls it too).  Returns hipErrorInvalidValue when the shape cannot
+// be split (no workspace, scatter / phase modes, N or leading dimensions not multiples of 4); `splits` is clamped to the workspace.
+extern "C" int whmr_gemm_bf16_split(const whmr_gemm* pp, int tile, int splits_in, void* stream) {
+    const whmr_gemm& p = *pp;
+    if (!p.workspace || p.n_phase > 1 || p.c_mode != 0 || (p.N & 3) || (p.ldc & 3) || (p.ldr & 3) || (p.K % 64)) return (int)hipErrorInvalidValue;
+    long splits = splits_in;
+    while (splits > 1 && splits * p.M * p.N * 4 > p.workspace_bytes) --splits;
+    if (splits <= 1) return (int)hipErrorInvalidValue;
+    const long kps = ((p.K / 64 + splits - 1) / splits) * 64;
+    splits = (p.K + kps - 1) / kps;
+    whmr_gemm q = p;
+    q.C = p.workspace; q.out_bf16 = 0; q.act = 0; q.bias = nullptr; q.residual = nullptr; q.epi_flags = 0; q.ldc = p.N;
+    q.split_k = kps;
+    const int rc = whmr_gemm_bf16_big(&q, tile, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)(((long)p.M * (p.N >> 2) + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p,
+                       (int)splits);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int whmr_gemm_bf16(const whmr_gemm* pp, int flags, void* stream) {
     const whmr_gemm& p = *pp;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % 64)) return (int)hipErrorInvalidValue;
@@ -58,37 +79,26 @@ extern "C" int whmr_gemm_bf16(const whmr_gemm* pp, int flags, void* stream) {
     if (flags > 1) return whmr_gemm_bf16_big(pp, flags, stream);          // explicit tile id (A/B tests)
     static const tile_cfg cands[] = {{320, 320, 256, 1, 100}, {257, 256, 256, 1, 100}, {192, 192, 256, 1, 100},
                                      {128, 128, 256, 2, 120}, {64, 128, 128, 2, 125}, {65, 128, 64, 3, 150}};
-    long best_cost = -1, best_tiles = 0;
+    // Few tiles and a deep K (ResNet layer3/4 3x3 convs on a frame or two, fc2 of the ViT at batch 1): every block walks K
+    // alone, one exposed L2/HBM round trip per K step on a mostly idle chip.  Slice K over blockIdx.z so that ~2 blocks per
+    // CU are resident; partial sums go to the fp32 workspace and splitk_epilogue_kernel finishes (fixed order: deterministic).
+    // Thresholds from tools/resnet_shapes.py: pays from K >= 2048 when the 128x128 grid covers less than half of the CUs.
+    const long tiles64 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    if (p.workspace && p.n_phase <= 1 && p.K >= 2048 && tiles64 <= 128) {
+        long splits = 512 / tiles64;
+        if (splits > p.K / 512) splits = p.K / 512;
+        if (splits > 1 && whmr_gemm_bf16_split(pp, 64, (int)splits, stream) == 0) return 0;
+    }
+    long best_cost = -1;
     const tile_cfg* best = &cands[4];
     for (const tile_cfg& c : cands) {
         const long tiles = (long)((p.M + c.bm - 1) / c.bm) * ((p.N + c.bn - 1) / c.bn) * (p.n_phase > 1 ? p.n_phase : 1);
         const long slots = 256L * c.per_cu;
-        const long rounds = (tiles + slots - 1) / slots;
-        const long cost = rounds * c.per_cu * c.bm * c.bn * c.eff_pct;
-        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = &c; best_tiles = tiles; }
-    }
-    // Few tiles and a deep K (ResNet layer3/4 convs on one frame, ViT at batch 1): every block walks K alone, one exposed
-    // HBM round trip per K step on a mostly idle chip.  Slice K over blockIdx.z so that the co-resident slots are full;
-    // partial sums go to the fp32 workspace, splitk_epilogue_kernel finishes (fixed summation order: deterministic).
-    const long slots = 256L * best->per_cu;
-    if (p.workspace && p.n_phase <= 1 && p.c_mode == 0 && best->bm <= 128 && best_tiles * 2 <= slots && p.K >= 512 &&
-        !(p.N & 3) && !(p.ldc & 3) && !(p.ldr & 3)) {
-        long splits = slots / best_tiles;
-        if (splits > p.K / 256) splits = p.K / 256;
-        while (splits > 1 && splits * p.M * p.N * 4 > p.workspace_bytes) --splits;
-        if (splits > 1) {
-            long kps = ((p.K / 64 + splits - 1) / splits) * 64;
-            splits = (p.K + kps - 1) / kps;
-            whmr_gemm q = p;
-            q.C = p.workspace; q.out_bf16 = 0; q.act = 0; q.bias = nullptr; q.residual = nullptr; q.epi_flags = 0; q.ldc = p.N;
-            q.split_k = kps;
-            const int rc = whmr_gemm_bf16_big(&q, best->id, stream);
-            if (rc) return rc;
-            hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)(((long)p.M * (p.N >> 2) + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p,
-                               (int)splits);
-            WHMR_CHECK_LAUNCH();
-            return 0;
-        }
+        // full rounds run per_cu co-resident blocks per CU (they share the matrix pipes); the last, partial round only as
+        // many per CU as it has blocks for
+        const long full = tiles / slots, rem = tiles % slots;
+        const long cost = (full * c.per_cu + (rem + 255) / 256) * c.bm * c.bn * c.eff_pct;
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = &c; }
     }
     return whmr_gemm_bf16_big(pp, best->id, stream);
 }

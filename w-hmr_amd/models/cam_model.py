@@ -4,7 +4,7 @@ Module/parameter names follow torchvision's ResNet so that ``cam_model.backbone.
 device ``CameraRegressorNetwork.forward`` runs the ResNet-50 on libwhmr_hip.so: activations NHWC, eval-mode BatchNorm
 folded into the conv weights, every conv an (implicit-)GEMM on the same MFMA kernels as the ViT --
 
-    stem 7x7 s2   im2col (k = ci,ky,kx; K 147 -> 192) + GEMM + ReLU        [bf16]   /  NHWC gather GEMM          [fp32]
+    stem 7x7 s2   im2col (k = ci,ky,kx8; K 168 -> 192) + GEMM + ReLU         [bf16]   /  NHWC gather GEMM          [fp32]
     max-pool      whmr_maxpool_nhwc
     bottleneck    1x1 GEMM+ReLU -> 3x3 gather GEMM+ReLU -> 1x1 GEMM + skip (added BEFORE the ReLU, epi_flags bit 1);
                   projection skip = 1x1 (strided) gather GEMM
@@ -110,8 +110,8 @@ class CameraRegressorNetwork(nn.Module):
             s = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach().float()
             w = conv.weight.detach().float() * s[:, None, None, None]
             b = (bn.bias - bn.running_mean * s).detach().float().contiguous()
-            if stem_cols:                                          # im2col column order (ci, ky, kx), K padded to 192
-                w = F.pad(w.reshape(w.shape[0], -1), (0, 192 - w[0].numel()))
+            if stem_cols:                                          # whmr_conv_im2col column order (ci, ky, kx 7->8), K 168 -> 192
+                w = F.pad(F.pad(w, (0, 1)).reshape(w.shape[0], -1), (0, 192 - 3 * 7 * 8))
             else:
                 w = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
             return w.to(dt).contiguous(), b
