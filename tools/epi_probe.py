@@ -1,3 +1,4 @@
+"""Epilogue decomposition of the four ViT-B GEMMs (M = 12544): full kernel vs main loop only vs cheaper epilogues."""
 import sys, os, math
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,16 +13,19 @@ def timeit(fn, n=30, w=5):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
-N, K = 2304, 768
-a = torch.randn(M, K, device=dev).bfloat16(); w = (torch.randn(N, K, device=dev) / math.sqrt(K)).bfloat16()
-out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
-alias = torch.empty(1, N, device=dev, dtype=torch.bfloat16).expand(M, N)
-print('fill 57.8MB bf16: %.1f us' % timeit(lambda: out.fill_(1.0)))
-big = torch.empty(M, N * 4, device=dev, dtype=torch.bfloat16)
-print('fill 231MB: %.1f us' % timeit(lambda: big.fill_(1.0)))
-print('copy 57.8MB->57.8MB: %.1f us' % timeit(lambda: out.copy_(big[:, :N])))
-for tile in (128, 256):
-    print('tile', tile, 'normal %.1f us' % timeit(lambda: L.gemm(a, w, out, tile=tile)),
-          'aliased-rows (no HBM writes) %.1f us' % timeit(lambda: L.gemm(a, w, alias, tile=tile)),
-          'main-loop-only %.1f us' % timeit(lambda: L.gemm(a, w, out, tile=tile, res_row_mod=-12345)))
-print('128x128 kernel normal %.1f us' % timeit(lambda: L.gemm(a, w, out)), 'aliased %.1f us' % timeit(lambda: L.gemm(a, w, alias)))
+for name, N, K, tiles in (('qkv', 2304, 768, (None, 257, 256, 320)), ('proj', 768, 768, (None, 192, 128, 257)),
+                          ('fc1', 3072, 768, (None, 320, 257, 256)), ('fc2', 768, 3072, (None, 192, 128, 257))):
+    a = torch.randn(M, K, device=dev).bfloat16(); w = (torch.randn(N, K, device=dev) / math.sqrt(K)).bfloat16()
+    bias = torch.randn(N, device=dev)
+    ob = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    of = torch.empty(M, N, device=dev)
+    res = torch.randn(M, N, device=dev)
+    for tile in tiles:
+        r = {}
+        r['main'] = timeit(lambda: L.gemm(a, w, ob, tile=tile or tiles[1], res_row_mod=-12345))
+        r['bf16'] = timeit(lambda: L.gemm(a, w, ob, bias=bias, tile=tile))
+        r['bf16+gelu'] = timeit(lambda: L.gemm(a, w, ob, bias=bias, act=L.ACT_GELU, tile=tile))
+        r['f32'] = timeit(lambda: L.gemm(a, w, of, bias=bias, tile=tile))
+        r['f32+res'] = timeit(lambda: L.gemm(a, w, of, bias=bias, residual=res, tile=tile))
+        r['f32+res inplace'] = timeit(lambda: L.gemm(a, w, res, bias=bias, residual=res, tile=tile))
+        print('%-4s tile %-4s ' % (name, tile) + '  '.join('%s %.1f' % kv for kv in r.items()) + '   (2MNK at 1 PF: %.1f us)' % (2.0 * M * N * K / 1e9), flush=True)

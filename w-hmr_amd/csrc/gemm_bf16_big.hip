@@ -297,9 +297,9 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
     };
     auto activate = [&](float* v) {
 #pragma unroll
-        for (int e = 0; e < CPT; ++e) {
-            if (ACT == 1) v[e] = gelu_fast(v[e]);
-            if (ACT == 2) v[e] = fmaxf(v[e], 0.f);
+        for (int e = 0; e < CPT; e += 2) {
+            if (ACT == 1) { const f32x2_t g = gelu_fast2(f32x2_t{v[e], v[e + 1]}); v[e] = g.x; v[e + 1] = g.y; }
+            if (ACT == 2) { v[e] = fmaxf(v[e], 0.f); v[e + 1] = fmaxf(v[e + 1], 0.f); }
         }
     };
     const bool res_bf16 = p.epi_flags & 1, res_first = p.epi_flags & 2;   // ResNet-style epilogue: act(acc + bias + bf16 skip)

@@ -89,14 +89,50 @@ __global__ __launch_bounds__(256) void patch_im2col_kernel(const float* __restri
     }
 }
 
+// P % 8 == 0: one thread per 8 consecutive kx -- index arithmetic once per 8 elements, one (bf16) or two (fp32) 16-B stores.
+template <typename TOUT>
+__global__ __launch_bounds__(256) void patch_im2col8_kernel(const float* __restrict__ x, TOUT* __restrict__ cols,
+                                                            int B, int Cin, int H, int W, int P, int pad, int Hp, int Wp,
+                                                            long sb, long sc, long sh, long sw) {
+    const int K8 = Cin * P * P / 8, P8 = P / 8;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)B * Hp * Wp * K8) return;
+    const int k8 = (int)(idx % K8);
+    const int m = (int)(idx / K8);
+    const int kx = (k8 % P8) * 8, ky = (k8 / P8) % P, ci = k8 / (P8 * P);
+    const int px = m % Wp, py = (m / Wp) % Hp, b = m / (Wp * Hp);
+    const int iy = py * P - pad + ky, ix = px * P - pad + kx;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if ((unsigned)iy < (unsigned)H) {
+        const float* row = x + b * sb + ci * sc + (long)iy * sh;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if ((unsigned)(ix + e) < (unsigned)W) v[e] = row[(long)(ix + e) * sw];
+    }
+    TOUT* dst = cols + idx * 8;
+    if constexpr (sizeof(TOUT) == 2) {
+        *(uint4*)dst = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+    } else {
+        *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+        *(float4*)(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+}
+
 extern "C" int whmr_patch_im2col(const float* x, void* cols, int B, int Cin, int H, int W, int P, int pad,
                                  long sb, long sc, long sh, long sw, int out_bf16, void* stream) {
     const int Hp = (H + 2 * pad - P) / P + 1, Wp = (W + 2 * pad - P) / P + 1;
     const long total = (long)B * Hp * Wp * Cin * P * P;
     if (total <= 0) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    if (P % 8 == 0 && total / 8 < (1L << 31)) {
+        dim3 grid8((unsigned)((total / 8 + 255) / 256)), block8(256);
+        if (out_bf16) hipLaunchKernelGGL(patch_im2col8_kernel<bf16_t>, grid8, block8, 0, st, x, (bf16_t*)cols, B, Cin, H, W, P, pad, Hp, Wp, sb, sc, sh, sw);
+        else hipLaunchKernelGGL(patch_im2col8_kernel<float>, grid8, block8, 0, st, x, (float*)cols, B, Cin, H, W, P, pad, Hp, Wp, sb, sc, sh, sw);
+        WHMR_CHECK_LAUNCH();
+        return 0;
+    }
     const long nb = (total + 255) / 256;
     dim3 grid((unsigned)(nb < 16384 ? nb : 16384)), block(256);
-    hipStream_t st = (hipStream_t)stream;
     if (out_bf16) hipLaunchKernelGGL(patch_im2col_kernel<bf16_t>, grid, block, 0, st, x, (bf16_t*)cols, B, Cin, H, W, P, pad, Hp, Wp, sb, sc, sh, sw);
     else hipLaunchKernelGGL(patch_im2col_kernel<float>, grid, block, 0, st, x, (float*)cols, B, Cin, H, W, P, pad, Hp, Wp, sb, sc, sh, sw);
     WHMR_CHECK_LAUNCH();
