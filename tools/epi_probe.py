@@ -5,6 +5,7 @@ import torch
 from whmr_amd import _lib as L
 dev = torch.device('cuda:0')
 M = 12544
+if len(sys.argv) > 1: M = int(sys.argv[1])
 def timeit(fn, n=30, w=5):
     for _ in range(w): fn()
     torch.cuda.synchronize()
@@ -13,8 +14,8 @@ def timeit(fn, n=30, w=5):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
-for name, N, K, tiles in (('qkv', 2304, 768, (None, 257, 256, 320)), ('proj', 768, 768, (None, 192, 128, 257)),
-                          ('fc1', 3072, 768, (None, 320, 257, 256)), ('fc2', 768, 3072, (None, 192, 128, 257))):
+for name, N, K, tiles in (('qkv', 2304, 768, (None, 257, 258, 259, 257, 258, 259)), ('proj', 768, 768, (None, 192, 258, 259)),
+                          ('fc1', 3072, 768, (None, 320, 258, 259)), ('fc2', 768, 3072, (None, 192, 258, 259)), ('sq4k', 4096, 4096, (257, 258, 259))):
     a = torch.randn(M, K, device=dev).bfloat16(); w = (torch.randn(N, K, device=dev) / math.sqrt(K)).bfloat16()
     bias = torch.randn(N, device=dev)
     ob = torch.empty(M, N, device=dev, dtype=torch.bfloat16)

@@ -45,5 +45,10 @@ print('layernorm: %.3f ms  %.1f GB/s' % (ms, M * 768 * 6 / ms / 1e6))
 
 m = ViT(img_size=224, qkv_bias=True, numerics='bf16').to(dev).eval()
 x = torch.randn(B, 3, 224, 224, device=dev)
+for rnd in range(3):                       # interleaved A/B of the ping-pong main loop (same process, same box)
+    for pp in (0, 1):
+        L.set_option(1, pp)
+        print('  round %d pingpong=%d: %.3f ms' % (rnd, pp, min(timeit(lambda: m(x), n=10) for _ in range(3))))
+L.set_option(1, 0)
 ms = min(timeit(lambda: m(x), n=10) for _ in range(5))
 print('ViT-B 224 B=%d bf16 forward: %.3f ms  %.0f img/s  %.1f TF' % (B, ms, B / ms * 1e3, 34.94e9 * B / ms / 1e9))

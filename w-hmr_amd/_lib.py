@@ -47,6 +47,7 @@ _SIGS = {
     'whmr_gemm_f32': [C.POINTER(WhmrGemm), _I, _P],
     'whmr_gemm_bf16_big': [C.POINTER(WhmrGemm), _I, _P],
     'whmr_gemm_bf16_split': [C.POINTER(WhmrGemm), _I, _I, _P],
+    'whmr_set_option': [_I, _I],
     'whmr_layernorm': [_P, _P, _P, _P, _I, _I, _F, _I, _P],
     'whmr_patch_im2col': [_P, _P, _I, _I, _I, _I, _I, _I, _L, _L, _L, _L, _I, _P],
     'whmr_cast_f32_bf16': [_P, _P, _L, _P],
@@ -393,3 +394,8 @@ def avgpool_nhwc(x):
     _check(lib().whmr_avgpool_nhwc(x.data_ptr(), y.data_ptr(), B, H * W, Cc, int(x.dtype == torch.bfloat16), _stream()),
            'whmr_avgpool_nhwc')
     return y
+
+
+def set_option(key, value):
+    """Tuning switches for A/B measurements (whmr_set_option)."""
+    _check(lib().whmr_set_option(int(key), int(value)), 'whmr_set_option')
