@@ -66,7 +66,8 @@ def test_gemm_bf16_rowmod_residual(dev):
     assert _rel(out.cpu(), ref) < 1e-4
 
 
-@pytest.mark.parametrize('M,N,K', [(64, 1024, 2250), (2, 216, 1024), (64, 3, 1024), (392, 768, 768), (320, 648, 216), (77, 130, 33)])
+@pytest.mark.parametrize('M,N,K', [(64, 1024, 2250), (2, 216, 1024), (64, 3, 1024), (392, 768, 768), (320, 648, 216), (77, 130, 33),
+                                   (64, 1024, 2149), (64, 20670, 207), (5, 144, 1024), (1, 1024, 2149), (64, 2048, 2164), (33, 70, 31)])
 def test_gemm_f32(dev, M, N, K):
     from whmr_amd import _lib as L
     g = torch.Generator().manual_seed(M * 7 + N + K)

@@ -11,6 +11,14 @@ dev = torch.device('cuda:0')
 H1, W1 = 150, 200
 def hw(l): return ((H1 - 1) // (2 ** l) + 1 if l else H1, (W1 - 1) // (2 ** l) + 1 if l else W1)
 dims = {0: (150, 200), 1: (75, 100), 2: (38, 50), 3: (19, 25)}
+def bench(fn, iters=20):
+    for _ in range(3): fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
 shapes = []   # (name, kind, in_level, out_level, Cin, N, skip)
 for li, planes in enumerate([64, 128, 256, 512]):
     cin_first = 64 if li == 0 else planes * 2
@@ -30,6 +38,15 @@ def bench(fn, iters=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
 
+if len(sys.argv) > 2 and sys.argv[2] == 'tz':        # Tz head conv0 of W-HMR (whmr.py:419): 7x7 s3, 256 -> 64 on the 128x96 map, batch n
+    for bs in (n,):
+        x = torch.randn(bs, 128, 96, 256, device=dev).bfloat16()
+        w = (torch.randn(64, 49 * 256, device=dev) / 112.).bfloat16()
+        out = torch.empty(bs, 41, 31, 64, device=dev, dtype=torch.bfloat16)
+        conv = dict(IH=128, IW=96, Cin=256, OH=41, OW=31, KW=7, SH=3, SW=3, PH=0, PW=0)
+        for tile in (None, 65, 66, 67, 64):
+            print('tz conv0 B=%d tile %s: %.1f us' % (bs, tile, bench(lambda: L.gemm(x, w, out.view(-1, 64), conv=conv, tile=tile))), flush=True)
+    sys.exit(0)
 for name, kind, lin, lout, Cin, N, skip in shapes:
     IH, IW = dims[lin]; OH, OW = dims[lout]; s = 1 if lin == lout else 2
     x = torch.randn(n, IH, IW, Cin, device=dev).bfloat16()
@@ -49,7 +66,7 @@ for name, kind, lin, lout, Cin, N, skip in shapes:
     def run(tile=None, splits=None):
         return bench(lambda: L.gemm(x, w, out, bias=bias, act=L.ACT_RELU, conv=conv, residual=sk, res_first=skip, tile=tile, splits=splits))
     res.append(('auto', run()))
-    for tile in (65, 64, 128, 256, 192, 257, 320):
+    for tile in (65, 66, 67, 64, 128, 256, 192, 257, 320):
         if tile in (128, 256) and conv is not None and Cin % 32: continue
         res.append((str(tile), run(tile)))
         if K >= 512 and tile in (65, 64, 128):

@@ -577,6 +577,8 @@ extern "C" int whmr_gemm_bf16_big(const whmr_gemm* pp, int tile, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     switch (tile) {
         case 65: return launch_big_mode<128, 64, 64, 2, 1, 2, 2, 0>(p, st);       // 48 KiB, 2 waves: narrow-N convs (N <= 64), 3 blocks / CU
+        case 66: return launch_big_mode<128, 64, 32, 2, 1, 4, 2, 0>(p, st);       // 48 KiB, 2 waves, 4-stage ring of BK = 32: deep-K narrow-N convs
+        case 67: return launch_big_mode<128, 64, 64, 2, 1, 3, 2, 0>(p, st);       // 72 KiB, 2 waves, 3-stage ring of BK = 64
         case 64: return launch_big_mode<128, 128, 64, 2, 2, 2, 2, 0>(p, st);      // 64 KiB, 4 waves (64x64 wave tiles): 2 blocks / CU
         case 128: return launch_big_mode<128, 256, 32, 1, 4, 3, 2, 0>(p, st);     // 72 KiB: 2 blocks / CU
         case 256: return launch_big_mode<256, 256, 32, 2, 4, 4, 2, 0>(p, st);     // 128 KiB: 1 block / CU, 3 steps ahead

@@ -133,14 +133,125 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const whmr_gemm p, int k_
     }
 }
 
+// ---- skinny variant (M <= 1024, typically M = batch: regressor / global-orient / Tz linears, SMPL pose-corrective product; whmr.py:118-126,295-301).
+// These GEMMs stream a weight matrix (9-17 MB) past 64 activation rows: the job is to keep HBM busy, not the matrix pipes.
+// Same 64x64 tile and exact-f32 MFMA as above, but K steps of 32 with the NEXT step's global loads (4 x 16 B per thread)
+// issued before the current step's MFMAs, so every block always has 16 KB in flight instead of one exposed round trip
+// per 16-wide K step.  Rows are only 4-byte aligned in general (K = 2149, 207): the 16-B loads are declared align(4).
+#define SBK 32
+#define SLD 33
+typedef float f32x4u_t __attribute__((ext_vector_type(4), aligned(4)));
+
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void gemm_f32_skinny_kernel(const whmr_gemm p, int k_per_split) {
+    __shared__ float sA[64 * SLD];
+    __shared__ float sB[64 * SLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * 64, m0 = blockIdx.z * 64;
+    const float* __restrict__ A = (const float*)p.A;
+    const float* __restrict__ W = (const float*)p.W;
+    const int k_begin = SPLIT ? blockIdx.y * k_per_split : 0;
+    const int k_end = SPLIT ? min(p.K, k_begin + k_per_split) : p.K;
+    // staging: thread -> rows (tid >> 3) and (tid >> 3) + 32, 4 consecutive k at (tid & 7) * 4
+    const int srow = tid >> 3, sk = (tid & 7) * 4;
+    const float* a_ptr[2];
+    const float* b_ptr[2];
+    bool a_ok[2], b_ok[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int r = srow + 32 * h;
+        a_ok[h] = m0 + r < p.M;
+        b_ok[h] = n0 + r < p.N;
+        a_ptr[h] = A + (size_t)(a_ok[h] ? m0 + r : 0) * p.lda + sk;
+        b_ptr[h] = W + (size_t)(b_ok[h] ? n0 + r : 0) * p.K + sk;
+    }
+    float ra[2][4], rb[2][4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (k0 + sk + 4 <= k_end) {                          // whole 16-B group inside the slice
+                const f32x4u_t va = a_ok[h] ? *(const f32x4u_t*)(a_ptr[h] + k0) : f32x4u_t{0.f, 0.f, 0.f, 0.f};
+                const f32x4u_t vb = b_ok[h] ? *(const f32x4u_t*)(b_ptr[h] + k0) : f32x4u_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { ra[h][e] = va[e]; rb[h][e] = vb[e]; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool in = k0 + sk + e < k_end;
+                    ra[h][e] = (in && a_ok[h]) ? a_ptr[h][k0 + e] : 0.f;
+                    rb[h][e] = (in && b_ok[h]) ? b_ptr[h][k0 + e] : 0.f;
+                }
+            }
+        }
+    };
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hi = lane >> 5;
+    f32x16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (k_begin < k_end) fetch(k_begin);
+    for (int k0 = k_begin; k0 < k_end; k0 += SBK) {
+        __syncthreads();                                         // previous step's fragment reads are done
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sA[(srow + 32 * h) * SLD + sk + e] = ra[h][e];
+                sB[(srow + 32 * h) * SLD + sk + e] = rb[h][e];
+            }
+        __syncthreads();
+        if (k0 + SBK < k_end) fetch(k0 + SBK);                   // in flight under the MFMAs below
+#pragma unroll
+        for (int kk = 0; kk < SBK; kk += 2) {
+            const float a = sA[(wm * 32 + l31) * SLD + kk + hi];
+            const float b = sB[(wn * 32 + l31) * SLD + kk + hi];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+    }
+    const int n = n0 + wn * 32 + l31;
+    if (n >= p.N) return;
+    if constexpr (SPLIT) {
+        float* ws = (float*)p.workspace + (size_t)blockIdx.y * p.M * p.N;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (m < p.M) ws[(size_t)m * p.N + n] = acc[r];
+        }
+        return;
+    }
+    const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (m >= p.M) continue;
+        float v = acc[r] + bv;
+        const float rv = p.residual ? p.residual[(size_t)(p.res_row_mod > 0 ? m % p.res_row_mod : m) * p.ldr + n] : 0.f;
+        if (p.epi_flags & 2) v += rv;
+        if (p.act == 1) v = gelu_erf(v);
+        else if (p.act == 2) v = fmaxf(v, 0.f);
+        if (!(p.epi_flags & 2)) v += rv;
+        const size_t off = (size_t)m * p.ldc + n;
+        if (p.out_bf16) ((bf16_t*)p.C)[off] = f32_to_bf16(v);
+        else ((float*)p.C)[off] = v;
+    }
+}
+
 // Sum the split-K partials in a fixed order (deterministic), then the usual epilogue.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const whmr_gemm p, int splits) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long)p.M * p.N) return;
     const int m = (int)(idx / p.N), n = (int)(idx - (long)m * p.N);
     const float* ws = (const float*)p.workspace + idx;
+    const size_t stride = (size_t)p.M * p.N;
     float v = 0.f;
-    for (int s = 0; s < splits; ++s) v += ws[(size_t)s * p.M * p.N];
+    int s = 0;
+    for (; s + 8 <= splits; s += 8) {                 // 8 independent loads in flight, summed in split order
+        float t[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = ws[(size_t)(s + e) * stride];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v += t[e];
+    }
+    for (; s < splits; ++s) v += ws[(size_t)s * stride];
     if (p.bias) v += p.bias[n];
     const float rv = p.residual ? p.residual[(size_t)(p.res_row_mod > 0 ? m % p.res_row_mod : m) * p.ldr + n] : 0.f;
     if (p.epi_flags & 2) v += rv;
@@ -158,6 +269,28 @@ extern "C" int whmr_gemm_f32(const whmr_gemm* pp, int flags, void* stream) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return (int)hipErrorInvalidValue;
     const int tiles = ((p.M + FBM - 1) / FBM) * ((p.N + FBN - 1) / FBN);
     hipStream_t st = (hipStream_t)stream;
+    if (p.M <= 1024 && p.a_mode == 0 && p.c_mode == 0) {
+        // weight-streaming regime: ~2 blocks per CU so that the whole weight matrix is in flight at once
+        const int tiles_n = (p.N + 63) / 64, tiles_m = (p.M + 63) / 64, tiles = tiles_n * tiles_m;
+        int splits = 1;
+        if (p.workspace && tiles < 384 && p.K >= 256) {
+            splits = (512 + tiles - 1) / tiles;              // ~2 blocks per CU
+            if (splits > p.K / 128) splits = p.K / 128;      // >= 4 pipelined K steps each; partial-sum traffic <= 1/2 of the weights
+            if (splits > 32) splits = 32;
+            while (splits > 1 && (int64_t)splits * p.M * p.N * 4 > p.workspace_bytes) --splits;
+        }
+        if (splits > 1) {
+            int kps = (p.K + splits - 1) / splits;
+            kps = (kps + SBK - 1) / SBK * SBK;
+            splits = (p.K + kps - 1) / kps;
+            hipLaunchKernelGGL((gemm_f32_skinny_kernel<true>), dim3(tiles_n, splits, tiles_m), dim3(256), 0, st, p, kps);
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((long)p.M * p.N + 255) / 256)), dim3(256), 0, st, p, splits);
+        } else {
+            hipLaunchKernelGGL((gemm_f32_skinny_kernel<false>), dim3(tiles_n, 1, tiles_m), dim3(256), 0, st, p, 0);
+        }
+        WHMR_CHECK_LAUNCH();
+        return 0;
+    }
     // Skinny shapes (M = batch: regressor / global-orient / Tz linears) leave most CUs idle and are weight-streaming bound:
     // split K across blocks so that ~2 blocks per CU stream the weight matrix concurrently.
     int splits = 1;

@@ -111,10 +111,21 @@ class Regressor(nn.Module):
         self.ssm = np.asarray(assets['ssm'])
         self._cache = _Cache()
 
-    def _heads(self):
-        ws = [self.decpose.weight, self.decshape.weight, self.deccam.weight, self.decpose.bias, self.decshape.bias, self.deccam.bias]
-        return self._cache.get('heads', ws, lambda: (torch.cat([w.detach() for w in ws[:3]], 0).contiguous(),
-                                                     torch.cat([b.detach() for b in ws[3:]], 0).contiguous()))
+    def _collapsed(self):
+        """fc1 -> fc2 -> [decpose | decshape | deccam] has no nonlinearity between its layers (whmr.py:118-126; the dropouts are
+        identities in eval), so the stage is ONE affine map: W = Wh.W2.W1 [229, in], b = Wh.(W2.b1 + b2) + bh.  Built once per
+        weight version in fp64 and rounded to fp32: the regressor then streams 2.2 MB instead of 13.5 MB per iteration and is
+        one launch instead of three.  (Different fp32 association than the reference's three sgemm calls: ~1e-7 relative.)"""
+        ws = [self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, self.decpose.weight, self.decshape.weight,
+              self.deccam.weight, self.decpose.bias, self.decshape.bias, self.deccam.bias]
+
+        def build():
+            w1, b1, w2, b2 = (t.detach().double() for t in ws[:4])
+            wh = torch.cat([w.detach().double() for w in ws[4:7]], 0)
+            bh = torch.cat([b.detach().double() for b in ws[7:]], 0)
+            w21 = w2 @ w1
+            return (wh @ w21).float().contiguous(), (wh @ (w2 @ b1 + b2) + bh).float().contiguous()
+        return self._cache.get('collapsed', ws, build)
 
     def _downsample(self, verts):
         """whmr.py:182-183 (train view only): dense Dmap0 / Dmap1 products on the fp32 GEMM kernel."""
@@ -167,14 +178,10 @@ class Regressor(nn.Module):
         xc[:, F + 5:F + 221] = pose                                                   # whmr.py:119
         xc[:, F + 221:F + 231] = shape
         xc[:, F + 231:] = cam
-        h1 = torch.empty(B, 1024, dtype=torch.float32, device=dev)
-        h2 = torch.empty(B, 1024, dtype=torch.float32, device=dev)
         new = torch.empty(B, 229, dtype=torch.float32, device=dev)
-        wh, bh = self._heads()
+        w_eff, b_eff = self._collapsed()
         for _ in range(n_iter):
-            L.gemm(xc, self.fc1.weight.detach(), h1, bias=self.fc1.bias.detach())
-            L.gemm(h1, self.fc2.weight.detach(), h2, bias=self.fc2.bias.detach())
-            L.gemm(h2, wh, new, bias=bh, residual=xc[:, F + 5:])                      # whmr.py:124-126 (+ residual state)
+            L.gemm(xc, w_eff, new, bias=b_eff, residual=xc[:, F + 5:])                # whmr.py:118-126 as one affine map (+ residual state)
             if n_iter > 1:
                 xc[:, F + 5:] = new
         out = self.smpl.run(new[:, 216:226], new[:, :216], gram_schmidt=True, want_aa=True, want_smpl_joints=True,
@@ -208,6 +215,16 @@ class Global_Orient_Regressor(nn.Module):
         mp = assets['mean_params']
         init_pose = _cpu_rot6d_to_rotmat(torch.from_numpy(np.asarray(mp['pose'], dtype=np.float32)).reshape(1, 24, 6)).reshape(1, 24, 9)
         self.register_buffer('init_pose', init_pose[:, 0])
+        self._cache = _Cache()
+
+    def _collapsed(self):
+        """fc1 -> fc2 -> decrot without a nonlinearity (whmr.py:295-301) = one [9, 2164] affine map (see Regressor._collapsed)."""
+        ws = [self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, self.decrot.weight, self.decrot.bias]
+
+        def build():
+            w1, b1, w2, b2, wd, bd = (t.detach().double() for t in ws)
+            return (wd @ (w2 @ w1)).float().contiguous(), (wd @ (w2 @ b1 + b2) + bd).float().contiguous()
+        return self._cache.get('collapsed', ws, build)
 
     @torch.no_grad()
     def forward(self, x, cam_rotmat, local_orient, is_train=False):
@@ -218,12 +235,9 @@ class Global_Orient_Regressor(nn.Module):
         xc[:, :2149] = x
         xc[:, 2149:2155] = cam_rotmat[:, :, :2].reshape(B, 6)                          # rotmat_to_rot6d, geometry.py:275-286
         xc[:, 2155:] = local_orient.reshape(B, 9)
-        h1 = torch.empty(B, 2048, dtype=torch.float32, device=dev)
-        h2 = torch.empty(B, 2048, dtype=torch.float32, device=dev)
         r = torch.empty(B, 9, dtype=torch.float32, device=dev)
-        L.gemm(xc, self.fc1.weight.detach(), h1, bias=self.fc1.bias.detach())
-        L.gemm(h1, self.fc2.weight.detach(), h2, bias=self.fc2.bias.detach())
-        L.gemm(h2, self.decrot.weight.detach(), r, bias=self.decrot.bias.detach(), residual=xc[:, 2155:])
+        w_eff, b_eff = self._collapsed()
+        L.gemm(xc, w_eff, r, bias=b_eff, residual=xc[:, 2155:])
         return unbiased_gram_schmidt(r.reshape(-1, 1, 3, 3))
 
 
