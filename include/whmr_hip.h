@@ -144,7 +144,7 @@ struct whmr_maf_weights {
  * (sb, sc, sy, sx), fp32 or bf16.  With neither pts2d nor pts3d, fmap is [B,256,P] pre-sampled features (reduce_dim).
  * point_feat (nullable) receives the raw sampled features [B,256,P]. */
 int whmr_maf_sample(const void* fmap, int fmap_bf16, long sb, long sc, long sy, long sx, int H, int W,
-                    const float* pts2d, const float* pts3d, const float* cam, float focal, float res_w, float res_h,
+                    const float* pts2d, const float* pts3d, const float* cam, long cam_ld, float focal, float res_w, float res_h,
                     const struct whmr_maf_weights* w, int B, int P, float* out, long out_stride, float* point_feat,
                     void* stream);
 
@@ -157,6 +157,11 @@ int whmr_conv_im2col(const float* x, void* cols, int B, int Cin, int H, int W, i
 int whmr_maxpool_nhwc(const void* x, void* y, int B, int H, int W, int C, int k, int s, int pad, int is_bf16, void* stream);
 /* AdaptiveAvgPool2d((1,1)) on NHWC bf16 / fp32 -> [B, C] fp32 (C % 64 == 0). */
 int whmr_avgpool_nhwc(const void* x, float* y, int B, int HW, int C, int is_bf16, void* stream);
+
+/* Regressor input assembly (whmr.py:105,119): xc[b, F..F+234) = [bbox_info(5) | pose(216) | shape(10) | cam(3)].  pose / shape /
+ * cam rows have element row strides ld_* (0 = one broadcast row). */
+int whmr_regressor_state(const float* bbox_info, const float* pose, long ld_p, const float* shape, long ld_s, const float* cam,
+                         long ld_c, int B, float* xc, long ld, int F, void* stream);
 
 /* Tz-head tail (whmr.py:574-577): tokens [B,T,D] -> mean over T -> Linear(D,Hd) -> Linear(Hd,1) -> BatchNorm1d(1) eval
  * (bn4 = weight, bias, running_mean, running_var) -> sigmoid -> x10. */

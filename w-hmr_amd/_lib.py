@@ -60,7 +60,8 @@ _SIGS = {
     'whmr_regressor_post': [_P, _L, _P, _P, _P, _P, _P, _P, _I, _F, _F, _F, _P, _P, _P, _P, _P, _P],
     'whmr_smpl_skin': [C.POINTER(WhmrSmplModel), _P, _L, _P, _P, _P, _I, _P, _P],
     'whmr_smpl_joints': [C.POINTER(WhmrSmplModel), _P, _P, _I, _P, _P, _P, _P, _P],
-    'whmr_maf_sample': [_P, _I, _L, _L, _L, _L, _I, _I, _P, _P, _P, _F, _F, _F, C.POINTER(WhmrMafWeights), _I, _I, _P, _L, _P, _P],
+    'whmr_maf_sample': [_P, _I, _L, _L, _L, _L, _I, _I, _P, _P, _P, _L, _F, _F, _F, C.POINTER(WhmrMafWeights), _I, _I, _P, _L, _P, _P],
+    'whmr_regressor_state': [_P, _P, _L, _P, _L, _P, _L, _I, _P, _L, _I, _P],
     'whmr_tz_tail': [_P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _F, _P, _P],
     'whmr_conv_im2col': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _L, _L, _L, _P],
     'whmr_maxpool_nhwc': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
@@ -350,8 +351,10 @@ def maf_sample(fmap_nchw, weights, out, pts2d=None, pts3d=None, cam=None, point_
         sb, sc, sy, sx = fmap_nchw.stride()
         P = (pts2d if pts2d is not None else pts3d).shape[1]
     assert out.dtype == torch.float32 and out.stride(-1) == 1
+    assert cam is None or (cam.dtype == torch.float32 and cam.stride(-1) == 1 and cam.shape[-1] == 3)
     _check(lib().whmr_maf_sample(fmap_nchw.data_ptr(), int(fmap_nchw.dtype == torch.bfloat16), sb, sc, sy, sx, H, W,
-                                 _ptr(pts2d), _ptr(pts3d), _ptr(cam), focal, res_w, res_h, C.byref(weights), B, P,
+                                 _ptr(pts2d), _ptr(pts3d), _ptr(cam), cam.stride(0) if cam is not None else 3, focal, res_w, res_h,
+                                 C.byref(weights), B, P,
                                  out.data_ptr(), out.stride(0), _ptr(point_feat), _stream()), 'whmr_maf_sample')
     return out
 
@@ -399,3 +402,14 @@ def avgpool_nhwc(x):
 def set_option(key, value):
     """Tuning switches for A/B measurements (whmr_set_option)."""
     _check(lib().whmr_set_option(int(key), int(value)), 'whmr_set_option')
+
+
+def regressor_state(xc, F, bbox_info, pose, shape, cam):
+    """xc[:, F:F+234] = [bbox_info | pose(216) | shape(10) | cam(3)]; pose/shape/cam [B,.] rows, any row stride (0 = broadcast)."""
+    _dev(xc, bbox_info, pose, shape, cam)
+    B = xc.shape[0]
+    for t, n in ((pose, 216), (shape, 10), (cam, 3)):
+        assert t.dtype == torch.float32 and t.shape == (B, n) and (n == 1 or t.stride(1) == 1)
+    assert bbox_info.dtype == torch.float32 and bbox_info.is_contiguous() and bbox_info.shape == (B, 5)
+    _check(lib().whmr_regressor_state(bbox_info.data_ptr(), pose.data_ptr(), pose.stride(0), shape.data_ptr(), shape.stride(0),
+                                      cam.data_ptr(), cam.stride(0), B, xc.data_ptr(), xc.stride(0), F, _stream()), 'whmr_regressor_state')

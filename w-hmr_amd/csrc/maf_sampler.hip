@@ -23,7 +23,7 @@ struct whmr_maf_weights {
 template <typename TF>
 __global__ __launch_bounds__(128) void maf_sample_kernel(const TF* __restrict__ fmap, long sb, long sc, long sy, long sx,
                                                          int H, int W, const float* __restrict__ pts2d,
-                                                         const float* __restrict__ pts3d, const float* __restrict__ cam,
+                                                         const float* __restrict__ pts3d, const float* __restrict__ cam, long cam_ld,
                                                          float focal, float res_w, float res_h,
                                                          const whmr_maf_weights wts, int P, float* __restrict__ out,
                                                          long out_stride, float* __restrict__ point_feat) {
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(128) void maf_sample_kernel(const TF* __restrict__ 
         if (tid < np && !direct) {
             const int p = p0 + tid;
             if (pts3d) {
-                const float s = cam[3 * b], tx = cam[3 * b + 1], ty = cam[3 * b + 2];
+                const float s = cam[cam_ld * b], tx = cam[cam_ld * b + 1], ty = cam[cam_ld * b + 2];
                 const float tz = 2 * focal / (res_h * s + 1e-9f);
                 const float* q = pts3d + ((size_t)b * P + p) * 3;
                 const float z = q[2] + tz;
@@ -153,18 +153,19 @@ __global__ __launch_bounds__(128) void maf_sample_kernel(const TF* __restrict__ 
 
 // fmap_bf16: element type of the feature map.  pts2d XOR (pts3d, cam) selects the sampling points; with neither, fmap is
 // an already-sampled [B,256,P] feature tensor (strides sb, sc, sx) and only the MLP runs (MAF_Extractor.reduce_dim).
-// out row b starts at out + b*out_stride (>= 32*P), so the result can land inside the regressor's input buffer.
+// out row b starts at out + b*out_stride (>= 32*P), so the result can land inside the regressor's input buffer;
+// cam row b starts at cam + b*cam_ld (a column slice of the regressor state is fine).
 extern "C" int whmr_maf_sample(const void* fmap, int fmap_bf16, long sb, long sc, long sy, long sx, int H, int W,
-                               const float* pts2d, const float* pts3d, const float* cam, float focal, float res_w,
+                               const float* pts2d, const float* pts3d, const float* cam, long cam_ld, float focal, float res_w,
                                float res_h, const whmr_maf_weights* w, int B, int P, float* out, long out_stride,
                                float* point_feat, void* stream) {
     if (B <= 0 || P <= 0 || (pts2d && pts3d) || (pts3d && !cam) || out_stride < 32L * P) return (int)hipErrorInvalidValue;
     dim3 grid((P + PT - 1) / PT, B), block(128);
     hipStream_t st = (hipStream_t)stream;
     if (fmap_bf16) hipLaunchKernelGGL(maf_sample_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)fmap, sb, sc, sy, sx, H, W,
-                                      pts2d, pts3d, cam, focal, res_w, res_h, *w, P, out, out_stride, point_feat);
+                                      pts2d, pts3d, cam, cam_ld, focal, res_w, res_h, *w, P, out, out_stride, point_feat);
     else hipLaunchKernelGGL(maf_sample_kernel<float>, grid, block, 0, st, (const float*)fmap, sb, sc, sy, sx, H, W, pts2d,
-                            pts3d, cam, focal, res_w, res_h, *w, P, out, out_stride, point_feat);
+                            pts3d, cam, cam_ld, focal, res_w, res_h, *w, P, out, out_stride, point_feat);
     WHMR_CHECK_LAUNCH();
     return 0;
 }

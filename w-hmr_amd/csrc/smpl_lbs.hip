@@ -324,3 +324,25 @@ extern "C" int whmr_regressor_post(const float* state, long state_stride, const 
     WHMR_CHECK_LAUNCH();
     return 0;
 }
+
+
+// Regressor input assembly (whmr.py:105,119): xc[b, F..F+234) = [bbox_info(5) | pose(216) | shape(10) | cam(3)] in one launch.
+// pose / shape / cam rows may be strided views (row stride 0 = one broadcast row: the mean-parameter initial state).
+__global__ __launch_bounds__(256) void regressor_state_kernel(const float* __restrict__ bbox, const float* __restrict__ pose, long ld_p,
+                                                              const float* __restrict__ shape, long ld_s, const float* __restrict__ cam,
+                                                              long ld_c, float* __restrict__ xc, long ld, int F) {
+    const int b = blockIdx.x, t = threadIdx.x;
+    float* row = xc + b * ld + F;
+    if (t < 216) row[5 + t] = pose[b * ld_p + t];
+    else if (t < 226) row[5 + t] = shape[b * ld_s + t - 216];
+    else if (t < 229) row[5 + t] = cam[b * ld_c + t - 226];
+    else if (t < 234) row[t - 229] = bbox[b * 5 + t - 229];
+}
+
+extern "C" int whmr_regressor_state(const float* bbox_info, const float* pose, long ld_p, const float* shape, long ld_s, const float* cam,
+                                    long ld_c, int B, float* xc, long ld, int F, void* stream) {
+    if (B <= 0) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(regressor_state_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, bbox_info, pose, ld_p, shape, ld_s, cam, ld_c, xc, ld, F);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}

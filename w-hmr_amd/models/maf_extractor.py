@@ -66,5 +66,6 @@ class MAF_Extractor(nn.Module):
         """maf_extractor.py:126-143: weak-perspective projection of p [B,N,3] with cam [B,3], then sampling (fused)."""
         cam = self.cam if cam is None else cam
         im_feat = self.im_feat if s_feat is None else s_feat
-        return self._run(im_feat, pts3d=p.float().contiguous(), cam=cam.float().contiguous(), out=out,
+        return self._run(im_feat, pts3d=p.float().contiguous(), cam=cam if (cam.dtype == torch.float32 and cam.stride(-1) == 1) else cam.float().contiguous(),
+                         out=out,
                          want_point_feat=want_point_feat)

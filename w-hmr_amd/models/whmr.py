@@ -174,10 +174,9 @@ class Regressor(nn.Module):
         pose = (self.init_pose.expand(B, -1) if init_pose is None else init_pose).reshape(B, -1)
         shape = self.init_shape.expand(B, -1) if init_shape is None else init_shape
         cam = self.init_cam.expand(B, -1) if init_cam is None else init_cam
-        xc[:, F:F + 5] = bbox_info                                                    # whmr.py:105
-        xc[:, F + 5:F + 221] = pose                                                   # whmr.py:119
-        xc[:, F + 221:F + 231] = shape
-        xc[:, F + 231:] = cam
+        if pose.stride(-1) != 1 or pose.dtype != torch.float32:
+            pose = pose.float().contiguous()
+        L.regressor_state(xc, F, bbox_info.float().contiguous(), pose, shape.float(), cam.float())     # whmr.py:105,119, one launch
         new = torch.empty(B, 229, dtype=torch.float32, device=dev)
         w_eff, b_eff = self._collapsed()
         for _ in range(n_iter):
@@ -227,17 +226,21 @@ class Global_Orient_Regressor(nn.Module):
         return self._cache.get('collapsed', ws, build)
 
     @torch.no_grad()
-    def forward(self, x, cam_rotmat, local_orient, is_train=False):
+    def forward(self, x, cam_rotmat, local_orient, is_train=False, xc=None):
+        """xc (optional): a buffer with >= 2164 columns whose first 2149 already hold x (the last regressor stage's input buffer);
+        columns 2149..2163 are overwritten in place instead of copying x."""
         if is_train:
             raise NotImplementedError('inference-only this round')
-        B, dev = x.shape[0], x.device
-        xc = torch.empty(B, 2149 + 6 + 9, dtype=torch.float32, device=dev)
-        xc[:, :2149] = x
+        B, dev = cam_rotmat.shape[0], cam_rotmat.device
+        if xc is None:
+            xc = torch.empty(B, 2149 + 6 + 9, dtype=torch.float32, device=dev)
+            xc[:, :2149] = x
+        xc = xc[:, :2164]
         xc[:, 2149:2155] = cam_rotmat[:, :, :2].reshape(B, 6)                          # rotmat_to_rot6d, geometry.py:275-286
         xc[:, 2155:] = local_orient.reshape(B, 9)
         r = torch.empty(B, 9, dtype=torch.float32, device=dev)
         w_eff, b_eff = self._collapsed()
-        L.gemm(xc, w_eff, r, bias=b_eff, residual=xc[:, 2155:])
+        L.gemm(xc, w_eff, r, bias=b_eff, residual=xc[:, 2155:], lda=xc.stride(0))
         return unbiased_gram_schmidt(r.reshape(-1, 1, 3, 3))
 
 
@@ -480,7 +483,7 @@ class WHMR(nn.Module):
                                          is_train=False, n_iter=1, J_regressor=J_regressor, with_aux=with_aux, xc=xc)
             outs.append(smpl_output)
 
-        g_rot = self.global_orient(body_feat, cam_rotmat, smpl_output['rotmat'][:, 0], False)     # whmr.py:630-654
+        g_rot = self.global_orient(body_feat, cam_rotmat, smpl_output['rotmat'][:, 0], False, xc=xc)     # whmr.py:630-654
         g_aa = rotation_matrix_to_angle_axis(g_rot.reshape(-1, 3, 3)).reshape(-1, 3)
         g_pose = torch.cat([g_aa, smpl_output['pose'][:, 3:]], dim=1)
         g_rotmat = torch.cat([g_rot, smpl_output['rotmat'][:, 1:]], dim=1)
