@@ -52,7 +52,8 @@ int whmr_gemm_bf16(const struct whmr_gemm* p, int flags, void* stream);
 /* Same contract with an explicit tile id: 64 = 128x128x64 (4 waves, 2 blocks/CU), 128 = 128x256x32 (4 waves, 3-stage),
  * 192 = 192x256x64, 257 = 256x256x64 (8 waves, 2-stage), 256 = 256x256x32 (8 waves, 4-stage). */
 int whmr_gemm_bf16_big(const struct whmr_gemm* p, int tile, void* stream);
-/* Tuning switch for in-process A/B measurements (key 1: ping-pong 256x256 main loop on/off; default off). */
+/* Tuning switch for in-process A/B measurements (key 1: ping-pong 256x256 main loop on/off, default off;
+ * keys 100..103: force a tile id for the qkv / proj / fc1 / fc2 shapes of the ViT, 0 = chooser). */
 int whmr_set_option(int key, int value);
 /* Same, K sliced over `splits` blocks per tile (fp32 partial sums in p->workspace, deterministic epilogue pass). */
 int whmr_gemm_bf16_split(const struct whmr_gemm* p, int tile, int splits, void* stream);

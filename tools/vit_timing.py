@@ -45,10 +45,16 @@ print('layernorm: %.3f ms  %.1f GB/s' % (ms, M * 768 * 6 / ms / 1e6))
 
 m = ViT(img_size=224, qkv_bias=True, numerics='bf16').to(dev).eval()
 x = torch.randn(B, 3, 224, 224, device=dev)
-for rnd in range(3):                       # interleaved A/B of the ping-pong main loop (same process, same box)
-    for pp in (0, 1):
-        L.set_option(1, pp)
-        print('  round %d pingpong=%d: %.3f ms' % (rnd, pp, min(timeit(lambda: m(x), n=10) for _ in range(3))))
-L.set_option(1, 0)
+def fwd_ms():
+    return min(timeit(lambda: m(x), n=10) for _ in range(3))
+# in-model A/B (same process, same box): per-shape tile overrides, interleaved with the default
+for slot, name, tiles in ((0, 'qkv', (257, 259, 256, 320, 192)), (1, 'proj', (192, 257, 259, 128, 64)), (2, 'fc1', (320, 257, 259, 192)),
+                          (3, 'fc2', (192, 257, 259, 320, 128))):
+    res = []
+    for t in tiles:
+        L.set_option(100 + slot, 0); base = fwd_ms()
+        L.set_option(100 + slot, t); res.append('%d: %+.0f us' % (t, (fwd_ms() - base) * 1e3))
+    L.set_option(100 + slot, 0)
+    print('  %-4s tile override vs chooser (per forward): %s' % (name, '  '.join(res)), flush=True)
 ms = min(timeit(lambda: m(x), n=10) for _ in range(5))
 print('ViT-B 224 B=%d bf16 forward: %.3f ms  %.0f img/s  %.1f TF' % (B, ms, B / ms * 1e3, 34.94e9 * B / ms / 1e9))

@@ -56,8 +56,10 @@ struct tile_cfg { int id, bm, bn, per_cu, eff_pct; };
 // Ping-pong wins the isolated GEMM benchmark (qkv 59.5 -> 56 us, 4096-deep K +10 %) but loses inside the ViT forward
 // (3.64 -> 3.69 ms per batch-64 step, interleaved A/B on one box), so it ships off.
 static int g_opt_pingpong = 0;
+static int g_opt_tile[4] = {0, 0, 0, 0};   // options 100..103: force a tile id for N = 2304 / (768, K <= 1024) / 3072 / (768, K > 1024); 0 = chooser
 extern "C" int whmr_set_option(int key, int value) {
     if (key == 1) { g_opt_pingpong = value; return 0; }
+    if (key >= 100 && key < 104) { g_opt_tile[key - 100] = value; return 0; }
     return (int)hipErrorInvalidValue;
 }   // eff_pct: measured main-loop cost per tile area, relative to 256x256
 
@@ -87,6 +89,10 @@ extern "C" int whmr_gemm_bf16(const whmr_gemm* pp, int flags, void* stream) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % 64)) return (int)hipErrorInvalidValue;
     if (p.n_phase > 1 && (p.n_phase != 4 || p.a_mode != 1 || p.c_mode != 1)) return (int)hipErrorInvalidValue;
     if (flags > 1) return whmr_gemm_bf16_big(pp, flags, stream);          // explicit tile id (A/B tests)
+    {
+        const int slot = p.N == 2304 ? 0 : p.N == 3072 ? 2 : p.N == 768 ? (p.K <= 1024 ? 1 : 3) : -1;
+        if (slot >= 0 && g_opt_tile[slot] && p.a_mode == 0) return whmr_gemm_bf16_big(pp, g_opt_tile[slot], stream);
+    }
     static const tile_cfg cands[] = {{320, 320, 256, 1, 100}, {259, 256, 256, 1, 94}, {192, 192, 256, 1, 100},
                                      {128, 128, 256, 2, 120}, {64, 128, 128, 2, 125}, {65, 128, 64, 3, 150}};
     // Few tiles and a deep K (ResNet layer3/4 3x3 convs on a frame or two, fc2 of the ViT at batch 1): every block walks K
