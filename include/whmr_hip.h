@@ -164,6 +164,13 @@ int whmr_avgpool_nhwc(const void* x, float* y, int B, int HW, int C, int is_bf16
 int whmr_regressor_state(const float* bbox_info, const float* pose, long ld_p, const float* shape, long ld_s, const float* cam,
                          long ld_c, int B, float* xc, long ld, int F, void* stream);
 
+/* ---- input side: cv2.warpAffine (8-bit INTER_LINEAR, BORDER_CONSTANT 0) + ToTensor + Normalize of
+ * datasets/data_utils/img_utils.py:89-101,209-242,318-326 for all B detections of one uint8 HWC frame.  inv_affine: B x 6
+ * doubles, the inverse 2x3 maps (patch pixel -> frame pixel).  out [B,3,patch_h,x_end-x_begin] fp32; raw (nullable) uint8 HWC. */
+int whmr_crop_normalize(const uint8_t* frame, int H, int W, long row_stride, const double* inv_affine, int B, int patch_w,
+                        int patch_h, int x_begin, int x_end, float* out, uint8_t* raw, const float* mean3, const float* std3,
+                        void* stream);
+
 /* Tz-head tail (whmr.py:574-577): tokens [B,T,D] -> mean over T -> Linear(D,Hd) -> Linear(Hd,1) -> BatchNorm1d(1) eval
  * (bn4 = weight, bias, running_mean, running_var) -> sigmoid -> x10. */
 int whmr_tz_tail(const float* tok, int B, int T, int D, const float* w0, const float* b0, int Hd, const float* w1,

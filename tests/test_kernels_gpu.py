@@ -316,3 +316,24 @@ def test_conv3x3_bf16_split_k(dev):
     L.gemm(x.permute(0, 2, 3, 1).contiguous().to(dev), w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to(dev), out,
            bias=bias.to(dev), act=L.ACT_RELU, conv=dict(IH=H, IW=W, Cin=Cin, OH=H, OW=W, KW=3, SH=1, SW=1, PH=1, PW=1))
     assert _rel(out.cpu(), ref) < 2e-5
+
+
+def test_crop_normalize_matches_oracle(dev):
+    """all person crops of a frame in one launch == the per-detection cv2-style CPU restatement, bit for bit."""
+    import numpy as np
+    from oracle import crop as OC
+    from whmr_amd.datasets.img_utils import crop_persons, get_single_image_crop_demo
+    rng = np.random.default_rng(5)
+    frame = rng.integers(0, 256, size=(360, 640, 3), dtype=np.uint8)
+    boxes = [(320.0, 180.0, 200.0, 200.0), (20.5, 30.25, 150.0, 150.0), (600.0, 340.0, 333.3, 333.3), (100.0, 100.0, 37.0, 37.0),
+             (319.7, 12.0, 512.0, 512.0)]                                  # centred, off the top-left / bottom-right edges, up- and down-scaled
+    out, raw = crop_persons(torch.from_numpy(frame).to(dev), boxes, crop_size=256, scale=1.0, want_raw=True)
+    sl = crop_persons(torch.from_numpy(frame).to(dev), boxes, crop_size=256, scale=1.0, x_slice=(32, 224))
+    for i, b in enumerate(boxes):
+        ref, ref_raw, _ = OC.get_single_image_crop_demo(frame, b, None, scale=1.0, crop_size=256)
+        assert np.array_equal(raw[i].cpu().numpy(), ref_raw)
+        assert np.array_equal(out[i].cpu().numpy(), ref)
+        assert np.array_equal(sl[i].cpu().numpy(), ref[:, :, 32:224])          # demo/tester.py:151
+    one, one_raw, _ = get_single_image_crop_demo(torch.from_numpy(frame).to(dev), boxes[0], None, scale=1.2, crop_size=224)
+    ref, ref_raw, _ = OC.get_single_image_crop_demo(frame, boxes[0], None, scale=1.2, crop_size=224)
+    assert np.array_equal(one.cpu().numpy(), ref) and np.array_equal(one_raw.cpu().numpy(), ref_raw)

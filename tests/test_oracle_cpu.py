@@ -127,3 +127,21 @@ def test_oracle_config1_hmr_matches_reference_fixture(assets):
     assert f.shape == (1, 2048, 7, 7) and gf.shape == (1, 2048)
     assert _rel(rot, g['rotmat']) < 1e-5 and _rel(shape, g['shape']) < 1e-5 and _rel(cam, g['cam']) < 1e-5
     assert _rel(OS.smpl_forward(shape, rot, assets['smpl'])[0], g['verts']) < 1e-5
+
+
+def test_crop_oracle_known_answers():
+    """oracle/crop.py (cv2 restatement, parity unpinned): identity box reproduces the frame; integer / half-pixel shifts are exact."""
+    import numpy as np
+    from oracle import crop as OC
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, size=(64, 64, 3), dtype=np.uint8)
+    patch, trans = OC.generate_patch_image_cv(img, 32.0, 32.0, 64.0, 64.0, 64, 64, False, 1.0, 0)
+    assert np.allclose(trans, [[1, 0, 0], [0, 1, 0]], atol=1e-12) and np.array_equal(patch, img)
+    shifted, _ = OC.generate_patch_image_cv(img, 35.0, 30.0, 64.0, 64.0, 64, 64, False, 1.0, 0)      # patch(x, y) = img(x + 3, y - 2)
+    assert np.array_equal(shifted[2:, :61], img[:62, 3:]) and not shifted[:2].any() and not shifted[:, 61:].any()
+    half, _ = OC.generate_patch_image_cv(img, 32.5, 32.0, 64.0, 64.0, 64, 64, False, 1.0, 0)         # half-pixel: mean of two neighbours
+    ref = (img[:, :-1].astype(np.int64) + img[:, 1:] + 1) >> 1
+    assert np.array_equal(half[:, :63], ref.astype(np.uint8))
+    t = OC.to_tensor_normalize(img)
+    assert t.shape == (3, 64, 64) and t.dtype == np.float32
+    assert np.allclose(t[0], (img[..., 0] / 255.0 - 0.485) / 0.229, atol=1e-6)

@@ -61,6 +61,7 @@ _SIGS = {
     'whmr_smpl_skin': [C.POINTER(WhmrSmplModel), _P, _L, _P, _P, _P, _I, _P, _P],
     'whmr_smpl_joints': [C.POINTER(WhmrSmplModel), _P, _P, _I, _P, _P, _P, _P, _P],
     'whmr_maf_sample': [_P, _I, _L, _L, _L, _L, _I, _I, _P, _P, _P, _L, _F, _F, _F, C.POINTER(WhmrMafWeights), _I, _I, _P, _L, _P, _P],
+    'whmr_crop_normalize': [_P, _I, _I, _L, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     'whmr_regressor_state': [_P, _P, _L, _P, _L, _P, _L, _I, _P, _L, _I, _P],
     'whmr_tz_tail': [_P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _F, _P, _P],
     'whmr_conv_im2col': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _L, _L, _L, _P],
@@ -413,3 +414,13 @@ def regressor_state(xc, F, bbox_info, pose, shape, cam):
     assert bbox_info.dtype == torch.float32 and bbox_info.is_contiguous() and bbox_info.shape == (B, 5)
     _check(lib().whmr_regressor_state(bbox_info.data_ptr(), pose.data_ptr(), pose.stride(0), shape.data_ptr(), shape.stride(0),
                                       cam.data_ptr(), cam.stride(0), B, xc.data_ptr(), xc.stride(0), F, _stream()), 'whmr_regressor_state')
+
+
+def crop_normalize(frame, inv_affine, patch_w, patch_h, x0, x1, out, raw, mean, std):
+    _dev(frame, inv_affine, out, raw)
+    assert frame.dtype == torch.uint8 and inv_affine.dtype == torch.float64 and inv_affine.is_contiguous() and out.is_contiguous()
+    H, W = frame.shape[:2]
+    m3, s3 = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+    _check(lib().whmr_crop_normalize(frame.data_ptr(), H, W, frame.stride(0), inv_affine.data_ptr(), inv_affine.shape[0], patch_w, patch_h,
+                                     x0, x1, out.data_ptr(), _ptr(raw), m3, s3, _stream()), 'whmr_crop_normalize')
+    return out
