@@ -77,6 +77,8 @@ int whmr_cast_f32_bf16(const float* src, void* dst, long n, void* stream);
 /* softmax(scale * Q K^T) V per (image, head) on qkv [B, N, 3, H, d] -> out [B, N, H*d].  vit.py:102-111.
  * is_bf16 = 1: MFMA kernel (d == 64, N <= 256); 0: fp32 kernel (N <= 256, any d). */
 int whmr_attention(const void* qkv, void* out, int B, int N, int H, int d, float scale, int is_bf16, void* stream);
+/* A/B switch of the bf16 kernel: 1 = chunked online-softmax variant (2 workgroups / CU, default), 0 = single pass. */
+int whmr_attention_set_variant(int chunked);
 
 /* ---- rotation / projection helpers: utils/geometry.py ------------------------------------------------------------ */
 /* mode 0: rot6d_to_rotmat (geometry.py:243-257, in [n,6]); 1: unbiased_gram_schmidt (:260-272, in [n,9]);

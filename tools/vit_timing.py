@@ -35,8 +35,10 @@ for (N, K) in [(768, 768), (2304, 768), (3072, 768), (768, 3072)]:
 
 qkv = torch.randn(B, 196, 2304, device=dev).bfloat16()
 att = torch.empty(B, 196, 768, device=dev, dtype=torch.bfloat16)
-ms = timeit(lambda: L.attention(qkv, att, B, 196, 12, 64, 0.125))
-print('attention bf16: %.3f ms  %.1f TF' % (ms, 4.0 * B * 12 * 196 * 196 * 64 / ms / 1e9))
+for var in (0, 1, 0, 1):
+    L.attention_set_variant(var)
+    ms = timeit(lambda: L.attention(qkv, att, B, 196, 12, 64, 0.125))
+    print('attention bf16 (chunked=%d): %.3f ms  %.1f TF' % (var, ms, 4.0 * B * 12 * 196 * 196 * 64 / ms / 1e9))
 t = torch.randn(M, 768, device=dev)
 h = torch.empty(M, 768, device=dev, dtype=torch.bfloat16)
 g = torch.ones(768, device=dev)
@@ -47,6 +49,10 @@ m = ViT(img_size=224, qkv_bias=True, numerics='bf16').to(dev).eval()
 x = torch.randn(B, 3, 224, 224, device=dev)
 def fwd_ms():
     return min(timeit(lambda: m(x), n=10) for _ in range(3))
+for rnd in range(3):
+    for var in (0, 1):
+        L.attention_set_variant(var)
+        print('  round %d attention chunked=%d: %.3f ms per forward' % (rnd, var, fwd_ms()), flush=True)
 # in-model A/B (same process, same box): per-shape tile overrides, interleaved with the default
 for slot, name, tiles in ((0, 'qkv', (257, 259, 256, 320, 192)), (1, 'proj', (192, 257, 259, 128, 64)), (2, 'fc1', (320, 257, 259, 192)),
                           (3, 'fc2', (192, 257, 259, 320, 128))):

@@ -48,6 +48,7 @@ _SIGS = {
     'whmr_gemm_bf16_big': [C.POINTER(WhmrGemm), _I, _P],
     'whmr_gemm_bf16_split': [C.POINTER(WhmrGemm), _I, _I, _P],
     'whmr_set_option': [_I, _I],
+    'whmr_attention_set_variant': [_I],
     'whmr_layernorm': [_P, _P, _P, _P, _I, _I, _F, _I, _P],
     'whmr_patch_im2col': [_P, _P, _I, _I, _I, _I, _I, _I, _L, _L, _L, _L, _I, _P],
     'whmr_cast_f32_bf16': [_P, _P, _L, _P],
@@ -424,3 +425,8 @@ def crop_normalize(frame, inv_affine, patch_w, patch_h, x0, x1, out, raw, mean, 
     _check(lib().whmr_crop_normalize(frame.data_ptr(), H, W, frame.stride(0), inv_affine.data_ptr(), inv_affine.shape[0], patch_w, patch_h,
                                      x0, x1, out.data_ptr(), _ptr(raw), m3, s3, _stream()), 'whmr_crop_normalize')
     return out
+
+
+def attention_set_variant(chunked):
+    """1 = chunked online-softmax bf16 attention kernel (default), 0 = single-pass kernel (A/B measurements)."""
+    _check(lib().whmr_attention_set_variant(int(chunked)), 'whmr_attention_set_variant')
