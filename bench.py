@@ -40,7 +40,7 @@ def parse():
 
 
 def build_workload(args, dev):
-    from oracle import synth                       # synthetic weights / inputs only (generator, not a compute path)
+    from whmr_amd.utils import synth                       # synthetic weights / inputs only (generator, not a compute path)
     from whmr_amd.models.pose_vit import ViT
     if args.workload in ('vit224', 'vit256x192', 'vitl256x192'):
         size = (224, 224) if args.workload == 'vit224' else (256, 192)

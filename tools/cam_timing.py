@@ -2,7 +2,7 @@
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from oracle import synth
+from whmr_amd.utils import synth
 from whmr_amd import _lib as L
 from whmr_amd.models import whmr_net
 from whmr_amd.graph import GraphedForward
