@@ -173,6 +173,21 @@ int whmr_crop_normalize(const uint8_t* frame, int H, int W, long row_stride, con
                         int patch_h, int x_begin, int x_end, float* out, uint8_t* raw, const float* mean3, const float* std3,
                         void* stream);
 
+/* ---- backward-pass helpers of the ViT backbone (autograd of vit.py:61-140,313-332; driven by core/trainer.py:410-470).
+ * The backward matrix products run on whmr_gemm_bf16 / whmr_gemm_f32: dX = dY.W uses W^T as the weight operand,
+ * dW = dY^T.X uses the transposed activations -- both produced by whmr_transpose_cast. */
+/* src [R,C] (row stride ld_src) -> dst [C,Rpad] (row stride ld_dst >= Rpad), fp32 <-> bf16; columns R..Rpad-1 are zero filled. */
+int whmr_transpose_cast(const void* src, int src_bf16, long ld_src, void* dst, int dst_bf16, long ld_dst, int R, int C, int Rpad,
+                        void* stream);
+/* out[c] (+)= sum_r x[r,c]; deterministic two-stage sum; scratch >= 64*C floats. */
+int whmr_colsum(const void* x, int is_bf16, long ld, int R, int C, float* out, int accumulate, float* scratch, void* stream);
+/* LayerNorm backward: dx = dLN(x; gamma)(dy) + dres (dres nullable, dx may alias it); dgamma/dbeta (+)=; scratch >= 512*C floats. */
+int whmr_layernorm_bwd(const float* x, const float* dy, const float* gamma, const float* dres, float* dx, float* dgamma,
+                       float* dbeta, int accumulate, int rows, int C, float eps, float* scratch, void* stream);
+/* exact-erf GELU: forward as its own pass (training keeps the pre-activation) and backward d_pre = d_hid * gelu'(pre). */
+int whmr_gelu_fwd(const void* pre, void* out, int is_bf16, long n, void* stream);
+int whmr_gelu_bwd(const void* pre, int pre_bf16, const float* dhid, void* dpre, int out_bf16, long n, void* stream);
+
 /* Tz-head tail (whmr.py:574-577): tokens [B,T,D] -> mean over T -> Linear(D,Hd) -> Linear(Hd,1) -> BatchNorm1d(1) eval
  * (bn4 = weight, bias, running_mean, running_var) -> sigmoid -> x10. */
 int whmr_tz_tail(const float* tok, int B, int T, int D, const float* w0, const float* b0, int Hd, const float* w1,

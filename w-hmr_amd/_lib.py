@@ -63,6 +63,11 @@ _SIGS = {
     'whmr_smpl_joints': [C.POINTER(WhmrSmplModel), _P, _P, _I, _P, _P, _P, _P, _P],
     'whmr_maf_sample': [_P, _I, _L, _L, _L, _L, _I, _I, _P, _P, _P, _L, _F, _F, _F, C.POINTER(WhmrMafWeights), _I, _I, _P, _L, _P, _P],
     'whmr_crop_normalize': [_P, _I, _I, _L, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
+    'whmr_transpose_cast': [_P, _I, _L, _P, _I, _L, _I, _I, _I, _P],
+    'whmr_colsum': [_P, _I, _L, _I, _I, _P, _I, _P, _P],
+    'whmr_layernorm_bwd': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P],
+    'whmr_gelu_fwd': [_P, _P, _I, _L, _P],
+    'whmr_gelu_bwd': [_P, _I, _P, _P, _I, _L, _P],
     'whmr_regressor_state': [_P, _P, _L, _P, _L, _P, _L, _I, _P, _L, _I, _P],
     'whmr_tz_tail': [_P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _F, _P, _P],
     'whmr_conv_im2col': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _L, _L, _L, _P],
@@ -430,3 +435,64 @@ def crop_normalize(frame, inv_affine, patch_w, patch_h, x0, x1, out, raw, mean, 
 def attention_set_variant(chunked):
     """1 = chunked online-softmax bf16 attention kernel (default), 0 = single-pass kernel (A/B measurements)."""
     _check(lib().whmr_attention_set_variant(int(chunked)), 'whmr_attention_set_variant')
+
+
+# ----------------------------------------------------------------------------- backward-pass helpers (train_ops.hip)
+_train_scratch = {}
+
+
+def train_scratch(device, nfloats):
+    t = _train_scratch.get(device)
+    if t is None or t.numel() < nfloats:
+        t = _train_scratch[device] = torch.empty(max(nfloats, 1 << 20), dtype=torch.float32, device=device)
+    return t
+
+
+def transpose_cast(src, dtype, pad_to=64):
+    """src [R,C] (fp32/bf16, row stride free) -> [C, Rpad] in ``dtype`` with Rpad = R rounded up to ``pad_to`` (zero filled)."""
+    _dev(src)
+    assert src.dim() == 2 and src.stride(1) == 1 and src.dtype in (torch.float32, torch.bfloat16) and dtype in (torch.float32, torch.bfloat16)
+    R, Cc = src.shape
+    Rpad = (R + pad_to - 1) // pad_to * pad_to
+    dst = torch.empty(Cc, Rpad, dtype=dtype, device=src.device)
+    _check(lib().whmr_transpose_cast(src.data_ptr(), int(src.dtype == torch.bfloat16), src.stride(0), dst.data_ptr(),
+                                     int(dtype == torch.bfloat16), Rpad, R, Cc, Rpad, _stream()), 'whmr_transpose_cast')
+    return dst
+
+
+def colsum(x, out, accumulate=False):
+    _dev(x, out)
+    assert x.dim() == 2 and x.stride(1) == 1 and out.dtype == torch.float32 and out.is_contiguous() and out.numel() == x.shape[1]
+    R, Cc = x.shape
+    sc = train_scratch(x.device, 64 * Cc)
+    _check(lib().whmr_colsum(x.data_ptr(), int(x.dtype == torch.bfloat16), x.stride(0), R, Cc, out.data_ptr(), int(accumulate),
+                             sc.data_ptr(), _stream()), 'whmr_colsum')
+    return out
+
+
+def layernorm_bwd(x, dy, gamma, dres, dx, dgamma, dbeta, eps, accumulate=False):
+    """dx = LN'(x)(dy) (+ dres); dgamma / dbeta written or accumulated.  All fp32, rows contiguous."""
+    _dev(x, dy, gamma, dres, dx, dgamma, dbeta)
+    for t in (x, dy, dx, dres):
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    sc = train_scratch(x.device, 512 * Cc)
+    _check(lib().whmr_layernorm_bwd(x.data_ptr(), dy.data_ptr(), gamma.data_ptr(), _ptr(dres), dx.data_ptr(), dgamma.data_ptr(),
+                                    dbeta.data_ptr(), int(accumulate), rows, Cc, eps, sc.data_ptr(), _stream()), 'whmr_layernorm_bwd')
+    return dx
+
+
+def gelu_fwd(pre, out):
+    _dev(pre, out)
+    assert pre.dtype == out.dtype and pre.is_contiguous() and out.is_contiguous()
+    _check(lib().whmr_gelu_fwd(pre.data_ptr(), out.data_ptr(), int(pre.dtype == torch.bfloat16), pre.numel(), _stream()), 'whmr_gelu_fwd')
+    return out
+
+
+def gelu_bwd(pre, dhid, dpre):
+    _dev(pre, dhid, dpre)
+    assert dhid.dtype == torch.float32 and pre.is_contiguous() and dhid.is_contiguous() and dpre.is_contiguous()
+    _check(lib().whmr_gelu_bwd(pre.data_ptr(), int(pre.dtype == torch.bfloat16), dhid.data_ptr(), dpre.data_ptr(),
+                               int(dpre.dtype == torch.bfloat16), pre.numel(), _stream()), 'whmr_gelu_bwd')
+    return dpre

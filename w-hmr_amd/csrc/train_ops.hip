@@ -1,0 +1,230 @@
+// Backward-pass helpers for the ViT backbone (north_star "forward/backward"; reference: autograd of
+// models/ViTPose/mmpose/models/backbones/vit.py:61-140,313-332 as driven by core/trainer.py:410-470).
+// The matrix products of the backward pass (dX = dY.W, dW = dY^T.X) run on the same GEMM kernels as the forward
+// (gemm_bf16*.hip / gemm_f32.hip); this file holds the memory-bound pieces around them:
+//   whmr_transpose_cast   [R,C] -> [C,Rpad] with dtype conversion (operands of the dW products; weights W -> W^T)
+//   whmr_colsum           bias gradients  db[c] = sum_r dY[r,c]         (deterministic two-stage)
+//   whmr_layernorm_bwd    dx (+ residual-stream gradient), dgamma, dbeta (deterministic two-stage)
+//   whmr_gelu_bwd         d_pre = d_hid * (Phi(pre) + pre * phi(pre))    (exact erf form, like nn.GELU)
+#include "common.h"
+
+template <typename TIN, typename TOUT>
+__global__ __launch_bounds__(256) void transpose_cast_kernel(const TIN* __restrict__ src, long ld_src, TOUT* __restrict__ dst, long ld_dst,
+                                                             int R, int C, int Rpad) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+    const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 8 * i, c = c0 + tx;
+        tile[ty + 8 * i][tx] = (r < R && c < C) ? io<TIN>::ld(src + (size_t)r * ld_src + c) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, r = r0 + tx;
+        if (c < C && r < Rpad) io<TOUT>::st(dst + (size_t)c * ld_dst + r, tile[tx][ty + 8 * i]);
+    }
+}
+
+extern "C" int whmr_transpose_cast(const void* src, int src_bf16, long ld_src, void* dst, int dst_bf16, long ld_dst, int R, int C, int Rpad,
+                                   void* stream) {
+    if (R <= 0 || C <= 0 || Rpad < R || ld_dst < Rpad || ld_src < C) return (int)hipErrorInvalidValue;
+    dim3 grid((Rpad + 31) / 32, (C + 31) / 32), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (src_bf16 && dst_bf16) hipLaunchKernelGGL((transpose_cast_kernel<bf16_t, bf16_t>), grid, block, 0, st, (const bf16_t*)src, ld_src, (bf16_t*)dst, ld_dst, R, C, Rpad);
+    else if (src_bf16) hipLaunchKernelGGL((transpose_cast_kernel<bf16_t, float>), grid, block, 0, st, (const bf16_t*)src, ld_src, (float*)dst, ld_dst, R, C, Rpad);
+    else if (dst_bf16) hipLaunchKernelGGL((transpose_cast_kernel<float, bf16_t>), grid, block, 0, st, (const float*)src, ld_src, (bf16_t*)dst, ld_dst, R, C, Rpad);
+    else hipLaunchKernelGGL((transpose_cast_kernel<float, float>), grid, block, 0, st, (const float*)src, ld_src, (float*)dst, ld_dst, R, C, Rpad);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- column sums: partial[chunk][c] over row chunks, then a fixed-order sum of the partials (+= into out when accumulate)
+#define CS_CHUNKS 64
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, long ld, int R, int C, float* __restrict__ partial) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+    const int rows_per = (R + CS_CHUNKS - 1) / CS_CHUNKS;
+    const int r_begin = blockIdx.y * rows_per, r_end = min(R, r_begin + rows_per);
+    float a = 0.f;
+    if (c < C)
+        for (int r = r_begin + part; r < r_end; r += 4) a += io<T>::ld(x + (size_t)r * ld + c);
+    red[part][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (part == 0 && c < C) partial[(size_t)blockIdx.y * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int nparts, int C, float* __restrict__ out,
+                                                           int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float a = 0.f;
+    for (int p = 0; p < nparts; ++p) a += partial[(size_t)p * C + c];
+    out[c] = accumulate ? out[c] + a : a;
+}
+
+// scratch: >= CS_CHUNKS * C floats
+extern "C" int whmr_colsum(const void* x, int is_bf16, long ld, int R, int C, float* out, int accumulate, float* scratch, void* stream) {
+    if (R <= 0 || C <= 0) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((C + 63) / 64, CS_CHUNKS);
+    if (is_bf16) hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, ld, R, C, scratch);
+    else hipLaunchKernelGGL(colsum_partial_kernel<float>, grid, dim3(256), 0, st, (const float*)x, ld, R, C, scratch);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, CS_CHUNKS, C, out, accumulate);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- LayerNorm backward.  One wave per row (row kept in registers, like the forward kernel); waves stride over the rows and
+// keep their dgamma / dbeta partial sums in registers; one partial per workgroup, reduced in a fixed order by the second kernel.
+//   xhat = (x - mean) * rstd;  g = dy * gamma;  dx = rstd * (g - mean(g) - xhat * mean(g * xhat))  [+ dres]
+template <int MAXV>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            const float* __restrict__ gamma, const float* __restrict__ dres,
+                                                            float* __restrict__ dx, float* __restrict__ partial, int rows, int C, float eps) {
+    extern __shared__ float red[];                 // [4 waves][2][C]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = C >> 2;
+    float4 dg[MAXV], db[MAXV], gm[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        dg[i] = db[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int c4 = lane + 64 * i;
+        gm[i] = c4 < nv ? *(const float4*)(gamma + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        const float* xr = x + (size_t)row * C;
+        const float* dyr = dy + (size_t)row * C;
+        float4 v[MAXV], d[MAXV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c4 = lane + 64 * i;
+            if (c4 < nv) {
+                v[i] = *(const float4*)(xr + c4 * 4);
+                d[i] = *(const float4*)(dyr + c4 * 4);
+                s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+            }
+        }
+        const float mean = wave_sum(s) / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c4 = lane + 64 * i;
+            if (c4 < nv) {
+                v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+                q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+            }
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c4 = lane + 64 * i;
+            if (c4 < nv) {
+                v[i].x *= rstd; v[i].y *= rstd; v[i].z *= rstd; v[i].w *= rstd;          // xhat
+                dg[i].x += d[i].x * v[i].x; dg[i].y += d[i].y * v[i].y; dg[i].z += d[i].z * v[i].z; dg[i].w += d[i].w * v[i].w;
+                db[i].x += d[i].x; db[i].y += d[i].y; db[i].z += d[i].z; db[i].w += d[i].w;
+                d[i].x *= gm[i].x; d[i].y *= gm[i].y; d[i].z *= gm[i].z; d[i].w *= gm[i].w;      // g
+                sg += (d[i].x + d[i].y) + (d[i].z + d[i].w);
+                sgx += (d[i].x * v[i].x + d[i].y * v[i].y) + (d[i].z * v[i].z + d[i].w * v[i].w);
+            }
+        }
+        const float mg = wave_sum(sg) / (float)C, mgx = wave_sum(sgx) / (float)C;
+        float* dxr = dx + (size_t)row * C;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c4 = lane + 64 * i;
+            if (c4 < nv) {
+                float4 o = make_float4(rstd * (d[i].x - mg - v[i].x * mgx), rstd * (d[i].y - mg - v[i].y * mgx),
+                                       rstd * (d[i].z - mg - v[i].z * mgx), rstd * (d[i].w - mg - v[i].w * mgx));
+                if (dres) {
+                    const float4 r = *(const float4*)(dres + (size_t)row * C + c4 * 4);
+                    o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+                }
+                *(float4*)(dxr + c4 * 4) = o;
+            }
+        }
+    }
+    // workgroup partial of dgamma / dbeta
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c4 = lane + 64 * i;
+        if (c4 < nv) {
+            *(float4*)(red + (wave * 2 + 0) * C + c4 * 4) = dg[i];
+            *(float4*)(red + (wave * 2 + 1) * C + c4 * 4) = db[i];
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+        const int which = i / C, c = i - which * C;
+        partial[(size_t)blockIdx.x * 2 * C + i] = (red[(0 * 2 + which) * C + c] + red[(1 * 2 + which) * C + c]) +
+                                                  (red[(2 * 2 + which) * C + c] + red[(3 * 2 + which) * C + c]);
+    }
+}
+
+__global__ __launch_bounds__(256) void layernorm_bwd_final_kernel(const float* __restrict__ partial, int nparts, int C, float* __restrict__ dgamma,
+                                                                  float* __restrict__ dbeta, int accumulate) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 2 * C) return;
+    float a = 0.f;
+    for (int p = 0; p < nparts; ++p) a += partial[(size_t)p * 2 * C + i];
+    float* dst = i < C ? dgamma + i : dbeta + (i - C);
+    *dst = accumulate ? *dst + a : a;
+}
+
+#define LNB_BLOCKS 256
+// dx may alias dres.  scratch: >= LNB_BLOCKS * 2 * C floats.
+extern "C" int whmr_layernorm_bwd(const float* x, const float* dy, const float* gamma, const float* dres, float* dx, float* dgamma,
+                                  float* dbeta, int accumulate, int rows, int C, float eps, float* scratch, void* stream) {
+    if (rows <= 0 || C <= 0 || (C & 3) || C > 64 * 4 * 4) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = rows < LNB_BLOCKS * 4 ? (rows + 3) / 4 : LNB_BLOCKS;
+    const size_t lds = (size_t)8 * C * sizeof(float);
+    if (C <= 64 * 4 * 3) hipLaunchKernelGGL(layernorm_bwd_kernel<3>, dim3(nblk), dim3(256), lds, st, x, dy, gamma, dres, dx, scratch, rows, C, eps);
+    else hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(nblk), dim3(256), lds, st, x, dy, gamma, dres, dx, scratch, rows, C, eps);
+    hipLaunchKernelGGL(layernorm_bwd_final_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, scratch, nblk, C, dgamma, dbeta, accumulate);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- GELU backward (exact erf form): d_pre = d_hid * (Phi(x) + x * phi(x)),  x = pre-activation
+template <typename TP, typename TO>
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const TP* __restrict__ pre, const float* __restrict__ dhid, TO* __restrict__ dpre, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float x = io<TP>::ld(pre + i);
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.3989422804014327f * expf(-0.5f * x * x);
+    io<TO>::st(dpre + i, dhid[i] * (cdf + x * pdf));
+}
+
+extern "C" int whmr_gelu_bwd(const void* pre, int pre_bf16, const float* dhid, void* dpre, int out_bf16, long n, void* stream) {
+    if (n <= 0) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (pre_bf16 && out_bf16) hipLaunchKernelGGL((gelu_bwd_kernel<bf16_t, bf16_t>), grid, block, 0, st, (const bf16_t*)pre, dhid, (bf16_t*)dpre, n);
+    else if (pre_bf16) hipLaunchKernelGGL((gelu_bwd_kernel<bf16_t, float>), grid, block, 0, st, (const bf16_t*)pre, dhid, (float*)dpre, n);
+    else if (out_bf16) hipLaunchKernelGGL((gelu_bwd_kernel<float, bf16_t>), grid, block, 0, st, (const float*)pre, dhid, (bf16_t*)dpre, n);
+    else hipLaunchKernelGGL((gelu_bwd_kernel<float, float>), grid, block, 0, st, (const float*)pre, dhid, (float*)dpre, n);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+// GELU forward as its own pass (training keeps the pre-activation; the inference path fuses GELU into the fc1 epilogue)
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const T* __restrict__ pre, T* __restrict__ out, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) io<T>::st(out + i, gelu_erf(io<T>::ld(pre + i)));
+}
+
+extern "C" int whmr_gelu_fwd(const void* pre, void* out, int is_bf16, long n, void* stream) {
+    if (n <= 0) return (int)hipErrorInvalidValue;
+    dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (is_bf16) hipLaunchKernelGGL(gelu_fwd_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)pre, (bf16_t*)out, n);
+    else hipLaunchKernelGGL(gelu_fwd_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)pre, (float*)out, n);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}

@@ -142,6 +142,14 @@ class ViT(nn.Module):
         return out, (B, Hp, Wp)
 
     def forward_features(self, x):
+        if self.training and torch.is_grad_enabled():
+            # training: forward keeps its activations, backward = whmr_amd.train.vit_backward (HIP GEMMs / LayerNorm / GELU kernels)
+            from ..train import ViTFn
+            B, _, H, W = x.shape
+            pad, P = self.patch_pad, self.patch_size
+            Hp, Wp = (H + 2 * pad - P) // P + 1, (W + 2 * pad - P) // P + 1
+            tok = ViTFn.apply(x, self, *self.parameters())
+            return tok.view(B, Hp, Wp, self.embed_dim).permute(0, 3, 1, 2)
         tok, (B, Hp, Wp) = self.forward_tokens(x)
         # vit.py:330 returns NCHW; the tokens already are NHWC, so hand back the NCHW *view* (channels-last memory).
         return tok.view(B, Hp, Wp, self.embed_dim).permute(0, 3, 1, 2)

@@ -1,0 +1,178 @@
+"""Forward-with-activations and hand-driven backward of the ViT backbone (north_star "forward/backward path").
+
+Reference semantics: autograd of ``ViT.forward_features`` (models/ViTPose/mmpose/models/backbones/vit.py:61-140,313-332) as
+driven by ``core/trainer.py:410-470`` (loss.backward()).  Here the backward pass is written out layer by layer:
+
+  * every matrix product -- dX = dY.W and dW = dY^T.X of the four Linears per block and of the patch embedding -- runs on the
+    forward GEMM kernels (``whmr_gemm_bf16`` / ``whmr_gemm_f32``): W^T and the transposed activations come from
+    ``whmr_transpose_cast`` (rows zero-padded to a multiple of 64 so that the token dimension can be the GEMM's K);
+  * LayerNorm backward (+ residual-stream accumulation), exact-erf GELU backward and the bias column sums are HIP kernels
+    (``train_ops.hip``), all deterministic (two-stage reductions, no atomics);
+  * the attention core's backward is, this round, a handful of batched PyTorch matmuls on the device (recompute P from the
+    saved qkv): ~4 % of the backward FLOPs -- a fused HIP kernel is the next step.
+
+``numerics='fp32'`` (exact-f32 MFMA) is the parity mode against the CPU reference's autograd; ``'bf16'`` casts GEMM operands
+to bf16 and keeps the residual-stream gradient, LayerNorm statistics and all weight gradients in fp32.
+drop_path / dropout are identities here (the reference's drop_path_rate only matters for its own training recipe).
+"""
+import torch
+
+from .. import _lib as L
+
+
+class _Saved:
+    pass
+
+
+def _dt(m):
+    return torch.float32 if m.numerics == 'fp32' else torch.bfloat16
+
+
+def _op(t, dt):
+    """GEMM operand copy of an fp32 activation / gradient in the compute dtype."""
+    if t.dtype == dt:
+        return t
+    return L.cast_bf16(t) if dt == torch.bfloat16 else t.float()
+
+
+@torch.no_grad()
+def vit_forward_train(m, x):
+    """Same arithmetic as ViT.forward_tokens except that GELU is its own (exact-erf) pass; keeps what the backward needs."""
+    if not x.is_cuda:
+        raise RuntimeError('whmr_amd.ViT runs on a HIP device only (no CPU fallback)')
+    B, Cin, H, W = x.shape
+    P, pad, D = m.patch_size, m.patch_pad, m.embed_dim
+    Hp, Wp = (H + 2 * pad - P) // P + 1, (W + 2 * pad - P) // P + 1
+    N, M = Hp * Wp, B * Hp * Wp
+    assert N + 1 == m.pos_embed.shape[1], 'input size does not match pos_embed (vit.py:231)'
+    dt, dev = _dt(m), x.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    s = _Saved()
+    s.dims = (B, N, Hp, Wp, M)
+    s.cols = torch.empty(M, Cin * P * P, dtype=dt, device=dev)
+    L.patch_im2col(x.float(), s.cols, P, pad)
+    pos = m.pos_embed[0, 1:] + m.pos_embed[0, :1]
+    t = torch.empty(M, D, **f32)
+    L.gemm(s.cols, m._w(m.patch_embed.proj.weight, (D, Cin * P * P)), t, bias=m.patch_embed.proj.bias, residual=pos, res_row_mod=N)
+    s.layers = []
+    hidden = m.blocks[0].mlp.fc1.weight.shape[0] if m.depth else 0
+    for blk in m.blocks:
+        a = _Saved()
+        a.t_in = t
+        a.h1 = torch.empty(M, D, dtype=dt, device=dev)
+        L.layernorm(a.t_in, blk.norm1.weight, blk.norm1.bias, a.h1, 1e-6)
+        a.qkv = torch.empty(M, 3 * D, dtype=dt, device=dev)
+        L.gemm(a.h1, m._w(blk.attn.qkv.weight), a.qkv, bias=blk.attn.qkv.bias)
+        a.att = torch.empty(M, D, dtype=dt, device=dev)
+        L.attention(a.qkv, a.att, B, N, m.num_heads, D // m.num_heads, m.scale)
+        a.t_mid = torch.empty(M, D, **f32)
+        L.gemm(a.att, m._w(blk.attn.proj.weight), a.t_mid, bias=blk.attn.proj.bias, residual=a.t_in)
+        a.h2 = torch.empty(M, D, dtype=dt, device=dev)
+        L.layernorm(a.t_mid, blk.norm2.weight, blk.norm2.bias, a.h2, 1e-6)
+        a.pre = torch.empty(M, hidden, dtype=dt, device=dev)
+        L.gemm(a.h2, m._w(blk.mlp.fc1.weight), a.pre, bias=blk.mlp.fc1.bias)
+        a.hid = torch.empty_like(a.pre)
+        L.gelu_fwd(a.pre, a.hid)
+        t = torch.empty(M, D, **f32)
+        L.gemm(a.hid, m._w(blk.mlp.fc2.weight), t, bias=blk.mlp.fc2.bias, residual=a.t_mid)
+        s.layers.append(a)
+    s.t_last = t
+    out = torch.empty(M, D, **f32)
+    L.layernorm(t, m.last_norm.weight, m.last_norm.bias, out, 1e-6)
+    return out, s
+
+
+def _attention_bwd(qkv, d_att, B, N, H, dh, scale, dt):
+    """Backward of softmax(q k^T * scale) v per (image, head): recompute P from the saved qkv (batched matmuls on the device)."""
+    q, k, v = qkv.view(B, N, 3, H, dh).permute(2, 0, 3, 1, 4).float()                # [B, H, N, dh] each
+    do = d_att.view(B, N, H, dh).permute(0, 2, 1, 3)
+    p = torch.softmax((q * scale) @ k.transpose(-1, -2), dim=-1)
+    dv = p.transpose(-1, -2) @ do
+    dp = do @ v.transpose(-1, -2)
+    ds = p * (dp - (dp * p).sum(-1, keepdim=True))
+    dq = (ds @ k) * scale
+    dk = ds.transpose(-1, -2) @ (q * scale)
+    return torch.stack((dq, dk, dv), 0).permute(1, 3, 0, 2, 4).reshape(B * N, 3 * H * dh).to(dt).contiguous()
+
+
+@torch.no_grad()
+def vit_backward(m, s, dout):
+    """dout: gradient of the [M, D] token output (after last_norm).  Returns {parameter: gradient} (fp32, parameter-shaped)."""
+    B, N, Hp, Wp, M = s.dims
+    D, dt, dev = m.embed_dim, _dt(m), dout.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    grads = {}
+
+    mpad = 64 if dt == torch.bfloat16 else 1     # the bf16 kernel needs K % 64 == 0; the token dimension is zero-padded up to it
+
+    def wt(p, shape=None):                       # W^T in the compute dtype: the weight operand of dX = dY . W
+        w = p.detach()
+        return L.transpose_cast(w.reshape(shape) if shape is not None else w, dt, pad_to=1)
+
+    def linear_bwd(dy_op, x_saved, lin, need_dx=True, wshape=None):
+        """dy_op [M, Nout] (compute dtype), x_saved [M, Kin] -> dx [M, Kin] fp32; records dW, db."""
+        w = lin.weight
+        n_out = dy_op.shape[1]
+        k_in = x_saved.shape[1]
+        dyt = L.transpose_cast(dy_op, dt, pad_to=mpad)                                 # [Nout, Mpad]
+        xt = L.transpose_cast(x_saved, dt, pad_to=mpad)                                # [Kin, Mpad]
+        dw = torch.empty(n_out, k_in, **f32)
+        L.gemm(dyt, xt, dw)
+        grads[w] = dw.view_as(w)
+        if lin.bias is not None:
+            db = torch.empty(n_out, **f32)
+            L.colsum(dy_op, db)
+            grads[lin.bias] = db
+        if not need_dx:
+            return None
+        dx = torch.empty(M, k_in, **f32)
+        L.gemm(dy_op, wt(w, wshape), dx)                                               # W^T: [Kin, Nout]
+        return dx
+
+    dt_grad = torch.empty(M, D, **f32)                                                 # gradient of the fp32 residual stream
+    dg, db = torch.empty(D, **f32), torch.empty(D, **f32)
+    L.layernorm_bwd(s.t_last, dout.contiguous().float(), m.last_norm.weight, None, dt_grad, dg, db, 1e-6)
+    grads[m.last_norm.weight], grads[m.last_norm.bias] = dg, db
+    for blk, a in zip(reversed(list(m.blocks)), reversed(s.layers)):
+        # t_out = t_mid + fc2(gelu(fc1(LN2(t_mid))))
+        d_hid = linear_bwd(_op(dt_grad, dt), a.hid, blk.mlp.fc2)
+        d_pre = torch.empty(M, a.pre.shape[1], dtype=dt, device=dev)
+        L.gelu_bwd(a.pre, d_hid, d_pre)
+        d_h2 = linear_bwd(d_pre, a.h2, blk.mlp.fc1)
+        dg, db = torch.empty(D, **f32), torch.empty(D, **f32)
+        L.layernorm_bwd(a.t_mid, d_h2, blk.norm2.weight, dt_grad, dt_grad, dg, db, 1e-6)   # dt_grad now = d t_mid
+        grads[blk.norm2.weight], grads[blk.norm2.bias] = dg, db
+        # t_mid = t_in + proj(attention(qkv(LN1(t_in))))
+        d_att = linear_bwd(_op(dt_grad, dt), a.att, blk.attn.proj)
+        d_qkv = _attention_bwd(a.qkv, d_att, B, N, m.num_heads, D // m.num_heads, m.scale, dt)
+        d_h1 = linear_bwd(d_qkv, a.h1, blk.attn.qkv)
+        dg, db = torch.empty(D, **f32), torch.empty(D, **f32)
+        L.layernorm_bwd(a.t_in, d_h1, blk.norm1.weight, dt_grad, dt_grad, dg, db, 1e-6)    # dt_grad now = d t_in
+        grads[blk.norm1.weight], grads[blk.norm1.bias] = dg, db
+    # t_0 = cols . Wp^T + b + (pos_embed[1:] + pos_embed[:1])
+    pe = m.patch_embed.proj
+    linear_bwd(_op(dt_grad, dt), s.cols, pe, need_dx=False)
+    dpos = torch.empty(N * D, **f32)
+    L.colsum(dt_grad.view(B, N * D), dpos)                                            # sum over the batch
+    dpos = dpos.view(N, D)
+    gpe = torch.zeros_like(m.pos_embed, dtype=torch.float32)
+    gpe[0, 1:] = dpos
+    gpe[0, 0] = dpos.sum(0)
+    grads[m.pos_embed] = gpe
+    return grads
+
+
+class ViTFn(torch.autograd.Function):
+    """tokens = ViTFn.apply(x, module, *module.parameters()): autograd node whose backward is ``vit_backward``."""
+
+    @staticmethod
+    def forward(ctx, x, module, *params):
+        out, saved = vit_forward_train(module, x)
+        ctx.module, ctx.saved, ctx.params = module, saved, params
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        grads = vit_backward(ctx.module, ctx.saved, dout)
+        ctx.saved = None
+        return (None, None) + tuple(grads.get(p) for p in ctx.params)
