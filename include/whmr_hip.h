@@ -181,7 +181,7 @@ int whmr_transpose_cast(const void* src, int src_bf16, long ld_src, void* dst, i
                         void* stream);
 /* out[c] (+)= sum_r x[r,c]; deterministic two-stage sum; scratch >= 64*C floats. */
 int whmr_colsum(const void* x, int is_bf16, long ld, int R, int C, float* out, int accumulate, float* scratch, void* stream);
-/* LayerNorm backward: dx = dLN(x; gamma)(dy) + dres (dres nullable, dx may alias it); dgamma/dbeta (+)=; scratch >= 512*C floats. */
+/* LayerNorm backward: dx = dLN(x; gamma)(dy) + dres (dres nullable, dx may alias it); dgamma/dbeta (+)=; scratch >= 2048*C floats. */
 int whmr_layernorm_bwd(const float* x, const float* dy, const float* gamma, const float* dres, float* dx, float* dgamma,
                        float* dbeta, int accumulate, int rows, int C, float eps, float* scratch, void* stream);
 /* exact-erf GELU: forward as its own pass (training keeps the pre-activation) and backward d_pre = d_hid * gelu'(pre). */

@@ -114,3 +114,37 @@ dist.destroy_process_group()
     import json
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
     assert out['t'] == 1.5 and abs(out['v'] - 2 * 64 * 10 / 1.5) < 1e-9 and out['shard'] == [128, 256]
+
+
+def test_grad_reducer_two_ranks_gloo(tmp_path):
+    """SURVEY 8e training row: bucketed gradient all-reduce(mean), world size 2 on CPU/gloo, against the single-process gradient."""
+    import json
+    script = tmp_path / 'ddp.py'
+    script.write_text('''
+import json, os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from whmr_amd.parallel import GradReducer, shard_batch
+dist.init_process_group('gloo')
+rank, world = dist.get_rank(), dist.get_world_size()
+torch.manual_seed(0)
+model = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.GELU(), torch.nn.Linear(32, 8), torch.nn.LayerNorm(8))
+x, y = torch.randn(12, 16), torch.randn(12, 8)
+# single-process reference on the whole batch (mean loss == mean of the per-shard mean losses for equal shards)
+ref = [torch.autograd.grad(((model(x) - y) ** 2).mean(), model.parameters())]
+red = GradReducer(model.parameters(), bucket_bytes=1200)          # several small buckets: exercises the bucket bookkeeping
+lo, hi = shard_batch(12, world, rank)
+for step in range(2):                                             # twice: buckets are re-armed after finish()
+    model.zero_grad(set_to_none=True)
+    ((model(x[lo:hi]) - y[lo:hi]) ** 2).mean().backward()
+    red.finish()
+err = max((p.grad - g).abs().max().item() for p, g in zip(model.parameters(), ref[0]))
+if rank == 0:
+    print(json.dumps({'err': err, 'buckets': len(red.buckets), 'shard': [lo, hi]}))
+dist.destroy_process_group()
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1')
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+                          '--master-port', '29533', str(script)], capture_output=True, text=True, timeout=240, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    assert res['err'] < 1e-6 and res['buckets'] >= 2 and res['shard'] == [0, 6]

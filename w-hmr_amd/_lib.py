@@ -477,7 +477,7 @@ def layernorm_bwd(x, dy, gamma, dres, dx, dgamma, dbeta, eps, accumulate=False):
         assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
     Cc = x.shape[-1]
     rows = x.numel() // Cc
-    sc = train_scratch(x.device, 512 * Cc)
+    sc = train_scratch(x.device, 2048 * Cc)
     _check(lib().whmr_layernorm_bwd(x.data_ptr(), dy.data_ptr(), gamma.data_ptr(), _ptr(dres), dx.data_ptr(), dgamma.data_ptr(),
                                     dbeta.data_ptr(), int(accumulate), rows, Cc, eps, sc.data_ptr(), _stream()), 'whmr_layernorm_bwd')
     return dx

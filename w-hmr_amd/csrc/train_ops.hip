@@ -27,11 +27,45 @@ __global__ __launch_bounds__(256) void transpose_cast_kernel(const TIN* __restri
     }
 }
 
+// bf16 -> bf16 fast path (the operands of the dW products): 64x64 tiles, 16-B global loads and stores.
+// Requires R, C, Rpad, ld_src, ld_dst multiples of 8 and 16-B aligned bases (checked by the launcher).
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ src, long ld_src, bf16_t* __restrict__ dst, long ld_dst,
+                                                             int R, int C, int Rpad) {
+    __shared__ __attribute__((aligned(16))) bf16_t tile[64][66];
+    const int t = threadIdx.x;
+    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (t >> 3) + 32 * i, c8 = (t & 7) * 8;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r0 + row < R && c0 + c8 < C) v = *(const uint4*)(src + (size_t)(r0 + row) * ld_src + c0 + c8);
+        uint32_t* d = (uint32_t*)&tile[row][c8];
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = (t >> 3) + 32 * i, r8 = (t & 7) * 8;
+        if (c0 + c < C && r0 + r8 < Rpad) {
+            uint32_t w[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) w[k] = (uint32_t)tile[r8 + 2 * k][c] | ((uint32_t)tile[r8 + 2 * k + 1][c] << 16);
+            *(uint4*)(dst + (size_t)(c0 + c) * ld_dst + r0 + r8) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    }
+}
+
 extern "C" int whmr_transpose_cast(const void* src, int src_bf16, long ld_src, void* dst, int dst_bf16, long ld_dst, int R, int C, int Rpad,
                                    void* stream) {
     if (R <= 0 || C <= 0 || Rpad < R || ld_dst < Rpad || ld_src < C) return (int)hipErrorInvalidValue;
     dim3 grid((Rpad + 31) / 32, (C + 31) / 32), block(256);
     hipStream_t st = (hipStream_t)stream;
+    if (src_bf16 && dst_bf16 && !((R | C | Rpad | ld_src | ld_dst) & 7) && !(((uintptr_t)src | (uintptr_t)dst) & 15)) {
+        hipLaunchKernelGGL(transpose_bf16_kernel, dim3((Rpad + 63) / 64, (C + 63) / 64), block, 0, st, (const bf16_t*)src, ld_src, (bf16_t*)dst,
+                           ld_dst, R, C, Rpad);
+        WHMR_CHECK_LAUNCH();
+        return 0;
+    }
     if (src_bf16 && dst_bf16) hipLaunchKernelGGL((transpose_cast_kernel<bf16_t, bf16_t>), grid, block, 0, st, (const bf16_t*)src, ld_src, (bf16_t*)dst, ld_dst, R, C, Rpad);
     else if (src_bf16) hipLaunchKernelGGL((transpose_cast_kernel<bf16_t, float>), grid, block, 0, st, (const bf16_t*)src, ld_src, (float*)dst, ld_dst, R, C, Rpad);
     else if (dst_bf16) hipLaunchKernelGGL((transpose_cast_kernel<float, bf16_t>), grid, block, 0, st, (const float*)src, ld_src, (bf16_t*)dst, ld_dst, R, C, Rpad);
@@ -56,13 +90,24 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
     if (part == 0 && c < C) partial[(size_t)blockIdx.y * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// block = 64 columns x 4 quarter-sums of the partials (fixed order: deterministic)
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int nparts, int C, float* __restrict__ out,
                                                            int accumulate) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+    const int per = (nparts + 3) / 4;
     float a = 0.f;
-    for (int p = 0; p < nparts; ++p) a += partial[(size_t)p * C + c];
-    out[c] = accumulate ? out[c] + a : a;
+    if (c < C) {
+        const int p1 = min(nparts, (part + 1) * per);
+#pragma unroll 8
+        for (int p = part * per; p < p1; ++p) a += partial[(size_t)p * C + c];
+    }
+    red[part][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (part == 0 && c < C) {
+        const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        out[c] = accumulate ? out[c] + v : v;
+    }
 }
 
 // scratch: >= CS_CHUNKS * C floats
@@ -72,7 +117,7 @@ extern "C" int whmr_colsum(const void* x, int is_bf16, long ld, int R, int C, fl
     dim3 grid((C + 63) / 64, CS_CHUNKS);
     if (is_bf16) hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, ld, R, C, scratch);
     else hipLaunchKernelGGL(colsum_partial_kernel<float>, grid, dim3(256), 0, st, (const float*)x, ld, R, C, scratch);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, CS_CHUNKS, C, out, accumulate);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64), dim3(256), 0, st, scratch, CS_CHUNKS, C, out, accumulate);
     WHMR_CHECK_LAUNCH();
     return 0;
 }
@@ -167,16 +212,26 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 
 __global__ __launch_bounds__(256) void layernorm_bwd_final_kernel(const float* __restrict__ partial, int nparts, int C, float* __restrict__ dgamma,
                                                                   float* __restrict__ dbeta, int accumulate) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= 2 * C) return;
+    __shared__ float red[4][64];
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+    const int per = (nparts + 3) / 4;
     float a = 0.f;
-    for (int p = 0; p < nparts; ++p) a += partial[(size_t)p * 2 * C + i];
-    float* dst = i < C ? dgamma + i : dbeta + (i - C);
-    *dst = accumulate ? *dst + a : a;
+    if (i < 2 * C) {
+        const int p1 = min(nparts, (part + 1) * per);
+#pragma unroll 8
+        for (int p = part * per; p < p1; ++p) a += partial[(size_t)p * 2 * C + i];
+    }
+    red[part][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (part == 0 && i < 2 * C) {
+        const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        float* dst = i < C ? dgamma + i : dbeta + (i - C);
+        *dst = accumulate ? *dst + v : v;
+    }
 }
 
-#define LNB_BLOCKS 256
-// dx may alias dres.  scratch: >= LNB_BLOCKS * 2 * C floats.
+#define LNB_BLOCKS 1024
+// dx may alias dres.  scratch: >= LNB_BLOCKS * 2 * C floats (2048 * C).
 extern "C" int whmr_layernorm_bwd(const float* x, const float* dy, const float* gamma, const float* dres, float* dx, float* dgamma,
                                   float* dbeta, int accumulate, int rows, int C, float eps, float* scratch, void* stream) {
     if (rows <= 0 || C <= 0 || (C & 3) || C > 64 * 4 * 4) return (int)hipErrorInvalidValue;
@@ -185,7 +240,7 @@ extern "C" int whmr_layernorm_bwd(const float* x, const float* dy, const float* 
     const size_t lds = (size_t)8 * C * sizeof(float);
     if (C <= 64 * 4 * 3) hipLaunchKernelGGL(layernorm_bwd_kernel<3>, dim3(nblk), dim3(256), lds, st, x, dy, gamma, dres, dx, scratch, rows, C, eps);
     else hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(nblk), dim3(256), lds, st, x, dy, gamma, dres, dx, scratch, rows, C, eps);
-    hipLaunchKernelGGL(layernorm_bwd_final_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, scratch, nblk, C, dgamma, dbeta, accumulate);
+    hipLaunchKernelGGL(layernorm_bwd_final_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, st, scratch, nblk, C, dgamma, dbeta, accumulate);
     WHMR_CHECK_LAUNCH();
     return 0;
 }
@@ -201,10 +256,43 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const TP* __restrict__ pr
     io<TO>::st(dpre + i, dhid[i] * (cdf + x * pdf));
 }
 
+// 8 elements per thread (bf16 in / bf16 or fp32 gradient in / bf16 out): the shapes of the training path
+template <typename TD>
+__global__ __launch_bounds__(256) void gelu_bwd8_kernel(const bf16_t* __restrict__ pre, const TD* __restrict__ dhid, bf16_t* __restrict__ dpre, long n8) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const uint4 pv = *(const uint4*)(pre + i * 8);
+    const uint32_t pw[4] = {pv.x, pv.y, pv.z, pv.w};
+    float g[8];
+    if constexpr (sizeof(TD) == 4) {
+        const float4 a = *(const float4*)(dhid + i * 8), b = *(const float4*)(dhid + i * 8 + 4);
+        g[0] = a.x; g[1] = a.y; g[2] = a.z; g[3] = a.w; g[4] = b.x; g[5] = b.y; g[6] = b.z; g[7] = b.w;
+    } else {
+        const uint4 dv = *(const uint4*)(dhid + i * 8);
+        const uint32_t dw[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { g[2 * e] = __uint_as_float(dw[e] << 16); g[2 * e + 1] = __uint_as_float(dw[e] & 0xffff0000u); }
+    }
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = (e & 1) ? __uint_as_float(pw[e >> 1] & 0xffff0000u) : __uint_as_float(pw[e >> 1] << 16);
+        const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+        const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+        o[e] = g[e] * (cdf + x * pdf);
+    }
+    *(uint4*)(dpre + i * 8) = make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
+}
+
 extern "C" int whmr_gelu_bwd(const void* pre, int pre_bf16, const float* dhid, void* dpre, int out_bf16, long n, void* stream) {
     if (n <= 0) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (pre_bf16 && out_bf16 && !(n & 7)) {
+        hipLaunchKernelGGL(gelu_bwd8_kernel<float>, dim3((unsigned)((n / 8 + 255) / 256)), block, 0, st, (const bf16_t*)pre, dhid, (bf16_t*)dpre, n / 8);
+        WHMR_CHECK_LAUNCH();
+        return 0;
+    }
     if (pre_bf16 && out_bf16) hipLaunchKernelGGL((gelu_bwd_kernel<bf16_t, bf16_t>), grid, block, 0, st, (const bf16_t*)pre, dhid, (bf16_t*)dpre, n);
     else if (pre_bf16) hipLaunchKernelGGL((gelu_bwd_kernel<bf16_t, float>), grid, block, 0, st, (const bf16_t*)pre, dhid, (float*)dpre, n);
     else if (out_bf16) hipLaunchKernelGGL((gelu_bwd_kernel<float, bf16_t>), grid, block, 0, st, (const float*)pre, dhid, (bf16_t*)dpre, n);

@@ -83,16 +83,18 @@ def vit_forward_train(m, x):
 
 
 def _attention_bwd(qkv, d_att, B, N, H, dh, scale, dt):
-    """Backward of softmax(q k^T * scale) v per (image, head): recompute P from the saved qkv (batched matmuls on the device)."""
-    q, k, v = qkv.view(B, N, 3, H, dh).permute(2, 0, 3, 1, 4).float()                # [B, H, N, dh] each
-    do = d_att.view(B, N, H, dh).permute(0, 2, 1, 3)
-    p = torch.softmax((q * scale) @ k.transpose(-1, -2), dim=-1)
-    dv = p.transpose(-1, -2) @ do
-    dp = do @ v.transpose(-1, -2)
-    ds = p * (dp - (dp * p).sum(-1, keepdim=True))
-    dq = (ds @ k) * scale
-    dk = ds.transpose(-1, -2) @ (q * scale)
-    return torch.stack((dq, dk, dv), 0).permute(1, 3, 0, 2, 4).reshape(B * N, 3 * H * dh).to(dt).contiguous()
+    """Backward of softmax(q k^T * scale) v per (image, head): recompute P from the saved qkv (batched matmuls on the device;
+    bf16 operands / fp32 softmax in the bf16 mode, all fp32 in the parity mode)."""
+    q, k, v = qkv.view(B, N, 3, H, dh).permute(2, 0, 3, 1, 4)                        # [B, H, N, dh] views
+    do = d_att.view(B, N, H, dh).permute(0, 2, 1, 3).to(dt)
+    p = torch.softmax((q @ k.transpose(-1, -2)).float() * scale, dim=-1)               # fp32 probabilities
+    pc = p.to(dt)
+    dv = pc.transpose(-1, -2) @ do
+    dp = (do @ v.transpose(-1, -2)).float()
+    ds = (p * (dp - (dp * p).sum(-1, keepdim=True)) * scale).to(dt)
+    dq = ds @ k
+    dk = ds.transpose(-1, -2) @ q
+    return torch.stack((dq, dk, dv), 0).permute(1, 3, 0, 2, 4).reshape(B * N, 3 * H * dh).contiguous()
 
 
 @torch.no_grad()
