@@ -188,6 +188,12 @@ int whmr_layernorm_bwd(const float* x, const float* dy, const float* gamma, cons
 int whmr_gelu_fwd(const void* pre, void* out, int is_bf16, long n, void* stream);
 int whmr_gelu_bwd(const void* pre, int pre_bf16, const float* dhid, void* dpre, int out_bf16, long n, void* stream);
 
+/* Attention core for training (bf16, d = 64, 64 < N <= 224): forward that also writes the per-query log-sum-exp (log2 domain,
+ * lse [B,H,N] fp32), and the MFMA backward dqkv [B,N,3,H,64] bf16 from qkv, o = forward output, dout = d(o) fp32, lse. */
+int whmr_attention_fwd_train(const void* qkv, void* out, float* lse, int B, int N, int H, int d, float scale, void* stream);
+int whmr_attention_bwd(const void* qkv, const void* o, const float* dout, const float* lse, void* dqkv, int B, int N, int H, int d,
+                       float scale, void* stream);
+
 /* Tz-head tail (whmr.py:574-577): tokens [B,T,D] -> mean over T -> Linear(D,Hd) -> Linear(Hd,1) -> BatchNorm1d(1) eval
  * (bn4 = weight, bias, running_mean, running_var) -> sigmoid -> x10. */
 int whmr_tz_tail(const float* tok, int B, int T, int D, const float* w0, const float* b0, int Hd, const float* w1,

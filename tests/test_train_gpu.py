@@ -1,4 +1,6 @@
 """Backward pass of the ViT backbone (HIP GEMM / LayerNorm / GELU kernels) against the CPU oracle's autograd."""
+import math
+
 import pytest
 import torch
 
@@ -73,3 +75,52 @@ def test_vit_backward_matches_oracle_autograd(dev, numerics, tol):
     m.eval()
     with torch.no_grad():
         assert _rel(m(x.to(dev)), out.detach()) < (1e-5 if numerics == 'fp32' else 2e-2)
+
+
+@pytest.mark.parametrize('N', [196, 192, 100])
+def test_attention_backward_kernel(dev, N):
+    """MFMA attention backward vs autograd of the fp32 attention on the same bf16 inputs."""
+    from whmr_amd import _lib as L
+    B, H, d = 2, 3, 64
+    g = torch.Generator().manual_seed(N)
+    qkv = (torch.randn(B, N, 3, H, d, generator=g) * 1.5).bfloat16()
+    dout = torch.randn(B, N, H * d, generator=g)
+    scale = d ** -0.5
+    ref_in = qkv.float().requires_grad_(True)
+    q, k, v = ref_in.permute(2, 0, 3, 1, 4)
+    o_ref = (torch.softmax((q * scale) @ k.transpose(-1, -2), -1) @ v).transpose(1, 2).reshape(B, N, H * d)
+    o_ref.backward(dout)
+    qd = qkv.view(B * N, 3 * H * d).to(dev)
+    out = torch.empty(B * N, H * d, dtype=torch.bfloat16, device=dev)
+    lse = torch.empty(B * H * N, device=dev)
+    L.attention_fwd_train(qd, out, lse, B, N, H, d, scale)
+    assert _rel(out.float().cpu().view(B, N, -1), o_ref.detach()) < 2e-2
+    lse_ref = torch.logsumexp((q * scale) @ k.transpose(-1, -2), -1).detach() / math.log(2.0)          # [B, H, N], log2 domain
+    assert (lse.cpu().view(B, H, N) - lse_ref).abs().max() < 2e-2
+    dqkv = torch.empty_like(qd)
+    L.attention_bwd(qd, out, dout.view(B * N, -1).contiguous().to(dev), lse, dqkv, B, N, H, d, scale)
+    got = dqkv.float().cpu().view(B, N, 3, H, d)
+    for i, name in enumerate('qkv'):
+        assert _rel(got[:, :, i], ref_in.grad[:, :, i]) < 3e-2, name
+
+
+def test_vit_backward_224_hip_attention(dev):
+    """Same gradient check at the bench shape (224x224 -> 196 tokens), depth 1: the path with the MFMA attention backward kernel."""
+    from oracle import synth
+    from oracle.vit import vit_forward
+    from whmr_amd.models.pose_vit import ViT
+    from whmr_amd.train.vit_autograd import _hip_attention_bwd
+    size = (224, 224)
+    sd = synth.make_vit_state(5, size, depth=1)
+    x = synth.make_inputs(2, 11, size)['x']
+    G = torch.randn(2, 768, 14, 14, generator=torch.Generator().manual_seed(6))
+    ref_sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    (vit_forward(ref_sd, x, depth=1) * G).sum().backward()
+    m = ViT(img_size=size, depth=1, qkv_bias=True, numerics='bf16')
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev).train()
+    assert _hip_attention_bwd(m, 196)
+    (m(x.to(dev)) * G.to(dev)).sum().backward()
+    bad = {n: _rel(p.grad.cpu(), ref_sd[n].grad) for n, p in m.named_parameters()}
+    bad = {k: v for k, v in bad.items() if not v < 4e-2}
+    assert not bad, 'gradient mismatch: %s' % sorted(bad.items(), key=lambda kv: -kv[1])[:6]

@@ -63,6 +63,8 @@ _SIGS = {
     'whmr_smpl_joints': [C.POINTER(WhmrSmplModel), _P, _P, _I, _P, _P, _P, _P, _P],
     'whmr_maf_sample': [_P, _I, _L, _L, _L, _L, _I, _I, _P, _P, _P, _L, _F, _F, _F, C.POINTER(WhmrMafWeights), _I, _I, _P, _L, _P, _P],
     'whmr_crop_normalize': [_P, _I, _I, _L, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
+    'whmr_attention_fwd_train': [_P, _P, _P, _I, _I, _I, _I, _F, _P],
+    'whmr_attention_bwd': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
     'whmr_transpose_cast': [_P, _I, _L, _P, _I, _L, _I, _I, _I, _P],
     'whmr_colsum': [_P, _I, _L, _I, _I, _P, _I, _P, _P],
     'whmr_layernorm_bwd': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P],
@@ -116,7 +118,7 @@ def splitk_workspace(device):
     """Per-device scratch for split-K partial sums (fp32 skinny GEMMs; bf16 GEMMs with too few tiles to fill 256 CUs)."""
     w = _splitk_ws.get(device)
     if w is None:
-        w = _splitk_ws[device] = torch.empty(64 << 20, dtype=torch.uint8, device=device)
+        w = _splitk_ws[device] = torch.empty(128 << 20, dtype=torch.uint8, device=device)
     return w
 
 
@@ -496,3 +498,22 @@ def gelu_bwd(pre, dhid, dpre):
     _check(lib().whmr_gelu_bwd(pre.data_ptr(), int(pre.dtype == torch.bfloat16), dhid.data_ptr(), dpre.data_ptr(),
                                int(dpre.dtype == torch.bfloat16), pre.numel(), _stream()), 'whmr_gelu_bwd')
     return dpre
+
+
+def attention_fwd_train(qkv, out, lse, B, N, H, d, scale):
+    _dev(qkv, out, lse)
+    assert qkv.dtype == torch.bfloat16 and out.dtype == torch.bfloat16 and lse.dtype == torch.float32
+    assert qkv.is_contiguous() and out.is_contiguous() and lse.is_contiguous() and lse.numel() == B * H * N
+    _check(lib().whmr_attention_fwd_train(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), B, N, H, d, scale, _stream()), 'whmr_attention_fwd_train')
+    return out
+
+
+def attention_bwd(qkv, o, dout, lse, dqkv, B, N, H, d, scale):
+    _dev(qkv, o, dout, lse, dqkv)
+    assert qkv.dtype == torch.bfloat16 and o.dtype == torch.bfloat16 and dqkv.dtype == torch.bfloat16
+    assert dout.dtype == torch.float32 and lse.dtype == torch.float32
+    for t in (qkv, o, dout, lse, dqkv):
+        assert t.is_contiguous()
+    _check(lib().whmr_attention_bwd(qkv.data_ptr(), o.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), B, N, H, d, scale,
+                                    _stream()), 'whmr_attention_bwd')
+    return dqkv

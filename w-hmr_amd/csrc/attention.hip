@@ -154,7 +154,7 @@ __global__ __launch_bounds__(NKT * 64) void attention_bf16_kernel(const bf16_t* 
 // through LDS (the K region, free after the last key tile) for 128-B row stores.
 template <int NKT>
 __global__ __launch_bounds__(NKT * 64, 4) void attention_bf16_chunk_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                                           int N, int H, float scale) {
+                                                                           int N, int H, float scale, float* __restrict__ lse) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NPAD = NKT * 32;
     constexpr int VS = NPAD + 4;
@@ -271,6 +271,8 @@ __global__ __launch_bounds__(NKT * 64, 4) void attention_bf16_chunk_kernel(const
     }
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;
+    // training: log2-domain log-sum-exp per query, P = exp2(s * scale * log2e - lse) in the backward kernel
+    if (lse && hi == 0 && q0 + l31 < N) lse[((size_t)b * H + h) * N + q0 + l31] = m + __log2f(l);
     // ---- transpose the wave's [32 queries x 64 d] tile through LDS (rows of 136 B: conflict-free 8-B writes) and store rows
     __syncthreads();                               // every wave is done with K / Vt
     constexpr int TS = 136;
@@ -291,6 +293,232 @@ __global__ __launch_bounds__(NKT * 64, 4) void attention_bf16_chunk_kernel(const
         const uint4 v = *(const uint4*)(tile + row * TS + ch * 16);
         if (q < N) *(uint4*)(obase + (size_t)q * C + ch * 8) = v;
     }
+}
+
+// ---- backward of the attention core (bf16, d = 64, N <= 256): dQ, dK, dV from the saved qkv, O, the log-sum-exp written by
+// the chunked forward kernel and dO.  One workgroup per (image, head), wave j owns KEY tile j (32 keys):
+//   dK_j, dV_j are complete sums over the queries inside the wave (accumulated TRANSPOSED, [d x keys], lane = key);
+//   dQ needs a sum over key tiles = over waves: in step s wave j works on query tile (j + s) % NKT, so every query tile is
+//   touched by exactly one wave per step and its fp32 accumulator in LDS is updated with plain loads/stores between two
+//   barriers -- deterministic, no atomics.
+// Per (key tile j, query tile i), all on v_mfma_f32_32x32x16_bf16:
+//   S^T = K_j Q_i^T, dP^T = V_j dO_i^T  (lane = query)  ->  dS^T = scale * P^T o (dP^T - D)  ->  dQ_i^T += K_j^T dS^T
+//   S   = Q_i K_j^T, dP   = dO_i V_j^T  (lane = key)    ->  P, dS                            ->  dV_j^T += dO_i^T P,  dK_j^T += Q_i^T dS
+// (the same operand registers serve S and S^T with the MFMA operands swapped).  The "transposed A" operands (K_j^T, dO_i^T,
+// Q_i^T: rows = d, k = keys / queries) are read from the row-major LDS tiles with ds_read_b64_tr_b16.
+__device__ __forceinline__ uint32_t swz_addr(int row, int col) {      // byte offset of element (row, col) in a [rows][64] bf16 tile
+    return row * 128 + ((((col >> 3) ^ ((row >> 1) & 7))) << 4) + (col & 7) * 2;
+}
+__device__ __forceinline__ uint2 lds_tr_read64(uint32_t addr) {
+    uint2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+// A operand "X^T": lane -> m = c0 + (lane & 31) (a column of X), k-slots hi*8 + e <-> X rows R0 + 4*hi + (e & 3) + 8*(e >> 2)
+__device__ __forceinline__ bf16x8_t tr_frag(uint32_t lds_base, int R0, int c0, int lane) {
+    const int g = lane >> 4, i = lane & 15;
+    const int col = c0 + 16 * (g & 1) + 4 * (i & 3);
+    const int row = R0 + 4 * (g >> 1) + (i >> 2);
+    const uint2 a = lds_tr_read64(lds_base + swz_addr(row, col));
+    const uint2 b = lds_tr_read64(lds_base + swz_addr(row + 8, col));
+    union { bf16x8_t v; uint32_t u[4]; } f;
+    f.u[0] = a.x; f.u[1] = a.y; f.u[2] = b.x; f.u[3] = b.y;
+    return f.v;
+}
+
+template <int NKT>
+__global__ __launch_bounds__(NKT * 64) void attention_bwd_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+                                                                       const float* __restrict__ dout, const float* __restrict__ lse,
+                                                                       bf16_t* __restrict__ dqkv, int N, int H, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NPAD = NKT * 32;
+    constexpr int DQS = 68;                                  // fp32 row stride of the dQ accumulator (16-B aligned, conflict-free)
+    char* Qs = smem;                                         // [NPAD][64] bf16, swizzled rows (like Ks of the forward kernel)
+    char* dOs = Qs + NPAD * 128;
+    char* Ks = dOs + NPAD * 128;
+    float* dQa = (float*)(Ks + NPAD * 128);                  // [NPAD][DQS]
+    float* lseS = dQa + NPAD * DQS;                          // [NPAD]
+    float* Ds = lseS + NPAD;                                 // [NPAD]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int C = H * 64, ld = 3 * C;
+    const bf16_t* base = qkv + (size_t)b * N * ld + h * 64;
+    const float* dob = dout + (size_t)b * N * C + h * 64;
+    const bf16_t* ob = o + (size_t)b * N * C + h * 64;
+    // ---- stage Q, K (bf16 rows), dO (fp32 -> bf16), zero the dQ accumulator, per-query lse and D = sum_d dO * O
+    for (int c = tid; c < NPAD * 8; c += NKT * 64) {
+        const int row = c >> 3, ch = c & 7;
+        uint4 q = make_uint4(0, 0, 0, 0), k = q, d = q;
+        if (row < N) {
+            q = *(const uint4*)(base + (size_t)row * ld + ch * 8);
+            k = *(const uint4*)(base + (size_t)row * ld + C + ch * 8);
+            const float4 a = *(const float4*)(dob + (size_t)row * C + ch * 8), bb = *(const float4*)(dob + (size_t)row * C + ch * 8 + 4);
+            d = make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(bb.x, bb.y), pack_bf16x2(bb.z, bb.w));
+        }
+        const int off = row * 128 + ((ch ^ ((row >> 1) & 7)) << 4);
+        *(uint4*)(Qs + off) = q;
+        *(uint4*)(Ks + off) = k;
+        *(uint4*)(dOs + off) = d;
+    }
+    for (int c = tid; c < NPAD * DQS / 4; c += NKT * 64) ((float4*)dQa)[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int row = tid; row < NPAD; row += NKT * 64) {
+        float dsum = 0.f, ls = INFINITY;                     // padded queries: P = exp2(-inf) = 0
+        if (row < N) {
+            ls = lse[((size_t)b * H + h) * N + row];
+            for (int dd = 0; dd < 64; dd += 4) {
+                const float4 a = *(const float4*)(dob + (size_t)row * C + dd);
+                const uint2 ov = *(const uint2*)(ob + (size_t)row * C + dd);
+                dsum += a.x * __uint_as_float(ov.x << 16) + a.y * __uint_as_float(ov.x & 0xffff0000u) +
+                        a.z * __uint_as_float(ov.y << 16) + a.w * __uint_as_float(ov.y & 0xffff0000u);
+            }
+        }
+        lseS[row] = ls;
+        Ds[row] = dsum;
+    }
+    // this wave's key tile: K_j / V_j row fragments (lane = key, k = d) straight from global memory
+    const int k0 = wave * 32;
+    int krow = k0 + l31;
+    const bool key_ok_lane = krow < N;                       // lane-as-key validity (S orientation)
+    if (krow > N - 1) krow = N - 1;
+    bf16x8_t kf[4], vf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        kf[kk] = *(const bf16x8_t*)(base + (size_t)krow * ld + C + kk * 16 + hi * 8);
+        vf[kk] = *(const bf16x8_t*)(base + (size_t)krow * ld + 2 * C + kk * 16 + hi * 8);
+    }
+    __syncthreads();
+    const uint32_t qs_l = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)Qs;
+    const uint32_t dos_l = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)dOs;
+    const uint32_t ks_l = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)Ks;
+    const float sc = scale * LOG2E;
+    f32x16_t dvt[2], dkt[2];                                 // dV_j^T, dK_j^T: [d = dh*32 + (r&3) + 8(r>>2) + 4hi][key = l31]
+#pragma unroll
+    for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dvt[dh][r] = 0.f; dkt[dh][r] = 0.f; }
+
+#pragma unroll 1
+    for (int step = 0; step < NKT; ++step) {
+        const int it = (wave + step) % NKT, q0 = it * 32;
+        bf16x8_t qf[4], dof[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int row = q0 + l31;
+            const int off = row * 128 + (((kk * 2 + hi) ^ ((row >> 1) & 7)) << 4);
+            qf[kk] = *(const bf16x8_t*)(Qs + off);
+            dof[kk] = *(const bf16x8_t*)(dOs + off);
+        }
+        // ---- lane = query orientation: dS^T -> dQ_i^T partial
+        {
+            f32x16_t st, dpt;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { st[r] = 0.f; dpt[r] = 0.f; }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk], qf[kk], st, 0, 0, 0);
+                dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kk], dof[kk], dpt, 0, 0, 0);
+            }
+            const float ls = lseS[q0 + l31], dq_ = Ds[q0 + l31];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const float p = key < N ? __builtin_amdgcn_exp2f(fmaf(st[r], sc, -ls)) : 0.f;
+                st[r] = scale * p * (dpt[r] - dq_);                                  // dS^T
+            }
+            f32x16_t dq[2];
+#pragma unroll
+            for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dq[dh][r] = 0.f;
+#pragma unroll
+            for (int j2 = 0; j2 < 2; ++j2) {
+                union { bf16x8_t v; uint32_t u[4]; } sf;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sf.u[e] = pack_bf16x2(st[8 * j2 + 2 * e], st[8 * j2 + 2 * e + 1]);
+#pragma unroll
+                for (int dh = 0; dh < 2; ++dh)
+                    dq[dh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(ks_l, k0 + 16 * j2, dh * 32, lane), sf.v, dq[dh], 0, 0, 0);
+            }
+            float* arow = dQa + (q0 + l31) * DQS;
+#pragma unroll
+            for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float4* ap = (float4*)(arow + dh * 32 + 8 * q + 4 * hi);
+                    float4 a = *ap;
+                    a.x += dq[dh][4 * q]; a.y += dq[dh][4 * q + 1]; a.z += dq[dh][4 * q + 2]; a.w += dq[dh][4 * q + 3];
+                    *ap = a;
+                }
+        }
+        // ---- lane = key orientation: P, dS -> dV_j^T, dK_j^T
+        {
+            f32x16_t s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[kk], kf[kk], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof[kk], vf[kk], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q = q0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const float p = key_ok_lane ? __builtin_amdgcn_exp2f(fmaf(s[r], sc, -lseS[q])) : 0.f;
+                s[r] = p;                                                            // P
+                dp[r] = scale * p * (dp[r] - Ds[q]);                                 // dS
+            }
+#pragma unroll
+            for (int j2 = 0; j2 < 2; ++j2) {
+                union { bf16x8_t v; uint32_t u[4]; } pf, sf;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    pf.u[e] = pack_bf16x2(s[8 * j2 + 2 * e], s[8 * j2 + 2 * e + 1]);
+                    sf.u[e] = pack_bf16x2(dp[8 * j2 + 2 * e], dp[8 * j2 + 2 * e + 1]);
+                }
+#pragma unroll
+                for (int dh = 0; dh < 2; ++dh) {
+                    dvt[dh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(dos_l, q0 + 16 * j2, dh * 32, lane), pf.v, dvt[dh], 0, 0, 0);
+                    dkt[dh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(qs_l, q0 + 16 * j2, dh * 32, lane), sf.v, dkt[dh], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                                     // the next step's owner of this query tile sees the update
+    }
+    // ---- dQ rows of query tile `wave` (fp32 accumulator -> bf16), 16 lanes per row
+    bf16_t* dqb = dqkv + (size_t)b * N * ld + h * 64;
+#pragma unroll
+    for (int itr = 0; itr < 8; ++itr) {
+        const int row = wave * 32 + itr * 4 + (lane >> 4), c4 = (lane & 15) * 4;
+        if (row < N) {
+            const float4 a = *(const float4*)(dQa + row * DQS + c4);
+            *(uint2*)(dqb + (size_t)row * ld + c4) = make_uint2(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w));
+        }
+    }
+    // ---- dK_j, dV_j: transpose [d x keys] -> [keys][d] through LDS (Q / dO tiles are dead after the last barrier)
+    constexpr int TS = 136;
+    char* tile = smem + wave * (2 * 32 * TS);
+#pragma unroll
+    for (int which = 0; which < 2; ++which)
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x16_t& a = which ? dvt[dh] : dkt[dh];
+                *(uint2*)(tile + which * 32 * TS + l31 * TS + (dh * 32 + 8 * q + 4 * hi) * 2) =
+                    make_uint2(pack_bf16x2(a[4 * q], a[4 * q + 1]), pack_bf16x2(a[4 * q + 2], a[4 * q + 3]));
+            }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int which = 0; which < 2; ++which)
+#pragma unroll
+        for (int itr = 0; itr < 4; ++itr) {
+            const int row = itr * 8 + (lane >> 3), ch = lane & 7;
+            const int key = k0 + row;
+            const uint4 v = *(const uint4*)(tile + which * 32 * TS + row * TS + ch * 16);
+            if (key < N) *(uint4*)(dqb + (size_t)key * ld + (1 + which) * C + ch * 8) = v;
+        }
 }
 
 // fp32, reference operation order: q*scale, dot over d, softmax(expf), weighted sum over keys.
@@ -358,12 +586,12 @@ static int g_attn_chunked = 1;      // whmr_attention_set_variant: 1 = chunked o
 extern "C" int whmr_attention_set_variant(int chunked) { g_attn_chunked = chunked; return 0; }
 
 template <int NKT>
-static int launch_bf16(const void* qkv, void* out, int B, int N, int H, float scale, hipStream_t st) {
+static int launch_bf16(const void* qkv, void* out, int B, int N, int H, float scale, hipStream_t st, float* lse = nullptr) {
     constexpr int NPAD = NKT * 32;
     const size_t lds = (size_t)NPAD * 128 + 64 * (NPAD + 4) * 2;
-    if (g_attn_chunked && NKT >= 3 && scale > 0.f)
+    if ((g_attn_chunked || lse) && NKT >= 3 && scale > 0.f)
         hipLaunchKernelGGL((attention_bf16_chunk_kernel<NKT>), dim3(B * H), dim3(NKT * 64), lds, st, (const bf16_t*)qkv,
-                           (bf16_t*)out, N, H, scale);
+                           (bf16_t*)out, N, H, scale, lse);
     else
     hipLaunchKernelGGL((attention_bf16_kernel<NKT>), dim3(B * H), dim3(NKT * 64), lds, st, (const bf16_t*)qkv,
                        (bf16_t*)out, N, H, scale);
@@ -401,3 +629,51 @@ extern "C" int whmr_attention(const void* qkv, void* out, int B, int N, int H, i
     WHMR_CHECK_LAUNCH();
     return 0;
 }
+
+template <int NKT>
+static int launch_bwd(const void* qkv, const void* o, const float* dout, const float* lse, void* dqkv, int B, int N, int H, float scale,
+                      hipStream_t st) {
+    constexpr int NPAD = NKT * 32;
+    const size_t lds = (size_t)3 * NPAD * 128 + (size_t)NPAD * 68 * 4 + (size_t)2 * NPAD * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)attention_bwd_bf16_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((attention_bwd_bf16_kernel<NKT>), dim3(B * H), dim3(NKT * 64), lds, st, (const bf16_t*)qkv, (const bf16_t*)o, dout, lse,
+                       (bf16_t*)dqkv, N, H, scale);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+// Forward with the per-query log-sum-exp kept for the backward pass (bf16, d = 64, 64 < N <= 256): lse [B, H, N] fp32.
+extern "C" int whmr_attention_fwd_train(const void* qkv, void* out, float* lse, int B, int N, int H, int d, float scale, void* stream) {
+    if (B <= 0 || N <= 64 || N > 256 || H <= 0 || d != 64 || !lse || scale <= 0.f) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    switch ((N + 31) / 32) {
+        case 3: return launch_bf16<3>(qkv, out, B, N, H, scale, st, lse);
+        case 4: return launch_bf16<4>(qkv, out, B, N, H, scale, st, lse);
+        case 5: return launch_bf16<5>(qkv, out, B, N, H, scale, st, lse);
+        case 6: return launch_bf16<6>(qkv, out, B, N, H, scale, st, lse);
+        case 7: return launch_bf16<7>(qkv, out, B, N, H, scale, st, lse);
+        case 8: return launch_bf16<8>(qkv, out, B, N, H, scale, st, lse);
+    }
+    return (int)hipErrorInvalidValue;
+}
+
+// dqkv [B, N, 3, H, 64] bf16 from qkv (same layout), o = forward output [B, N, H*64] bf16, dout = its gradient (fp32), lse.
+extern "C" int whmr_attention_bwd(const void* qkv, const void* o, const float* dout, const float* lse, void* dqkv, int B, int N, int H, int d,
+                                  float scale, void* stream) {
+    if (B <= 0 || N <= 64 || N > 224 || H <= 0 || d != 64) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    switch ((N + 31) / 32) {
+        case 3: return launch_bwd<3>(qkv, o, dout, lse, dqkv, B, N, H, scale, st);
+        case 4: return launch_bwd<4>(qkv, o, dout, lse, dqkv, B, N, H, scale, st);
+        case 5: return launch_bwd<5>(qkv, o, dout, lse, dqkv, B, N, H, scale, st);
+        case 6: return launch_bwd<6>(qkv, o, dout, lse, dqkv, B, N, H, scale, st);
+        case 7: return launch_bwd<7>(qkv, o, dout, lse, dqkv, B, N, H, scale, st);
+    }
+    return (int)hipErrorInvalidValue;
+}
+

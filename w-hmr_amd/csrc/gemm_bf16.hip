@@ -100,6 +100,13 @@ extern "C" int whmr_gemm_bf16(const whmr_gemm* pp, int flags, void* stream) {
     // CU are resident; partial sums go to the fp32 workspace and splitk_epilogue_kernel finishes (fixed order: deterministic).
     // Thresholds from tools/resnet_shapes.py: pays from K >= 2048 when the 128x128 grid covers less than half of the CUs.
     const long tiles64 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    // Weight-gradient products of the backward pass (dW = dY^T . X: a few dozen 256x256 tiles, K = all tokens): 256x256 tiles
+    // sliced over K so that every CU owns exactly one block (tools/dw_probe.py: 3072x768x12544 124 -> 81 us).
+    const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+    if (p.workspace && p.n_phase <= 1 && p.a_mode == 0 && p.K >= 4096 && tiles256 >= 16 && tiles256 <= 128) {
+        const long splits = 256 / tiles256;
+        if (splits > 1 && whmr_gemm_bf16_split(pp, 257, (int)splits, stream) == 0) return 0;
+    }
     if (p.workspace && p.n_phase <= 1 && p.K >= 2048 && tiles64 <= 128) {
         long splits = 512 / tiles64;
         if (splits > p.K / 512) splits = p.K / 512;

@@ -8,8 +8,9 @@ driven by ``core/trainer.py:410-470`` (loss.backward()).  Here the backward pass
     ``whmr_transpose_cast`` (rows zero-padded to a multiple of 64 so that the token dimension can be the GEMM's K);
   * LayerNorm backward (+ residual-stream accumulation), exact-erf GELU backward and the bias column sums are HIP kernels
     (``train_ops.hip``), all deterministic (two-stage reductions, no atomics);
-  * the attention core's backward is, this round, a handful of batched PyTorch matmuls on the device (recompute P from the
-    saved qkv): ~4 % of the backward FLOPs -- a fused HIP kernel is the next step.
+  * the attention core's backward is the MFMA kernel ``whmr_attention_bwd`` (bf16 mode, head dim 64, 64 < N <= 224; P is
+    recomputed from the saved qkv and the log-sum-exp the training forward writes); the fp32 parity mode and other shapes
+    use a handful of batched PyTorch matmuls on the device instead.
 
 ``numerics='fp32'`` (exact-f32 MFMA) is the parity mode against the CPU reference's autograd; ``'bf16'`` casts GEMM operands
 to bf16 and keeps the residual-stream gradient, LayerNorm statistics and all weight gradients in fp32.
@@ -64,7 +65,12 @@ def vit_forward_train(m, x):
         a.qkv = torch.empty(M, 3 * D, dtype=dt, device=dev)
         L.gemm(a.h1, m._w(blk.attn.qkv.weight), a.qkv, bias=blk.attn.qkv.bias)
         a.att = torch.empty(M, D, dtype=dt, device=dev)
-        L.attention(a.qkv, a.att, B, N, m.num_heads, D // m.num_heads, m.scale)
+        a.lse = None
+        if _hip_attention_bwd(m, N):
+            a.lse = torch.empty(B * m.num_heads * N, **f32)
+            L.attention_fwd_train(a.qkv, a.att, a.lse, B, N, m.num_heads, D // m.num_heads, m.scale)
+        else:
+            L.attention(a.qkv, a.att, B, N, m.num_heads, D // m.num_heads, m.scale)
         a.t_mid = torch.empty(M, D, **f32)
         L.gemm(a.att, m._w(blk.attn.proj.weight), a.t_mid, bias=blk.attn.proj.bias, residual=a.t_in)
         a.h2 = torch.empty(M, D, dtype=dt, device=dev)
@@ -80,6 +86,11 @@ def vit_forward_train(m, x):
     out = torch.empty(M, D, **f32)
     L.layernorm(t, m.last_norm.weight, m.last_norm.bias, out, 1e-6)
     return out, s
+
+
+def _hip_attention_bwd(m, N):
+    """The MFMA attention backward kernel covers the bf16 mode at head dim 64 and 64 < N <= 224 tokens (ViT-B/L at 224^2, 256x192)."""
+    return m.numerics != 'fp32' and m.embed_dim // m.num_heads == 64 and 64 < N <= 224
 
 
 def _attention_bwd(qkv, d_att, B, N, H, dh, scale, dt):
@@ -146,7 +157,11 @@ def vit_backward(m, s, dout):
         grads[blk.norm2.weight], grads[blk.norm2.bias] = dg, db
         # t_mid = t_in + proj(attention(qkv(LN1(t_in))))
         d_att = linear_bwd(_op(dt_grad, dt), a.att, blk.attn.proj)
-        d_qkv = _attention_bwd(a.qkv, d_att, B, N, m.num_heads, D // m.num_heads, m.scale, dt)
+        if a.lse is not None:
+            d_qkv = torch.empty_like(a.qkv)
+            L.attention_bwd(a.qkv, a.att, d_att, a.lse, d_qkv, B, N, m.num_heads, D // m.num_heads, m.scale)
+        else:
+            d_qkv = _attention_bwd(a.qkv, d_att, B, N, m.num_heads, D // m.num_heads, m.scale, dt)
         d_h1 = linear_bwd(d_qkv, a.h1, blk.attn.qkv)
         dg, db = torch.empty(D, **f32), torch.empty(D, **f32)
         L.layernorm_bwd(a.t_in, d_h1, blk.norm1.weight, dt_grad, dt_grad, dg, db, 1e-6)    # dt_grad now = d t_in
