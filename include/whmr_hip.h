@@ -194,6 +194,10 @@ int whmr_attention_fwd_train(const void* qkv, void* out, float* lse, int B, int 
 int whmr_attention_bwd(const void* qkv, const void* o, const float* dout, const float* lse, void* dqkv, int B, int N, int H, int d,
                        float scale, void* stream);
 
+/* Second convolution of the Tz head (whmr.py:420 + the reshape at :571): Conv2d(64,5,k7,s2) on the NHWC map x [B,IH,IW,64]
+ * (bf16 or fp32), weights w [5][7*7][64] fp32 -> tokens [B,5,OH*OW] fp32. */
+int whmr_tz_conv1(const void* x, int x_bf16, const float* w, float* tok, int B, int IH, int IW, void* stream);
+
 /* Tz-head tail (whmr.py:574-577): tokens [B,T,D] -> mean over T -> Linear(D,Hd) -> Linear(Hd,1) -> BatchNorm1d(1) eval
  * (bn4 = weight, bias, running_mean, running_var) -> sigmoid -> x10. */
 int whmr_tz_tail(const float* tok, int B, int T, int D, const float* w0, const float* b0, int Hd, const float* w1,

@@ -65,6 +65,7 @@ _SIGS = {
     'whmr_crop_normalize': [_P, _I, _I, _L, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     'whmr_attention_fwd_train': [_P, _P, _P, _I, _I, _I, _I, _F, _P],
     'whmr_attention_bwd': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
+    'whmr_tz_conv1': [_P, _I, _P, _P, _I, _I, _I, _P],
     'whmr_transpose_cast': [_P, _I, _L, _P, _I, _L, _I, _I, _I, _P],
     'whmr_colsum': [_P, _I, _L, _I, _I, _P, _I, _P, _P],
     'whmr_layernorm_bwd': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P],
@@ -517,3 +518,13 @@ def attention_bwd(qkv, o, dout, lse, dqkv, B, N, H, d, scale):
     _check(lib().whmr_attention_bwd(qkv.data_ptr(), o.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), B, N, H, d, scale,
                                     _stream()), 'whmr_attention_bwd')
     return dqkv
+
+
+def tz_conv1(x_nhwc, w, tok):
+    """x [B,IH,IW,64] (bf16 / fp32) , w [5,49,64] fp32 -> tok [B,5,OH*OW] fp32 (whmr.py:420 + the reshape at :571)."""
+    _dev(x_nhwc, w, tok)
+    B, IH, IW, Cc = x_nhwc.shape
+    assert Cc == 64 and x_nhwc.is_contiguous() and w.dtype == torch.float32 and w.is_contiguous() and tok.is_contiguous()
+    _check(lib().whmr_tz_conv1(x_nhwc.data_ptr(), int(x_nhwc.dtype == torch.bfloat16), w.data_ptr(), tok.data_ptr(), B, IH, IW, _stream()),
+           'whmr_tz_conv1')
+    return tok

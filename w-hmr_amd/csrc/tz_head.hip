@@ -1,0 +1,43 @@
+// Second convolution of the Tz / focal head (whmr.py:420): Conv2d(64, 5, k7, s2) on the NHWC map of conv0 -> tokens [B, 5, 216]
+// (the reference's reshape(B, 5, -1) of the NCHW result, whmr.py:571).  N = 5 output channels is no GEMM shape: one wave per
+// output pixel, lane = input channel, 49 taps x 5 FMAs per lane, wave reduction; fp32 accumulation and weights.
+// (A one-workgroup-per-image fusion of the following timm Block + est_Tz tail was tried: 265 us vs ~70 us for the 8 small
+// launches on the pipelined skinny GEMM -- 5 tokens per image give every weight load only 5 FMAs; dropped.)
+#include "common.h"
+
+template <typename T>
+__global__ __launch_bounds__(256) void tz_conv1_kernel(const T* __restrict__ x, const float* __restrict__ w /*[5][49][64]*/,
+                                                       float* __restrict__ tok, int B, int IH, int IW, int OH, int OW) {
+    const int lane = threadIdx.x & 63;
+    const int pix = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int npix = OH * OW;
+    if (pix >= B * npix) return;
+    const int b = pix / npix, p = pix - b * npix;
+    const int oy = p / OW, ox = p - oy * OW;
+    const T* xb = x + ((size_t)b * IH * IW) * 64 + lane;
+    float a[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx) {
+            const float v = io<T>::ld(xb + ((size_t)(oy * 2 + ky) * IW + (ox * 2 + kx)) * 64);
+            const float* wt = w + (ky * 7 + kx) * 64 + lane;
+#pragma unroll
+            for (int n = 0; n < 5; ++n) a[n] = fmaf(v, wt[n * 49 * 64], a[n]);
+        }
+#pragma unroll
+    for (int n = 0; n < 5; ++n) {
+        const float s = wave_sum(a[n]);
+        if (lane == 0) tok[((size_t)b * 5 + n) * npix + p] = s;
+    }
+}
+
+extern "C" int whmr_tz_conv1(const void* x, int x_bf16, const float* w, float* tok, int B, int IH, int IW, void* stream) {
+    const int OH = (IH - 7) / 2 + 1, OW = (IW - 7) / 2 + 1;
+    if (B <= 0 || OH <= 0 || OW <= 0) return (int)hipErrorInvalidValue;
+    const int waves = B * OH * OW;
+    hipStream_t st = (hipStream_t)stream;
+    if (x_bf16) hipLaunchKernelGGL(tz_conv1_kernel<bf16_t>, dim3((waves + 3) / 4), dim3(256), 0, st, (const bf16_t*)x, w, tok, B, IH, IW, OH, OW);
+    else hipLaunchKernelGGL(tz_conv1_kernel<float>, dim3((waves + 3) / 4), dim3(256), 0, st, (const float*)x, w, tok, B, IH, IW, OH, OW);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}

@@ -353,8 +353,7 @@ class WHMR(nn.Module):
         def build():
             w0 = c0.detach().permute(0, 2, 3, 1).reshape(c0.shape[0], -1).contiguous()     # [64, (ky,kx,ci)]
             w0 = w0 if self._dt == torch.float32 else L.cast_bf16(w0)
-            w1 = c1.detach().permute(0, 2, 3, 1).reshape(c1.shape[0], -1).contiguous()     # [5, (ky,kx,ci)]
-            w1 = w1 if self._dt == torch.float32 else L.cast_bf16(w1)
+            w1 = c1.detach().float().permute(0, 2, 3, 1).reshape(c1.shape[0], 49, 64).contiguous()        # [5, (ky,kx), ci] fp32
             bn = self.est_Tz[2]
             bn4 = torch.stack([bn.weight.detach()[0], bn.bias.detach()[0], bn.running_mean[0], bn.running_var[0]]).float().contiguous()
             return w0, w1, bn4
@@ -385,14 +384,14 @@ class WHMR(nn.Module):
         B, H, W, C = f_nhwc.shape
         dev = f_nhwc.device
         w0, w1, bn4 = self._tz_operands()
+        assert (C, self.conv[1].weight.shape[0], self.conv[0].weight.shape[0]) == (256, 5, 64)
         H1, W1 = (H - 7) // 3 + 1, (W - 7) // 3 + 1
         y0 = torch.empty(B, H1, W1, 64, dtype=self._dt, device=dev)                  # NHWC, mode dtype (feeds the 2nd conv)
         L.gemm(f_nhwc, w0, y0.view(-1, 64), conv=dict(IH=H, IW=W, Cin=C, OH=H1, OW=W1, KW=7, SH=3, SW=3, PH=0, PW=0))
         H2, W2 = (H1 - 7) // 2 + 1, (W1 - 7) // 2 + 1
-        y1 = torch.empty(B, H2 * W2, 5, dtype=torch.float32, device=dev)
-        L.gemm(y0, w1, y1.view(-1, 5), conv=dict(IH=H1, IW=W1, Cin=64, OH=H2, OW=W2, KW=7, SH=2, SW=2, PH=0, PW=0))
         D = H2 * W2
-        t = y1.transpose(1, 2).contiguous().view(B * 5, D)                            # reshape(B, 5, -1) of the NCHW map
+        t = torch.empty(B * 5, D, dtype=torch.float32, device=dev)                  # == conv1(...).reshape(B, 5, -1), whmr.py:571
+        L.tz_conv1(y0, w1, t.view(B, 5, D))                                           # N = 5 output channels: one wave per pixel
         td = self.transformer_decoder
         h = torch.empty_like(t)
         qkv = torch.empty(B * 5, 3 * D, dtype=torch.float32, device=dev)
