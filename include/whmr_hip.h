@@ -186,7 +186,7 @@ int whmr_layernorm_bwd(const float* x, const float* dy, const float* gamma, cons
                        float* dbeta, int accumulate, int rows, int C, float eps, float* scratch, void* stream);
 /* exact-erf GELU: forward as its own pass (training keeps the pre-activation) and backward d_pre = d_hid * gelu'(pre). */
 int whmr_gelu_fwd(const void* pre, void* out, int is_bf16, long n, void* stream);
-int whmr_gelu_bwd(const void* pre, int pre_bf16, const float* dhid, void* dpre, int out_bf16, long n, void* stream);
+int whmr_gelu_bwd(const void* pre, int pre_bf16, const void* dhid, int dhid_bf16, void* dpre, int out_bf16, long n, void* stream);
 
 /* Attention core for training (bf16, d = 64, 64 < N <= 224): forward that also writes the per-query log-sum-exp (log2 domain,
  * lse [B,H,N] fp32), and the MFMA backward dqkv [B,N,3,H,64] bf16 from qkv, o = forward output, dout = d(o) fp32, lse. */

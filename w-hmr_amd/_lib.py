@@ -70,7 +70,7 @@ _SIGS = {
     'whmr_colsum': [_P, _I, _L, _I, _I, _P, _I, _P, _P],
     'whmr_layernorm_bwd': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P],
     'whmr_gelu_fwd': [_P, _P, _I, _L, _P],
-    'whmr_gelu_bwd': [_P, _I, _P, _P, _I, _L, _P],
+    'whmr_gelu_bwd': [_P, _I, _P, _I, _P, _I, _L, _P],
     'whmr_regressor_state': [_P, _P, _L, _P, _L, _P, _L, _I, _P, _L, _I, _P],
     'whmr_tz_tail': [_P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _F, _P, _P],
     'whmr_conv_im2col': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _L, _L, _L, _P],
@@ -495,9 +495,9 @@ def gelu_fwd(pre, out):
 
 def gelu_bwd(pre, dhid, dpre):
     _dev(pre, dhid, dpre)
-    assert dhid.dtype == torch.float32 and pre.is_contiguous() and dhid.is_contiguous() and dpre.is_contiguous()
-    _check(lib().whmr_gelu_bwd(pre.data_ptr(), int(pre.dtype == torch.bfloat16), dhid.data_ptr(), dpre.data_ptr(),
-                               int(dpre.dtype == torch.bfloat16), pre.numel(), _stream()), 'whmr_gelu_bwd')
+    assert dhid.dtype in (torch.float32, torch.bfloat16) and pre.is_contiguous() and dhid.is_contiguous() and dpre.is_contiguous()
+    _check(lib().whmr_gelu_bwd(pre.data_ptr(), int(pre.dtype == torch.bfloat16), dhid.data_ptr(), int(dhid.dtype == torch.bfloat16),
+                               dpre.data_ptr(), int(dpre.dtype == torch.bfloat16), pre.numel(), _stream()), 'whmr_gelu_bwd')
     return dpre
 
 

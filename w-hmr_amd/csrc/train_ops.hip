@@ -284,15 +284,20 @@ __global__ __launch_bounds__(256) void gelu_bwd8_kernel(const bf16_t* __restrict
     *(uint4*)(dpre + i * 8) = make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
 }
 
-extern "C" int whmr_gelu_bwd(const void* pre, int pre_bf16, const float* dhid, void* dpre, int out_bf16, long n, void* stream) {
+// dhid_bf16: the incoming gradient is bf16 (bf16 mode keeps d_hid in the compute dtype), else fp32
+extern "C" int whmr_gelu_bwd(const void* pre, int pre_bf16, const void* dhid_v, int dhid_bf16, void* dpre, int out_bf16, long n, void* stream) {
     if (n <= 0) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)((n + 255) / 256)), block(256);
     if (pre_bf16 && out_bf16 && !(n & 7)) {
-        hipLaunchKernelGGL(gelu_bwd8_kernel<float>, dim3((unsigned)((n / 8 + 255) / 256)), block, 0, st, (const bf16_t*)pre, dhid, (bf16_t*)dpre, n / 8);
+        const dim3 g8((unsigned)((n / 8 + 255) / 256));
+        if (dhid_bf16) hipLaunchKernelGGL(gelu_bwd8_kernel<bf16_t>, g8, block, 0, st, (const bf16_t*)pre, (const bf16_t*)dhid_v, (bf16_t*)dpre, n / 8);
+        else hipLaunchKernelGGL(gelu_bwd8_kernel<float>, g8, block, 0, st, (const bf16_t*)pre, (const float*)dhid_v, (bf16_t*)dpre, n / 8);
         WHMR_CHECK_LAUNCH();
         return 0;
     }
+    if (dhid_bf16) return (int)hipErrorInvalidValue;
+    const float* dhid = (const float*)dhid_v;
     if (pre_bf16 && out_bf16) hipLaunchKernelGGL((gelu_bwd_kernel<bf16_t, bf16_t>), grid, block, 0, st, (const bf16_t*)pre, dhid, (bf16_t*)dpre, n);
     else if (pre_bf16) hipLaunchKernelGGL((gelu_bwd_kernel<bf16_t, float>), grid, block, 0, st, (const bf16_t*)pre, dhid, (float*)dpre, n);
     else if (out_bf16) hipLaunchKernelGGL((gelu_bwd_kernel<float, bf16_t>), grid, block, 0, st, (const float*)pre, dhid, (bf16_t*)dpre, n);

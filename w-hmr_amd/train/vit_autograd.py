@@ -122,8 +122,8 @@ def vit_backward(m, s, dout):
         w = p.detach()
         return L.transpose_cast(w.reshape(shape) if shape is not None else w, dt, pad_to=1)
 
-    def linear_bwd(dy_op, x_saved, lin, need_dx=True, wshape=None):
-        """dy_op [M, Nout] (compute dtype), x_saved [M, Kin] -> dx [M, Kin] fp32; records dW, db."""
+    def linear_bwd(dy_op, x_saved, lin, need_dx=True, wshape=None, dx_dtype=torch.float32):
+        """dy_op [M, Nout] (compute dtype), x_saved [M, Kin] -> dx [M, Kin] (fp32 unless dx_dtype); records dW, db."""
         w = lin.weight
         n_out = dy_op.shape[1]
         k_in = x_saved.shape[1]
@@ -138,7 +138,7 @@ def vit_backward(m, s, dout):
             grads[lin.bias] = db
         if not need_dx:
             return None
-        dx = torch.empty(M, k_in, **f32)
+        dx = torch.empty(M, k_in, dtype=dx_dtype, device=dev)
         L.gemm(dy_op, wt(w, wshape), dx)                                               # W^T: [Kin, Nout]
         return dx
 
@@ -148,7 +148,7 @@ def vit_backward(m, s, dout):
     grads[m.last_norm.weight], grads[m.last_norm.bias] = dg, db
     for blk, a in zip(reversed(list(m.blocks)), reversed(s.layers)):
         # t_out = t_mid + fc2(gelu(fc1(LN2(t_mid))))
-        d_hid = linear_bwd(_op(dt_grad, dt), a.hid, blk.mlp.fc2)
+        d_hid = linear_bwd(_op(dt_grad, dt), a.hid, blk.mlp.fc2, dx_dtype=dt)             # only feeds the GELU backward: compute dtype
         d_pre = torch.empty(M, a.pre.shape[1], dtype=dt, device=dev)
         L.gelu_bwd(a.pre, d_hid, d_pre)
         d_h2 = linear_bwd(d_pre, a.h2, blk.mlp.fc1)
