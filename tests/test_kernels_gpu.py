@@ -33,7 +33,7 @@ def test_gemm_bf16(dev, M, N, K, glds):
 
 
 @pytest.mark.parametrize('M,N,K', [(392, 768, 768), (12544, 2304, 768), (300, 3072, 768), (392, 768, 3072), (1000, 130, 64)])
-@pytest.mark.parametrize('tile', [64, 65, 128, 256, 192, 257, 258, 259, 320])
+@pytest.mark.parametrize('tile', [64, 65, 128, 256, 192, 257, 259, 320])
 def test_gemm_bf16_big_tile(dev, M, N, K, tile):
     from whmr_amd import _lib as L
     g = torch.Generator().manual_seed(M + N + K + tile)

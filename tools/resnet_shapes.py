@@ -44,7 +44,7 @@ if len(sys.argv) > 2 and sys.argv[2] == 'tz':        # Tz head conv0 of W-HMR (w
         w = (torch.randn(64, 49 * 256, device=dev) / 112.).bfloat16()
         out = torch.empty(bs, 41, 31, 64, device=dev, dtype=torch.bfloat16)
         conv = dict(IH=128, IW=96, Cin=256, OH=41, OW=31, KW=7, SH=3, SW=3, PH=0, PW=0)
-        for tile in (None, 65, 66, 67, 64):
+        for tile in (None, 65, 64):
             print('tz conv0 B=%d tile %s: %.1f us' % (bs, tile, bench(lambda: L.gemm(x, w, out.view(-1, 64), conv=conv, tile=tile))), flush=True)
     sys.exit(0)
 for name, kind, lin, lout, Cin, N, skip in shapes:
@@ -66,7 +66,7 @@ for name, kind, lin, lout, Cin, N, skip in shapes:
     def run(tile=None, splits=None):
         return bench(lambda: L.gemm(x, w, out, bias=bias, act=L.ACT_RELU, conv=conv, residual=sk, res_first=skip, tile=tile, splits=splits))
     res.append(('auto', run()))
-    for tile in (65, 66, 67, 64, 128, 256, 192, 257, 320):
+    for tile in (65, 64, 128, 256, 192, 257, 320):
         if tile in (128, 256) and conv is not None and Cin % 32: continue
         res.append((str(tile), run(tile)))
         if K >= 512 and tile in (65, 64, 128):

@@ -202,71 +202,29 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
         else wait_vmcnt<0>();
     };
     if constexpr (PP) {
-        // ---- 8-phase ping-pong main loop (256x256x64, 8 waves = two groups of 4, one wave of each group per SIMD).
-        // A K tile is computed in 4 phases of 8 MFMAs (one 64x32 quadrant of the wave tile x K = 64); every phase is
-        //   [ds_read the fragments this quadrant adds | issue 2 global_load_lds | counted vmcnt] s_barrier [MFMAs] s_barrier
+        // ---- ping-pong main loop (opt-in tile 259: 256x256x64, 8 waves = two groups of 4, one wave of each group per SIMD).
+        // A K tile is computed in 2 phases of 16 MFMAs (two 64x32 quadrants of the wave tile x K = 64); every phase is
+        //   [ds_read the fragments the quadrants add | issue 4 global_load_lds | counted vmcnt] s_barrier [MFMAs] s_barrier
         // and group 1 runs one barrier behind group 0, so on every SIMD one wave is in its MFMA cluster while the other reads
-        // LDS / issues DMA: the matrix pipe never waits for a lockstep LDS burst.  DMA units (16 KiB = 2 loads per thread):
-        //   S1 = A rows {0-63,128-191} (the quadrant-1/2 fragments of both groups), S3 = the other A rows, S2a/S2b = B halves.
-        // Issue order ... S3(t+1) | S1(t+2) | S2a(t+2) | S2b(t+2) in phases 1..4 of K tile t, each into the region whose last
-        // ds_read retired one barrier earlier; S1/S2(t+1) are awaited in phase 4 (vmcnt(8): 4 younger units), S3(t) in
-        // phase 2 (vmcnt(10)) -- both one barrier before the first read, because the other group issues half of every unit.
+        // LDS / issues DMA.  DMA units (16 KiB = 2 loads per thread): S1 = A rows {0-63,128-191} (the first-phase fragments of
+        // both groups), S3 = the other A rows, S2a / S2b = B halves; each is re-staged into the region whose last ds_read
+        // retired one barrier earlier and awaited one barrier before its first read (the other group issues half of every unit).
         static_assert(BM == 256 && BN == 256 && BK == 64 && WM == 2 && WN == 4 && NS == 2, "ping-pong schedule is written for 256x256x64 / 8 waves");
         bf16x8_t fa[2][4], fb0[4], fb1[4];
         auto rd_a = [&](int buf, int i, int kk) { return lds_read128(lds0 + buf * cfg::STAGE + a_off[i] + ((((kk << 1) + hi) ^ a_sw[i]) << 4)); };
         auto rd_b = [&](int buf, int j, int kk) { return lds_read128(lds0 + buf * cfg::STAGE + cfg::A_BYTES + b_off[j] + ((((kk << 1) + hi) ^ b_sw[j]) << 4)); };
-        auto quad = [&](int i0, int j, const bf16x8_t* fb) {
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                acc[i0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[kk], fa[0][kk], acc[i0][j], 0, 0, 0);
-                acc[i0 + 1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[kk], fa[1][kk], acc[i0 + 1][j], 0, 0, 0);
-            }
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-        };
         // prologue: K tiles 0 and 1 (except S3(1)), in the steady-state order
         stage_sel(0, 0, 0x5, 0x0); stage_sel(0, 0, 0x0, 0x3); stage_sel(0, 0, 0x0, 0xc); stage_sel(0, 0, 0xa, 0x0);
         if (nkt > 1) {
             stage_sel(1, 1, 0x5, 0x0); stage_sel(1, 1, 0x0, 0x3);
-            if constexpr (PP == 1) { stage_sel(1, 1, 0x0, 0xc); wait_vmcnt<8>(); } else { wait_vmcnt<6>(); }
+            wait_vmcnt<6>();
         } else {
             wait_vmcnt<0>();
         }
         __builtin_amdgcn_s_barrier();
         if (wm == 1) __builtin_amdgcn_s_barrier();            // group 1 runs one barrier behind
-        if constexpr (PP == 1) {
-            for (int t = 0; t < nkt; ++t) {
-                const int buf = t & 1;
-                // phase 1: A rows 0-63 of the wave tile, B columns 0-31
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) fb0[kk] = rd_b(buf, 0, kk);
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) { fa[0][kk] = rd_a(buf, 0, kk); fa[1][kk] = rd_a(buf, 1, kk); }
-                if (t + 1 < nkt) stage_sel(t + 1, buf ^ 1, 0xa, 0x0);
-                wait_lgkmcnt<0>();
-                quad(0, 0, fb0);
-                // phase 2: B columns 32-63
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) fb1[kk] = rd_b(buf, 1, kk);
-                if (t + 2 < nkt) { stage_sel(t + 2, buf, 0x5, 0x0); wait_vmcnt<10>(); } else { wait_vmcnt<0>(); }
-                wait_lgkmcnt<0>();
-                quad(0, 1, fb1);
-                // phase 3: A rows 64-127
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) { fa[0][kk] = rd_a(buf, 2, kk); fa[1][kk] = rd_a(buf, 3, kk); }
-                if (t + 2 < nkt) stage_sel(t + 2, buf, 0x0, 0x3);
-                wait_lgkmcnt<0>();
-                quad(2, 1, fb1);
-                // phase 4: B columns 0-31 again (fragments still in registers)
-                if (t + 2 < nkt) { stage_sel(t + 2, buf, 0x0, 0xc); wait_vmcnt<8>(); } else { wait_vmcnt<0>(); }
-                quad(2, 0, fb0);
-            }
-        } else {
-            // PP == 2: two phases per K tile (16 MFMAs each): half the barriers.  Phase A reads A rows 0-63 + both B fragments
+        {
+            // two phases per K tile (16 MFMAs each).  Phase A reads A rows 0-63 + both B fragments
             // and computes quadrants 1-2; phase B reads A rows 64-127 and computes quadrants 3-4.  DMA: B(t) issues S1, S2a of
             // K tile t+2, A(t+1) issues S2b, S3 of t+2; waits vmcnt(6) in B (S1/S2 of t+1 landed) and vmcnt(8) in A (S3(t)).
             auto quad2 = [&](int i0, int j0, const bf16x8_t* fbx, const bf16x8_t* fby) {
@@ -577,15 +535,12 @@ extern "C" int whmr_gemm_bf16_big(const whmr_gemm* pp, int tile, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     switch (tile) {
         case 65: return launch_big_mode<128, 64, 64, 2, 1, 2, 2, 0>(p, st);       // 48 KiB, 2 waves: narrow-N convs (N <= 64), 3 blocks / CU
-        case 66: return launch_big_mode<128, 64, 32, 2, 1, 4, 2, 0>(p, st);       // 48 KiB, 2 waves, 4-stage ring of BK = 32: deep-K narrow-N convs
-        case 67: return launch_big_mode<128, 64, 64, 2, 1, 3, 2, 0>(p, st);       // 72 KiB, 2 waves, 3-stage ring of BK = 64
         case 64: return launch_big_mode<128, 128, 64, 2, 2, 2, 2, 0>(p, st);      // 64 KiB, 4 waves (64x64 wave tiles): 2 blocks / CU
         case 128: return launch_big_mode<128, 256, 32, 1, 4, 3, 2, 0>(p, st);     // 72 KiB: 2 blocks / CU
         case 256: return launch_big_mode<256, 256, 32, 2, 4, 4, 2, 0>(p, st);     // 128 KiB: 1 block / CU, 3 steps ahead
         case 192: return launch_big_mode<192, 256, 64, 2, 4, 2, 2, 0>(p, st);     // 112 KiB, 2 stages
         case 257: return launch_big_mode<256, 256, 64, 2, 4, 2, 2, 0>(p, st);     // 128 KiB, 2 stages
         case 320: return launch_big_mode<320, 256, 64, 2, 4, 2, 2, 0>(p, st);
-        case 258: return launch_big_mode<256, 256, 64, 2, 4, 2, 2, 1>(p, st);     // 128 KiB, 8-phase ping-pong main loop (two 4-wave groups)
         case 259: return launch_big_mode<256, 256, 64, 2, 4, 2, 2, 2>(p, st);     // same, 4 phases per K tile (half the barriers)     // 144 KiB, 2 stages, 160x64 wave tiles
     }
     return (int)hipErrorInvalidValue;
