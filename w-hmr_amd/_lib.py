@@ -116,10 +116,12 @@ _splitk_ws = {}
 
 
 def splitk_workspace(device):
-    """Per-device scratch for split-K partial sums (fp32 skinny GEMMs; bf16 GEMMs with too few tiles to fill 256 CUs)."""
-    w = _splitk_ws.get(device)
+    """Scratch for split-K partial sums (fp32 skinny GEMMs; bf16 GEMMs with too few tiles to fill 256 CUs): one buffer per
+    (device, stream) -- GEMMs of two streams may run concurrently (WHMR.forward overlaps the regressor loop with the deconvs)."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    w = _splitk_ws.get(key)
     if w is None:
-        w = _splitk_ws[device] = torch.empty(128 << 20, dtype=torch.uint8, device=device)
+        w = _splitk_ws[key] = torch.empty(128 << 20, dtype=torch.uint8, device=device)
     return w
 
 
