@@ -198,6 +198,11 @@ int whmr_attention_bwd(const void* qkv, const void* o, const float* dout, const 
  * (bf16 or fp32), weights w [5][7*7][64] fp32 -> tokens [B,5,OH*OW] fp32. */
 int whmr_tz_conv1(const void* x, int x_bf16, const float* w, float* tok, int B, int IH, int IW, void* stream);
 
+/* estimate_translation (utils/geometry.py:344-408; trainer host stall): S [B,J,3], joints_2d [B,J,3] = (x, y, conf);
+ * joints j0..j0+nj-1 enter the weighted least squares; out [B,3]. */
+int whmr_estimate_translation(const float* S, const float* joints_2d, int B, int J, int j0, int nj, float focal, float img_w,
+                              float img_h, float* out, void* stream);
+
 /* Tz-head tail (whmr.py:574-577): tokens [B,T,D] -> mean over T -> Linear(D,Hd) -> Linear(Hd,1) -> BatchNorm1d(1) eval
  * (bn4 = weight, bias, running_mean, running_var) -> sigmoid -> x10. */
 int whmr_tz_tail(const float* tok, int B, int T, int D, const float* w0, const float* b0, int Hd, const float* w1,

@@ -162,3 +162,32 @@ def batch_euler2matrix(r):
         cx * sy * cz + sx * cy * sz,
         cx * cy * sz - sx * sy * cz], dim=1)
     return quat_to_rotmat(q)
+
+
+def estimate_translation_np(S, joints_2d, joints_conf, focal_length=5000, img_size=(224., 224.)):
+    """utils/geometry.py:344-385: weighted least squares for the camera translation of one sample (numpy, float64)."""
+    import numpy as np
+    n = S.shape[0]
+    f = np.array([focal_length, focal_length])
+    center = np.array(img_size) / 2.
+    Z = np.reshape(np.tile(S[:, 2], (2, 1)).T, -1)
+    XY = np.reshape(S[:, 0:2], -1)
+    O = np.tile(center, n)
+    Fv = np.tile(f, n)
+    w2 = np.reshape(np.tile(np.sqrt(joints_conf), (2, 1)).T, -1)
+    Q = np.array([Fv * np.tile(np.array([1, 0]), n), Fv * np.tile(np.array([0, 1]), n), O - np.reshape(joints_2d, -1)]).T
+    c = (np.reshape(joints_2d, -1) - O) * Z - Fv * XY
+    Q = w2[:, None] * Q                                   # == np.dot(np.diagflat(w2), Q)
+    c = w2 * c
+    return np.linalg.solve(Q.T @ Q, Q.T @ c)
+
+
+def estimate_translation(S, joints_2d, focal_length=5000., img_size=(224., 224.)):
+    """utils/geometry.py:388-408: joints 25:49 only, per-sample solve, float32 result."""
+    import numpy as np
+    Sn = S[:, 25:, :].cpu().numpy()
+    j = joints_2d[:, 25:, :].cpu().numpy()
+    out = np.zeros((Sn.shape[0], 3), dtype=np.float32)
+    for i in range(Sn.shape[0]):
+        out[i] = estimate_translation_np(Sn[i], j[i, :, :-1], j[i, :, -1], focal_length=focal_length, img_size=list(img_size))
+    return torch.from_numpy(out).to(S.device)

@@ -414,7 +414,16 @@ def main():
     tr = torch.cat([torch.randn(4, 2, generator=gen), torch.rand(4, 1, generator=gen) * 5 + 2], 1)
     fl = torch.rand(4, generator=gen) * 1000 + 500
     cc = torch.rand(4, 2, generator=gen) * 500
-    geo = {'R': Rall, 'aa_in': aa_in, 'r6': r6, 'm33': m33, 'pts': pts, 'cam': cam, 'tr': tr, 'fl': fl, 'cc': cc}
+    # estimate_translation (trainer-only host stall): 3-D joints in front of the camera, 2-D joints = a noisy
+    # projection, confidences with zeros (undetected joints)
+    et_S = torch.randn(6, 49, 3, generator=gen) * 0.4
+    et_t = torch.cat([torch.randn(6, 2, generator=gen) * 0.3, torch.rand(6, 1, generator=gen) * 6 + 3], 1)
+    et_p = et_S + et_t[:, None]
+    et_xy = 5000. * et_p[..., :2] / et_p[..., 2:] + 112. + torch.randn(6, 49, 2, generator=gen)
+    et_conf = (torch.rand(6, 49, 1, generator=gen) > 0.3).float() * torch.rand(6, 49, 1, generator=gen)
+    et_j2d = torch.cat([et_xy, et_conf], -1)
+    geo = {'R': Rall, 'aa_in': aa_in, 'r6': r6, 'm33': m33, 'pts': pts, 'cam': cam, 'tr': tr, 'fl': fl, 'cc': cc, 'et_S': et_S,
+           'et_j2d': et_j2d}
     ref = {
         'aa': RG.rotation_matrix_to_angle_axis(Rall),
         'rod': RG.batch_rodrigues(aa_in),
@@ -424,6 +433,7 @@ def main():
         'persp': RG.perspective_projection(pts, torch.eye(3).unsqueeze(0).expand(4, -1, -1), tr, fl, cc),
         'full_cam': RG.convert_pare_to_full_img_cam(cam, fl, cc, torch.full((4,), 1280.), torch.full((4,), 720.), Tz=tr[:, 2]),
         'rot6d': RG.rotmat_to_rot6d(Rall),
+        'est_trans': RG.estimate_translation(et_S, et_j2d, focal_length=5000., img_size=[224., 224.]),
     }
     my = {
         'aa': OG.rotation_matrix_to_angle_axis(Rall), 'rod': OG.batch_rodrigues(aa_in), 'r6_to_R': OG.rot6d_to_rotmat(r6),
@@ -431,6 +441,7 @@ def main():
         'persp': OG.perspective_projection(pts, torch.eye(3).unsqueeze(0), tr, fl, cc),
         'full_cam': OG.convert_pare_to_full_img_cam(cam, fl, cc, torch.full((4,), 1280.), torch.full((4,), 720.), tr[:, 2]),
         'rot6d': OG.rotmat_to_rot6d(Rall),
+        'est_trans': OG.estimate_translation(et_S, et_j2d, 5000., (224., 224.)),
     }
     for k in ref:
         chk('geometry.' + k, my[k], ref[k], 1e-6)

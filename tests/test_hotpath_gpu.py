@@ -41,6 +41,8 @@ def test_geometry_matches_reference_fixture(dev, geo):
     w, h = torch.full((4,), 1280., device=dev), torch.full((4,), 720., device=dev)
     assert _rel(G.convert_pare_to_full_img_cam(d('cam'), d('fl'), d('cc'), w, h, Tz=d('tr')[:, 2]), geo['out_full_cam']) < 1e-6
     assert torch.equal(G.rotmat_to_rot6d(d('R')).cpu(), geo['out_rot6d'])
+    # trainer-side least squares: float64 normal equations on the device vs the reference's numpy loop
+    assert _rel(G.estimate_translation(d('et_S'), d('et_j2d'), focal_length=5000., img_size=[224., 224.]), geo['out_est_trans']) < 1e-5
 
 
 def test_maf_sampler_matches_reference_fixture(dev, geo, state_dict):

@@ -59,6 +59,14 @@ def test_oracle_geometry_matches_reference_fixture():
     assert _rel(OG.projection(g['in_pts'], g['in_cam']), g['out_proj']) < 1e-6
     assert _rel(OG.perspective_projection(g['in_pts'], torch.eye(3).unsqueeze(0), g['in_tr'], g['in_fl'], g['in_cc']),
                 g['out_persp']) < 1e-6
+    et = OG.estimate_translation(g['in_et_S'], g['in_et_j2d'], 5000., (224., 224.))
+    assert _rel(et, g['out_est_trans']) < 1e-6
+    # known answer: exact projections with unit confidence recover the translation that produced them
+    S = g['in_et_S'][:2].clone()
+    t = torch.tensor([[0.2, -0.1, 5.0], [-0.3, 0.4, 8.0]])
+    p = S + t[:, None]
+    j2d = torch.cat([5000. * p[..., :2] / p[..., 2:] + 112., torch.ones(2, 49, 1)], -1)
+    assert torch.allclose(OG.estimate_translation(S, j2d, 5000., (224., 224.)), t, atol=2e-3)
 
 
 def test_geometry_known_answers():

@@ -66,6 +66,7 @@ _SIGS = {
     'whmr_attention_fwd_train': [_P, _P, _P, _I, _I, _I, _I, _F, _P],
     'whmr_attention_bwd': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
     'whmr_tz_conv1': [_P, _I, _P, _P, _I, _I, _I, _P],
+    'whmr_estimate_translation': [_P, _P, _I, _I, _I, _I, _F, _F, _F, _P, _P],
     'whmr_transpose_cast': [_P, _I, _L, _P, _I, _L, _I, _I, _I, _P],
     'whmr_colsum': [_P, _I, _L, _I, _I, _P, _I, _P, _P],
     'whmr_layernorm_bwd': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P],
@@ -530,3 +531,13 @@ def tz_conv1(x_nhwc, w, tok):
     _check(lib().whmr_tz_conv1(x_nhwc.data_ptr(), int(x_nhwc.dtype == torch.bfloat16), w.data_ptr(), tok.data_ptr(), B, IH, IW, _stream()),
            'whmr_tz_conv1')
     return tok
+
+
+def estimate_translation(S, joints_2d, j0, nj, focal, img_w, img_h):
+    _dev(S, joints_2d)
+    S, joints_2d = _f32c(S), _f32c(joints_2d)
+    B, J = S.shape[:2]
+    out = torch.empty(B, 3, dtype=torch.float32, device=S.device)
+    _check(lib().whmr_estimate_translation(S.data_ptr(), joints_2d.data_ptr(), B, J, j0, nj, focal, img_w, img_h, out.data_ptr(), _stream()),
+           'whmr_estimate_translation')
+    return out

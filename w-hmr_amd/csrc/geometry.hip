@@ -97,3 +97,55 @@ extern "C" int whmr_weak_projection(const float* pts, const float* cam, float* o
     WHMR_CHECK_LAUNCH();
     return 0;
 }
+
+// estimate_translation (utils/geometry.py:344-408; called per batch at core/trainer.py:435 with a .cpu() round trip and a numpy
+// loop over the samples -- SURVEY 8f N3): weighted least squares for the camera translation that best re-projects the 3-D joints
+// S onto the 2-D joints, one thread per sample, float64 like numpy: rows (F w, 0, (Ox - x) w | ((x - Ox) Z - F X) w) and
+// (0, F w, (Oy - y) w | ((y - Oy) Z - F Y) w) with w = sqrtf(conf); A = Q^T Q, b = Q^T c, 3x3 solve with partial pivoting.
+__global__ __launch_bounds__(64) void estimate_translation_kernel(const float* __restrict__ S, const float* __restrict__ j2d, int B, int J, int j0,
+                                                                  int nj, double F, double Ox, double Oy, float* __restrict__ out) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    double A[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};           // augmented [A | b]
+    for (int j = j0; j < j0 + nj; ++j) {
+        const float* s = S + ((size_t)b * J + j) * 3;
+        const float* p = j2d + ((size_t)b * J + j) * 3;
+        const double w = (double)sqrtf(p[2]);
+        const double x = p[0], y = p[1], X = s[0], Y = s[1], Z = s[2];
+        const double q0 = F * w, q2x = (Ox - x) * w, q2y = (Oy - y) * w;
+        const double cx = ((x - Ox) * Z - F * X) * w, cy = ((y - Oy) * Z - F * Y) * w;
+        A[0][0] += q0 * q0; A[0][2] += q0 * q2x; A[0][3] += q0 * cx;
+        A[1][1] += q0 * q0; A[1][2] += q0 * q2y; A[1][3] += q0 * cy;
+        A[2][2] += q2x * q2x + q2y * q2y; A[2][3] += q2x * cx + q2y * cy;
+    }
+    A[2][0] = A[0][2]; A[2][1] = A[1][2];
+    // Gaussian elimination with partial pivoting (what LAPACK's dgesv behind np.linalg.solve does)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < 3; ++r)
+            if (fabs(A[r][c]) > fabs(A[piv][c])) piv = r;
+        if (piv != c)
+            for (int k = 0; k < 4; ++k) { const double t = A[c][k]; A[c][k] = A[piv][k]; A[piv][k] = t; }
+        for (int r = c + 1; r < 3; ++r) {
+            const double f = A[r][c] / A[c][c];
+            for (int k = c; k < 4; ++k) A[r][k] -= f * A[c][k];
+        }
+    }
+    double t[3];
+    for (int r = 2; r >= 0; --r) {
+        double v = A[r][3];
+        for (int k = r + 1; k < 3; ++k) v -= A[r][k] * t[k];
+        t[r] = v / A[r][r];
+    }
+    out[b * 3 + 0] = (float)t[0]; out[b * 3 + 1] = (float)t[1]; out[b * 3 + 2] = (float)t[2];
+}
+
+extern "C" int whmr_estimate_translation(const float* S, const float* joints_2d, int B, int J, int j0, int nj, float focal, float img_w,
+                                         float img_h, float* out, void* stream) {
+    if (B <= 0 || nj <= 0 || j0 < 0 || j0 + nj > J) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(estimate_translation_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, S, joints_2d, B, J, j0, nj,
+                       (double)focal, (double)img_w / 2.0, (double)img_h / 2.0, out);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}

@@ -57,3 +57,9 @@ def convert_pare_to_full_img_cam(pare_cam, bbox_height, bbox_center, img_w, img_
     cx = 2 * (bbox_center[:, 0] - (img_w / 2.)) / (s * bbox_height)
     cy = 2 * (bbox_center[:, 1] - (img_h / 2.)) / (s * bbox_height)
     return torch.stack([tx + cx, ty + cy, tz], dim=-1)
+
+
+def estimate_translation(S, joints_2d, focal_length=5000., img_size=(224., 224.)):
+    """utils/geometry.py:388-408: camera translation [B,3] that best re-projects S [B,49,3] onto joints_2d [B,49,3] (x, y, conf),
+    GT joints 25:49 only.  One HIP launch on the device instead of .cpu() + a numpy loop over the batch (core/trainer.py:435)."""
+    return L.estimate_translation(S, joints_2d, 25, S.shape[1] - 25, float(focal_length), float(img_size[0]), float(img_size[1]))
