@@ -309,18 +309,18 @@ __global__ __launch_bounds__(NKT * 64, 4) void attention_bf16_chunk_kernel(const
 __device__ __forceinline__ uint32_t swz_addr(int row, int col) {      // byte offset of element (row, col) in a [rows][64] bf16 tile
     return row * 128 + ((((col >> 3) ^ ((row >> 1) & 7))) << 4) + (col & 7) * 2;
 }
-__device__ __forceinline__ uint2 lds_tr_read64(uint32_t addr) {
-    uint2 v;
-    asm volatile("ds_read_b64_tr_b16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
-    return v;
+// both halves of a fragment are issued before the one wait
+__device__ __forceinline__ void lds_tr_read64x2(uint32_t addr_a, uint32_t addr_b, uint2& a, uint2& b) {
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(a), "=&v"(b) : "v"(addr_a), "v"(addr_b) : "memory");
 }
 // A operand "X^T": lane -> m = c0 + (lane & 31) (a column of X), k-slots hi*8 + e <-> X rows R0 + 4*hi + (e & 3) + 8*(e >> 2)
 __device__ __forceinline__ bf16x8_t tr_frag(uint32_t lds_base, int R0, int c0, int lane) {
     const int g = lane >> 4, i = lane & 15;
     const int col = c0 + 16 * (g & 1) + 4 * (i & 3);
     const int row = R0 + 4 * (g >> 1) + (i >> 2);
-    const uint2 a = lds_tr_read64(lds_base + swz_addr(row, col));
-    const uint2 b = lds_tr_read64(lds_base + swz_addr(row + 8, col));
+    uint2 a, b;
+    lds_tr_read64x2(lds_base + swz_addr(row, col), lds_base + swz_addr(row + 8, col), a, b);
     union { bf16x8_t v; uint32_t u[4]; } f;
     f.u[0] = a.x; f.u[1] = a.y; f.u[2] = b.x; f.u[3] = b.y;
     return f.v;

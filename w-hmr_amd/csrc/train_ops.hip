@@ -110,12 +110,41 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
     }
 }
 
+// bf16, C % 8 == 0: thread = 8 consecutive columns (16-B loads), block = 256 columns x 8 row lanes
+__global__ __launch_bounds__(256) void colsum_partial8_kernel(const bf16_t* __restrict__ x, long ld, int R, int C, float* __restrict__ partial) {
+    __shared__ float red[8][256 + 8];
+    const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 256 + cg * 8;
+    const int rows_per = (R + CS_CHUNKS - 1) / CS_CHUNKS;
+    const int r_begin = blockIdx.y * rows_per, r_end = min(R, r_begin + rows_per);
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (c < C)
+        for (int r = r_begin + rl; r < r_end; r += 8) {
+            const uint4 v = *(const uint4*)(x + (size_t)r * ld + c);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a[2 * e] += __uint_as_float(w[e] << 16); a[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u); }
+        }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[rl][cg * 8 + e] = a[e];
+    __syncthreads();
+    const int cc = blockIdx.x * 256 + threadIdx.x;
+    if (cc < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) t += red[r][threadIdx.x];
+        partial[(size_t)blockIdx.y * C + cc] = t;
+    }
+}
+
 // scratch: >= CS_CHUNKS * C floats
 extern "C" int whmr_colsum(const void* x, int is_bf16, long ld, int R, int C, float* out, int accumulate, float* scratch, void* stream) {
     if (R <= 0 || C <= 0) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((C + 63) / 64, CS_CHUNKS);
-    if (is_bf16) hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, ld, R, C, scratch);
+    if (is_bf16 && !(C & 7) && !(ld & 7) && !((uintptr_t)x & 15))
+        hipLaunchKernelGGL(colsum_partial8_kernel, dim3((C + 255) / 256, CS_CHUNKS), dim3(256), 0, st, (const bf16_t*)x, ld, R, C, scratch);
+    else if (is_bf16) hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, ld, R, C, scratch);
     else hipLaunchKernelGGL(colsum_partial_kernel<float>, grid, dim3(256), 0, st, (const float*)x, ld, R, C, scratch);
     hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64), dim3(256), 0, st, scratch, CS_CHUNKS, C, out, accumulate);
     WHMR_CHECK_LAUNCH();
