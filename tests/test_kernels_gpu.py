@@ -337,3 +337,21 @@ def test_crop_normalize_matches_oracle(dev):
     one, one_raw, _ = get_single_image_crop_demo(torch.from_numpy(frame).to(dev), boxes[0], None, scale=1.2, crop_size=224)
     ref, ref_raw, _ = OC.get_single_image_crop_demo(frame, boxes[0], None, scale=1.2, crop_size=224)
     assert np.array_equal(one.cpu().numpy(), ref) and np.array_equal(one_raw.cpu().numpy(), ref_raw)
+
+
+def test_conv_gather_chunk_major_k_order(dev):
+    """epi_flags bit 3: weight columns ordered (ci chunk of 64, ky, kx, ci in chunk); same conv result as the (ky, kx, ci) order."""
+    from whmr_amd import _lib as L
+    g = torch.Generator().manual_seed(31)
+    B, Cin, IH, IW, Cout, KH, KW, S = 2, 128, 23, 20, 64, 7, 7, 3
+    x = torch.randn(B, Cin, IH, IW, generator=g).bfloat16()
+    w = (torch.randn(Cout, Cin, KH, KW, generator=g) / math.sqrt(Cin * KH * KW)).bfloat16()
+    ref = F.conv2d(x.float(), w.float(), stride=S).permute(0, 2, 3, 1)
+    OH, OW = ref.shape[1:3]
+    xn = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    wk = w.permute(0, 2, 3, 1)                                                            # [Cout, ky, kx, ci]
+    w_cm = wk.reshape(Cout, KH * KW, Cin // 64, 64).permute(0, 2, 1, 3).reshape(Cout, -1).contiguous().to(dev)
+    out = torch.empty(B, OH, OW, Cout, device=dev)
+    for tile in (None, 65, 64):
+        L.gemm(xn, w_cm, out.view(-1, Cout), conv=dict(IH=IH, IW=IW, Cin=Cin, OH=OH, OW=OW, KW=KW, SH=S, SW=S, PH=0, PW=0, chunk_major=True), tile=tile)
+        assert _rel(out.cpu(), ref) < 2e-5

@@ -44,8 +44,10 @@ if len(sys.argv) > 2 and sys.argv[2] == 'tz':        # Tz head conv0 of W-HMR (w
         w = (torch.randn(64, 49 * 256, device=dev) / 112.).bfloat16()
         out = torch.empty(bs, 41, 31, 64, device=dev, dtype=torch.bfloat16)
         conv = dict(IH=128, IW=96, Cin=256, OH=41, OW=31, KW=7, SH=3, SW=3, PH=0, PW=0)
-        for tile in (None, 65, 64):
-            print('tz conv0 B=%d tile %s: %.1f us' % (bs, tile, bench(lambda: L.gemm(x, w, out.view(-1, 64), conv=conv, tile=tile))), flush=True)
+        for cm in (False, True):
+            conv['chunk_major'] = cm
+            for tile in (None, 65, 64):
+                print('tz conv0 B=%d chunk_major=%d tile %s: %.1f us' % (bs, cm, tile, bench(lambda: L.gemm(x, w, out.view(-1, 64), conv=conv, tile=tile))), flush=True)
     sys.exit(0)
 for name, kind, lin, lout, Cin, N, skip in shapes:
     IH, IW = dims[lin]; OH, OW = dims[lout]; s = 1 if lin == lout else 2

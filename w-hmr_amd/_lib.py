@@ -171,6 +171,9 @@ def gemm(a, w, out, bias=None, residual=None, res_row_mod=0, act=ACT_NONE, conv=
         B = a.shape[0]
         p.M = B * conv['OH'] * conv['OW'] if M is None else M
         assert K % conv['Cin'] == 0
+        if conv.get('chunk_major'):          # weight columns ordered (ci chunk of 64, ky, kx, ci in chunk)
+            assert a.dtype == torch.bfloat16
+            p.epi_flags |= 8
         p.zeros = zero_page(a.device).data_ptr()
     else:
         p.M = (a.numel() // a.shape[-1]) if M is None else M

@@ -74,7 +74,7 @@ extern "C" int whmr_gemm_bf16_split(const whmr_gemm* pp, int tile, int splits_in
     const long kps = ((p.K / 64 + splits - 1) / splits) * 64;
     splits = (p.K + kps - 1) / kps;
     whmr_gemm q = p;
-    q.C = p.workspace; q.out_bf16 = 0; q.act = 0; q.bias = nullptr; q.residual = nullptr; q.epi_flags = 0; q.ldc = p.N;
+    q.C = p.workspace; q.out_bf16 = 0; q.act = 0; q.bias = nullptr; q.residual = nullptr; q.epi_flags = p.epi_flags & 8; q.ldc = p.N;    // bit 3 (K order of the gather) belongs to the main loop
     q.split_k = kps;
     const int rc = whmr_gemm_bf16_big(&q, tile, stream);
     if (rc) return rc;

@@ -114,8 +114,15 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
         const int k0 = k_first + kt * BK;
         int ky = 0, kx = 0, ci0 = 0;
         if constexpr (GATHER) {
-            const int tap = k0 / p.Cin;
-            ci0 = k0 - tap * p.Cin;
+            int tap;
+            if (p.epi_flags & 8) {               // chunk-major K order (ci chunk of 64, ky, kx, ci in chunk): see gemm_params.h
+                const int ntaps = p.K / p.Cin, blk = k0 >> 6, chunk = blk / ntaps;
+                tap = blk - chunk * ntaps;
+                ci0 = (chunk << 6) + (k0 & 63);
+            } else {
+                tap = k0 / p.Cin;
+                ci0 = k0 - tap * p.Cin;
+            }
             ky = tap / p.KW;
             kx = tap - ky * p.KW;
         }

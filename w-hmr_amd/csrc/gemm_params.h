@@ -24,7 +24,10 @@ struct whmr_gemm {
     // Sub-pixel phases of ConvTranspose2d(k4, s2, p1) in ONE launch (bf16 kernel, a_mode = c_mode = 1): n_phase = 4,
     // phase = blockIdx.y = 2*py + px:  W += phase*phase_w_stride;  PH -= py;  PW -= px;  c_off += py*phase_cy + px*phase_cx.
     int32_t n_phase;
-    int32_t epi_flags;      /* bit 0: residual is bf16 (else fp32); bit 1: residual is added BEFORE the activation (ResNet blocks) */
+    int32_t epi_flags;      /* bit 0: residual is bf16 (else fp32); bit 1: residual is added BEFORE the activation (ResNet blocks);
+                             * bit 3 (bf16 gather): K is ordered (ci chunk of 64, ky, kx, ci in chunk) instead of (ky, kx, ci): all taps of one
+                             * 64-channel slice are walked before the next slice, so the window overlap of a large-kernel conv on a map that
+                             * exceeds the Infinity Cache is re-read from cache instead of HBM (Tz-head 7x7 s3 conv) */
     int64_t phase_w_stride, phase_cy, phase_cx;
     int64_t split_k;        /* internal (set by the bf16 launcher, pass 0): K elements per split-K slice, blockIdx.z = slice */
 };

@@ -351,8 +351,12 @@ class WHMR(nn.Module):
         c0, c1 = self.conv[0].weight, self.conv[1].weight
 
         def build():
-            w0 = c0.detach().permute(0, 2, 3, 1).reshape(c0.shape[0], -1).contiguous()     # [64, (ky,kx,ci)]
-            w0 = w0 if self._dt == torch.float32 else L.cast_bf16(w0)
+            w0 = c0.detach().permute(0, 2, 3, 1)                                             # [64, ky, kx, ci]
+            if self._dt == torch.float32:
+                w0 = w0.reshape(c0.shape[0], -1).contiguous()                              # [64, (ky,kx,ci)]
+            else:   # chunk-major K order (epi_flags bit 3): (ci chunk of 64, ky, kx, ci in chunk) -- window overlap re-read from cache
+                n, kh, kw, ci = w0.shape
+                w0 = L.cast_bf16(w0.reshape(n, kh * kw, ci // 64, 64).permute(0, 2, 1, 3).reshape(n, -1).contiguous())
             w1 = c1.detach().float().permute(0, 2, 3, 1).reshape(c1.shape[0], 49, 64).contiguous()        # [5, (ky,kx), ci] fp32
             bn = self.est_Tz[2]
             bn4 = torch.stack([bn.weight.detach()[0], bn.bias.detach()[0], bn.running_mean[0], bn.running_var[0]]).float().contiguous()
@@ -387,7 +391,8 @@ class WHMR(nn.Module):
         assert (C, self.conv[1].weight.shape[0], self.conv[0].weight.shape[0]) == (256, 5, 64)
         H1, W1 = (H - 7) // 3 + 1, (W - 7) // 3 + 1
         y0 = torch.empty(B, H1, W1, 64, dtype=self._dt, device=dev)                  # NHWC, mode dtype (feeds the 2nd conv)
-        L.gemm(f_nhwc, w0, y0.view(-1, 64), conv=dict(IH=H, IW=W, Cin=C, OH=H1, OW=W1, KW=7, SH=3, SW=3, PH=0, PW=0))
+        L.gemm(f_nhwc, w0, y0.view(-1, 64), conv=dict(IH=H, IW=W, Cin=C, OH=H1, OW=W1, KW=7, SH=3, SW=3, PH=0, PW=0,
+                                                      chunk_major=self._dt != torch.float32))
         H2, W2 = (H1 - 7) // 2 + 1, (W1 - 7) // 2 + 1
         D = H2 * W2
         t = torch.empty(B * 5, D, dtype=torch.float32, device=dev)                  # == conv1(...).reshape(B, 5, -1), whmr.py:571
