@@ -248,3 +248,30 @@ def test_whmr_eval_view_with_h36m_regressor_and_sliced_input(dev, assets, state_
         for k in ('global_pose', 'global_shape', 'global_rotmat', 'global_kp_3d', 'global_verts'):
             assert _rel(out['global_output'][k], ref['global_output'][k]) < 1e-4, (B, k)
         assert out['global_output']['global_kp_3d'].shape == (B, 14, 3)
+
+
+def test_demo_frame_pipeline(dev, assets, state_dict):
+    """whmr_amd.demo: the per-frame input preparation of demo/tester.py:106-146 (restated inline with the CPU crop oracle) + forward."""
+    from oracle import crop as OC
+    from whmr_amd.demo import prepare_frame, infer_frame
+    from whmr_amd.models import whmr_net
+    rng = np.random.default_rng(3)
+    frame = rng.integers(0, 256, size=(360, 640, 3), dtype=np.uint8)
+    dets = [(320.0, 180.0, 220.0, 220.0), (100.5, 90.0, 150.0, 150.0), (600.0, 300.0, 180.0, 180.0)]
+    kw = prepare_frame(torch.from_numpy(frame).to(dev), dets)
+    # tester.py:106-146 on the CPU
+    H, W = frame.shape[:2]
+    inp = np.stack([OC.get_single_image_crop_demo(frame, b, None, scale=1.0, crop_size=256)[0] for b in dets])
+    assert np.array_equal(kw['x'].cpu().numpy(), inp[:, :, :, 32:-32])
+    scale = np.array([b[2] / 200. for b in dets], dtype=np.float32)
+    focal = np.sqrt(np.float64(H) ** 2 + np.float64(W) ** 2).astype(np.float32)
+    info = (np.array([[b[0] - W / 2., b[1] - H / 2., 200 * s, W, H] for b, s in zip(dets, scale)]) / focal).astype(np.float32)
+    assert np.allclose(kw['bbox_info'].cpu().numpy(), info, rtol=1e-6, atol=1e-7)
+    assert np.allclose(kw['scale'].cpu().numpy(), scale) and np.allclose(kw['bbox_height'].cpu().numpy(), 200 * scale)
+    assert kw['orig_shape'].cpu().tolist() == [[H, W]] * 3 and kw['center'].cpu().tolist() == [[b[0], b[1]] for b in dets]
+    assert kw['full_x'].shape == (1, 3, 600, 1066)                                       # Resize(600): short side 600, aspect kept
+    m = whmr_net(None, assets=assets, numerics='bf16')
+    m.load_state_dict(state_dict, strict=False)
+    out = infer_frame(m.to(dev).eval(), torch.from_numpy(frame).to(dev), dets)
+    assert out['smpl_vertices'].shape == (3, 6890, 3) and out['cam_rotmat'].shape == (3, 3, 3)
+    assert all(torch.isfinite(v).all() for v in out.values())
