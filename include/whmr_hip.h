@@ -144,6 +144,7 @@ struct whmr_maf_weights {
     const float* w0t; const float* b0;   /* conv0 transposed [256][128], bias [128] */
     const float* w1t; const float* b1;   /* conv1 transposed [384][64]  (inputs: y0 | raw feature) */
     const float* w2t; const float* b2;   /* conv2 transposed [320][32]  (inputs: y1 | raw feature) */
+    const void *w0b, *w1b, *w2b;         /* optional bf16 copies in Conv1d layout [out][in]: with a bf16 channels-last map the MLP runs on MFMA */
 };
 /* (weak-perspective projection of pts3d with cam ->) bilinear grid_sample(align_corners=True, zero padding) of 256
  * channels at P points -> 3-layer point MLP -> out[b*out_stride + c*P + p].  fmap is addressed by element strides

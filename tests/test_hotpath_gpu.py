@@ -275,3 +275,25 @@ def test_demo_frame_pipeline(dev, assets, state_dict):
     out = infer_frame(m.to(dev).eval(), torch.from_numpy(frame).to(dev), dets)
     assert out['smpl_vertices'].shape == (3, 6890, 3) and out['cam_rotmat'].shape == (3, 3, 3)
     assert all(torch.isfinite(v).all() for v in out.values())
+
+
+def test_maf_sampler_mfma_variant(dev, state_dict):
+    """bf16 channels-last map: the MFMA point-MLP variant against the fp32 VALU kernel on the same map (points incl. out-of-range)."""
+    from whmr_amd.models.maf_extractor import MAF_Extractor
+    ext = MAF_Extractor()
+    ext.load_state_dict({k[len('maf_extractor.1.'):]: v for k, v in state_dict.items() if k.startswith('maf_extractor.1.')}, strict=False)
+    ext = ext.to(dev)
+    g = torch.Generator().manual_seed(2)
+    B, H, W, P = 5, 64, 48, 67
+    fmap = torch.randn(B, H, W, 256, generator=g).bfloat16().to(dev).permute(0, 3, 1, 2)          # logical NCHW, channels-last memory
+    pts = (torch.rand(B, P, 2, generator=g) * 2.4 - 1.2).to(dev)
+    ref, _ = ext.sampling(pts, im_feat=fmap, want_point_feat=True)                                  # VALU kernel (point_feat requested)
+    out = torch.zeros(B, 32 * P + 7, device=dev)                                                    # wider rows: out_stride != 32 P
+    ext.sampling(pts, im_feat=fmap, out=out, want_point_feat=False)                                 # MFMA kernel
+    assert not out[:, 32 * P:].any()
+    assert _rel(out[:, :32 * P], ref) < 2e-2
+    p3 = torch.randn(B, P, 3, generator=g).to(dev) * 0.3
+    cam = torch.cat([torch.rand(B, 1, generator=g) + 0.6, torch.randn(B, 2, generator=g) * 0.1], 1).to(dev)
+    ref3, _ = ext(p3, s_feat=fmap, cam=cam, want_point_feat=True)
+    got3, _ = ext(p3, s_feat=fmap, cam=cam, want_point_feat=False)
+    assert _rel(got3, ref3) < 2e-2

@@ -38,7 +38,7 @@ class WhmrSmplModel(C.Structure):
 
 class WhmrMafWeights(C.Structure):
     _fields_ = [('w0t', C.c_void_p), ('b0', C.c_void_p), ('w1t', C.c_void_p), ('b1', C.c_void_p),
-                ('w2t', C.c_void_p), ('b2', C.c_void_p)]
+                ('w2t', C.c_void_p), ('b2', C.c_void_p), ('w0b', C.c_void_p), ('w1b', C.c_void_p), ('w2b', C.c_void_p)]
 
 
 _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_long

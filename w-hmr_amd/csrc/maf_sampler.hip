@@ -18,6 +18,8 @@ struct whmr_maf_weights {
     const float* w0t; const float* b0;   // [256][128], [128]
     const float* w1t; const float* b1;   // [384][64],  [64]     input order: [y0 (128) | f (256)]
     const float* w2t; const float* b2;   // [320][32],  [32]     input order: [y1 (64)  | f (256)]
+    // optional bf16 copies in nn.Conv1d layout [out][in] for the MFMA variant (bf16 feature maps); null = VALU kernel only
+    const bf16_t* w0b; const bf16_t* w1b; const bf16_t* w2b;
 };
 
 template <typename TF>
@@ -151,6 +153,128 @@ __global__ __launch_bounds__(128) void maf_sample_kernel(const TF* __restrict__ 
     }
 }
 
+// ---- MFMA variant for bf16 NHWC feature maps (the perf numerics mode): 32 points per workgroup (points of consecutive images
+// are packed: global point g = b * P + p), gather -> F[32][256] bf16 in LDS, then the three layers on v_mfma_f32_32x32x16_bf16
+// with the operands swapped (rows = output channels, columns = points) so that every lane owns one point: the activations go
+// back to LDS as 8-B row pieces and the final channel-major store is coalesced over points.  fp32 accumulation, bf16 weights.
+__device__ __forceinline__ uint32_t maf_f_addr(int row, int chunk, int nchunk_mask) { return row * ((nchunk_mask + 1) * 16) + ((chunk ^ (row & nchunk_mask)) << 4); }
+
+__global__ __launch_bounds__(256) void maf_sample_mfma_kernel(const bf16_t* __restrict__ fmap, long sb, long sy, long sx, int H, int W,
+                                                              const float* __restrict__ pts2d, const float* __restrict__ pts3d,
+                                                              const float* __restrict__ cam, long cam_ld, float focal, float res_w, float res_h,
+                                                              const whmr_maf_weights wts, int B, int P, float* __restrict__ out, long out_stride) {
+    __shared__ __attribute__((aligned(16))) char sFb[32 * 512];       // F  [32 points][256 ch] bf16, 16-B chunks XOR-swizzled by the row
+    __shared__ __attribute__((aligned(16))) char sY0b[32 * 256];      // Y0 [32][128]
+    __shared__ __attribute__((aligned(16))) char sY1b[32 * 128];      // Y1 [32][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const long g0 = (long)blockIdx.x * 32, total = (long)B * P;
+    // ---- gather: 8 threads per point, 32 channels (4 x 16 B) each
+    {
+        const int r = tid >> 3, part = tid & 7;
+        const long g = g0 + r;
+        float acc[32];
+#pragma unroll
+        for (int e = 0; e < 32; ++e) acc[e] = 0.f;
+        if (g < total) {
+            const int b = (int)(g / P), p = (int)(g - (long)b * P);
+            float x, y;
+            if (pts3d) {
+                const float s = cam[cam_ld * b], tx = cam[cam_ld * b + 1], ty = cam[cam_ld * b + 2];
+                const float tz = 2 * focal / (res_h * s + 1e-9f);
+                const float* q = pts3d + ((size_t)b * P + p) * 3;
+                const float z = q[2] + tz;
+                x = (focal * ((q[0] + tx) / z)) / (res_w / 2.f);
+                y = (focal * ((q[1] + ty) / z)) / (res_h / 2.f);
+            } else {
+                x = pts2d[((size_t)b * P + p) * 2];
+                y = pts2d[((size_t)b * P + p) * 2 + 1];
+            }
+            const float ix = ((x + 1.f) / 2.f) * (float)(W - 1), iy = ((y + 1.f) / 2.f) * (float)(H - 1);
+            const float fx0 = floorf(ix), fy0 = floorf(iy);
+            const int x0 = (int)fx0, y0 = (int)fy0;
+            const float wx1 = ix - fx0, wx0 = (fx0 + 1.f) - ix, wy1 = iy - fy0, wy0 = (fy0 + 1.f) - iy;
+            const bf16_t* fb = fmap + (size_t)b * sb + part * 32;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int xx = x0 + (t & 1), yy = y0 + (t >> 1);
+                const float wgt = ((t & 1) ? wx1 : wx0) * ((t >> 1) ? wy1 : wy0);
+                if ((unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H) {
+                    const uint4* src = (const uint4*)(fb + (size_t)yy * sy + (size_t)xx * sx);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const uint4 v = src[c];
+                        const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            acc[c * 8 + 2 * e] = fmaf(__uint_as_float(w4[e] << 16), wgt, acc[c * 8 + 2 * e]);
+                            acc[c * 8 + 2 * e + 1] = fmaf(__uint_as_float(w4[e] & 0xffff0000u), wgt, acc[c * 8 + 2 * e + 1]);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            *(uint4*)(sFb + maf_f_addr(r, part * 4 + c, 31)) = make_uint4(pack_bf16x2(acc[c * 8], acc[c * 8 + 1]), pack_bf16x2(acc[c * 8 + 2], acc[c * 8 + 3]),
+                                                                           pack_bf16x2(acc[c * 8 + 4], acc[c * 8 + 5]), pack_bf16x2(acc[c * 8 + 6], acc[c * 8 + 7]));
+    }
+    __syncthreads();
+    auto f_frag = [&](const char* base, int kk, int mask) { return *(const bf16x8_t*)(base + maf_f_addr(l31, kk * 2 + hi, mask)); };
+    auto w_frag = [&](const bf16_t* w, int ld, int n0, int kk) { return *(const bf16x8_t*)(w + (size_t)(n0 + l31) * ld + kk * 16 + hi * 8); };
+    // rows (regs) = output channel n0 + (r&3) + 8(r>>2) + 4hi, column (lane) = point l31
+    auto store_act = [&](char* dst, int mask, int n0, const f32x16_t& a, const float* bias) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t = a[4 * q + e] + bias[n0 + 8 * q + 4 * hi + e];
+                v[e] = t > 0.f ? t : 0.01f * t;                                  // LeakyReLU(0.01)
+            }
+            const int col = n0 + 8 * q + 4 * hi;                                 // 4 consecutive channels = 8 B inside one 16-B chunk
+            *(uint2*)(dst + maf_f_addr(l31, col >> 3, mask) + (col & 7) * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+        }
+    };
+    {   // layer 0: 256 -> 128; wave = one 32-channel tile
+        f32x16_t a;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[r] = 0.f;
+#pragma unroll 4
+        for (int kk = 0; kk < 16; ++kk) a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_frag(wts.w0b, 256, wave * 32, kk), f_frag(sFb, kk, 31), a, 0, 0, 0);
+        store_act(sY0b, 15, wave * 32, a, wts.b0);
+    }
+    __syncthreads();
+    if (wave < 2) {   // layer 1: [Y0 (128) | F (256)] -> 64
+        f32x16_t a;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[r] = 0.f;
+#pragma unroll 4
+        for (int kk = 0; kk < 8; ++kk) a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_frag(wts.w1b, 384, wave * 32, kk), f_frag(sY0b, kk, 15), a, 0, 0, 0);
+#pragma unroll 4
+        for (int kk = 0; kk < 16; ++kk) a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_frag(wts.w1b, 384, wave * 32, 8 + kk), f_frag(sFb, kk, 31), a, 0, 0, 0);
+        store_act(sY1b, 7, wave * 32, a, wts.b1);
+    }
+    __syncthreads();
+    if (wave == 0) {  // layer 2: [Y1 (64) | F (256)] -> 32, ReLU, channel-major store out[b][o * P + p]
+        f32x16_t a;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_frag(wts.w2b, 320, 0, kk), f_frag(sY1b, kk, 7), a, 0, 0, 0);
+#pragma unroll 4
+        for (int kk = 0; kk < 16; ++kk) a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_frag(wts.w2b, 320, 0, 4 + kk), f_frag(sFb, kk, 31), a, 0, 0, 0);
+        const long g = g0 + l31;
+        if (g < total) {
+            const int b = (int)(g / P), p = (int)(g - (long)b * P);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                out[(size_t)b * out_stride + (size_t)o * P + p] = fmaxf(a[r] + wts.b2[o], 0.f);
+            }
+        }
+    }
+}
+
 // fmap_bf16: element type of the feature map.  pts2d XOR (pts3d, cam) selects the sampling points; with neither, fmap is
 // an already-sampled [B,256,P] feature tensor (strides sb, sc, sx) and only the MLP runs (MAF_Extractor.reduce_dim).
 // out row b starts at out + b*out_stride (>= 32*P), so the result can land inside the regressor's input buffer;
@@ -162,6 +286,13 @@ extern "C" int whmr_maf_sample(const void* fmap, int fmap_bf16, long sb, long sc
     if (B <= 0 || P <= 0 || (pts2d && pts3d) || (pts3d && !cam) || out_stride < 32L * P) return (int)hipErrorInvalidValue;
     dim3 grid((P + PT - 1) / PT, B), block(128);
     hipStream_t st = (hipStream_t)stream;
+    if (fmap_bf16 && sc == 1 && w->w0b && w->w1b && w->w2b && (pts2d || pts3d) && !point_feat && !((sb | sy | sx) & 7) && !((uintptr_t)fmap & 15)) {
+        const long tiles = ((long)B * P + 31) / 32;
+        hipLaunchKernelGGL(maf_sample_mfma_kernel, dim3((unsigned)tiles), dim3(256), 0, st, (const bf16_t*)fmap, sb, sy, sx, H, W, pts2d, pts3d, cam,
+                           cam_ld, focal, res_w, res_h, *w, B, P, out, out_stride);
+        WHMR_CHECK_LAUNCH();
+        return 0;
+    }
     if (fmap_bf16) hipLaunchKernelGGL(maf_sample_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)fmap, sb, sc, sy, sx, H, W,
                                       pts2d, pts3d, cam, cam_ld, focal, res_w, res_h, *w, P, out, out_stride, point_feat);
     else hipLaunchKernelGGL(maf_sample_kernel<float>, grid, block, 0, st, (const float*)fmap, sb, sc, sy, sx, H, W, pts2d,

@@ -36,6 +36,9 @@ class MAF_Extractor(nn.Module):
                     ps[4].detach()[:, :, 0].t().contiguous(), ps[5].detach().contiguous()]
             w = L.WhmrMafWeights()
             w.w0t, w.b0, w.w1t, w.b1, w.w2t, w.b2 = [t.data_ptr() for t in keep]
+            if ps[0].is_cuda:                      # bf16 [out][in] copies: the MFMA variant of the sampler (bf16 feature maps)
+                keep += [L.cast_bf16(ps[i].detach()[:, :, 0].float().contiguous()) for i in (0, 2, 4)]
+                w.w0b, w.w1b, w.w2b = [t.data_ptr() for t in keep[6:]]
             self._wcache = (ver, w, keep)
         return self._wcache[1]
 
