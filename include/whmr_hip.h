@@ -102,9 +102,9 @@ int whmr_weak_projection(const float* pts, const float* cam, float* out, int B, 
 /* ---- SMPL forward: pare.models.SMPL / smplx lbs as called at whmr.py:132-137,227-232,641-644 ---------------------- */
 struct whmr_smpl_model {
     const float* v_template;         /* [6890,3] */
-    const float* shapedirs;          /* [6890,3,10] */
+    const float* shapedirs;          /* [30,6890]: shapedirs[v][c][l] stored as [(c*10+l)][v] (transposed once by the host) */
     const float* posedirs;           /* [207,20670] (smplx layout) */
-    const float* lbs_weights;        /* [6890,24] */
+    const float* lbs_weights;        /* [24,6890]: transposed once by the host */
     const float* J_template;         /* [24,3]    = J_regressor . v_template  (folded once on the host) */
     const float* J_shapedirs;        /* [24,3,10] = J_regressor . shapedirs */
     const float* J_regressor;        /* [24,6890] (for smpl_joints45; may be null) */

@@ -20,9 +20,9 @@
 
 struct whmr_smpl_model {
     const float* v_template;     // [6890,3]
-    const float* shapedirs;      // [6890,3,10]
+    const float* shapedirs;      // [30,6890]   = shapedirs[v][c][l] transposed to [(c*10+l)][v] by the host: coalesced over vertices
     const float* posedirs;       // [207, 20670]  (smplx layout)
-    const float* lbs_weights;    // [6890,24]
+    const float* lbs_weights;    // [24,6890]   = lbs_weights transposed by the host
     const float* J_template;     // [24,3]      = J_regressor . v_template
     const float* J_shapedirs;    // [24,3,10]   = J_regressor . shapedirs
     const float* J_regressor;    // [24,6890]   (whmr.py:186 smpl_joints; may be null if never requested)
@@ -117,9 +117,8 @@ __global__ __launch_bounds__(128) void smpl_skin_kernel(const whmr_smpl_model m,
     {   // v_shaped = T + S . beta   (verts.py:46-48)
         const float t0 = m.v_template[3 * v], t1 = m.v_template[3 * v + 1], t2 = m.v_template[3 * v + 2];
         float s[30];
-        const float* sd = m.shapedirs + (size_t)v * 30;
 #pragma unroll
-        for (int k = 0; k < 30; ++k) s[k] = sd[k];
+        for (int k = 0; k < 30; ++k) s[k] = m.shapedirs[(size_t)k * NV + v];
 #pragma unroll
         for (int bb = 0; bb < BT; ++bb) {
             float a0 = 0.f, a1 = 0.f, a2 = 0.f;
@@ -158,9 +157,8 @@ __global__ __launch_bounds__(128) void smpl_skin_kernel(const whmr_smpl_model m,
     }
     // skinning: T = sum_j w_j A_j ; v = T [v_posed; 1]   (lbs.py:67-77)
     float w[NJ];
-    const float* wr = m.lbs_weights + (size_t)v * NJ;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) w[j] = wr[j];
+    for (int j = 0; j < NJ; ++j) w[j] = m.lbs_weights[(size_t)j * NV + v];
 #pragma unroll
     for (int bb = 0; bb < BT; ++bb) {
         if (b0 + bb >= B) break;
@@ -254,6 +252,15 @@ extern "C" int whmr_smpl_pose_chain(const whmr_smpl_model* m, const float* pose9
 extern "C" int whmr_smpl_skin(const whmr_smpl_model* m, const float* betas, long beta_stride, const float* pose_feat, const float* A,
                               const float* pose_off, int B, float* verts, void* stream) {
     if (B <= 0) return (int)hipErrorInvalidValue;
+    // images per block: with the pose-corrective offsets precomputed (pose_off) the per-vertex constants are small, so more, smaller
+    // blocks (1 image each: ~7 waves per SIMD at batch 64) hide the LDS / load latency that one 8-image block per 128 vertices exposes
+    if (pose_off) {
+        constexpr int BT = 1;
+        hipLaunchKernelGGL(smpl_skin_kernel<BT>, dim3((NV + 127) / 128, (B + BT - 1) / BT), dim3(128), 0, (hipStream_t)stream, *m,
+                           betas, beta_stride, pose_feat, A, pose_off, B, verts);
+        WHMR_CHECK_LAUNCH();
+        return 0;
+    }
     constexpr int BT = 8;
     hipLaunchKernelGGL(smpl_skin_kernel<BT>, dim3((NV + 127) / 128, (B + BT - 1) / BT), dim3(128), 0, (hipStream_t)stream, *m,
                        betas, beta_stride, pose_feat, A, pose_off, B, verts);

@@ -75,12 +75,14 @@ class SMPL(nn.Module):
             keep = {'regs': torch.cat([self.J_regressor_extra, self.J_regressor], 0).contiguous(),   # [9 + 24, 6890]
                     'posedirs_t': self.posedirs.t().contiguous(),                                     # [20670, 207]: GEMM weight layout
                     'J_template': (Jreg64 @ self.v_template.double()).float().contiguous(),
+                    'shapedirs_t': self.shapedirs.reshape(self.NUM_VERTS, 30).t().contiguous(),         # [30, 6890]: coalesced over vertices
+                    'lbs_weights_t': self.lbs_weights.t().contiguous(),                               # [24, 6890]
                     'J_shapedirs': torch.einsum('jv,vcl->jcl', Jreg64, self.shapedirs.double()).float().contiguous(),
                     'parents': i32(self.parents), 'extra': i32(self.extra_joints_idxs), 'jmap': i32(self.joint_map),
                     'markers': i32(self.marker_ids)}
             m = L.WhmrSmplModel()
-            m.v_template, m.shapedirs = self.v_template.data_ptr(), self.shapedirs.data_ptr()
-            m.posedirs, m.lbs_weights = self.posedirs.data_ptr(), self.lbs_weights.data_ptr()
+            m.v_template, m.shapedirs = self.v_template.data_ptr(), keep['shapedirs_t'].data_ptr()
+            m.posedirs, m.lbs_weights = self.posedirs.data_ptr(), keep['lbs_weights_t'].data_ptr()
             m.J_template, m.J_shapedirs = keep['J_template'].data_ptr(), keep['J_shapedirs'].data_ptr()
             m.J_regressor_extra = keep['regs'].data_ptr()
             m.J_regressor = keep['regs'].data_ptr() + 9 * self.NUM_VERTS * 4
