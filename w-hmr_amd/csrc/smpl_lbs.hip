@@ -181,29 +181,34 @@ __global__ __launch_bounds__(128) void smpl_skin_kernel(const whmr_smpl_model m,
     }
 }
 
-// Regress `R` rows of a dense [R,6890] matrix over every image's skinned mesh: one WAVE per (image, row) -- 33 rows x B
-// images give thousands of independent waves instead of one block per image walking the rows serially.
+// Regress `R` rows of a dense [R,6890] matrix over every image's skinned mesh: one workgroup per (image, row) -- 33 rows x B
+// images give thousands of independent workgroups instead of one block per image walking the rows serially.
 // out[(b*R + r)*3 + c] = sum_v reg[r][v] * verts[b][v][c].  Exact zeros are skipped (the real regressors are >99 % zeros).
 __global__ __launch_bounds__(256) void smpl_regress_kernel(const float* __restrict__ reg, int R, const float* __restrict__ verts,
                                                            int B, float* __restrict__ out) {
-    const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (w >= B * R) return;
+    // one WORKGROUP per (image, row): the 6890-vertex dot product is split over 4 waves, so a lane walks 3 rounds of
+    // [9 weight loads -> (non-zero?) -> 27 vertex loads] instead of 12 -- the two dependent memory round trips per round
+    // were the whole run time.
+    __shared__ float red[4][3];
+    const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = w / R, r = w - b * R;
     const float* rr = reg + (size_t)r * NV;
     const float* vb = verts + (size_t)b * NV * 3;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-    for (int v0 = lane; v0 < NV; v0 += 64 * 9) {          // 9 independent coalesced weight loads in flight per lane
+    for (int v0 = tid; v0 < NV; v0 += 256 * 9) {          // 9 independent coalesced weight loads in flight per lane
         float wv[9];
 #pragma unroll
-        for (int u = 0; u < 9; ++u) { const int v = v0 + 64 * u; wv[u] = v < NV ? rr[v] : 0.f; }
+        for (int u = 0; u < 9; ++u) { const int v = v0 + 256 * u; wv[u] = v < NV ? rr[v] : 0.f; }
 #pragma unroll
         for (int u = 0; u < 9; ++u) {
-            const int v = v0 + 64 * u;
+            const int v = v0 + 256 * u;
             if (wv[u] != 0.f) { a0 = fmaf(wv[u], vb[3 * v], a0); a1 = fmaf(wv[u], vb[3 * v + 1], a1); a2 = fmaf(wv[u], vb[3 * v + 2], a2); }
         }
     }
     a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
-    if (lane == 0) { out[(size_t)w * 3] = a0; out[(size_t)w * 3 + 1] = a1; out[(size_t)w * 3 + 2] = a2; }
+    if (lane == 0) { red[wave][0] = a0; red[wave][1] = a1; red[wave][2] = a2; }
+    __syncthreads();
+    if (tid < 3) out[(size_t)w * 3 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
 }
 
 // Gather stage: 54-joint superset (24 posed SMPL joints, 21 picked vertices, 9 regressed; models/smpl.py:61-83) -> JOINT_MAP
@@ -277,7 +282,7 @@ extern "C" int whmr_smpl_joints(const whmr_smpl_model* m, const float* verts, co
     const int R = smpl_joints45 ? 33 : 9;
     if (smpl_joints45 && m->J_regressor != m->J_regressor_extra + 9 * NV) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(smpl_regress_kernel, dim3((B * R + 3) / 4), dim3(256), 0, st, m->J_regressor_extra, R, verts, B, scratch);
+    hipLaunchKernelGGL(smpl_regress_kernel, dim3(B * R), dim3(256), 0, st, m->J_regressor_extra, R, verts, B, scratch);
     hipLaunchKernelGGL(smpl_joints_kernel, dim3(B), dim3(256), 0, st, *m, verts, posed_joints, scratch, R, joints49,
                        smpl_joints45, markers);
     WHMR_CHECK_LAUNCH();
