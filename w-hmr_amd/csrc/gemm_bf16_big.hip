@@ -57,7 +57,13 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_n = (p.N + BN - 1) / BN;
     const int tiles_m = (p.M + BM - 1) / BM;
-    const int lid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    // Sub-pixel deconv: the phase is the FASTEST tile index, so the 4 phases of one M tile (which gather the same input
+    // neighbourhood and write interleaved output pixels) run back to back on one XCD: shared A reads hit its L2 and the
+    // interleaved 512-B pixel rows of the output meet in cache before they go to HBM.
+    const int nph = (GATHER && p.n_phase > 1) ? p.n_phase : 1;
+    int lid = xcd_remap(blockIdx.x, tiles_m * tiles_n * nph);
+    const int phase = lid % nph;
+    lid /= nph;
     const int tm = lid / tiles_n, tn = lid % tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
     const bf16_t* __restrict__ A = (const bf16_t*)p.A;
@@ -66,8 +72,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
     int64_t c_off = p.c_off;
     if constexpr (GATHER) {
         if (p.n_phase > 1) {                  // sub-pixel deconv phase of this block (gemm_params.h)
-            const int py = blockIdx.y >> 1, px = blockIdx.y & 1;
-            W += (size_t)blockIdx.y * p.phase_w_stride;
+            const int py = phase >> 1, px = phase & 1;
+            W += (size_t)phase * p.phase_w_stride;
             PH -= py; PW -= px;
             c_off += py * p.phase_cy + px * p.phase_cx;
         }
@@ -440,6 +446,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
             return;
         }
     }
+    const int ohw_ = spatial ? p.OH * p.OW : 1;
+    const float rcp_ohw = 1.0f / (float)ohw_, rcp_ow = spatial ? 1.0f / (float)p.OW : 1.0f;
     // ---- generic path (no residual, conv scatter, N tail): rolled store loop, code exists once
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -451,9 +459,14 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
             if (m >= p.M || ncol >= p.N) continue;
             size_t crow;
             if (spatial) {
-                const int ohw = p.OH * p.OW;
-                const int b = m / ohw, rem = m - b * ohw;
-                const int oy = rem / p.OW, ox = rem - oy * p.OW;
+                // (b, oy, ox) of row m through reciprocal multiplies (M < 2^24: exact after one correction) -- the two integer
+                // divisions per row were ~1000 instructions per thread and tile on the deconv scatter path
+                int b = (int)((float)m * rcp_ohw);
+                int rem = m - b * ohw_;
+                if (rem >= ohw_) { ++b; rem -= ohw_; } else if (rem < 0) { --b; rem += ohw_; }
+                int oy = (int)((float)rem * rcp_ow);
+                int ox = rem - oy * p.OW;
+                if (ox >= p.OW) { ++oy; ox -= p.OW; } else if (ox < 0) { --oy; ox += p.OW; }
                 crow = (size_t)(c_off + b * p.osb + oy * p.osy + ox * p.osx);
             } else {
                 crow = (size_t)m * p.ldc;
@@ -504,7 +517,7 @@ static int launch_big(const whmr_gemm& p, hipStream_t st) {
         attr_done = true;
     }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    hipLaunchKernelGGL(kern, dim3(tiles, GATHER && p.n_phase > 1 ? p.n_phase : 1, p.split_k ? (unsigned)((p.K + p.split_k - 1) / p.split_k) : 1), dim3(cfg::THREADS), cfg::LDS, st, p);
+    hipLaunchKernelGGL(kern, dim3(tiles * (GATHER && p.n_phase > 1 ? p.n_phase : 1), 1, p.split_k ? (unsigned)((p.K + p.split_k - 1) / p.split_k) : 1), dim3(cfg::THREADS), cfg::LDS, st, p);
     WHMR_CHECK_LAUNCH();
     return 0;
 }
