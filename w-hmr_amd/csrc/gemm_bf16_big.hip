@@ -27,6 +27,12 @@ struct big_cfg {
     static constexpr int CLD_BF16 = BN + 4;                // bf16 staging row stride (elements): (BN+4)/2 dwords = 2 mod 32
     static constexpr int EPI_BYTES = CROWS * CLD_F32 * 4;
     static constexpr int LDS = (NS * STAGE > EPI_BYTES) ? NS * STAGE : EPI_BYTES;
+    // bf16-output kernels stage the finished tile as bf16 (bias / activation already applied): all MI passes at once when they
+    // fit in 160 KiB, else as many as fit in the main-loop allocation
+    static constexpr int EPI16_ROW = CLD_BF16 * 2;                                       // bytes per staged row
+    static constexpr int EPI16_ALL = MI * CROWS * EPI16_ROW;
+    static constexpr int LDS16 = (EPI16_ALL <= 160 * 1024 && EPI16_ALL > LDS) ? EPI16_ALL : LDS;
+    static constexpr int GP16 = (LDS16 / (CROWS * EPI16_ROW)) < MI ? (LDS16 / (CROWS * EPI16_ROW)) : MI;   // passes staged per group
     static constexpr int G = AP + BP;                      // global_load_lds per thread per K step
     static_assert(BM % RP == 0 && BN % RP == 0, "staging passes must tile the block");
     static_assert(BK == 32 || BK == 64, "BK");
@@ -339,6 +345,77 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
         return;
     }
 
+    // ---- bf16 outputs without a skip tensor (qkv, fc1 + GELU, deconvs, ResNet 3x3 / 1x1 convs): bias + activation in registers
+    // (each lane owns 4 consecutive columns per register quad), pack to bf16, park the WHOLE tile in LDS as 8-B pieces, one
+    // barrier, then every thread streams 16-B row chunks straight to global memory.  Half the LDS bytes of the fp32 slab
+    // below, no per-pass barriers and no arithmetic in the store loop: the fp32-slab epilogue cost ~11 us of a 60 us qkv launch
+    // with the global stores removed (tools/alias_probe.py), i.e. it was instruction / LDS bound, not HBM bound.
+    if constexpr (OUT_BF16) {
+        if (!p.residual && !p.split_k && !(p.N & 7) && (p.c_mode == 1 || !(p.ldc & 7))) {
+            constexpr int ROWB = cfg::EPI16_ROW, GP = cfg::GP16, CPRW = BN / 8, RPI2 = cfg::THREADS / CPRW;
+            void* const Cout16 = p.C;
+            const bool nostore16 = p.res_row_mod == -2003;
+            const bool spatial16 = GATHER && p.c_mode == 1;
+            const int ohw16 = spatial16 ? p.OH * p.OW : 1;
+            const float rcp_ohw16 = 1.0f / (float)ohw16, rcp_ow16 = spatial16 ? 1.0f / (float)p.OW : 1.0f;
+            float4 bq[NJ][4];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int col = n0 + wn * cfg::WTN + j * 32 + 8 * q + 4 * hi;
+                    bq[j][q] = (p.bias && col < p.N) ? *(const float4*)(p.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+            for (int i0 = 0; i0 < MI; i0 += GP) {
+                if (i0) { wait_lgkmcnt<0>(); __builtin_amdgcn_s_barrier(); }          // previous group fully read
+#pragma unroll
+                for (int i = i0; i < i0 + GP && i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            float v[4] = {acc[i][j][4 * q] + bq[j][q].x, acc[i][j][4 * q + 1] + bq[j][q].y, acc[i][j][4 * q + 2] + bq[j][q].z,
+                                          acc[i][j][4 * q + 3] + bq[j][q].w};
+                            if (ACT == 1) {
+                                const f32x2_t g0 = gelu_fast2(f32x2_t{v[0], v[1]}), g1 = gelu_fast2(f32x2_t{v[2], v[3]});
+                                v[0] = g0.x; v[1] = g0.y; v[2] = g1.x; v[3] = g1.y;
+                            }
+                            if (ACT == 2) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                            *(uint2*)(smem + ((i - i0) * cfg::CROWS + wm * 32 + l31) * ROWB + (wn * cfg::WTN + j * 32 + 8 * q + 4 * hi) * 2) =
+                                make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                        }
+                wait_lgkmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+                const int npass = (MI - i0) < GP ? (MI - i0) : GP;
+                const int nrows = npass * cfg::CROWS;
+#pragma unroll 4
+                for (int lr = tid / CPRW; lr < nrows; lr += RPI2) {
+                    const int chunk = tid % CPRW;
+                    const int pi = lr / cfg::CROWS, within = lr - pi * cfg::CROWS;
+                    const int m = m0 + (within >> 5) * cfg::WTM + (i0 + pi) * 32 + (within & 31);
+                    const int col = n0 + chunk * 8;
+                    if (m >= p.M || col >= p.N) continue;
+                    const uint4 v = *(const uint4*)(smem + lr * ROWB + chunk * 16);
+                    size_t crow;
+                    if (spatial16) {
+                        int b = (int)((float)m * rcp_ohw16);
+                        int rem = m - b * ohw16;
+                        if (rem >= ohw16) { ++b; rem -= ohw16; } else if (rem < 0) { --b; rem += ohw16; }
+                        int oy = (int)((float)rem * rcp_ow16);
+                        int ox = rem - oy * p.OW;
+                        if (ox >= p.OW) { ++oy; ox -= p.OW; } else if (ox < 0) { --oy; ox += p.OW; }
+                        crow = (size_t)(c_off + b * p.osb + oy * p.osy + ox * p.osx);
+                    } else {
+                        crow = (size_t)m * p.ldc;
+                    }
+                    if (!nostore16 || v.x == 0x12345678u) *(uint4*)((bf16_t*)Cout16 + crow + col) = v;
+                }
+            }
+            return;
+        }
+    }
+
     // ---- epilogue, written for CODE SIZE (a fully unrolled epilogue made this kernel 85-92 KB and every tile paid an
     // instruction-cache miss storm -- +20-30 us per GEMM): MI passes; in pass i every wave parks its RAW acc[i][*] (32 rows
     // x WTN cols) in LDS as 16-B writes; then a rolled loop streams whole rows out: 16-B LDS reads -> bias -> activation ->
@@ -446,6 +523,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
             return;
         }
     }
+    const bool nostore = p.res_row_mod == -2003;
     const int ohw_ = spatial ? p.OH * p.OW : 1;
     const float rcp_ohw = 1.0f / (float)ohw_, rcp_ow = spatial ? 1.0f / (float)p.OW : 1.0f;
     // ---- generic path (no residual, conv scatter, N tail): rolled store loop, code exists once
@@ -491,7 +569,9 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
                 }
             }
             if (res_first) activate(v);
-            if (vec_ok) {
+            if (nostore) {                           // timing probe: the whole epilogue except the global stores
+                if (v[0] == 12345.678f) store_vec(crow + ncol, v);
+            } else if (vec_ok) {
                 store_vec(crow + ncol, v);
             } else {
 #pragma unroll 1
@@ -512,12 +592,12 @@ static int launch_big(const whmr_gemm& p, hipStream_t st) {
     auto kern = gemm_bf16_big_kernel<BM, BN, BK, WM, WN, NS, MINW, PP, OUT_BF16, ACT, GATHER>;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, cfg::LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, OUT_BF16 ? cfg::LDS16 : cfg::LDS);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    hipLaunchKernelGGL(kern, dim3(tiles * (GATHER && p.n_phase > 1 ? p.n_phase : 1), 1, p.split_k ? (unsigned)((p.K + p.split_k - 1) / p.split_k) : 1), dim3(cfg::THREADS), cfg::LDS, st, p);
+    hipLaunchKernelGGL(kern, dim3(tiles * (GATHER && p.n_phase > 1 ? p.n_phase : 1), 1, p.split_k ? (unsigned)((p.K + p.split_k - 1) / p.split_k) : 1), dim3(cfg::THREADS), OUT_BF16 ? cfg::LDS16 : cfg::LDS, st, p);
     WHMR_CHECK_LAUNCH();
     return 0;
 }
