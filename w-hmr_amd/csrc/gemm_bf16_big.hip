@@ -358,7 +358,9 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
     // below, no per-pass barriers and no arithmetic in the store loop: the fp32-slab epilogue cost ~11 us of a 60 us qkv launch
     // with the global stores removed (tools/alias_probe.py), i.e. it was instruction / LDS bound, not HBM bound.
     if constexpr (OUT_BF16) {
-        if (!p.residual && !p.split_k && !(p.N & 7) && (p.c_mode == 1 || !(p.ldc & 7))) {
+        const bool skip16 = p.residual && (p.epi_flags & 1) && !(p.ldr & 7) && p.res_row_mod <= 0 && p.res_row_mod != -2003;   // bf16 skip tensor (ResNet)
+        if ((!p.residual || skip16) && !p.split_k && !(p.N & 7) && (p.c_mode == 1 || !(p.ldc & 7))) {
+            const bool act_late = skip16 && (p.epi_flags & 2);               // ResNet: the skip is added BEFORE the activation -> activate in the store loop
             constexpr int ROWB = cfg::EPI16_ROW, GP = cfg::GP16, CPRW = BN / 8, RPI2 = cfg::THREADS / CPRW;
             void* const Cout16 = p.C;
             const bool nostore16 = p.res_row_mod == -2003;
@@ -385,11 +387,11 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
                         for (int q = 0; q < 4; ++q) {
                             float v[4] = {acc[i][j][4 * q] + bq[j][q].x, acc[i][j][4 * q + 1] + bq[j][q].y, acc[i][j][4 * q + 2] + bq[j][q].z,
                                           acc[i][j][4 * q + 3] + bq[j][q].w};
-                            if (ACT == 1) {
+                            if (ACT == 1 && !act_late) {
                                 const f32x2_t g0 = gelu_fast2(f32x2_t{v[0], v[1]}), g1 = gelu_fast2(f32x2_t{v[2], v[3]});
                                 v[0] = g0.x; v[1] = g0.y; v[2] = g1.x; v[3] = g1.y;
                             }
-                            if (ACT == 2) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                            if (ACT == 2 && !act_late) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
                             *(uint2*)(smem + ((i - i0) * cfg::CROWS + wm * 32 + l31) * ROWB + (wn * cfg::WTN + j * 32 + 8 * q + 4 * hi) * 2) =
                                 make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
                         }
@@ -404,7 +406,23 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
                     const int m = m0 + (within >> 5) * cfg::WTM + (i0 + pi) * 32 + (within & 31);
                     const int col = n0 + chunk * 8;
                     if (m >= p.M || col >= p.N) continue;
-                    const uint4 v = *(const uint4*)(smem + lr * ROWB + chunk * 16);
+                    uint4 v = *(const uint4*)(smem + lr * ROWB + chunk * 16);
+                    if (skip16) {                    // + bf16 skip row (one 16-B load), optional late activation, re-pack
+                        const uint4 sk = *(const uint4*)((const bf16_t*)p.residual + (size_t)m * p.ldr + col);
+                        const uint32_t a[4] = {v.x, v.y, v.z, v.w}, b[4] = {sk.x, sk.y, sk.z, sk.w};
+                        uint32_t o[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float lo = __uint_as_float(a[e] << 16) + __uint_as_float(b[e] << 16);
+                            float hi2 = __uint_as_float(a[e] & 0xffff0000u) + __uint_as_float(b[e] & 0xffff0000u);
+                            if (act_late) {
+                                if (ACT == 2) { lo = fmaxf(lo, 0.f); hi2 = fmaxf(hi2, 0.f); }
+                                if (ACT == 1) { const f32x2_t g = gelu_fast2(f32x2_t{lo, hi2}); lo = g.x; hi2 = g.y; }
+                            }
+                            o[e] = pack_bf16x2(lo, hi2);
+                        }
+                        v = make_uint4(o[0], o[1], o[2], o[3]);
+                    }
                     size_t crow;
                     if (spatial16) {
                         int b = (int)((float)m * rcp_ohw16);
