@@ -32,7 +32,7 @@ def test_gemm_bf16(dev, M, N, K, glds):
     assert _rel(out2.float().cpu(), a.float() @ w.float().t()) < 1e-2
 
 
-@pytest.mark.parametrize('M,N,K', [(392, 768, 768), (12544, 2304, 768), (300, 3072, 768), (392, 768, 3072), (1000, 130, 64)])
+@pytest.mark.parametrize('M,N,K', [(392, 768, 768), (12544, 2304, 768), (300, 3072, 768), (392, 768, 3072), (1000, 130, 64), (1001, 136, 128)])
 @pytest.mark.parametrize('tile', [64, 65, 128, 256, 192, 257, 259, 320])
 def test_gemm_bf16_big_tile(dev, M, N, K, tile):
     from whmr_amd import _lib as L
@@ -355,3 +355,21 @@ def test_conv_gather_chunk_major_k_order(dev):
     for tile in (None, 65, 64):
         L.gemm(xn, w_cm, out.view(-1, Cout), conv=dict(IH=IH, IW=IW, Cin=Cin, OH=OH, OW=OW, KW=KW, SH=S, SW=S, PH=0, PW=0, chunk_major=True), tile=tile)
         assert _rel(out.cpu(), ref) < 2e-5
+
+
+@pytest.mark.parametrize('tile', [None, 64, 65, 128, 192, 257, 320])
+@pytest.mark.parametrize('act', [0, 1, 2])
+def test_gemm_bf16_staged_epilogue(dev, tile, act):
+    """bf16 outputs take the whole-tile bf16 staging epilogue (bias from LDS, activation in registers): ragged M, N % 8 == 0 only."""
+    from whmr_amd import _lib as L
+    g = torch.Generator().manual_seed(41 + act)
+    M, N, K = 777, 328, 192
+    a = torch.randn(M, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).bfloat16()
+    bias = torch.randn(N, generator=g)
+    pre = a.float() @ w.float().t() + bias
+    ref = pre if act == 0 else (F.gelu(pre) if act == 1 else F.relu(pre))
+    out = torch.full((M + 3, N), 7.0, device=dev, dtype=torch.bfloat16)
+    L.gemm(a.to(dev), w.to(dev), out[:M], bias=bias.to(dev), act=act, tile=tile)
+    assert _rel(out[:M].float().cpu(), ref) < 1e-2
+    assert (out[M:] == 7.0).all()                                      # rows past M untouched

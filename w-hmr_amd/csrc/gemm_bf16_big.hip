@@ -498,7 +498,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
     };
 
     if constexpr (!GATHER && MI <= 4) {
-        if (res && vec_ok && (p.ldr % (res_bf16 ? CPT : 4)) == 0) {
+        if (res && n0 + BN <= p.N && (p.ldc % CPT) == 0 && (p.ldr % (res_bf16 ? CPT : 4)) == 0) {   // block-uniform: the two paths have different barrier sequences
             // ---- fast residual path (proj / fc2 / patch-embed; ResNet conv3 + bf16 skip): all residual rows of a pass are
             // prefetched one pass ahead, NIT independent 16-B loads in flight per thread instead of one exposed HBM round
             // trip per row.  rv holds raw bits: CPT fp32 values (CPT/4 x 16 B) or CPT bf16 values (first CPT*2 bytes).
