@@ -358,7 +358,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
     // below, no per-pass barriers and no arithmetic in the store loop: the fp32-slab epilogue cost ~11 us of a 60 us qkv launch
     // with the global stores removed (tools/alias_probe.py), i.e. it was instruction / LDS bound, not HBM bound.
     if constexpr (OUT_BF16) {
-        const bool skip16 = p.residual && (p.epi_flags & 1) && !(p.ldr & 7) && p.res_row_mod <= 0 && p.res_row_mod != -2003;   // bf16 skip tensor (ResNet)
+        // bf16 skip tensor (ResNet); a GELU that must follow the skip add stays on the fp32-slab path
+        const bool skip16 = p.residual && (p.epi_flags & 1) && !(p.ldr & 7) && p.res_row_mod <= 0 && p.res_row_mod != -2003 && !(ACT == 1 && (p.epi_flags & 2));
         if ((!p.residual || skip16) && !p.split_k && !(p.N & 7) && (p.c_mode == 1 || !(p.ldc & 7))) {
             const bool act_late = skip16 && (p.epi_flags & 2);               // ResNet: the skip is added BEFORE the activation -> activate in the store loop
             constexpr int ROWB = cfg::EPI16_ROW, GP = cfg::GP16, CPRW = BN / 8, RPI2 = cfg::THREADS / CPRW;
@@ -399,31 +400,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
                 __builtin_amdgcn_s_barrier();
                 const int npass = (MI - i0) < GP ? (MI - i0) : GP;
                 const int nrows = npass * cfg::CROWS;
-#pragma unroll 4
-                for (int lr = tid / CPRW; lr < nrows; lr += RPI2) {
-                    const int chunk = tid % CPRW;
-                    const int pi = lr / cfg::CROWS, within = lr - pi * cfg::CROWS;
-                    const int m = m0 + (within >> 5) * cfg::WTM + (i0 + pi) * 32 + (within & 31);
-                    const int col = n0 + chunk * 8;
-                    if (m >= p.M || col >= p.N) continue;
-                    uint4 v = *(const uint4*)(smem + lr * ROWB + chunk * 16);
-                    if (skip16) {                    // + bf16 skip row (one 16-B load), optional late activation, re-pack
-                        const uint4 sk = *(const uint4*)((const bf16_t*)p.residual + (size_t)m * p.ldr + col);
-                        const uint32_t a[4] = {v.x, v.y, v.z, v.w}, b[4] = {sk.x, sk.y, sk.z, sk.w};
-                        uint32_t o[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float lo = __uint_as_float(a[e] << 16) + __uint_as_float(b[e] << 16);
-                            float hi2 = __uint_as_float(a[e] & 0xffff0000u) + __uint_as_float(b[e] & 0xffff0000u);
-                            if (act_late) {
-                                if (ACT == 2) { lo = fmaxf(lo, 0.f); hi2 = fmaxf(hi2, 0.f); }
-                                if (ACT == 1) { const f32x2_t g = gelu_fast2(f32x2_t{lo, hi2}); lo = g.x; hi2 = g.y; }
-                            }
-                            o[e] = pack_bf16x2(lo, hi2);
-                        }
-                        v = make_uint4(o[0], o[1], o[2], o[3]);
-                    }
-                    size_t crow;
+                auto row_addr = [&](int m) -> size_t {
                     if (spatial16) {
                         int b = (int)((float)m * rcp_ohw16);
                         int rem = m - b * ohw16;
@@ -431,11 +408,39 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
                         int oy = (int)((float)rem * rcp_ow16);
                         int ox = rem - oy * p.OW;
                         if (ox >= p.OW) { ++oy; ox -= p.OW; } else if (ox < 0) { --oy; ox += p.OW; }
-                        crow = (size_t)(c_off + b * p.osb + oy * p.osy + ox * p.osx);
-                    } else {
-                        crow = (size_t)m * p.ldc;
+                        return (size_t)(c_off + b * p.osb + oy * p.osy + ox * p.osx);
                     }
-                    if (!nostore16 || v.x == 0x12345678u) *(uint4*)((bf16_t*)Cout16 + crow + col) = v;
+                    return (size_t)m * p.ldc;
+                };
+                const int chunk = tid % CPRW, col = n0 + chunk * 8;
+                if (!skip16) {                       // the hot loop (qkv, fc1, deconvs): LDS read -> global store, nothing else
+#pragma unroll 4
+                    for (int lr = tid / CPRW; lr < nrows; lr += RPI2) {
+                        const int pi = lr / cfg::CROWS, within = lr - pi * cfg::CROWS;
+                        const int m = m0 + (within >> 5) * cfg::WTM + (i0 + pi) * 32 + (within & 31);
+                        if (m >= p.M || col >= p.N) continue;
+                        const uint4 v = *(const uint4*)(smem + lr * ROWB + chunk * 16);
+                        if (!nostore16 || v.x == 0x12345678u) *(uint4*)((bf16_t*)Cout16 + row_addr(m) + col) = v;
+                    }
+                } else {                             // + bf16 skip row (one 16-B load), late ReLU (ResNet), re-pack
+#pragma unroll 2
+                    for (int lr = tid / CPRW; lr < nrows; lr += RPI2) {
+                        const int pi = lr / cfg::CROWS, within = lr - pi * cfg::CROWS;
+                        const int m = m0 + (within >> 5) * cfg::WTM + (i0 + pi) * 32 + (within & 31);
+                        if (m >= p.M || col >= p.N) continue;
+                        const uint4 v = *(const uint4*)(smem + lr * ROWB + chunk * 16);
+                        const uint4 sk = *(const uint4*)((const bf16_t*)p.residual + (size_t)m * p.ldr + col);
+                        const uint32_t a[4] = {v.x, v.y, v.z, v.w}, b[4] = {sk.x, sk.y, sk.z, sk.w};
+                        uint32_t o[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float lo = __uint_as_float(a[e] << 16) + __uint_as_float(b[e] << 16);
+                            float hi2 = __uint_as_float(a[e] & 0xffff0000u) + __uint_as_float(b[e] & 0xffff0000u);
+                            if (ACT == 2 && act_late) { lo = fmaxf(lo, 0.f); hi2 = fmaxf(hi2, 0.f); }
+                            o[e] = pack_bf16x2(lo, hi2);
+                        }
+                        *(uint4*)((bf16_t*)Cout16 + row_addr(m) + col) = make_uint4(o[0], o[1], o[2], o[3]);
+                    }
                 }
             }
             return;
