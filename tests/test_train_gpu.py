@@ -124,3 +124,23 @@ def test_vit_backward_224_hip_attention(dev):
     bad = {n: _rel(p.grad.cpu(), ref_sd[n].grad) for n, p in m.named_parameters()}
     bad = {k: v for k, v in bad.items() if not v < 4e-2}
     assert not bad, 'gradient mismatch: %s' % sorted(bad.items(), key=lambda kv: -kv[1])[:6]
+
+
+def test_vit_large_backward_256x192(dev):
+    """ViT-L/16 geometry (dim 1024, 16 heads, 192 tokens), depth 1: gradients of the HIP backward vs the CPU oracle's autograd."""
+    from oracle import synth
+    from oracle.vit import vit_forward
+    from whmr_amd.models.pose_vit import ViT
+    size = (256, 192)
+    sd = synth.make_vit_state(7, size, embed_dim=1024, depth=1)
+    x = synth.make_inputs(2, 13, size)['x']
+    G = torch.randn(2, 1024, 16, 12, generator=torch.Generator().manual_seed(8))
+    ref_sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    (vit_forward(ref_sd, x, num_heads=16, depth=1) * G).sum().backward()
+    m = ViT(img_size=size, embed_dim=1024, depth=1, num_heads=16, qkv_bias=True, numerics='bf16')
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev).train()
+    (m(x.to(dev)) * G.to(dev)).sum().backward()
+    bad = {n: _rel(p.grad.cpu(), ref_sd[n].grad) for n, p in m.named_parameters()}
+    bad = {k: v for k, v in bad.items() if not v < 4e-2}
+    assert not bad, 'gradient mismatch: %s' % sorted(bad.items(), key=lambda kv: -kv[1])[:6]
