@@ -33,7 +33,7 @@ def test_gemm_bf16(dev, M, N, K, glds):
 
 
 @pytest.mark.parametrize('M,N,K', [(392, 768, 768), (12544, 2304, 768), (300, 3072, 768), (392, 768, 3072), (1000, 130, 64), (1001, 136, 128)])
-@pytest.mark.parametrize('tile', [64, 65, 128, 256, 192, 257, 259, 320])
+@pytest.mark.parametrize('tile', [64, 65, 128, 256, 192, 257, 259, 320, 160, 224])
 def test_gemm_bf16_big_tile(dev, M, N, K, tile):
     from whmr_amd import _lib as L
     g = torch.Generator().manual_seed(M + N + K + tile)
@@ -206,7 +206,7 @@ def test_patch_im2col(dev):
     assert torch.equal(out.cpu(), ref)
 
 
-@pytest.mark.parametrize('tile', [None, 64, 65, 128, 257])
+@pytest.mark.parametrize('tile', [None, 64, 65, 128, 257, 160, 224])
 @pytest.mark.parametrize('out_bf16', [True, False])
 def test_gemm_bf16_skip_before_relu(dev, tile, out_bf16):
     """ResNet bottleneck epilogue: relu(a.w^T + bias + skip) with a bf16 skip tensor (epi_flags bits 0|1)."""
@@ -357,7 +357,7 @@ def test_conv_gather_chunk_major_k_order(dev):
         assert _rel(out.cpu(), ref) < 2e-5
 
 
-@pytest.mark.parametrize('tile', [None, 64, 65, 128, 192, 257, 320])
+@pytest.mark.parametrize('tile', [None, 64, 65, 128, 192, 257, 320, 160, 224])
 @pytest.mark.parametrize('act', [0, 1, 2])
 def test_gemm_bf16_staged_epilogue(dev, tile, act):
     """bf16 outputs take the whole-tile bf16 staging epilogue (bias from LDS, activation in registers): ragged M, N % 8 == 0 only."""

@@ -14,8 +14,7 @@ def timeit(fn, n=30, w=5):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
-for name, N, K, tiles in (('qkv', 2304, 768, (None, 257, 320, 192, 259)), ('proj', 768, 768, (None, 192, 257, 320)),
-                          ('fc1', 3072, 768, (None, 320, 257, 192)), ('fc2', 768, 3072, (None, 192, 257, 320))):
+for name, N, K, tiles in (('qkv', 2304, 768, (257, 224, 257, 224)), ('proj', 768, 768, (192, 160, 192, 160)), ('fc1', 3072, 768, (320, 224)), ('fc2', 768, 3072, (192, 160, 192, 160))):
     a = torch.randn(M, K, device=dev).bfloat16(); w = (torch.randn(N, K, device=dev) / math.sqrt(K)).bfloat16()
     bias = torch.randn(N, device=dev)
     ob = torch.empty(M, N, device=dev, dtype=torch.bfloat16)

@@ -93,8 +93,14 @@ extern "C" int whmr_gemm_bf16(const whmr_gemm* pp, int flags, void* stream) {
         const int slot = p.N == 2304 ? 0 : p.N == 3072 ? 2 : p.N == 768 ? (p.K <= 1024 ? 1 : 3) : -1;
         if (slot >= 0 && g_opt_tile[slot] && p.a_mode == 0) return whmr_gemm_bf16_big(pp, g_opt_tile[slot], stream);
     }
+    // 160: the 192-row kernel with the last 32-row block trimmed (gemm_bf16_big.hip, PP == 3): 12544 x 768 becomes ONE round of
+    // 237 tiles instead of 198 (23 % of the CUs idle).  Interleaved in-model A/B (tools/trim_ab.py, ViT-B batch 64): fc2
+    // (K = 3072) -35 us per forward, proj (K = 768) +-0; the 224-row form of the 256 kernel (qkv: 504 tiles in two rounds) wins
+    // the isolated benchmark by 4 us per launch and LOSES 50 us per forward in the model (the chip is power-limited: filling
+    // the idle CUs lowers everyone's clock), so it stays an explicit tile id only.  Deep-K shapes only.
     static const tile_cfg cands[] = {{320, 320, 256, 1, 100}, {259, 256, 256, 1, 94}, {192, 192, 256, 1, 100},
-                                     {128, 128, 256, 2, 120}, {64, 128, 128, 2, 125}, {65, 128, 64, 3, 150}};
+                                     {128, 128, 256, 2, 120}, {64, 128, 128, 2, 125}, {65, 128, 64, 3, 150},
+                                     {160, 160, 256, 1, 103}};
     // Few tiles and a deep K (ResNet layer3/4 3x3 convs on a frame or two, fc2 of the ViT at batch 1): every block walks K
     // alone, one exposed L2/HBM round trip per K step on a mostly idle chip.  Slice K over blockIdx.z so that ~2 blocks per
     // CU are resident; partial sums go to the fp32 workspace and splitk_epilogue_kernel finishes (fixed order: deterministic).
@@ -115,6 +121,7 @@ extern "C" int whmr_gemm_bf16(const whmr_gemm* pp, int flags, void* stream) {
     long best_cost = -1;
     const tile_cfg* best = &cands[4];
     for (const tile_cfg& c : cands) {
+        if (c.id == 160 && (p.K < 2048 || p.a_mode != 0)) continue;
         const long tiles = (long)((p.M + c.bm - 1) / c.bm) * ((p.N + c.bn - 1) / c.bn) * (p.n_phase > 1 ? p.n_phase : 1);
         const long slots = 256L * c.per_cu;
         // full rounds run per_cu co-resident blocks per CU (they share the matrix pipes); the last, partial round only as

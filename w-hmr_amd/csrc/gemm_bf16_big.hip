@@ -7,6 +7,7 @@
 // Differences from gemm_bf16.hip (128x128, 64x64 wave tiles): larger wave tile; MFMA operands are swapped
 // (D^T = W_tile . A_tile^T) so that each lane owns 4 consecutive output COLUMNS per register quad -- the epilogue packs
 // them (bias + activation applied in registers) into 16-B / 8-B LDS writes, and leaves through whole-row 16-B stores.
+#include <type_traits>
 #include "common.h"
 #include "gemm_params.h"
 
@@ -60,9 +61,16 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
     using cfg = big_cfg<BM, BN, BK, WM, WN, NS>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int AP = cfg::AP, BP = cfg::BP, MI = cfg::MI, NJ = cfg::NJ, CPR = cfg::CPR, RP = cfg::RP;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // PP == 3: "trimmed" tile.  The LDS / register layout is the BM-row one, but the last 32-row block of the LAST wave row is
+    // dead (not multiplied, not stored) and tiles advance by BM - 32 rows: 160 x 256 and 224 x 256 tiles out of the 192 / 256
+    // kernels.  Each SIMD hosts one wave of every wave row, so the SIMDs stay balanced (MI + MI - 1 row blocks each).  Lets the
+    // chooser fit 12544 x 768 into ONE round of 237 tiles (was 198 of 192 rows: 23 % of the CUs idle) and 12544 x 2304 into two
+    // rounds of 224-row tiles (504 of 512 slots).
+    constexpr int TRIM = (PP == 3) ? 32 : 0, BME = BM - TRIM;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = TRIM ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);   // provably wave-uniform: the trimmed main loop branches on it around s_barrier
     const int tiles_n = (p.N + BN - 1) / BN;
-    const int tiles_m = (p.M + BM - 1) / BM;
+    const int tiles_m = (p.M + BME - 1) / BME;
     // Sub-pixel deconv: the phase is the FASTEST tile index, so the 4 phases of one M tile (which gather the same input
     // neighbourhood and write interleaved output pixels) run back to back on one XCD: shared A reads hit its L2 and the
     // interleaved 512-B pixel rows of the output meet in cache before they go to HBM.
@@ -71,7 +79,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
     const int phase = lid % nph;
     lid /= nph;
     const int tm = lid / tiles_n, tn = lid % tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * BME, n0 = tn * BN;
+    const int m_end = (m0 + BME < p.M) ? m0 + BME : p.M;      // first row this tile does NOT own
     const bf16_t* __restrict__ A = (const bf16_t*)p.A;
     const bf16_t* __restrict__ W = (const bf16_t*)p.W;
     int PH = p.PH, PW = p.PW;
@@ -198,9 +207,13 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
     // after it the wave issues the next stage's DMA and the first fragments of step kt+1, then still has MFMAs queued.
     constexpr int KK = BK / 16;
     const int nkt = (p.split_k ? min((int)p.split_k, p.K - k_first) : p.K) / BK;
-    bf16x8_t af[2][MI], bfr[2][NJ];
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)smem;
-    constexpr int NF = MI + NJ;          // ds_read_b128 per fragment set
+    // MIW = row blocks this wave multiplies (MI, or MI - 1 for the last wave row of a trimmed tile): the counted lgkmcnt waits
+    // depend on it, so the loop body is instantiated per value and selected by a wave-uniform branch (same barrier count).
+    auto main_loop = [&](auto miw_tag) {
+    constexpr int MIW = decltype(miw_tag)::value;
+    bf16x8_t af[2][MIW], bfr[2][NJ];
+    constexpr int NF = MIW + NJ;          // ds_read_b128 per fragment set
     auto load_frags = [&](int buf, int kk, int set) {
         const uint32_t sa = lds0 + buf * cfg::STAGE;
         const uint32_t sb = sa + cfg::A_BYTES;
@@ -208,11 +221,11 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
 #pragma unroll
         for (int j = 0; j < NJ; ++j) bfr[set][j] = lds_read128(sb + b_off[j] + ((c ^ b_sw[j]) << 4));
 #pragma unroll
-        for (int i = 0; i < MI; ++i) af[set][i] = lds_read128(sa + a_off[i] + ((c ^ a_sw[i]) << 4));
+        for (int i = 0; i < MIW; ++i) af[set][i] = lds_read128(sa + a_off[i] + ((c ^ a_sw[i]) << 4));
     };
     auto mfmas = [&](int set) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+        for (int i = 0; i < MIW; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[set][j], af[set][i], acc[i][j], 0, 0, 0);
@@ -227,7 +240,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
         else if (younger == 1) wait_vmcnt<cfg::G>();
         else wait_vmcnt<0>();
     };
-    if constexpr (PP) {
+    if constexpr (PP == 2) {
         // ---- ping-pong main loop (opt-in tile 259: 256x256x64, 8 waves = two groups of 4, one wave of each group per SIMD).
         // A K tile is computed in 2 phases of 16 MFMAs (two 64x32 quadrants of the wave tile x K = 64); every phase is
         //   [ds_read the fragments the quadrants add | issue 4 global_load_lds | counted vmcnt] s_barrier [MFMAs] s_barrier
@@ -338,6 +351,13 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
         }
     }
     }   // !PP
+    };
+    if constexpr (TRIM) {
+        if (wave / WN == WM - 1) main_loop(std::integral_constant<int, MI - 1>{});
+        else main_loop(std::integral_constant<int, MI>{});
+    } else {
+        main_loop(std::integral_constant<int, MI>{});
+    }
     __syncthreads();                         // all fragment reads done before the epilogue reuses the LDS
 
     if (p.res_row_mod == -12345) {            // timing probe: main loop only (keeps the accumulators live)
@@ -418,7 +438,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
                     for (int lr = tid / CPRW; lr < nrows; lr += RPI2) {
                         const int pi = lr / cfg::CROWS, within = lr - pi * cfg::CROWS;
                         const int m = m0 + (within >> 5) * cfg::WTM + (i0 + pi) * 32 + (within & 31);
-                        if (m >= p.M || col >= p.N) continue;
+                        if (m >= m_end || col >= p.N) continue;
                         const uint4 v = *(const uint4*)(smem + lr * ROWB + chunk * 16);
                         if (!nostore16 || v.x == 0x12345678u) *(uint4*)((bf16_t*)Cout16 + row_addr(m) + col) = v;
                     }
@@ -427,7 +447,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
                     for (int lr = tid / CPRW; lr < nrows; lr += RPI2) {
                         const int pi = lr / cfg::CROWS, within = lr - pi * cfg::CROWS;
                         const int m = m0 + (within >> 5) * cfg::WTM + (i0 + pi) * 32 + (within & 31);
-                        if (m >= p.M || col >= p.N) continue;
+                        if (m >= m_end || col >= p.N) continue;
                         const uint4 v = *(const uint4*)(smem + lr * ROWB + chunk * 16);
                         const uint4 sk = *(const uint4*)((const bf16_t*)p.residual + (size_t)m * p.ldr + col);
                         const uint32_t a[4] = {v.x, v.y, v.z, v.w}, b[4] = {sk.x, sk.y, sk.z, sk.w};
@@ -514,12 +534,12 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
                     const int m = row_of(i, it);
                     if (res_bf16) {
                         const bf16_t* rp = (const bf16_t*)p.residual + (size_t)(p.res_row_mod > 0 ? m % p.res_row_mod : m) * p.ldr + ncol;
-                        if constexpr (CPT == 8) rv[it][0] = (m < p.M) ? *(const uint4*)rp : make_uint4(0, 0, 0, 0);
-                        else { const uint2 r = (m < p.M) ? *(const uint2*)rp : make_uint2(0, 0); rv[it][0].x = r.x; rv[it][0].y = r.y; }
+                        if constexpr (CPT == 8) rv[it][0] = (m < m_end) ? *(const uint4*)rp : make_uint4(0, 0, 0, 0);
+                        else { const uint2 r = (m < m_end) ? *(const uint2*)rp : make_uint2(0, 0); rv[it][0].x = r.x; rv[it][0].y = r.y; }
                     } else {
 #pragma unroll
                         for (int e = 0; e < CPT / 4; ++e)
-                            rv[it][e] = (m < p.M) ? *(const uint4*)(res_ptr(m) + 4 * e) : make_uint4(0, 0, 0, 0);
+                            rv[it][e] = (m < m_end) ? *(const uint4*)(res_ptr(m) + 4 * e) : make_uint4(0, 0, 0, 0);
                     }
                 }
             };
@@ -546,7 +566,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
                         }
                     }
                     if (res_first) activate(v);
-                    if (m < p.M && (p.res_row_mod != -2003 || v[0] == 12345.678f)) store_vec((size_t)m * p.ldc + ncol, v);
+                    if (m < m_end && (p.res_row_mod != -2003 || v[0] == 12345.678f)) store_vec((size_t)m * p.ldc + ncol, v);
                 }
                 lds_barrier();                                   // slab consumed: the next pass may overwrite it
                 if (i + 1 < MI) prefetch_res(i + 1);
@@ -565,7 +585,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
 #pragma unroll 1
         for (int it = 0; it < NIT; ++it) {
             const int m = row_of(i, it);
-            if (m >= p.M || ncol >= p.N) continue;
+            if (m >= m_end || ncol >= p.N) continue;
             size_t crow;
             if (spatial) {
                 // (b, oy, ox) of row m through reciprocal multiplies (M < 2^24: exact after one correction) -- the two integer
@@ -627,7 +647,8 @@ static int launch_big(const whmr_gemm& p, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    constexpr int BME = BM - (PP == 3 ? 32 : 0);
+    const int tiles = ((p.M + BME - 1) / BME) * ((p.N + BN - 1) / BN);
     hipLaunchKernelGGL(kern, dim3(tiles * (GATHER && p.n_phase > 1 ? p.n_phase : 1), 1, p.split_k ? (unsigned)((p.K + p.split_k - 1) / p.split_k) : 1), dim3(cfg::THREADS), OUT_BF16 ? cfg::LDS16 + BN * 4 : cfg::LDS, st, p);
     WHMR_CHECK_LAUNCH();
     return 0;
@@ -672,6 +693,8 @@ extern "C" int whmr_gemm_bf16_big(const whmr_gemm* pp, int tile, void* stream) {
         case 192: return launch_big_mode<192, 256, 64, 2, 4, 2, 2, 0>(p, st);     // 112 KiB, 2 stages
         case 257: return launch_big_mode<256, 256, 64, 2, 4, 2, 2, 0>(p, st);     // 128 KiB, 2 stages
         case 320: return launch_big_mode<320, 256, 64, 2, 4, 2, 2, 0>(p, st);
+        case 160: return launch_big_mode<192, 256, 64, 2, 4, 2, 2, 3>(p, st);     // trimmed: 160 x 256 (wave rows of 96 + 64)
+        case 224: return launch_big_mode<256, 256, 64, 2, 4, 2, 2, 3>(p, st);     // trimmed: 224 x 256 (wave rows of 128 + 96)
         case 259: return launch_big_mode<256, 256, 64, 2, 4, 2, 2, 2>(p, st);     // same, 4 phases per K tile (half the barriers)     // 144 KiB, 2 stages, 160x64 wave tiles
     }
     return (int)hipErrorInvalidValue;
