@@ -212,6 +212,23 @@ int whmr_estimate_translation(const float* S, const float* joints_2d, int B, int
 int whmr_tz_tail(const float* tok, int B, int T, int D, const float* w0, const float* b0, int Hd, const float* w1,
                  const float* b1, const float* bn4, float bn_eps, float* tz, void* stream);
 
+/* ---- training mode of the deconv pyramid: ConvTranspose2d(k4,s2,p1) -> BatchNorm2d(batch statistics) -> ReLU
+ * (models/whmr.py:459-501,560-564; their autograd as driven by core/trainer.py:410-470).  Maps are channels-last [M = B*H*W, C],
+ * C % 8 == 0, 256 % (C/8) == 0.  The matrix products run on whmr_gemm_*: forward = the 4 sub-pixel phases without BN folding,
+ * dX = Conv2d(k4,s2,p1) gather of dZ (a_mode 1), dW = X^T . whmr_im2col_t(dZ). */
+/* stats [4*C] = mean | 1/sqrt(var+eps) | a = gamma*invstd | b = beta - mean*a; running_mean / running_var (nullable) get the
+ * nn.BatchNorm2d momentum update (unbiased variance).  scratch >= 2050*C floats. */
+int whmr_bn_stats(const void* z, int z_bf16, long M, int C, const float* gamma, const float* beta, float eps, float momentum,
+                  float* running_mean, float* running_var, float* stats, float* scratch, void* stream);
+/* y = relu(z*a + b). */
+int whmr_bn_apply_relu(const void* z, int z_bf16, const float* stats, void* y, int y_bf16, long M, int C, void* stream);
+/* backward of relu(bn(z)) for the upstream gradient dy: dz, dgamma, dbeta ((+)= when accumulate).  scratch >= 2050*C floats. */
+int whmr_bn_relu_bwd(const void* z, int z_bf16, const void* dy, int dy_bf16, const float* stats, void* dz, int dz_bf16, float* dgamma,
+                     float* dbeta, int accumulate, long M, int C, float* scratch, void* stream);
+/* dst[(ky*KW+kx)*C + c][m] = src[b, oy*S+ky-P, ox*S+kx-P, c] (NHWC src, zero outside), m = (b, oy, ox) < B*OH*OW, row length Mpad. */
+int whmr_im2col_t(const void* src, void* dst, int is_bf16, int B, int IH, int IW, int C, int OH, int OW, int KH, int KW, int S, int P,
+                  long Mpad, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

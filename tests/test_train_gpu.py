@@ -144,3 +144,73 @@ def test_vit_large_backward_256x192(dev):
     bad = {n: _rel(p.grad.cpu(), ref_sd[n].grad) for n, p in m.named_parameters()}
     bad = {k: v for k, v in bad.items() if not v < 4e-2}
     assert not bad, 'gradient mismatch: %s' % sorted(bad.items(), key=lambda kv: -kv[1])[:6]
+
+
+def _rms(a, b):
+    return ((a.double() - b.double()).pow(2).mean().sqrt() / b.double().pow(2).mean().sqrt().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize('numerics,tol', [('fp32', 2e-4), ('bf16', 1e-1)])
+def test_deconv_bn_relu_train_matches_autograd(dev, numerics, tol):
+    """Two chained deconv stages (768 -> 256 -> 256) in train mode: outputs, running stats and every gradient vs CPU autograd.
+    fp32: max-abs error / max-abs reference <= 2e-4.  bf16: the maps z are stored in bf16, so ~0.25 % of the ReLU gates sit within
+    one rounding step of zero and open / close differently from the fp32 reference; with the white-noise cotangent of this test
+    every flipped gate moves a gradient sum by O(1), which bounds the agreement at ~5-7 % RMS (tools/probes/deconv_bwd_diag.py:
+    the same figure at every size, also for the pure column sum dbeta) -- gated as RMS error / RMS reference <= 1e-1."""
+    _rel = globals()['_rel'] if numerics == 'fp32' else _rms
+    from oracle.train import deconv_bn_relu_train
+    from whmr_amd.train.deconv_autograd import DeconvBNReLUFn
+    dt = torch.float32 if numerics == 'fp32' else torch.bfloat16
+    g = torch.Generator().manual_seed(11)
+    B, H, W = 3, 4, 3
+    x = torch.randn(B, 768, H, W, generator=g)
+    ws = [torch.randn(768, 256, 4, 4, generator=g) * 0.02, torch.randn(256, 256, 4, 4, generator=g) * 0.03]
+    gam = [torch.rand(256, generator=g) + 0.5 for _ in range(2)]
+    bet = [torch.randn(256, generator=g) * 0.2 for _ in range(2)]
+    dy = torch.randn(B, 256, 4 * H, 4 * W, generator=g)
+    # reference
+    rx = x.clone().requires_grad_(True)
+    rp = [[t.clone().requires_grad_(True) for t in (ws[i], gam[i], bet[i])] for i in range(2)]
+    rstats = [[torch.zeros(256), torch.ones(256)] for _ in range(2)]
+    h = rx
+    for i in range(2):
+        h = deconv_bn_relu_train(h, rp[i][0], rp[i][1], rp[i][2], rstats[i][0], rstats[i][1])
+    h.backward(dy)
+    # HIP
+    bns = []
+    for i in range(2):
+        bn = torch.nn.BatchNorm2d(256, momentum=0.1).to(dev)
+        bns.append(bn)
+    dp = [[t.clone().to(dev).requires_grad_(True) for t in (ws[i], gam[i], bet[i])] for i in range(2)]
+    dx_in = x.permute(0, 2, 3, 1).contiguous().to(dev).to(dt).requires_grad_(True)
+    hh = dx_in
+    for i in range(2):
+        hh = DeconvBNReLUFn.apply(hh, dp[i][0], dp[i][1], dp[i][2], bns[i], dt)
+    assert hh.shape == (B, 4 * H, 4 * W, 256) and hh.dtype == dt
+    hh.backward(dy.permute(0, 2, 3, 1).contiguous().to(dev).to(dt))
+    assert _rel(hh.detach().float().cpu().permute(0, 3, 1, 2), h.detach()) < tol
+    for i in range(2):
+        assert _rel(bns[i].running_mean.cpu(), rstats[i][0]) < tol and _rel(bns[i].running_var.cpu(), rstats[i][1]) < tol
+        for a, b, name in zip(dp[i], rp[i], ('weight', 'gamma', 'beta')):
+            assert a.grad is not None and a.grad.shape == b.grad.shape
+            assert _rel(a.grad.float().cpu(), b.grad) < tol, (i, name, _rel(a.grad.float().cpu(), b.grad))
+    assert _rel(dx_in.grad.float().cpu().permute(0, 3, 1, 2), rx.grad) < tol
+
+
+def test_im2col_t_and_bn_kernels(dev):
+    """whmr_im2col_t against F.unfold; BN statistics with a large common offset (the shifted two-stage sum must not cancel)."""
+    from whmr_amd import _lib as L
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 64, 6, 10, generator=g)                                        # NCHW
+    for dt in (torch.float32, torch.bfloat16):
+        xs = x.to(dt)
+        t = L.im2col_t(xs.permute(0, 2, 3, 1).contiguous().to(dev), 3, 5, 4, 4, 2, 1, pad_to=64)
+        M = 2 * 3 * 5
+        assert t.shape == (16 * 64, 64) and not t[:, M:].any()
+        u = torch.nn.functional.unfold(xs.float(), 4, padding=1, stride=2)            # [B, C*16, L], k = (c, ky, kx)
+        u = u.view(2, 64, 16, 15).permute(2, 1, 0, 3).reshape(16 * 64, M)             # [(ky,kx,c), (b, oy, ox)]
+        assert torch.equal(t[:, :M].float().cpu(), u)
+    z = torch.randn(5000, 256, generator=g) * 0.01 + 100.0
+    st = L.bn_stats(z.to(dev), torch.ones(256, device=dev), torch.zeros(256, device=dev), 1e-5).cpu()
+    assert _rel(st[0], z.double().mean(0)) < 1e-6
+    assert _rel(st[1], 1.0 / torch.sqrt(z.double().var(0, unbiased=False) + 1e-5)) < 1e-4

@@ -75,6 +75,10 @@ _SIGS = {
     'whmr_regressor_state': [_P, _P, _L, _P, _L, _P, _L, _I, _P, _L, _I, _P],
     'whmr_tz_tail': [_P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _F, _P, _P],
     'whmr_conv_im2col': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _L, _L, _L, _P],
+    'whmr_bn_stats': [_P, _I, _L, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P],
+    'whmr_bn_apply_relu': [_P, _I, _P, _P, _I, _L, _I, _P],
+    'whmr_bn_relu_bwd': [_P, _I, _P, _I, _P, _P, _I, _P, _P, _I, _L, _I, _P, _P],
+    'whmr_im2col_t': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _P],
     'whmr_maxpool_nhwc': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'whmr_avgpool_nhwc': [_P, _P, _I, _I, _I, _I, _P],
 }
@@ -544,3 +548,51 @@ def estimate_translation(S, joints_2d, j0, nj, focal, img_w, img_h):
     _check(lib().whmr_estimate_translation(S.data_ptr(), joints_2d.data_ptr(), B, J, j0, nj, focal, img_w, img_h, out.data_ptr(), _stream()),
            'whmr_estimate_translation')
     return out
+
+
+# ---- training mode of the deconv pyramid (deconv_train.hip) ----------------------------------------------------------
+def _bf(t):
+    return int(t.dtype == torch.bfloat16)
+
+
+def bn_stats(z, gamma, beta, eps, momentum=0.0, running_mean=None, running_var=None):
+    """z [M, C] channels-last -> stats [4, C] = mean | invstd | a | b (fp32); running stats updated in place when given."""
+    _dev(z, gamma, beta, running_mean, running_var)
+    assert z.dim() == 2 and z.is_contiguous() and z.dtype in (torch.float32, torch.bfloat16)
+    M, Cc = z.shape
+    stats = torch.empty(4, Cc, dtype=torch.float32, device=z.device)
+    sc = train_scratch(z.device, 2050 * Cc)
+    _check(lib().whmr_bn_stats(z.data_ptr(), _bf(z), M, Cc, _ptr(gamma), _ptr(beta), eps, momentum, _ptr(running_mean), _ptr(running_var),
+                               stats.data_ptr(), sc.data_ptr(), _stream()), 'whmr_bn_stats')
+    return stats
+
+
+def bn_apply_relu(z, stats, y):
+    _dev(z, stats, y)
+    assert z.is_contiguous() and y.is_contiguous() and z.shape == y.shape
+    M, Cc = z.shape
+    _check(lib().whmr_bn_apply_relu(z.data_ptr(), _bf(z), stats.data_ptr(), y.data_ptr(), _bf(y), M, Cc, _stream()), 'whmr_bn_apply_relu')
+    return y
+
+
+def bn_relu_bwd(z, dy, stats, dz, dgamma, dbeta, accumulate=False):
+    _dev(z, dy, stats, dz, dgamma, dbeta)
+    assert z.is_contiguous() and dy.is_contiguous() and dz.is_contiguous() and z.shape == dy.shape == dz.shape
+    M, Cc = z.shape
+    sc = train_scratch(z.device, 2050 * Cc)
+    _check(lib().whmr_bn_relu_bwd(z.data_ptr(), _bf(z), dy.data_ptr(), _bf(dy), stats.data_ptr(), dz.data_ptr(), _bf(dz), dgamma.data_ptr(),
+                                  dbeta.data_ptr(), int(accumulate), M, Cc, sc.data_ptr(), _stream()), 'whmr_bn_relu_bwd')
+    return dz
+
+
+def im2col_t(src_nhwc, OH, OW, KH, KW, S, P, pad_to=64):
+    """NHWC map -> transposed column matrix [(ky, kx, c), Mpad], m = (b, oy, ox)."""
+    _dev(src_nhwc)
+    assert src_nhwc.dim() == 4 and src_nhwc.is_contiguous() and src_nhwc.dtype in (torch.float32, torch.bfloat16)
+    B, IH, IW, Cc = src_nhwc.shape
+    M = B * OH * OW
+    Mpad = (M + pad_to - 1) // pad_to * pad_to
+    dst = torch.empty(KH * KW * Cc, Mpad, dtype=src_nhwc.dtype, device=src_nhwc.device)
+    _check(lib().whmr_im2col_t(src_nhwc.data_ptr(), dst.data_ptr(), _bf(src_nhwc), B, IH, IW, Cc, OH, OW, KH, KW, S, P, Mpad, _stream()),
+           'whmr_im2col_t')
+    return dst

@@ -1,0 +1,107 @@
+"""Training mode of one deconv stage: ConvTranspose2d(k4, s2, p1, no bias) -> BatchNorm2d(batch statistics) -> ReLU.
+
+Reference semantics: the ``nn.Sequential`` built at models/whmr.py:459-501 and run at :560-564 in ``model.train()``, and its
+autograd as driven by ``core/trainer.py:410-470``.  Maps are channels-last (NHWC) like the inference path:
+
+  forward   z = sub-pixel GEMM (4 phases, one launch in bf16 mode; no BN folding, the statistics come from z itself)
+            stats = whmr_bn_stats(z) (+ running-stat update, momentum 0.1, unbiased variance)     y = relu(z*a + b)
+  backward  dz, dgamma, dbeta = whmr_bn_relu_bwd(z, dy)               (mask and xhat recomputed from the saved z)
+            dx = Conv2d(k4, s2, p1) of dz with W[ci, (ky,kx,co)]      (implicit GEMM, NHWC gather, K = 16*Cout)
+            dW = X^T [Cin, M] . col(dz)^T [(ky,kx,co), M]             (whmr_transpose_cast + whmr_im2col_t, K = M = B*H*W)
+
+``dt`` = torch.bfloat16 (perf numerics: bf16 maps and GEMM operands, fp32 statistics / parameter gradients) or torch.float32
+(parity numerics against the CPU reference's autograd).
+"""
+import torch
+
+from .. import _lib as L
+
+
+def _phase_weights(w, dt):
+    """ConvTranspose2d weight [Cin, Cout, 4, 4] -> 4 sub-pixel phase matrices [4, Cout, 4*Cin], k = (a, b, ci) (whmr.py:488-495)."""
+    phases = []
+    for py in range(2):
+        for px in range(2):
+            taps = [w[:, :, 3 - py - 2 * a, 3 - px - 2 * b] for a in range(2) for b in range(2)]          # each [Cin, Cout]
+            phases.append(torch.stack(taps, 0).permute(2, 0, 1).reshape(w.shape[1], -1))
+    p = torch.stack(phases, 0).contiguous()
+    return L.cast_bf16(p) if dt == torch.bfloat16 else p
+
+
+@torch.no_grad()
+def deconv_forward_train(x_nhwc, weight, gamma, beta, bn, dt, update_running=True):
+    """x [B,H,W,Cin] (dt) -> (y [B,2H,2W,Cout] (dt), saved).  ``bn``: the nn.BatchNorm2d whose eps / momentum / running stats are used."""
+    if not x_nhwc.is_cuda:
+        raise RuntimeError('whmr_amd deconv stages run on a HIP device only (no CPU fallback)')
+    B, H, W, Cin = x_nhwc.shape
+    Cout = weight.shape[1]
+    assert weight.shape == (Cin, Cout, 4, 4) and x_nhwc.dtype == dt and x_nhwc.is_contiguous()
+    dev = x_nhwc.device
+    wp = _phase_weights(weight.detach().float(), dt)
+    z = torch.empty(B, 2 * H, 2 * W, Cout, dtype=dt, device=dev)
+    if dt == torch.bfloat16:
+        L.gemm(x_nhwc, wp, z, conv=dict(IH=H, IW=W, Cin=Cin, OH=H, OW=W, KW=2, SH=1, SW=1, PH=1, PW=1),
+               scatter=dict(c_off=0, osb=4 * H * W * Cout, osy=4 * W * Cout, osx=2 * Cout), phases=dict(cy=2 * W * Cout, cx=Cout))
+    else:
+        for py in range(2):
+            for px in range(2):
+                L.gemm(x_nhwc, wp[py * 2 + px], z, conv=dict(IH=H, IW=W, Cin=Cin, OH=H, OW=W, KW=2, SH=1, SW=1, PH=1 - py, PW=1 - px),
+                       scatter=dict(c_off=(py * 2 * W + px) * Cout, osb=4 * H * W * Cout, osy=4 * W * Cout, osx=2 * Cout))
+    z2 = z.view(-1, Cout)
+    track = update_running and bn.track_running_stats and bn.running_mean is not None
+    stats = L.bn_stats(z2, gamma.detach(), beta.detach(), bn.eps, bn.momentum if track else 0.0,
+                       bn.running_mean if track else None, bn.running_var if track else None)
+    if track and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    y = torch.empty_like(z)
+    L.bn_apply_relu(z2, stats, y.view(-1, Cout))
+    return y, (x_nhwc, z, stats)
+
+
+@torch.no_grad()
+def deconv_backward(saved, weight, dy, dt, need_dx=True, dx_dtype=None):
+    """dy [B,2H,2W,Cout] (dt or fp32) -> (dx [B,H,W,Cin] or None, dW [Cin,Cout,4,4] fp32, dgamma [Cout], dbeta [Cout])."""
+    x, z, stats = saved
+    B, H, W, Cin = x.shape
+    Cout = z.shape[-1]
+    dev = x.device
+    dy = dy.contiguous()
+    if dy.dtype != dt and not (dt == torch.bfloat16 and dy.dtype == torch.float32):
+        dy = dy.to(dt)
+    dz = torch.empty_like(z)
+    dg, db = torch.empty(Cout, dtype=torch.float32, device=dev), torch.empty(Cout, dtype=torch.float32, device=dev)
+    L.bn_relu_bwd(z.view(-1, Cout), dy.view(-1, Cout), stats, dz.view(-1, Cout), dg, db)
+    M = B * H * W
+    # dW[ci, (ky,kx,co)] = sum_m x[m, ci] * dz[b, 2iy-1+ky, 2ix-1+kx, co]
+    pad = 64 if dt == torch.bfloat16 else 8          # the bf16 GEMM needs K % 64 == 0; rows are zero-padded up to it
+    xt = L.transpose_cast(x.view(M, Cin), dt, pad_to=pad)                                  # [Cin, Mpad]
+    colt = L.im2col_t(dz, H, W, 4, 4, 2, 1, pad_to=pad)                                    # [16*Cout, Mpad]
+    dwm = torch.empty(Cin, 16 * Cout, dtype=torch.float32, device=dev)
+    L.gemm(xt, colt, dwm)
+    dW = dwm.view(Cin, 4, 4, Cout).permute(0, 3, 1, 2)
+    del colt, xt
+    dx = None
+    if need_dx:
+        wd = weight.detach().float().permute(0, 2, 3, 1).reshape(Cin, 16 * Cout).contiguous()       # [ci, (ky,kx,co)]
+        if dt == torch.bfloat16:
+            wd = L.cast_bf16(wd)
+        dx = torch.empty(B, H, W, Cin, dtype=dx_dtype or dt, device=dev)
+        L.gemm(dz, wd, dx.view(M, Cin), conv=dict(IH=2 * H, IW=2 * W, Cin=Cout, OH=H, OW=W, KW=4, SH=2, SW=2, PH=1, PW=1))
+    return dx, dW, dg, db
+
+
+class DeconvBNReLUFn(torch.autograd.Function):
+    """y = DeconvBNReLUFn.apply(x_nhwc, ct.weight, bn.weight, bn.bias, bn, dt): autograd node of one deconv stage."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, bn, dt):
+        y, saved = deconv_forward_train(x, weight, gamma, beta, bn, dt)
+        ctx.saved, ctx.weight, ctx.dt = saved, weight, dt
+        ctx.need_dx = ctx.needs_input_grad[0]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dx, dW, dg, db = deconv_backward(ctx.saved, ctx.weight, dy, ctx.dt, need_dx=ctx.need_dx)
+        ctx.saved = None
+        return dx, dW, dg, db, None, None
