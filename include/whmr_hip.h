@@ -229,6 +229,19 @@ int whmr_bn_relu_bwd(const void* z, int z_bf16, const void* dy, int dy_bf16, con
 int whmr_im2col_t(const void* src, void* dst, int is_bf16, int B, int IH, int IW, int C, int OH, int OW, int KH, int KW, int S, int P,
                   long Mpad, void* stream);
 
+/* ---- backward of the SMPL forward (autograd through pare.models.SMPL as called at whmr.py:132-137, pose2rot=False) -------------------
+ * whmr_smpl_joints_bwd: gradients of joints49 [B,49,3] / smpl_joints45 [B,45,3] / markers (each nullable) -> d_posed_joints [B,24,3],
+ *   d_regd [B,R,3] (R = 33 with d_smpl_joints45, else 9), and the vertex picks added IN PLACE into d_verts [B,6890,3].
+ * whmr_smpl_skin_bwd: d_vposed [B,20670] and the per-block partial sums dA_partial [B,54,288] of the skinning-transform gradient.
+ * whmr_smpl_chain_bwd: reverse kinematic chain -> d_rotmat [B,24,9], d_betas [B,10]; d_pf_beta [B,217] = d_vposed . [posedirs ; S]^T
+ *   (S = shapedirs as [10, 20670]) comes from whmr_gemm_f32. */
+int whmr_smpl_joints_bwd(const struct whmr_smpl_model* m, const float* d_joints49, const float* d_smpl_joints45, const float* d_markers,
+                         int B, float* d_verts, float* d_posed_joints, float* d_regd, void* stream);
+int whmr_smpl_skin_bwd(const struct whmr_smpl_model* m, const float* betas, long beta_stride, const float* A, const float* pose_off,
+                       const float* d_verts, const float* d_regd, int R, int B, float* d_vposed, float* dA_partial, void* stream);
+int whmr_smpl_chain_bwd(const struct whmr_smpl_model* m, const float* rotmat, const float* betas, long beta_stride, const float* dA_partial,
+                        const float* d_posed_joints, const float* d_pf_beta, int B, float* d_rotmat, float* d_betas, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -214,3 +214,37 @@ def test_im2col_t_and_bn_kernels(dev):
     st = L.bn_stats(z.to(dev), torch.ones(256, device=dev), torch.zeros(256, device=dev), 1e-5).cpu()
     assert _rel(st[0], z.double().mean(0)) < 1e-6
     assert _rel(st[1], 1.0 / torch.sqrt(z.double().var(0, unbiased=False) + 1e-5)) < 1e-4
+
+
+@pytest.mark.parametrize('B', [1, 5])
+def test_smpl_backward_matches_oracle_autograd(dev, assets, B):
+    """d(betas), d(rotmats) of the SMPL forward for random cotangents on vertices, 49 joints, 45 SMPL joints and markers, against torch
+    autograd through the CPU restatement (oracle/smpl.py).  Raw (non-orthonormal) 3x3 blocks: the training path has no Gram-Schmidt."""
+    from oracle import geometry as OG
+    from oracle import smpl as OS
+    from whmr_amd.models.smpl import SMPL
+    from whmr_amd.train.smpl_autograd import SMPLFn
+    g = torch.Generator().manual_seed(40 + B)
+    betas = torch.randn(B, 10, generator=g)
+    rot = OG.batch_rodrigues(torch.randn(B * 24, 3, generator=g) * 0.7).view(B, 24, 3, 3) + 0.05 * torch.randn(B, 24, 3, 3, generator=g)
+    cv, cj = torch.randn(B, 6890, 3, generator=g), torch.randn(B, 49, 3, generator=g) * 30
+    cs, cm = torch.randn(B, 45, 3, generator=g) * 30, torch.randn(B, len(assets['ssm']), 3, generator=g) * 10
+    rb, rr = betas.clone().requires_grad_(True), rot.clone().requires_grad_(True)
+    v, j = OS.smpl_forward(rb, rr, assets['smpl'])
+    sj = OS.vertex_joint_selector(v, torch.einsum('bik,ji->bjk', v, assets['smpl']['J_regressor']))
+    mk = v[:, assets['ssm']]
+    ((v * cv).sum() + (j * cj).sum() + (sj * cs).sum() + (mk * cm).sum()).backward()
+    m = SMPL(arrays=assets['smpl'], marker_ids=assets['ssm']).to(dev)
+    db, dr = betas.clone().to(dev).requires_grad_(True), rot.clone().to(dev).requires_grad_(True)
+    hv, hj, hs, hm = SMPLFn.apply(db, dr, m)
+    assert _rel(hv.detach().cpu(), v.detach()) < 1e-5 and _rel(hj.detach().cpu(), j.detach()) < 1e-5
+    assert _rel(hs.detach().cpu(), sj.detach()) < 1e-5 and _rel(hm.detach().cpu(), mk.detach()) < 1e-6
+    ((hv * cv.to(dev)).sum() + (hj * cj.to(dev)).sum() + (hs * cs.to(dev)).sum() + (hm * cm.to(dev)).sum()).backward()
+    assert _rel(db.grad.cpu(), rb.grad) < 1e-4, _rel(db.grad.cpu(), rb.grad)
+    assert _rel(dr.grad.cpu(), rr.grad) < 1e-4, _rel(dr.grad.cpu(), rr.grad)
+    # vertices-only cotangent (no joint gradients at all)
+    db2, dr2 = betas.clone().to(dev).requires_grad_(True), rot.clone().to(dev).requires_grad_(True)
+    rb.grad = rr.grad = None
+    (OS.smpl_forward(rb, rr, assets['smpl'])[0] * cv).sum().backward()
+    (SMPLFn.apply(db2, dr2, m)[0] * cv.to(dev)).sum().backward()
+    assert _rel(db2.grad.cpu(), rb.grad) < 1e-4 and _rel(dr2.grad.cpu(), rr.grad) < 1e-4

@@ -79,6 +79,9 @@ _SIGS = {
     'whmr_bn_apply_relu': [_P, _I, _P, _P, _I, _L, _I, _P],
     'whmr_bn_relu_bwd': [_P, _I, _P, _I, _P, _P, _I, _P, _P, _I, _L, _I, _P, _P],
     'whmr_im2col_t': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _P],
+    'whmr_smpl_joints_bwd': [C.POINTER(WhmrSmplModel), _P, _P, _P, _I, _P, _P, _P, _P],
+    'whmr_smpl_skin_bwd': [C.POINTER(WhmrSmplModel), _P, _L, _P, _P, _P, _P, _I, _I, _P, _P, _P],
+    'whmr_smpl_chain_bwd': [C.POINTER(WhmrSmplModel), _P, _P, _L, _P, _P, _P, _I, _P, _P, _P],
     'whmr_maxpool_nhwc': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'whmr_avgpool_nhwc': [_P, _P, _I, _I, _I, _I, _P],
 }
@@ -596,3 +599,28 @@ def im2col_t(src_nhwc, OH, OW, KH, KW, S, P, pad_to=64):
     _check(lib().whmr_im2col_t(src_nhwc.data_ptr(), dst.data_ptr(), _bf(src_nhwc), B, IH, IW, Cc, OH, OW, KH, KW, S, P, Mpad, _stream()),
            'whmr_im2col_t')
     return dst
+
+
+def smpl_joints_bwd(model, d_joints49, d_smpl_joints45, d_markers, d_verts, d_posed_joints, d_regd):
+    _dev(d_joints49, d_smpl_joints45, d_markers, d_verts, d_posed_joints, d_regd)
+    for t in (d_joints49, d_smpl_joints45, d_markers, d_verts, d_posed_joints, d_regd):
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
+    B = d_verts.shape[0]
+    _check(lib().whmr_smpl_joints_bwd(C.byref(model), _ptr(d_joints49), _ptr(d_smpl_joints45), _ptr(d_markers), B, d_verts.data_ptr(),
+                                      d_posed_joints.data_ptr(), d_regd.data_ptr(), _stream()), 'whmr_smpl_joints_bwd')
+
+
+def smpl_skin_bwd(model, betas, A, pose_off, d_verts, d_regd, d_vposed, dA_partial):
+    _dev(betas, A, pose_off, d_verts, d_regd, d_vposed, dA_partial)
+    B = d_verts.shape[0]
+    R = 0 if d_regd is None else d_regd.shape[1]
+    _check(lib().whmr_smpl_skin_bwd(C.byref(model), betas.data_ptr(), betas.stride(0), A.data_ptr(), pose_off.data_ptr(), d_verts.data_ptr(),
+                                    _ptr(d_regd), R, B, d_vposed.data_ptr(), dA_partial.data_ptr(), _stream()), 'whmr_smpl_skin_bwd')
+
+
+def smpl_chain_bwd(model, rotmat, betas, dA_partial, d_posed_joints, d_pf_beta, d_rotmat, d_betas):
+    _dev(rotmat, betas, dA_partial, d_posed_joints, d_pf_beta, d_rotmat, d_betas)
+    B = rotmat.shape[0]
+    _check(lib().whmr_smpl_chain_bwd(C.byref(model), rotmat.data_ptr(), betas.data_ptr(), betas.stride(0), dA_partial.data_ptr(),
+                                     _ptr(d_posed_joints), d_pf_beta.data_ptr(), B, d_rotmat.data_ptr(), d_betas.data_ptr(), _stream()),
+           'whmr_smpl_chain_bwd')

@@ -358,3 +358,223 @@ extern "C" int whmr_regressor_state(const float* bbox_info, const float* pose, l
     WHMR_CHECK_LAUNCH();
     return 0;
 }
+
+
+// =====================================================================================================================
+// Backward of the SMPL forward above (training; reference: autograd through pare.models.SMPL / smplx lbs as called at
+// models/whmr.py:132-137 with pose2rot=False, driven by core/trainer.py:410-470).  Inputs of the differentiated function:
+// betas [B,10], rotmats [B,24,3,3]; outputs: verts, joints49 (+ smpl_joints45, markers).  Four launches + one GEMM:
+//   smpl_joints_bwd  d(joints49 / smpl_joints45 / markers) -> d(posed joints), d(regressed rows), vertex picks added into d_verts
+//   smpl_skin_bwd    vertex-parallel: d_vposed = T_rot^T dv, per-block partial sums of dA_j = sum_v w_vj [dv (x) v_posed | dv]
+//   (GEMM)           [B,20670] x [posedirs ; shapedirs]^T -> d(pose feature) [B,207] | d(betas via v_shaped) [B,10]
+//   smpl_chain_bwd   per image: partial sums -> dA, reverse kinematic chain -> d(rotmats), d(betas)
+// All reductions are fixed-order (no atomics): the vertex picks are distinct indices, so the in-place adds cannot collide.
+#define SKIN_BWD_BLOCKS ((NV + 127) / 128)
+
+__global__ __launch_bounds__(256) void smpl_joints_bwd_kernel(const whmr_smpl_model m, const float* __restrict__ d_joints49,
+                                                              const float* __restrict__ d_smpl_joints45, const float* __restrict__ d_markers,
+                                                              float* __restrict__ d_verts, float* __restrict__ d_posed_joints,
+                                                              float* __restrict__ d_regd, int R) {
+    __shared__ float d54[54][3];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid < 54 * 3) {
+        const int s = tid / 3, c = tid % 3;
+        float a = 0.f;
+        if (d_joints49)
+            for (int j = 0; j < 49; ++j) if (m.joint_map[j] == s) a += d_joints49[((size_t)b * 49 + j) * 3 + c];
+        d54[s][c] = a;
+    }
+    __syncthreads();
+    float* dv = d_verts + (size_t)b * NV * 3;
+    if (tid < 24 * 3) d_posed_joints[(size_t)b * 72 + tid] = d54[tid / 3][tid % 3];
+    if (tid < R * 3) {
+        const int r = tid / 3, c = tid % 3;
+        d_regd[((size_t)b * R + r) * 3 + c] = r < 9 ? d54[45 + r][c] : d_smpl_joints45[((size_t)b * 45 + (r - 9)) * 3 + c];
+    }
+    if (tid < 21 * 3) {
+        const int i = tid / 3, c = tid % 3;
+        float a = d54[24 + i][c];
+        if (d_smpl_joints45) a += d_smpl_joints45[((size_t)b * 45 + 24 + i) * 3 + c];
+        dv[3 * m.extra_vertex_ids[i] + c] += a;
+    }
+    __syncthreads();                                    // markers may pick the same vertices as the joint selector: ordered second
+    if (d_markers)
+        for (int e = tid; e < m.n_markers * 3; e += 256) dv[3 * m.marker_ids[e / 3] + e % 3] += d_markers[(size_t)b * m.n_markers * 3 + e];
+}
+
+__global__ __launch_bounds__(128) void smpl_skin_bwd_kernel(const whmr_smpl_model m, const float* __restrict__ betas, long beta_stride,
+                                                            const float* __restrict__ A, const float* __restrict__ pose_off,
+                                                            const float* __restrict__ d_verts, const float* __restrict__ d_regd, int R,
+                                                            float* __restrict__ d_vposed, float* __restrict__ dA_partial) {
+    __shared__ __attribute__((aligned(16))) float sA[NJ * 12];
+    __shared__ float sBeta[10];
+    __shared__ float sReg[33 * 3];
+    __shared__ float sQ[12][129];
+    __shared__ float sW[NJ][129];
+    const int tid = threadIdx.x, b = blockIdx.y, v = blockIdx.x * 128 + tid;
+    for (int e = tid; e < NJ * 12; e += 128) sA[e] = A[(size_t)b * NJ * 12 + e];
+    if (tid < 10) sBeta[tid] = betas[(size_t)b * beta_stride + tid];
+    if (tid < R * 3) sReg[tid] = d_regd[(size_t)b * R * 3 + tid];
+    __syncthreads();
+    float q[12], w[NJ];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) q[e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) w[j] = 0.f;
+    if (v < NV) {
+        float vp[3];
+        {   // v_posed recomputed like the forward: T + S.beta + pose_off
+            float s[30];
+#pragma unroll
+            for (int k = 0; k < 30; ++k) s[k] = m.shapedirs[(size_t)k * NV + v];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float a = 0.f;
+#pragma unroll
+                for (int l = 0; l < 10; ++l) a = fmaf(s[c * 10 + l], sBeta[l], a);
+                vp[c] = m.v_template[3 * v + c] + a + pose_off[((size_t)b * NV + v) * 3 + c];
+            }
+        }
+        float dv[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dv[c] = d_verts[((size_t)b * NV + v) * 3 + c];
+        for (int r = 0; r < R; ++r) {                    // regressed joints: d_verts += reg^T . d_regd
+            const float g = m.J_regressor_extra[(size_t)r * NV + v];
+            dv[0] = fmaf(g, sReg[r * 3], dv[0]); dv[1] = fmaf(g, sReg[r * 3 + 1], dv[1]); dv[2] = fmaf(g, sReg[r * 3 + 2], dv[2]);
+        }
+        float T[9];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) T[e] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            w[j] = m.lbs_weights[(size_t)j * NV + v];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) T[r * 3 + c] = fmaf(w[j], sA[j * 12 + r * 4 + c], T[r * 3 + c]);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            d_vposed[((size_t)b * NV + v) * 3 + c] = T[c] * dv[0] + T[3 + c] * dv[1] + T[6 + c] * dv[2];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            q[r * 4] = dv[r] * vp[0]; q[r * 4 + 1] = dv[r] * vp[1]; q[r * 4 + 2] = dv[r] * vp[2]; q[r * 4 + 3] = dv[r];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 12; ++e) sQ[e][tid] = q[e];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) sW[j][tid] = w[j];
+    __syncthreads();
+    for (int e = tid; e < NJ * 12; e += 128) {
+        const int j = e / 12, k = e % 12;
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll 8
+        for (int u = 0; u < 128; u += 2) { a0 = fmaf(sW[j][u], sQ[k][u], a0); a1 = fmaf(sW[j][u + 1], sQ[k][u + 1], a1); }
+        dA_partial[((size_t)b * gridDim.x + blockIdx.x) * (NJ * 12) + e] = a0 + a1;
+    }
+}
+
+__global__ __launch_bounds__(64) void smpl_chain_bwd_kernel(const whmr_smpl_model m, const float* __restrict__ rotmat, const float* __restrict__ betas,
+                                                            long beta_stride, const float* __restrict__ dA_partial, int nparts,
+                                                            const float* __restrict__ d_posed_joints, const float* __restrict__ d_pf_beta,
+                                                            float* __restrict__ d_rotmat, float* __restrict__ d_betas) {
+    __shared__ float sR[NJ][9], sJ[NJ][3], sGr[NJ][9], sGt[NJ][3];
+    __shared__ float dA[NJ][12], dGr[NJ][9], dT[NJ][3], dJ[NJ][3], dR[NJ][9];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    for (int e = lane; e < NJ * 9; e += 64) sR[e / 9][e % 9] = rotmat[(size_t)b * NJ * 9 + e];
+    for (int e = lane; e < NJ * 3; e += 64) {
+        float acc = 0.f;
+        for (int l = 0; l < 10; ++l) acc = fmaf(m.J_shapedirs[e * 10 + l], betas[(size_t)b * beta_stride + l], acc);
+        sJ[e / 3][e % 3] = m.J_template[e] + acc;
+    }
+    for (int e = lane; e < NJ * 12; e += 64) {
+        float a = 0.f;
+        for (int p = 0; p < nparts; ++p) a += dA_partial[((size_t)b * nparts + p) * (NJ * 12) + e];
+        dA[e / 12][e % 12] = a;
+    }
+    __syncthreads();
+    // forward chain (global rotations / translations)
+    if (lane < 9) sGr[0][lane] = sR[0][lane];
+    if (lane < 3) sGt[0][lane] = sJ[0][lane];
+    __syncthreads();
+    for (int i = 1; i < NJ; ++i) {
+        const int p = m.parents[i];
+        if (lane < 9) {
+            const int r = lane / 3, c = lane % 3;
+            sGr[i][lane] = sGr[p][r * 3] * sR[i][c] + sGr[p][r * 3 + 1] * sR[i][3 + c] + sGr[p][r * 3 + 2] * sR[i][6 + c];
+        } else if (lane < 12) {
+            const int r = lane - 9;
+            sGt[i][r] = sGr[p][r * 3] * (sJ[i][0] - sJ[p][0]) + sGr[p][r * 3 + 1] * (sJ[i][1] - sJ[p][1]) + sGr[p][r * 3 + 2] * (sJ[i][2] - sJ[p][2]) + sGt[p][r];
+        }
+        __syncthreads();
+    }
+    // A_i = [Gr_i | t_i - Gr_i J_i],  posed_joints_i = t_i
+    for (int e = lane; e < NJ * 9; e += 64) {
+        const int j = e / 9, r = (e % 9) / 3, c = e % 3;
+        dGr[j][r * 3 + c] = dA[j][r * 4 + c] - dA[j][r * 4 + 3] * sJ[j][c];
+    }
+    for (int e = lane; e < NJ * 3; e += 64) {
+        const int j = e / 3, c = e % 3;
+        dT[j][c] = dA[j][c * 4 + 3] + (d_posed_joints ? d_posed_joints[(size_t)b * 72 + e] : 0.f);
+        dJ[j][c] = -(sGr[j][c] * dA[j][3] + sGr[j][3 + c] * dA[j][7] + sGr[j][6 + c] * dA[j][11]);
+    }
+    __syncthreads();
+    for (int i = NJ - 1; i >= 1; --i) {
+        const int p = m.parents[i];
+        if (lane < 9) {
+            const int r = lane / 3, c = lane % 3;
+            dR[i][lane] = sGr[p][r] * dGr[i][c] + sGr[p][3 + r] * dGr[i][3 + c] + sGr[p][6 + r] * dGr[i][6 + c];
+            dGr[p][lane] += dGr[i][r * 3] * sR[i][c * 3] + dGr[i][r * 3 + 1] * sR[i][c * 3 + 1] + dGr[i][r * 3 + 2] * sR[i][c * 3 + 2]
+                          + dT[i][r] * (sJ[i][c] - sJ[p][c]);
+        } else if (lane < 12) {
+            const int c = lane - 9;
+            const float g = sGr[p][c] * dT[i][0] + sGr[p][3 + c] * dT[i][1] + sGr[p][6 + c] * dT[i][2];
+            dJ[i][c] += g;
+            dJ[p][c] -= g;
+            dT[p][c] += dT[i][c];
+        }
+        __syncthreads();
+    }
+    if (lane < 9) dR[0][lane] = dGr[0][lane];
+    if (lane < 3) dJ[0][lane] += dT[0][lane];
+    __syncthreads();
+    for (int e = lane; e < NJ * 9; e += 64)
+        d_rotmat[(size_t)b * NJ * 9 + e] = dR[e / 9][e % 9] + (e >= 9 ? d_pf_beta[(size_t)b * 217 + e - 9] : 0.f);
+    if (lane < 10) {
+        float a = d_pf_beta[(size_t)b * 217 + NPF + lane];
+        for (int e = 0; e < NJ * 3; ++e) a = fmaf(m.J_shapedirs[e * 10 + lane], dJ[e / 3][e % 3], a);
+        d_betas[(size_t)b * 10 + lane] = a;
+    }
+}
+
+// d_verts [B,6890,3] is read-modify-write (vertex picks are added in place); d_posed_joints [B,24,3]; d_regd [B,R,3] with
+// R = 33 when d_smpl_joints45 is given, else 9.
+extern "C" int whmr_smpl_joints_bwd(const whmr_smpl_model* m, const float* d_joints49, const float* d_smpl_joints45, const float* d_markers,
+                                    int B, float* d_verts, float* d_posed_joints, float* d_regd, void* stream) {
+    if (B <= 0 || !d_verts || !d_posed_joints || !d_regd) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(smpl_joints_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, *m, d_joints49, d_smpl_joints45, d_markers, d_verts,
+                       d_posed_joints, d_regd, d_smpl_joints45 ? 33 : 9);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+// d_vposed [B,20670]; dA_partial [B, 54, 288] (54 = vertex blocks of 128).  R rows of d_regd (0, 9 or 33; regressor rows as in whmr_smpl_joints).
+extern "C" int whmr_smpl_skin_bwd(const whmr_smpl_model* m, const float* betas, long beta_stride, const float* A, const float* pose_off,
+                                  const float* d_verts, const float* d_regd, int R, int B, float* d_vposed, float* dA_partial, void* stream) {
+    if (B <= 0 || !pose_off || (R != 0 && R != 9 && R != 33)) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(smpl_skin_bwd_kernel, dim3(SKIN_BWD_BLOCKS, B), dim3(128), 0, (hipStream_t)stream, *m, betas, beta_stride, A, pose_off, d_verts,
+                       d_regd, R, d_vposed, dA_partial);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+// d_pf_beta [B,217] = d_vposed . [posedirs (207 rows) ; shapedirs as [10, 20670]]^T (whmr_gemm_f32).
+extern "C" int whmr_smpl_chain_bwd(const whmr_smpl_model* m, const float* rotmat, const float* betas, long beta_stride, const float* dA_partial,
+                                   const float* d_posed_joints, const float* d_pf_beta, int B, float* d_rotmat, float* d_betas, void* stream) {
+    if (B <= 0) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(smpl_chain_bwd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, *m, rotmat, betas, beta_stride, dA_partial, SKIN_BWD_BLOCKS,
+                       d_posed_joints, d_pf_beta, d_rotmat, d_betas);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}
