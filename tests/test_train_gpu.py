@@ -248,3 +248,59 @@ def test_smpl_backward_matches_oracle_autograd(dev, assets, B):
     (OS.smpl_forward(rb, rr, assets['smpl'])[0] * cv).sum().backward()
     (SMPLFn.apply(db2, dr2, m)[0] * cv.to(dev)).sum().backward()
     assert _rel(db2.grad.cpu(), rb.grad) < 1e-4 and _rel(dr2.grad.cpu(), rr.grad) < 1e-4
+
+
+@pytest.mark.parametrize('map_dtype', [torch.float32, torch.bfloat16])
+def test_maf_sampler_backward_matches_autograd(dev, map_dtype):
+    """d(feature map) and d(Conv1d weights / biases) of the sampler against torch autograd through grid_sample + the point MLP
+    (oracle/whmr.py restatement of maf_extractor.py:75-124), for 2-D points (incl. out-of-range ones) and projected 3-D points."""
+    import torch.nn.functional as F
+    from whmr_amd.models.maf_extractor import MAF_Extractor
+    from whmr_amd.train.maf_autograd import MAFSampleFn
+    g = torch.Generator().manual_seed(3)
+    B, H, W, P = 3, 10, 7, 21
+    ext = MAF_Extractor()
+    for p_ in ext.parameters():
+        p_.data = torch.randn(p_.shape, generator=g) * (0.1 if p_.dim() > 1 else 0.05)
+    fmap = torch.randn(B, 256, H, W, generator=g).to(map_dtype).float()
+    pts2 = torch.rand(B, P, 2, generator=g) * 2.4 - 1.2
+    pts3 = torch.randn(B, P, 3, generator=g) * 0.4
+    cam = torch.cat([torch.rand(B, 1, generator=g) * 0.5 + 0.7, torch.randn(B, 2, generator=g) * 0.1], 1)
+    cot = torch.randn(B, 32 * P, generator=g)
+
+    def ref(pts):
+        fm = fmap.clone().requires_grad_(True)
+        ps = [p_.detach().clone().requires_grad_(True) for p_ in ext.parameters()]
+        pf = F.grid_sample(fm, pts.unsqueeze(2), align_corners=True)[..., 0]            # maf_extractor.py:118
+        y = pf
+        for i in range(3):                                                              # maf_extractor.py:84-99
+            y = F.conv1d(y, ps[2 * i], ps[2 * i + 1])
+            y = F.leaky_relu(y) if i < 2 else F.relu(y)
+            if i < 2:
+                y = torch.cat([y, pf], 1)
+        y = y.reshape(B, -1)
+        y.backward(cot)
+        return y.detach(), fm.grad, [p_.grad for p_ in ps]
+
+    ext_d = MAF_Extractor().to(dev)
+    ext_d.load_state_dict(ext.state_dict())
+    for mode in ('2d', '3d'):
+        if mode == '2d':
+            y_ref, gmap_ref, gp_ref = ref(pts2)
+        else:
+            tz = 2 * 1000.0 / (256.0 * cam[:, 0] + 1e-9)                              # utils/geometry.py:289-307 with the cfg res 256
+            z = pts3[..., 2] + tz[:, None]
+            p2 = torch.stack([1000.0 * (pts3[..., 0] + cam[:, 1:2]) / z / 128.0, 1000.0 * (pts3[..., 1] + cam[:, 2:3]) / z / 128.0], -1)
+            y_ref, gmap_ref, gp_ref = ref(p2)
+        fm_d = fmap.permute(0, 2, 3, 1).contiguous().to(dev).to(map_dtype).permute(0, 3, 1, 2).requires_grad_(True)
+        ps_d = [p_.detach().clone().requires_grad_(True) for p_ in ext_d.parameters()]
+        args = (pts2.to(dev), None, None) if mode == '2d' else (None, pts3.to(dev), cam.to(dev))
+        y = MAFSampleFn.apply(fm_d, *ps_d, ext_d, *args)
+        # the weights actually used are ext_d's (same values as ps_d)
+        assert _rel(y.detach().cpu(), y_ref) < 1e-5
+        y.backward(cot.to(dev))
+        # a bf16 leaf receives its gradient rounded to bf16 by autograd (2^-9 relative); the kernel's own output is fp32
+        map_tol = 1e-4 if map_dtype == torch.float32 else 4e-3
+        assert _rel(fm_d.grad.float().cpu(), gmap_ref) < map_tol, (mode, _rel(fm_d.grad.float().cpu(), gmap_ref))
+        for a, b_ in zip(ps_d, gp_ref):
+            assert a.grad.shape == b_.shape and _rel(a.grad.cpu(), b_) < 1e-4, (mode, a.shape, _rel(a.grad.cpu(), b_))

@@ -338,3 +338,195 @@ extern "C" int whmr_tz_tail(const float* tok, int B, int T, int D, const float* 
     WHMR_CHECK_LAUNCH();
     return 0;
 }
+
+
+// =====================================================================================================================
+// Backward of the sampler (training; reference: autograd of MAF_Extractor.sampling / .reduce_dim, models/maf_extractor.py:75-124,
+// driven by core/trainer.py:410-470).  The sample points carry no gradient: the reference detaches markers / pred_cam before the
+// call (models/whmr.py:586-592) and the iteration-0 grid is a constant buffer.  What flows back:
+//   d(fmap)  : the bilinear weights times d(f), scatter-added into an fp32 gradient map (hardware fp32 atomics: two points may
+//              share a texel; the map is zero-filled by the caller)
+//   d(MLP weights): the kernel recomputes the activations of its 8 points and writes, point-minor (= K-contiguous for the GEMM),
+//              XT = [y0 (128) ; f (256) ; y1 (64)] x [B*P] and DT = [d_pre0 (128) ; d_pre1 (64) ; d_pre2 (32)] x [B*P];
+//              dW_l = DT_l . XT_l^T then runs on whmr_gemm_f32 (K = B*P), the bias gradients are DT's row sums.
+// wts holds the transposed [in][out] weights of the forward; w0 / w1 / w2 are the Conv1d-layout [out][in] matrices.
+template <typename TF>
+__global__ __launch_bounds__(256) void maf_sample_bwd_kernel(const TF* __restrict__ fmap, long sb, long sc, long sy, long sx, int H, int W,
+                                                             const float* __restrict__ pts2d, const float* __restrict__ pts3d,
+                                                             const float* __restrict__ cam, long cam_ld, float focal, float res_w, float res_h,
+                                                             const whmr_maf_weights wts, const float* __restrict__ w0, const float* __restrict__ w1,
+                                                             const float* __restrict__ w2, int P, const float* __restrict__ d_out, long dout_stride,
+                                                             float* __restrict__ d_fmap, long gsb, long gsc, long gsy, long gsx,
+                                                             float* __restrict__ XT, float* __restrict__ DT, long ldt) {
+    __shared__ float sF[CF][PT], sY0[128][PT], sY1[64][PT];
+    __shared__ float sD0[128][PT], sD1[64][PT], sD2[32][PT], sDF[CF][PT];
+    __shared__ float sWgt[PT][4];
+    __shared__ int sIdx[PT][4];                // texel offsets (y*W + x) or -1
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y, p0 = blockIdx.x * PT;
+    const int np = min(PT, P - p0);
+    if (tid < PT) {
+        float wq[4] = {0.f, 0.f, 0.f, 0.f};
+        int iq[4] = {-1, -1, -1, -1};
+        if (tid < np) {
+            const int p = p0 + tid;
+            float x, y;
+            if (pts3d) {
+                const float s = cam[cam_ld * b], tx = cam[cam_ld * b + 1], ty = cam[cam_ld * b + 2];
+                const float tz = 2 * focal / (res_h * s + 1e-9f);
+                const float* q = pts3d + ((size_t)b * P + p) * 3;
+                const float z = q[2] + tz;
+                x = (focal * ((q[0] + tx) / z)) / (res_w / 2.f);
+                y = (focal * ((q[1] + ty) / z)) / (res_h / 2.f);
+            } else {
+                x = pts2d[((size_t)b * P + p) * 2];
+                y = pts2d[((size_t)b * P + p) * 2 + 1];
+            }
+            const float ix = ((x + 1.f) / 2.f) * (float)(W - 1), iy = ((y + 1.f) / 2.f) * (float)(H - 1);
+            const float fx0 = floorf(ix), fy0 = floorf(iy);
+            const int x0 = (int)fx0, y0 = (int)fy0;
+            const float wx1 = ix - fx0, wx0 = (fx0 + 1.f) - ix, wy1 = iy - fy0, wy0 = (fy0 + 1.f) - iy;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int xx = x0 + (t & 1), yy = y0 + (t >> 1);
+                if ((unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H) { iq[t] = yy * W + xx; wq[t] = ((t & 1) ? wx1 : wx0) * ((t >> 1) ? wy1 : wy0); }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { sWgt[tid][t] = wq[t]; sIdx[tid][t] = iq[t]; }
+    }
+    __syncthreads();
+    {   // gather: thread = channel
+        const TF* fc = fmap + (size_t)b * sb + (size_t)tid * sc;
+        for (int pp = 0; pp < PT; ++pp) {
+            float v = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int id = sIdx[pp][t];
+                if (id >= 0) v += io<TF>::ld(fc + (size_t)(id / W) * sy + (size_t)(id % W) * sx) * sWgt[pp][t];
+            }
+            sF[tid][pp] = v;
+        }
+    }
+    __syncthreads();
+    // ---- forward recompute (same summation order as maf_sample_kernel: bias first, inputs in index order)
+    if (tid < 128) {
+        float acc[PT];
+#pragma unroll
+        for (int pp = 0; pp < PT; ++pp) acc[pp] = wts.b0[tid];
+        for (int i = 0; i < CF; ++i) {
+            const float w = wts.w0t[(size_t)i * 128 + tid];
+#pragma unroll
+            for (int pp = 0; pp < PT; ++pp) acc[pp] = fmaf(w, sF[i][pp], acc[pp]);
+        }
+#pragma unroll
+        for (int pp = 0; pp < PT; ++pp) sY0[tid][pp] = acc[pp] > 0.f ? acc[pp] : 0.01f * acc[pp];
+    }
+    __syncthreads();
+    {
+        const int o = tid & 63, hp = (tid >> 6) * 2;
+        float acc[2] = {wts.b1[o], wts.b1[o]};
+        for (int i = 0; i < 128; ++i) { const float w = wts.w1t[(size_t)i * 64 + o]; acc[0] = fmaf(w, sY0[i][hp], acc[0]); acc[1] = fmaf(w, sY0[i][hp + 1], acc[1]); }
+        for (int i = 0; i < CF; ++i) { const float w = wts.w1t[(size_t)(128 + i) * 64 + o]; acc[0] = fmaf(w, sF[i][hp], acc[0]); acc[1] = fmaf(w, sF[i][hp + 1], acc[1]); }
+        sY1[o][hp] = acc[0] > 0.f ? acc[0] : 0.01f * acc[0];
+        sY1[o][hp + 1] = acc[1] > 0.f ? acc[1] : 0.01f * acc[1];
+    }
+    __syncthreads();
+    {   // layer 2 + ReLU gate + upstream gradient: thread = (output channel, point)
+        const int o = tid & 31, pp = tid >> 5;
+        float acc = wts.b2[o];
+        for (int i = 0; i < 64; ++i) acc = fmaf(wts.w2t[(size_t)i * 32 + o], sY1[i][pp], acc);
+        for (int i = 0; i < CF; ++i) acc = fmaf(wts.w2t[(size_t)(64 + i) * 32 + o], sF[i][pp], acc);
+        const int p = p0 + pp;
+        sD2[o][pp] = (p < P && acc > 0.f) ? d_out[(size_t)b * dout_stride + (size_t)o * P + p] : 0.f;
+    }
+    __syncthreads();
+    // ---- d(inputs of layer 2) = W2^T d2: inputs [y1 (64) | f (256)]
+    for (int i = tid; i < 320; i += 256) {
+        float acc[PT];
+#pragma unroll
+        for (int pp = 0; pp < PT; ++pp) acc[pp] = 0.f;
+        for (int o = 0; o < 32; ++o) {
+            const float w = w2[(size_t)o * 320 + i];
+#pragma unroll
+            for (int pp = 0; pp < PT; ++pp) acc[pp] = fmaf(w, sD2[o][pp], acc[pp]);
+        }
+        if (i < 64) {
+#pragma unroll
+            for (int pp = 0; pp < PT; ++pp) sD1[i][pp] = sY1[i][pp] > 0.f ? acc[pp] : 0.01f * acc[pp];
+        } else {
+#pragma unroll
+            for (int pp = 0; pp < PT; ++pp) sDF[i - 64][pp] = acc[pp];
+        }
+    }
+    __syncthreads();
+    // ---- layer 1: inputs [y0 (128) | f (256)]
+    for (int i = tid; i < 384; i += 256) {
+        float acc[PT];
+#pragma unroll
+        for (int pp = 0; pp < PT; ++pp) acc[pp] = 0.f;
+        for (int o = 0; o < 64; ++o) {
+            const float w = w1[(size_t)o * 384 + i];
+#pragma unroll
+            for (int pp = 0; pp < PT; ++pp) acc[pp] = fmaf(w, sD1[o][pp], acc[pp]);
+        }
+        if (i < 128) {
+#pragma unroll
+            for (int pp = 0; pp < PT; ++pp) sD0[i][pp] = sY0[i][pp] > 0.f ? acc[pp] : 0.01f * acc[pp];
+        } else {
+#pragma unroll
+            for (int pp = 0; pp < PT; ++pp) sDF[i - 128][pp] += acc[pp];
+        }
+    }
+    __syncthreads();
+    {   // layer 0: inputs f (256); thread = channel
+        float acc[PT];
+#pragma unroll
+        for (int pp = 0; pp < PT; ++pp) acc[pp] = 0.f;
+        for (int o = 0; o < 128; ++o) {
+            const float w = w0[(size_t)o * CF + tid];
+#pragma unroll
+            for (int pp = 0; pp < PT; ++pp) acc[pp] = fmaf(w, sD0[o][pp], acc[pp]);
+        }
+        // scatter d(f) into the gradient map
+        float* gc = d_fmap ? d_fmap + (size_t)b * gsb + (size_t)tid * gsc : nullptr;
+        for (int pp = 0; pp < np; ++pp) {
+            const float df = sDF[tid][pp] + acc[pp];
+            if (gc) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int id = sIdx[pp][t];
+                    if (id >= 0) unsafeAtomicAdd(gc + (size_t)(id / W) * gsy + (size_t)(id % W) * gsx, df * sWgt[pp][t]);
+                }
+            }
+        }
+    }
+    // ---- operands of the weight-gradient GEMMs, point-minor
+    const long col0 = (long)b * P + p0;
+    for (int e = tid; e < 448 * PT; e += 256) {
+        const int r = e / PT, pp = e % PT;
+        if (pp < np) XT[(size_t)r * ldt + col0 + pp] = r < 128 ? sY0[r][pp] : (r < 384 ? sF[r - 128][pp] : sY1[r - 384][pp]);
+    }
+    for (int e = tid; e < 224 * PT; e += 256) {
+        const int r = e / PT, pp = e % PT;
+        if (pp < np) DT[(size_t)r * ldt + col0 + pp] = r < 128 ? sD0[r][pp] : (r < 192 ? sD1[r - 128][pp] : sD2[r - 192][pp]);
+    }
+}
+
+// d_out [B, >= 32*P rows of stride dout_stride]; d_fmap (nullable) fp32 with element strides (gsb, gsc, gsy, gsx), accumulated into;
+// XT [448, ldt], DT [224, ldt] with ldt >= B*P (the caller zero-fills the padding columns once).
+extern "C" int whmr_maf_sample_bwd(const void* fmap, int fmap_bf16, long sb, long sc, long sy, long sx, int H, int W, const float* pts2d,
+                                   const float* pts3d, const float* cam, long cam_ld, float focal, float res_w, float res_h,
+                                   const whmr_maf_weights* w, const float* w0, const float* w1, const float* w2, int B, int P,
+                                   const float* d_out, long dout_stride, float* d_fmap, long gsb, long gsc, long gsy, long gsx, float* XT,
+                                   float* DT, long ldt, void* stream) {
+    if (B <= 0 || P <= 0 || (!pts2d == !pts3d) || (pts3d && !cam) || dout_stride < 32L * P || ldt < (long)B * P) return (int)hipErrorInvalidValue;
+    dim3 grid((P + PT - 1) / PT, B), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (fmap_bf16) hipLaunchKernelGGL(maf_sample_bwd_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)fmap, sb, sc, sy, sx, H, W, pts2d, pts3d, cam, cam_ld,
+                                      focal, res_w, res_h, *w, w0, w1, w2, P, d_out, dout_stride, d_fmap, gsb, gsc, gsy, gsx, XT, DT, ldt);
+    else hipLaunchKernelGGL(maf_sample_bwd_kernel<float>, grid, block, 0, st, (const float*)fmap, sb, sc, sy, sx, H, W, pts2d, pts3d, cam, cam_ld, focal,
+                            res_w, res_h, *w, w0, w1, w2, P, d_out, dout_stride, d_fmap, gsb, gsc, gsy, gsx, XT, DT, ldt);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}
