@@ -254,6 +254,11 @@ int whmr_maf_sample_bwd(const void* fmap, int fmap_bf16, long sb, long sc, long 
                         const float* d_out, long dout_stride, float* d_fmap, long gsb, long gsc, long gsy, long gsx, float* XT,
                         float* DT, long ldt, void* stream);
 
+/* col2im (gather form): dx [B,IH,IW,C] = fold of the column-space gradient dcol [(b,oy,ox)][(ky,kx,c)] (row stride ldcol) of a strided,
+ * padded Conv2d -- the data gradient of the Tz-head convolutions (whmr.py:419-420) after dcol = dY . W on whmr_gemm_*. */
+int whmr_col2im(const void* dcol, int dcol_bf16, long ldcol, void* dx, int dx_bf16, int B, int IH, int IW, int C, int OH, int OW,
+                int KH, int KW, int S, int P, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,3 +13,101 @@ def deconv_bn_relu_train(x, weight, gamma, beta, running_mean=None, running_var=
     z = F.conv_transpose2d(x, weight, None, stride=2, padding=1, output_padding=0)
     z = F.batch_norm(z, running_mean, running_var, gamma, beta, training=True, momentum=momentum, eps=eps)
     return F.relu(z)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# WHMR.forward in model.train() (models/whmr.py:503-678 as driven by core/trainer.py:410-470), functional over a state dict whose
+# tensors may require grad.  Dropout is the identity here (the parity runs set p = 0 on both sides: the masks are random draws).
+# Pinned against the imported reference by tests/golden/make_golden_train.py (per-stage outputs and every parameter gradient).
+from . import geometry as G
+from . import smpl as S
+from . import whmr as OW
+from .vit import vit_forward
+
+TRAIN_LOSS_KEYS = ('rotmat', 'pred_shape', 'pred_cam', 'kp_2d', 'kp_2d_w', 'kp_3d', 'verts', 'sub_verts', 'temp_verts', 'focal_length')
+
+
+def _bn_train(x, sd, p, stats):
+    rm, rv = sd[p + 'running_mean'].detach().clone(), sd[p + 'running_var'].detach().clone()
+    y = F.batch_norm(x, rm, rv, sd[p + 'weight'], sd[p + 'bias'], True, 0.1, OW.BN_EPS)
+    if stats is not None:
+        stats[p + 'running_mean'], stats[p + 'running_var'] = rm, rv
+    return y
+
+
+def tz_head_train(sd, s_feat, stats=None):
+    """whmr.py:567-577, est_Tz's BatchNorm1d with batch statistics."""
+    B = s_feat.shape[0]
+    y = F.conv2d(s_feat, sd['conv.0.weight'], None, stride=3)
+    y = F.conv2d(y, sd['conv.1.weight'], None, stride=2).reshape(B, 5, -1)
+    y = OW.timm_block(sd, y, 'transformer_decoder.', 2).transpose(1, 2)
+    y = F.avg_pool1d(y, 5).squeeze(-1)
+    y = F.linear(F.linear(y, sd['est_Tz.0.weight'], sd['est_Tz.0.bias']), sd['est_Tz.1.weight'], sd['est_Tz.1.bias'])
+    return 10.0 * torch.sigmoid(_bn_train(y, sd, 'est_Tz.2.', stats)).squeeze(-1)
+
+
+def regressor_forward_train(sd, assets, i, x, bbox_info, Tz, orig_shape, center, scale, bbox_height, pose, shape, cam, stage=2):
+    """whmr.py:102-209 with is_train=True, n_iter=1, J_regressor=None (no Gram-Schmidt; TRAIN.STAGE detach rules at :142-163)."""
+    p = 'regressor.%d.' % i
+    B = x.shape[0]
+    x = torch.cat((x, bbox_info), dim=1)
+    pose = pose.reshape(B, -1)
+    xc = torch.cat([x, pose, shape, cam], 1)
+    xc = F.linear(F.linear(xc, sd[p + 'fc1.weight'], sd[p + 'fc1.bias']), sd[p + 'fc2.weight'], sd[p + 'fc2.bias'])
+    pose = F.linear(xc, sd[p + 'decpose.weight'], sd[p + 'decpose.bias']) + pose
+    shape = F.linear(xc, sd[p + 'decshape.weight'], sd[p + 'decshape.bias']) + shape
+    cam = F.linear(xc, sd[p + 'deccam.weight'], sd[p + 'deccam.bias']) + cam
+    rotmat = pose.view(B, 24, 3, 3)
+    verts, joints = S.smpl_forward(shape, rotmat, assets['smpl'])
+    kp_2d = G.projection(joints if stage == 1 else joints.detach(), cam)
+    focal = cam[:, 0].detach() * bbox_height * Tz / 2.0
+    cam_center = orig_shape[:, [1, 0]] / 2.0
+    cam_t = G.convert_pare_to_full_img_cam(cam.detach(), bbox_height, center, orig_shape[:, 1], orig_shape[:, 0], Tz)
+    kp_w = G.perspective_projection(joints.detach() if stage == 1 else joints, torch.eye(3).unsqueeze(0), cam_t, focal, cam_center)
+    kp_w = kp_w / cam_center.unsqueeze(1) - 1
+    aa = G.rotation_matrix_to_angle_axis(rotmat.reshape(-1, 3, 3)).reshape(-1, 72)
+    sub, temp, markers, smpl_j = OW._smpl_aux(verts, assets)
+    out = {'theta': torch.cat([cam, shape, aa], dim=1), 'verts': verts, 'sub_verts': sub, 'temp_verts': temp, 'kp_2d': kp_2d,
+           'kp_2d_w': kp_w, 'kp_3d': joints, 'smpl_kp_3d': smpl_j, 'rotmat': rotmat, 'pred_cam': cam, 'pred_cam_t': cam_t,
+           'pred_shape': shape, 'pred_pose': pose, 'pose': aa, 'pelvis': smpl_j[:, :1], 'scale': scale, 'focal_length': focal,
+           'markers': markers}
+    return out, x
+
+
+def whmr_forward_train(sd, assets, x, center, scale, bbox_height, orig_shape, bbox_info, stage=2, stats=None):
+    """-> list of the 4 ``smpl_out`` dicts (mean-pose mesh + 3 stages).  ``stats`` (dict, optional) receives the updated BN running stats."""
+    B = x.shape[0]
+    s_feat = vit_forward(sd, x, 'feature_extractor.backbone.')
+    smpl_out = OW.regressor_forward_init(sd, assets, B)
+    outs, fmaps = [smpl_out], []
+    for i in range(3):
+        w = sd['deconv_layers.%d.weight' % (3 * i)]
+        s_feat = F.relu(_bn_train(F.conv_transpose2d(s_feat, w, None, stride=2, padding=1), sd, 'deconv_layers.%d.' % (3 * i + 1), stats))
+        fmaps.append(s_feat)
+    Tz = tz_head_train(sd, s_feat.detach() if stage == 1 else s_feat, stats)
+    for i in range(3):
+        cam, shape = smpl_out['pred_cam'].detach(), smpl_out['pred_shape'].detach()
+        pose, markers = smpl_out['rotmat'].detach(), smpl_out['markers'].detach()
+        pts = sd['points_grid'].expand(B, -1, -1).transpose(1, 2) if i == 0 else G.projection(markers, cam)
+        ref, _ = OW.maf_sampling(sd, pts, fmaps[i], 'maf_extractor.%d.' % i)
+        smpl_out, _ = regressor_forward_train(sd, assets, i, ref, bbox_info, Tz, orig_shape, center, scale, bbox_height, pose, shape, cam, stage)
+        outs.append(smpl_out)
+    return outs
+
+
+def cotangent_loss(outs, seed=0, dev=None):
+    """A fixed random linear functional of the stage outputs core/trainer.py:500-600 puts losses on (TRAIN_LOSS_KEYS of stages 1-3):
+    sum_k <c_k, out_k> with unit-scale cotangents normalised by each tensor's size.  Shared by the reference run, the oracle and the
+    HIP test so that all three differentiate the same scalar."""
+    g = torch.Generator().manual_seed(seed)
+    total = 0.0
+    for l in range(1, len(outs)):
+        for k in TRAIN_LOSS_KEYS:
+            t = outs[l][k]
+            c = torch.randn(t.shape, generator=g) / float(max(1, t[0].numel())) ** 0.5
+            if k in ('kp_2d', 'kp_2d_w'):
+                c = c * 0.05
+            if k == 'focal_length':
+                c = c * 1e-3
+            total = total + (t * (c.to(dev) if dev is not None else c)).sum()
+    return total

@@ -83,6 +83,7 @@ _SIGS = {
     'whmr_smpl_skin_bwd': [C.POINTER(WhmrSmplModel), _P, _L, _P, _P, _P, _P, _I, _I, _P, _P, _P],
     'whmr_smpl_chain_bwd': [C.POINTER(WhmrSmplModel), _P, _P, _L, _P, _P, _P, _I, _P, _P, _P],
     'whmr_maf_sample_bwd': [_P, _I, _L, _L, _L, _L, _I, _I, _P, _P, _P, _L, _F, _F, _F, C.POINTER(WhmrMafWeights), _P, _P, _P, _I, _I, _P, _L, _P, _L, _L, _L, _L, _P, _P, _L, _P],
+    'whmr_col2im': [_P, _I, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'whmr_maxpool_nhwc': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'whmr_avgpool_nhwc': [_P, _P, _I, _I, _I, _I, _P],
 }
@@ -642,3 +643,13 @@ def maf_sample_bwd(fmap_nchw, weights, w0, w1, w2, d_out, d_fmap_nchw, XT, DT, p
                                      cam.stride(0) if cam is not None else 0, focal, res_w, res_h, C.byref(weights), w0.data_ptr(),
                                      w1.data_ptr(), w2.data_ptr(), B, P, d_out.data_ptr(), d_out.stride(0), _ptr(d_fmap_nchw), g[0], g[1],
                                      g[2], g[3], XT.data_ptr(), DT.data_ptr(), XT.shape[1], _stream()), 'whmr_maf_sample_bwd')
+
+
+def col2im(dcol, dx_nhwc, OH, OW, KH, KW, S, P):
+    """dcol [B*OH*OW, KH*KW*C] (row stride free) -> dx [B,IH,IW,C] (written, not accumulated)."""
+    _dev(dcol, dx_nhwc)
+    B, IH, IW, Cc = dx_nhwc.shape
+    assert dcol.dim() == 2 and dcol.stride(1) == 1 and dcol.shape == (B * OH * OW, KH * KW * Cc) and dx_nhwc.is_contiguous()
+    _check(lib().whmr_col2im(dcol.data_ptr(), _bf(dcol), dcol.stride(0), dx_nhwc.data_ptr(), _bf(dx_nhwc), B, IH, IW, Cc, OH, OW, KH, KW, S, P,
+                             _stream()), 'whmr_col2im')
+    return dx_nhwc

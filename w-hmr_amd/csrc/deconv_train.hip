@@ -282,3 +282,48 @@ extern "C" int whmr_im2col_t(const void* src, void* dst, int is_bf16, int B, int
     WHMR_CHECK_LAUNCH();
     return 0;
 }
+
+// col2im (gather form, no atomics): dx[b, iy, ix, c] = sum over the (oy, ox, ky, kx) with oy*S + ky - P == iy, ox*S + kx - P == ix of
+// dcol[(b, oy, ox)][(ky*KW + kx)*C + c].  The data gradient of a strided Conv2d whose column-space gradient dcol = dY . W came from the
+// GEMM kernel (Tz-head 7x7 s3 conv, models/whmr.py:419: every input pixel collects <= 9 of the 49 taps).  Thread = 8 channels of a pixel.
+template <typename T, typename TO>
+__global__ __launch_bounds__(256) void col2im_kernel(const T* __restrict__ dcol, long ldcol, TO* __restrict__ dx, int B, int IH, int IW, int C,
+                                                     int OH, int OW, int KH, int KW, int S, int P) {
+    const int tpr = C >> 3, rpb = 256 / tpr;
+    const int cg = threadIdx.x % tpr, rl = threadIdx.x / tpr, c = cg * 8;
+    const long npix = (long)B * IH * IW;
+    const long pix = (long)blockIdx.x * rpb + rl;
+    if (pix >= npix) return;
+    const int ix = (int)(pix % IW), iy = (int)((pix / IW) % IH), b = (int)(pix / ((long)IW * IH));
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    const int oy_lo = max(0, (iy + P - KH + 1 + S - 1) / S), oy_hi = min(OH - 1, (iy + P) / S);
+    const int ox_lo = max(0, (ix + P - KW + 1 + S - 1) / S), ox_hi = min(OW - 1, (ix + P) / S);
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+        const int ky = iy + P - oy * S;
+        for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+            const int kx = ix + P - ox * S;
+            float v[8];
+            load8<T>(dcol + (((long)b * OH + oy) * OW + ox) * ldcol + (long)(ky * KW + kx) * C + c, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += v[e];
+        }
+    }
+    store8<TO>(dx + pix * C + c, acc);
+}
+
+extern "C" int whmr_col2im(const void* dcol, int dcol_bf16, long ldcol, void* dx, int dx_bf16, int B, int IH, int IW, int C, int OH, int OW,
+                           int KH, int KW, int S, int P, void* stream) {
+    if (B <= 0 || (C & 7) || C > 2048 || 256 % (C >> 3) || S <= 0) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    const int rpb = 256 / (C >> 3);
+    const long npix = (long)B * IH * IW;
+    dim3 grid((unsigned)((npix + rpb - 1) / rpb)), block(256);
+    if (dcol_bf16 && dx_bf16) hipLaunchKernelGGL((col2im_kernel<bf16_t, bf16_t>), grid, block, 0, st, (const bf16_t*)dcol, ldcol, (bf16_t*)dx, B, IH, IW, C, OH, OW, KH, KW, S, P);
+    else if (dcol_bf16) hipLaunchKernelGGL((col2im_kernel<bf16_t, float>), grid, block, 0, st, (const bf16_t*)dcol, ldcol, (float*)dx, B, IH, IW, C, OH, OW, KH, KW, S, P);
+    else if (!dx_bf16) hipLaunchKernelGGL((col2im_kernel<float, float>), grid, block, 0, st, (const float*)dcol, ldcol, (float*)dx, B, IH, IW, C, OH, OW, KH, KW, S, P);
+    else return (int)hipErrorInvalidValue;
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}

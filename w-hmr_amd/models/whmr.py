@@ -426,19 +426,11 @@ class WHMR(nn.Module):
             self._init_cache = (key, reg.forward_init(x1, with_aux=with_aux))
         return expand(self._init_cache[1])
 
-    # ------------------------------------------------------------------ forward
     @torch.no_grad()
-    def forward(self, x, meta_masks=None, center=None, scale=None, bbox_height=None, orig_shape=None, bbox_info=None,
-                is_train=False, J_regressor=None, full_x=None, cam_rotmat=None, view=None):
-        if is_train:
-            raise NotImplementedError('whmr_amd is inference-only this round (backward kernels: SURVEY 7 step 7)')
-        if not x.is_cuda:
-            raise RuntimeError('whmr_amd.WHMR runs on a HIP device only (no CPU fallback)')
-        view = view or self.return_view
-        with_aux = view == 'train'
-        B, dev = x.shape[0], x.device
+    def _camera(self, full_x, cam_rotmat, B, dev):
+        """whmr.py:509-524: camera-calibration head on the full image -> (cam_rotmat, render_rotmat); detached in the reference too."""
         render_rotmat = None
-        if cam_rotmat is None:                                                        # whmr.py:509-524
+        if cam_rotmat is None:
             if full_x is not None:
                 # demo/tester.py:161 replicates the full image once per person; a batch-1 full_x is accepted here and its
                 # camera prediction broadcast (identical result, the ~80 GFLOP ResNet-50 runs once per image -- SURVEY 8f N1)
@@ -454,6 +446,25 @@ class WHMR(nn.Module):
                 cam_rotmat = torch.eye(3, device=dev).unsqueeze(0).expand(B, -1, -1).float()
         if render_rotmat is None:
             render_rotmat = cam_rotmat
+        return cam_rotmat, render_rotmat
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x, meta_masks=None, center=None, scale=None, bbox_height=None, orig_shape=None, bbox_info=None,
+                is_train=False, J_regressor=None, full_x=None, cam_rotmat=None, view=None):
+        if not x.is_cuda:
+            raise RuntimeError('whmr_amd.WHMR runs on a HIP device only (no CPU fallback)')
+        if is_train:       # training graph: HIP forward kernels + hand-written HIP backward behind autograd nodes (whmr_amd.train)
+            from ..train.whmr_train import whmr_forward_train
+            return whmr_forward_train(self, x, center, scale, bbox_height, orig_shape, bbox_info, J_regressor=J_regressor,
+                                      full_x=full_x, cam_rotmat=cam_rotmat)
+        with torch.no_grad():
+            return self._forward_eval(x, center, scale, bbox_height, orig_shape, bbox_info, J_regressor, full_x, cam_rotmat, view)
+
+    def _forward_eval(self, x, center, scale, bbox_height, orig_shape, bbox_info, J_regressor, full_x, cam_rotmat, view):
+        view = view or self.return_view
+        with_aux = view == 'train'
+        B, dev = x.shape[0], x.device
+        cam_rotmat, render_rotmat = self._camera(full_x, cam_rotmat, B, dev)
 
         # backbone (tokens are NHWC already) -> deconv pyramid in NHWC
         vit = self.feature_extractor.backbone

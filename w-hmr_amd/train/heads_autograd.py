@@ -1,0 +1,137 @@
+"""Autograd nodes of the small heads around the ViT / deconv / sampler / SMPL stages (training mode), all on the HIP GEMM kernels.
+
+  LinearFn       nn.Linear (Regressor fc1/fc2/dec*, whmr.py:118-126; Tz-head Block and est_Tz linears, whmr.py:423-427): fp32 GEMM,
+                 dX = dY . W, dW = dY^T . X (transposed operands from whmr_transpose_cast), db = column sum.
+  ConvNHWCFn     Conv2d without bias / padding on a channels-last map (Tz head, whmr.py:419-420): forward = implicit GEMM with the
+                 NHWC gather; dW = dY^T . col(X) with col(X)^T from whmr_im2col_t; dX = col2im(dY . W) (whmr_col2im).
+  DownsampleFn   the dense mesh down-sampling products sub_verts = Dmap0 . verts, temp_verts = Dmap1 . sub_verts (whmr.py:182-183).
+"""
+import torch
+
+from .. import _lib as L
+
+
+def _f32(t):
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+
+
+class LinearFn(torch.autograd.Function):
+    """y = LinearFn.apply(x [M,K], weight [N,K], bias [N] | None)  (fp32)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        if not x.is_cuda:
+            raise RuntimeError('whmr_amd runs on a HIP device only (no CPU fallback)')
+        x = _f32(x.detach())
+        w = _f32(weight.detach())
+        y = torch.empty(x.shape[0], w.shape[0], dtype=torch.float32, device=x.device)
+        L.gemm(x, w, y, bias=None if bias is None else _f32(bias.detach()))
+        ctx.saved = (x, w)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved
+        ctx.saved = None
+        dy = _f32(dy)
+        dev = dy.device
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            L.gemm(dy, L.transpose_cast(w, torch.float32, pad_to=1), dx)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            L.gemm(L.transpose_cast(dy, torch.float32, pad_to=1), L.transpose_cast(x, torch.float32, pad_to=1), dw)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty(w.shape[0], dtype=torch.float32, device=dev)
+            L.colsum(dy, db)
+        return dx, dw, db
+
+
+class ConvNHWCFn(torch.autograd.Function):
+    """y [B,OH,OW,Cout] (dt) = ConvNHWCFn.apply(x [B,IH,IW,Cin] (dt), weight [Cout,Cin,KH,KW], stride, dt): Conv2d, no bias, no padding."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, dt):
+        if not x.is_cuda:
+            raise RuntimeError('whmr_amd runs on a HIP device only (no CPU fallback)')
+        x = x.detach()
+        assert x.dtype == dt and x.is_contiguous()
+        B, IH, IW, Cin = x.shape
+        Cout, _, KH, KW = weight.shape
+        OH, OW = (IH - KH) // stride + 1, (IW - KW) // stride + 1
+        npad = Cout if dt == torch.float32 else (Cout + 63) // 64 * 64           # the bf16 tiles want whole 64-column groups
+        wm = torch.zeros(npad, KH * KW * Cin, dtype=torch.float32, device=x.device)
+        wm[:Cout] = weight.detach().float().permute(0, 2, 3, 1).reshape(Cout, -1)   # [co, (ky, kx, ci)]
+        wm = L.cast_bf16(wm) if dt == torch.bfloat16 else wm
+        y = torch.empty(B * OH * OW, npad, dtype=dt, device=x.device)
+        L.gemm(x, wm, y, conv=dict(IH=IH, IW=IW, Cin=Cin, OH=OH, OW=OW, KW=KW, SH=stride, SW=stride, PH=0, PW=0))
+        ctx.saved = (x, wm)
+        ctx.dims = (B, IH, IW, Cin, Cout, KH, KW, OH, OW, stride, npad, dt)
+        out = y if npad == Cout else y[:, :Cout].contiguous()
+        return out.view(B, OH, OW, Cout)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wm = ctx.saved
+        ctx.saved = None
+        B, IH, IW, Cin, Cout, KH, KW, OH, OW, S, npad, dt = ctx.dims
+        dev = x.device
+        M, K = B * OH * OW, KH * KW * Cin
+        dyp = torch.zeros(M, npad, dtype=dt, device=dev) if npad != Cout else None
+        if dyp is None:
+            dyp = dy.reshape(M, Cout).to(dt).contiguous()
+        else:
+            dyp[:, :Cout] = dy.reshape(M, Cout)
+        pad = 64 if dt == torch.bfloat16 else 8
+        dx = dw = None
+        if ctx.needs_input_grad[1]:
+            dyt = L.transpose_cast(dyp, dt, pad_to=pad)                            # [npad, Mpad]
+            colt = L.im2col_t(x, OH, OW, KH, KW, S, 0, pad_to=pad)                 # [K, Mpad]
+            dwm = torch.empty(npad, K, dtype=torch.float32, device=dev)
+            L.gemm(dyt, colt, dwm)
+            dw = dwm[:Cout].view(Cout, KH, KW, Cin).permute(0, 3, 1, 2)
+            del colt, dyt
+        if ctx.needs_input_grad[0]:
+            wt = L.transpose_cast(wm, dt, pad_to=1)                                # [K, npad]
+            dcol = torch.empty(M, K, dtype=dt, device=dev)
+            L.gemm(dyp, wt, dcol)
+            dx = torch.empty(B, IH, IW, Cin, dtype=dt, device=dev)
+            L.col2im(dcol, dx, OH, OW, KH, KW, S, 0)
+        return dx, dw, None, None
+
+
+class DownsampleFn(torch.autograd.Function):
+    """sub_verts [B,n0,3], temp_verts [B,n1,3] = DownsampleFn.apply(verts [B,6890,3], Dmap0 [n0,6890], Dmap1 [n1,n0], cache_dict)."""
+
+    @staticmethod
+    def forward(ctx, verts, d0, d1, cache):
+        B = verts.shape[0]
+        dev = verts.device
+        vt = verts.detach().permute(0, 2, 1).reshape(B * 3, -1).contiguous()                       # [3B, 6890]
+        sub = torch.empty(d0.shape[0], B * 3, dtype=torch.float32, device=dev)
+        L.gemm(d0, vt, sub)
+        st = sub.t().contiguous()                                                                  # [3B, n0]
+        tmp = torch.empty(d1.shape[0], B * 3, dtype=torch.float32, device=dev)
+        L.gemm(d1, st, tmp)
+        key = (d0.data_ptr(), d0._version, d1.data_ptr(), d1._version)
+        if cache.get('key') != key:
+            cache.update(key=key, d0t=d0.t().contiguous(), d1t=d1.t().contiguous())
+        ctx.cache, ctx.B = cache, B
+        n0, n1 = d0.shape[0], d1.shape[0]
+        return sub.view(n0, B, 3).permute(1, 0, 2).contiguous(), tmp.view(n1, B, 3).permute(1, 0, 2).contiguous()
+
+    @staticmethod
+    def backward(ctx, d_sub, d_tmp):
+        B, c = ctx.B, ctx.cache
+        n0, n1 = c['d1t'].shape
+        dev = c['d0t'].device
+        ds = torch.zeros(B * 3, n0, dtype=torch.float32, device=dev)
+        if d_tmp is not None:
+            L.gemm(d_tmp.float().permute(0, 2, 1).reshape(B * 3, n1).contiguous(), c['d1t'], ds)   # [3B, n1] . Dmap1 -> [3B, n0]
+        if d_sub is not None:
+            ds += d_sub.float().permute(0, 2, 1).reshape(B * 3, n0)
+        dv = torch.empty(B * 3, c['d0t'].shape[0], dtype=torch.float32, device=dev)
+        L.gemm(ds, c['d0t'], dv)                                                                   # [3B, n0] . Dmap0 -> [3B, 6890]
+        return dv.view(B, 3, -1).permute(0, 2, 1).contiguous(), None, None, None

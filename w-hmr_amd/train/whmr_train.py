@@ -1,0 +1,174 @@
+"""``WHMR.forward(is_train=True)``: the training graph of the W-HMR path with hand-written HIP forward AND backward kernels.
+
+Reference semantics: models/whmr.py:503-678 in ``model.train()`` as driven by ``core/trainer.py:410-470`` (loss.backward()), with the
+train-view return the trainer consumes (``out_list`` with ``smpl_out`` = [mean-pose mesh, 3 regressor stages]).
+
+Every stage is an autograd node whose forward and backward are HIP kernels from this library:
+
+  ViTFn (vit_autograd)            backbone, models/ViTPose/.../vit.py:61-140,313-332
+  DeconvBNReLUFn (deconv_autograd)  3 x ConvTranspose2d -> BatchNorm2d (batch statistics, running-stat update) -> ReLU, whmr.py:459-501
+  ConvNHWCFn / LinearFn (heads_autograd)  Tz head, whmr.py:417-430,567-577; Regressor linears, whmr.py:118-126
+  MAFSampleFn (maf_autograd)      bilinear gather + point MLP, maf_extractor.py:75-143
+  SMPLFn (smpl_autograd)          kinematic chain + LBS + joint regressors, whmr.py:132-137,184-187
+  DownsampleFn                    sub_verts / temp_verts, whmr.py:182-183
+
+The glue between them is O(batch) tensor arithmetic on the device, differentiated by torch autograd: the residual parameter updates,
+the weak-perspective / full-image projections of 49 joints (utils/geometry.py:289-341,139-157), dropout masks, and the 5-token
+timm Block + BatchNorm1d of the Tz head.
+
+Graph structure (all from the reference): the previous stage's pose / shape / cam and the sample points are detached
+(whmr.py:586-592), so each regressor stage back-propagates into ITS feature map only; with ``cfg.TRAIN.STAGE == 2``
+(configs/pymaf_config.yaml:26) ``kp_2d`` sees detached joints (whmr.py:142-145) while ``kp_2d_w`` differentiates joints, Tz and hence
+the Tz head and the last feature map (whmr.py:156-173,567-570); ``STAGE == 1`` swaps those roles.
+Not differentiated here (outputs only): the angle-axis copy of the pose in ``theta`` (whmr.py:174), ``global_output`` (its loss terms
+are not part of core/trainer.py:500-600; computed without dropout), the IUV head ``dp_head`` (AUX supervision needs the pytorch3d
+rasteriser).
+"""
+import torch
+import torch.nn.functional as F
+
+from .. import _lib as L
+from ..core.cfgs import cfg
+from ..core.constants import FOCAL_LENGTH
+from .deconv_autograd import DeconvBNReLUFn
+from .heads_autograd import ConvNHWCFn, DownsampleFn, LinearFn
+from .maf_autograd import MAFSampleFn
+from .smpl_autograd import SMPLFn
+
+
+def _linear(x, lin):
+    return LinearFn.apply(x, lin.weight, lin.bias)
+
+
+def _projection(joints, cam):
+    """utils/geometry.py:289-307 as differentiable tensor arithmetic ([B,J,3], [B,3] -> [B,J,2])."""
+    tz = 2.0 * FOCAL_LENGTH / (float(cfg.IMG_RES.HEIGHT) * cam[:, 0] + 1e-9)
+    z = joints[..., 2] + tz[:, None]
+    x = FOCAL_LENGTH * ((joints[..., 0] + cam[:, 1:2]) / z) / (float(cfg.IMG_RES.WIDTH) / 2.0)
+    y = FOCAL_LENGTH * ((joints[..., 1] + cam[:, 2:3]) / z) / (float(cfg.IMG_RES.HEIGHT) / 2.0)
+    return torch.stack([x, y], dim=-1)
+
+
+def _perspective_norm(joints, cam_t, focal, cam_center):
+    """utils/geometry.py:310-341 with identity rotation, then whmr.py:173: / camera_center - 1."""
+    p = joints + cam_t[:, None, :]
+    x = focal[:, None] * (p[..., 0] / p[..., 2]) + cam_center[:, None, 0]
+    y = focal[:, None] * (p[..., 1] / p[..., 2]) + cam_center[:, None, 1]
+    return torch.stack([x, y], dim=-1) / cam_center[:, None, :] - 1.0
+
+
+def tz_head_train(model, f_nhwc):
+    """whmr.py:567-577 in training mode.  f_nhwc [B,128,96,256] in the compute dtype (detached by the caller when TRAIN.STAGE == 1)."""
+    dt = model._dt
+    B = f_nhwc.shape[0]
+    y0 = ConvNHWCFn.apply(f_nhwc, model.conv[0].weight, 3, dt)
+    y1 = ConvNHWCFn.apply(y0, model.conv[1].weight, 2, dt)                            # [B, 18, 12, 5]
+    t = y1.float().permute(0, 3, 1, 2).reshape(B, 5, -1)                               # == conv(...).reshape(B, 5, -1) on NCHW, whmr.py:571
+    D = t.shape[-1]
+    td = model.transformer_decoder                                                     # timm Block(dim 216, 2 heads, qkv_bias False)
+    nh, hd = 2, D // 2
+    h = F.layer_norm(t, (D,), td.norm1.weight, td.norm1.bias, 1e-5)
+    qkv = _linear(h.reshape(B * 5, D), td.attn.qkv).reshape(B, 5, 3, nh, hd).permute(2, 0, 3, 1, 4)
+    a = ((qkv[0] @ qkv[1].transpose(-2, -1)) * hd ** -0.5).softmax(dim=-1)
+    h = (a @ qkv[2]).transpose(1, 2).reshape(B * 5, D)
+    t = t + _linear(h, td.attn.proj).view(B, 5, D)
+    h = F.layer_norm(t, (D,), td.norm2.weight, td.norm2.bias, 1e-5)
+    h = F.gelu(_linear(h.reshape(B * 5, D), td.mlp.fc1))
+    t = t + _linear(h, td.mlp.fc2).view(B, 5, D)
+    s = t.mean(dim=1)                                                                  # transpose + AvgPool1d(5) + squeeze, whmr.py:574-575
+    e = model.est_Tz
+    y = _linear(_linear(s, e[0]), e[1])
+    y = e[2](y)                                                                        # BatchNorm1d(1): batch statistics in train mode
+    return 10.0 * torch.sigmoid(y).squeeze(-1)
+
+
+def regressor_train(reg, ref, bbox_info, Tz, orig_shape, center, scale, bbox_height, pose, shape, cam, cache):
+    """Regressor.forward(is_train=True, n_iter=1), whmr.py:102-209.  pose / shape / cam: the previous stage's (detached) estimates."""
+    B = ref.shape[0]
+    stage = int(cfg.TRAIN.STAGE)
+    x = torch.cat((ref, bbox_info), dim=1)
+    pose = pose.reshape(B, -1)
+    xc = torch.cat([x, pose, shape, cam], 1)
+    h = reg.drop1(_linear(xc, reg.fc1))
+    h = reg.drop2(_linear(h, reg.fc2))
+    pose_n = _linear(h, reg.decpose) + pose
+    shape_n = _linear(h, reg.decshape) + shape
+    cam_n = _linear(h, reg.deccam) + cam
+    rotmat = pose_n.view(B, 24, 3, 3)                                                  # no Gram-Schmidt in training (whmr.py:129)
+    verts, joints, smpl_j, markers = SMPLFn.apply(shape_n, rotmat, reg.smpl)
+    kp_2d = _projection(joints if stage == 1 else joints.detach(), cam_n)              # whmr.py:142-145
+    s = cam_n[:, 0].detach()
+    focal = s * bbox_height * Tz / 2.0                                                 # whmr.py:147-149
+    cam_center = orig_shape[:, [1, 0]] / 2.0
+    cd = cam_n.detach()                                                                # geometry.py:139-157 on pred_cam.detach()
+    cam_t = torch.stack([cd[:, 1] + 2.0 * (center[:, 0] - orig_shape[:, 1] / 2.0) / (cd[:, 0] * bbox_height),
+                         cd[:, 2] + 2.0 * (center[:, 1] - orig_shape[:, 0] / 2.0) / (cd[:, 0] * bbox_height), Tz], dim=-1)
+    kp_w = _perspective_norm(joints.detach() if stage == 1 else joints, cam_t, focal, cam_center)   # whmr.py:156-173
+    with torch.no_grad():
+        aa = L.mat_to_aa(rotmat.detach().reshape(-1, 9).contiguous()).reshape(B, 72)   # whmr.py:174 (no gradient, see module docstring)
+    sub, temp = DownsampleFn.apply(verts, reg.Dmap0, reg.Dmap1, cache)
+    out = {'theta': torch.cat([cam_n, shape_n, aa], dim=1), 'verts': verts, 'sub_verts': sub, 'temp_verts': temp, 'kp_2d': kp_2d,
+           'kp_2d_w': kp_w, 'kp_3d': joints, 'smpl_kp_3d': smpl_j, 'rotmat': rotmat, 'pred_cam': cam_n, 'pred_cam_t': cam_t,
+           'pred_shape': shape_n, 'pred_pose': pose_n, 'pose': aa, 'pelvis': smpl_j[:, :1, :], 'scale': scale, 'focal_length': focal,
+           'markers': markers}
+    return out, x
+
+
+def whmr_forward_train(model, x, center, scale, bbox_height, orig_shape, bbox_info, J_regressor=None, full_x=None, cam_rotmat=None):
+    """-> (out_list, vis_feat_list): the train view of WHMR.forward (whmr.py:545-554,627,635-654) with an autograd graph attached."""
+    if J_regressor is not None:
+        raise NotImplementedError('J_regressor (H36M evaluation joints) is an eval-time option: core/trainer.py:410 trains without it')
+    if not model.training:
+        raise RuntimeError('is_train=True needs model.train() (BatchNorm batch statistics, dropout, the ViT autograd node)')
+    dt = model._dt
+    B, dev = x.shape[0], x.device
+    cam_rotmat, _ = model._camera(full_x, cam_rotmat, B, dev)
+    center, scale, bbox_height = center.float().contiguous(), scale.float(), bbox_height.float().contiguous()
+    orig_shape, bbox_info = orig_shape.float().contiguous(), bbox_info.float().contiguous()
+
+    s_feat = model.feature_extractor(x)                                               # [B,768,Hp,Wp] view of NHWC tokens, ViTFn node
+    f = s_feat.permute(0, 2, 3, 1).contiguous().to(dt)
+    fmaps = []
+    for i in range(3):
+        ct, bn = model.deconv_layers[3 * i], model.deconv_layers[3 * i + 1]
+        assert ct.bias is None
+        f = DeconvBNReLUFn.apply(f, ct.weight, bn.weight, bn.bias, bn, dt)
+        fmaps.append(f)
+        model.maf_extractor[i].im_feat = f.detach().permute(0, 3, 1, 2)
+    Tz = tz_head_train(model, fmaps[-1].detach() if int(cfg.TRAIN.STAGE) == 1 else fmaps[-1])
+
+    smpl_output = model._init_mesh(B, None, True)                                      # constant mean-pose mesh (whmr.py:548-550)
+    outs = [smpl_output]
+    body_feat = None
+    cache = model.__dict__.setdefault('_train_cache', {})
+    for i in range(3):                                                                 # whmr.py:580-627
+        reg, ext = model.regressor[i], model.maf_extractor[i]
+        cam, shp = smpl_output['pred_cam'].detach(), smpl_output['pred_shape'].detach()
+        pose, markers = smpl_output['rotmat'].detach(), smpl_output['markers'].detach()
+        ext.cam = cam
+        fm = fmaps[i].permute(0, 3, 1, 2)
+        ps = (ext.conv0.weight, ext.conv0.bias, ext.conv1.weight, ext.conv1.bias, ext.conv2.weight, ext.conv2.bias)
+        if i == 0:
+            pts = model.points_grid.expand(B, -1, -1).transpose(1, 2).contiguous()
+            ref = MAFSampleFn.apply(fm, *ps, ext, pts, None, None)
+        else:
+            ref = MAFSampleFn.apply(fm, *ps, ext, None, markers.contiguous(), cam.contiguous())
+        smpl_output, body_feat = regressor_train(reg, ref, bbox_info, Tz, orig_shape, center, scale, bbox_height, pose, shp, cam,
+                                                 cache.setdefault(i, {}))
+        outs.append(smpl_output)
+
+    with torch.no_grad():                                                              # whmr.py:630-654, outputs only
+        go = model.global_orient
+        lo = smpl_output['rotmat'][:, 0].reshape(B, 9)
+        xc = torch.cat([body_feat, cam_rotmat[:, :, :2].reshape(B, 6), lo], dim=1).contiguous()
+        w_eff, b_eff = go._collapsed()
+        g_rot = torch.empty(B, 9, dtype=torch.float32, device=dev)
+        L.gemm(xc, w_eff, g_rot, bias=b_eff, residual=lo.contiguous())
+        g_rot = g_rot.view(B, 1, 3, 3)
+        g_aa = L.mat_to_aa(g_rot.reshape(-1, 9).contiguous()).reshape(B, 3)
+        g_rotmat = torch.cat([g_rot, smpl_output['rotmat'][:, 1:]], dim=1)
+        g = model.regressor[0].smpl.run(smpl_output['pred_shape'], g_rotmat)
+        g_out = {'global_pose': torch.cat([g_aa, smpl_output['pose'][:, 3:]], dim=1), 'global_shape': smpl_output['pred_shape'],
+                 'global_rotmat': g_rotmat, 'global_kp_3d': g.joints, 'global_verts': g.vertices}
+    vis_feat = [s_feat.detach()] + [m.detach().permute(0, 3, 1, 2) for m in fmaps]
+    return {'smpl_out': outs, 'dp_out': [], 'dpth_out': [], 'global_output': g_out}, vis_feat
