@@ -153,3 +153,40 @@ def test_crop_oracle_known_answers():
     t = OC.to_tensor_normalize(img)
     assert t.shape == (3, 64, 64) and t.dtype == np.float32
     assert np.allclose(t[0], (img[..., 0] / 255.0 - 0.485) / 0.229, atol=1e-6)
+
+
+def test_train_oracle_matches_reference_fixture(assets, state_dict):
+    """oracle/train.py (training-mode forward + torch autograd) against tests/golden/whmr_train_b2.npz, which holds the imported
+    reference's loss, per-parameter gradient (norm, sum) pairs, a few full gradients and the BatchNorm running statistics after the step
+    (tests/golden/make_golden_train.py).  TRAIN.STAGE 2 (the configs/pymaf_config.yaml default)."""
+    import os
+    import numpy as np
+    from oracle import synth
+    from oracle import train as OT
+    from conftest import GOLDEN
+    fx = np.load(os.path.join(GOLDEN, 'whmr_train_b2.npz'))
+    keys = [str(k) for k in fx['grad_keys']]
+    inp = synth.make_inputs(2, 0)
+    p = {k: (v.clone().requires_grad_(True) if k in keys else v) for k, v in state_dict.items()}
+    stats = {}
+    outs = OT.whmr_forward_train(p, assets, inp['x'], inp['center'], inp['scale'], inp['bbox_height'], inp['orig_shape'], inp['bbox_info'],
+                                 stage=2, stats=stats)
+    loss = OT.cotangent_loss(outs)
+    loss.backward()
+    assert abs(loss.item() - float(fx['loss_stage2'])) < 1e-5
+    ns = fx['grad_norm_sum_stage2']
+    for i, k in enumerate(keys):
+        g = p[k].grad.double()
+        if ns[i, 0] < 1e-8:
+            assert g.norm().item() < 1e-6, k
+            continue
+        assert abs(g.norm().item() - ns[i, 0]) < 2e-4 * ns[i, 0], k
+    for name in fx.files:
+        if name.startswith('grad_stage2/'):
+            k = name.split('/', 1)[1]
+            ref = torch.from_numpy(fx[name])
+            assert ((p[k].grad - ref).abs().max() / ref.abs().max()).item() < 5e-4, k
+        if name.startswith('stat_stage2/'):
+            k = name.split('/', 1)[1]
+            ref = torch.from_numpy(fx[name])
+            assert ((stats[k] - ref).abs().max() / ref.abs().max().clamp_min(1e-12)).item() < 2e-5, k
