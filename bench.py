@@ -1,6 +1,6 @@
 """Benchmark of the W-HMR hot path on MI355X.  Contract: see the task brief / DESIGN.md "Measurement".
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload vit224|vit256x192|whmr] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload vit224|vit256x192|vitl256x192|whmr|whmr_train] [--no-cpu]
 
 A step = one forward of the hot path over one batch of 64 synthetic crops per GPU (inputs resident in HBM).
 N=1 default workload = BASELINE.json configs[1]: ViT-B/16 backbone only, 224x224, batch 64, bf16 MFMA.
@@ -19,12 +19,15 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-VIT_FLOP_PER_IMG = {'vit224': 34.94e9, 'vit256x192': 34.20e9, 'vitl256x192': 119.9e9, 'whmr': 34.20e9 + 9.26e9 + 1.98e9}
+VIT_FLOP_PER_IMG = {'vit224': 34.94e9, 'vit256x192': 34.20e9, 'vitl256x192': 119.9e9, 'whmr': 34.20e9 + 9.26e9 + 1.98e9,
+                    'whmr_train': 3 * (34.20e9 + 9.26e9 + 1.98e9)}
 METRIC = {'vit224': 'images/sec ViT-B 224^2 batch-64 fwd', 'vit256x192': 'images/sec ViT-B 256x192 batch-64 fwd',
           'vitl256x192': 'images/sec ViT-L 256x192 fwd',
-          'whmr': 'images/sec full W-HMR fwd (ViT-B + 3-iter MAF loop + orientation) batch-64'}
+          'whmr': 'images/sec full W-HMR fwd (ViT-B + 3-iter MAF loop + orientation) batch-64',
+          'whmr_train': 'images/sec W-HMR train step (fwd + bwd + DP gradient all-reduce, no optimizer) batch-64 per GPU'}
 WORKLOAD = {'vit224': 'ViT-B/16 backbone forward', 'vit256x192': 'ViT-B/16 backbone forward', 'vitl256x192': 'ViT-L/16 backbone forward',
-            'whmr': 'full W-HMR forward (ViT-B + deconv pyramid + Tz head + 3-iteration MAF/regressor/SMPL loop + global orientation)'}
+            'whmr': 'full W-HMR forward (ViT-B + deconv pyramid + Tz head + 3-iteration MAF/regressor/SMPL loop + global orientation)',
+            'whmr_train': 'W-HMR training step: WHMR.forward(is_train=True), synthetic loss on the supervised outputs, HIP backward, gradient buckets'}
 
 
 def parse():
@@ -65,6 +68,35 @@ def build_workload(args, dev):
         inp = {k: v.to(dev) for k, v in synth.make_inputs(args.batch, 7).items()}
         a = (inp['x'], None, inp['center'], inp['scale'], inp['bbox_height'], inp['orig_shape'], inp['bbox_info'])
         return (lambda: m(*a)), None, inp['x'], (256, 192)
+    if args.workload == 'whmr_train':
+        # BASELINE configs[3] (train.py pymaf_net step, batch 64 per GPU, DP gradient all-reduce over RCCL): forward in training mode,
+        # a synthetic L2 loss on the tensors core/trainer.py:500-600 supervises, backward through the HIP autograd nodes, bucketed
+        # all-reduce(mean) of the gradients (whmr_amd.parallel.GradReducer); no optimizer step (the reference's Adam is not a path kernel)
+        from whmr_amd.models import whmr_net
+        from whmr_amd.parallel import GradReducer
+        assets = synth.make_assets(0)
+        sd = synth.make_state_dict(0, assets, with_cam_model=False)
+        m = whmr_net(None, assets=assets, numerics=args.numerics)
+        m.load_state_dict(sd, strict=False)
+        m = m.to(dev).train()
+        for name, p in m.named_parameters():       # frozen (cam_model) or outside the trainer's loss (dp_head, global_orient)
+            if name.startswith(('cam_model', 'dp_head', 'global_orient')):
+                p.requires_grad_(False)
+        params = [p for p in m.parameters() if p.requires_grad]
+        red = GradReducer(params)
+        rank = int(os.environ.get('RANK', '0'))
+        inp = {k: v.to(dev) for k, v in synth.make_inputs(args.batch, 7 + rank).items()}
+        a = (inp['x'], None, inp['center'], inp['scale'], inp['bbox_height'], inp['orig_shape'], inp['bbox_info'])
+        keys = ('rotmat', 'pred_shape', 'pred_cam', 'kp_2d', 'kp_2d_w', 'kp_3d', 'verts', 'sub_verts', 'temp_verts')
+
+        def train_step():
+            for p in params:
+                p.grad = None
+            out, _ = m(*a, is_train=True)
+            loss = sum(out['smpl_out'][l][k].float().pow(2).mean() for l in range(1, 4) for k in keys)
+            loss.backward()
+            red.finish()
+        return train_step, None, inp['x'], (256, 192)
     raise SystemExit('unknown workload %s' % args.workload)
 
 
@@ -149,7 +181,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    with torch.no_grad():
+    training = args.workload == 'whmr_train'
+    with (torch.enable_grad() if training else torch.no_grad()):
         for _ in range(args.warmup):
             step()
         barrier()
@@ -180,7 +213,8 @@ def main():
             'dtype': args.numerics, 'data': 'synthetic',
             'config': {'workload': '%s (%s), %dx%d crops, batch %d per GPU, random-init weights'
                                    % (WORKLOAD[args.workload], args.workload, size[0], size[1], args.batch),
-                       'global_batch': world * args.batch, 'parallelism': 'replicas x%d (no data-path collective)' % world},
+                       'global_batch': world * args.batch, 'parallelism': ('dp%d (RCCL all-reduce of the gradients, 128 MiB buckets)' % world) if training
+                                      else 'replicas x%d (no data-path collective)' % world},
             'model_tflops': VIT_FLOP_PER_IMG[args.workload] * world * args.batch * args.steps / dt / 1e12,
             'roofline': {'bound': 'mfma', 'kernel': 'gemm_bf16_big_kernel (all %d GEMM launches of one step)' % len(gemm),
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,

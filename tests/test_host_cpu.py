@@ -42,8 +42,14 @@ def test_no_cpu_fallback(assets, state_dict):
     m = whmr_net(None, assets=assets)
     with pytest.raises(RuntimeError):
         m(torch.zeros(1, 3, 256, 192))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError):                  # the training graph is HIP-only as well
         m(torch.zeros(1, 3, 256, 192), is_train=True)
+    from whmr_amd.train import DeconvBNReLUFn, LinearFn, MAFSampleFn, SMPLFn
+    with pytest.raises(RuntimeError):
+        LinearFn.apply(torch.zeros(2, 4), torch.zeros(3, 4), None)
+    with pytest.raises(RuntimeError):
+        DeconvBNReLUFn.apply(torch.zeros(1, 2, 2, 64), torch.zeros(64, 64, 4, 4), torch.ones(64), torch.zeros(64), torch.nn.BatchNorm2d(64),
+                             torch.float32)
 
 
 def test_state_dict_contract(assets, state_dict):

@@ -418,3 +418,37 @@ def test_conv_linear_downsample_nodes(dev, assets, numerics, tol):
     assert _rel(hs.detach().cpu(), sub.detach()) < 1e-5 and _rel(ht.detach().cpu(), tmp.detach()) < 1e-5
     ((hs * cs.to(dev)).sum() + (ht * ct.to(dev)).sum()).backward()
     assert _rel(dv.grad.cpu(), rv.grad) < 1e-5
+
+
+def test_whmr_train_step_bf16_error_report(dev, assets, state_dict):
+    """bf16 perf numerics of the full training step (B=2): outputs within 2e-2 of the fp32 oracle and every parameter gradient within
+    0.35 RMS -- a gross-error gate for the bf16-only code paths (one-launch 4-phase deconv, padded N=5 convolution, bf16 transposed
+    im2col / col2im, bf16 BatchNorm maps).  The agreement is bounded by ReLU / leaky-ReLU gates that flip under the 2^-9 rounding of the
+    feature maps against a white-noise cotangent at batch 2 (observed: regressor 0.5-1 %, Tz head 5 %, sampler MLP / deconv / ViT
+    10-16 % RMS; tools/probes/train_step_diag.py bf16); the fp32 mode is the parity gate."""
+    from oracle import synth
+    from oracle import train as OT
+    inp = synth.make_inputs(2, 0)
+    keys = _grad_keys(state_dict)
+    p = {k: (v.clone().requires_grad_(True) if k in keys else v) for k, v in state_dict.items()}
+    outs_ref = OT.whmr_forward_train(p, assets, inp['x'], inp['center'], inp['scale'], inp['bbox_height'], inp['orig_shape'], inp['bbox_info'])
+    OT.cotangent_loss(outs_ref).backward()
+    m = _train_model(assets, state_dict, 'bf16', dev)
+    d = {k: inp[k].to(dev) for k in ('x', 'center', 'scale', 'bbox_height', 'orig_shape', 'bbox_info')}
+    out_list, _ = m(d['x'], None, d['center'], d['scale'], d['bbox_height'], d['orig_shape'], d['bbox_info'], is_train=True)
+    OT.cotangent_loss(out_list['smpl_out'], dev=dev).backward()
+    for l in range(1, 4):
+        for k in ('verts', 'kp_2d', 'kp_3d', 'rotmat', 'pred_shape', 'pred_cam'):
+            assert _rel(out_list['smpl_out'][l][k].detach().cpu(), outs_ref[l][k].detach()) < 2e-2, (l, k)
+    named = dict(m.named_parameters())
+    rep = {}
+    for k in keys:
+        if p[k].grad.abs().max() < 1e-8:
+            continue
+        rep[k] = _rms(named[k].grad.cpu(), p[k].grad)
+    bad = {k: v for k, v in rep.items() if not v < 0.35}
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:8]
+    groups = {}
+    for k, v in rep.items():
+        groups.setdefault(k.split('.')[0], []).append(v)
+    print('bf16 train-step gradient RMS error by module: ' + ', '.join('%s %.3f' % (g, max(v)) for g, v in sorted(groups.items())))

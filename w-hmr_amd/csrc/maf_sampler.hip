@@ -414,6 +414,7 @@ __global__ __launch_bounds__(256) void maf_sample_bwd_kernel(const TF* __restric
         float acc[PT];
 #pragma unroll
         for (int pp = 0; pp < PT; ++pp) acc[pp] = wts.b0[tid];
+#pragma unroll 8
         for (int i = 0; i < CF; ++i) {
             const float w = wts.w0t[(size_t)i * 128 + tid];
 #pragma unroll
@@ -426,7 +427,9 @@ __global__ __launch_bounds__(256) void maf_sample_bwd_kernel(const TF* __restric
     {
         const int o = tid & 63, hp = (tid >> 6) * 2;
         float acc[2] = {wts.b1[o], wts.b1[o]};
+#pragma unroll 8
         for (int i = 0; i < 128; ++i) { const float w = wts.w1t[(size_t)i * 64 + o]; acc[0] = fmaf(w, sY0[i][hp], acc[0]); acc[1] = fmaf(w, sY0[i][hp + 1], acc[1]); }
+#pragma unroll 8
         for (int i = 0; i < CF; ++i) { const float w = wts.w1t[(size_t)(128 + i) * 64 + o]; acc[0] = fmaf(w, sF[i][hp], acc[0]); acc[1] = fmaf(w, sF[i][hp + 1], acc[1]); }
         sY1[o][hp] = acc[0] > 0.f ? acc[0] : 0.01f * acc[0];
         sY1[o][hp + 1] = acc[1] > 0.f ? acc[1] : 0.01f * acc[1];
@@ -435,7 +438,9 @@ __global__ __launch_bounds__(256) void maf_sample_bwd_kernel(const TF* __restric
     {   // layer 2 + ReLU gate + upstream gradient: thread = (output channel, point)
         const int o = tid & 31, pp = tid >> 5;
         float acc = wts.b2[o];
+#pragma unroll 8
         for (int i = 0; i < 64; ++i) acc = fmaf(wts.w2t[(size_t)i * 32 + o], sY1[i][pp], acc);
+#pragma unroll 8
         for (int i = 0; i < CF; ++i) acc = fmaf(wts.w2t[(size_t)(64 + i) * 32 + o], sF[i][pp], acc);
         const int p = p0 + pp;
         sD2[o][pp] = (p < P && acc > 0.f) ? d_out[(size_t)b * dout_stride + (size_t)o * P + p] : 0.f;
@@ -446,6 +451,7 @@ __global__ __launch_bounds__(256) void maf_sample_bwd_kernel(const TF* __restric
         float acc[PT];
 #pragma unroll
         for (int pp = 0; pp < PT; ++pp) acc[pp] = 0.f;
+#pragma unroll 8
         for (int o = 0; o < 32; ++o) {
             const float w = w2[(size_t)o * 320 + i];
 #pragma unroll
@@ -465,6 +471,7 @@ __global__ __launch_bounds__(256) void maf_sample_bwd_kernel(const TF* __restric
         float acc[PT];
 #pragma unroll
         for (int pp = 0; pp < PT; ++pp) acc[pp] = 0.f;
+#pragma unroll 8
         for (int o = 0; o < 64; ++o) {
             const float w = w1[(size_t)o * 384 + i];
 #pragma unroll
@@ -483,6 +490,7 @@ __global__ __launch_bounds__(256) void maf_sample_bwd_kernel(const TF* __restric
         float acc[PT];
 #pragma unroll
         for (int pp = 0; pp < PT; ++pp) acc[pp] = 0.f;
+#pragma unroll 8
         for (int o = 0; o < 128; ++o) {
             const float w = w0[(size_t)o * CF + tid];
 #pragma unroll

@@ -475,21 +475,23 @@ __global__ __launch_bounds__(128) void smpl_skin_bwd_kernel(const whmr_smpl_mode
     }
 }
 
-__global__ __launch_bounds__(64) void smpl_chain_bwd_kernel(const whmr_smpl_model m, const float* __restrict__ rotmat, const float* __restrict__ betas,
+__global__ __launch_bounds__(256) void smpl_chain_bwd_kernel(const whmr_smpl_model m, const float* __restrict__ rotmat, const float* __restrict__ betas,
                                                             long beta_stride, const float* __restrict__ dA_partial, int nparts,
                                                             const float* __restrict__ d_posed_joints, const float* __restrict__ d_pf_beta,
                                                             float* __restrict__ d_rotmat, float* __restrict__ d_betas) {
     __shared__ float sR[NJ][9], sJ[NJ][3], sGr[NJ][9], sGt[NJ][3];
     __shared__ float dA[NJ][12], dGr[NJ][9], dT[NJ][3], dJ[NJ][3], dR[NJ][9];
+    // 256 threads: the partial-sum / element-wise phases use all of them, the serial chain steps only lanes 0..11
     const int b = blockIdx.x, lane = threadIdx.x;
-    for (int e = lane; e < NJ * 9; e += 64) sR[e / 9][e % 9] = rotmat[(size_t)b * NJ * 9 + e];
-    for (int e = lane; e < NJ * 3; e += 64) {
+    for (int e = lane; e < NJ * 9; e += 256) sR[e / 9][e % 9] = rotmat[(size_t)b * NJ * 9 + e];
+    for (int e = lane; e < NJ * 3; e += 256) {
         float acc = 0.f;
         for (int l = 0; l < 10; ++l) acc = fmaf(m.J_shapedirs[e * 10 + l], betas[(size_t)b * beta_stride + l], acc);
         sJ[e / 3][e % 3] = m.J_template[e] + acc;
     }
-    for (int e = lane; e < NJ * 12; e += 64) {
+    for (int e = lane; e < NJ * 12; e += 256) {
         float a = 0.f;
+#pragma unroll 6
         for (int p = 0; p < nparts; ++p) a += dA_partial[((size_t)b * nparts + p) * (NJ * 12) + e];
         dA[e / 12][e % 12] = a;
     }
@@ -510,11 +512,11 @@ __global__ __launch_bounds__(64) void smpl_chain_bwd_kernel(const whmr_smpl_mode
         __syncthreads();
     }
     // A_i = [Gr_i | t_i - Gr_i J_i],  posed_joints_i = t_i
-    for (int e = lane; e < NJ * 9; e += 64) {
+    for (int e = lane; e < NJ * 9; e += 256) {
         const int j = e / 9, r = (e % 9) / 3, c = e % 3;
         dGr[j][r * 3 + c] = dA[j][r * 4 + c] - dA[j][r * 4 + 3] * sJ[j][c];
     }
-    for (int e = lane; e < NJ * 3; e += 64) {
+    for (int e = lane; e < NJ * 3; e += 256) {
         const int j = e / 3, c = e % 3;
         dT[j][c] = dA[j][c * 4 + 3] + (d_posed_joints ? d_posed_joints[(size_t)b * 72 + e] : 0.f);
         dJ[j][c] = -(sGr[j][c] * dA[j][3] + sGr[j][3 + c] * dA[j][7] + sGr[j][6 + c] * dA[j][11]);
@@ -539,7 +541,7 @@ __global__ __launch_bounds__(64) void smpl_chain_bwd_kernel(const whmr_smpl_mode
     if (lane < 9) dR[0][lane] = dGr[0][lane];
     if (lane < 3) dJ[0][lane] += dT[0][lane];
     __syncthreads();
-    for (int e = lane; e < NJ * 9; e += 64)
+    for (int e = lane; e < NJ * 9; e += 256)
         d_rotmat[(size_t)b * NJ * 9 + e] = dR[e / 9][e % 9] + (e >= 9 ? d_pf_beta[(size_t)b * 217 + e - 9] : 0.f);
     if (lane < 10) {
         float a = d_pf_beta[(size_t)b * 217 + NPF + lane];
@@ -573,7 +575,7 @@ extern "C" int whmr_smpl_skin_bwd(const whmr_smpl_model* m, const float* betas, 
 extern "C" int whmr_smpl_chain_bwd(const whmr_smpl_model* m, const float* rotmat, const float* betas, long beta_stride, const float* dA_partial,
                                    const float* d_posed_joints, const float* d_pf_beta, int B, float* d_rotmat, float* d_betas, void* stream) {
     if (B <= 0) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(smpl_chain_bwd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, *m, rotmat, betas, beta_stride, dA_partial, SKIN_BWD_BLOCKS,
+    hipLaunchKernelGGL(smpl_chain_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, *m, rotmat, betas, beta_stride, dA_partial, SKIN_BWD_BLOCKS,
                        d_posed_joints, d_pf_beta, d_rotmat, d_betas);
     WHMR_CHECK_LAUNCH();
     return 0;

@@ -24,8 +24,9 @@ def shard_batch(global_batch, world_size, rank):
 
 
 class GradReducer:
-    def __init__(self, params, bucket_bytes=128 << 20, process_group=None, average=True):
+    def __init__(self, params, bucket_bytes=128 << 20, process_group=None, average=True, always_bucket=False):
         self.params = [p for p in params if p.requires_grad]
+        self.always_bucket = always_bucket       # pack into flat buckets even at world size 1 (tests / flat-gradient optimizers)
         self.group = process_group
         self.average = average
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -55,12 +56,16 @@ class GradReducer:
         self.buckets.append(dict(params=ps, offsets=offs, numel=n, flat=None, pending=len(ps), work=None, event=None))
 
     def _on_grad(self, p):
+        if self.world == 1 and not self.always_bucket:
+            return                               # single process: nothing to exchange, the gradients stay where autograd put them
         b, i = self._slot[id(p)]
-        if b['flat'] is None:
-            b['flat'] = torch.empty(b['numel'], dtype=torch.float32, device=p.grad.device)
-        b['flat'][b['offsets'][i]:b['offsets'][i] + p.numel()].copy_(p.grad.reshape(-1))
         b['pending'] -= 1
         if b['pending'] == 0:
+            # the bucket's last gradient has arrived: ONE multi-tensor copy packs all of them (a copy per hook was ~225 small launches
+            # per step: 1.3 ms of the batch-64 W-HMR step), then the exchange starts
+            flat = b['flat'] = torch.empty(b['numel'], dtype=torch.float32, device=p.grad.device)
+            views = [flat[off:off + q.numel()].view_as(q) for q, off in zip(b['params'], b['offsets'])]
+            torch._foreach_copy_(views, [q.grad for q in b['params']])
             self._launch(b)
 
     def _launch(self, b):
@@ -79,6 +84,8 @@ class GradReducer:
 
     def finish(self):
         """Wait for every bucket, apply the 1/world mean, and make ``p.grad`` views of the reduced buckets."""
+        if self.world == 1 and not self.always_bucket:
+            return
         for b in self.buckets:
             if b['pending'] != 0:
                 missing = [tuple(p.shape) for p in b['params'] if p.grad is None]
