@@ -452,3 +452,21 @@ def test_whmr_train_step_bf16_error_report(dev, assets, state_dict):
     for k, v in rep.items():
         groups.setdefault(k.split('.')[0], []).append(v)
     print('bf16 train-step gradient RMS error by module: ' + ', '.join('%s %.3f' % (g, max(v)) for g, v in sorted(groups.items())))
+
+
+def test_regressor_forward_is_train_direct_call(dev, assets, state_dict):
+    """Regressor.forward(is_train=True) called on its own (whmr.py:102-209): output dict with a graph, gradients reach its Linear layers."""
+    m = _train_model(assets, state_dict, 'fp32', dev)
+    reg = m.regressor[1]
+    B = 3
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(B, 67 * 32, generator=g).to(dev).requires_grad_(True)
+    bbox = torch.rand(B, 5, generator=g).to(dev)
+    Tz = (torch.rand(B, generator=g) * 5 + 2).to(dev)
+    orig = torch.tensor([[720., 1280.]] * B, device=dev)
+    center = torch.tensor([[640., 360.]] * B, device=dev)
+    out, feat = reg(x, bbox, Tz, orig, center, torch.ones(B, device=dev), torch.full((B,), 300., device=dev), is_train=True)
+    assert feat.shape == (B, 67 * 32 + 5) and out['verts'].shape == (B, 6890, 3) and out['verts'].requires_grad
+    (out['verts'].pow(2).mean() + out['kp_2d_w'].pow(2).mean()).backward()
+    assert x.grad is not None and reg.fc1.weight.grad is not None and reg.deccam.weight.grad is not None
+    assert torch.isfinite(reg.fc1.weight.grad).all() and reg.fc1.weight.grad.abs().max() > 0

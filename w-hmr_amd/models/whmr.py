@@ -159,12 +159,24 @@ class Regressor(nn.Module):
             d['sub_verts'], d['temp_verts'] = self._downsample(verts)
         return d
 
-    @torch.no_grad()
     def forward(self, x, bbox_info, Tz, orig_shape, center, scale, bbox_height, init_pose=None, init_shape=None,
                 init_cam=None, is_train=False, n_iter=1, J_regressor=None, with_aux=True, xc=None):
         """x [B, feat] (or pre-filled xc buffer [B, feat+5+229] whose first ``feat`` columns hold x) -> (dict, body_feat)."""
-        if is_train:
-            raise NotImplementedError('whmr_amd is inference-only this round (backward kernels: SURVEY 7 step 7)')
+        if is_train:       # whmr.py:102-209 in training: autograd nodes with HIP forward + backward (whmr_amd.train.whmr_train)
+            from ..train.whmr_train import regressor_train
+            assert n_iter == 1 and J_regressor is None, 'the training graph is built for n_iter = 1 without J_regressor (core/trainer.py:410)'
+            B = bbox_info.shape[0]
+            pose = self.init_pose.expand(B, -1) if init_pose is None else init_pose
+            shape = self.init_shape.expand(B, -1) if init_shape is None else init_shape
+            cam = self.init_cam.expand(B, -1) if init_cam is None else init_cam
+            return regressor_train(self, x, bbox_info.float(), Tz, orig_shape.float(), center.float(), scale, bbox_height.float(), pose, shape,
+                                   cam, self.__dict__.setdefault('_train_cache', {}))
+        with torch.no_grad():
+            return self._forward_eval(x, bbox_info, Tz, orig_shape, center, scale, bbox_height, init_pose, init_shape, init_cam, n_iter,
+                                      J_regressor, with_aux, xc)
+
+    def _forward_eval(self, x, bbox_info, Tz, orig_shape, center, scale, bbox_height, init_pose, init_shape, init_cam, n_iter, J_regressor,
+                      with_aux, xc):
         B = bbox_info.shape[0]
         dev = bbox_info.device
         F = self.fc1.in_features - 229 - 5
