@@ -467,6 +467,53 @@ def test_regressor_forward_is_train_direct_call(dev, assets, state_dict):
     center = torch.tensor([[640., 360.]] * B, device=dev)
     out, feat = reg(x, bbox, Tz, orig, center, torch.ones(B, device=dev), torch.full((B,), 300., device=dev), is_train=True)
     assert feat.shape == (B, 67 * 32 + 5) and out['verts'].shape == (B, 6890, 3) and out['verts'].requires_grad
-    (out['verts'].pow(2).mean() + out['kp_2d_w'].pow(2).mean()).backward()
+    (out['verts'].pow(2).mean() + out['kp_2d_w'].pow(2).mean() + out['kp_2d'].pow(2).mean()).backward()    # kp_2d carries the camera gradient
     assert x.grad is not None and reg.fc1.weight.grad is not None and reg.deccam.weight.grad is not None
     assert torch.isfinite(reg.fc1.weight.grad).all() and reg.fc1.weight.grad.abs().max() > 0
+
+
+def test_train_step_hip_graph_replay_matches_eager(dev, assets, state_dict):
+    """capture_train_step: the replayed whole-step HIP graph (forward + loss + backward, B=2, fp32, dropout off) reproduces the eager step's
+    loss and parameter gradients, and follows new data copied into the static input tensors."""
+    from oracle import synth
+    from oracle import train as OT
+    from whmr_amd.train import capture_train_step
+    m = _train_model(assets, state_dict, 'fp32', dev)
+    for name, p_ in m.named_parameters():
+        if name.startswith(('cam_model', 'dp_head', 'global_orient')):
+            p_.requires_grad_(False)
+    params = [p_ for p_ in m.parameters() if p_.requires_grad]
+    inp = synth.make_inputs(2, 0)
+    d = {k: inp[k].to(dev).clone() for k in ('x', 'center', 'scale', 'bbox_height', 'orig_shape', 'bbox_info')}
+
+    with torch.no_grad():                                   # device-resident cotangents (no host -> device copy inside the captured step)
+        out0, _ = m(d['x'], None, d['center'], d['scale'], d['bbox_height'], d['orig_shape'], d['bbox_info'], is_train=True)
+    g = torch.Generator().manual_seed(3)
+    cots = [[(torch.randn(out0['smpl_out'][l][k].shape, generator=g) / out0['smpl_out'][l][k][0].numel() ** 0.5).to(dev)
+             for k in OT.TRAIN_LOSS_KEYS] for l in range(1, 4)]
+
+    def step():
+        for p_ in params:
+            p_.grad = None
+        out, _ = m(d['x'], None, d['center'], d['scale'], d['bbox_height'], d['orig_shape'], d['bbox_info'], is_train=True)
+        loss = sum((out['smpl_out'][l + 1][k] * cots[l][i]).sum() for l in range(3) for i, k in enumerate(OT.TRAIN_LOSS_KEYS))
+        loss.backward()
+        return loss
+    replay, loss = capture_train_step(m, step)
+    bn_state = {k: v.clone() for k, v in m.state_dict().items() if 'running' in k}
+
+    def eager_reference():
+        m.load_state_dict(bn_state, strict=False)               # the running statistics are updated in place by every step
+        le = step()
+        return le.item(), {id(p_): p_.grad.clone() for p_ in params}
+    for seed in (0, 5):
+        new = synth.make_inputs(2, seed)
+        for k in d:
+            d[k].copy_(new[k].to(dev))
+        le, ge = eager_reference()
+        m.load_state_dict(bn_state, strict=False)
+        replay()
+        torch.cuda.synchronize()
+        assert abs(loss.item() - le) < 1e-5 * max(1.0, abs(le)), (seed, loss.item(), le)
+        worst = max(_rel(p_.grad, ge[id(p_)]) for p_ in params if ge[id(p_)].abs().max() > 1e-8)
+        assert worst < 1e-4, (seed, worst)

@@ -18,7 +18,7 @@ LOSS_KEYS = ('rotmat', 'pred_shape', 'pred_cam', 'kp_2d', 'kp_2d_w', 'kp_3d', 'v
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-    numerics = sys.argv[3] if len(sys.argv) > 3 else 'bf16'
+    numerics = sys.argv[3] if (len(sys.argv) > 3 and not sys.argv[3].startswith('--')) else 'bf16'
     dev = torch.device('cuda:0')
     assets = synth.make_assets(0)
     sd = synth.make_state_dict(0, assets, with_cam_model=False)
@@ -29,7 +29,8 @@ def main():
         if name.startswith(('cam_model', 'dp_head', 'global_orient')):
             p.requires_grad_(False)
     params = [p for p in m.parameters() if p.requires_grad]
-    red = GradReducer(params)
+    use_graph = '--graph' in sys.argv
+    red = None if use_graph else GradReducer(params)   # (its hooks keep the AccumulateGrad nodes of the first eager step alive)
     inp = synth.make_inputs(B, 0)
     d = {k: inp[k].to(dev) for k in ('x', 'center', 'scale', 'bbox_height', 'orig_shape', 'bbox_info')}
 
@@ -42,21 +43,32 @@ def main():
             for k in LOSS_KEYS:
                 loss = loss + out['smpl_out'][l][k].float().pow(2).mean()
         loss.backward()
-        red.finish()
+        if red is not None:
+            red.finish()
         return loss
 
-    for _ in range(2):
-        loss = step()
-    torch.cuda.synchronize()
+    if not use_graph:
+        for _ in range(2):
+            loss = step()
+        torch.cuda.synchronize()
+    if use_graph:      # whole step captured once and replayed (whmr_amd.train.capture_train_step)
+        from whmr_amd.train import capture_train_step
+        replay, static_loss = capture_train_step(m, step)
+        step = lambda: (replay(), static_loss)[1]
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     flops = 3 * (34.20e9 + 9.26e9 + 1.98e9) * B
-    print('W-HMR train step B=%d %s (forward + backward + gradient buckets, no optimizer): %.2f ms  %.0f img/s  %.0f TFLOP/s (3 x forward FLOPs of '
-          'ViT + deconvs + Tz conv)  loss %.4f  peak memory %.1f GB' % (B, numerics, dt * 1e3, B / dt, flops / dt / 1e12, float(loss),
-                                                                        torch.cuda.max_memory_allocated() / 2 ** 30))
+    fmt = ('W-HMR train step B=%d %s' + (' [HIP graph replay]' if use_graph else '') + ' (forward + backward + gradient buckets, no optimizer): '
+           '%.2f ms  %.0f img/s  %.0f TFLOP/s (3 x forward FLOPs of ViT + deconvs + Tz conv)  loss %.4f  peak memory %.1f GB')
+    print(fmt % (B, numerics, dt * 1e3, B / dt, flops / dt / 1e12, float(loss.detach()), torch.cuda.max_memory_allocated() / 2 ** 30))
+    if use_graph:
+        return
     # forward / backward split
     torch.cuda.synchronize()
     e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]

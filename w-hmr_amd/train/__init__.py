@@ -4,3 +4,4 @@ from .smpl_autograd import SMPLFn, smpl_forward_train, smpl_backward      # noqa
 from .maf_autograd import MAFSampleFn      # noqa: F401
 from .heads_autograd import LinearFn, ConvNHWCFn, DownsampleFn      # noqa: F401
 from .whmr_train import whmr_forward_train, regressor_train, tz_head_train      # noqa: F401
+from .graph_step import capture_train_step      # noqa: F401

@@ -99,7 +99,7 @@ def regressor_train(reg, ref, bbox_info, Tz, orig_shape, center, scale, bbox_hei
     kp_2d = _projection(joints if stage == 1 else joints.detach(), cam_n)              # whmr.py:142-145
     s = cam_n[:, 0].detach()
     focal = s * bbox_height * Tz / 2.0                                                 # whmr.py:147-149
-    cam_center = orig_shape[:, [1, 0]] / 2.0
+    cam_center = orig_shape.flip(1) / 2.0                                               # == orig_shape[:, [1, 0]] (no index upload: graph-capturable)
     cd = cam_n.detach()                                                                # geometry.py:139-157 on pred_cam.detach()
     cam_t = torch.stack([cd[:, 1] + 2.0 * (center[:, 0] - orig_shape[:, 1] / 2.0) / (cd[:, 0] * bbox_height),
                          cd[:, 2] + 2.0 * (center[:, 1] - orig_shape[:, 0] / 2.0) / (cd[:, 0] * bbox_height), Tz], dim=-1)
