@@ -39,6 +39,7 @@ def parse():
     ap.add_argument('--workload', default='vit224')
     ap.add_argument('--numerics', default='bf16')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
+    ap.add_argument('--graph', action='store_true', help='whmr_train on one GPU: replay the whole step from one HIP graph')
     return ap.parse_args()
 
 
@@ -83,7 +84,9 @@ def build_workload(args, dev):
             if name.startswith(('cam_model', 'dp_head', 'global_orient')):
                 p.requires_grad_(False)
         params = [p for p in m.parameters() if p.requires_grad]
-        red = GradReducer(params)
+        world = int(os.environ.get('WORLD_SIZE', '1'))
+        use_graph = args.graph and world == 1
+        red = None if use_graph else GradReducer(params)      # (no exchange on one GPU; its hooks would pin pre-capture autograd nodes)
         rank = int(os.environ.get('RANK', '0'))
         inp = {k: v.to(dev) for k, v in synth.make_inputs(args.batch, 7 + rank).items()}
         a = (inp['x'], None, inp['center'], inp['scale'], inp['bbox_height'], inp['orig_shape'], inp['bbox_info'])
@@ -95,7 +98,15 @@ def build_workload(args, dev):
             out, _ = m(*a, is_train=True)
             loss = sum(out['smpl_out'][l][k].float().pow(2).mean() for l in range(1, 4) for k in keys)
             loss.backward()
-            red.finish()
+            if red is not None:
+                red.finish()
+            return loss
+        if use_graph:
+            from whmr_amd.train import capture_train_step
+            with torch.enable_grad():
+                replay, _ = capture_train_step(m, train_step)
+            args.eager_step = train_step                       # the instrumented (per-GEMM event) step cannot come from a graph replay
+            return replay, None, inp['x'], (256, 192)
         return train_step, None, inp['x'], (256, 192)
     raise SystemExit('unknown workload %s' % args.workload)
 
@@ -193,7 +204,7 @@ def main():
         dt = time.perf_counter() - t0
         # dominant-kernel timing: one instrumented step, HIP events around every GEMM launch on the launch stream
         L.PROFILE = []
-        step()
+        getattr(args, 'eager_step', step)()
         torch.cuda.synchronize()
         prof, L.PROFILE = L.PROFILE, None
     dt = reduce_max_time(dt, dist, dev)
