@@ -24,10 +24,10 @@ VIT_FLOP_PER_IMG = {'vit224': 34.94e9, 'vit256x192': 34.20e9, 'vitl256x192': 119
 METRIC = {'vit224': 'images/sec ViT-B 224^2 batch-64 fwd', 'vit256x192': 'images/sec ViT-B 256x192 batch-64 fwd',
           'vitl256x192': 'images/sec ViT-L 256x192 fwd',
           'whmr': 'images/sec full W-HMR fwd (ViT-B + 3-iter MAF loop + orientation) batch-64',
-          'whmr_train': 'images/sec W-HMR train step (fwd + bwd + DP gradient all-reduce, no optimizer) batch-64 per GPU'}
+          'whmr_train': 'images/sec W-HMR train step (fwd + bwd + DP gradient all-reduce + Adam) batch-64 per GPU'}
 WORKLOAD = {'vit224': 'ViT-B/16 backbone forward', 'vit256x192': 'ViT-B/16 backbone forward', 'vitl256x192': 'ViT-L/16 backbone forward',
             'whmr': 'full W-HMR forward (ViT-B + deconv pyramid + Tz head + 3-iteration MAF/regressor/SMPL loop + global orientation)',
-            'whmr_train': 'W-HMR training step: WHMR.forward(is_train=True), synthetic loss on the supervised outputs, HIP backward, gradient buckets'}
+            'whmr_train': 'W-HMR training step: WHMR.forward(is_train=True), synthetic loss on the supervised outputs, HIP backward, gradient buckets, fused Adam'}
 
 
 def parse():
@@ -72,7 +72,7 @@ def build_workload(args, dev):
     if args.workload == 'whmr_train':
         # BASELINE configs[3] (train.py pymaf_net step, batch 64 per GPU, DP gradient all-reduce over RCCL): forward in training mode,
         # a synthetic L2 loss on the tensors core/trainer.py:500-600 supervises, backward through the HIP autograd nodes, bucketed
-        # all-reduce(mean) of the gradients (whmr_amd.parallel.GradReducer); no optimizer step (the reference's Adam is not a path kernel)
+        # all-reduce(mean) of the gradients (whmr_amd.parallel.GradReducer), Adam update
         from whmr_amd.models import whmr_net
         from whmr_amd.parallel import GradReducer
         assets = synth.make_assets(0)
@@ -92,7 +92,12 @@ def build_workload(args, dev):
         a = (inp['x'], None, inp['center'], inp['scale'], inp['bbox_height'], inp['orig_shape'], inp['bbox_info'])
         keys = ('rotmat', 'pred_shape', 'pred_cam', 'kp_2d', 'kp_2d_w', 'kp_3d', 'verts', 'sub_verts', 'temp_verts')
 
-        def train_step():
+        # the reference's optimizer (core/trainer.py:110-114: Adam, lr = SOLVER.BASE_LR 5e-5) runs inside the timed step: torch's fused
+        # multi-tensor Adam -- not a path kernel, but a training number without the update would be incomplete.  Its in-place update bumps
+        # the parameter versions, so the bf16 operand copies of the weights are re-cast every step, as in a real run.
+        opt = torch.optim.Adam(params, lr=5e-5, fused=True)
+
+        def fwd_bwd():
             for p in params:
                 p.grad = None
             out, _ = m(*a, is_train=True)
@@ -101,12 +106,21 @@ def build_workload(args, dev):
             if red is not None:
                 red.finish()
             return loss
+
+        def train_step():
+            loss = fwd_bwd()
+            opt.step()
+            return loss
         if use_graph:
             from whmr_amd.train import capture_train_step
             with torch.enable_grad():
-                replay, _ = capture_train_step(m, train_step)
+                replay, _ = capture_train_step(m, fwd_bwd)       # forward + backward replayed; the optimizer step stays eager
+
+            def graph_step():
+                replay()
+                opt.step()
             args.eager_step = train_step                       # the instrumented (per-GEMM event) step cannot come from a graph replay
-            return replay, None, inp['x'], (256, 192)
+            return graph_step, None, inp['x'], (256, 192)
         return train_step, None, inp['x'], (256, 192)
     raise SystemExit('unknown workload %s' % args.workload)
 

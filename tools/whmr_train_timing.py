@@ -31,6 +31,7 @@ def main():
     params = [p for p in m.parameters() if p.requires_grad]
     use_graph = '--graph' in sys.argv
     red = None if use_graph else GradReducer(params)   # (its hooks keep the AccumulateGrad nodes of the first eager step alive)
+    opt = torch.optim.Adam(params, lr=5e-5, fused=True) if '--adam' in sys.argv else None     # core/trainer.py:110-114
     inp = synth.make_inputs(B, 0)
     d = {k: inp[k].to(dev) for k in ('x', 'center', 'scale', 'bbox_height', 'orig_shape', 'bbox_info')}
 
@@ -45,6 +46,8 @@ def main():
         loss.backward()
         if red is not None:
             red.finish()
+        if opt is not None and not use_graph:
+            opt.step()
         return loss
 
     if not use_graph:
@@ -54,7 +57,7 @@ def main():
     if use_graph:      # whole step captured once and replayed (whmr_amd.train.capture_train_step)
         from whmr_amd.train import capture_train_step
         replay, static_loss = capture_train_step(m, step)
-        step = lambda: (replay(), static_loss)[1]
+        step = (lambda: (replay(), opt.step(), static_loss)[2]) if opt is not None else (lambda: (replay(), static_loss)[1])
         for _ in range(2):
             step()
         torch.cuda.synchronize()
@@ -64,7 +67,7 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     flops = 3 * (34.20e9 + 9.26e9 + 1.98e9) * B
-    fmt = ('W-HMR train step B=%d %s' + (' [HIP graph replay]' if use_graph else '') + ' (forward + backward + gradient buckets, no optimizer): '
+    fmt = ('W-HMR train step B=%d %s' + (' [HIP graph replay]' if use_graph else '') + ' (forward + backward + gradient buckets' + (' + fused Adam' if opt is not None else ', no optimizer') + '): '
            '%.2f ms  %.0f img/s  %.0f TFLOP/s (3 x forward FLOPs of ViT + deconvs + Tz conv)  loss %.4f  peak memory %.1f GB')
     print(fmt % (B, numerics, dt * 1e3, B / dt, flops / dt / 1e12, float(loss.detach()), torch.cuda.max_memory_allocated() / 2 ** 30))
     if use_graph:
