@@ -517,3 +517,41 @@ def test_train_step_hip_graph_replay_matches_eager(dev, assets, state_dict):
         assert abs(loss.item() - le) < 1e-5 * max(1.0, abs(le)), (seed, loss.item(), le)
         worst = max(_rel(p_.grad, ge[id(p_)]) for p_ in params if ge[id(p_)].abs().max() > 1e-8)
         assert worst < 1e-4, (seed, worst)
+
+
+def test_bn_and_col2im_edge_shapes(dev):
+    """BatchNorm kernels at C = 64 (32 rows per block pass) with a row count that is not a multiple of anything, fp32 and bf16 maps, running
+    statistics and accumulate mode; col2im with padding against F.fold."""
+    import torch.nn.functional as F
+    from whmr_amd import _lib as L
+    g = torch.Generator().manual_seed(9)
+    M, C = 1237, 64
+    z = torch.randn(M, C, generator=g) * 2.0 + 0.7
+    gam, bet = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    dy = torch.randn(M, C, generator=g)
+    for dt, tol in ((torch.float32, 1e-5), (torch.bfloat16, 2e-2)):
+        zr = z.to(dt).float().detach().clone().requires_grad_(True)
+        gr, br = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+        rm, rv = torch.zeros(C), torch.ones(C)
+        y = F.relu(F.batch_norm(zr, rm, rv, gr, br, True, 0.1, 1e-5))
+        y.backward(dy.to(dt).float())
+        zd = z.to(dt).to(dev)
+        drm, drv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        st = L.bn_stats(zd, gam.to(dev), bet.to(dev), 1e-5, 0.1, drm, drv)
+        assert _rel(drm.cpu(), rm) < 1e-5 and _rel(drv.cpu(), rv) < 1e-5
+        yd = torch.empty_like(zd)
+        L.bn_apply_relu(zd, st, yd)
+        assert _rel(yd.float().cpu(), y.detach()) < tol
+        dz = torch.empty_like(zd)
+        dg, db = torch.ones(C, device=dev), torch.ones(C, device=dev)
+        L.bn_relu_bwd(zd, dy.to(dt).to(dev), st, dz, dg, db, accumulate=True)
+        assert _rel(dz.float().cpu(), zr.grad) < tol and _rel(dg.cpu() - 1, gr.grad) < 1e-4 and _rel(db.cpu() - 1, br.grad) < 1e-4
+    B, Cc, IH, IW, KH, KW, S, P = 2, 64, 9, 7, 4, 4, 2, 1
+    OH, OW = (IH + 2 * P - KH) // S + 1, (IW + 2 * P - KW) // S + 1
+    dcol = torch.randn(B * OH * OW, KH * KW * Cc, generator=g)
+    # F.fold wants [B, C*KH*KW, L] with channel-major patches: our columns are (ky, kx, c)
+    cols = dcol.view(B, OH * OW, KH * KW, Cc).permute(0, 3, 2, 1).reshape(B, Cc * KH * KW, OH * OW)
+    ref = F.fold(cols, (IH, IW), (KH, KW), padding=P, stride=S)                       # [B, C, IH, IW]
+    dx = torch.empty(B, IH, IW, Cc, device=dev)
+    L.col2im(dcol.to(dev), dx, OH, OW, KH, KW, S, P)
+    assert _rel(dx.cpu().permute(0, 3, 1, 2), ref) < 1e-5
