@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 VIT_FLOP_PER_IMG = {'vit224': 34.94e9, 'vit256x192': 34.20e9, 'vitl256x192': 119.9e9, 'whmr': 34.20e9 + 9.26e9 + 1.98e9,
-                    'whmr_train': 3 * (34.20e9 + 9.26e9 + 1.98e9)}
+                    'whmr_train': 3 * (34.20e9 + 9.26e9 + 1.98e9 + 5.10e9)}        # + IUV head: 4 3x3 convs, 90 channels on the 128x96 map
 METRIC = {'vit224': 'images/sec ViT-B 224^2 batch-64 fwd', 'vit256x192': 'images/sec ViT-B 256x192 batch-64 fwd',
           'vitl256x192': 'images/sec ViT-L 256x192 fwd',
           'whmr': 'images/sec full W-HMR fwd (ViT-B + 3-iter MAF loop + orientation) batch-64',
@@ -102,6 +102,7 @@ def build_workload(args, dev):
                 p.grad = None
             out, _ = m(*a, is_train=True)
             loss = sum(out['smpl_out'][l][k].float().pow(2).mean() for l in range(1, 4) for k in keys)
+            loss = loss + sum(v.pow(2).mean() for v in (out['dp_out'][0].values() if out['dp_out'] else ()))     # IUV head (AUX_SUPV_ON)
             loss.backward()
             if red is not None:
                 red.finish()

@@ -74,8 +74,9 @@ def regressor_forward_train(sd, assets, i, x, bbox_info, Tz, orig_shape, center,
     return out, x
 
 
-def whmr_forward_train(sd, assets, x, center, scale, bbox_height, orig_shape, bbox_info, stage=2, stats=None):
-    """-> list of the 4 ``smpl_out`` dicts (mean-pose mesh + 3 stages).  ``stats`` (dict, optional) receives the updated BN running stats."""
+def whmr_forward_train(sd, assets, x, center, scale, bbox_height, orig_shape, bbox_info, stage=2, stats=None, dp_out=None):
+    """-> list of the 4 ``smpl_out`` dicts (mean-pose mesh + 3 stages).  ``stats`` (dict, optional) receives the updated BN running stats,
+    ``dp_out`` (list, optional) the IUV head's output dict."""
     B = x.shape[0]
     s_feat = vit_forward(sd, x, 'feature_extractor.backbone.')
     smpl_out = OW.regressor_forward_init(sd, assets, B)
@@ -85,6 +86,8 @@ def whmr_forward_train(sd, assets, x, center, scale, bbox_height, orig_shape, bb
         s_feat = F.relu(_bn_train(F.conv_transpose2d(s_feat, w, None, stride=2, padding=1), sd, 'deconv_layers.%d.' % (3 * i + 1), stats))
         fmaps.append(s_feat)
     Tz = tz_head_train(sd, s_feat.detach() if stage == 1 else s_feat, stats)
+    if dp_out is not None:
+        dp_out.append(dp_head_forward(sd, s_feat))
     for i in range(3):
         cam, shape = smpl_out['pred_cam'].detach(), smpl_out['pred_shape'].detach()
         pose, markers = smpl_out['rotmat'].detach(), smpl_out['markers'].detach()
@@ -93,6 +96,24 @@ def whmr_forward_train(sd, assets, x, center, scale, bbox_height, orig_shape, bb
         smpl_out, _ = regressor_forward_train(sd, assets, i, ref, bbox_info, Tz, orig_shape, center, scale, bbox_height, pose, shape, cam, stage)
         outs.append(smpl_out)
     return outs
+
+
+def dp_head_forward(sd, s_feat):
+    """IUV_predict_layer.forward (models/iuv_predictor.py:71-91) on the last feature map (whmr.py:656-658, AUX_SUPV_ON)."""
+    c = lambda n: F.conv2d(s_feat, sd['dp_head.%s.weight' % n], sd['dp_head.%s.bias' % n], stride=1, padding=1)
+    return {'predict_uv_index': c('predict_uv_index'), 'predict_ann_index': c('predict_ann_index'), 'predict_u': c('predict_u'),
+            'predict_v': c('predict_v')}
+
+
+def dp_cotangent_loss(dp, seed=1, dev=None):
+    """Fixed random linear functional of the IUV head's four outputs (same role as cotangent_loss)."""
+    g = torch.Generator().manual_seed(seed)
+    total = 0.0
+    for k in ('predict_u', 'predict_v', 'predict_uv_index', 'predict_ann_index'):
+        t = dp[k]
+        c = torch.randn(t.shape, generator=g) / float(t[0].numel()) ** 0.5
+        total = total + (t * (c.to(dev) if dev is not None else c)).sum()
+    return total
 
 
 def cotangent_loss(outs, seed=0, dev=None):

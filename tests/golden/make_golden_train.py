@@ -30,10 +30,10 @@ spec.loader.exec_module(MG)
 from oracle import synth                     # noqa: E402
 from oracle import train as OT               # noqa: E402
 
-FULL_KEYS = ('regressor.2.deccam.weight', 'regressor.0.decshape.bias', 'est_Tz.0.weight', 'deconv_layers.7.weight', 'deconv_layers.1.bias',
+FULL_KEYS = ('dp_head.predict_ann_index.bias', 'regressor.2.deccam.weight', 'regressor.0.decshape.bias', 'est_Tz.0.weight', 'deconv_layers.7.weight', 'deconv_layers.1.bias',
              'maf_extractor.2.conv2.bias', 'maf_extractor.0.conv2.weight', 'transformer_decoder.norm1.weight', 'conv.1.weight',
              'feature_extractor.backbone.last_norm.weight', 'feature_extractor.backbone.blocks.0.attn.qkv.bias')
-SKIP = ('running', 'cam_model', 'smpl', 'Dmap', 'points_grid', 'init_', 'num_batches', 'dp_head', 'global_orient')
+SKIP = ('running', 'cam_model', 'smpl', 'Dmap', 'points_grid', 'init_', 'num_batches', 'global_orient')
 
 
 def grad_keys(sd):
@@ -65,6 +65,8 @@ def main():
     cap = []
     for reg in net.regressor:
         reg.register_forward_hook(lambda m, i, o: cap.append(o[0]))
+    dp_cap = []
+    net.dp_head.register_forward_hook(lambda m, i, o: dp_cap.append(o))
     fixture = {'grad_keys': np.array(keys)}
 
     def rel(a, b):
@@ -81,20 +83,27 @@ def main():
                 mod.p = 0.0
         net.zero_grad()
         del cap[:]
+        del dp_cap[:]
         net(inp['x'], None, inp['center'], inp['scale'], inp['bbox_height'], inp['orig_shape'], inp['bbox_info'], is_train=True,
             J_regressor=None, full_x=inp['full_x'])
         assert len(cap) == 3
         loss_ref = OT.cotangent_loss([None] + cap)
-        loss_ref.backward()
+        assert len(dp_cap) == 1                      # AUX_SUPV_ON: the IUV head ran on the last feature map (whmr.py:656-658)
+        loss_dp_ref = OT.dp_cotangent_loss(dp_cap[0])
+        (loss_ref + loss_dp_ref).backward()
         ref_named = dict(net.named_parameters())
         ref_state = net.state_dict()
 
         p = {k: (v.clone().requires_grad_(True) if k in keys else v) for k, v in sd.items()}
-        stats = {}
+        stats, dp = {}, []
         outs = OT.whmr_forward_train(p, MG.ASSETS, inp['x'], inp['center'], inp['scale'], inp['bbox_height'], inp['orig_shape'],
-                                     inp['bbox_info'], stage=stage, stats=stats)
+                                     inp['bbox_info'], stage=stage, stats=stats, dp_out=dp)
         loss = OT.cotangent_loss(outs)
-        loss.backward()
+        loss_dp = OT.dp_cotangent_loss(dp[0])
+        (loss + loss_dp).backward()
+        for k in dp[0]:
+            assert rel(dp[0][k].detach(), dp_cap[0][k].detach()) < 2e-5, k
+        assert abs(loss_dp.item() - loss_dp_ref.item()) < 1e-5 * max(1.0, abs(loss_dp_ref.item()))
         print('TRAIN.STAGE %d: loss reference %.8f oracle %.8f' % (stage, loss_ref.item(), loss.item()))
         assert abs(loss_ref.item() - loss.item()) < 1e-5 * max(1.0, abs(loss_ref.item()))
         for l in range(3):
@@ -119,6 +128,7 @@ def main():
         print('  outputs, running stats and %d parameter gradients agree (worst max-rel %.2e); no gradient in the reference for: %s'
               % (len(keys), worst, sorted(set(k.split('.')[0] for k in untouched))))
         fixture['loss_stage%d' % stage] = np.array(loss_ref.item())
+        fixture['loss_dp_stage%d' % stage] = np.array(loss_dp_ref.item())
         fixture['grad_norm_sum_stage%d' % stage] = np.array([[ref_named[k].grad.double().norm().item(), ref_named[k].grad.double().sum().item()]
                                                              for k in keys])
         for k in FULL_KEYS:

@@ -168,12 +168,12 @@ def test_train_oracle_matches_reference_fixture(assets, state_dict):
     keys = [str(k) for k in fx['grad_keys']]
     inp = synth.make_inputs(2, 0)
     p = {k: (v.clone().requires_grad_(True) if k in keys else v) for k, v in state_dict.items()}
-    stats = {}
+    stats, dp = {}, []
     outs = OT.whmr_forward_train(p, assets, inp['x'], inp['center'], inp['scale'], inp['bbox_height'], inp['orig_shape'], inp['bbox_info'],
-                                 stage=2, stats=stats)
-    loss = OT.cotangent_loss(outs)
-    loss.backward()
-    assert abs(loss.item() - float(fx['loss_stage2'])) < 1e-5
+                                 stage=2, stats=stats, dp_out=dp)
+    loss, loss_dp = OT.cotangent_loss(outs), OT.dp_cotangent_loss(dp[0])
+    (loss + loss_dp).backward()
+    assert abs(loss.item() - float(fx['loss_stage2'])) < 1e-5 and abs(loss_dp.item() - float(fx['loss_dp_stage2'])) < 1e-5
     ns = fx['grad_norm_sum_stage2']
     for i, k in enumerate(keys):
         g = p[k].grad.double()

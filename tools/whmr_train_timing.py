@@ -43,6 +43,8 @@ def main():
         for l in range(1, 4):
             for k in LOSS_KEYS:
                 loss = loss + out['smpl_out'][l][k].float().pow(2).mean()
+        for v in (out['dp_out'][0].values() if out['dp_out'] else ()):     # IUV head (AUX_SUPV_ON, the yaml default): core/trainer.py:466-480
+            loss = loss + v.pow(2).mean()
         loss.backward()
         if red is not None:
             red.finish()
@@ -66,7 +68,7 @@ def main():
         loss = step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    flops = 3 * (34.20e9 + 9.26e9 + 1.98e9) * B
+    flops = 3 * (34.20e9 + 9.26e9 + 1.98e9 + 5.10e9) * B          # ViT + deconvs + Tz conv + IUV head (2*12288*2304*90)
     fmt = ('W-HMR train step B=%d %s' + (' [HIP graph replay]' if use_graph else '') + ' (forward + backward + gradient buckets' + (' + fused Adam' if opt is not None else ', no optimizer') + '): '
            '%.2f ms  %.0f img/s  %.0f TFLOP/s (3 x forward FLOPs of ViT + deconvs + Tz conv)  loss %.4f  peak memory %.1f GB')
     print(fmt % (B, numerics, dt * 1e3, B / dt, flops / dt / 1e12, float(loss.detach()), torch.cuda.max_memory_allocated() / 2 ** 30))
@@ -80,6 +82,7 @@ def main():
     e[0].record()
     out, _ = m(d['x'], None, d['center'], d['scale'], d['bbox_height'], d['orig_shape'], d['bbox_info'], is_train=True)
     loss = sum(out['smpl_out'][l][k].float().pow(2).mean() for l in range(1, 4) for k in LOSS_KEYS)
+    loss = loss + sum(v.pow(2).mean() for v in (out['dp_out'][0].values() if out['dp_out'] else ()))
     e[1].record()
     loss.backward()
     e[2].record()

@@ -50,25 +50,31 @@ class LinearFn(torch.autograd.Function):
 
 
 class ConvNHWCFn(torch.autograd.Function):
-    """y [B,OH,OW,Cout] (dt) = ConvNHWCFn.apply(x [B,IH,IW,Cin] (dt), weight [Cout,Cin,KH,KW], stride, dt): Conv2d, no bias, no padding."""
+    """y [B,OH,OW,Cout] (dt) = ConvNHWCFn.apply(x [B,IH,IW,Cin] (dt), weight [Cout,Cin,KH,KW], stride, dt, padding=0, bias=None): Conv2d on a
+    channels-last map (Tz head: 7x7 s3 / s2 without bias or padding, whmr.py:419-420; IUV head: 3x3 s1 p1 with bias, iuv_predictor.py:71-91)."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride, dt):
+    def forward(ctx, x, weight, stride, dt, padding=0, bias=None):
         if not x.is_cuda:
             raise RuntimeError('whmr_amd runs on a HIP device only (no CPU fallback)')
         x = x.detach()
         assert x.dtype == dt and x.is_contiguous()
         B, IH, IW, Cin = x.shape
         Cout, _, KH, KW = weight.shape
-        OH, OW = (IH - KH) // stride + 1, (IW - KW) // stride + 1
+        OH, OW = (IH + 2 * padding - KH) // stride + 1, (IW + 2 * padding - KW) // stride + 1
         npad = Cout if dt == torch.float32 else (Cout + 63) // 64 * 64           # the bf16 tiles want whole 64-column groups
         wm = torch.zeros(npad, KH * KW * Cin, dtype=torch.float32, device=x.device)
         wm[:Cout] = weight.detach().float().permute(0, 2, 3, 1).reshape(Cout, -1)   # [co, (ky, kx, ci)]
         wm = L.cast_bf16(wm) if dt == torch.bfloat16 else wm
+        bp = None
+        if bias is not None:
+            bp = torch.zeros(npad, dtype=torch.float32, device=x.device)
+            bp[:Cout] = bias.detach().float()
         y = torch.empty(B * OH * OW, npad, dtype=dt, device=x.device)
-        L.gemm(x, wm, y, conv=dict(IH=IH, IW=IW, Cin=Cin, OH=OH, OW=OW, KW=KW, SH=stride, SW=stride, PH=0, PW=0))
+        L.gemm(x, wm, y, bias=bp, conv=dict(IH=IH, IW=IW, Cin=Cin, OH=OH, OW=OW, KW=KW, SH=stride, SW=stride, PH=padding, PW=padding))
         ctx.saved = (x, wm)
-        ctx.dims = (B, IH, IW, Cin, Cout, KH, KW, OH, OW, stride, npad, dt)
+        ctx.dims = (B, IH, IW, Cin, Cout, KH, KW, OH, OW, stride, padding, npad, dt)
+        ctx.has_bias = bias is not None
         out = y if npad == Cout else y[:, :Cout].contiguous()
         return out.view(B, OH, OW, Cout)
 
@@ -76,30 +82,42 @@ class ConvNHWCFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, wm = ctx.saved
         ctx.saved = None
-        B, IH, IW, Cin, Cout, KH, KW, OH, OW, S, npad, dt = ctx.dims
+        B, IH, IW, Cin, Cout, KH, KW, OH, OW, S, P, npad, dt = ctx.dims
         dev = x.device
         M, K = B * OH * OW, KH * KW * Cin
-        dyp = torch.zeros(M, npad, dtype=dt, device=dev) if npad != Cout else None
-        if dyp is None:
-            dyp = dy.reshape(M, Cout).to(dt).contiguous()
-        else:
+        if npad != Cout:
+            dyp = torch.zeros(M, npad, dtype=dt, device=dev)
             dyp[:, :Cout] = dy.reshape(M, Cout)
+        else:
+            dyp = dy.reshape(M, Cout).to(dt).contiguous()
         pad = 64 if dt == torch.bfloat16 else 8
-        dx = dw = None
+        dx = dw = db = None
         if ctx.needs_input_grad[1]:
             dyt = L.transpose_cast(dyp, dt, pad_to=pad)                            # [npad, Mpad]
-            colt = L.im2col_t(x, OH, OW, KH, KW, S, 0, pad_to=pad)                 # [K, Mpad]
+            colt = L.im2col_t(x, OH, OW, KH, KW, S, P, pad_to=pad)                 # [K, Mpad]
             dwm = torch.empty(npad, K, dtype=torch.float32, device=dev)
             L.gemm(dyt, colt, dwm)
             dw = dwm[:Cout].view(Cout, KH, KW, Cin).permute(0, 3, 1, 2)
             del colt, dyt
+        if ctx.has_bias and ctx.needs_input_grad[5]:
+            dbp = torch.empty(npad, dtype=torch.float32, device=dev)
+            L.colsum(dyp, dbp)
+            db = dbp[:Cout]
         if ctx.needs_input_grad[0]:
-            wt = L.transpose_cast(wm, dt, pad_to=1)                                # [K, npad]
-            dcol = torch.empty(M, K, dtype=dt, device=dev)
-            L.gemm(dyp, wt, dcol)
             dx = torch.empty(B, IH, IW, Cin, dtype=dt, device=dev)
-            L.col2im(dcol, dx, OH, OW, KH, KW, S, 0)
-        return dx, dw, None, None
+            if S == 1 and npad % 64 == 0 and OH == IH and OW == IW:
+                # stride 1, 'same' padding: the data gradient is itself a convolution of dY with the flipped kernel -- an implicit GEMM
+                # with the NHWC gather (K = KH*KW*npad), no column matrix at all
+                w4 = wm.float().view(npad, KH, KW, Cin).flip(1, 2).permute(3, 1, 2, 0).reshape(Cin, KH * KW * npad).contiguous()
+                w4 = L.cast_bf16(w4) if dt == torch.bfloat16 else w4
+                L.gemm(dyp.view(B, OH, OW, npad), w4, dx.view(B * IH * IW, Cin),
+                       conv=dict(IH=OH, IW=OW, Cin=npad, OH=IH, OW=IW, KW=KW, SH=1, SW=1, PH=KH - 1 - P, PW=KW - 1 - P))
+            else:
+                wt = L.transpose_cast(wm, dt, pad_to=1)                            # [K, npad]
+                dcol = torch.empty(M, K, dtype=dt, device=dev)
+                L.gemm(dyp, wt, dcol)
+                L.col2im(dcol, dx, OH, OW, KH, KW, S, P)
+        return dx, dw, None, None, None, db
 
 
 class DownsampleFn(torch.autograd.Function):

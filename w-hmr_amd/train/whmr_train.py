@@ -20,9 +20,9 @@ Graph structure (all from the reference): the previous stage's pose / shape / ca
 (whmr.py:586-592), so each regressor stage back-propagates into ITS feature map only; with ``cfg.TRAIN.STAGE == 2``
 (configs/pymaf_config.yaml:26) ``kp_2d`` sees detached joints (whmr.py:142-145) while ``kp_2d_w`` differentiates joints, Tz and hence
 the Tz head and the last feature map (whmr.py:156-173,567-570); ``STAGE == 1`` swaps those roles.
-Not differentiated here (outputs only): the angle-axis copy of the pose in ``theta`` (whmr.py:174), ``global_output`` (its loss terms
-are not part of core/trainer.py:500-600; computed without dropout), the IUV head ``dp_head`` (AUX supervision needs the pytorch3d
-rasteriser).
+Not differentiated here (outputs only): the angle-axis copy of the pose in ``theta`` (whmr.py:174) and ``global_output`` (its loss terms
+are not part of core/trainer.py:500-600; computed without dropout).  The IUV head ``dp_head`` IS part of the graph (``dp_out``, whmr.py:656-658);
+its ground truth comes from the pytorch3d rasteriser in the reference, which this package does not provide.
 """
 import torch
 import torch.nn.functional as F
@@ -80,6 +80,19 @@ def tz_head_train(model, f_nhwc):
     y = _linear(_linear(s, e[0]), e[1])
     y = e[2](y)                                                                        # BatchNorm1d(1): batch statistics in train mode
     return 10.0 * torch.sigmoid(y).squeeze(-1)
+
+
+def dp_head_train(model, f_nhwc):
+    """IUV_predict_layer.forward (models/iuv_predictor.py:71-91, called at whmr.py:656-658 when AUX_SUPV_ON): four 3x3 convolutions of the last
+    feature map, run as ONE implicit GEMM over the concatenated output channels (25 + 25 + 25 + 15); NCHW views of the NHWC result."""
+    h = model.dp_head
+    convs = (h.predict_u, h.predict_v, h.predict_uv_index, h.predict_ann_index)
+    w = torch.cat([c.weight for c in convs], 0)
+    b = torch.cat([c.bias for c in convs], 0)
+    y = ConvNHWCFn.apply(f_nhwc, w, 1, model._dt, convs[0].padding[0], b).float()
+    u, v, idx, ann = torch.split(y, [c.out_channels for c in convs], dim=-1)
+    nchw = lambda t: t.permute(0, 3, 1, 2)
+    return {'predict_uv_index': nchw(idx), 'predict_ann_index': nchw(ann), 'predict_u': nchw(u), 'predict_v': nchw(v)}
 
 
 def regressor_train(reg, ref, bbox_info, Tz, orig_shape, center, scale, bbox_height, pose, shape, cam, cache):
@@ -170,5 +183,6 @@ def whmr_forward_train(model, x, center, scale, bbox_height, orig_shape, bbox_in
         g = model.regressor[0].smpl.run(smpl_output['pred_shape'], g_rotmat)
         g_out = {'global_pose': torch.cat([g_aa, smpl_output['pose'][:, 3:]], dim=1), 'global_shape': smpl_output['pred_shape'],
                  'global_rotmat': g_rotmat, 'global_kp_3d': g.joints, 'global_verts': g.vertices}
+    dp_out = [dp_head_train(model, fmaps[-1])] if (cfg.MODEL.PyMAF.AUX_SUPV_ON and hasattr(model, 'dp_head')) else []     # whmr.py:656-658
     vis_feat = [s_feat.detach()] + [m.detach().permute(0, 3, 1, 2) for m in fmaps]
-    return {'smpl_out': outs, 'dp_out': [], 'dpth_out': [], 'global_output': g_out}, vis_feat
+    return {'smpl_out': outs, 'dp_out': dp_out, 'dpth_out': [], 'global_output': g_out}, vis_feat
