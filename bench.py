@@ -81,7 +81,7 @@ def build_workload(args, dev):
         m.load_state_dict(sd, strict=False)
         m = m.to(dev).train()
         for name, p in m.named_parameters():       # frozen (cam_model) or outside the trainer's loss (dp_head, global_orient)
-            if name.startswith(('cam_model', 'dp_head', 'global_orient')):
+            if name.startswith(('cam_model', 'global_orient')):
                 p.requires_grad_(False)
         params = [p for p in m.parameters() if p.requires_grad]
         world = int(os.environ.get('WORLD_SIZE', '1'))

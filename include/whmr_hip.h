@@ -183,7 +183,7 @@ int whmr_crop_normalize(const uint8_t* frame, int H, int W, long row_stride, con
 /* src [R,C] (row stride ld_src) -> dst [C,Rpad] (row stride ld_dst >= Rpad), fp32 <-> bf16; columns R..Rpad-1 are zero filled. */
 int whmr_transpose_cast(const void* src, int src_bf16, long ld_src, void* dst, int dst_bf16, long ld_dst, int R, int C, int Rpad,
                         void* stream);
-/* out[c] (+)= sum_r x[r,c]; deterministic two-stage sum; scratch >= 64*C floats. */
+/* out[c] (+)= sum_r x[r,c]; deterministic two-stage sum; scratch >= max(64*C, 2^20) floats. */
 int whmr_colsum(const void* x, int is_bf16, long ld, int R, int C, float* out, int accumulate, float* scratch, void* stream);
 /* LayerNorm backward: dx = dLN(x; gamma)(dy) + dres (dres nullable, dx may alias it); dgamma/dbeta (+)=; scratch >= 2048*C floats. */
 int whmr_layernorm_bwd(const float* x, const float* dy, const float* gamma, const float* dres, float* dx, float* dgamma,

@@ -26,7 +26,7 @@ def main():
     m.load_state_dict(sd, strict=False)
     m = m.to(dev).train()
     for name, p in m.named_parameters():           # frozen / not in the loss: cam_model (detached in the reference), dp_head, global_orient
-        if name.startswith(('cam_model', 'dp_head', 'global_orient')):
+        if name.startswith(('cam_model', 'global_orient')):
             p.requires_grad_(False)
     params = [p for p in m.parameters() if p.requires_grad]
     use_graph = '--graph' in sys.argv

@@ -482,7 +482,7 @@ def colsum(x, out, accumulate=False):
     _dev(x, out)
     assert x.dim() == 2 and x.stride(1) == 1 and out.dtype == torch.float32 and out.is_contiguous() and out.numel() == x.shape[1]
     R, Cc = x.shape
-    sc = train_scratch(x.device, 64 * Cc)
+    sc = train_scratch(x.device, max(64 * Cc, 1 << 20))
     _check(lib().whmr_colsum(x.data_ptr(), int(x.dtype == torch.bfloat16), x.stride(0), R, Cc, out.data_ptr(), int(accumulate),
                              sc.data_ptr(), _stream()), 'whmr_colsum')
     return out

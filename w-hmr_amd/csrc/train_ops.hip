@@ -80,7 +80,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, long ld, int R, int C, float* __restrict__ partial) {
     __shared__ float red[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
-    const int rows_per = (R + CS_CHUNKS - 1) / CS_CHUNKS;
+    const int rows_per = (R + (int)gridDim.y - 1) / (int)gridDim.y;
     const int r_begin = blockIdx.y * rows_per, r_end = min(R, r_begin + rows_per);
     float a = 0.f;
     if (c < C)
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void colsum_partial8_kernel(const bf16_t* __re
     __shared__ float red[8][256 + 8];
     const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
     const int c = blockIdx.x * 256 + cg * 8;
-    const int rows_per = (R + CS_CHUNKS - 1) / CS_CHUNKS;
+    const int rows_per = (R + (int)gridDim.y - 1) / (int)gridDim.y;
     const int r_begin = blockIdx.y * rows_per, r_end = min(R, r_begin + rows_per);
     float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (c < C)
@@ -137,16 +137,21 @@ __global__ __launch_bounds__(256) void colsum_partial8_kernel(const bf16_t* __re
     }
 }
 
-// scratch: >= CS_CHUNKS * C floats
+// scratch: >= max(64 * C, 2^20) floats
 extern "C" int whmr_colsum(const void* x, int is_bf16, long ld, int R, int C, float* out, int accumulate, float* scratch, void* stream) {
     if (R <= 0 || C <= 0) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((C + 63) / 64, CS_CHUNKS);
-    if (is_bf16 && !(C & 7) && !(ld & 7) && !((uintptr_t)x & 15))
-        hipLaunchKernelGGL(colsum_partial8_kernel, dim3((C + 255) / 256, CS_CHUNKS), dim3(256), 0, st, (const bf16_t*)x, ld, R, C, scratch);
-    else if (is_bf16) hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, ld, R, C, scratch);
-    else hipLaunchKernelGGL(colsum_partial_kernel<float>, grid, dim3(256), 0, st, (const float*)x, ld, R, C, scratch);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64), dim3(256), 0, st, scratch, CS_CHUNKS, C, out, accumulate);
+    const bool vec8 = is_bf16 && !(C & 7) && !(ld & 7) && !((uintptr_t)x & 15);
+    // row chunks: 64 for the ViT shapes (12544 rows, 3-12 column blocks); tall narrow maps (IUV head: 786432 x 128) get more chunks so
+    // that the partial pass fills the chip (64 blocks took 0.7 ms there).  chunks * C <= 2^20 floats of scratch.
+    const int ncb = vec8 ? (C + 255) / 256 : (C + 63) / 64;
+    int chunks = CS_CHUNKS;
+    while (chunks < 1024 && (long)ncb * chunks < 1024 && R / chunks > 512 && (long)2 * chunks * C <= (1L << 20)) chunks *= 2;
+    if (vec8)
+        hipLaunchKernelGGL(colsum_partial8_kernel, dim3(ncb, chunks), dim3(256), 0, st, (const bf16_t*)x, ld, R, C, scratch);
+    else if (is_bf16) hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, dim3(ncb, chunks), dim3(256), 0, st, (const bf16_t*)x, ld, R, C, scratch);
+    else hipLaunchKernelGGL(colsum_partial_kernel<float>, dim3(ncb, chunks), dim3(256), 0, st, (const float*)x, ld, R, C, scratch);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64), dim3(256), 0, st, scratch, chunks, C, out, accumulate);
     WHMR_CHECK_LAUNCH();
     return 0;
 }

@@ -92,7 +92,18 @@ class ConvNHWCFn(torch.autograd.Function):
             dyp = dy.reshape(M, Cout).to(dt).contiguous()
         pad = 64 if dt == torch.bfloat16 else 8
         dx = dw = db = None
-        if ctx.needs_input_grad[1]:
+        same = S == 1 and OH == IH and OW == IW
+        if ctx.needs_input_grad[1] and same and npad % 64 == 0 and npad < Cin:
+            # stride-1 'same' convolution with fewer output than input channels (IUV head: 128 padded vs 256): gather the SMALLER operand.
+            # dW[co, ci, ky, kx] = sum_m' dY[m' - shift(ky, kx), co] . X[m', ci]: the transposed column matrix is built from dY with the
+            # flipped taps (KH*KW*npad rows instead of KH*KW*Cin) and X is transposed once.
+            xt = L.transpose_cast(x.view(B * IH * IW, Cin), dt, pad_to=pad)        # [Cin, Mpad]
+            dcolt = L.im2col_t(dyp.view(B, OH, OW, npad), IH, IW, KH, KW, 1, KH - 1 - P, pad_to=pad)     # [(k'y, k'x, co), Mpad]
+            dwm = torch.empty(KH * KW * npad, Cin, dtype=torch.float32, device=dev)
+            L.gemm(dcolt, xt, dwm)
+            dw = dwm.view(KH, KW, npad, Cin).flip(0, 1)[:, :, :Cout].permute(2, 3, 0, 1)              # [co, ci, ky, kx]
+            del dcolt, xt
+        elif ctx.needs_input_grad[1]:
             dyt = L.transpose_cast(dyp, dt, pad_to=pad)                            # [npad, Mpad]
             colt = L.im2col_t(x, OH, OW, KH, KW, S, P, pad_to=pad)                 # [K, Mpad]
             dwm = torch.empty(npad, K, dtype=torch.float32, device=dev)
@@ -105,7 +116,7 @@ class ConvNHWCFn(torch.autograd.Function):
             db = dbp[:Cout]
         if ctx.needs_input_grad[0]:
             dx = torch.empty(B, IH, IW, Cin, dtype=dt, device=dev)
-            if S == 1 and npad % 64 == 0 and OH == IH and OW == IW:
+            if same and npad % 64 == 0:
                 # stride 1, 'same' padding: the data gradient is itself a convolution of dY with the flipped kernel -- an implicit GEMM
                 # with the NHWC gather (K = KH*KW*npad), no column matrix at all
                 w4 = wm.float().view(npad, KH, KW, Cin).flip(1, 2).permute(3, 1, 2, 0).reshape(Cin, KH * KW * npad).contiguous()
