@@ -243,16 +243,16 @@ int whmr_smpl_chain_bwd(const struct whmr_smpl_model* m, const float* rotmat, co
                         const float* d_posed_joints, const float* d_pf_beta, int B, float* d_rotmat, float* d_betas, void* stream);
 
 /* ---- backward of the MAF sampler (autograd of maf_extractor.py:75-124; the sample points are constants: whmr.py:586-592 detaches
- * them).  d_out [B, 32*P] (row stride dout_stride) -> d_fmap (nullable; fp32, element strides gsb/gsc/gsy/gsx, ACCUMULATED into with
- * fp32 atomics) and the point-minor operands of the weight-gradient GEMMs: XT [448, ldt] = [y0 (128) ; f (256) ; y1 (64)],
+ * them).  d_out [B, 32*P] (row stride dout_stride) -> d_fmap (nullable; element strides gsb/gsc/gsy/gsx; ACCUMULATED into: fp32 maps with fp32
+ * atomics, bf16 channels-last maps (gsc == 1) with a 32-bit compare-and-swap per channel pair) and the point-minor operands of the weight-gradient GEMMs: XT [448, ldt] = [y0 (128) ; f (256) ; y1 (64)],
  * DT [224, ldt] = [d_pre0 (128) ; d_pre1 (64) ; d_pre2 (32)], columns = b*P + p (ldt >= B*P).  dW0 = DT[0:128] . XT[128:384]^T,
  * dW1 = DT[128:192] . XT[0:384]^T, dW2 = DT[192:224] . [XT[384:448] ; XT[128:384]]^T, biases = row sums of DT (whmr_gemm_f32).
  * w = the forward's transposed weights; w0 / w1 / w2 = the Conv1d-layout [out][in] fp32 matrices. */
 int whmr_maf_sample_bwd(const void* fmap, int fmap_bf16, long sb, long sc, long sy, long sx, int H, int W, const float* pts2d,
                         const float* pts3d, const float* cam, long cam_ld, float focal, float res_w, float res_h,
                         const struct whmr_maf_weights* w, const float* w0, const float* w1, const float* w2, int B, int P,
-                        const float* d_out, long dout_stride, float* d_fmap, long gsb, long gsc, long gsy, long gsx, float* XT,
-                        float* DT, long ldt, void* stream);
+                        const float* d_out, long dout_stride, void* d_fmap, int d_fmap_bf16, long gsb, long gsc, long gsy, long gsx,
+                        float* XT, float* DT, long ldt, void* stream);
 
 /* col2im (gather form): dx [B,IH,IW,C] = fold of the column-space gradient dcol [(b,oy,ox)][(ky,kx,c)] (row stride ldcol) of a strided,
  * padded Conv2d -- the data gradient of the Tz-head convolutions (whmr.py:419-420) after dcol = dY . W on whmr_gemm_*. */

@@ -299,8 +299,9 @@ def test_maf_sampler_backward_matches_autograd(dev, map_dtype):
         # the weights actually used are ext_d's (same values as ps_d)
         assert _rel(y.detach().cpu(), y_ref) < 1e-5
         y.backward(cot.to(dev))
-        # a bf16 leaf receives its gradient rounded to bf16 by autograd (2^-9 relative); the kernel's own output is fp32
-        map_tol = 1e-4 if map_dtype == torch.float32 else 4e-3
+        # a bf16 map gets a bf16 gradient map, accumulated in bf16 (2^-9 relative per add; this 10 x 7 map makes 21 points share texels
+        # far more often than the 32 x 24 ... 128 x 96 maps of the model do)
+        map_tol = 1e-4 if map_dtype == torch.float32 else 1e-2
         assert _rel(fm_d.grad.float().cpu(), gmap_ref) < map_tol, (mode, _rel(fm_d.grad.float().cpu(), gmap_ref))
         for a, b_ in zip(ps_d, gp_ref):
             assert a.grad.shape == b_.shape and _rel(a.grad.cpu(), b_) < 1e-4, (mode, a.shape, _rel(a.grad.cpu(), b_))

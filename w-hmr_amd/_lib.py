@@ -82,7 +82,7 @@ _SIGS = {
     'whmr_smpl_joints_bwd': [C.POINTER(WhmrSmplModel), _P, _P, _P, _I, _P, _P, _P, _P],
     'whmr_smpl_skin_bwd': [C.POINTER(WhmrSmplModel), _P, _L, _P, _P, _P, _P, _I, _I, _P, _P, _P],
     'whmr_smpl_chain_bwd': [C.POINTER(WhmrSmplModel), _P, _P, _L, _P, _P, _P, _I, _P, _P, _P],
-    'whmr_maf_sample_bwd': [_P, _I, _L, _L, _L, _L, _I, _I, _P, _P, _P, _L, _F, _F, _F, C.POINTER(WhmrMafWeights), _P, _P, _P, _I, _I, _P, _L, _P, _L, _L, _L, _L, _P, _P, _L, _P],
+    'whmr_maf_sample_bwd': [_P, _I, _L, _L, _L, _L, _I, _I, _P, _P, _P, _L, _F, _F, _F, C.POINTER(WhmrMafWeights), _P, _P, _P, _I, _I, _P, _L, _P, _I, _L, _L, _L, _L, _P, _P, _L, _P],
     'whmr_col2im': [_P, _I, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'whmr_maxpool_nhwc': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'whmr_avgpool_nhwc': [_P, _P, _I, _I, _I, _I, _P],
@@ -638,10 +638,11 @@ def maf_sample_bwd(fmap_nchw, weights, w0, w1, w2, d_out, d_fmap_nchw, XT, DT, p
     assert d_out.dtype == torch.float32 and d_out.stride(-1) == 1 and XT.shape[0] == 448 and DT.shape[0] == 224
     assert XT.is_contiguous() and DT.is_contiguous() and XT.shape[1] == DT.shape[1] >= B * P
     g = (0, 0, 0, 0) if d_fmap_nchw is None else d_fmap_nchw.stride()
-    assert d_fmap_nchw is None or (d_fmap_nchw.dtype == torch.float32 and d_fmap_nchw.shape == fmap_nchw.shape)
+    assert d_fmap_nchw is None or (d_fmap_nchw.dtype in (torch.float32, torch.bfloat16) and d_fmap_nchw.shape == fmap_nchw.shape)
     _check(lib().whmr_maf_sample_bwd(fmap_nchw.data_ptr(), _bf(fmap_nchw), sb, sc, sy, sx, H, W, _ptr(pts2d), _ptr(pts3d), _ptr(cam),
                                      cam.stride(0) if cam is not None else 0, focal, res_w, res_h, C.byref(weights), w0.data_ptr(),
-                                     w1.data_ptr(), w2.data_ptr(), B, P, d_out.data_ptr(), d_out.stride(0), _ptr(d_fmap_nchw), g[0], g[1],
+                                     w1.data_ptr(), w2.data_ptr(), B, P, d_out.data_ptr(), d_out.stride(0), _ptr(d_fmap_nchw),
+                                     0 if d_fmap_nchw is None else _bf(d_fmap_nchw), g[0], g[1],
                                      g[2], g[3], XT.data_ptr(), DT.data_ptr(), XT.shape[1], _stream()), 'whmr_maf_sample_bwd')
 
 

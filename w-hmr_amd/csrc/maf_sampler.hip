@@ -9,6 +9,7 @@
 // deconv GEMMs (256 contiguous channels per texel: the gather is 1 KiB-coalesced) and a caller's NCHW tensor work.
 // Block = 128 threads = PT points of one image; features and activations live in LDS; weights are pre-transposed
 // to [in][out] on the host so every weight read is coalesced and L2-resident (66 K floats).
+#include <type_traits>
 #include "common.h"
 
 #define CF 256
@@ -350,13 +351,24 @@ extern "C" int whmr_tz_tail(const float* tok, int B, int T, int D, const float* 
 //              XT = [y0 (128) ; f (256) ; y1 (64)] x [B*P] and DT = [d_pre0 (128) ; d_pre1 (64) ; d_pre2 (32)] x [B*P];
 //              dW_l = DT_l . XT_l^T then runs on whmr_gemm_f32 (K = B*P), the bias gradients are DT's row sums.
 // wts holds the transposed [in][out] weights of the forward; w0 / w1 / w2 are the Conv1d-layout [out][in] matrices.
-template <typename TF>
+// bf16 gradient maps: two channels per 32-bit word, added with a compare-and-swap loop (gfx950 has no packed-bf16 atomic add in HIP's
+// portable surface); texels shared by two points are rare, so the loop almost always runs once.
+__device__ __forceinline__ void atomic_add_bf16x2(uint32_t* addr, float lo, float hi) {
+    uint32_t old = *addr, assumed;
+    do {
+        assumed = old;
+        const float a = __uint_as_float(assumed << 16) + lo, b = __uint_as_float(assumed & 0xffff0000u) + hi;
+        old = atomicCAS(addr, assumed, pack_bf16x2(a, b));
+    } while (old != assumed);
+}
+
+template <typename TF, typename TG>
 __global__ __launch_bounds__(256) void maf_sample_bwd_kernel(const TF* __restrict__ fmap, long sb, long sc, long sy, long sx, int H, int W,
                                                              const float* __restrict__ pts2d, const float* __restrict__ pts3d,
                                                              const float* __restrict__ cam, long cam_ld, float focal, float res_w, float res_h,
                                                              const whmr_maf_weights wts, const float* __restrict__ w0, const float* __restrict__ w1,
                                                              const float* __restrict__ w2, int P, const float* __restrict__ d_out, long dout_stride,
-                                                             float* __restrict__ d_fmap, long gsb, long gsc, long gsy, long gsx,
+                                                             TG* __restrict__ d_fmap, long gsb, long gsc, long gsy, long gsx,
                                                              float* __restrict__ XT, float* __restrict__ DT, long ldt) {
     __shared__ float sF[CF][PT], sY0[128][PT], sY1[64][PT];
     __shared__ float sD0[128][PT], sD1[64][PT], sD2[32][PT], sDF[CF][PT];
@@ -497,14 +509,31 @@ __global__ __launch_bounds__(256) void maf_sample_bwd_kernel(const TF* __restric
             for (int pp = 0; pp < PT; ++pp) acc[pp] = fmaf(w, sD0[o][pp], acc[pp]);
         }
         // scatter d(f) into the gradient map
-        float* gc = d_fmap ? d_fmap + (size_t)b * gsb + (size_t)tid * gsc : nullptr;
-        for (int pp = 0; pp < np; ++pp) {
-            const float df = sDF[tid][pp] + acc[pp];
-            if (gc) {
+        if constexpr (std::is_same<TG, float>::value) {
+            float* gc = d_fmap ? d_fmap + (size_t)b * gsb + (size_t)tid * gsc : nullptr;
+            for (int pp = 0; pp < np; ++pp) {
+                const float df = sDF[tid][pp] + acc[pp];
+                if (gc) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int id = sIdx[pp][t];
-                    if (id >= 0) unsafeAtomicAdd(gc + (size_t)(id / W) * gsy + (size_t)(id % W) * gsx, df * sWgt[pp][t]);
+                    for (int t = 0; t < 4; ++t) {
+                        const int id = sIdx[pp][t];
+                        if (id >= 0) unsafeAtomicAdd(gc + (size_t)(id / W) * gsy + (size_t)(id % W) * gsx, df * sWgt[pp][t]);
+                    }
+                }
+            }
+        } else {        // bf16 channels-last map (gsc == 1): even threads add the channel pair (tid, tid + 1) as one 32-bit word
+#pragma unroll
+            for (int pp = 0; pp < PT; ++pp) sDF[tid][pp] += acc[pp];
+            __syncthreads();
+            if (d_fmap && !(tid & 1)) {
+                bf16_t* gc = d_fmap + (size_t)b * gsb + tid;
+                for (int pp = 0; pp < np; ++pp) {
+                    const float d0 = sDF[tid][pp], d1 = sDF[tid + 1][pp];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int id = sIdx[pp][t];
+                        if (id >= 0) atomic_add_bf16x2((uint32_t*)(gc + (size_t)(id / W) * gsy + (size_t)(id % W) * gsx), d0 * sWgt[pp][t], d1 * sWgt[pp][t]);
+                    }
                 }
             }
         }
@@ -526,15 +555,19 @@ __global__ __launch_bounds__(256) void maf_sample_bwd_kernel(const TF* __restric
 extern "C" int whmr_maf_sample_bwd(const void* fmap, int fmap_bf16, long sb, long sc, long sy, long sx, int H, int W, const float* pts2d,
                                    const float* pts3d, const float* cam, long cam_ld, float focal, float res_w, float res_h,
                                    const whmr_maf_weights* w, const float* w0, const float* w1, const float* w2, int B, int P,
-                                   const float* d_out, long dout_stride, float* d_fmap, long gsb, long gsc, long gsy, long gsx, float* XT,
-                                   float* DT, long ldt, void* stream) {
+                                   const float* d_out, long dout_stride, void* d_fmap, int d_fmap_bf16, long gsb, long gsc, long gsy, long gsx,
+                                   float* XT, float* DT, long ldt, void* stream) {
     if (B <= 0 || P <= 0 || (!pts2d == !pts3d) || (pts3d && !cam) || dout_stride < 32L * P || ldt < (long)B * P) return (int)hipErrorInvalidValue;
+    if (d_fmap && d_fmap_bf16 && (gsc != 1 || ((gsb | gsy | gsx) & 1) || ((uintptr_t)d_fmap & 3))) return (int)hipErrorInvalidValue;
     dim3 grid((P + PT - 1) / PT, B), block(256);
     hipStream_t st = (hipStream_t)stream;
-    if (fmap_bf16) hipLaunchKernelGGL(maf_sample_bwd_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)fmap, sb, sc, sy, sx, H, W, pts2d, pts3d, cam, cam_ld,
-                                      focal, res_w, res_h, *w, w0, w1, w2, P, d_out, dout_stride, d_fmap, gsb, gsc, gsy, gsx, XT, DT, ldt);
-    else hipLaunchKernelGGL(maf_sample_bwd_kernel<float>, grid, block, 0, st, (const float*)fmap, sb, sc, sy, sx, H, W, pts2d, pts3d, cam, cam_ld, focal,
-                            res_w, res_h, *w, w0, w1, w2, P, d_out, dout_stride, d_fmap, gsb, gsc, gsy, gsx, XT, DT, ldt);
+#define MAF_BWD(TF, TG) hipLaunchKernelGGL((maf_sample_bwd_kernel<TF, TG>), grid, block, 0, st, (const TF*)fmap, sb, sc, sy, sx, H, W, pts2d, pts3d, cam, \
+                                           cam_ld, focal, res_w, res_h, *w, w0, w1, w2, P, d_out, dout_stride, (TG*)d_fmap, gsb, gsc, gsy, gsx, XT, DT, ldt)
+    if (fmap_bf16 && d_fmap_bf16) MAF_BWD(bf16_t, bf16_t);
+    else if (fmap_bf16) MAF_BWD(bf16_t, float);
+    else if (!d_fmap_bf16) MAF_BWD(float, float);
+    else return (int)hipErrorInvalidValue;
+#undef MAF_BWD
     WHMR_CHECK_LAUNCH();
     return 0;
 }
