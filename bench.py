@@ -157,6 +157,38 @@ def cpu_baseline(sd, x_cpu, size, heads=12):
                       % (reps, n, size[0], size[1], dt, best[0], ncpu)}
 
 
+def cpu_train_baseline(n_img=4):
+    """CPU leg of the whmr_train workload: the oracle's training forward (oracle/train.py, the reference's arithmetic in plain PyTorch fp32)
+    + torch autograd backward + Adam on a bounded sample of ``n_img`` 256x192 crops (the full batch of 64 would take minutes)."""
+    from oracle import synth as osynth
+    from oracle import train as OT
+    threads = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    assets = osynth.make_assets(0)
+    sd = osynth.make_state_dict(0, assets, with_cam_model=False)
+    skip = ('running', 'cam_model', 'smpl', 'Dmap', 'points_grid', 'init_', 'num_batches', 'global_orient')
+    p = {k: (v.clone().requires_grad_(True) if (v.is_floating_point() and not any(t in k for t in skip)) else v) for k, v in sd.items()}
+    params = [v for v in p.values() if v.requires_grad]
+    opt = torch.optim.Adam(params, lr=5e-5)
+    inp = osynth.make_inputs(n_img, 7)
+    keys = ('rotmat', 'pred_shape', 'pred_cam', 'kp_2d', 'kp_2d_w', 'kp_3d', 'verts', 'sub_verts', 'temp_verts')
+    best = None
+    for it in range(2):                                        # first pass warms the allocator / thread pool
+        t0 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        dp = []
+        outs = OT.whmr_forward_train(p, assets, inp['x'], inp['center'], inp['scale'], inp['bbox_height'], inp['orig_shape'], inp['bbox_info'],
+                                     dp_out=dp)
+        loss = sum(outs[l][k].pow(2).mean() for l in range(1, 4) for k in keys) + sum(v.pow(2).mean() for v in dp[0].values())
+        loss.backward()
+        opt.step()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return {'value': n_img / best, 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
+            'sample': 'oracle.train.whmr_forward_train + autograd backward + Adam (CPU restatement of the reference training step, fp32), one '
+                      'step on %d 256x192 crops (%.1f s), torch threads = %d' % (n_img, best, threads)}
+
+
 def gemm_traffic():
     """HBM bytes per GEMM launch from the committed rocprofv3 --pmc pass of this same command (profiles/), or None."""
     path = os.path.join(ROOT, 'profiles', 'r01_vit224_gemm_traffic.json')
@@ -248,7 +280,9 @@ def main():
                          'traffic': traffic['bytes_per_launch'] if traffic else None,
                          'traffic_note': traffic['note'] if traffic else 'no PMC pass committed'},
         }
-        if not args.no_cpu and world == 1 and sd is not None:
+        if not args.no_cpu and world == 1 and training:
+            res['cpu_baseline'] = cpu_train_baseline()
+        elif not args.no_cpu and world == 1 and sd is not None:
             res['cpu_baseline'] = cpu_baseline(sd, x.cpu(), size, 16 if args.workload == 'vitl256x192' else 12)
         else:
             res['cpu_baseline'] = None
