@@ -45,6 +45,11 @@ def test_train_helper_kernels(dev):
     assert _rel(L.gelu_fwd(pre.detach().to(dev), o).cpu(), torch.nn.functional.gelu(pre.detach())) < 1e-6
     dp = torch.empty(1000, device=dev)
     assert _rel(L.gelu_bwd(pre.detach().to(dev), dh.to(dev), dp).cpu(), pre.grad) < 1e-5
+    pb = (torch.randn(4096 + 8, generator=g) * 2).bfloat16()                           # 8-per-thread bf16 path and the scalar tail path
+    for n in (4096, 4099):
+        ob = torch.empty(n, dtype=torch.bfloat16, device=dev)
+        L.gelu_fwd(pb[:n].contiguous().to(dev), ob)
+        assert torch.equal(ob.cpu(), torch.nn.functional.gelu(pb[:n].float()).bfloat16())
 
 
 @pytest.mark.parametrize('numerics,tol', [('fp32', 2e-4), ('bf16', 4e-2)])

@@ -347,10 +347,25 @@ __global__ __launch_bounds__(256) void gelu_fwd_kernel(const T* __restrict__ pre
     if (i < n) io<T>::st(out + i, gelu_erf(io<T>::ld(pre + i)));
 }
 
+// bf16, 8 elements per thread (16-B loads / stores): the one-element form ran at 2.2 TB/s on the 12544 x 3072 hidden map
+__global__ __launch_bounds__(256) void gelu_fwd8_kernel(const bf16_t* __restrict__ pre, bf16_t* __restrict__ out, long n8) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const uint4 pv = *(const uint4*)(pre + i * 8);
+    const uint32_t pw[4] = {pv.x, pv.y, pv.z, pv.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        o[e] = pack_bf16x2(gelu_erf(__uint_as_float(pw[e] << 16)), gelu_erf(__uint_as_float(pw[e] & 0xffff0000u)));
+    *(uint4*)(out + i * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
 extern "C" int whmr_gelu_fwd(const void* pre, void* out, int is_bf16, long n, void* stream) {
     if (n <= 0) return (int)hipErrorInvalidValue;
     dim3 grid((unsigned)((n + 255) / 256)), block(256);
-    if (is_bf16) hipLaunchKernelGGL(gelu_fwd_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)pre, (bf16_t*)out, n);
+    if (is_bf16 && !(n & 7) && !(((uintptr_t)pre | (uintptr_t)out) & 15))
+        hipLaunchKernelGGL(gelu_fwd8_kernel, dim3((unsigned)((n / 8 + 255) / 256)), block, 0, (hipStream_t)stream, (const bf16_t*)pre, (bf16_t*)out, n / 8);
+    else if (is_bf16) hipLaunchKernelGGL(gelu_fwd_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)pre, (bf16_t*)out, n);
     else hipLaunchKernelGGL(gelu_fwd_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)pre, (float*)out, n);
     WHMR_CHECK_LAUNCH();
     return 0;
