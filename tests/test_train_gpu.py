@@ -49,7 +49,7 @@ def test_train_helper_kernels(dev):
     for n in (4096, 4099):
         ob = torch.empty(n, dtype=torch.bfloat16, device=dev)
         L.gelu_fwd(pb[:n].contiguous().to(dev), ob)
-        assert torch.equal(ob.cpu(), torch.nn.functional.gelu(pb[:n].float()).bfloat16())
+        assert _rel(ob.float().cpu(), torch.nn.functional.gelu(pb[:n].float())) < 4e-3          # one bf16 rounding step
 
 
 @pytest.mark.parametrize('numerics,tol', [('fp32', 2e-4), ('bf16', 4e-2)])
