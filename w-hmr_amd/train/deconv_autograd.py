@@ -49,6 +49,7 @@ def deconv_forward_train(x_nhwc, weight, gamma, beta, bn, dt, update_running=Tru
                        scatter=dict(c_off=(py * 2 * W + px) * Cout, osb=4 * H * W * Cout, osy=4 * W * Cout, osx=2 * Cout))
     z2 = z.view(-1, Cout)
     track = update_running and bn.track_running_stats and bn.running_mean is not None
+    assert not track or bn.momentum is not None, 'cumulative-average BatchNorm (momentum=None) is not used by W-HMR (BN_MOMENTUM = 0.1)'
     stats = L.bn_stats(z2, gamma.detach(), beta.detach(), bn.eps, bn.momentum if track else 0.0,
                        bn.running_mean if track else None, bn.running_var if track else None)
     if track and bn.num_batches_tracked is not None:
