@@ -183,6 +183,10 @@ int whmr_crop_normalize(const uint8_t* frame, int H, int W, long row_stride, con
 /* src [R,C] (row stride ld_src) -> dst [C,Rpad] (row stride ld_dst >= Rpad), fp32 <-> bf16; columns R..Rpad-1 are zero filled. */
 int whmr_transpose_cast(const void* src, int src_bf16, long ld_src, void* dst, int dst_bf16, long ld_dst, int R, int C, int Rpad,
                         void* stream);
+/* whmr_transpose_cast (bf16 -> bf16, 8-aligned shapes) fused with whmr_colsum of the source: the transpose of dY for the dW product also
+ * yields the bias gradient.  scratch >= ceil(R/64)*C floats. */
+int whmr_transpose_colsum(const void* src, long ld_src, void* dst, long ld_dst, int R, int C, int Rpad, float* out, int accumulate,
+                          float* scratch, void* stream);
 /* out[c] (+)= sum_r x[r,c]; deterministic two-stage sum; scratch >= max(64*C, 2^20) floats. */
 int whmr_colsum(const void* x, int is_bf16, long ld, int R, int C, float* out, int accumulate, float* scratch, void* stream);
 /* LayerNorm backward: dx = dLN(x; gamma)(dy) + dres (dres nullable, dx may alias it); dgamma/dbeta (+)=; scratch >= 2048*C floats. */

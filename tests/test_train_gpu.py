@@ -27,6 +27,13 @@ def test_train_helper_kernels(dev):
     assert _rel(L.colsum(x.to(dev), out).cpu(), x.sum(0)) < 2e-6
     L.colsum(x.to(dev), out, accumulate=True)
     assert _rel(out.cpu(), 2 * x.sum(0)) < 2e-6
+    # transpose fused with the column sums (bias gradient from the dY transpose), fast path and fallback
+    for shape in ((328, 200), (333, 200)):
+        xb = torch.randn(*shape, generator=g).bfloat16()
+        cs = torch.ones(shape[1], device=dev)
+        tt = L.transpose_colsum(xb.to(dev), cs, pad_to=64, accumulate=True)
+        assert tt.shape == (shape[1], 384) and torch.equal(tt[:, :shape[0]].cpu(), xb.t()) and not tt[:, shape[0]:].any()
+        assert _rel(cs.cpu() - 1, xb.float().sum(0)) < 1e-5
     # LayerNorm backward vs autograd
     C = 768
     xx = torch.randn(50, C, generator=g, requires_grad=True)

@@ -69,6 +69,7 @@ _SIGS = {
     'whmr_estimate_translation': [_P, _P, _I, _I, _I, _I, _F, _F, _F, _P, _P],
     'whmr_transpose_cast': [_P, _I, _L, _P, _I, _L, _I, _I, _I, _P],
     'whmr_colsum': [_P, _I, _L, _I, _I, _P, _I, _P, _P],
+    'whmr_transpose_colsum': [_P, _L, _P, _L, _I, _I, _I, _P, _I, _P, _P],
     'whmr_layernorm_bwd': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P],
     'whmr_gelu_fwd': [_P, _P, _I, _L, _P],
     'whmr_gelu_bwd': [_P, _I, _P, _I, _P, _I, _L, _P],
@@ -475,6 +476,23 @@ def transpose_cast(src, dtype, pad_to=64):
     dst = torch.empty(Cc, Rpad, dtype=dtype, device=src.device)
     _check(lib().whmr_transpose_cast(src.data_ptr(), int(src.dtype == torch.bfloat16), src.stride(0), dst.data_ptr(),
                                      int(dtype == torch.bfloat16), Rpad, R, Cc, Rpad, _stream()), 'whmr_transpose_cast')
+    return dst
+
+
+def transpose_colsum(src, out, pad_to=64, accumulate=False):
+    """bf16 src [R,C] -> (src^T [C,Rpad] bf16, out[c] (+)= sum_r src[r,c]) in one pass over src; falls back to the two separate kernels when
+    the shape misses the fast path's 8-element alignment."""
+    _dev(src, out)
+    assert src.dim() == 2 and src.stride(1) == 1 and out.dtype == torch.float32 and out.is_contiguous() and out.numel() == src.shape[1]
+    R, Cc = src.shape
+    Rpad = (R + pad_to - 1) // pad_to * pad_to
+    if src.dtype != torch.bfloat16 or ((R | Cc | Rpad | src.stride(0)) & 7) or (src.data_ptr() & 15):
+        colsum(src, out, accumulate)
+        return transpose_cast(src, src.dtype, pad_to)
+    dst = torch.empty(Cc, Rpad, dtype=torch.bfloat16, device=src.device)
+    sc = train_scratch(src.device, ((R + 63) // 64) * Cc)
+    _check(lib().whmr_transpose_colsum(src.data_ptr(), src.stride(0), dst.data_ptr(), Rpad, R, Cc, Rpad, out.data_ptr(), int(accumulate),
+                                       sc.data_ptr(), _stream()), 'whmr_transpose_colsum')
     return dst
 
 

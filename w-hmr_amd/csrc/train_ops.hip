@@ -55,6 +55,45 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
     }
 }
 
+// Same transpose, plus the column sums of the source tile (bias gradient db[c] = sum_r dY[r, c]: the transpose of dY for the dW product
+// reads every element of dY anyway): partial[blockIdx.x][c] over the tile's 64 rows, finished by colsum_final_kernel in a fixed order.
+__global__ __launch_bounds__(256) void transpose_bf16_colsum_kernel(const bf16_t* __restrict__ src, long ld_src, bf16_t* __restrict__ dst, long ld_dst,
+                                                                    int R, int C, int Rpad, float* __restrict__ partial) {
+    __shared__ __attribute__((aligned(16))) bf16_t tile[64][66];
+    __shared__ float csum[4][64];
+    const int t = threadIdx.x;
+    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (t >> 3) + 32 * i, c8 = (t & 7) * 8;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r0 + row < R && c0 + c8 < C) v = *(const uint4*)(src + (size_t)(r0 + row) * ld_src + c0 + c8);
+        uint32_t* d = (uint32_t*)&tile[row][c8];
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    __syncthreads();
+    {   // column sums: thread = (column, quarter of the rows)
+        const int c = t & 63, q = t >> 6;
+        float a = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a += bf16_to_f32(tile[q * 16 + r][c]);
+        csum[q][c] = a;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = (t >> 3) + 32 * i, r8 = (t & 7) * 8;
+        if (c0 + c < C && r0 + r8 < Rpad) {
+            uint32_t w[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) w[k] = (uint32_t)tile[r8 + 2 * k][c] | ((uint32_t)tile[r8 + 2 * k + 1][c] << 16);
+            *(uint4*)(dst + (size_t)(c0 + c) * ld_dst + r0 + r8) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    }
+    __syncthreads();
+    if (t < 64 && c0 + t < C && r0 < R)
+        partial[(size_t)blockIdx.x * C + c0 + t] = (csum[0][t] + csum[1][t]) + (csum[2][t] + csum[3][t]);
+}
+
 extern "C" int whmr_transpose_cast(const void* src, int src_bf16, long ld_src, void* dst, int dst_bf16, long ld_dst, int R, int C, int Rpad,
                                    void* stream) {
     if (R <= 0 || C <= 0 || Rpad < R || ld_dst < Rpad || ld_src < C) return (int)hipErrorInvalidValue;
@@ -367,6 +406,21 @@ extern "C" int whmr_gelu_fwd(const void* pre, void* out, int is_bf16, long n, vo
         hipLaunchKernelGGL(gelu_fwd8_kernel, dim3((unsigned)((n / 8 + 255) / 256)), block, 0, (hipStream_t)stream, (const bf16_t*)pre, (bf16_t*)out, n / 8);
     else if (is_bf16) hipLaunchKernelGGL(gelu_fwd_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)pre, (bf16_t*)out, n);
     else hipLaunchKernelGGL(gelu_fwd_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)pre, (float*)out, n);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+// bf16 [R,C] -> bf16 [C,Rpad] transpose fused with the column sums of the source (out[c] (+)= sum_r src[r,c]).  Needs R, C, Rpad, ld_src, ld_dst
+// multiples of 8 and 16-B aligned bases; scratch >= ceil(R/64) * C floats.
+extern "C" int whmr_transpose_colsum(const void* src, long ld_src, void* dst, long ld_dst, int R, int C, int Rpad, float* out, int accumulate,
+                                     float* scratch, void* stream) {
+    if (R <= 0 || C <= 0 || Rpad < R || ld_dst < Rpad || ld_src < C) return (int)hipErrorInvalidValue;
+    if (((R | C | Rpad | ld_src | ld_dst) & 7) || (((uintptr_t)src | (uintptr_t)dst) & 15)) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    const int nrb = (R + 63) / 64;                     // row blocks that hold real rows (blocks beyond them only write the zero padding)
+    hipLaunchKernelGGL(transpose_bf16_colsum_kernel, dim3((Rpad + 63) / 64, (C + 63) / 64), dim3(256), 0, st, (const bf16_t*)src, ld_src, (bf16_t*)dst,
+                       ld_dst, R, C, Rpad, scratch);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64), dim3(256), 0, st, scratch, nrb, C, out, accumulate);
     WHMR_CHECK_LAUNCH();
     return 0;
 }

@@ -127,15 +127,16 @@ def vit_backward(m, s, dout):
         w = lin.weight
         n_out = dy_op.shape[1]
         k_in = x_saved.shape[1]
-        dyt = L.transpose_cast(dy_op, dt, pad_to=mpad)                                 # [Nout, Mpad]
+        if lin.bias is not None:                                                       # db from the same pass that transposes dY
+            db = torch.empty(n_out, **f32)
+            dyt = L.transpose_colsum(dy_op, db, pad_to=mpad)                           # [Nout, Mpad]
+            grads[lin.bias] = db
+        else:
+            dyt = L.transpose_cast(dy_op, dt, pad_to=mpad)
         xt = L.transpose_cast(x_saved, dt, pad_to=mpad)                                # [Kin, Mpad]
         dw = torch.empty(n_out, k_in, **f32)
         L.gemm(dyt, xt, dw)
         grads[w] = dw.view_as(w)
-        if lin.bias is not None:
-            db = torch.empty(n_out, **f32)
-            L.colsum(dy_op, db)
-            grads[lin.bias] = db
         if not need_dx:
             return None
         dx = torch.empty(M, k_in, dtype=dx_dtype, device=dev)
