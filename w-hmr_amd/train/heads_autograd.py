@@ -3,7 +3,8 @@
   LinearFn       nn.Linear (Regressor fc1/fc2/dec*, whmr.py:118-126; Tz-head Block and est_Tz linears, whmr.py:423-427): fp32 GEMM,
                  dX = dY . W, dW = dY^T . X (transposed operands from whmr_transpose_cast), db = column sum.
   ConvNHWCFn     Conv2d without bias / padding on a channels-last map (Tz head, whmr.py:419-420): forward = implicit GEMM with the
-                 NHWC gather; dW = dY^T . col(X) with col(X)^T from whmr_im2col_t; dX = col2im(dY . W) (whmr_col2im).
+                 NHWC gather; dW = dY^T . col(X) with col(X)^T from whmr_im2col_t (or from dY when that side is narrower); dX = flipped-kernel
+                 gather conv (stride 1), S*S residue-class gather convs (stride S, no padding) or col2im(dY . W) (whmr_col2im) otherwise.
   DownsampleFn   the dense mesh down-sampling products sub_verts = Dmap0 . verts, temp_verts = Dmap1 . sub_verts (whmr.py:182-183).
 """
 import torch
@@ -123,6 +124,20 @@ class ConvNHWCFn(torch.autograd.Function):
                 w4 = L.cast_bf16(w4) if dt == torch.bfloat16 else w4
                 L.gemm(dyp.view(B, OH, OW, npad), w4, dx.view(B * IH * IW, Cin),
                        conv=dict(IH=OH, IW=OW, Cin=npad, OH=IH, OW=IW, KW=KW, SH=1, SW=1, PH=KH - 1 - P, PW=KW - 1 - P))
+            elif P == 0 and S > 1 and KH >= S and KW >= S and (dt == torch.float32 or npad % 64 == 0):
+                # strided convolution (Tz head, 7x7 s3 / s2): the input pixels split into S*S residue classes (iy mod S, ix mod S); class
+                # (ry, rx) only ever meets the taps ky = ry + S*t, kx = rx + S*u, so its data gradient is a small stride-1 convolution of dY
+                # (ceil((KH-ry)/S) x ceil((KW-rx)/S) taps, flipped) -- S*S implicit GEMMs that scatter into the interleaved pixels, instead
+                # of a 2 GB column-space gradient plus col2im.
+                w4 = wm.view(npad, KH, KW, Cin)
+                dy_img = dyp.view(B, OH, OW, npad)
+                for ry in range(S):
+                    for rx in range(S):
+                        Ty, Tx = len(range(ry, KH, S)), len(range(rx, KW, S))
+                        Jy, Jx = (IH - ry + S - 1) // S, (IW - rx + S - 1) // S
+                        wp = w4[:, ry::S, rx::S, :].flip(1, 2).permute(3, 1, 2, 0).reshape(Cin, Ty * Tx * npad).contiguous()
+                        L.gemm(dy_img, wp, dx, conv=dict(IH=OH, IW=OW, Cin=npad, OH=Jy, OW=Jx, KW=Tx, SH=1, SW=1, PH=Ty - 1, PW=Tx - 1),
+                               scatter=dict(c_off=(ry * IW + rx) * Cin, osb=IH * IW * Cin, osy=S * IW * Cin, osx=S * Cin))
             else:
                 wt = L.transpose_cast(wm, dt, pad_to=1)                            # [K, npad]
                 dcol = torch.empty(M, K, dtype=dt, device=dev)
