@@ -263,6 +263,12 @@ int whmr_maf_sample_bwd(const void* fmap, int fmap_bf16, long sb, long sc, long 
 int whmr_col2im(const void* dcol, int dcol_bf16, long ldcol, void* dx, int dx_bf16, int B, int IH, int IW, int C, int OH, int OW,
                 int KH, int KW, int S, int P, void* stream);
 
+/* Sparse matrix (CSR: ptr [n_out+1], col, val) applied to B point sets: out[b, r, :] (+)= sum_k val[k] * in[b, col[k], :].  The mesh
+ * down-sampling products of whmr.py:182-183 (the reference multiplies the densified 1723 x 6890 / 431 x 1723 matrices) and, with the CSR of
+ * the transpose, their backward. */
+int whmr_csr_apply3(const int32_t* ptr, const int32_t* col, const float* val, const float* in, int n_in, float* out, int n_out, int B,
+                    int accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

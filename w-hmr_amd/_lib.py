@@ -85,6 +85,7 @@ _SIGS = {
     'whmr_smpl_chain_bwd': [C.POINTER(WhmrSmplModel), _P, _P, _L, _P, _P, _P, _I, _P, _P, _P],
     'whmr_maf_sample_bwd': [_P, _I, _L, _L, _L, _L, _I, _I, _P, _P, _P, _L, _F, _F, _F, C.POINTER(WhmrMafWeights), _P, _P, _P, _I, _I, _P, _L, _P, _I, _L, _L, _L, _L, _P, _P, _L, _P],
     'whmr_col2im': [_P, _I, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    'whmr_csr_apply3': [_P, _P, _P, _P, _I, _P, _I, _I, _I, _P],
     'whmr_maxpool_nhwc': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'whmr_avgpool_nhwc': [_P, _P, _I, _I, _I, _I, _P],
 }
@@ -672,3 +673,23 @@ def col2im(dcol, dx_nhwc, OH, OW, KH, KW, S, P):
     _check(lib().whmr_col2im(dcol.data_ptr(), _bf(dcol), dcol.stride(0), dx_nhwc.data_ptr(), _bf(dx_nhwc), B, IH, IW, Cc, OH, OW, KH, KW, S, P,
                              _stream()), 'whmr_col2im')
     return dx_nhwc
+
+
+def dense_to_csr(d):
+    """Dense [n_out, n_in] device matrix -> (ptr int32 [n_out+1], col int32, val fp32); one host sync (the non-zero count), done once per
+    weight version by the callers' caches."""
+    sp = d.detach().float().to_sparse_csr()
+    return (sp.crow_indices().to(torch.int32).contiguous(), sp.col_indices().to(torch.int32).contiguous(), sp.values().contiguous())
+
+
+def csr_apply3(csr, x, n_out, out=None, accumulate=False):
+    """x [B, n_in, 3] fp32 -> out [B, n_out, 3] = D . x for the CSR triple of D."""
+    _dev(x, out)
+    ptr, col, val = csr
+    x = _f32c(x)
+    B, n_in = x.shape[0], x.shape[1]
+    if out is None:
+        out = torch.empty(B, n_out, 3, dtype=torch.float32, device=x.device)
+    _check(lib().whmr_csr_apply3(ptr.data_ptr(), col.data_ptr(), val.data_ptr(), x.data_ptr(), n_in, out.data_ptr(), n_out, B, int(accumulate),
+                                 _stream()), 'whmr_csr_apply3')
+    return out

@@ -580,3 +580,31 @@ extern "C" int whmr_smpl_chain_bwd(const whmr_smpl_model* m, const float* rotmat
     WHMR_CHECK_LAUNCH();
     return 0;
 }
+
+
+// =====================================================================================================================
+// Mesh down-sampling sub_verts = Dmap0 . verts, temp_verts = Dmap1 . sub_verts (models/whmr.py:95-98,182-183).  The reference densifies the
+// sparse down-sampling matrices of data/mesh_downsampling.npz (1723 x 6890 and 431 x 1723 with ~3 non-zeros per row) and multiplies
+// 47.5 MB of zeros per call; here the dense buffer is compressed once per weight version (CSR, built by the host wrapper) and applied as a
+// gather: out[b, r, :] = sum_k val[k] * in[b, col[k], :], k in [ptr[r], ptr[r+1]).  The backward is the same kernel on the CSR of D^T.
+__global__ __launch_bounds__(256) void csr_apply3_kernel(const int32_t* __restrict__ ptr, const int32_t* __restrict__ col, const float* __restrict__ val,
+                                                         const float* __restrict__ in, int n_in, float* __restrict__ out, int n_out, int B,
+                                                         int accumulate) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;           // (b, r, c)
+    if (i >= (long)B * n_out * 3) return;
+    const int c = (int)(i % 3), r = (int)((i / 3) % n_out), b = (int)(i / (3L * n_out));
+    const float* ib = in + (size_t)b * n_in * 3 + c;
+    float a = 0.f;
+    for (int k = ptr[r]; k < ptr[r + 1]; ++k) a = fmaf(val[k], ib[(size_t)col[k] * 3], a);
+    out[i] = accumulate ? out[i] + a : a;
+}
+
+extern "C" int whmr_csr_apply3(const int32_t* ptr, const int32_t* col, const float* val, const float* in, int n_in, float* out, int n_out, int B,
+                               int accumulate, void* stream) {
+    if (B <= 0 || n_in <= 0 || n_out <= 0) return (int)hipErrorInvalidValue;
+    const long n = (long)B * n_out * 3;
+    hipLaunchKernelGGL(csr_apply3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ptr, col, val, in, n_in, out, n_out, B,
+                       accumulate);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}

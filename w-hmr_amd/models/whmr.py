@@ -128,16 +128,12 @@ class Regressor(nn.Module):
         return self._cache.get('collapsed', ws, build)
 
     def _downsample(self, verts):
-        """whmr.py:182-183 (train view only): dense Dmap0 / Dmap1 products on the fp32 GEMM kernel."""
-        B = verts.shape[0]
-        vt = verts.permute(0, 2, 1).reshape(B * 3, -1).contiguous()                  # [3B, 6890]
-        sub = torch.empty(self.Dmap0.shape[0], B * 3, dtype=torch.float32, device=verts.device)
-        L.gemm(self.Dmap0, vt, sub)
-        st = sub.t().contiguous()                                                      # [3B, 1723]
-        tmp = torch.empty(self.Dmap1.shape[0], B * 3, dtype=torch.float32, device=verts.device)
-        L.gemm(self.Dmap1, st, tmp)
-        n0, n1 = self.Dmap0.shape[0], self.Dmap1.shape[0]
-        return sub.view(n0, B, 3).permute(1, 0, 2).contiguous(), tmp.view(n1, B, 3).permute(1, 0, 2).contiguous()
+        """whmr.py:182-183 (train view only): sub_verts = Dmap0 . verts, temp_verts = Dmap1 . sub_verts.  The reference multiplies the
+        densified matrices; here they are compressed once per buffer version (CSR) and applied as a gather (whmr_csr_apply3)."""
+        from ..train.heads_autograd import downsample_csr
+        c = downsample_csr(self.Dmap0, self.Dmap1, self.__dict__.setdefault('_ds_cache', {}))
+        sub = L.csr_apply3(c['d0'], verts, self.Dmap0.shape[0])
+        return sub, L.csr_apply3(c['d1'], sub, self.Dmap1.shape[0])
 
     def _outputs(self, out, state, scale, J_regressor, with_aux, Tz=None, orig_shape=None, center=None, bbox_height=None):
         """state [B,229] = [pose(216) | shape(10) | cam(3)] rows (possibly a strided view).  whmr.py:139-209."""

@@ -5,7 +5,8 @@
   ConvNHWCFn     Conv2d without bias / padding on a channels-last map (Tz head, whmr.py:419-420): forward = implicit GEMM with the
                  NHWC gather; dW = dY^T . col(X) with col(X)^T from whmr_im2col_t (or from dY when that side is narrower); dX = flipped-kernel
                  gather conv (stride 1), S*S residue-class gather convs (stride S, no padding) or col2im(dY . W) (whmr_col2im) otherwise.
-  DownsampleFn   the dense mesh down-sampling products sub_verts = Dmap0 . verts, temp_verts = Dmap1 . sub_verts (whmr.py:182-183).
+  DownsampleFn   the mesh down-sampling products sub_verts = Dmap0 . verts, temp_verts = Dmap1 . sub_verts (whmr.py:182-183), applied
+                 from the CSR form of the (densified-in-the-reference) matrices; backward = CSR of the transposes.
 """
 import torch
 
@@ -146,36 +147,35 @@ class ConvNHWCFn(torch.autograd.Function):
         return dx, dw, None, None, None, db
 
 
+def downsample_csr(d0, d1, cache):
+    """CSR triples of Dmap0, Dmap1 and their transposes, rebuilt when a buffer changes (one host sync each, outside any graph capture)."""
+    key = (d0.data_ptr(), d0._version, d1.data_ptr(), d1._version)
+    if cache.get('key') != key:
+        cache.update(key=key, d0=L.dense_to_csr(d0), d1=L.dense_to_csr(d1), d0t=L.dense_to_csr(d0.t()), d1t=L.dense_to_csr(d1.t()))
+    return cache
+
+
 class DownsampleFn(torch.autograd.Function):
-    """sub_verts [B,n0,3], temp_verts [B,n1,3] = DownsampleFn.apply(verts [B,6890,3], Dmap0 [n0,6890], Dmap1 [n1,n0], cache_dict)."""
+    """sub_verts [B,n0,3], temp_verts [B,n1,3] = DownsampleFn.apply(verts [B,6890,3], Dmap0 [n0,6890], Dmap1 [n1,n0], cache_dict).
+    The matrices are applied in compressed form (~3 non-zeros per row in data/mesh_downsampling.npz; any dense content works)."""
 
     @staticmethod
     def forward(ctx, verts, d0, d1, cache):
-        B = verts.shape[0]
-        dev = verts.device
-        vt = verts.detach().permute(0, 2, 1).reshape(B * 3, -1).contiguous()                       # [3B, 6890]
-        sub = torch.empty(d0.shape[0], B * 3, dtype=torch.float32, device=dev)
-        L.gemm(d0, vt, sub)
-        st = sub.t().contiguous()                                                                  # [3B, n0]
-        tmp = torch.empty(d1.shape[0], B * 3, dtype=torch.float32, device=dev)
-        L.gemm(d1, st, tmp)
-        key = (d0.data_ptr(), d0._version, d1.data_ptr(), d1._version)
-        if cache.get('key') != key:
-            cache.update(key=key, d0t=d0.t().contiguous(), d1t=d1.t().contiguous())
-        ctx.cache, ctx.B = cache, B
-        n0, n1 = d0.shape[0], d1.shape[0]
-        return sub.view(n0, B, 3).permute(1, 0, 2).contiguous(), tmp.view(n1, B, 3).permute(1, 0, 2).contiguous()
+        c = downsample_csr(d0, d1, cache)
+        sub = L.csr_apply3(c['d0'], verts.detach(), d0.shape[0])
+        tmp = L.csr_apply3(c['d1'], sub, d1.shape[0])
+        ctx.cache, ctx.dims = c, (d0.shape[1], d0.shape[0])
+        return sub, tmp
 
     @staticmethod
     def backward(ctx, d_sub, d_tmp):
-        B, c = ctx.B, ctx.cache
-        n0, n1 = c['d1t'].shape
-        dev = c['d0t'].device
-        ds = torch.zeros(B * 3, n0, dtype=torch.float32, device=dev)
+        c = ctx.cache
+        n_v, n0 = ctx.dims
+        ds = None
         if d_tmp is not None:
-            L.gemm(d_tmp.float().permute(0, 2, 1).reshape(B * 3, n1).contiguous(), c['d1t'], ds)   # [3B, n1] . Dmap1 -> [3B, n0]
+            ds = L.csr_apply3(c['d1t'], d_tmp, n0)                                   # Dmap1^T . d_tmp
         if d_sub is not None:
-            ds += d_sub.float().permute(0, 2, 1).reshape(B * 3, n0)
-        dv = torch.empty(B * 3, c['d0t'].shape[0], dtype=torch.float32, device=dev)
-        L.gemm(ds, c['d0t'], dv)                                                                   # [3B, n0] . Dmap0 -> [3B, 6890]
-        return dv.view(B, 3, -1).permute(0, 2, 1).contiguous(), None, None, None
+            ds = d_sub.float().contiguous() if ds is None else ds + d_sub
+        if ds is None:
+            return None, None, None, None
+        return L.csr_apply3(c['d0t'], ds, n_v), None, None, None
