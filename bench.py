@@ -74,7 +74,7 @@ def build_workload(args, dev):
         # a synthetic L2 loss on the tensors core/trainer.py:500-600 supervises, backward through the HIP autograd nodes, bucketed
         # all-reduce(mean) of the gradients (whmr_amd.parallel.GradReducer), Adam update
         from whmr_amd.models import whmr_net
-        from whmr_amd.parallel import GradReducer
+        from whmr_amd.parallel import GradReducer, broadcast_buffers
         assets = synth.make_assets(0)
         sd = synth.make_state_dict(0, assets, with_cam_model=False)
         m = whmr_net(None, assets=assets, numerics=args.numerics)
@@ -106,6 +106,7 @@ def build_workload(args, dev):
             loss.backward()
             if red is not None:
                 red.finish()
+                broadcast_buffers(m)                            # DDP broadcast_buffers: BatchNorm running statistics follow rank 0
             return loss
 
         def train_step():

@@ -129,7 +129,7 @@ def test_grad_reducer_two_ranks_gloo(tmp_path):
     script.write_text('''
 import json, os, sys, torch, torch.distributed as dist
 sys.path.insert(0, %r)
-from whmr_amd.parallel import GradReducer, shard_batch
+from whmr_amd.parallel import GradReducer, shard_batch, broadcast_buffers
 dist.init_process_group('gloo')
 rank, world = dist.get_rank(), dist.get_world_size()
 torch.manual_seed(0)
@@ -144,8 +144,16 @@ for step in range(2):                                             # twice: bucke
     ((model(x[lo:hi]) - y[lo:hi]) ** 2).mean().backward()
     red.finish()
 err = max((p.grad - g).abs().max().item() for p, g in zip(model.parameters(), ref[0]))
+# running statistics: every rank saw a different shard; after broadcast_buffers all ranks hold rank 0's copy
+bn = torch.nn.BatchNorm1d(16)
+bn.train()
+bn(x[lo:hi])
+n_b = broadcast_buffers(bn)
+gathered = [torch.zeros(16) for _ in range(world)]
+dist.all_gather(gathered, bn.running_mean)
+same = all(torch.equal(g, gathered[0]) for g in gathered)
 if rank == 0:
-    print(json.dumps({'err': err, 'buckets': len(red.buckets), 'shard': [lo, hi]}))
+    print(json.dumps({'err': err, 'buckets': len(red.buckets), 'shard': [lo, hi], 'n_buffers': n_b, 'buffers_equal': same}))
 dist.destroy_process_group()
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     env = dict(os.environ, MASTER_ADDR='127.0.0.1')
@@ -154,3 +162,4 @@ dist.destroy_process_group()
     assert out.returncode == 0, out.stderr[-2000:]
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
     assert res['err'] < 1e-6 and res['buckets'] >= 2 and res['shard'] == [0, 6]
+    assert res['n_buffers'] == 2 and res['buffers_equal']

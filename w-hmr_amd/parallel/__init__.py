@@ -1,1 +1,1 @@
-from .grad_reducer import GradReducer, shard_batch      # noqa: F401
+from .grad_reducer import GradReducer, shard_batch, broadcast_buffers      # noqa: F401

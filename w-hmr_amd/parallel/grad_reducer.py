@@ -106,3 +106,22 @@ class GradReducer:
     def remove(self):
         for h in self._hooks:
             h.remove()
+
+
+def broadcast_buffers(module, src=0, process_group=None):
+    """DistributedDataParallel's ``broadcast_buffers=True`` (the reference wraps the model in DDP, core/trainer.py:88-104): every floating-point
+    buffer -- here the BatchNorm running statistics, which each rank updates from its own batch -- is overwritten with rank ``src``'s copy.
+    All buffers travel as ONE flat fp32 broadcast (a few KB for W-HMR), so calling it once per step costs one small collective."""
+    if not dist.is_initialized() or dist.get_world_size(process_group) == 1:
+        return 0
+    named = [(n, b) for n, b in module.named_buffers() if b.is_floating_point() and 'running_' in n]
+    if not named:
+        return 0
+    flat = torch.cat([b.detach().reshape(-1).float() for _, b in named])
+    dist.broadcast(flat, src=src, group=process_group)
+    off = 0
+    with torch.no_grad():
+        for _, b in named:
+            b.copy_(flat[off:off + b.numel()].view_as(b))
+            off += b.numel()
+    return len(named)
