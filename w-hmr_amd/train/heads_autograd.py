@@ -77,8 +77,8 @@ class ConvNHWCFn(torch.autograd.Function):
         ctx.saved = (x, wm)
         ctx.dims = (B, IH, IW, Cin, Cout, KH, KW, OH, OW, stride, padding, npad, dt)
         ctx.has_bias = bias is not None
-        out = y if npad == Cout else y[:, :Cout].contiguous()
-        return out.view(B, OH, OW, Cout)
+        # padded channel groups are returned as a strided view (the consumer's dtype cast / permute reads it once; no compaction pass)
+        return y.view(B, OH, OW, npad)[..., :Cout] if npad != Cout else y.view(B, OH, OW, Cout)
 
     @staticmethod
     def backward(ctx, dy):
