@@ -269,6 +269,17 @@ int whmr_col2im(const void* dcol, int dcol_bf16, long ldcol, void* dx, int dx_bf
 int whmr_csr_apply3(const int32_t* ptr, const int32_t* col, const float* val, const float* in, int n_in, float* out, int n_out, int B,
                     int accumulate, void* stream);
 
+/* Training form of the regressor tail (whmr.py:142-173; geometry.py:289-341,139-157): joints [B,J,3], cam [B,3], Tz [B] -> kp2d, kp2d_w
+ * [B,J,2], cam_t [B,3] (from cam.detach()), focal [B] = s.detach()*h*Tz/2, and the backward of all four in one launch.  stage = cfg.TRAIN.STAGE:
+ * 1 -> kp2d differentiates the joints, otherwise kp2d_w does (whmr.py:142-145,156-163).  Gradient inputs are nullable. */
+int whmr_regressor_post_train(const float* joints, const float* cam, const float* Tz, const float* bbox_h, const float* center,
+                              const float* orig_shape, int B, int J, float focal0, float res_w, float res_h, float* kp2d, float* kp2d_w,
+                              float* cam_t, float* focal, void* stream);
+int whmr_regressor_post_train_bwd(const float* joints, const float* cam, const float* Tz, const float* bbox_h, const float* center,
+                                  const float* orig_shape, int B, int J, float focal0, float res_w, float res_h, int stage,
+                                  const float* d_kp2d, const float* d_kp2d_w, const float* d_cam_t, const float* d_focal, float* d_joints,
+                                  float* d_cam, float* d_Tz, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -587,3 +587,40 @@ def test_bn_and_col2im_edge_shapes(dev):
     dx = torch.empty(B, IH, IW, Cc, device=dev)
     L.col2im(dcol.to(dev), dx, OH, OW, KH, KW, S, P)
     assert _rel(dx.cpu().permute(0, 3, 1, 2), ref) < 1e-5
+
+
+@pytest.mark.parametrize('stage', [1, 2])
+def test_regressor_post_node_matches_tensor_arithmetic(dev, stage):
+    """RegressorPostFn (fused forward / backward of whmr.py:142-173) against the same arithmetic written as differentiable tensor expressions
+    (whmr_train._projection / _perspective_norm), with cotangents on all four outputs including cam_t and focal."""
+    from whmr_amd.train.heads_autograd import RegressorPostFn
+    from whmr_amd.train.whmr_train import _perspective_norm, _projection
+    g = torch.Generator().manual_seed(stage)
+    B, J = 5, 49
+    joints = (torch.randn(B, J, 3, generator=g) * 0.4).to(dev)
+    cam = torch.cat([torch.rand(B, 1, generator=g) * 0.6 + 0.6, torch.randn(B, 2, generator=g) * 0.1], 1).to(dev)
+    Tz = (torch.rand(B, generator=g) * 6 + 2).to(dev)
+    bh = (torch.rand(B, generator=g) * 300 + 150).to(dev)
+    orig = torch.tensor([[720., 1280.]] * B, device=dev)
+    center = (torch.rand(B, 2, generator=g) * torch.tensor([1280., 720.])).to(dev)
+    cots = [torch.randn(B, J, 2, generator=g).to(dev), torch.randn(B, J, 2, generator=g).to(dev), torch.randn(B, 3, generator=g).to(dev),
+            torch.randn(B, generator=g).to(dev) * 1e-3]
+
+    def ref(j, c, t):
+        kp = _projection(j if stage == 1 else j.detach(), c)
+        focal = c[:, 0].detach() * bh * t / 2.0
+        cd = c.detach()
+        cam_t = torch.stack([cd[:, 1] + 2.0 * (center[:, 0] - orig[:, 1] / 2.0) / (cd[:, 0] * bh),
+                             cd[:, 2] + 2.0 * (center[:, 1] - orig[:, 0] / 2.0) / (cd[:, 0] * bh), t], dim=-1)
+        kw = _perspective_norm(j.detach() if stage == 1 else j, cam_t, focal, orig.flip(1) / 2.0)
+        return kp, kw, cam_t, focal
+    leaves_r = [t.clone().requires_grad_(True) for t in (joints, cam, Tz)]
+    leaves_h = [t.clone().requires_grad_(True) for t in (joints, cam, Tz)]
+    out_r = ref(*leaves_r)
+    out_h = RegressorPostFn.apply(*leaves_h, bh, center, orig, stage, (1000.0, 256.0, 256.0))
+    for a, b in zip(out_h, out_r):
+        assert _rel(a.detach(), b.detach()) < 1e-5
+    sum((o * c).sum() for o, c in zip(out_r, cots)).backward()
+    sum((o * c).sum() for o, c in zip(out_h, cots)).backward()
+    for a, b, name in zip(leaves_h, leaves_r, ('joints', 'cam', 'Tz')):
+        assert _rel(a.grad, b.grad) < 1e-4, (name, _rel(a.grad, b.grad))

@@ -86,6 +86,8 @@ _SIGS = {
     'whmr_maf_sample_bwd': [_P, _I, _L, _L, _L, _L, _I, _I, _P, _P, _P, _L, _F, _F, _F, C.POINTER(WhmrMafWeights), _P, _P, _P, _I, _I, _P, _L, _P, _I, _L, _L, _L, _L, _P, _P, _L, _P],
     'whmr_col2im': [_P, _I, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'whmr_csr_apply3': [_P, _P, _P, _P, _I, _P, _I, _I, _I, _P],
+    'whmr_regressor_post_train': [_P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P],
+    'whmr_regressor_post_train_bwd': [_P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     'whmr_maxpool_nhwc': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'whmr_avgpool_nhwc': [_P, _P, _I, _I, _I, _I, _P],
 }

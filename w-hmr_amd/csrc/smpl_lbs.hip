@@ -608,3 +608,117 @@ extern "C" int whmr_csr_apply3(const int32_t* ptr, const int32_t* col, const flo
     WHMR_CHECK_LAUNCH();
     return 0;
 }
+
+
+// =====================================================================================================================
+// Training form of the regressor tail (whmr.py:142-173): weak-perspective key points kp_2d (geometry.py:289-307), focal length
+// s.detach()*h*Tz/2, full-image camera translation from pred_cam.detach() (geometry.py:139-157), full-image key points kp_2d_w, in ONE launch,
+// and their backward in one launch.  cfg.TRAIN.STAGE decides which of the two projections differentiates the joints (whmr.py:142-145,156-163):
+// stage 1 -> kp_2d, otherwise kp_2d_w.  One wave per image, lane = joint; the camera / Tz gradients are wave sums (fixed order).
+__global__ __launch_bounds__(64) void regressor_post_train_fwd_kernel(const float* __restrict__ joints, const float* __restrict__ cam,
+                                                                      const float* __restrict__ Tz, const float* __restrict__ bbox_h,
+                                                                      const float* __restrict__ center, const float* __restrict__ orig_shape,
+                                                                      int J, float focal0, float res_w, float res_h, float* __restrict__ kp2d,
+                                                                      float* __restrict__ kp2d_w, float* __restrict__ cam_t_out,
+                                                                      float* __restrict__ focal_out) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const float s = cam[3 * b], tx = cam[3 * b + 1], ty = cam[3 * b + 2];
+    const float h = bbox_h[b], tz = Tz[b];
+    const float focal = s * h * tz / 2.f;
+    const float H = orig_shape[2 * b], W = orig_shape[2 * b + 1];
+    const float ctx = tx + 2.f * (center[2 * b] - W / 2.f) / (s * h);
+    const float cty = ty + 2.f * (center[2 * b + 1] - H / 2.f) / (s * h);
+    if (lane == 0) {
+        cam_t_out[3 * b] = ctx; cam_t_out[3 * b + 1] = cty; cam_t_out[3 * b + 2] = tz;
+        focal_out[b] = focal;
+    }
+    const float tzw = 2.f * focal0 / (res_h * s + 1e-9f);
+    const float cxw = W / 2.f, cyw = H / 2.f;
+    for (int j = lane; j < J; j += 64) {
+        const float* q = joints + ((size_t)b * J + j) * 3;
+        const float x = q[0], y = q[1], z = q[2];
+        const float zw = z + tzw;
+        kp2d[((size_t)b * J + j) * 2] = (focal0 * ((x + tx) / zw)) / (res_w / 2.f);
+        kp2d[((size_t)b * J + j) * 2 + 1] = (focal0 * ((y + ty) / zw)) / (res_h / 2.f);
+        const float zf = z + tz;
+        kp2d_w[((size_t)b * J + j) * 2] = (focal * ((x + ctx) / zf) + cxw) / cxw - 1.f;
+        kp2d_w[((size_t)b * J + j) * 2 + 1] = (focal * ((y + cty) / zf) + cyw) / cyw - 1.f;
+    }
+}
+
+// d_kp2d / d_kp2d_w [B,J,2], d_cam_t [B,3], d_focal [B] (each nullable) -> d_joints [B,J,3], d_cam [B,3], d_Tz [B].
+__global__ __launch_bounds__(64) void regressor_post_train_bwd_kernel(const float* __restrict__ joints, const float* __restrict__ cam,
+                                                                      const float* __restrict__ Tz, const float* __restrict__ bbox_h,
+                                                                      const float* __restrict__ center, const float* __restrict__ orig_shape,
+                                                                      int J, float focal0, float res_w, float res_h, int stage,
+                                                                      const float* __restrict__ d_kp2d, const float* __restrict__ d_kp2d_w,
+                                                                      const float* __restrict__ d_cam_t, const float* __restrict__ d_focal,
+                                                                      float* __restrict__ d_joints, float* __restrict__ d_cam,
+                                                                      float* __restrict__ d_Tz) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const float s = cam[3 * b], tx = cam[3 * b + 1], ty = cam[3 * b + 2];
+    const float h = bbox_h[b], tz = Tz[b];
+    const float focal = s * h * tz / 2.f;
+    const float H = orig_shape[2 * b], W = orig_shape[2 * b + 1];
+    const float ctx = tx + 2.f * (center[2 * b] - W / 2.f) / (s * h);
+    const float cty = ty + 2.f * (center[2 * b + 1] - H / 2.f) / (s * h);
+    const float den = res_h * s + 1e-9f;
+    const float tzw = 2.f * focal0 / den;
+    const float cxw = W / 2.f, cyw = H / 2.f;
+    const float kx = focal0 / (res_w / 2.f), ky = focal0 / (res_h / 2.f);
+    float g_tx = 0.f, g_ty = 0.f, g_tzw = 0.f, g_focal = 0.f, g_tz = 0.f;
+    for (int j = lane; j < J; j += 64) {
+        const float* q = joints + ((size_t)b * J + j) * 3;
+        const float x = q[0], y = q[1], z = q[2];
+        float dj[3] = {0.f, 0.f, 0.f};
+        if (d_kp2d) {
+            const float gx = d_kp2d[((size_t)b * J + j) * 2], gy = d_kp2d[((size_t)b * J + j) * 2 + 1];
+            const float zw = z + tzw;
+            const float du = kx / zw * gx, dv = ky / zw * gy;
+            const float dz = -(kx * (x + tx) * gx + ky * (y + ty) * gy) / (zw * zw);
+            g_tx += du; g_ty += dv; g_tzw += dz;
+            if (stage == 1) { dj[0] += du; dj[1] += dv; dj[2] += dz; }
+        }
+        if (d_kp2d_w) {
+            const float gx = d_kp2d_w[((size_t)b * J + j) * 2], gy = d_kp2d_w[((size_t)b * J + j) * 2 + 1];
+            const float zf = z + tz;
+            const float ax = (x + ctx) / (zf * cxw), ay = (y + cty) / (zf * cyw);
+            g_focal += ax * gx + ay * gy;
+            const float da = focal / (zf * cxw) * gx, db = focal / (zf * cyw) * gy;
+            const float dz = -focal * (ax * gx + ay * gy) / zf;
+            g_tz += dz;
+            if (stage != 1) { dj[0] += da; dj[1] += db; dj[2] += dz; }
+        }
+        d_joints[((size_t)b * J + j) * 3] = dj[0]; d_joints[((size_t)b * J + j) * 3 + 1] = dj[1]; d_joints[((size_t)b * J + j) * 3 + 2] = dj[2];
+    }
+    g_tx = wave_sum(g_tx); g_ty = wave_sum(g_ty); g_tzw = wave_sum(g_tzw); g_focal = wave_sum(g_focal); g_tz = wave_sum(g_tz);
+    if (lane == 0) {
+        if (d_focal) g_focal += d_focal[b];
+        if (d_cam_t) g_tz += d_cam_t[3 * b + 2];             // cam_t = [f(cam.detach()), f(cam.detach()), Tz]
+        d_cam[3 * b] = g_tzw * (-2.f * focal0 * res_h / (den * den));
+        d_cam[3 * b + 1] = g_tx;
+        d_cam[3 * b + 2] = g_ty;
+        d_Tz[b] = g_tz + g_focal * s * h / 2.f;              // focal = s.detach() * h * Tz / 2
+    }
+}
+
+extern "C" int whmr_regressor_post_train(const float* joints, const float* cam, const float* Tz, const float* bbox_h, const float* center,
+                                         const float* orig_shape, int B, int J, float focal0, float res_w, float res_h, float* kp2d,
+                                         float* kp2d_w, float* cam_t, float* focal, void* stream) {
+    if (B <= 0 || J <= 0) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(regressor_post_train_fwd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, joints, cam, Tz, bbox_h, center, orig_shape, J,
+                       focal0, res_w, res_h, kp2d, kp2d_w, cam_t, focal);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int whmr_regressor_post_train_bwd(const float* joints, const float* cam, const float* Tz, const float* bbox_h, const float* center,
+                                             const float* orig_shape, int B, int J, float focal0, float res_w, float res_h, int stage,
+                                             const float* d_kp2d, const float* d_kp2d_w, const float* d_cam_t, const float* d_focal,
+                                             float* d_joints, float* d_cam, float* d_Tz, void* stream) {
+    if (B <= 0 || J <= 0) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(regressor_post_train_bwd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, joints, cam, Tz, bbox_h, center, orig_shape, J,
+                       focal0, res_w, res_h, stage, d_kp2d, d_kp2d_w, d_cam_t, d_focal, d_joints, d_cam, d_Tz);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}

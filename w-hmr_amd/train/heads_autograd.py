@@ -179,3 +179,39 @@ class DownsampleFn(torch.autograd.Function):
         if ds is None:
             return None, None, None, None
         return L.csr_apply3(c['d0t'], ds, n_v), None, None, None
+
+
+class RegressorPostFn(torch.autograd.Function):
+    """kp_2d, kp_2d_w, cam_t, focal = RegressorPostFn.apply(joints [B,J,3], cam [B,3], Tz [B], bbox_h, center, orig_shape, stage, consts):
+    the regressor tail of whmr.py:142-173 in one launch forward and one backward (consts = (FOCAL_LENGTH, IMG_RES.WIDTH, IMG_RES.HEIGHT))."""
+
+    @staticmethod
+    def forward(ctx, joints, cam, Tz, bbox_h, center, orig_shape, stage, consts):
+        if not joints.is_cuda:
+            raise RuntimeError('whmr_amd runs on a HIP device only (no CPU fallback)')
+        j, c, t = _f32(joints.detach()), _f32(cam.detach()), _f32(Tz.detach())
+        bh, ce, os_ = _f32(bbox_h), _f32(center), _f32(orig_shape)
+        B, J = j.shape[0], j.shape[1]
+        dev = j.device
+        kp, kw = torch.empty(B, J, 2, device=dev), torch.empty(B, J, 2, device=dev)
+        ct, fo = torch.empty(B, 3, device=dev), torch.empty(B, device=dev)
+        L._check(L.lib().whmr_regressor_post_train(j.data_ptr(), c.data_ptr(), t.data_ptr(), bh.data_ptr(), ce.data_ptr(), os_.data_ptr(), B, J,
+                                                   consts[0], consts[1], consts[2], kp.data_ptr(), kw.data_ptr(), ct.data_ptr(), fo.data_ptr(),
+                                                   L._stream()), 'whmr_regressor_post_train')
+        ctx.saved = (j, c, t, bh, ce, os_)
+        ctx.stage, ctx.consts = int(stage), consts
+        return kp, kw, ct, fo
+
+    @staticmethod
+    def backward(ctx, d_kp, d_kw, d_ct, d_fo):
+        j, c, t, bh, ce, os_ = ctx.saved
+        ctx.saved = None
+        B, J = j.shape[0], j.shape[1]
+        dev = j.device
+        g = [None if x is None else _f32(x) for x in (d_kp, d_kw, d_ct, d_fo)]
+        dj, dc, dt = torch.empty(B, J, 3, device=dev), torch.empty(B, 3, device=dev), torch.empty(B, device=dev)
+        L._check(L.lib().whmr_regressor_post_train_bwd(j.data_ptr(), c.data_ptr(), t.data_ptr(), bh.data_ptr(), ce.data_ptr(), os_.data_ptr(), B, J,
+                                                       ctx.consts[0], ctx.consts[1], ctx.consts[2], ctx.stage, L._ptr(g[0]), L._ptr(g[1]),
+                                                       L._ptr(g[2]), L._ptr(g[3]), dj.data_ptr(), dc.data_ptr(), dt.data_ptr(), L._stream()),
+                 'whmr_regressor_post_train_bwd')
+        return dj, dc, dt, None, None, None, None, None

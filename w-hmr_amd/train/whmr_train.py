@@ -31,7 +31,7 @@ from .. import _lib as L
 from ..core.cfgs import cfg
 from ..core.constants import FOCAL_LENGTH
 from .deconv_autograd import DeconvBNReLUFn
-from .heads_autograd import ConvNHWCFn, DownsampleFn, LinearFn
+from .heads_autograd import ConvNHWCFn, DownsampleFn, LinearFn, RegressorPostFn
 from .maf_autograd import MAFSampleFn
 from .smpl_autograd import SMPLFn
 
@@ -112,14 +112,9 @@ def regressor_train(reg, ref, bbox_info, Tz, orig_shape, center, scale, bbox_hei
     cam_n = dec[:, 226:] + cam
     rotmat = pose_n.view(B, 24, 3, 3)                                                  # no Gram-Schmidt in training (whmr.py:129)
     verts, joints, smpl_j, markers = SMPLFn.apply(shape_n, rotmat, reg.smpl)
-    kp_2d = _projection(joints if stage == 1 else joints.detach(), cam_n)              # whmr.py:142-145
-    s = cam_n[:, 0].detach()
-    focal = s * bbox_height * Tz / 2.0                                                 # whmr.py:147-149
-    cam_center = orig_shape.flip(1) / 2.0                                               # == orig_shape[:, [1, 0]] (no index upload: graph-capturable)
-    cd = cam_n.detach()                                                                # geometry.py:139-157 on pred_cam.detach()
-    cam_t = torch.stack([cd[:, 1] + 2.0 * (center[:, 0] - orig_shape[:, 1] / 2.0) / (cd[:, 0] * bbox_height),
-                         cd[:, 2] + 2.0 * (center[:, 1] - orig_shape[:, 0] / 2.0) / (cd[:, 0] * bbox_height), Tz], dim=-1)
-    kp_w = _perspective_norm(joints.detach() if stage == 1 else joints, cam_t, focal, cam_center)   # whmr.py:156-173
+    # whmr.py:142-173 in one launch (and one for the backward): kp_2d, focal = s.detach()*h*Tz/2, cam_t from pred_cam.detach(), kp_2d_w
+    kp_2d, kp_w, cam_t, focal = RegressorPostFn.apply(joints, cam_n, Tz, bbox_height, center, orig_shape, stage,
+                                                      (FOCAL_LENGTH, float(cfg.IMG_RES.WIDTH), float(cfg.IMG_RES.HEIGHT)))
     with torch.no_grad():
         aa = L.mat_to_aa(rotmat.detach().reshape(-1, 9).contiguous()).reshape(B, 72)   # whmr.py:174 (no gradient, see module docstring)
     sub, temp = DownsampleFn.apply(verts, reg.Dmap0, reg.Dmap1, cache)
