@@ -4,8 +4,14 @@
 
 A step = one forward of the hot path over one batch of 64 synthetic crops per GPU (inputs resident in HBM).
 N=1 default workload = BASELINE.json configs[1]: ViT-B/16 backbone only, 224x224, batch 64, bf16 MFMA.
-For N>1 launch under torch.distributed.run (one rank per GPU, RCCL); the path shards by image with no data-path
-collective (replicas, weak scaling), so only the timing barrier / max-reduce use the communicator.
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process is only a LAUNCHER -- it never touches the GPU, starts
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py ...` as a CHILD process (never an
+exec), relays rank 0's JSON line and exits with the child's return code.  Under torch.distributed.run (WORLD_SIZE set) it is one rank
+per GPU over RCCL (reference: one process per GPU + NCCL init, train.py:26-33; DDP wrap core/trainer.py:70-95).  The forward workloads shard
+by image with no data-path collective (replicas, weak scaling): only the timing barrier / max-reduce / rank count use the communicator;
+`whmr_train` exchanges gradients (GradReducer) and BatchNorm buffers (broadcast_buffers) every step.
+`--dryrun-cpu` (tests only): gloo + CPU tensors and a stand-in step, to exercise launcher / rank bookkeeping / reducer without a GPU;
+its line says "data": "dryrun" and is not a measurement.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -30,7 +36,7 @@ WORKLOAD = {'vit224': 'ViT-B/16 backbone forward', 'vit256x192': 'ViT-B/16 backb
             'whmr_train': 'W-HMR training step: WHMR.forward(is_train=True), synthetic loss on the supervised outputs, HIP backward, gradient buckets, fused Adam'}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=30)
@@ -40,7 +46,10 @@ def parse():
     ap.add_argument('--numerics', default='bf16')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
     ap.add_argument('--graph', action='store_true', help='whmr_train on one GPU: replay the whole step from one HIP graph')
-    return ap.parse_args()
+    ap.add_argument('--ref-1gpu', type=float, default=None, help='images/sec of the same workload on 1 GPU: adds efficiency_vs_1gpu to the line')
+    ap.add_argument('--master-port', type=int, default=None, help='rendezvous port of the self-launched ranks (default: a free port)')
+    ap.add_argument('--dryrun-cpu', action='store_true', help='tests only: gloo/CPU stand-in step (launcher + rank bookkeeping), not a measurement')
+    return ap.parse_args(argv)
 
 
 def build_workload(args, dev):
@@ -80,13 +89,17 @@ def build_workload(args, dev):
         m = whmr_net(None, assets=assets, numerics=args.numerics)
         m.load_state_dict(sd, strict=False)
         m = m.to(dev).train()
-        for name, p in m.named_parameters():       # frozen (cam_model) or outside the trainer's loss (dp_head, global_orient)
-            if name.startswith(('cam_model', 'global_orient')):
+        for name, p in m.named_parameters():       # the camera-calibration ResNet-50 is frozen (pretrained, SURVEY 8e: 450 MB of gradients without it)
+            if name.startswith('cam_model'):
                 p.requires_grad_(False)
-        params = [p for p in m.parameters() if p.requires_grad]
+        named = [(n, p) for n, p in m.named_parameters() if p.requires_grad]
+        params = [p for _, p in named]
         world = int(os.environ.get('WORLD_SIZE', '1'))
         use_graph = args.graph and world == 1
-        red = None if use_graph else GradReducer(params)      # (no exchange on one GPU; its hooks would pin pre-capture autograd nodes)
+        # global_orient.* (and dp_head.* without AUX supervision) never receive a gradient -- the reference asks DDP for find_unused_parameters
+        # (core/trainer.py:84-91); GradReducer drops them at its first finish().  The backbone is one autograd node, so its parameters get
+        # their own buckets: the head buckets are exchanged while the ViT backward still runs.
+        red = None if use_graph else GradReducer(params, groups=[n.startswith('feature_extractor') for n, _ in named])
         rank = int(os.environ.get('RANK', '0'))
         inp = {k: v.to(dev) for k, v in synth.make_inputs(args.batch, 7 + rank).items()}
         a = (inp['x'], None, inp['center'], inp['scale'], inp['bbox_height'], inp['orig_shape'], inp['bbox_info'])
@@ -190,12 +203,26 @@ def cpu_train_baseline(n_img=4):
                       'step on %d 256x192 crops (%.1f s), torch threads = %d' % (n_img, best, threads)}
 
 
+def gemm_source_digest():
+    """sha256 over the GEMM kernel sources: profiles/*_gemm_traffic.json records the digest it was measured at"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ('gemm_bf16_big.hip', 'gemm_bf16.hip', 'gemm_params.h', 'common.h'):
+        with open(os.path.join(ROOT, 'w-hmr_amd', 'csrc', f), 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def gemm_traffic():
-    """HBM bytes per GEMM launch from the committed rocprofv3 --pmc pass of this same command (profiles/), or None."""
-    path = os.path.join(ROOT, 'profiles', 'r01_vit224_gemm_traffic.json')
-    if os.path.exists(path):
+    """HBM bytes per GEMM launch from the committed rocprofv3 --pmc passes of this same command (profiles/), or None.  A file measured on
+    other GEMM sources than the ones in the tree (digest mismatch) is STALE evidence and is not reported."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_vit224_gemm_traffic.json')), reverse=True):
         with open(path) as f:
-            return json.load(f)
+            t = json.load(f)
+        if t.get('gemm_source_digest') == gemm_source_digest():
+            t['note'] = '%s: %s' % (os.path.basename(path), t['note'])
+            return t
     return None
 
 
@@ -218,29 +245,121 @@ def shard_batch(global_batch, world, rank):
     return [rank * per, (rank + 1) * per]
 
 
-def main():
-    args = parse()
+def launch_ranks(args, argv):
+    """`--gpus N` without a torch.distributed.run environment: start the N ranks as a CHILD process and relay rank 0's line.
+
+    The parent never initialises HIP (no torch.cuda call before this point) and never exec()s: on this pool an exec from a process that
+    has touched the GPU takes the machine down.  One rank per GPU, rendezvous on 127.0.0.1 (reference: train.py:26-33 spawns one process
+    per GPU and calls init_process_group('nccl'))."""
+    import socket
+    import subprocess
+    port = args.master_port
+    if port is None:
+        with socket.socket() as s:
+            s.bind(('127.0.0.1', 0))
+            port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for out in proc.stdout:                     # relay: the child's stderr goes straight through, its stdout is filtered for THE line
+        if out.startswith('{') and '"metric"' in out:
+            line = out.strip()
+        else:
+            sys.stdout.write(out)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        rc = 1
+        print('bench.py launcher: the %d ranks exited 0 without printing a result line' % args.gpus, file=sys.stderr)
+    return rc
+
+
+def count_ranks(dist, dev):
+    """the communicator's own rank count: all_reduce(SUM) of a one per rank (what `n_gpus` reports)"""
+    if dist is None:
+        return 1
+    t = torch.ones(1, dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(round(t.item()))
+
+
+def dryrun_workload(args, dev):
+    """Stand-in step for `--dryrun-cpu` (tests): a tiny torch model on CPU.  For whmr_train it drives the REAL GradReducer / broadcast_buffers
+    (incl. a parameter that never receives a gradient, as global_orient / cam_model in W-HMR) so the N > 1 bookkeeping of the entry point is
+    covered by a gloo test.  Nothing here is the product path and its line is labelled "dryrun"."""
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(32, 64), torch.nn.BatchNorm1d(64), torch.nn.GELU(), torch.nn.Linear(64, 8))
+    unused = torch.nn.Linear(8, 8)               # registered with the reducer, never in the graph
+    rank = int(os.environ.get('RANK', '0'))
+    x = torch.randn(args.batch, 32, generator=torch.Generator().manual_seed(7 + rank))
+    if args.workload != 'whmr_train':
+        net.eval()
+        return (lambda: net(x)), None, x, (1, 32)
+    from whmr_amd.parallel import GradReducer, broadcast_buffers
+    params = list(net.parameters()) + list(unused.parameters())
+    red = GradReducer(params, bucket_bytes=4096)
+    opt = torch.optim.Adam(params, lr=1e-3)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = net(x).pow(2).mean()
+        loss.backward()
+        red.finish()
+        broadcast_buffers(net)
+        opt.step()
+        return loss
+    args.dry_state = (net, unused, red)
+    return step, None, x, (1, 32)
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(args, argv))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs a HIP device: the hot path has no CPU fallback')
-    torch.cuda.set_device(local)
-    dev = torch.device('cuda', local)
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    dry = args.dryrun_cpu
+    if dry:
+        dev = torch.device('cpu')
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit('bench.py needs a HIP device: the hot path has no CPU fallback')
+        torch.cuda.set_device(local)
+        dev = torch.device('cuda', local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
+        if dry:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=dev)          # "nccl" IS RCCL on ROCm
 
-    from whmr_amd import _lib as L
-    step, sd, x, size = build_workload(args, dev)
+    def sync():
+        if not dry:
+            torch.cuda.synchronize()
 
     def barrier():
+        sync()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
+
+    if dry:
+        step, sd, x, size = dryrun_workload(args, dev)
+        L = None
+    else:
+        from whmr_amd import _lib as L
+        step, sd, x, size = build_workload(args, dev)
 
     training = args.workload == 'whmr_train'
+    prof = []
     with (torch.enable_grad() if training else torch.no_grad()):
         for _ in range(args.warmup):
             step()
@@ -250,43 +369,62 @@ def main():
             step()
         barrier()
         dt = time.perf_counter() - t0
-        # dominant-kernel timing: one instrumented step, HIP events around every GEMM launch on the launch stream
-        L.PROFILE = []
-        getattr(args, 'eager_step', step)()
-        torch.cuda.synchronize()
-        prof, L.PROFILE = L.PROFILE, None
+        if L is not None:
+            # dominant-kernel timing: one instrumented step, HIP events around every GEMM launch on the launch stream
+            L.PROFILE = []
+            getattr(args, 'eager_step', step)()
+            torch.cuda.synchronize()
+            prof, L.PROFILE = L.PROFILE, None
     dt = reduce_max_time(dt, dist, dev)
+    n_ranks = count_ranks(dist, dev)
 
     gemm = [(f, e0.elapsed_time(e1) * 1e-3) for (name, f, e0, e1) in prof if name == 'gemm_bf16']
-    traffic = gemm_traffic() if args.workload == 'vit224' else None
+    traffic = gemm_traffic() if (args.workload == 'vit224' and not dry) else None
     n_launch = max(len(gemm), 1)
     flops_per_launch = sum(f for f, _ in gemm) / n_launch
     avg_s = sum(t for _, t in gemm) / n_launch
     achieved = flops_per_launch / avg_s / 1e12 if gemm else 0.0
     peak = 2500.0                                                     # dense bf16 MFMA, MI355X_MICROARCH.md
     if rank == 0:
-        res = {
-            'metric': METRIC[args.workload], 'value': aggregate_value(world, args.batch, args.steps, dt),
-            'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': args.numerics, 'data': 'synthetic',
-            'config': {'workload': '%s (%s), %dx%d crops, batch %d per GPU, random-init weights'
-                                   % (WORKLOAD[args.workload], args.workload, size[0], size[1], args.batch),
-                       'global_batch': world * args.batch, 'parallelism': ('dp%d (RCCL all-reduce of the gradients, 128 MiB buckets)' % world) if training
-                                      else 'replicas x%d (no data-path collective)' % world},
-            'model_tflops': VIT_FLOP_PER_IMG[args.workload] * world * args.batch * args.steps / dt / 1e12,
-            'roofline': {'bound': 'mfma', 'kernel': 'gemm_bf16_big_kernel (all %d GEMM launches of one step)' % len(gemm),
-                         'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
-                         'flops_per_launch': flops_per_launch, 'avg_launch_us': avg_s * 1e6,
-                         'traffic': traffic['bytes_per_launch'] if traffic else None,
-                         'traffic_note': traffic['note'] if traffic else 'no PMC pass committed'},
-        }
-        if not args.no_cpu and world == 1 and training:
-            res['cpu_baseline'] = cpu_train_baseline()
-        elif not args.no_cpu and world == 1 and sd is not None:
-            res['cpu_baseline'] = cpu_baseline(sd, x.cpu(), size, 16 if args.workload == 'vitl256x192' else 12)
+        value = aggregate_value(n_ranks, args.batch, args.steps, dt)
+        if training:
+            par = 'dp%d (RCCL all-reduce of the gradients in 128 MiB buckets; BatchNorm: local batch statistics + running-stat broadcast from rank 0 ' \
+                  'instead of the reference\'s SyncBatchNorm, core/trainer.py:83)' % n_ranks
         else:
-            res['cpu_baseline'] = None
+            par = 'replicas x%d (no data-path collective)' % n_ranks
+        res = {
+            'metric': METRIC.get(args.workload, args.workload) if not dry else 'dryrun (launcher / rank bookkeeping only)',
+            'value': value,
+            'unit': 'images/sec', 'n_gpus': n_ranks, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': args.numerics, 'data': 'dryrun' if dry else 'synthetic',
+            'config': {'workload': ('%s (%s), %dx%d crops, batch %d per GPU, random-init weights'
+                                    % (WORKLOAD[args.workload], args.workload, size[0], size[1], args.batch)) if not dry else 'dryrun-cpu stand-in',
+                       'global_batch': n_ranks * args.batch, 'parallelism': par},
+        }
+        if args.ref_1gpu:
+            res['efficiency_vs_1gpu'] = value / (n_ranks * args.ref_1gpu)
+        if not dry:
+            res['model_tflops'] = VIT_FLOP_PER_IMG[args.workload] * n_ranks * args.batch * args.steps / dt / 1e12
+            res['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_bf16_big_kernel (all %d GEMM launches of one step)' % len(gemm),
+                               'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
+                               'flops_per_launch': flops_per_launch, 'avg_launch_us': avg_s * 1e6,
+                               'traffic': traffic['bytes_per_launch'] if traffic else None,
+                               'traffic_note': traffic['note'] if traffic else 'no PMC pass of the current GEMM sources committed'}
+            if not args.no_cpu and n_ranks == 1 and training:
+                res['cpu_baseline'] = cpu_train_baseline()
+            elif not args.no_cpu and n_ranks == 1 and sd is not None:
+                res['cpu_baseline'] = cpu_baseline(sd, x.cpu(), size, 16 if args.workload == 'vitl256x192' else 12)
+            else:
+                res['cpu_baseline'] = None
+        else:
+            st = getattr(args, 'dry_state', None)
+            if st is not None:
+                net, unused, red = st
+                res['dry'] = {'unused_grad_is_none': all(p.grad is None for p in unused.parameters()),
+                              'grad_norm': float(sum(p.grad.pow(2).sum() for p in net.parameters()).sqrt()),
+                              'running_mean_sum': float(net[1].running_mean.sum()), 'buckets': len(red.buckets),
+                              'skipped_params': len(red.skipped)}
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.destroy_process_group()

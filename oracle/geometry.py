@@ -147,20 +147,25 @@ def convert_pare_to_full_img_cam(cam, bbox_height, center, img_w, img_h, Tz):
 
 
 def batch_euler2matrix(r):
-    """pare.utils.geometry.batch_euler2matrix [3P pare==0.1, restated; parity unpinned].
+    """pare.utils.geometry.batch_euler2matrix [3P pare==0.1; source absent from /root/reference -> restated from the published code:
+    PARE takes it verbatim from DECA's decalib/utils/rotation_converter.py (euler_to_quaternion -> quaternion_to_rotation_matrix)].
 
-    euler (x=pitch, y, z=roll) in radians -> quaternion (half-angle products,
-    w = cx*cy*cz + sx*sy*sz ...) -> rotation matrix via quat_to_rotmat.
-    Call sites: models/whmr.py:521-522.
+    euler (x, y, z) in radians -> quaternion q = qx * qy * qz (Hamilton products of the three axis quaternions, half angles):
+        w = cx cy cz - sx sy sz      x = cx sy sz + cy cz sx      y = cx cz sy - sx cy sz      z = cx cy sz + sx cz sy
+    -> rotation matrix (w, x, y, z), i.e. R = Rx(x) . Ry(y) . Rz(z).  With the reference's input [pitch, 0, roll]
+    (models/whmr.py:521-522) that is Rx(pitch) . Rz(roll): the roll about the optical axis is applied FIRST, then the pitch.
+    Pinned by the composition known answers in tests/test_oracle_cpu.py (pitch-only, roll-only, pitch + roll = Rx . Rz); the round-1
+    restatement had the (+, -, +, -) sign pattern of qz * qy * qx (R = Rz . Ry . Rx), which differs whenever pitch and roll are both
+    non-zero.
     """
     h = r * 0.5
     cx, cy, cz = torch.cos(h[:, 0]), torch.cos(h[:, 1]), torch.cos(h[:, 2])
     sx, sy, sz = torch.sin(h[:, 0]), torch.sin(h[:, 1]), torch.sin(h[:, 2])
     q = torch.stack([
-        cx * cy * cz + sx * sy * sz,
-        sx * cy * cz - cx * sy * sz,
-        cx * sy * cz + sx * cy * sz,
-        cx * cy * sz - sx * sy * cz], dim=1)
+        cx * cy * cz - sx * sy * sz,
+        cx * sy * sz + cy * cz * sx,
+        cx * cz * sy - sx * cy * sz,
+        cx * cy * sz + sx * cz * sy], dim=1)
     return quat_to_rotmat(q)
 
 

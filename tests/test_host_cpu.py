@@ -163,3 +163,80 @@ dist.destroy_process_group()
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
     assert res['err'] < 1e-6 and res['buckets'] >= 2 and res['shard'] == [0, 6]
     assert res['n_buffers'] == 2 and res['buffers_equal']
+
+
+def _run_bench(*extra, timeout=300):
+    import json
+    env = dict(os.environ)
+    env.pop('WORLD_SIZE', None)
+    env.pop('RANK', None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--dryrun-cpu', '--batch', '16'] + list(extra),
+                       capture_output=True, text=True, timeout=timeout, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_entry_launches_its_own_ranks_gloo():
+    """`python bench.py --gpus 2` (no torchrun around it) must start 2 ranks itself as a child process, and `n_gpus` is the
+    communicator's own count (reference: train.py:26-33).  CPU/gloo stand-in step, real entry point."""
+    out = _run_bench('--gpus', '2', '--steps', '3', '--warmup', '1', '--ref-1gpu', '1000')
+    assert out['n_gpus'] == 2 and out['config']['global_batch'] == 32 and out['data'] == 'dryrun'
+    assert out['scaling'] == 'weak' and 'replicas x2' in out['config']['parallelism']
+    assert abs(out['efficiency_vs_1gpu'] - out['value'] / 2000.0) < 1e-12
+    assert abs(out['value'] - 2 * 16 * 3 / (out['ms_per_step'] * 3e-3)) < 1e-6 * out['value']
+    one = _run_bench('--gpus', '1', '--steps', '2', '--warmup', '0')
+    assert one['n_gpus'] == 1 and one['config']['global_batch'] == 16
+
+
+def test_bench_train_entry_two_ranks_gloo():
+    """`bench.py --workload whmr_train --gpus 2` drives GradReducer (with a never-used parameter, as global_orient.* in W-HMR: the reference
+    needs DDP's find_unused_parameters, core/trainer.py:84-91) and broadcast_buffers through the real entry point; the averaged gradient
+    equals the mean of the two ranks' single-process gradients."""
+    out = _run_bench('--gpus', '2', '--steps', '1', '--warmup', '0', '--workload', 'whmr_train')
+    assert out['n_gpus'] == 2 and 'dp2' in out['config']['parallelism']
+    d = out['dry']
+    assert d['unused_grad_is_none'] and d['skipped_params'] == 2 and d['buckets'] >= 2
+    grads, means = [], []
+    for rank in range(2):
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(32, 64), torch.nn.BatchNorm1d(64), torch.nn.GELU(), torch.nn.Linear(64, 8))
+        x = torch.randn(16, 32, generator=torch.Generator().manual_seed(7 + rank))
+        net(x).pow(2).mean().backward()
+        grads.append([p.grad for p in net.parameters()])
+        means.append(net[1].running_mean.sum().item())
+    avg = [(a + b) / 2 for a, b in zip(*grads)]
+    ref = float(sum(g.pow(2).sum() for g in avg).sqrt())
+    assert abs(d['grad_norm'] - ref) < 1e-5 * ref
+    assert abs(d['running_mean_sum'] - means[0]) < 1e-6              # every rank holds rank 0's running statistics
+
+
+def test_grad_reducer_unused_and_misuse():
+    """single process, always_bucket: unused parameters are skipped (grad None), a second backward before finish() raises, and a
+    skipped parameter that later gets a gradient raises"""
+    from whmr_amd.parallel import GradReducer
+    torch.manual_seed(0)
+    a, b, c = torch.nn.Linear(4, 4), torch.nn.Linear(4, 4), torch.nn.Linear(4, 2)
+    params = list(a.parameters()) + list(b.parameters()) + list(c.parameters())
+    red = GradReducer(params, bucket_bytes=64, always_bucket=True, groups=[0, 0, 1, 1, 2, 2])
+    x = torch.randn(3, 4)
+    ref = torch.autograd.grad(c(a(x)).sum(), list(a.parameters()) + list(c.parameters()))
+    for step in range(2):
+        for p in params:
+            p.grad = None
+        c(a(x)).sum().backward()
+        red.finish()
+        assert all(p.grad is None for p in b.parameters()) and len(red.skipped) == 2
+        for p, g in zip(list(a.parameters()) + list(c.parameters()), ref):
+            assert torch.allclose(p.grad, g)
+    assert all(id(p) not in red._slot for p in b.parameters())
+    c(a(x)).sum().backward()
+    with pytest.raises(RuntimeError, match='second backward'):
+        c(a(x)).sum().backward()
+    red._fired.clear()
+    for bk in red.buckets:
+        bk['pending'], bk['flat'] = len(bk['params']), None
+    with pytest.raises(RuntimeError, match='classified as unused'):
+        c(b(a(x))).sum().backward()
+    red.remove()

@@ -82,6 +82,53 @@ def test_geometry_known_answers():
     assert torch.allclose(OG.batch_rodrigues(torch.zeros(1, 3)), torch.eye(3).unsqueeze(0), atol=1e-6)
 
 
+def _rx(a):
+    c, s = np.cos(a), np.sin(a)
+    return np.array([[1, 0, 0], [0, c, -s], [0, s, c]])
+
+
+def _ry(a):
+    c, s = np.cos(a), np.sin(a)
+    return np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])
+
+
+def _rz(a):
+    c, s = np.cos(a), np.sin(a)
+    return np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]])
+
+
+def _euler_cases():
+    return [(0.37, 0.0, 0.0), (0.0, 0.0, -0.52), (0.0, 0.41, 0.0), (0.37, 0.0, -0.52), (-0.6, 0.0, 0.6), (0.3, -0.2, 0.5)]
+
+
+def test_batch_euler2matrix_composition_order():
+    """pare.utils.geometry.batch_euler2matrix (3P, = DECA's euler_to_quaternion o quaternion_to_rotation_matrix): R = Rx(x) . Ry(y) . Rz(z).
+    The reference calls it with [pitch, 0, roll] (models/whmr.py:521-522): pitch-only = Rx, roll-only = Rz, both = Rx(pitch) . Rz(roll) --
+    NOT Rz . Rx (the two differ in the sign of q_y = -+ sx sz; VERDICT r1 weak #1)."""
+    from oracle import geometry as OG
+    e = torch.tensor(_euler_cases(), dtype=torch.float64)
+    R = OG.batch_euler2matrix(e).numpy()
+    for (x, y, z), r in zip(_euler_cases(), R):
+        assert np.allclose(r, _rx(x) @ _ry(y) @ _rz(z), atol=1e-12), (x, y, z)
+    both = OG.batch_euler2matrix(torch.tensor([[0.37, 0.0, -0.52]], dtype=torch.float64))[0].numpy()
+    assert np.allclose(both, _rx(0.37) @ _rz(-0.52), atol=1e-12)
+    assert np.abs(both - _rz(-0.52) @ _rx(0.37)).max() > 1e-2            # the other order is a different matrix
+    # the quaternion itself, component by component (the published formula)
+    h = e[3] / 2
+    cx, cy, cz, sx, sy, sz = torch.cos(h[0]), torch.cos(h[1]), torch.cos(h[2]), torch.sin(h[0]), torch.sin(h[1]), torch.sin(h[2])
+    q = torch.stack([cx * cy * cz - sx * sy * sz, cx * sy * sz + cy * cz * sx, cx * cz * sy - sx * cy * sz, cx * cy * sz + sx * cz * sy])
+    assert torch.allclose(OG.quat_to_rotmat(q[None]), torch.from_numpy(both)[None], atol=1e-12)
+
+
+def test_product_euler2matrix_matches_oracle():
+    """the device-side post-processing of cam_model uses the same tensor expression (pure torch, runs on CPU)"""
+    from oracle import geometry as OG
+    from whmr_amd.models.cam_model import batch_euler2matrix
+    e = torch.tensor(_euler_cases(), dtype=torch.float32)
+    assert torch.allclose(batch_euler2matrix(e), OG.batch_euler2matrix(e), atol=1e-6)
+    assert torch.allclose(batch_euler2matrix(e[3:4])[0].double(), torch.from_numpy(_rx(0.37) @ _rz(-0.52)), atol=1e-6)
+
+
 def test_smpl_known_answers(assets):
     """pins the un-vendored SMPL arithmetic analytically (SURVEY 8c): identity pose, rigid root rotation, single-joint rotation"""
     from oracle import geometry as OG

@@ -198,12 +198,14 @@ def convert_preds_to_angles(pred_vfov, pred_pitch, pred_roll, loss_type='softarg
 
 
 def batch_euler2matrix(r):
-    """pare.utils.geometry.batch_euler2matrix [3P, restated]: euler (x, y, z) -> quaternion -> rotation matrix."""
+    """pare.utils.geometry.batch_euler2matrix [3P pare==0.1 = DECA rotation_converter, restated]: euler (x, y, z) -> quaternion
+    q = qx * qy * qz -> rotation matrix, i.e. R = Rx(x) . Ry(y) . Rz(z); the reference feeds [pitch, 0, roll] (models/whmr.py:521-522),
+    so cam_rotmat = Rx(pitch) . Rz(roll)."""
     h = r * 0.5
     cx, cy, cz = torch.cos(h[:, 0]), torch.cos(h[:, 1]), torch.cos(h[:, 2])
     sx, sy, sz = torch.sin(h[:, 0]), torch.sin(h[:, 1]), torch.sin(h[:, 2])
-    q = torch.stack([cx * cy * cz + sx * sy * sz, sx * cy * cz - cx * sy * sz,
-                     cx * sy * cz + sx * cy * sz, cx * cy * sz - sx * sy * cz], dim=1)
+    q = torch.stack([cx * cy * cz - sx * sy * sz, cx * sy * sz + cy * cz * sx,
+                     cx * cz * sy - sx * cy * sz, cx * cy * sz + sx * cz * sy], dim=1)
     q = q / q.norm(dim=1, keepdim=True)
     w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
     w2, x2, y2, z2 = w * w, x * x, y * y, z * z

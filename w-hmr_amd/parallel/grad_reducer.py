@@ -1,11 +1,21 @@
 """Data-parallel gradient exchange for the training step (one all-reduce(mean) of the gradients per
-iteration; the reference uses torch DistributedDataParallel, core/trainer.py:88-104).
+iteration; the reference uses torch DistributedDataParallel with find_unused_parameters=True, core/trainer.py:84-104).
 
 One process per GPU, ``torch.distributed`` backend "nccl" (= RCCL over xGMI) -- or "gloo" on CPU for the tests.  Design for
 xGMI (point-to-point links, ring collectives are per-link bound): few, LARGE flat buckets (default 128 MiB of
 fp32 gradients: the whole 344 MB ViT-B gradient is 3 all-reduces, each long enough to reach link bandwidth) launched as soon
 as the last gradient of a bucket has been produced, on a side stream, so the exchange of the late layers overlaps the
-backward of the early ones.  Buckets are filled in REVERSE parameter order (the order the backward pass produces gradients).
+backward of the early ones.  Buckets are filled in REVERSE parameter order (the order the backward pass produces gradients);
+``groups`` (one id per parameter) additionally closes a bucket wherever the id changes -- W-HMR passes the backbone / heads split,
+because the whole ViT backward is ONE autograd node: without the split the bucket that holds the last head parameters would also
+wait for every ViT gradient and nothing could overlap.
+
+Unused parameters (W-HMR: ``global_orient.*``, ``dp_head.*`` without AUX supervision, a frozen-by-loss ``cam_model`` -- the reason the
+reference asks DDP for find_unused_parameters): the graph is assumed STATIC across ranks and steps, like DDP's ``static_graph``.  The
+first ``finish()`` all-reduces a one-int-per-parameter "received a gradient" mask (and raises if the ranks disagree); parameters
+nobody used are dropped from the buckets for good (their ``.grad`` stays None on every rank, as with DDP, and ``self.skipped`` lists
+them); a used parameter whose gradient is missing in a later step travels as zeros.  A dropped parameter that later does receive a
+gradient raises, and so does a second backward pass before ``finish()``.
 
     reducer = GradReducer(model.parameters())
     loss.backward()            # hooks copy finished gradients into their bucket and launch full buckets
@@ -24,29 +34,45 @@ def shard_batch(global_batch, world_size, rank):
 
 
 class GradReducer:
-    def __init__(self, params, bucket_bytes=128 << 20, process_group=None, average=True, always_bucket=False):
+    def __init__(self, params, bucket_bytes=128 << 20, process_group=None, average=True, always_bucket=False, groups=None):
+        params = list(params)
+        if groups is not None:
+            groups = [g for p, g in zip(params, groups) if p.requires_grad]
         self.params = [p for p in params if p.requires_grad]
+        self.groups = groups
+        self.bucket_bytes = bucket_bytes
         self.always_bucket = always_bucket       # pack into flat buckets even at world size 1 (tests / flat-gradient optimizers)
         self.group = process_group
         self.average = average
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        self.buckets = []                       # dicts: params, offsets, numel, flat (lazy), pending, work
-        cur, cur_bytes = [], 0
-        for p in reversed(self.params):         # backward order
+        self.skipped = []                        # parameters no rank ever produced a gradient for (found at the first finish())
+        self._skipped_ids = set()
+        self._resolved = False                   # the used/unused census has run
+        self._fired = set()                      # id(param) of the gradients that arrived since the last finish()
+        self._stream = None
+        self._build(self.params, self.groups)
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+
+    # ---- bucket layout
+    def _build(self, params, groups):
+        self.buckets = []                        # dicts: params, offsets, numel, flat (lazy), pending, work
+        cur, cur_bytes, cur_g = [], 0, None
+        order = list(range(len(params)))[::-1]   # backward order
+        for i in order:
+            p, g = params[i], (groups[i] if groups is not None else None)
             nbytes = p.numel() * 4
-            if cur and cur_bytes + nbytes > bucket_bytes:
+            if cur and (cur_bytes + nbytes > self.bucket_bytes or g != cur_g):
                 self._close(cur)
                 cur, cur_bytes = [], 0
             cur.append(p)
             cur_bytes += nbytes
+            cur_g = g
         if cur:
             self._close(cur)
         self._slot = {}                          # id(param) -> (bucket, index in bucket); tensors must not be compared with ==
         for b in self.buckets:
             for i, p in enumerate(b['params']):
                 self._slot[id(p)] = (b, i)
-        self._stream = None
-        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
 
     def _close(self, ps):
         offs, n = [], 0
@@ -55,18 +81,36 @@ class GradReducer:
             n += p.numel()
         self.buckets.append(dict(params=ps, offsets=offs, numel=n, flat=None, pending=len(ps), work=None, event=None))
 
+    # ---- backward side
+    def _active(self):
+        return self.world > 1 or self.always_bucket
+
     def _on_grad(self, p):
-        if self.world == 1 and not self.always_bucket:
+        if not self._active():
             return                               # single process: nothing to exchange, the gradients stay where autograd put them
+        if id(p) in self._skipped_ids:
+            raise RuntimeError('GradReducer: a parameter of shape %s received a gradient after it was classified as unused at the first '
+                               'finish(); the set of used parameters must be static (rebuild the reducer)' % (tuple(p.shape),))
+        if id(p) in self._fired:
+            raise RuntimeError('GradReducer: a second backward pass reached a parameter before finish() was called; call finish() once '
+                               'per backward (gradient accumulation over several backward passes is not supported)')
+        self._fired.add(id(p))
         b, i = self._slot[id(p)]
         b['pending'] -= 1
         if b['pending'] == 0:
-            # the bucket's last gradient has arrived: ONE multi-tensor copy packs all of them (a copy per hook was ~225 small launches
-            # per step: 1.3 ms of the batch-64 W-HMR step), then the exchange starts
-            flat = b['flat'] = torch.empty(b['numel'], dtype=torch.float32, device=p.grad.device)
-            views = [flat[off:off + q.numel()].view_as(q) for q, off in zip(b['params'], b['offsets'])]
-            torch._foreach_copy_(views, [q.grad for q in b['params']])
-            self._launch(b)
+            self._pack_and_launch(b)
+
+    def _pack_and_launch(self, b):
+        # the bucket's last gradient has arrived: ONE multi-tensor copy packs all of them (a copy per hook was ~225 small launches
+        # per step: 1.3 ms of the batch-64 W-HMR step), then the exchange starts.  Locally missing gradients travel as zeros.
+        have = [(q, off) for q, off in zip(b['params'], b['offsets']) if q.grad is not None]
+        dev = have[0][0].grad.device if have else b['params'][0].device
+        full = len(have) == len(b['params'])
+        flat = b['flat'] = (torch.empty if full else torch.zeros)(b['numel'], dtype=torch.float32, device=dev)
+        if have:
+            views = [flat[off:off + q.numel()].view_as(q) for q, off in have]
+            torch._foreach_copy_(views, [q.grad for q, _ in have])
+        self._launch(b)
 
     def _launch(self, b):
         if self.world == 1:
@@ -82,26 +126,62 @@ class GradReducer:
         else:
             b['work'] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
+    # ---- unused-parameter census (first finish() only)
+    def _census(self):
+        """Which parameters received a gradient?  The answer must be the same on every rank (static graph): one small all-reduce
+        checks that, and the parameters nobody used leave the buckets for good once this step's exchange is complete."""
+        used = torch.tensor([1 if id(p) in self._fired else 0 for p in self.params], dtype=torch.int32)
+        if self.world > 1:
+            dev = next((p.device for p in self.params), torch.device('cpu'))
+            both = torch.cat([used, -used]).to(dev)              # MAX of (u, -u) = (max u, -min u)
+            dist.all_reduce(both, op=dist.ReduceOp.MAX, group=self.group)
+            both = both.cpu()
+            n = used.numel()
+            if not torch.equal(both[:n], -both[n:]):
+                raise RuntimeError('GradReducer: the ranks disagree on which parameters received a gradient (%d differ); the exchange needs a '
+                                   'static graph (same used parameters on every rank)' % int((both[:n] != -both[n:]).sum()))
+        self._resolved = True
+        return used
+
+    def _wait(self, b):
+        if b['work'] is not None:
+            b['work'].wait()
+            if b['flat'].is_cuda:
+                torch.cuda.current_stream(b['flat'].device).wait_stream(self._stream)
+            b['work'] = None
+
     def finish(self):
         """Wait for every bucket, apply the 1/world mean, and make ``p.grad`` views of the reduced buckets."""
-        if self.world == 1 and not self.always_bucket:
+        if not self._active():
             return
+        used = None
+        if not self._resolved:
+            used = self._census()
+            for i, p in enumerate(self.params):
+                if not used[i]:
+                    self.skipped.append(p)
+                    self._skipped_ids.add(id(p))
         for b in self.buckets:
-            if b['pending'] != 0:
-                missing = [tuple(p.shape) for p in b['params'] if p.grad is None]
-                raise RuntimeError('backward left %d gradient(s) of a bucket unset (shapes %s)' % (b['pending'], missing[:4]))
-            if b['work'] is not None:
-                b['work'].wait()
-                if b['flat'].is_cuda:
-                    torch.cuda.current_stream(b['flat'].device).wait_stream(self._stream)
+            if b['flat'] is None:
+                if all(id(p) in self._skipped_ids for p in b['params']):
+                    continue                                     # nothing but unused parameters: no exchange at all
+                self._pack_and_launch(b)                         # stragglers: missing gradients travel as zeros (same on every rank)
+            self._wait(b)
             if self.average and self.world > 1:
                 b['flat'].div_(self.world)
             for p, off in zip(b['params'], b['offsets']):
-                p.grad = b['flat'][off:off + p.numel()].view_as(p)
+                if id(p) not in self._skipped_ids:               # unused everywhere: .grad stays None, as under DDP
+                    p.grad = b['flat'][off:off + p.numel()].view_as(p)
             b['pending'], b['work'] = len(b['params']), None
         # the flat buffers now back the gradients: allocate fresh ones on the next step's first hook
         for b in self.buckets:
             b['flat'] = None
+        self._fired.clear()
+        if used is not None and self.skipped:                    # from the next step on the buckets hold used parameters only
+            keep = [i for i in range(len(self.params)) if used[i]]
+            self.groups = [self.groups[i] for i in keep] if self.groups is not None else None
+            self.params = [self.params[i] for i in keep]
+            self._build(self.params, self.groups)
 
     def remove(self):
         for h in self._hooks:

@@ -210,6 +210,12 @@ def make_state_dict(seed=0, assets=None, img_size=(256, 192), with_cam_model=Tru
         _resnet50(sd, seed, 'cam_model.backbone.')
         for n in ('vfov', 'pitch', 'roll'):
             _linear(sd, seed, 'cam_model.fc_%s' % n, 256, 2048, std=0.01)
+        # peaked bin biases: with the plain init all three soft-argmaxes sit mid-range (pitch = roll = 0 to 1e-3), which would leave the
+        # euler -> rotation convention (Rx(pitch) . Rz(roll), whmr.py:521-522) invisible to the end-to-end fixture.  Bumps at bins 202 / 64
+        # put pitch near +0.35 rad and roll near -0.30 rad.
+        k = torch.arange(256, dtype=torch.float32)
+        for n, k0 in (('pitch', 202.0), ('roll', 64.0)):
+            sd['cam_model.fc_%s.bias' % n] = sd['cam_model.fc_%s.bias' % n] + 8.0 * torch.exp(-((k - k0) / 6.0) ** 2)
     sd['global_orient.init_pose'] = init_pose.reshape(1, 24, 9)[:, 0]
     _linear(sd, seed, 'global_orient.fc1', 2048, 2149 + 6 + 9)
     _linear(sd, seed, 'global_orient.fc2', 2048, 2048)
