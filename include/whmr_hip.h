@@ -61,6 +61,33 @@ int whmr_set_option(int key, int value);
 /* Same, K sliced over `splits` blocks per tile (fp32 partial sums in p->workspace, deterministic epilogue pass). */
 int whmr_gemm_bf16_split(const struct whmr_gemm* p, int tile, int splits, void* stream);
 
+/* ---- blocked-layout bf16 GEMM: the ViT's bf16 inference path (vit.py:61-140 qkv / proj / fc1 + GELU / fc2, vit.py:157 patch embed).
+ * A [R, C] matrix is stored as [ceil(R/32)][C/E][32][E], E = 8 (bf16) / 4 (fp32): 512-byte units of 32 rows x 16 bytes -- the unit a
+ * half-wave of an MFMA 32x32x16 operand fetch reads AND a half-wave of its (operand-swapped) result owns.  LDS-DMA staging copies whole
+ * units (no swizzle), the epilogue stores straight from the accumulators; two wave groups run in ping-pong (gemm_blk.hip). */
+struct whmr_gemm_blk_desc {
+    const void* A;        /* bf16 blocked [ceil(M/32)][K/8][32][8] */
+    const void* W;        /* bf16 blocked [N/32][K/8][32][8] (nn.Linear weight [N, K], packed once) */
+    void* C;              /* epi 0/1: bf16 blocked [ceil(M/32)][N/8][32][8]; epi 2/3: fp32 blocked [ceil(M/32)][N/4][32][4] */
+    const float* bias;    /* [N] or null */
+    const float* res;     /* epi 2: fp32 blocked like C (may alias C); epi 3: row-major [res_rows, N], row = m % res_rows (pos embed, vit.py:320) */
+    int32_t M, N, K;      /* N % 256 == 0, K % 32 == 0; buffers hold whole 32-row blocks */
+    int32_t epi;          /* 0: bf16(acc + bias); 1: bf16(gelu(acc + bias)); 2 / 3: fp32(acc + bias + res) */
+    int32_t res_rows;
+    int32_t tile;         /* 0 = chooser, else (MI0 << 4) | MI1 row blocks of the two wave rows: 0x44 = 256 x 256, 0x55 = 320, 0x43 = 224, ... */
+};
+int whmr_gemm_blk(const struct whmr_gemm_blk_desc* p, void* stream);
+int whmr_gemm_blk_tile(const struct whmr_gemm_blk_desc* p, int tile, void* stream);
+/* A/B switch: force a tile for the ViT-B shapes (slot 0 qkv N = 2304, 1 proj, 2 fc1 N = 3072, 3 fc2); 0 = chooser. */
+int whmr_gemm_blk_set_tile(int slot, int tile);
+/* LayerNorm on the blocked fp32 residual stream -> blocked bf16 GEMM operand (out_std 0) or row-major fp32 [rows, C] (out_std 1: last_norm). */
+int whmr_layernorm_blk(const float* x, const float* gamma, const float* beta, void* y, int rows, int C, float eps, int out_std, void* stream);
+/* PatchEmbed gather (vit.py:157,161) into the blocked bf16 operand layout. */
+int whmr_patch_im2col_blk(const float* x, void* cols, int B, int Cin, int H, int W, int P, int pad, long sb, long sc, long sh, long sw,
+                          void* stream);
+/* whmr_attention (bf16, d = 64, 64 < N <= 256) on blocked qkv [ceil(B*N/32)][3*H*8][32][8] -> blocked out [ceil(B*N/32)][H*8][32][8]. */
+int whmr_attention_blk(const void* qkv, void* out, int B, int N, int H, float scale, void* stream);
+
 /* exact-fp32 MFMA GEMM (v_mfma_f32_32x32x2_f32), any M/N/K.  Parity mode of the calls above, plus always:
  * Regressor fc1/fc2/decpose/decshape/deccam (whmr.py:118-126), Global_Orient_Regressor (whmr.py:295-301),
  * est_Tz linears (whmr.py:425-427), second Tz conv (whmr.py:420), the timm Block linears (whmr.py:423). */

@@ -1,0 +1,191 @@
+"""Blocked-layout kernels of the bf16 ViT inference path (csrc/gemm_blk.hip + blocked LayerNorm / attention / patch gather) against
+plain fp32 torch on the same inputs, and the blocked ViT forward against the row-major path and the reference fixture."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+TILES = [0x44, 0x55, 0x43, 0x33, 0x32, 0x22, 0x54]
+
+
+def _rel(a, b):
+    return ((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30)).item()
+
+
+def test_blocked_layout_round_trip(dev):
+    from whmr_amd import _lib as L
+    g = torch.Generator().manual_seed(0)
+    for dt, E in ((torch.bfloat16, 8), (torch.float32, 4)):
+        x = torch.randn(70, 64, generator=g).to(dt).to(dev)
+        xb = L.to_blocked(x)
+        assert xb.shape == (3, 64 // E, 32, E)
+        assert torch.equal(L.from_blocked(xb, 70), x)
+        # element (r, c) sits at [r // 32][c // E][r % 32][c % E]
+        assert xb[1, 3, 5, 2] == x[37, 3 * E + 2]
+
+
+@pytest.mark.parametrize('M,N,K', [(392, 768, 768), (1000, 256, 32), (1001, 512, 64), (777, 256, 96), (12544, 2304, 768), (3000, 768, 3072)])
+@pytest.mark.parametrize('tile', [0] + TILES)
+def test_gemm_blk(dev, M, N, K, tile):
+    """every epilogue x every tile: asymmetric random operands (a transposed C write cannot pass), M tails that end inside a tile and inside
+    a 32-row block, K of 1 / 2 / 3 half tiles (ring prologue edge cases) up to the ViT shapes"""
+    from whmr_amd import _lib as L
+    if M > 4000 and tile not in (0, 0x44, 0x43, 0x55):
+        pytest.skip('full-size shape: chooser + the tiles the ViT uses')
+    g = torch.Generator().manual_seed(M + N + K + tile)
+    a = torch.randn(M, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).bfloat16()
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    pos = torch.randn(196, N, generator=g)
+    ab, wb = L.to_blocked(a.to(dev)), L.to_blocked(w.to(dev))
+    nb = ab.shape[0]
+    lin = a.float() @ w.float().t() + bias
+    # epi 0: bf16(acc + bias)
+    out = torch.full((nb, N // 8, 32, 8), float('nan'), device=dev, dtype=torch.bfloat16)
+    L.gemm_blk(ab, wb, out, M, bias=bias.to(dev), epi=L.EPI_BF16, tile=tile)
+    assert _rel(L.from_blocked(out, M).float().cpu(), lin) < 1e-2
+    # no bias
+    L.gemm_blk(ab, wb, out, M, epi=L.EPI_BF16, tile=tile)
+    assert _rel(L.from_blocked(out, M).float().cpu(), a.float() @ w.float().t()) < 1e-2
+    # epi 1: bf16(gelu(acc + bias))  (polynomial GELU: <= 1.9e-4 absolute from the erf form)
+    L.gemm_blk(ab, wb, out, M, bias=bias.to(dev), epi=L.EPI_BF16_GELU, tile=tile)
+    assert _rel(L.from_blocked(out, M).float().cpu(), F.gelu(lin)) < 1e-2
+    # epi 2: fp32 acc + bias + blocked residual, in place
+    t = L.to_blocked(res.to(dev))
+    L.gemm_blk(ab, wb, t, M, bias=bias.to(dev), epi=L.EPI_F32_RES, res=t, tile=tile)
+    assert _rel(L.from_blocked(t, M).cpu(), lin + res) < 2e-5 * math.sqrt(K) / 8 + 1e-5
+    # epi 3: fp32 acc + bias + pos[m % 196] (row-major residual)
+    t2 = torch.full((nb, N // 4, 32, 4), float('nan'), device=dev)
+    L.gemm_blk(ab, wb, t2, M, bias=bias.to(dev), epi=L.EPI_F32_POS, res=pos.to(dev), res_rows=196, tile=tile)
+    assert _rel(L.from_blocked(t2, M).cpu(), lin + pos[torch.arange(M) % 196]) < 2e-5 * math.sqrt(K) / 8 + 1e-5
+
+
+def test_gemm_blk_matches_row_major_kernel_bitwise(dev):
+    """same MFMA instruction, same k order: the blocked kernel and the row-major kernel must agree bit for bit on an exact epilogue"""
+    from whmr_amd import _lib as L
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 1568, 768, 768
+    a = torch.randn(M, K, generator=g).bfloat16().to(dev)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).bfloat16().to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    res = torch.randn(M, N, generator=g).to(dev)
+    ref = torch.empty(M, N, device=dev)
+    L.gemm(a, w, ref, bias=bias, residual=res)
+    t = L.to_blocked(res)
+    L.gemm_blk(L.to_blocked(a), L.to_blocked(w), t, M, bias=bias, epi=L.EPI_F32_RES, res=t)
+    assert torch.equal(L.from_blocked(t, M), ref)
+
+
+@pytest.mark.parametrize('C', [768, 1024, 256])
+def test_layernorm_blk(dev, C):
+    from whmr_amd import _lib as L
+    g = torch.Generator().manual_seed(C)
+    rows = 391
+    x = torch.randn(rows, C, generator=g) * 3 + 0.5
+    w, b = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    ref = F.layer_norm(x, (C,), w, b, 1e-6)
+    xb = L.to_blocked(x.to(dev))
+    out = torch.empty(xb.shape[0], C // 8, 32, 8, device=dev, dtype=torch.bfloat16)
+    L.layernorm_blk(xb, w.to(dev), b.to(dev), out, rows, 1e-6)
+    assert _rel(L.from_blocked(out, rows).float().cpu(), ref) < 1e-2
+    std = torch.empty(rows, C, device=dev)
+    L.layernorm_blk(xb, w.to(dev), b.to(dev), std, rows, 1e-6, out_std=True)
+    assert _rel(std.cpu(), ref) < 2e-6
+    # against the row-major kernel: same two-pass statistics, different summation tree -> fp32 rounding only
+    rm = torch.empty(rows, C, device=dev)
+    L.layernorm(x.to(dev), w.to(dev), b.to(dev), rm, 1e-6)
+    assert _rel(std, rm) < 2e-6
+
+
+@pytest.mark.parametrize('N', [196, 192, 100, 256])
+def test_attention_blk(dev, N):
+    from whmr_amd import _lib as L
+    g = torch.Generator().manual_seed(N)
+    B, H, d = 3, 12, 64
+    qkv = (torch.randn(B, N, 3, H, d, generator=g) * 1.5).bfloat16()
+    q, k, v = qkv.float().permute(2, 0, 3, 1, 4)
+    ref = ((q * d ** -0.5) @ k.transpose(-2, -1)).softmax(-1) @ v
+    ref = ref.transpose(1, 2).reshape(B * N, H * d)
+    qb = L.to_blocked(qkv.view(B * N, 3 * H * d).to(dev))
+    out = torch.full((qb.shape[0], H * d // 8, 32, 8), float('nan'), device=dev, dtype=torch.bfloat16)
+    L.attention_blk(qb, out, B, N, H, d ** -0.5)
+    got = L.from_blocked(out, B * N)
+    assert _rel(got.float().cpu(), ref) < 2e-2
+    # identical arithmetic to the row-major chunked kernel
+    rm = torch.empty(B, N, H * d, device=dev, dtype=torch.bfloat16)
+    L.attention(qkv.to(dev).view(B, N, 3 * H * d), rm, B, N, H, d, d ** -0.5)
+    assert torch.equal(got, rm.view(B * N, H * d))
+
+
+def test_patch_im2col_blk(dev):
+    from whmr_amd import _lib as L
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(3, 3, 64, 80, generator=g)[:, :, :, 8:-8]             # sliced view like demo/tester.py:152
+    M = 3 * 4 * 4                                                        # 48 rows: the second 32-row block is half padding
+    out = torch.full(((M + 31) // 32, 768 // 8, 32, 8), float('nan'), device=dev, dtype=torch.bfloat16)
+    L.patch_im2col_blk(x.to(dev)[:, :, :, :], out, 16, 2)
+    ref = F.unfold(x, 16, padding=2, stride=16).transpose(1, 2).reshape(-1, 768).bfloat16()
+    assert torch.equal(L.from_blocked(out, M).cpu(), ref)
+    assert torch.equal(L.from_blocked(out, 64)[M:].cpu(), torch.zeros(64 - M, 768, dtype=torch.bfloat16))   # padding rows are zero, not garbage
+
+
+def _vit(sd, size, dev, blocked, dim=768, depth=12, heads=12):
+    from whmr_amd.models.pose_vit import ViT
+    m = ViT(img_size=size, patch_size=16, embed_dim=dim, depth=depth, num_heads=heads, ratio=1, mlp_ratio=4, qkv_bias=True, numerics='bf16')
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev).eval()
+    m.blocked = blocked
+    return m
+
+
+def test_vit_blocked_path_matches_row_major_path_and_fixture(dev):
+    """ViT-B/16 224^2 (BASELINE configs[1]) in bf16: the blocked pipeline against the row-major kernels (same arithmetic up to the fp32
+    summation order of LayerNorm) and against the reference fixture (fp32 CPU forward of the imported reference)."""
+    from oracle import synth
+    g = np.load(os.path.join(GOLDEN, 'vit224_b2.npz'))
+    sd = synth.make_vit_state(1, (224, 224))
+    x = torch.from_numpy(g['x']).to(dev)
+    ref = torch.from_numpy(g['s_feat'])
+    out_b = _vit(sd, (224, 224), dev, True)(x)
+    out_r = _vit(sd, (224, 224), dev, False)(x)
+    assert out_b.shape == (2, 768, 14, 14)
+    eb, er = _rel(out_b.cpu(), ref), _rel(out_r.cpu(), ref)
+    print('bf16 ViT vs fp32 reference fixture: blocked %.3e, row-major %.3e, blocked vs row-major %.3e' % (eb, er, _rel(out_b, out_r)))
+    assert eb < 5e-2 and er < 5e-2
+    assert _rel(out_b, out_r) < 2e-2
+
+
+def test_vit_blocked_256x192_and_large(dev):
+    """the other backbone shapes on the blocked path: 256x192 (N = 192 tokens, ref-native) and ViT-L (dim 1024, 16 heads, depth 2) vs the CPU oracle"""
+    from oracle import synth
+    from oracle.vit import vit_forward
+    for dim, depth, heads in ((768, 2, 12), (1024, 2, 16)):
+        sd = synth.make_vit_state(3, (256, 192), embed_dim=dim, depth=depth)
+        x = synth.make_inputs(3, 9, (256, 192))['x']
+        ref = vit_forward(sd, x, num_heads=heads)
+        out = _vit(sd, (256, 192), dev, True, dim, depth, heads)(x.to(dev))
+        assert out.shape == (3, dim, 16, 12)
+        assert _rel(out.cpu(), ref) < 5e-2, dim
+
+
+def test_vit_blocked_full_size_properties(dev):
+    """BASELINE batch-64 size: per-image independence on the blocked path, bit for bit (a batch of 64 == the same images in two halves;
+    the tile chooser picks different tile heights for M = 12544 and M = 6272) and the result is a fresh tensor per call"""
+    from oracle import synth
+    sd = synth.make_vit_state(1, (224, 224))
+    m = _vit(sd, (224, 224), dev, True)
+    x = synth.make_inputs(64, 3, (224, 224))['x'].to(dev)
+    full = m(x)
+    a = m(x[:32])
+    b = m(x[32:])
+    assert torch.equal(full, torch.cat([a, b]))
+    assert torch.isfinite(full).all()
+    assert full.data_ptr() != a.data_ptr() and a.data_ptr() != b.data_ptr()

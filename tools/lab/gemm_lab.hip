@@ -1,0 +1,493 @@
+// GEMM laboratory for the blocked-layout bf16 MFMA kernel (development aid; the product kernel lives in w-hmr_amd/csrc).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/lab/gemm_lab.hip -o tools/lab/gemm_lab && tools/lab/gemm_lab
+// Layouts ("blocked": 32 rows x 8 bf16 = 512 B contiguous, the unit both the MFMA operand fetch and the MFMA result own):
+//   A  [M/32][K/8][32][8] bf16      W  [N/32][K/8][32][8] bf16      C16 [M/32][N/8][32][8] bf16      C32 [M/32][N/4][32][4] fp32
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <vector>
+#include <algorithm>
+#include <type_traits>
+
+typedef uint16_t bf16_t;
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+typedef __bf16 bf16x2_native_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_native_t __attribute__((ext_vector_type(2)));
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    const bf16x2_native_t v = __builtin_convertvector((f32x2_native_t){lo, hi}, bf16x2_native_t);
+    return __builtin_bit_cast(uint32_t, v);
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void wait_lgkmcnt() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+template <int OFF> __device__ __forceinline__ bf16x8_t lds_read128(uint32_t addr) {
+    bf16x8_t v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+__device__ __forceinline__ uint64_t memtime() {
+    uint64_t t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+struct GemmP {
+    const bf16_t* A; const bf16_t* W; void* C; const float* bias; const float* res;
+    int M, N, K;
+    int tiles_m, tiles_n;
+    unsigned long long* ts;      // timestamps [block][wave][slot]
+    int abl;                     // ablation bits: 1 = no DMA in loop, 2 = no ds_read in loop, 4 = no MFMA, 8 = no epilogue stores
+};
+
+// VAR: 0 = 2 stages x BK 64, lock-step, DMA burst after the barrier
+//      1 = 4 half-stages x BK 32 ring, DMA 3 half-steps ahead
+//      2 = VAR 0 with two wave groups one barrier apart (group 1 = waves 4-7 lags by half a K step)
+// EPI: 0 = bf16 blocked out (+bias), 1 = bf16 + GELU, 2 = fp32 blocked out + bias + residual (in place)
+template <int BM, int VAR, int EPI, int TS>
+__global__ __launch_bounds__(512, 2) void gemm_blk_kernel(const GemmP p) {
+    constexpr int BN = 256, WTM = BM / 2, MI = WTM / 32, NJ = 2;
+    constexpr int MB = BM / 32;                       // A row blocks per tile
+    constexpr int A_BYTES = MB * 4096, B_BYTES = 8 * 4096, STAGE = A_BYTES + B_BYTES;      // BK = 64: 8 chunks x 512 B per row block
+    constexpr int UNITS = STAGE / 1024;               // 1-KiB DMA units per stage
+    constexpr int UPW = (UNITS + 7) / 8;              // units per wave
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int lid = xcd_remap(blockIdx.x, ntiles);
+    const int tm = lid / p.tiles_n, tn = lid % p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int KC = p.K >> 3;                          // 16-B chunks per row
+    const int nkt = p.K >> 6;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)smem;
+
+    // DMA source of unit u (wave-uniform part) + lane * 16: A units [0, MB*4), then B units
+    const char* usrc[UPW];
+#pragma unroll
+    for (int i = 0; i < UPW; ++i) {
+        const int u = wave + 8 * i;
+        if (u < MB * 4) {
+            int rb = (m0 >> 5) + (u >> 2);
+            const int rbmax = (p.M >> 5) - 1;
+            if (rb > rbmax) rb = rbmax;
+            usrc[i] = (const char*)p.A + ((size_t)rb * KC) * 512 + (u & 3) * 1024 + lane * 16;
+        } else {
+            const int v = u - MB * 4;
+            usrc[i] = (const char*)p.W + ((size_t)((n0 >> 5) + (v >> 2)) * KC) * 512 + (v & 3) * 1024 + lane * 16;
+        }
+    }
+    auto stage = [&](int kt, int s) {
+#pragma unroll
+        for (int i = 0; i < UPW; ++i) {
+            const int u = wave + 8 * i;
+            if (u < UNITS)
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)(usrc[i] + (size_t)kt * 4096), (lds_void_t*)(smem + s * STAGE + u * 1024), 16, 0, 0);
+        }
+    };
+    f32x16_t acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment addresses: A block (wm*MI + i), chunk kk*2 + hi, row l31;  B block (wn*2 + j)
+    const uint32_t a_base = lds0 + (wm * MI) * 4096 + hi * 512 + l31 * 16;
+    const uint32_t b_base = lds0 + A_BYTES + (wn * 2) * 4096 + hi * 512 + l31 * 16;
+    bf16x8_t af[2][MI], bfr[2][NJ];
+    auto load_frags = [&](int s, auto kk_tag, auto set_tag) {
+        constexpr int kk = decltype(kk_tag)::value, set = decltype(set_tag)::value;
+        const uint32_t sa = a_base + s * STAGE, sb = b_base + s * STAGE;
+        bfr[set][0] = lds_read128<kk * 1024>(sb);
+        bfr[set][1] = lds_read128<4096 + kk * 1024>(sb);
+        af[set][0] = lds_read128<kk * 1024>(sa);
+        if constexpr (MI > 1) af[set][1] = lds_read128<4096 + kk * 1024>(sa);
+        if constexpr (MI > 2) af[set][2] = lds_read128<8192 + kk * 1024>(sa);
+        if constexpr (MI > 3) af[set][3] = lds_read128<12288 + kk * 1024>(sa);
+        if constexpr (MI > 4) af[set][4] = lds_read128<16384 + kk * 1024>(sa);
+    };
+    auto mfmas = [&](auto set_tag) {
+        constexpr int set = decltype(set_tag)::value;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[set][j], af[set][i], acc[i][j], 0, 0, 0);
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    constexpr int NF = MI + NJ;
+    unsigned long long* ts = nullptr;
+    if constexpr (TS) ts = p.ts + ((size_t)blockIdx.x * 8 + wave) * 128;
+    int tsi = 0;
+    auto stamp = [&]() { if constexpr (TS) { if (lane == 0 && tsi < 128) ts[tsi] = memtime(); ++tsi; } };
+
+    const bool do_dma = !(p.abl & 1), do_lds = !(p.abl & 2), do_mfma = !(p.abl & 4);
+    stamp();
+    if constexpr (VAR == 0) {
+        stage(0, 0);
+        for (int kt = 0; kt < nkt; ++kt) {
+            stamp();                                   // t0: about to wait for this stage
+            wait_vmcnt<0>();
+            stamp();                                   // t1: own DMAs landed
+            __builtin_amdgcn_s_barrier();
+            stamp();                                   // t2: barrier passed
+            if (kt + 1 < nkt && do_dma) stage(kt + 1, (kt + 1) & 1);
+            stamp();                                   // t3: DMA issued
+            const int s = kt & 1;
+            if (do_lds) load_frags(s, I0{}, I0{});
+            if (do_lds) load_frags(s, I1{}, I1{});
+            if (do_lds) wait_lgkmcnt<NF>();
+            __builtin_amdgcn_sched_barrier(0);
+            stamp();                                   // t4: first fragments in registers
+            if (do_mfma) mfmas(I0{});
+            __builtin_amdgcn_sched_barrier(0);
+            if (do_lds) load_frags(s, I2{}, I0{});
+            if (do_lds) wait_lgkmcnt<NF>();
+            __builtin_amdgcn_sched_barrier(0);
+            if (do_mfma) mfmas(I1{});
+            __builtin_amdgcn_sched_barrier(0);
+            if (do_lds) load_frags(s, I3{}, I1{});
+            if (do_lds) wait_lgkmcnt<NF>();
+            __builtin_amdgcn_sched_barrier(0);
+            if (do_mfma) mfmas(I0{});
+            __builtin_amdgcn_sched_barrier(0);
+            if (do_lds) wait_lgkmcnt<0>();
+            __builtin_amdgcn_sched_barrier(0);
+            if (do_mfma) mfmas(I1{});
+            __builtin_amdgcn_sched_barrier(0);
+            stamp();                                   // t5: all MFMAs of the step issued
+        }
+    }
+    if constexpr (VAR == 2) {
+        // ---- two wave groups (G0 = waves 0-3 = wave row 0, G1 = waves 4-7; one wave of each per SIMD) one barrier apart.  Unit of work = a
+        // half K tile (32 deep): MEM(h) = read this wave's 12 fragments of half tile h + issue its share of the DMA for half tile h+3
+        // (ring of 4 half-stage slots) ; MFMA(h) = 16 MFMAs straight from registers.  While G0 is in MFMA(h), G1 is in MEM(h) and vice versa,
+        // so on every SIMD one wave feeds the matrix pipe while the other one talks to LDS / the texture addresser.
+        constexpr int SLOT = (MB + 8) * 2048, HU = (MB + 8) * 2, HUPW = HU / 8;
+        static_assert(HU % 8 == 0, "every wave must issue the same number of DMA units (counted vmcnt)");
+        const int H = p.K >> 5;
+        const char* hsrc[HUPW];
+#pragma unroll
+        for (int i = 0; i < HUPW; ++i) {
+            const int u = wave + 8 * i, b = u >> 1, half = u & 1;
+            if (b < MB) {
+                int rb = (m0 >> 5) + b;
+                const int rbmax = (p.M >> 5) - 1;
+                if (rb > rbmax) rb = rbmax;
+                hsrc[i] = (const char*)p.A + ((size_t)rb * KC) * 512 + half * 1024 + lane * 16;
+            } else {
+                hsrc[i] = (const char*)p.W + ((size_t)((n0 >> 5) + b - MB) * KC) * 512 + half * 1024 + lane * 16;
+            }
+        }
+        auto hstage = [&](int h) {
+            const int slot = h & 3;
+#pragma unroll
+            for (int i = 0; i < HUPW; ++i)
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)(hsrc[i] + (size_t)h * 2048), (lds_void_t*)(smem + slot * SLOT + (wave + 8 * i) * 1024), 16, 0, 0);
+        };
+        const uint32_t a_b2 = lds0 + (wm * MI) * 2048 + hi * 512 + l31 * 16;
+        const uint32_t b_b2 = lds0 + (MB + wn * 2) * 2048 + hi * 512 + l31 * 16;
+        bf16x8_t fa[MI][2], fb[NJ][2];
+        hstage(0);
+        if (H > 1) hstage(1);
+        if (H > 2) hstage(2);
+        if (H > 2) wait_vmcnt<2 * HUPW>(); else if (H > 1) wait_vmcnt<HUPW>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (wm == 1) __builtin_amdgcn_s_barrier();                 // G1 runs one barrier behind
+        for (int h = 0; h < H; ++h) {
+            stamp();
+            // MEM(h)
+            const uint32_t sa = a_b2 + (h & 3) * SLOT, sb = b_b2 + (h & 3) * SLOT;
+            if (do_lds) {
+                fb[0][0] = lds_read128<0>(sb); fb[1][0] = lds_read128<2048>(sb);
+                fa[0][0] = lds_read128<0>(sa);
+                if constexpr (MI > 1) fa[1][0] = lds_read128<2048>(sa);
+                if constexpr (MI > 2) fa[2][0] = lds_read128<4096>(sa);
+                if constexpr (MI > 3) fa[3][0] = lds_read128<6144>(sa);
+                fb[0][1] = lds_read128<1024>(sb); fb[1][1] = lds_read128<2048 + 1024>(sb);
+                fa[0][1] = lds_read128<1024>(sa);
+                if constexpr (MI > 1) fa[1][1] = lds_read128<2048 + 1024>(sa);
+                if constexpr (MI > 2) fa[2][1] = lds_read128<4096 + 1024>(sa);
+                if constexpr (MI > 3) fa[3][1] = lds_read128<6144 + 1024>(sa);
+            }
+            if (h + 3 < H && do_dma) hstage(h + 3);
+            // own DMA of half tile h+1 must have landed: younger groups in flight = half tiles h+2, h+3 (as far as they exist)
+            if (h + 3 < H) wait_vmcnt<2 * HUPW>(); else if (h + 2 < H) wait_vmcnt<HUPW>(); else wait_vmcnt<0>();
+            stamp();
+            wait_lgkmcnt<0>();
+            stamp();
+            if (!(p.abl & 16)) __builtin_amdgcn_s_barrier();
+            stamp();
+            __builtin_amdgcn_sched_barrier(0);
+            // MFMA(h)
+            __builtin_amdgcn_s_setprio(1);
+            if (do_mfma) {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j][kk], fa[i][kk], acc[i][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            stamp();
+            if (!(p.abl & 16)) __builtin_amdgcn_s_barrier();
+        }
+    }
+    stamp();
+    // ---- epilogue: straight from the accumulators, coalesced 1-KiB wave stores into the blocked layouts
+    if (p.abl & 8) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+        if (t == 12345.678f) ((float*)p.C)[0] = t;
+        if constexpr (VAR == 2) { if (wm == 0) __builtin_amdgcn_s_barrier(); }
+        return;
+    }
+    const int nb0 = n0 + wn * 64;
+    if constexpr (EPI == 0 || EPI == 1) {
+        const int NC8 = p.N >> 3;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            float4 bq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bq[q] = p.bias ? *(const float4*)(p.bias + nb0 + j * 32 + 8 * q + 4 * hi) : make_float4(0, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int m = m0 + wm * WTM + i * 32;              // row block base (multiple of 32)
+                if (m >= p.M) continue;
+                uint32_t pk[4][2];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v0 = acc[i][j][4 * q] + bq[q].x, v1 = acc[i][j][4 * q + 1] + bq[q].y, v2 = acc[i][j][4 * q + 2] + bq[q].z, v3 = acc[i][j][4 * q + 3] + bq[q].w;
+                    if constexpr (EPI == 1) {
+                        auto g = [](float x) { const float s = __builtin_amdgcn_fmed3f(x, -4.0f, 4.0f), t = s * s;
+                            float r = fmaf(t, 2.258814658e-08f, -1.588823733e-06f); r = fmaf(r, t, 4.776381398e-05f); r = fmaf(r, t, -8.121867222e-04f);
+                            r = fmaf(r, t, 8.763687250e-03f); r = fmaf(r, t, -6.455440501e-02f); r = fmaf(r, t, 3.978702657e-01f); return x * fmaf(s, r, 0.5f); };
+                        v0 = g(v0); v1 = g(v1); v2 = g(v2); v3 = g(v3);
+                    }
+                    pk[q][0] = pack_bf16x2(v0, v1); pk[q][1] = pack_bf16x2(v2, v3);
+                }
+                char* rowp = (char*)p.C + ((size_t)(m >> 5) * NC8 + ((nb0 + j * 32) >> 3)) * 512 + l31 * 16;
+#pragma unroll
+                for (int q = 0; q < 4; q += 2) {
+                    auto r0 = __builtin_amdgcn_permlane32_swap(pk[q][0], pk[q + 1][0], false, false);
+                    auto r1 = __builtin_amdgcn_permlane32_swap(pk[q][1], pk[q + 1][1], false, false);
+                    // lanes 0-31: cols 8q..8q+7 (block q); lanes 32-63: cols 8(q+1).. (block q+1)
+                    *(uint4*)(rowp + (q + hi) * 512) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+                }
+            }
+        }
+    } else {
+        const int NC4 = p.N >> 2;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            float4 bq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bq[q] = p.bias ? *(const float4*)(p.bias + nb0 + j * 32 + 8 * q + 4 * hi) : make_float4(0, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int m = m0 + wm * WTM + i * 32;
+                if (m >= p.M) continue;
+                const size_t off = ((size_t)(m >> 5) * NC4 + ((nb0 + j * 32) >> 2) + hi) * 512 + l31 * 16;
+                float4 rv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rv[q] = *(const float4*)((const char*)p.res + off + q * 1024);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float4 o;
+                    o.x = acc[i][j][4 * q] + bq[q].x + rv[q].x; o.y = acc[i][j][4 * q + 1] + bq[q].y + rv[q].y;
+                    o.z = acc[i][j][4 * q + 2] + bq[q].z + rv[q].z; o.w = acc[i][j][4 * q + 3] + bq[q].w + rv[q].w;
+                    *(float4*)((char*)p.C + off + q * 1024) = o;
+                }
+            }
+        }
+    }
+    stamp();
+    if constexpr (VAR == 2) { if (wm == 0) __builtin_amdgcn_s_barrier(); }      // G0's count catches up with G1's extra barrier
+}
+
+// ------------------------------------------------------------------------------------------------ host
+static inline bf16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fff + ((u >> 16) & 1); return (bf16_t)(u >> 16); }
+static inline float bf2f(bf16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; }
+static size_t blk16(int r, int c, int C) { return ((size_t)(r >> 5) * (C >> 3) + (c >> 3)) * 256 + (r & 31) * 8 + (c & 7); }   // element index
+static size_t blk32(int r, int c, int C) { return ((size_t)(r >> 5) * (C >> 2) + (c >> 2)) * 128 + (r & 31) * 4 + (c & 3); }
+
+struct Shape { const char* name; int N, K, epi; };
+
+template <int BM, int VAR, int EPI, int TS>
+static void launch(const GemmP& p, hipStream_t st) {
+    constexpr int STAGE = (BM / 32 + 8) * 4096;
+    auto kern = gemm_blk_kernel<BM, VAR, EPI, TS>;
+    static bool done = false;
+    if (!done) { CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE)); done = true; }
+    GemmP q = p;
+    q.tiles_m = (p.M + BM - 1) / BM; q.tiles_n = p.N / 256;
+    hipLaunchKernelGGL(kern, dim3(q.tiles_m * q.tiles_n), dim3(512), 2 * STAGE, st, q);
+}
+
+template <int BM, int VAR, int TS>
+static void launch_epi(const GemmP& p, int epi, hipStream_t st) {
+    if (epi == 0) launch<BM, VAR, 0, TS>(p, st);
+    else if (epi == 1) launch<BM, VAR, 1, TS>(p, st);
+    else launch<BM, VAR, 2, TS>(p, st);
+}
+
+static void launch_any(const GemmP& p, int bm, int var, int epi, hipStream_t st) {
+    if (var == 0) {
+        if (bm == 256) launch_epi<256, 0, 0>(p, epi, st);
+        else if (bm == 192) launch_epi<192, 0, 0>(p, epi, st);
+        else if (bm == 320) launch_epi<320, 0, 0>(p, epi, st);
+        else if (bm == 128) launch_epi<128, 0, 0>(p, epi, st);
+    } else if (var == 2) {
+        if (bm == 256) launch_epi<256, 2, 0>(p, epi, st);
+        else if (bm == 128) launch_epi<128, 2, 0>(p, epi, st);
+    }
+}
+
+int main(int argc, char** argv) {
+    const int M = 12544;
+    const Shape shapes[] = {{"qkv", 2304, 768, 0}, {"proj", 768, 768, 2}, {"fc1", 3072, 768, 1}, {"fc2", 768, 3072, 2}};
+    hipStream_t st; CK(hipStreamCreate(&st));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    srand(1);
+    // operands: max sizes
+    const size_t maxA = (size_t)M * 3072, maxW = (size_t)3072 * 3072, maxC = (size_t)M * 3072;
+    std::vector<bf16_t> hA(maxA), hW(maxW);
+    const bool zero_fill = argc > 1 && !strcmp(argv[1], "zero");
+    for (auto& v : hA) v = zero_fill ? 0 : f2bf((float)rand() / RAND_MAX * 2.f - 1.f);
+    for (auto& v : hW) v = zero_fill ? 0 : f2bf(((float)rand() / RAND_MAX * 2.f - 1.f) * 0.05f);
+    std::vector<float> hB(3072), hR((size_t)M * 768);
+    for (auto& v : hB) v = (float)rand() / RAND_MAX - 0.5f;
+    for (auto& v : hR) v = (float)rand() / RAND_MAX - 0.5f;
+    bf16_t *dA, *dW; void* dC; float *dB, *dR; unsigned long long* dTs;
+    CK(hipMalloc(&dA, maxA * 2)); CK(hipMalloc(&dW, maxW * 2)); CK(hipMalloc(&dC, maxC * 4)); CK(hipMalloc(&dB, 3072 * 4)); CK(hipMalloc(&dR, (size_t)M * 768 * 4));
+    CK(hipMalloc(&dTs, (size_t)1024 * 8 * 128 * 8));
+    CK(hipMemcpy(dA, hA.data(), maxA * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dW, hW.data(), maxW * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dB, hB.data(), 3072 * 4, hipMemcpyHostToDevice));
+
+    auto timeit = [&](auto fn, int n = 20, int w = 3) {
+        for (int i = 0; i < w; ++i) fn();
+        CK(hipStreamSynchronize(st));
+        CK(hipEventRecord(e0, st));
+        for (int i = 0; i < n; ++i) fn();
+        CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        return ms / n * 1e3f;
+    };
+
+    if (argc > 1 && !strcmp(argv[1], "dbg")) {
+        // element-wise comparison of VAR 2 against VAR 0 (qkv shape): where do they differ?
+        const int N = 2304, K = argc > 2 ? atoi(argv[2]) : 768;
+        GemmP p{}; p.A = dA; p.W = dW; p.C = dC; p.bias = dB; p.M = M; p.N = N; p.K = K; p.ts = dTs;
+        std::vector<bf16_t> c0((size_t)M * N), c2((size_t)M * N);
+        launch_any(p, 256, 0, 0, st); CK(hipStreamSynchronize(st)); CK(hipMemcpy(c0.data(), dC, c0.size() * 2, hipMemcpyDeviceToHost));
+        CK(hipMemset(dC, 0xff, c0.size() * 2));
+        launch_any(p, 256, 2, 0, st); CK(hipStreamSynchronize(st)); CK(hipMemcpy(c2.data(), dC, c2.size() * 2, hipMemcpyDeviceToHost));
+        long bad = 0; long byblk[8][8] = {};
+        for (int r = 0; r < M; ++r) for (int c = 0; c < N; ++c) {
+            const float a = bf2f(c0[blk16(r, c, N)]), b = bf2f(c2[blk16(r, c, N)]);
+            if (!(fabs(a - b) <= 0.02 * (fabs(a) + 0.1))) { ++bad; ++byblk[(r % 256) / 32][(c % 256) / 32]; }
+        }
+        printf("K=%d mismatches %ld of %ld\n", K, bad, (long)M * N);
+        for (int i = 0; i < 8; ++i) { for (int j = 0; j < 8; ++j) printf("%8ld", byblk[i][j]); printf("\n"); }
+        return 0;
+    }
+    struct Cfg { int var, bm; };
+    const Cfg cfgs[] = {{0, 256}, {0, 320}, {2, 256}};
+    // ---- correctness: sampled outputs vs a host fp64 dot product on the blocked data
+    for (const Shape& s : shapes) {
+        for (const Cfg& c : cfgs) {
+            GemmP p{}; p.A = dA; p.W = dW; p.C = dC; p.bias = dB; p.res = (const float*)dC; p.M = M; p.N = s.N; p.K = s.K; p.ts = dTs;
+            if (s.epi == 2) CK(hipMemcpy(dC, hR.data(), (size_t)M * 768 * 4, hipMemcpyHostToDevice));
+            else CK(hipMemset(dC, 0xff, (size_t)M * s.N * 2));
+            launch_any(p, c.bm, c.var, s.epi, st);
+            CK(hipStreamSynchronize(st)); CK(hipGetLastError());
+            std::vector<char> hC((size_t)M * s.N * (s.epi == 2 ? 4 : 2));
+            CK(hipMemcpy(hC.data(), dC, hC.size(), hipMemcpyDeviceToHost));
+            double worst = 0;
+            for (int t = 0; t < 600; ++t) {
+                const int r = (t < 8) ? (t < 4 ? t : M - 1 - (t - 4)) : rand() % M, cc = (t < 8) ? ((t * 37) % s.N) : rand() % s.N;
+                double ref = hB[cc];
+                for (int k = 0; k < s.K; ++k) ref += (double)bf2f(hA[blk16(r, k, s.K)]) * (double)bf2f(hW[blk16(cc, k, s.K)]);
+                double got;
+                if (s.epi == 2) { ref += hR[blk32(r, cc, s.N)]; got = ((float*)hC.data())[blk32(r, cc, s.N)]; }
+                else {
+                    if (s.epi == 1) ref = 0.5 * ref * (1.0 + erf(ref * 0.7071067811865476));
+                    got = bf2f(((bf16_t*)hC.data())[blk16(r, cc, s.N)]);
+                }
+                const double e = fabs(got - ref) / (fabs(ref) + 0.05);
+                worst = std::max(worst, e == e ? e : 1e9);
+            }
+            printf("check %-4s var %d BM %3d: worst rel err %.3e %s\n", s.name, c.var, c.bm, worst, worst < 2e-2 ? "ok" : "FAIL");
+        }
+    }
+
+    // ---- timing: per shape x tile x ablation
+    for (const Shape& s : shapes) {
+        const double gf = 2.0 * M * s.N * s.K / 1e6;
+        for (const Cfg& c : cfgs) {
+            GemmP p{}; p.A = dA; p.W = dW; p.C = dC; p.bias = dB; p.res = (const float*)dC; p.M = M; p.N = s.N; p.K = s.K; p.ts = dTs;
+            float t[7]; const int abls[7] = {0, 8, 8 | 1, 8 | 2, 8 | 1 | 2, 8 | 4, 8 | 1 | 2 | 16};
+            for (int a = 0; a < 7; ++a) t[a] = 1e9f;
+            for (int rnd = 0; rnd < 3; ++rnd)
+                for (int a = 0; a < 7; ++a) { p.abl = abls[a]; t[a] = std::min(t[a], timeit([&] { launch_any(p, c.bm, c.var, s.epi, st); }, 10, 2)); }
+            printf("%-4s var %d BM %3d tiles %4d: full %6.1f us %5.0f TF | mainloop %6.1f (%5.0f TF) | -dma %6.1f | -lds %6.1f | mfma only %6.1f (%5.0f TF) | no mfma %6.1f | mfma no barrier %6.1f (%5.0f TF)\n", s.name, c.var, c.bm,
+                   ((M + c.bm - 1) / c.bm) * (s.N / 256), t[0], gf / t[0], t[1], gf / t[1], t[2], t[3], t[4], gf / t[4], t[5], t[6], gf / t[6]);
+        }
+    }
+
+    // ---- timestamps of one launch (qkv, 256)
+    {
+        GemmP p{}; p.A = dA; p.W = dW; p.C = dC; p.bias = dB; p.M = M; p.N = 2304; p.K = 768; p.ts = dTs;
+        for (int rep = 0; rep < 3; ++rep) launch<256, 0, 0, 1>(p, st);
+        CK(hipStreamSynchronize(st));
+        std::vector<unsigned long long> h((size_t)441 * 8 * 128);
+        CK(hipMemcpy(h.data(), dTs, h.size() * 8, hipMemcpyDeviceToHost));
+        for (int blk : {0, 300}) for (int w : {0, 4}) {
+            const unsigned long long* t = h.data() + ((size_t)blk * 8 + w) * 128;
+            printf("var 0 block %3d wave %d: start->first-step %llu clk;", blk, w, t[1] - t[0]);
+            double d[5] = {0, 0, 0, 0, 0};
+            for (int kt = 0; kt < 12; ++kt) { const unsigned long long* q = t + 1 + kt * 6; for (int i = 0; i < 5; ++i) d[i] += (double)(q[i + 1] - q[i]); }
+            printf(" per K step: vmcnt-wait %.0f  barrier %.0f  dma-issue %.0f  frag-wait %.0f  mfma-issue %.0f  (sum %.0f);", d[0] / 12, d[1] / 12, d[2] / 12, d[3] / 12, d[4] / 12,
+                   (d[0] + d[1] + d[2] + d[3] + d[4]) / 12);
+            printf(" epilogue %llu clk, total %llu clk\n", t[1 + 72 + 1] - t[1 + 72], t[1 + 72 + 1] - t[0]);
+        }
+        for (int rep = 0; rep < 3; ++rep) launch<256, 2, 0, 1>(p, st);
+        CK(hipStreamSynchronize(st));
+        CK(hipMemcpy(h.data(), dTs, h.size() * 8, hipMemcpyDeviceToHost));
+        for (int blk : {0, 300}) for (int w : {0, 4}) {
+            const unsigned long long* t = h.data() + ((size_t)blk * 8 + w) * 128;
+            printf("var 2 block %3d wave %d: start->loop %llu clk;", blk, w, t[1] - t[0]);
+            double d[5] = {0, 0, 0, 0, 0};
+            const int H = 24;
+            for (int hh = 0; hh < H; ++hh) { const unsigned long long* q = t + 1 + hh * 5; for (int i = 0; i < 4; ++i) d[i] += (double)(q[i + 1] - q[i]); if (hh + 1 < H) d[4] += (double)(q[5] - q[4]); }
+            printf(" per half K tile: reads+dma+vmcnt %.0f  lgkm-wait %.0f  barrier %.0f  mfma-issue %.0f  end-barrier %.0f  (sum %.0f);", d[0] / H, d[1] / H, d[2] / H, d[3] / H, d[4] / (H - 1),
+                   (d[0] + d[1] + d[2] + d[3]) / H + d[4] / (H - 1));
+            printf(" epilogue %llu clk, total %llu clk\n", t[1 + 5 * H + 1] - t[1 + 5 * H], t[1 + 5 * H + 1] - t[0]);
+        }
+    }
+    return 0;
+}

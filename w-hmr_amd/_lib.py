@@ -28,6 +28,12 @@ class WhmrGemm(C.Structure):
                 ('phase_w_stride', C.c_int64), ('phase_cy', C.c_int64), ('phase_cx', C.c_int64), ('split_k', C.c_int64)]
 
 
+class WhmrGemmBlk(C.Structure):
+    """struct whmr_gemm_blk_desc (include/whmr_hip.h): blocked-layout bf16 GEMM of the ViT inference path"""
+    _fields_ = [('A', C.c_void_p), ('W', C.c_void_p), ('C', C.c_void_p), ('bias', C.c_void_p), ('res', C.c_void_p),
+                ('M', C.c_int32), ('N', C.c_int32), ('K', C.c_int32), ('epi', C.c_int32), ('res_rows', C.c_int32), ('tile', C.c_int32)]
+
+
 class WhmrSmplModel(C.Structure):
     _fields_ = [('v_template', C.c_void_p), ('shapedirs', C.c_void_p), ('posedirs', C.c_void_p),
                 ('lbs_weights', C.c_void_p), ('J_template', C.c_void_p), ('J_shapedirs', C.c_void_p),
@@ -48,6 +54,12 @@ _SIGS = {
     'whmr_gemm_bf16_big': [C.POINTER(WhmrGemm), _I, _P],
     'whmr_gemm_bf16_split': [C.POINTER(WhmrGemm), _I, _I, _P],
     'whmr_set_option': [_I, _I],
+    'whmr_gemm_blk': [C.POINTER(WhmrGemmBlk), _P],
+    'whmr_gemm_blk_tile': [C.POINTER(WhmrGemmBlk), _I, _P],
+    'whmr_gemm_blk_set_tile': [_I, _I],
+    'whmr_layernorm_blk': [_P, _P, _P, _P, _I, _I, _F, _I, _P],
+    'whmr_patch_im2col_blk': [_P, _P, _I, _I, _I, _I, _I, _I, _L, _L, _L, _L, _P],
+    'whmr_attention_blk': [_P, _P, _I, _I, _I, _F, _P],
     'whmr_attention_set_variant': [_I],
     'whmr_layernorm': [_P, _P, _P, _P, _I, _I, _F, _I, _P],
     'whmr_patch_im2col': [_P, _P, _I, _I, _I, _I, _I, _I, _L, _L, _L, _L, _I, _P],
@@ -221,6 +233,83 @@ def gemm(a, w, out, bias=None, residual=None, res_row_mod=0, act=ACT_NONE, conv=
         PROFILE.append(('gemm_bf16' if a.dtype == torch.bfloat16 else 'gemm_f32', 2.0 * p.M * p.N * p.K * max(1, p.n_phase), e0, e1))
         return out
     _check(fn(C.byref(p), 0 if glds else 1, _stream()), 'whmr_gemm')
+    return out
+
+
+# ---- blocked layouts (gemm_blk.hip): [R, C] stored as [ceil(R/32)][C/E][32][E], E = 8 (bf16) / 4 (fp32) -----------------------------
+EPI_BF16, EPI_BF16_GELU, EPI_F32_RES, EPI_F32_POS = 0, 1, 2, 3
+
+
+def to_blocked(t):
+    """row-major [R, C] (bf16 or fp32) -> blocked copy (rows padded to a multiple of 32 with zeros).  Host-side packing of weights / test data."""
+    _dev(t)
+    R, Cc = t.shape
+    E = 8 if t.dtype == torch.bfloat16 else 4
+    assert t.dtype in (torch.bfloat16, torch.float32) and Cc % E == 0
+    Rp = (R + 31) // 32 * 32
+    if Rp != R:
+        t = torch.cat([t, t.new_zeros(Rp - R, Cc)], 0)
+    return t.reshape(Rp // 32, 32, Cc // E, E).permute(0, 2, 1, 3).contiguous()
+
+
+def from_blocked(t, R):
+    """blocked [R/32][C/E][32][E] -> row-major [R, C] copy (tests / hand-over to row-major consumers)"""
+    nb, nu, _, E = t.shape
+    return t.permute(0, 2, 1, 3).reshape(nb * 32, nu * E)[:R].contiguous()
+
+
+def gemm_blk(a, w, out, M, bias=None, epi=EPI_BF16, res=None, res_rows=0, tile=0):
+    """out = epi(a . w^T + bias [+ res]) on blocked operands: a [M/32][K/8][32][8] bf16, w [N/32][K/8][32][8] bf16,
+    out bf16 [M/32][N/8][32][8] (epi 0/1) or fp32 [M/32][N/4][32][4] (epi 2: + blocked res, may be `out`; epi 3: + res[m % res_rows] row-major)."""
+    _dev(a, w, out, bias, res)
+    assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and a.is_contiguous() and w.is_contiguous() and out.is_contiguous()
+    N, K = w.shape[0] * 32, w.shape[1] * 8
+    assert a.shape[1] * 8 == K and a.shape[0] * 32 >= M and out.shape[0] * 32 >= M
+    assert out.dtype == (torch.float32 if epi >= 2 else torch.bfloat16) and out.shape[1] * out.shape[3] == N
+    p = WhmrGemmBlk()
+    p.A, p.W, p.C = a.data_ptr(), w.data_ptr(), out.data_ptr()
+    p.bias = bias.data_ptr() if bias is not None else None
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() == N
+    if res is not None:
+        assert res.dtype == torch.float32 and res.is_contiguous()
+        p.res = res.data_ptr()
+    p.M, p.N, p.K, p.epi, p.res_rows, p.tile = M, N, K, epi, res_rows, tile
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _check(lib().whmr_gemm_blk(C.byref(p), _stream()), 'whmr_gemm_blk')
+        e1.record()
+        PROFILE.append(('gemm_bf16', 2.0 * M * N * K, e0, e1))
+        return out
+    _check(lib().whmr_gemm_blk(C.byref(p), _stream()), 'whmr_gemm_blk')
+    return out
+
+
+def layernorm_blk(x, weight, bias, out, rows, eps, out_std=False):
+    """LayerNorm of a blocked fp32 stream -> blocked bf16 operand (out_std False) or row-major fp32 [rows, C] (out_std True)"""
+    _dev(x, weight, bias, out)
+    assert x.dtype == torch.float32 and x.is_contiguous() and out.is_contiguous()
+    Cdim = x.shape[1] * 4
+    assert out.dtype == (torch.float32 if out_std else torch.bfloat16)
+    _check(lib().whmr_layernorm_blk(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), out.data_ptr(), rows, Cdim, eps, int(out_std), _stream()),
+           'whmr_layernorm_blk')
+    return out
+
+
+def patch_im2col_blk(x, out, patch, pad):
+    _dev(x, out)
+    assert x.dtype == torch.float32 and x.dim() == 4 and out.dtype == torch.bfloat16 and out.is_contiguous()
+    B, Cin, H, W = x.shape
+    sb, sc, sh, sw = x.stride()
+    _check(lib().whmr_patch_im2col_blk(x.data_ptr(), out.data_ptr(), B, Cin, H, W, patch, pad, sb, sc, sh, sw, _stream()), 'whmr_patch_im2col_blk')
+    return out
+
+
+def attention_blk(qkv, out, B, N, H, scale):
+    _dev(qkv, out)
+    assert qkv.is_contiguous() and out.is_contiguous() and qkv.dtype == torch.bfloat16 and out.dtype == torch.bfloat16
+    _check(lib().whmr_attention_blk(qkv.data_ptr(), out.data_ptr(), B, N, H, scale, _stream()), 'whmr_attention_blk')
     return out
 
 

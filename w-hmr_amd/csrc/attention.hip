@@ -152,7 +152,12 @@ __global__ __launch_bounds__(NKT * 64) void attention_bf16_kernel(const bf16_t* 
 // O is accumulated TRANSPOSED (O^T = V^T . P^T, i.e. the two MFMA operands above swapped): each lane then owns one query
 // column of O^T, so the running rescale exp2(m_old - m_new) and the final 1/l are lane-local; the tile is transposed back
 // through LDS (the K region, free after the last key tile) for 128-B row stores.
-template <int NKT>
+// BLK: qkv and out are in the blocked layout of gemm_blk.hip ([rows/32][cols/8][32][8] bf16 over the token rows m = b*N + n): the
+// staging loops walk keys fastest (32 consecutive rows of one 16-B column unit are contiguous), and O leaves straight from the
+// accumulators in the same (lane = row, 8 consecutive columns) ownership the GEMM epilogue uses -- no LDS transpose.
+__device__ __forceinline__ size_t blk_elem(int m, int col8, int ld8) { return ((size_t)(m >> 5) * ld8 + col8) * 256 + (m & 31) * 8; }
+
+template <int NKT, bool BLK = false>
 __global__ __launch_bounds__(NKT * 64, 4) void attention_bf16_chunk_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                                            int N, int H, float scale, float* __restrict__ lse) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -165,6 +170,28 @@ __global__ __launch_bounds__(NKT * 64, 4) void attention_bf16_chunk_kernel(const
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int C = H * 64, ld = 3 * C;
     const bf16_t* base = qkv + (size_t)b * N * ld + h * 64;
+    const int ld8 = ld >> 3, m_img = b * N;
+    if constexpr (BLK) {
+        for (int c = tid; c < NPAD * 8; c += NKT * 64) {
+            const int key = c % NPAD, ch = c / NPAD;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (key < N) v = *(const uint4*)(qkv + blk_elem(m_img + key, (C + h * 64) / 8 + ch, ld8));
+            *(uint4*)(Ks + key * 128 + ((ch ^ ((key >> 1) & 7)) << 4)) = v;
+        }
+        for (int c = tid; c < (NPAD / 2) * 8; c += NKT * 64) {
+            const int kp = c % (NPAD / 2), ch = c / (NPAD / 2);
+            const int k0 = 2 * kp;
+            uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0;
+            if (k0 < N) v0 = *(const uint4*)(qkv + blk_elem(m_img + k0, (2 * C + h * 64) / 8 + ch, ld8));
+            if (k0 + 1 < N) v1 = *(const uint4*)(qkv + blk_elem(m_img + k0 + 1, (2 * C + h * 64) / 8 + ch, ld8));
+            const uint32_t a[4] = {v0.x, v0.y, v0.z, v0.w}, bb[4] = {v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                *(uint32_t*)(Vt + (ch * 8 + 2 * i) * VS + k0) = (a[i] & 0xffffu) | (bb[i] << 16);
+                *(uint32_t*)(Vt + (ch * 8 + 2 * i + 1) * VS + k0) = (a[i] >> 16) | (bb[i] & 0xffff0000u);
+            }
+        }
+    } else {
     for (int c = tid; c < NPAD * 8; c += NKT * 64) {
         const int key = c >> 3, ch = c & 7;
         uint4 v = make_uint4(0, 0, 0, 0);
@@ -184,12 +211,15 @@ __global__ __launch_bounds__(NKT * 64, 4) void attention_bf16_chunk_kernel(const
             *(uint32_t*)(Vt + (ch * 8 + 2 * i + 1) * VS + k0) = (a[i] >> 16) | (bb[i] & 0xffff0000u);
         }
     }
+    }
     const int q0 = wave * 32;
     int qrow = q0 + l31;
     if (qrow > N - 1) qrow = N - 1;
     bf16x8_t qf[4];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const bf16x8_t*)(base + (size_t)qrow * ld + kk * 16 + hi * 8);
+    for (int kk = 0; kk < 4; ++kk)
+        qf[kk] = BLK ? *(const bf16x8_t*)(qkv + blk_elem(m_img + qrow, (h * 64) / 8 + kk * 2 + hi, ld8))
+                     : *(const bf16x8_t*)(base + (size_t)qrow * ld + kk * 16 + hi * 8);
     __syncthreads();
 
     const float sc = scale * LOG2E;
@@ -273,6 +303,25 @@ __global__ __launch_bounds__(NKT * 64, 4) void attention_bf16_chunk_kernel(const
     const float inv = 1.0f / l;
     // training: log2-domain log-sum-exp per query, P = exp2(s * scale * log2e - lse) in the backward kernel
     if (lse && hi == 0 && q0 + l31 < N) lse[((size_t)b * H + h) * N + q0 + l31] = m + __log2f(l);
+    if constexpr (BLK) {
+        // lane = query row, 4 consecutive d per register quad: pack, exchange halves (v_permlane32_swap) -> 8 consecutive d = one 16-B
+        // piece of a blocked unit; lanes 0-31 write unit 2p, lanes 32-63 unit 2p + 1 of the head's 8 units
+        const int q = q0 + l31;
+        if (q < N) {
+            bf16_t* orow = out + blk_elem(m_img + q, h * 8, C >> 3);
+#pragma unroll
+            for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+                for (int qq = 0; qq < 4; qq += 2) {
+                    const uint32_t a0 = pack_bf16x2(o[dh][4 * qq] * inv, o[dh][4 * qq + 1] * inv), a1 = pack_bf16x2(o[dh][4 * qq + 2] * inv, o[dh][4 * qq + 3] * inv);
+                    const uint32_t b0 = pack_bf16x2(o[dh][4 * qq + 4] * inv, o[dh][4 * qq + 5] * inv), b1 = pack_bf16x2(o[dh][4 * qq + 6] * inv, o[dh][4 * qq + 7] * inv);
+                    const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+                    const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+                    *(uint4*)(orow + (size_t)(dh * 4 + qq + hi) * 256) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+                }
+        }
+        return;
+    }
     // ---- transpose the wave's [32 queries x 64 d] tile through LDS (rows of 136 B: conflict-free 8-B writes) and store rows
     __syncthreads();                               // every wave is done with K / Vt
     constexpr int TS = 136;
@@ -597,6 +646,31 @@ static int launch_bf16(const void* qkv, void* out, int B, int N, int H, float sc
                        (bf16_t*)out, N, H, scale);
     WHMR_CHECK_LAUNCH();
     return 0;
+}
+
+template <int NKT>
+static int launch_bf16_blk(const void* qkv, void* out, int B, int N, int H, float scale, hipStream_t st) {
+    constexpr int NPAD = NKT * 32;
+    const size_t lds = (size_t)NPAD * 128 + 64 * (NPAD + 4) * 2;
+    hipLaunchKernelGGL((attention_bf16_chunk_kernel<NKT, true>), dim3(B * H), dim3(NKT * 64), lds, st, (const bf16_t*)qkv, (bf16_t*)out, N, H, scale,
+                       (float*)nullptr);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+// Same attention core on the BLOCKED token layout of whmr_gemm_blk: qkv [ceil(B*N/32)][3*H*8][32][8], out [ceil(B*N/32)][H*8][32][8] (bf16, d = 64).
+extern "C" int whmr_attention_blk(const void* qkv, void* out, int B, int N, int H, float scale, void* stream) {
+    if (B <= 0 || N <= 64 || N > 256 || H <= 0 || scale <= 0.f) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    switch ((N + 31) / 32) {
+        case 3: return launch_bf16_blk<3>(qkv, out, B, N, H, scale, st);
+        case 4: return launch_bf16_blk<4>(qkv, out, B, N, H, scale, st);
+        case 5: return launch_bf16_blk<5>(qkv, out, B, N, H, scale, st);
+        case 6: return launch_bf16_blk<6>(qkv, out, B, N, H, scale, st);
+        case 7: return launch_bf16_blk<7>(qkv, out, B, N, H, scale, st);
+        case 8: return launch_bf16_blk<8>(qkv, out, B, N, H, scale, st);
+    }
+    return (int)hipErrorInvalidValue;
 }
 
 extern "C" int whmr_attention(const void* qkv, void* out, int B, int N, int H, int d, float scale, int is_bf16,

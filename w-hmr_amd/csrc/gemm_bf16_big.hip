@@ -334,6 +334,42 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
             mfmas((KK - 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
         }
+    } else if constexpr (PP == 4) {
+        // ---- 2-stage loop with the DMA issue SPREAD behind the MFMAs (one global_load_lds after every second MFMA of sub-steps 0-1)
+        // instead of a burst of G loads per wave right after the barrier: the burst keeps all 8 waves in VMEM issue (the texture
+        // addresser takes ~16 clk per 1-KiB wave instruction: 64 of them per K step = ~1000 clk with the matrix pipes idle).
+        static_assert(NS == 2 && BK == 64, "spread-DMA schedule: 2 stages of BK = 64");
+        for (int kt = 0; kt < nkt; ++kt) {
+            wait_step(kt, 0);
+            __builtin_amdgcn_s_barrier();
+            const bool more = kt + 1 < nkt;
+            const int nb = (kt + 1) & 1;
+            load_frags(kt & 1, 0, 0);
+            int d = 0;                            // next DMA unit (0..AP-1: A passes, AP..AP+BP-1: B passes)
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                if (kk + 1 < KK) { load_frags(kt & 1, kk + 1, (kk + 1) & 1); wait_lgkmcnt<NF>(); }
+                else wait_lgkmcnt<0>();
+                __builtin_amdgcn_sched_barrier(0);
+                int n = 0;
+#pragma unroll
+                for (int i = 0; i < MIW; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[kk & 1][j], af[kk & 1][i], acc[i][j], 0, 0, 0);
+                        ++n;
+                        constexpr int PER = (cfg::G + 1) / 2;               // DMA units per sub-step (sub-steps 0 and 1 carry all G)
+                        constexpr int EVERY = (MIW * NJ) / PER > 0 ? (MIW * NJ) / PER : 1;
+                        if (kk < 2 && (n % EVERY) == 0 && d < cfg::G && d < (kk + 1) * PER) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (more) { if (d < AP) stage_sel(kt + 1, nb, 1u << d, 0u); else stage_sel(kt + 1, nb, 0u, 1u << (d - AP)); }
+                            __builtin_amdgcn_sched_barrier(0);
+                            ++d;
+                        }
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
     } else {
         for (int kt = 0; kt < nkt; ++kt) {
             wait_step(kt, NS - 2);
@@ -695,6 +731,9 @@ extern "C" int whmr_gemm_bf16_big(const whmr_gemm* pp, int tile, void* stream) {
         case 320: return launch_big_mode<320, 256, 64, 2, 4, 2, 2, 0>(p, st);
         case 160: return launch_big_mode<192, 256, 64, 2, 4, 2, 2, 3>(p, st);     // trimmed: 160 x 256 (wave rows of 96 + 64)
         case 224: return launch_big_mode<256, 256, 64, 2, 4, 2, 2, 3>(p, st);     // trimmed: 224 x 256 (wave rows of 128 + 96)
+        case 258: return launch_big_mode<256, 256, 64, 2, 4, 2, 2, 4>(p, st);     // 256x256, DMA issue spread behind the MFMAs
+        case 194: return launch_big_mode<192, 256, 64, 2, 4, 2, 2, 4>(p, st);     // 192x256, same
+        case 322: return launch_big_mode<320, 256, 64, 2, 4, 2, 2, 4>(p, st);     // 320x256, same
         case 259: return launch_big_mode<256, 256, 64, 2, 4, 2, 2, 2>(p, st);     // same, 4 phases per K tile (half the barriers)     // 144 KiB, 2 stages, 160x64 wave tiles
     }
     return (int)hipErrorInvalidValue;

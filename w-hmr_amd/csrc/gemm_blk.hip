@@ -1,0 +1,301 @@
+// whmr_gemm_blk_desc: bf16 MFMA GEMM on BLOCKED operand layouts, two wave groups in ping-pong.  The bf16 inference path of the ViT
+// (vit.py:61-140: qkv / proj / fc1 + GELU / fc2, vit.py:157 patch embed) runs on this kernel; the row-major kernel of
+// gemm_bf16_big.hip stays for the convolutions, the training graph and odd shapes.
+//
+// Layout ("blocked"): a [R, C] matrix is stored as [R/32][C/E][32][E] with E = 8 (bf16) or 4 (fp32), i.e. 512-byte units of
+// 32 rows x 16 bytes.  That unit is at once
+//   * what one half-wave of an MFMA 32x32x16 operand fetch reads (lane = row, 8 consecutive k),
+//   * what one half-wave of the (operand-swapped) MFMA result owns (lane = row, 4 fp32 / 8 bf16 consecutive columns),
+//   * a contiguous 512 B of global memory AND of LDS.
+// Consequences: global_load_lds copies whole 1-KiB runs (no swizzle: the ds_read_b128 fragment reads of a linear image are
+// conflict-free), and the epilogue stores straight from the accumulators in 1-KiB wave stores -- no LDS transpose, no barrier.
+//
+// Schedule (measured in tools/lab/gemm_lab.hip): 8 waves = 2 wave rows x 4 wave columns, wave tile (32 MI) x 64.  The two
+// wave rows are two GROUPS (one wave of each per SIMD) that run one s_barrier apart.  Work unit = half a K tile (32 deep):
+//   MEM(h)  : ds_read this wave's fragments of half tile h (2 MI + 4 reads), issue its share of the LDS-DMA of half tile h + 3
+//             (ring of 4 half-tile slots, counted vmcnt: two younger groups stay in flight), wait, barrier
+//   MFMA(h) : 4 MI MFMAs straight from registers, barrier
+// While group 0 is in MFMA(h) group 1 is in MEM(h) and vice versa: on every SIMD one wave feeds the matrix pipe while the other
+// talks to LDS and the texture addresser.  In a lock-step loop all 8 waves issue their DMA at the same time and the matrix pipes
+// idle for the ~1000 clk the L1 needs to take 64 KiB (qkv main loop 48 -> 39 us).
+#include <type_traits>
+#include "common.h"
+#include "gemm_blk.h"
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+
+template <int N> __device__ __forceinline__ void blk_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void blk_wait_lgkmcnt() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+// fragment read hidden from hipcc's waitcnt bookkeeping (valid after the counted wait + sched_barrier that follows it)
+template <int OFF> __device__ __forceinline__ bf16x8_t blk_lds_read128(uint32_t addr) {
+    bf16x8_t v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+
+template <int MI0, int MI1>
+struct blk_cfg {
+    static constexpr int MB = MI0 + MI1;                 // A row blocks (32 rows) per tile
+    static constexpr int BM = MB * 32, BN = 256;
+    static constexpr int SLOT = (MB + 8) * 2048;         // one half K tile (32 deep) of A and W: 2 KiB per row block
+    static constexpr int HU = (MB + 8) * 2;              // 1-KiB DMA units per half tile
+    static constexpr int HUPW = (HU + 7) / 8;            // units per wave (waves >= HU % 8 issue one less when HU % 8 != 0)
+    static constexpr int BIAS_OFF = 4 * SLOT;            // [256] floats behind the ring
+    static constexpr int LDS = 4 * SLOT + 1024;
+    static constexpr int MIMAX = MI0 > MI1 ? MI0 : MI1;
+};
+
+template <int MI0, int MI1, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_blk_kernel(const whmr_gemm_blk_desc p) {
+    using cfg = blk_cfg<MI0, MI1>;
+    constexpr int MB = cfg::MB, BM = cfg::BM, BN = cfg::BN, SLOT = cfg::SLOT, HU = cfg::HU, HUPW = cfg::HUPW, NJ = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;              // wm = group
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int tiles_n = p.N / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int lid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int tm = lid / tiles_n, tn = lid % tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int KC = p.K >> 3;                              // 16-B chunks per row
+    const int H = p.K >> 5;                               // half K tiles
+    const int rb_last = ((p.M + 31) >> 5) - 1;            // last valid row block
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)smem;
+
+    // this tile's bias slice -> LDS (one float per thread, in flight under the whole main loop)
+    if (tid < BN) ((float*)(smem + cfg::BIAS_OFF))[tid] = p.bias ? p.bias[n0 + tid] : 0.f;
+
+    // ---- DMA units of this wave: u = wave + 8 i -> row block u >> 1 (A blocks first, then the 8 W blocks), 1-KiB half u & 1
+    const bool dma_full = (HU % 8 == 0) || (wave < HU % 8);          // this wave issues HUPW units (else HUPW - 1)
+    const char* hsrc[HUPW];
+#pragma unroll
+    for (int i = 0; i < HUPW; ++i) {
+        int u = wave + 8 * i;
+        if (u >= HU) u = HU - 1;                          // never issued (dma_full is false); keeps the address valid
+        const int b = u >> 1, half = u & 1;
+        if (b < MB) {
+            int rb = (m0 >> 5) + b;
+            if (rb > rb_last) rb = rb_last;               // M tail: re-read the last block (its results are not stored)
+            hsrc[i] = (const char*)p.A + ((size_t)rb * KC) * 512 + half * 1024 + lane * 16;
+        } else {
+            hsrc[i] = (const char*)p.W + ((size_t)((n0 >> 5) + b - MB) * KC) * 512 + half * 1024 + lane * 16;
+        }
+    }
+    auto hstage = [&](int h) {
+        const int slot = h & 3;
+#pragma unroll
+        for (int i = 0; i < HUPW; ++i) {
+            if (i < HUPW - 1 || dma_full)
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)(hsrc[i] + (size_t)h * 2048), (lds_void_t*)(smem + slot * SLOT + (wave + 8 * i) * 1024), 16, 0, 0);
+        }
+    };
+    // own DMA groups still allowed in flight: `young` groups of (HUPW or HUPW - 1) loads
+    auto wait_dma = [&](int young) {
+        if (young >= 2) { if (dma_full) blk_wait_vmcnt<2 * HUPW>(); else blk_wait_vmcnt<2 * (HUPW - 1)>(); }
+        else if (young == 1) { if (dma_full) blk_wait_vmcnt<HUPW>(); else blk_wait_vmcnt<HUPW - 1>(); }
+        else blk_wait_vmcnt<0>();
+    };
+
+    f32x16_t acc[cfg::MIMAX][NJ];
+#pragma unroll
+    for (int i = 0; i < cfg::MIMAX; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    hstage(0);
+    if (H > 1) hstage(1);
+    if (H > 2) hstage(2);
+    wait_dma(H > 2 ? 2 : H - 1);
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();                        // group 1 runs one barrier behind
+
+    auto main_loop = [&](auto miw_tag) {
+        constexpr int MIW = decltype(miw_tag)::value;
+        const uint32_t a_b = lds0 + (wm * MI0) * 2048 + hi * 512 + l31 * 16;
+        const uint32_t b_b = lds0 + (MB + wn * 2) * 2048 + hi * 512 + l31 * 16;
+        bf16x8_t fa[MIW][2], fb[NJ][2];
+        for (int h = 0; h < H; ++h) {
+            // ---- MEM(h)
+            const uint32_t sa = a_b + (h & 3) * SLOT, sb = b_b + (h & 3) * SLOT;
+            fb[0][0] = blk_lds_read128<0>(sb); fb[1][0] = blk_lds_read128<2048>(sb);
+            fa[0][0] = blk_lds_read128<0>(sa);
+            if constexpr (MIW > 1) fa[1][0] = blk_lds_read128<2048>(sa);
+            if constexpr (MIW > 2) fa[2][0] = blk_lds_read128<4096>(sa);
+            if constexpr (MIW > 3) fa[3][0] = blk_lds_read128<6144>(sa);
+            if constexpr (MIW > 4) fa[4][0] = blk_lds_read128<8192>(sa);
+            fb[0][1] = blk_lds_read128<1024>(sb); fb[1][1] = blk_lds_read128<2048 + 1024>(sb);
+            fa[0][1] = blk_lds_read128<1024>(sa);
+            if constexpr (MIW > 1) fa[1][1] = blk_lds_read128<2048 + 1024>(sa);
+            if constexpr (MIW > 2) fa[2][1] = blk_lds_read128<4096 + 1024>(sa);
+            if constexpr (MIW > 3) fa[3][1] = blk_lds_read128<6144 + 1024>(sa);
+            if constexpr (MIW > 4) fa[4][1] = blk_lds_read128<8192 + 1024>(sa);
+            if (h + 3 < H) hstage(h + 3);                              // slot (h - 1) & 3: every wave finished reading it one barrier ago
+            wait_dma(H - 2 - h);                                       // own share of half tile h + 1 has landed (h + 2, h + 3 may fly)
+            blk_wait_lgkmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- MFMA(h)
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < MIW; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j][kk], fa[i][kk], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        }
+    };
+    if constexpr (MI0 == MI1) {
+        main_loop(std::integral_constant<int, MI0>{});
+    } else {
+        if (wm == 0) main_loop(std::integral_constant<int, MI0>{});
+        else main_loop(std::integral_constant<int, MI1>{});
+    }
+
+    // ---- epilogue: straight from the accumulators (lane = row l31 of a 32-row block, 4 consecutive columns per register quad)
+    const int miw = wm == 0 ? MI0 : MI1;
+    const int rb0 = (m0 >> 5) + (wm == 0 ? 0 : MI0);                   // first row block of this wave
+    const int nb0 = n0 + wn * 64;
+    const float* sBias = (const float*)(smem + cfg::BIAS_OFF) + wn * 64;
+    if constexpr (EPI == 0 || EPI == 1) {
+        const int NC8 = p.N >> 3;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            float4 bq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bq[q] = *(const float4*)(sBias + j * 32 + 8 * q + 4 * hi);
+#pragma unroll
+            for (int i = 0; i < cfg::MIMAX; ++i) {
+                if (i >= miw || rb0 + i > rb_last) continue;
+                uint32_t pk[4][2];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x2_t v0 = {acc[i][j][4 * q] + bq[q].x, acc[i][j][4 * q + 1] + bq[q].y};
+                    f32x2_t v1 = {acc[i][j][4 * q + 2] + bq[q].z, acc[i][j][4 * q + 3] + bq[q].w};
+                    if constexpr (EPI == 1) { v0 = gelu_fast2(v0); v1 = gelu_fast2(v1); }
+                    pk[q][0] = pack_bf16x2(v0.x, v0.y); pk[q][1] = pack_bf16x2(v1.x, v1.y);
+                }
+                char* rowp = (char*)p.C + ((size_t)(rb0 + i) * NC8 + ((nb0 + j * 32) >> 3)) * 512 + l31 * 16;
+#pragma unroll
+                for (int q = 0; q < 4; q += 2) {
+                    // half exchange: lanes 0-31 end up with columns 8q..8q+7 (unit q), lanes 32-63 with 8(q+1)..8(q+1)+7 (unit q+1)
+                    const auto r0 = __builtin_amdgcn_permlane32_swap(pk[q][0], pk[q + 1][0], false, false);
+                    const auto r1 = __builtin_amdgcn_permlane32_swap(pk[q][1], pk[q + 1][1], false, false);
+                    *(uint4*)(rowp + (q + hi) * 512) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+                }
+            }
+        }
+    } else {
+        const int NC4 = p.N >> 2;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            float4 bq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bq[q] = *(const float4*)(sBias + j * 32 + 8 * q + 4 * hi);
+#pragma unroll
+            for (int i = 0; i < cfg::MIMAX; ++i) {
+                if (i >= miw || rb0 + i > rb_last) continue;
+                const size_t off = ((size_t)(rb0 + i) * NC4 + ((nb0 + j * 32) >> 2) + hi) * 512 + l31 * 16;
+                float4 rv[4];
+                if constexpr (EPI == 2) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) rv[q] = *(const float4*)((const char*)p.res + off + q * 1024);
+                } else {                                                // EPI 3: row-major residual, row = m % res_rows (pos embed, vit.py:320)
+                    const int m = (rb0 + i) * 32 + l31;
+                    const float* rr = p.res + (size_t)(m % p.res_rows) * p.N + nb0 + j * 32 + 4 * hi;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) rv[q] = *(const float4*)(rr + 8 * q);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float4 o;
+                    o.x = acc[i][j][4 * q] + bq[q].x + rv[q].x; o.y = acc[i][j][4 * q + 1] + bq[q].y + rv[q].y;
+                    o.z = acc[i][j][4 * q + 2] + bq[q].z + rv[q].z; o.w = acc[i][j][4 * q + 3] + bq[q].w + rv[q].w;
+                    *(float4*)((char*)p.C + off + q * 1024) = o;
+                }
+            }
+        }
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();                        // group 0's count catches up with group 1's extra barrier
+}
+
+template <int MI0, int MI1, int EPI>
+static int launch_blk(const whmr_gemm_blk_desc& p, hipStream_t st) {
+    using cfg = blk_cfg<MI0, MI1>;
+    auto kern = gemm_blk_kernel<MI0, MI1, EPI>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, cfg::LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    const int tiles = ((p.M + cfg::BM - 1) / cfg::BM) * (p.N / cfg::BN);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), cfg::LDS, st, p);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int MI0, int MI1>
+static int launch_blk_epi(const whmr_gemm_blk_desc& p, hipStream_t st) {
+    switch (p.epi) {
+        case 0: return launch_blk<MI0, MI1, 0>(p, st);
+        case 1: return launch_blk<MI0, MI1, 1>(p, st);
+        case 2: return launch_blk<MI0, MI1, 2>(p, st);
+        case 3: return launch_blk<MI0, MI1, 3>(p, st);
+    }
+    return (int)hipErrorInvalidValue;
+}
+
+// Tile heights (x 256 columns): the wave rows own MI0 and MI1 row blocks.  The chooser minimises (rounds over 256 CUs) x (tile rows).
+static const int kBlkTiles[][2] = {{4, 4}, {5, 5}, {4, 3}, {3, 3}, {3, 2}, {2, 2}, {5, 4}};
+
+extern "C" int whmr_gemm_blk_tile(const whmr_gemm_blk_desc* pp, int tile, void* stream) {
+    const whmr_gemm_blk_desc& p = *pp;
+    if (p.M <= 0 || p.N <= 0 || (p.N % 256) || p.K < 32 || (p.K % 32) || p.epi < 0 || p.epi > 3) return (int)hipErrorInvalidValue;
+    if ((p.epi >= 2) && !p.res) return (int)hipErrorInvalidValue;
+    if (p.epi == 3 && p.res_rows <= 0) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    switch (tile) {
+        case 0x44: return launch_blk_epi<4, 4>(p, st);      // 256 x 256
+        case 0x55: return launch_blk_epi<5, 5>(p, st);      // 320 x 256
+        case 0x43: return launch_blk_epi<4, 3>(p, st);      // 224 x 256
+        case 0x33: return launch_blk_epi<3, 3>(p, st);      // 192 x 256
+        case 0x32: return launch_blk_epi<3, 2>(p, st);      // 160 x 256
+        case 0x22: return launch_blk_epi<2, 2>(p, st);      // 128 x 256
+        case 0x54: return launch_blk_epi<5, 4>(p, st);      // 288 x 256
+    }
+    return (int)hipErrorInvalidValue;
+}
+
+static int g_blk_force[4] = {0, 0, 0, 0};                   // whmr_set_option keys 110..113: tile for N = 2304 / (768, K <= 1024) / 3072 / (768, K > 1024)
+extern "C" int whmr_gemm_blk_set_tile(int slot, int tile) {
+    if (slot < 0 || slot > 3) return (int)hipErrorInvalidValue;
+    g_blk_force[slot] = tile;
+    return 0;
+}
+
+extern "C" int whmr_gemm_blk(const whmr_gemm_blk_desc* pp, void* stream) {
+    const whmr_gemm_blk_desc& p = *pp;
+    if (p.tile) return whmr_gemm_blk_tile(pp, p.tile, stream);
+    const int slot = p.N == 2304 ? 0 : p.N == 3072 ? 2 : p.N == 768 ? (p.K <= 1024 ? 1 : 3) : -1;
+    if (slot >= 0 && g_blk_force[slot]) return whmr_gemm_blk_tile(pp, g_blk_force[slot], stream);
+    long best_cost = -1;
+    int best = 0x44;
+    const int tiles_n = p.N / 256;
+    for (const auto& t : kBlkTiles) {
+        const int bm = 32 * (t[0] + t[1]);
+        const long tiles = (long)((p.M + bm - 1) / bm) * tiles_n;
+        const long rounds = (tiles + 255) / 256;
+        // cost ~ rounds x rows per tile, + a per-round constant (prologue / epilogue / block switch ~ 64 rows' worth of time)
+        const long cost = rounds * (bm + 64);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = (t[0] << 4) | t[1]; }
+    }
+    return whmr_gemm_blk_tile(pp, best, stream);
+}

@@ -157,3 +157,129 @@ extern "C" int whmr_cast_f32_bf16(const float* src, void* dst, long n, void* str
     WHMR_CHECK_LAUNCH();
     return 0;
 }
+
+// ---- blocked-layout variants (the bf16 inference path of the ViT keeps its activations in the 512-B units of gemm_blk.hip) ----------
+// LayerNorm of the fp32 residual stream x [rows/32][C/4][32][4] -> bf16 GEMM operand [rows/32][C/8][32][8] (OUT_STD = 0) or the plain
+// row-major fp32 [rows, C] map the heads consume (OUT_STD = 1: the final last_norm, vit.py:242,330).  One workgroup per 32-row block
+// (a contiguous 32*C*4 bytes): thread = (row, part), each part owns NPER consecutive 16-B column units of its row in registers;
+// two-pass mean / variance like layernorm_kernel, partial sums combined through LDS.
+template <int NPER, int PARTS, int OUT_STD>
+__global__ __launch_bounds__(32 * PARTS) void layernorm_blk_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
+                                                                   void* __restrict__ y, int rows, int C, float eps) {
+    __shared__ float red[2][PARTS][32];
+    const int row = threadIdx.x & 31, part = threadIdx.x >> 5;
+    const int rb = blockIdx.x;
+    const int n4_0 = part * NPER, NC4 = C >> 2;
+    const float* xb = x + ((size_t)rb * NC4 + n4_0) * 128 + row * 4;
+    float4 v[NPER];
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < NPER; ++q) {
+        v[q] = *(const float4*)(xb + q * 128);
+        s += (v[q].x + v[q].y) + (v[q].z + v[q].w);
+    }
+    red[0][part][row] = s;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int pp = 0; pp < PARTS; ++pp) tot += red[0][pp][row];
+    const float mean = tot / (float)C;
+    float qs = 0.f;
+#pragma unroll
+    for (int q = 0; q < NPER; ++q) {
+        const float dx = v[q].x - mean, dy = v[q].y - mean, dz = v[q].z - mean, dw = v[q].w - mean;
+        qs += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+    red[1][part][row] = qs;
+    __syncthreads();
+    float var = 0.f;
+#pragma unroll
+    for (int pp = 0; pp < PARTS; ++pp) var += red[1][pp][row];
+    const float rstd = 1.0f / sqrtf(var / (float)C + eps);
+    const int m = rb * 32 + row;
+    if constexpr (OUT_STD) {
+        if (m >= rows) return;
+        float* yr = (float*)y + (size_t)m * C + n4_0 * 4;
+#pragma unroll
+        for (int q = 0; q < NPER; ++q) {
+            const float4 gg = *(const float4*)(g + (n4_0 + q) * 4), bb = *(const float4*)(b + (n4_0 + q) * 4);
+            *(float4*)(yr + q * 4) = make_float4((v[q].x - mean) * rstd * gg.x + bb.x, (v[q].y - mean) * rstd * gg.y + bb.y,
+                                                 (v[q].z - mean) * rstd * gg.z + bb.z, (v[q].w - mean) * rstd * gg.w + bb.w);
+        }
+    } else {
+        bf16_t* yb = (bf16_t*)y + ((size_t)rb * (C >> 3) + (n4_0 >> 1)) * 256 + row * 8;
+#pragma unroll
+        for (int q = 0; q < NPER; q += 2) {
+            const float4 g0 = *(const float4*)(g + (n4_0 + q) * 4), b0 = *(const float4*)(b + (n4_0 + q) * 4);
+            const float4 g1 = *(const float4*)(g + (n4_0 + q + 1) * 4), b1 = *(const float4*)(b + (n4_0 + q + 1) * 4);
+            *(uint4*)(yb + (q >> 1) * 256) =
+                make_uint4(pack_bf16x2((v[q].x - mean) * rstd * g0.x + b0.x, (v[q].y - mean) * rstd * g0.y + b0.y),
+                           pack_bf16x2((v[q].z - mean) * rstd * g0.z + b0.z, (v[q].w - mean) * rstd * g0.w + b0.w),
+                           pack_bf16x2((v[q + 1].x - mean) * rstd * g1.x + b1.x, (v[q + 1].y - mean) * rstd * g1.y + b1.y),
+                           pack_bf16x2((v[q + 1].z - mean) * rstd * g1.z + b1.z, (v[q + 1].w - mean) * rstd * g1.w + b1.w));
+        }
+    }
+}
+
+template <int NPER, int PARTS>
+static int launch_ln_blk(const float* x, const float* g, const float* b, void* y, int rows, int C, float eps, int out_std, hipStream_t st) {
+    const dim3 grid((rows + 31) / 32), block(32 * PARTS);
+    if (out_std) hipLaunchKernelGGL((layernorm_blk_kernel<NPER, PARTS, 1>), grid, block, 0, st, x, g, b, y, rows, C, eps);
+    else hipLaunchKernelGGL((layernorm_blk_kernel<NPER, PARTS, 0>), grid, block, 0, st, x, g, b, y, rows, C, eps);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int whmr_layernorm_blk(const float* x, const float* gamma, const float* beta, void* y, int rows, int C, float eps, int out_std,
+                                  void* stream) {
+    if (rows <= 0) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    switch (C) {
+        case 768: return launch_ln_blk<24, 8>(x, gamma, beta, y, rows, C, eps, out_std, st);       // ViT-B
+        case 1024: return launch_ln_blk<16, 16>(x, gamma, beta, y, rows, C, eps, out_std, st);     // ViT-L
+        case 1280: return launch_ln_blk<20, 16>(x, gamma, beta, y, rows, C, eps, out_std, st);     // ViT-H
+        case 256: return launch_ln_blk<8, 8>(x, gamma, beta, y, rows, C, eps, out_std, st);
+    }
+    return (int)hipErrorInvalidValue;
+}
+
+// PatchEmbed gather into the blocked bf16 operand layout [ceil(M/32)][K/8][32][8] (P % 8 == 0): thread = (row in block, k unit),
+// rows fastest, so a half-wave writes one contiguous 512-B unit.
+__global__ __launch_bounds__(256) void patch_im2col_blk_kernel(const float* __restrict__ x, bf16_t* __restrict__ cols, int B, int Cin, int H, int W,
+                                                               int P, int pad, int Hp, int Wp, long sb, long sc, long sh, long sw) {
+    const int K8 = Cin * P * P / 8, P8 = P / 8;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int M = B * Hp * Wp;
+    const int r = (int)(idx & 31);
+    const long u = idx >> 5;
+    const int k8 = (int)(u % K8);
+    const int rb = (int)(u / K8);
+    const int m = rb * 32 + r;
+    if (rb > (M - 1) / 32) return;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (m < M) {
+        const int kx = (k8 % P8) * 8, ky = (k8 / P8) % P, ci = k8 / (P8 * P);
+        const int px = m % Wp, py = (m / Wp) % Hp, b = m / (Wp * Hp);
+        const int iy = py * P - pad + ky, ix = px * P - pad + kx;
+        if ((unsigned)iy < (unsigned)H) {
+            const float* row = x + b * sb + ci * sc + (long)iy * sh;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if ((unsigned)(ix + e) < (unsigned)W) v[e] = row[(long)(ix + e) * sw];
+        }
+    }
+    *(uint4*)(cols + ((size_t)rb * K8 + k8) * 256 + r * 8) =
+        make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+}
+
+extern "C" int whmr_patch_im2col_blk(const float* x, void* cols, int B, int Cin, int H, int W, int P, int pad,
+                                     long sb, long sc, long sh, long sw, void* stream) {
+    const int Hp = (H + 2 * pad - P) / P + 1, Wp = (W + 2 * pad - P) / P + 1;
+    if (B <= 0 || Hp <= 0 || Wp <= 0 || (P % 8)) return (int)hipErrorInvalidValue;
+    const long M = (long)B * Hp * Wp, K8 = (long)Cin * P * P / 8;
+    const long total = ((M + 31) / 32) * 32 * K8;
+    hipLaunchKernelGGL(patch_im2col_blk_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)cols, B, Cin, H, W,
+                       P, pad, Hp, Wp, sb, sc, sh, sw);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}

@@ -7,6 +7,12 @@ parts W-HMR uses, identical ``state_dict`` keys, ``forward(x) ->
 Forward (inference) = 1 im2col + 1 + 12*4 GEMM launches + 25 LayerNorms + 12 attention launches, all from
 libwhmr_hip.so.  ``numerics``: 'bf16' (default; bf16 MFMA operands, fp32 accumulate, fp32 residual stream)
 or 'fp32' (exact-f32 MFMA everywhere: the 1e-4 parity mode of BASELINE.json).
+
+bf16 inference keeps every activation between the patch gather and the last LayerNorm in the BLOCKED layout of
+``csrc/gemm_blk.hip`` ([rows/32][cols/E][32][E]: 512-byte units that are at once an MFMA operand fetch, an MFMA result
+and a contiguous run of memory), so the GEMMs need no LDS swizzle / transpose and run the two-group ping-pong schedule;
+LayerNorm, the attention core and the patch gather have blocked variants.  ``ViT.blocked = False`` selects the row-major
+kernels (same arithmetic; kept for A/B runs, the training graph and the fp32 parity mode use them too).
 """
 import math
 
@@ -83,6 +89,7 @@ class ViT(nn.Module):
         _ln_params(self, 'last_norm', embed_dim)
         self._wcache = {}
         self._ws = {}
+        self.blocked = True                 # bf16 inference on the blocked-layout kernels when the shapes allow it
 
     # ------------------------------------------------------------------ weight / workspace caches
     def _w(self, p, shape=None):
@@ -95,6 +102,16 @@ class ViT(nn.Module):
         if ent is None or ent[0] != p._version or ent[1].device != p.device:
             w = L.cast_bf16(p.detach())
             ent = (p._version, w.reshape(shape) if shape is not None else w)
+            self._wcache[key] = ent
+        return ent[1]
+
+    def _wblk(self, p, shape=None):
+        """bf16 copy of a weight [N, K] packed into the blocked operand layout [N/32][K/8][32][8] (re-made when the parameter changes)"""
+        key = ('blk', id(p))
+        ent = self._wcache.get(key)
+        if ent is None or ent[0] != p._version or ent[1].device != p.device:
+            w = L.cast_bf16(p.detach())
+            ent = (p._version, L.to_blocked(w.reshape(shape) if shape is not None else w))
             self._wcache[key] = ent
         return ent[1]
 
@@ -118,6 +135,10 @@ class ViT(nn.Module):
         assert N + 1 == self.pos_embed.shape[1], 'input size does not match pos_embed (vit.py:231)'
         dt = torch.float32 if self.numerics == 'fp32' else torch.bfloat16
         dev = x.device
+        hid_dim = self.blocks[0].mlp.fc1.weight.shape[0] if self.depth else D
+        if (self.blocked and self.numerics == 'bf16' and D % 256 == 0 and hid_dim % 256 == 0 and D // self.num_heads == 64
+                and 64 < N <= 256 and P % 8 == 0 and (Cin * P * P) % 32 == 0 and D in (256, 768, 1024, 1280)):
+            return self._forward_tokens_blocked(x, B, Hp, Wp), (B, Hp, Wp)
         cols = self._buf('cols', (M, Cin * P * P), dt, dev)
         L.patch_im2col(x.float(), cols, P, pad)
         pos = self._buf('pos', (N, D), torch.float32, dev)
@@ -137,9 +158,41 @@ class ViT(nn.Module):
             L.layernorm(t, blk.norm2.weight, blk.norm2.bias, h, 1e-6)
             L.gemm(h, self._w(blk.mlp.fc1.weight), hid, bias=blk.mlp.fc1.bias, act=L.ACT_GELU)
             L.gemm(hid, self._w(blk.mlp.fc2.weight), t, bias=blk.mlp.fc2.bias, residual=t)
-        out = self._buf('out', (M, D), torch.float32, dev)
+        out = torch.empty((M, D), dtype=torch.float32, device=dev)     # fresh: the caller keeps it (nn.Module value semantics)
         L.layernorm(t, self.last_norm.weight, self.last_norm.bias, out, 1e-6)
         return out, (B, Hp, Wp)
+
+    def _forward_tokens_blocked(self, x, B, Hp, Wp):
+        """bf16 inference on the blocked-layout kernels: same arithmetic as the row-major path below the patch gather (bf16 MFMA operands,
+        fp32 accumulate, fp32 residual stream, fp32 LayerNorm statistics); only where an element lives in memory differs."""
+        Cin, P, pad, D, heads = x.shape[1], self.patch_size, self.patch_pad, self.embed_dim, self.num_heads
+        N, M = Hp * Wp, B * Hp * Wp
+        nb = (M + 31) // 32
+        dev, bf, f32 = x.device, torch.bfloat16, torch.float32
+        K0 = Cin * P * P
+        cols = self._buf('cols_blk', (nb, K0 // 8, 32, 8), bf, dev)
+        L.patch_im2col_blk(x.float(), cols, P, pad)
+        pos = self._buf('pos', (N, D), f32, dev)
+        torch.add(self.pos_embed[0, 1:], self.pos_embed[0, :1], out=pos)              # vit.py:320
+        t = self._buf('t_blk', (nb, D // 4, 32, 4), f32, dev)
+        L.gemm_blk(cols, self._wblk(self.patch_embed.proj.weight, (D, K0)), t, M, bias=self.patch_embed.proj.bias, epi=L.EPI_F32_POS,
+                   res=pos, res_rows=N)
+        h = self._buf('h_blk', (nb, D // 8, 32, 8), bf, dev)
+        qkv = self._buf('qkv_blk', (nb, 3 * D // 8, 32, 8), bf, dev)
+        att = self._buf('att_blk', (nb, D // 8, 32, 8), bf, dev)
+        hd = self.blocks[0].mlp.fc1.weight.shape[0] if self.depth else D
+        hid = self._buf('hid_blk', (nb, hd // 8, 32, 8), bf, dev)
+        for blk in self.blocks:
+            L.layernorm_blk(t, blk.norm1.weight, blk.norm1.bias, h, M, 1e-6)
+            L.gemm_blk(h, self._wblk(blk.attn.qkv.weight), qkv, M, bias=blk.attn.qkv.bias, epi=L.EPI_BF16)
+            L.attention_blk(qkv, att, B, N, heads, self.scale)
+            L.gemm_blk(att, self._wblk(blk.attn.proj.weight), t, M, bias=blk.attn.proj.bias, epi=L.EPI_F32_RES, res=t)
+            L.layernorm_blk(t, blk.norm2.weight, blk.norm2.bias, h, M, 1e-6)
+            L.gemm_blk(h, self._wblk(blk.mlp.fc1.weight), hid, M, bias=blk.mlp.fc1.bias, epi=L.EPI_BF16_GELU)
+            L.gemm_blk(hid, self._wblk(blk.mlp.fc2.weight), t, M, bias=blk.mlp.fc2.bias, epi=L.EPI_F32_RES, res=t)
+        out = torch.empty((M, D), dtype=f32, device=dev)
+        L.layernorm_blk(t, self.last_norm.weight, self.last_norm.bias, out, M, 1e-6, out_std=True)
+        return out
 
     def forward_features(self, x):
         if self.training and torch.is_grad_enabled():
