@@ -207,7 +207,7 @@ def gemm_source_digest():
     """sha256 over the GEMM kernel sources: profiles/*_gemm_traffic.json records the digest it was measured at"""
     import hashlib
     h = hashlib.sha256()
-    for f in ('gemm_bf16_big.hip', 'gemm_bf16.hip', 'gemm_params.h', 'common.h'):
+    for f in ('gemm_blk.hip', 'gemm_blk.h', 'gemm_bf16_big.hip', 'gemm_bf16.hip', 'gemm_params.h', 'common.h'):
         with open(os.path.join(ROOT, 'w-hmr_amd', 'csrc', f), 'rb') as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -406,7 +406,7 @@ def main(argv=None):
             res['efficiency_vs_1gpu'] = value / (n_ranks * args.ref_1gpu)
         if not dry:
             res['model_tflops'] = VIT_FLOP_PER_IMG[args.workload] * n_ranks * args.batch * args.steps / dt / 1e12
-            res['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_bf16_big_kernel (all %d GEMM launches of one step)' % len(gemm),
+            res['roofline'] = {'bound': 'mfma', 'kernel': 'bf16 MFMA GEMM launches of one step (%d: gemm_blk_kernel on the blocked ViT path, gemm_bf16_big_kernel elsewhere)' % len(gemm),
                                'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
                                'flops_per_launch': flops_per_launch, 'avg_launch_us': avg_s * 1e6,
                                'traffic': traffic['bytes_per_launch'] if traffic else None,

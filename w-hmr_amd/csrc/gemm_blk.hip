@@ -13,11 +13,12 @@
 // Schedule (measured in tools/lab/gemm_lab.hip): 8 waves = 2 wave rows x 4 wave columns, wave tile (32 MI) x 64.  The two
 // wave rows are two GROUPS (one wave of each per SIMD) that run one s_barrier apart.  Work unit = half a K tile (32 deep):
 //   MEM(h)  : ds_read this wave's fragments of half tile h (2 MI + 4 reads), issue its share of the LDS-DMA of half tile h + 3
-//             (ring of 4 half-tile slots, counted vmcnt: two younger groups stay in flight), wait, barrier
-//   MFMA(h) : 4 MI MFMAs straight from registers, barrier
-// While group 0 is in MFMA(h) group 1 is in MEM(h) and vice versa: on every SIMD one wave feeds the matrix pipe while the other
-// talks to LDS and the texture addresser.  In a lock-step loop all 8 waves issue their DMA at the same time and the matrix pipes
-// idle for the ~1000 clk the L1 needs to take 64 KiB (qkv main loop 48 -> 39 us).
+//             (ring of 4 half-tile slots, counted vmcnt: two younger groups stay in flight), wait
+//   MFMA(h) : 4 MI MFMAs straight from registers
+// with ONE s_barrier per half tile and the two groups walking each slot in opposite order (group 0: MFMA then MEM, group 1: MEM then
+// MFMA): on every SIMD one wave feeds the matrix pipe while the other talks to LDS and the texture addresser.  In a lock-step loop all
+// 8 waves issue their DMA at the same time and the matrix pipes idle for the ~1000 clk the L1 needs to take 64 KiB (qkv main loop
+// 48 -> 36-38 us in the lab).
 #include <type_traits>
 #include "common.h"
 #include "gemm_blk.h"
@@ -46,7 +47,8 @@ struct blk_cfg {
     static constexpr int MIMAX = MI0 > MI1 ? MI0 : MI1;
 };
 
-template <int MI0, int MI1, int EPI>
+// SCHED 1: one barrier per half tile, groups in opposite order within a slot;  SCHED 0: two barriers per half tile (MEM | MFMA rendezvous)
+template <int MI0, int MI1, int EPI, int SCHED>
 __global__ __launch_bounds__(512, 2) void gemm_blk_kernel(const whmr_gemm_blk_desc p) {
     using cfg = blk_cfg<MI0, MI1>;
     constexpr int MB = cfg::MB, BM = cfg::BM, BN = cfg::BN, SLOT = cfg::SLOT, HU = cfg::HU, HUPW = cfg::HUPW, NJ = 2;
@@ -111,16 +113,20 @@ __global__ __launch_bounds__(512, 2) void gemm_blk_kernel(const whmr_gemm_blk_de
     if (H > 2) hstage(2);
     wait_dma(H > 2 ? 2 : H - 1);
     __builtin_amdgcn_s_barrier();
-    if (wm == 1) __builtin_amdgcn_s_barrier();                        // group 1 runs one barrier behind
 
+    // ONE barrier per half K tile; the two groups walk a slot in opposite order:
+    //   slot k:   group 0: MFMA(k), MEM(k+1)      group 1: MEM(k+1), MFMA(k+1)
+    // so the first half of a slot is MFMA (g0) beside MEM (g1) and the second half the reverse, with no rendezvous in the middle (a slot
+    // costs MEM + MFMA, not 2 x max(MEM, MFMA) + a second barrier: qkv 53.9 -> 47.2 us in the lab).  Hazards: MEM(x) of both groups
+    // lies in slot x-1: it reads ring slot x & 3 (DMA issued in slot x-4, own share awaited in slot x-2, then a barrier) and refills ring
+    // slot (x-1) & 3, last read in slot x-2 by MEM(x-1) -- whose ds_reads are drained (lgkmcnt(0)) before the barrier that ends that slot.
     auto main_loop = [&](auto miw_tag) {
         constexpr int MIW = decltype(miw_tag)::value;
         const uint32_t a_b = lds0 + (wm * MI0) * 2048 + hi * 512 + l31 * 16;
         const uint32_t b_b = lds0 + (MB + wn * 2) * 2048 + hi * 512 + l31 * 16;
         bf16x8_t fa[MIW][2], fb[NJ][2];
-        for (int h = 0; h < H; ++h) {
-            // ---- MEM(h)
-            const uint32_t sa = a_b + (h & 3) * SLOT, sb = b_b + (h & 3) * SLOT;
+        auto MEM = [&](int x) {
+            const uint32_t sa = a_b + (x & 3) * SLOT, sb = b_b + (x & 3) * SLOT;
             fb[0][0] = blk_lds_read128<0>(sb); fb[1][0] = blk_lds_read128<2048>(sb);
             fa[0][0] = blk_lds_read128<0>(sa);
             if constexpr (MIW > 1) fa[1][0] = blk_lds_read128<2048>(sa);
@@ -133,13 +139,13 @@ __global__ __launch_bounds__(512, 2) void gemm_blk_kernel(const whmr_gemm_blk_de
             if constexpr (MIW > 2) fa[2][1] = blk_lds_read128<4096 + 1024>(sa);
             if constexpr (MIW > 3) fa[3][1] = blk_lds_read128<6144 + 1024>(sa);
             if constexpr (MIW > 4) fa[4][1] = blk_lds_read128<8192 + 1024>(sa);
-            if (h + 3 < H) hstage(h + 3);                              // slot (h - 1) & 3: every wave finished reading it one barrier ago
-            wait_dma(H - 2 - h);                                       // own share of half tile h + 1 has landed (h + 2, h + 3 may fly)
+            if (x + 3 < H) hstage(x + 3);
+            wait_dma(H - 2 - x);                                       // own share of half tile x + 1 has landed (x + 2, x + 3 may fly)
             blk_wait_lgkmcnt<0>();
-            __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            // ---- MFMA(h)
-            __builtin_amdgcn_s_setprio(1);
+        };
+        auto MFMA = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -147,9 +153,31 @@ __global__ __launch_bounds__(512, 2) void gemm_blk_kernel(const whmr_gemm_blk_de
 #pragma unroll
                     for (int j = 0; j < NJ; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j][kk], fa[i][kk], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
+        };
+        if constexpr (SCHED == 1) {
+            MEM(0);
+            if (wm == 1) MFMA();                                           // group 1 is half a slot ahead
+            for (int k = 0; k < H; ++k) {
+                __builtin_amdgcn_s_barrier();
+                if (wm == 0) MFMA();                                       // MFMA(k)
+                if (k + 1 < H) {
+                    MEM(k + 1);
+                    if (wm == 1) MFMA();                                   // MFMA(k + 1)
+                }
+            }
+        } else {
+            // two barriers per half tile: MEM(h) of one group beside MFMA(h) of the other, rendezvous after each; group 1 one barrier behind
+            if (wm == 1) __builtin_amdgcn_s_barrier();
+            for (int h = 0; h < H; ++h) {
+                MEM(h);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_s_setprio(1);
+                MFMA();
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_s_barrier();
+            }
+            if (wm == 0) __builtin_amdgcn_s_barrier();
         }
     };
     if constexpr (MI0 == MI1) {
@@ -223,13 +251,14 @@ __global__ __launch_bounds__(512, 2) void gemm_blk_kernel(const whmr_gemm_blk_de
             }
         }
     }
-    if (wm == 0) __builtin_amdgcn_s_barrier();                        // group 0's count catches up with group 1's extra barrier
 }
 
-template <int MI0, int MI1, int EPI>
-static int launch_blk(const whmr_gemm_blk_desc& p, hipStream_t st) {
+static int g_blk_sched = 1;
+
+template <int MI0, int MI1, int EPI, int SCHED>
+static int launch_blk_s(const whmr_gemm_blk_desc& p, hipStream_t st) {
     using cfg = blk_cfg<MI0, MI1>;
-    auto kern = gemm_blk_kernel<MI0, MI1, EPI>;
+    auto kern = gemm_blk_kernel<MI0, MI1, EPI, SCHED>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, cfg::LDS);
@@ -240,6 +269,11 @@ static int launch_blk(const whmr_gemm_blk_desc& p, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), cfg::LDS, st, p);
     WHMR_CHECK_LAUNCH();
     return 0;
+}
+
+template <int MI0, int MI1, int EPI>
+static int launch_blk(const whmr_gemm_blk_desc& p, hipStream_t st) {
+    return g_blk_sched ? launch_blk_s<MI0, MI1, EPI, 1>(p, st) : launch_blk_s<MI0, MI1, EPI, 0>(p, st);
 }
 
 template <int MI0, int MI1>
@@ -276,6 +310,7 @@ extern "C" int whmr_gemm_blk_tile(const whmr_gemm_blk_desc* pp, int tile, void* 
 
 static int g_blk_force[4] = {0, 0, 0, 0};                   // whmr_set_option keys 110..113: tile for N = 2304 / (768, K <= 1024) / 3072 / (768, K > 1024)
 extern "C" int whmr_gemm_blk_set_tile(int slot, int tile) {
+    if (slot == 4) { g_blk_sched = tile; return 0; }                 // A/B: main-loop schedule (0 two barriers per half tile, 1 one barrier)
     if (slot < 0 || slot > 3) return (int)hipErrorInvalidValue;
     g_blk_force[slot] = tile;
     return 0;
@@ -286,6 +321,10 @@ extern "C" int whmr_gemm_blk(const whmr_gemm_blk_desc* pp, void* stream) {
     if (p.tile) return whmr_gemm_blk_tile(pp, p.tile, stream);
     const int slot = p.N == 2304 ? 0 : p.N == 3072 ? 2 : p.N == 768 ? (p.K <= 1024 ? 1 : 3) : -1;
     if (slot >= 0 && g_blk_force[slot]) return whmr_gemm_blk_tile(pp, g_blk_force[slot], stream);
+    // Cost model (in-model A/B on three boxes, tools/blk_ab.py; ViT-B 224^2 batch 64): with ONE round of tiles (<= 256) a launch lasts one
+    // tile, so the lowest tile wins (N = 768: 160 rows / 237 tiles beats 192 / 198 by 4 us per launch).  With two or more rounds every CU
+    // is busy all the time, the chip sits at its power limit and what counts is total CU time incl. the per-tile prologue / epilogue
+    // (~64 rows' worth): qkv on 441 tiles of 256 rows beats 504 tiles of 224 by 9 us per launch although the latter fills two rounds.
     long best_cost = -1;
     int best = 0x44;
     const int tiles_n = p.N / 256;
@@ -293,8 +332,8 @@ extern "C" int whmr_gemm_blk(const whmr_gemm_blk_desc* pp, void* stream) {
         const int bm = 32 * (t[0] + t[1]);
         const long tiles = (long)((p.M + bm - 1) / bm) * tiles_n;
         const long rounds = (tiles + 255) / 256;
-        // cost ~ rounds x rows per tile, + a per-round constant (prologue / epilogue / block switch ~ 64 rows' worth of time)
-        const long cost = rounds * (bm + 64);
+        long cost = rounds * (bm + 64) * 256;
+        if (rounds >= 2) { const long thr = tiles * (bm + 64) * 5 / 4; if (thr > cost) cost = thr; }
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = (t[0] << 4) | t[1]; }
     }
     return whmr_gemm_blk_tile(pp, best, stream);
