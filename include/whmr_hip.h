@@ -45,6 +45,8 @@ struct whmr_gemm {
                              * exceeds the Infinity Cache is re-read from cache instead of HBM (Tz-head 7x7 s3 conv) */
     int64_t phase_w_stride, phase_cy, phase_cx;
     int64_t split_k;        /* internal (set by the bf16 launcher, pass 0): K elements per split-K slice, blockIdx.z = slice */
+    const float* row_scale; /* optional [M]: act(acc + bias) is multiplied by row_scale[m] BEFORE the (post-activation) residual is added --
+                             * stochastic depth of the training ViT (vit.py:132-139: x + drop_path(branch), per-sample mask / keep_prob) */
 };
 
 /* bf16 MFMA GEMM (v_mfma_f32_32x32x16_bf16, fp32 accumulate).  Needs K % 64 == 0 (and Cin % 64 == 0 for a_mode 1).
@@ -306,6 +308,9 @@ int whmr_regressor_post_train_bwd(const float* joints, const float* cam, const f
                                   const float* orig_shape, int B, int J, float focal0, float res_w, float res_h, int stage,
                                   const float* d_kp2d, const float* d_kp2d_w, const float* d_cam_t, const float* d_focal, float* d_joints,
                                   float* d_cam, float* d_Tz, void* stream);
+
+/* dst[m, :] = scale[m] * src[m, :] (fp32 -> fp32 / bf16): stochastic-depth mask on the gradient entering a branch (autograd of vit.py:132-139). */
+int whmr_scale_rows_cast(const float* src, const float* scale, void* dst, int M, int C, int out_bf16, void* stream);
 
 #ifdef __cplusplus
 }

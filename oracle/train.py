@@ -74,11 +74,12 @@ def regressor_forward_train(sd, assets, i, x, bbox_info, Tz, orig_shape, center,
     return out, x
 
 
-def whmr_forward_train(sd, assets, x, center, scale, bbox_height, orig_shape, bbox_info, stage=2, stats=None, dp_out=None):
+def whmr_forward_train(sd, assets, x, center, scale, bbox_height, orig_shape, bbox_info, stage=2, stats=None, dp_out=None,
+                       drop_masks=None, drop_path_rate=0.0):
     """-> list of the 4 ``smpl_out`` dicts (mean-pose mesh + 3 stages).  ``stats`` (dict, optional) receives the updated BN running stats,
     ``dp_out`` (list, optional) the IUV head's output dict."""
     B = x.shape[0]
-    s_feat = vit_forward(sd, x, 'feature_extractor.backbone.')
+    s_feat = vit_forward(sd, x, 'feature_extractor.backbone.', drop_masks=drop_masks, drop_path_rate=drop_path_rate)   # stochastic depth (vit.py:132-139)
     smpl_out = OW.regressor_forward_init(sd, assets, B)
     outs, fmaps = [smpl_out], []
     for i in range(3):

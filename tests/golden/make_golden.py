@@ -184,12 +184,24 @@ class VJS(nn.Module):
         return OS.vertex_joint_selector(vertices, joints)
 
 
+DROP_QUEUE = []      # make_golden_train.py: per-call [B] keep masks for the stub of timm's drop_path (empty -> identity, as in eval mode)
+
+
+def drop_path_stub(x, drop_prob=0., training=False):
+    """timm.models.layers.drop_path [3P timm 0.4.9, restated]: mask = floor(keep_prob + rand(B, 1, ..)); x / keep_prob * mask.  The random
+    draw is replaced by a queue of pre-drawn masks so that the oracle can be run on exactly the same masks."""
+    if drop_prob == 0. or not training or not DROP_QUEUE:
+        return x
+    mask = DROP_QUEUE.pop(0).to(x.dtype).view((x.shape[0],) + (1,) * (x.ndim - 1))
+    return x.div(1 - drop_prob) * mask
+
+
 def install_stubs():
     _mod('yacs')
     _mod('yacs.config', CfgNode=CfgNode)
     _mod('timm')
     _mod('timm.models')
-    _mod('timm.models.layers', drop_path=lambda x, p=0., training=False: x,
+    _mod('timm.models.layers', drop_path=drop_path_stub,
          to_2tuple=lambda v: v if isinstance(v, tuple) else (v, v), trunc_normal_=nn.init.trunc_normal_)
     _mod('timm.models.vision_transformer', Block=TimmBlock)
     _mod('torchvision')

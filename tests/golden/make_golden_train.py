@@ -72,8 +72,20 @@ def main():
     def rel(a, b):
         return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-12)
 
-    for stage in (2, 1):
+    # third run: TRAIN.STAGE 2 WITH stochastic depth (vit.py:132-139,233; drop_path_rate 0.3): seeded keep masks, fed to the reference through
+    # the drop_path stub's queue (block 0 has dpr = 0 -> nn.Identity, no call) and to the oracle as ``drop_masks``
+    depth, rate = 12, 0.3
+    gen = torch.Generator().manual_seed(11)
+    dpr = torch.linspace(0, rate, depth)
+    drop_masks = torch.floor((1 - dpr).repeat_interleave(2).view(-1, 1) + torch.rand(2 * depth, 2, generator=gen))
+    assert 0 < drop_masks[2:].sum() < drop_masks[2:].numel()              # some branches dropped, some kept
+    fixture['drop_masks'] = drop_masks.numpy().copy()
+    for stage, with_dp in ((2, False), (1, False), (2, True)):
         cfg.TRAIN.STAGE = stage
+        tag = 'stage%d%s' % (stage, '_droppath' if with_dp else '')
+        del MG.DROP_QUEUE[:]
+        if with_dp:
+            MG.DROP_QUEUE.extend(drop_masks[i] for i in range(2, 2 * depth))
         res = net.load_state_dict(sd, strict=False)
         assert not res.unexpected_keys and not res.missing_keys
         net.train()
@@ -96,15 +108,17 @@ def main():
 
         p = {k: (v.clone().requires_grad_(True) if k in keys else v) for k, v in sd.items()}
         stats, dp = {}, []
+        assert not MG.DROP_QUEUE                     # the reference consumed every mask: 2 per block with dpr > 0
         outs = OT.whmr_forward_train(p, MG.ASSETS, inp['x'], inp['center'], inp['scale'], inp['bbox_height'], inp['orig_shape'],
-                                     inp['bbox_info'], stage=stage, stats=stats, dp_out=dp)
+                                     inp['bbox_info'], stage=stage, stats=stats, dp_out=dp,
+                                     drop_masks=drop_masks if with_dp else None, drop_path_rate=rate if with_dp else 0.0)
         loss = OT.cotangent_loss(outs)
         loss_dp = OT.dp_cotangent_loss(dp[0])
         (loss + loss_dp).backward()
         for k in dp[0]:
             assert rel(dp[0][k].detach(), dp_cap[0][k].detach()) < 2e-5, k
         assert abs(loss_dp.item() - loss_dp_ref.item()) < 1e-5 * max(1.0, abs(loss_dp_ref.item()))
-        print('TRAIN.STAGE %d: loss reference %.8f oracle %.8f' % (stage, loss_ref.item(), loss.item()))
+        print('TRAIN.STAGE %d%s: loss reference %.8f oracle %.8f' % (stage, ' + stochastic depth' if with_dp else '', loss_ref.item(), loss.item()))
         assert abs(loss_ref.item() - loss.item()) < 1e-5 * max(1.0, abs(loss_ref.item()))
         for l in range(3):
             for k in OT.TRAIN_LOSS_KEYS + ('theta', 'pred_cam_t', 'smpl_kp_3d', 'markers'):
@@ -127,14 +141,14 @@ def main():
         untouched = [k for k, q in ref_named.items() if q.grad is None and not k.startswith('cam_model')]
         print('  outputs, running stats and %d parameter gradients agree (worst max-rel %.2e); no gradient in the reference for: %s'
               % (len(keys), worst, sorted(set(k.split('.')[0] for k in untouched))))
-        fixture['loss_stage%d' % stage] = np.array(loss_ref.item())
-        fixture['loss_dp_stage%d' % stage] = np.array(loss_dp_ref.item())
-        fixture['grad_norm_sum_stage%d' % stage] = np.array([[ref_named[k].grad.double().norm().item(), ref_named[k].grad.double().sum().item()]
+        fixture['loss_%s' % tag] = np.array(loss_ref.item())
+        fixture['loss_dp_%s' % tag] = np.array(loss_dp_ref.item())
+        fixture['grad_norm_sum_%s' % tag] = np.array([[ref_named[k].grad.double().norm().item(), ref_named[k].grad.double().sum().item()]
                                                              for k in keys])
         for k in FULL_KEYS:
-            fixture['grad_stage%d/%s' % (stage, k)] = ref_named[k].grad.numpy().copy()
+            fixture['grad_%s/%s' % (tag, k)] = ref_named[k].grad.numpy().copy()
         for k in stats:
-            fixture['stat_stage%d/%s' % (stage, k)] = ref_state[k].numpy().copy()
+            fixture['stat_%s/%s' % (tag, k)] = ref_state[k].numpy().copy()
     np.savez_compressed(os.path.join(HERE, 'whmr_train_b2.npz'), **fixture)
     print('wrote whmr_train_b2.npz')
 

@@ -202,10 +202,12 @@ def test_crop_oracle_known_answers():
     assert np.allclose(t[0], (img[..., 0] / 255.0 - 0.485) / 0.229, atol=1e-6)
 
 
-def test_train_oracle_matches_reference_fixture(assets, state_dict):
+@pytest.mark.parametrize('droppath', [False, True])
+def test_train_oracle_matches_reference_fixture(assets, state_dict, droppath):
     """oracle/train.py (training-mode forward + torch autograd) against tests/golden/whmr_train_b2.npz, which holds the imported
     reference's loss, per-parameter gradient (norm, sum) pairs, a few full gradients and the BatchNorm running statistics after the step
-    (tests/golden/make_golden_train.py).  TRAIN.STAGE 2 (the configs/pymaf_config.yaml default)."""
+    (tests/golden/make_golden_train.py).  TRAIN.STAGE 2 (the configs/pymaf_config.yaml default); ``droppath``: the run with stochastic depth
+    (vit.py:132-139,233, drop_path_rate 0.3) on the keep masks the fixture stores -- the reference consumed the same masks."""
     import os
     import numpy as np
     from oracle import synth
@@ -216,12 +218,16 @@ def test_train_oracle_matches_reference_fixture(assets, state_dict):
     inp = synth.make_inputs(2, 0)
     p = {k: (v.clone().requires_grad_(True) if k in keys else v) for k, v in state_dict.items()}
     stats, dp = {}, []
+    tag = 'stage2_droppath' if droppath else 'stage2'
+    masks = torch.from_numpy(fx['drop_masks']) if droppath else None
     outs = OT.whmr_forward_train(p, assets, inp['x'], inp['center'], inp['scale'], inp['bbox_height'], inp['orig_shape'], inp['bbox_info'],
-                                 stage=2, stats=stats, dp_out=dp)
+                                 stage=2, stats=stats, dp_out=dp, drop_masks=masks, drop_path_rate=0.3 if droppath else 0.0)
     loss, loss_dp = OT.cotangent_loss(outs), OT.dp_cotangent_loss(dp[0])
     (loss + loss_dp).backward()
-    assert abs(loss.item() - float(fx['loss_stage2'])) < 1e-5 and abs(loss_dp.item() - float(fx['loss_dp_stage2'])) < 1e-5
-    ns = fx['grad_norm_sum_stage2']
+    assert abs(loss.item() - float(fx['loss_' + tag])) < 1e-5 and abs(loss_dp.item() - float(fx['loss_dp_' + tag])) < 1e-5
+    if droppath:
+        assert abs(float(fx['loss_stage2_droppath']) - float(fx['loss_stage2'])) > 1e-4       # the masks really change the function
+    ns = fx['grad_norm_sum_' + tag]
     for i, k in enumerate(keys):
         g = p[k].grad.double()
         if ns[i, 0] < 1e-8:
@@ -229,11 +235,11 @@ def test_train_oracle_matches_reference_fixture(assets, state_dict):
             continue
         assert abs(g.norm().item() - ns[i, 0]) < 2e-4 * ns[i, 0], k
     for name in fx.files:
-        if name.startswith('grad_stage2/'):
+        if name.startswith('grad_%s/' % tag):
             k = name.split('/', 1)[1]
             ref = torch.from_numpy(fx[name])
             assert ((p[k].grad - ref).abs().max() / ref.abs().max()).item() < 5e-4, k
-        if name.startswith('stat_stage2/'):
+        if name.startswith('stat_%s/' % tag):
             k = name.split('/', 1)[1]
             ref = torch.from_numpy(fx[name])
             assert ((stats[k] - ref).abs().max() / ref.abs().max().clamp_min(1e-12)).item() < 2e-5, k

@@ -328,6 +328,9 @@ def _train_model(assets, state_dict, numerics, dev):
     for mod in m.modules():                     # dropout masks are random draws: parity runs use p = 0 on both sides
         if isinstance(mod, torch.nn.Dropout):
             mod.p = 0.0
+    # stochastic depth: the plain parity runs switch it off on both sides (rate 0 = the oracle without masks); test_*_stochastic_depth
+    # below injects the SAME keep masks on both sides instead
+    m.feature_extractor.backbone.drop_path_rate = 0.0
     return m
 
 
@@ -624,3 +627,85 @@ def test_regressor_post_node_matches_tensor_arithmetic(dev, stage):
     sum((o * c).sum() for o, c in zip(out_h, cots)).backward()
     for a, b, name in zip(leaves_h, leaves_r, ('joints', 'cam', 'Tz')):
         assert _rel(a.grad, b.grad) < 1e-4, (name, _rel(a.grad, b.grad))
+
+
+@pytest.mark.parametrize('numerics,tol', [('fp32', 2e-4), ('bf16', 4e-2)])
+def test_vit_backward_stochastic_depth(dev, numerics, tol):
+    """Stochastic depth of the training ViT (vit.py:132-139,233: x + drop_path(branch), per-sample keep mask / keep_prob, dpr = linspace(0, rate,
+    depth)): output and every parameter gradient of a depth-3 ViT-B with injected masks against torch autograd through the oracle on the
+    same masks; a dropped sample's branch contributes nothing (its tokens equal the skip path), and fresh draws keep ~keep_prob of them."""
+    from oracle import synth
+    from oracle.vit import vit_forward
+    from whmr_amd.models.pose_vit import ViT
+    size, depth, rate, B = (64, 48), 3, 0.5, 4
+    sd = synth.make_vit_state(3, size, depth=depth)
+    x = synth.make_inputs(B, 9, size)['x']
+    G = torch.randn(B, 768, 4, 3, generator=torch.Generator().manual_seed(4))
+    masks = torch.tensor([[1, 1, 1, 1], [1, 1, 1, 1], [1, 0, 1, 1], [0, 1, 1, 0], [0, 0, 1, 1], [1, 1, 0, 0]], dtype=torch.float32)   # [2*depth, B]
+    ref_sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref_out = vit_forward(ref_sd, x, depth=depth, drop_masks=masks, drop_path_rate=rate)
+    (ref_out * G).sum().backward()
+    m = ViT(img_size=size, depth=depth, qkv_bias=True, numerics=numerics, drop_path_rate=rate)
+    assert [round(v, 6) for v in m.dpr] == [0.0, 0.25, 0.5]
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev).train()
+    m.drop_masks = masks
+    out = m(x.to(dev))
+    assert _rel(out.detach().cpu(), ref_out.detach()) < (1e-4 if numerics == 'fp32' else 3e-2)
+    (out * G.to(dev)).sum().backward()
+    bad = {}
+    for name, p in m.named_parameters():
+        e = _rel(p.grad.cpu(), ref_sd[name].grad)
+        if not e < tol:
+            bad[name] = e
+    assert not bad, 'gradient mismatch: %s' % sorted(bad.items(), key=lambda kv: -kv[1])[:6]
+    # identity masks at rate 0 == eval path; at rate > 0 the masked run must differ from it
+    m.eval()
+    with torch.no_grad():
+        assert _rel(m(x.to(dev)), out.detach()) > 1e-2
+    # fresh draws: Bernoulli(keep_prob) per (branch, sample); block 0 (dpr 0) never drops
+    m.train()
+    m.drop_masks = None
+    from whmr_amd.train.vit_autograd import vit_forward_train
+    torch.manual_seed(0)
+    kept = []
+    for _ in range(20):
+        _, saved = vit_forward_train(m, x.to(dev))
+        assert saved.layers[0].rs_attn is None
+        kept.append(torch.stack([(saved.layers[2].rs_attn > 0).float().mean(), (saved.layers[2].rs_mlp > 0).float().mean()]))
+        assert set(saved.layers[2].rs_attn.unique().tolist()) <= {0.0, 2.0}              # 0 or 1 / keep_prob
+    assert 0.3 < torch.stack(kept).mean().item() < 0.7
+
+
+def test_whmr_train_step_stochastic_depth_matches_oracle(dev, assets, state_dict):
+    """the whole training step with the reference's stochastic depth (ViTPose-B drop_path_rate 0.3) on the keep masks of the fixture: loss
+    against the imported reference's value (tests/golden/whmr_train_b2.npz) and backbone / head gradients against the oracle's autograd"""
+    import numpy as np
+    import os
+    from conftest import GOLDEN
+    from oracle import synth
+    from oracle import train as OT
+    fx = np.load(os.path.join(GOLDEN, 'whmr_train_b2.npz'))
+    masks = torch.from_numpy(fx['drop_masks'])
+    inp = synth.make_inputs(2, 0)
+    keys = _grad_keys(state_dict)
+    p = {k: (v.clone().requires_grad_(True) if k in keys else v) for k, v in state_dict.items()}
+    dp_ref = []
+    outs_ref = OT.whmr_forward_train(p, assets, inp['x'], inp['center'], inp['scale'], inp['bbox_height'], inp['orig_shape'], inp['bbox_info'],
+                                     stage=2, dp_out=dp_ref, drop_masks=masks, drop_path_rate=0.3)
+    (OT.cotangent_loss(outs_ref) + OT.dp_cotangent_loss(dp_ref[0])).backward()
+    m = _train_model(assets, state_dict, 'fp32', dev)
+    vit = m.feature_extractor.backbone
+    vit.drop_path_rate = 0.3
+    vit.drop_masks = masks
+    assert abs(vit.dpr[-1] - 0.3) < 1e-6 and vit.dpr[0] == 0.0
+    d = {k: inp[k].to(dev) for k in ('x', 'center', 'scale', 'bbox_height', 'orig_shape', 'bbox_info')}
+    out_list, _ = m(d['x'], None, d['center'], d['scale'], d['bbox_height'], d['orig_shape'], d['bbox_info'], is_train=True)
+    loss = OT.cotangent_loss(out_list['smpl_out'], dev=dev)
+    (loss + OT.dp_cotangent_loss(out_list['dp_out'][0], dev=dev)).backward()
+    assert abs(loss.item() - float(fx['loss_stage2_droppath'])) < 1e-4 * max(1.0, abs(float(fx['loss_stage2_droppath'])))
+    assert abs(loss.item() - float(fx['loss_stage2'])) > 1e-4                            # not the function without stochastic depth
+    named = dict(m.named_parameters())
+    for k in ('feature_extractor.backbone.blocks.5.attn.proj.weight', 'feature_extractor.backbone.blocks.11.mlp.fc2.bias',
+              'feature_extractor.backbone.blocks.0.attn.qkv.weight', 'feature_extractor.backbone.pos_embed', 'regressor.2.deccam.weight'):
+        assert _rms(named[k].grad.cpu(), p[k].grad) < 1e-2, k

@@ -25,7 +25,7 @@ class WhmrGemm(C.Structure):
                 ('c_off', C.c_int64), ('osb', C.c_int64), ('osy', C.c_int64), ('osx', C.c_int64),
                 ('workspace', C.c_void_p), ('workspace_bytes', C.c_int64),
                 ('n_phase', C.c_int32), ('epi_flags', C.c_int32),
-                ('phase_w_stride', C.c_int64), ('phase_cy', C.c_int64), ('phase_cx', C.c_int64), ('split_k', C.c_int64)]
+                ('phase_w_stride', C.c_int64), ('phase_cy', C.c_int64), ('phase_cx', C.c_int64), ('split_k', C.c_int64), ('row_scale', C.c_void_p)]
 
 
 class WhmrGemmBlk(C.Structure):
@@ -100,6 +100,7 @@ _SIGS = {
     'whmr_csr_apply3': [_P, _P, _P, _P, _I, _P, _I, _I, _I, _P],
     'whmr_regressor_post_train': [_P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P],
     'whmr_regressor_post_train_bwd': [_P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P, _P],
+    'whmr_scale_rows_cast': [_P, _P, _P, _I, _I, _I, _P],
     'whmr_maxpool_nhwc': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'whmr_avgpool_nhwc': [_P, _P, _I, _I, _I, _I, _P],
 }
@@ -163,7 +164,7 @@ PROFILE = None        # bench.py sets this to a list: (kernel, flops, start_even
 
 
 def gemm(a, w, out, bias=None, residual=None, res_row_mod=0, act=ACT_NONE, conv=None, scatter=None, M=None,
-         lda=None, glds=True, tile=None, phases=None, res_first=False, splits=None):
+         lda=None, glds=True, tile=None, phases=None, res_first=False, splits=None, row_scale=None):
     """out = act(a . w^T + bias) + residual.  a/w dtype selects the kernel (bf16 MFMA or exact-fp32 MFMA).
 
     conv = dict(IH, IW, Cin, OH, OW, KW, SH, SW, PH, PW): a is an NHWC image [B, IH, IW, Cin], rows are output pixels.
@@ -187,6 +188,10 @@ def gemm(a, w, out, bias=None, residual=None, res_row_mod=0, act=ACT_NONE, conv=
         assert residual.dtype == torch.float32 or a.dtype == torch.bfloat16, 'bf16 residuals exist in the bf16 kernel only'
     p.res_row_mod = res_row_mod
     p.act = act
+    if row_scale is not None:           # out = residual + row_scale[m] * act(a . w^T + bias): stochastic depth (vit.py:132-139)
+        _dev(row_scale)
+        assert row_scale.dtype == torch.float32 and row_scale.is_contiguous() and not res_first and out.dtype == torch.float32
+        p.row_scale = row_scale.data_ptr()
     assert out.dtype in (torch.bfloat16, torch.float32)
     p.out_bf16 = int(out.dtype == torch.bfloat16)
     if conv is not None:
@@ -311,6 +316,16 @@ def attention_blk(qkv, out, B, N, H, scale):
     assert qkv.is_contiguous() and out.is_contiguous() and qkv.dtype == torch.bfloat16 and out.dtype == torch.bfloat16
     _check(lib().whmr_attention_blk(qkv.data_ptr(), out.data_ptr(), B, N, H, scale, _stream()), 'whmr_attention_blk')
     return out
+
+
+def scale_rows_cast(src, scale, dtype):
+    """(dtype)(scale[m] * src[m, :]) for an fp32 [M, C] matrix -- stochastic-depth mask on a gradient, fused with the operand cast"""
+    _dev(src, scale)
+    assert src.dtype == torch.float32 and src.is_contiguous() and scale.dtype == torch.float32 and scale.numel() == src.shape[0]
+    dst = torch.empty(src.shape, dtype=dtype, device=src.device)
+    _check(lib().whmr_scale_rows_cast(src.data_ptr(), scale.data_ptr(), dst.data_ptr(), src.shape[0], src.shape[1], int(dtype == torch.bfloat16),
+                                      _stream()), 'whmr_scale_rows_cast')
+    return dst
 
 
 def layernorm(x, weight, bias, out, eps):

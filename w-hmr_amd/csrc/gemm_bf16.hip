@@ -42,6 +42,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const whmr_gemm p,
         if (p.epi_flags & 2) v[e] += r[e];
         if (p.act == 1) v[e] = gelu_fast(v[e]);
         else if (p.act == 2) v[e] = fmaxf(v[e], 0.f);
+        if (p.row_scale) v[e] *= p.row_scale[m];
         if (!(p.epi_flags & 2)) v[e] += r[e];
     }
     const size_t off = (size_t)m * p.ldc + n;
@@ -74,7 +75,7 @@ extern "C" int whmr_gemm_bf16_split(const whmr_gemm* pp, int tile, int splits_in
     const long kps = ((p.K / 64 + splits - 1) / splits) * 64;
     splits = (p.K + kps - 1) / kps;
     whmr_gemm q = p;
-    q.C = p.workspace; q.out_bf16 = 0; q.act = 0; q.bias = nullptr; q.residual = nullptr; q.epi_flags = p.epi_flags & 8; q.ldc = p.N;    // bit 3 (K order of the gather) belongs to the main loop
+    q.C = p.workspace; q.out_bf16 = 0; q.act = 0; q.bias = nullptr; q.residual = nullptr; q.row_scale = nullptr; q.epi_flags = p.epi_flags & 8; q.ldc = p.N;    // bit 3 (K order of the gather) belongs to the main loop
     q.split_k = kps;
     const int rc = whmr_gemm_bf16_big(&q, tile, stream);
     if (rc) return rc;

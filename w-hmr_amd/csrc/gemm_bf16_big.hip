@@ -416,7 +416,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
     if constexpr (OUT_BF16) {
         // bf16 skip tensor (ResNet); a GELU that must follow the skip add stays on the fp32-slab path
         const bool skip16 = p.residual && (p.epi_flags & 1) && !(p.ldr & 7) && p.res_row_mod <= 0 && p.res_row_mod != -2003 && !(ACT == 1 && (p.epi_flags & 2));
-        if ((!p.residual || skip16) && !p.split_k && !(p.N & 7) && (p.c_mode == 1 || !(p.ldc & 7))) {
+        if ((!p.residual || skip16) && !p.row_scale && !p.split_k && !(p.N & 7) && (p.c_mode == 1 || !(p.ldc & 7))) {
             const bool act_late = skip16 && (p.epi_flags & 2);               // ResNet: the skip is added BEFORE the activation -> activate in the store loop
             constexpr int ROWB = cfg::EPI16_ROW, GP = cfg::GP16, CPRW = BN / 8, RPI2 = cfg::THREADS / CPRW;
             void* const Cout16 = p.C;
@@ -590,6 +590,11 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
                     float v[CPT];
                     load_raw(it * RPI + rsub, v);
                     if (!res_first) activate(v);
+                    if (p.row_scale) {                                   // stochastic depth: per-row factor on the branch before the skip is added
+                        const float rs = m < m_end ? p.row_scale[m] : 0.f;
+#pragma unroll
+                        for (int e = 0; e < CPT; ++e) v[e] *= rs;
+                    }
                     if (res_bf16) {
                         const uint32_t w[4] = {rv[it][0].x, rv[it][0].y, rv[it][0].z, rv[it][0].w};
 #pragma unroll
@@ -639,6 +644,11 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
             float v[CPT];
             load_raw(it * RPI + rsub, v);
             if (!res_first) activate(v);
+            if (p.row_scale) {
+                const float rs = p.row_scale[m];
+#pragma unroll
+                for (int e = 0; e < CPT; ++e) v[e] *= rs;
+            }
             if (res) {                              // fp32 or bf16 skip tensor, added after (ViT) or before (ResNet) the activation
                 const size_t roff = (size_t)(p.res_row_mod > 0 ? m % p.res_row_mod : m) * p.ldr + ncol;
                 if (res_bf16 && vec_ok && (p.ldr % CPT) == 0) {          // one 16-B (8-B) load of CPT bf16 skip values

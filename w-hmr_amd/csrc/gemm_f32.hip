@@ -118,6 +118,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const whmr_gemm p, int k_
         if (p.epi_flags & 2) v += rv;                 // ResNet bottleneck: skip added before the ReLU
         if (p.act == 1) v = gelu_erf(v);
         else if (p.act == 2) v = fmaxf(v, 0.f);
+        if (p.row_scale) v *= p.row_scale[m];
         if (!(p.epi_flags & 2)) v += rv;
         size_t off;
         if (p.c_mode == 1) {
@@ -228,6 +229,7 @@ __global__ __launch_bounds__(256) void gemm_f32_skinny_kernel(const whmr_gemm p,
         if (p.epi_flags & 2) v += rv;
         if (p.act == 1) v = gelu_erf(v);
         else if (p.act == 2) v = fmaxf(v, 0.f);
+        if (p.row_scale) v *= p.row_scale[m];
         if (!(p.epi_flags & 2)) v += rv;
         const size_t off = (size_t)m * p.ldc + n;
         if (p.out_bf16) ((bf16_t*)p.C)[off] = f32_to_bf16(v);
@@ -257,6 +259,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const whmr_gemm p, i
     if (p.epi_flags & 2) v += rv;
     if (p.act == 1) v = gelu_erf(v);
     else if (p.act == 2) v = fmaxf(v, 0.f);
+    if (p.row_scale) v *= p.row_scale[m];
     if (!(p.epi_flags & 2)) v += rv;
     const size_t off = (size_t)m * p.ldc + n;
     if (p.out_bf16) ((bf16_t*)p.C)[off] = f32_to_bf16(v);

@@ -30,4 +30,6 @@ struct whmr_gemm {
                              * exceeds the Infinity Cache is re-read from cache instead of HBM (Tz-head 7x7 s3 conv) */
     int64_t phase_w_stride, phase_cy, phase_cx;
     int64_t split_k;        /* internal (set by the bf16 launcher, pass 0): K elements per split-K slice, blockIdx.z = slice */
+    const float* row_scale; /* optional [M]: act(acc + bias) is multiplied by row_scale[m] BEFORE the (post-activation) residual is added --
+                             * stochastic depth of the training ViT (vit.py:132-139: x + drop_path(branch), per-sample mask / keep_prob) */
 };

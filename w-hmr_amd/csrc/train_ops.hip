@@ -424,3 +424,24 @@ extern "C" int whmr_transpose_colsum(const void* src, long ld_src, void* dst, lo
     WHMR_CHECK_LAUNCH();
     return 0;
 }
+
+// dst[m, :] = (T)(scale[m] * src[m, :]): the stochastic-depth mask applied to the residual-stream gradient that enters a dropped branch's
+// backward (autograd of vit.py:132-139: d branch = mask / keep_prob * d out), fused with the cast to the GEMM operand dtype.
+__global__ __launch_bounds__(256) void scale_rows_cast_kernel(const float* __restrict__ src, const float* __restrict__ scale, void* __restrict__ dst,
+                                                              int M, int C4, int out_bf16) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)M * C4) return;
+    const int m = (int)(idx / C4);
+    const float s = scale[m];
+    const float4 v = *(const float4*)(src + idx * 4);
+    if (out_bf16) *(uint2*)((bf16_t*)dst + idx * 4) = make_uint2(pack_bf16x2(v.x * s, v.y * s), pack_bf16x2(v.z * s, v.w * s));
+    else *(float4*)((float*)dst + idx * 4) = make_float4(v.x * s, v.y * s, v.z * s, v.w * s);
+}
+
+extern "C" int whmr_scale_rows_cast(const float* src, const float* scale, void* dst, int M, int C, int out_bf16, void* stream) {
+    if (M <= 0 || C <= 0 || (C & 3)) return (int)hipErrorInvalidValue;
+    const long n4 = (long)M * (C >> 2);
+    hipLaunchKernelGGL(scale_rows_cast_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, scale, dst, M, C >> 2, out_bf16);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}

@@ -64,6 +64,10 @@ class ViT(nn.Module):
         self.depth, self.num_heads = depth, num_heads
         self.scale = qk_scale or (embed_dim // num_heads) ** -0.5
         self.numerics = numerics
+        # stochastic depth (vit.py:233): block i drops each of its two residual branches per SAMPLE with probability dpr[i] in training mode
+        self.drop_path_rate = float(drop_path_rate)
+        self.dpr = [v.item() for v in torch.linspace(0, drop_path_rate, depth)]
+        self.drop_masks = None              # test hook: [2*depth, B] 0/1 keep masks used instead of fresh draws (row 2i attention, 2i+1 MLP)
         self.patch_pad = 4 + 2 * (ratio // 2 - 1)                       # vit.py:157 -> 2
         num_patches = (img_size[0] // ps[0]) * (img_size[1] // ps[1])
         self.patch_embed = _Holder()

@@ -14,7 +14,11 @@ driven by ``core/trainer.py:410-470`` (loss.backward()).  Here the backward pass
 
 ``numerics='fp32'`` (exact-f32 MFMA) is the parity mode against the CPU reference's autograd; ``'bf16'`` casts GEMM operands
 to bf16 and keeps the residual-stream gradient, LayerNorm statistics and all weight gradients in fp32.
-drop_path / dropout are identities here (the reference's drop_path_rate only matters for its own training recipe).
+Stochastic depth (vit.py:132-139,233; drop_path_rate 0.3 for ViTPose-B, 0.5 for -L): in training mode block i multiplies each of its two
+residual branches by a per-sample mask / keep_prob (keep_prob = 1 - linspace(0, rate, depth)[i]).  The factor rides in the proj / fc2
+GEMM epilogue (``row_scale``) and, in the backward pass, in the cast that makes the GEMM operand out of the residual-stream gradient
+(``whmr_scale_rows_cast``).  Masks are drawn with torch's generator on the device (``ViT.drop_masks`` injects them in tests).
+The Dropout layers of the reference ViT have p = 0 (drop_rate / attn_drop_rate defaults).
 """
 import torch
 
@@ -57,8 +61,20 @@ def vit_forward_train(m, x):
     L.gemm(s.cols, m._w(m.patch_embed.proj.weight, (D, Cin * P * P)), t, bias=m.patch_embed.proj.bias, residual=pos, res_row_mod=N)
     s.layers = []
     hidden = m.blocks[0].mlp.fc1.weight.shape[0] if m.depth else 0
-    for blk in m.blocks:
+    # stochastic depth: one [2*depth, B] draw per forward (timm drop_path: mask = floor(keep_prob + U[0,1))), expanded to token rows
+    masks = None
+    if m.training and m.drop_path_rate > 0.0:
+        masks = m.drop_masks.to(dev).float() if m.drop_masks is not None else None
+        if masks is None:
+            keep = 1.0 - torch.tensor(m.dpr, **f32).repeat_interleave(2).view(-1, 1)
+            masks = torch.floor(keep + torch.rand(2 * m.depth, B, **f32))
+    for li, blk in enumerate(m.blocks):
         a = _Saved()
+        a.rs_attn = a.rs_mlp = None
+        if masks is not None and m.dpr[li] > 0.0:
+            keep = 1.0 - m.dpr[li]
+            a.rs_attn = (masks[2 * li] / keep).repeat_interleave(N).contiguous()         # [M]: row m = (b, n) -> sample b
+            a.rs_mlp = (masks[2 * li + 1] / keep).repeat_interleave(N).contiguous()
         a.t_in = t
         a.h1 = torch.empty(M, D, dtype=dt, device=dev)
         L.layernorm(a.t_in, blk.norm1.weight, blk.norm1.bias, a.h1, 1e-6)
@@ -72,7 +88,7 @@ def vit_forward_train(m, x):
         else:
             L.attention(a.qkv, a.att, B, N, m.num_heads, D // m.num_heads, m.scale)
         a.t_mid = torch.empty(M, D, **f32)
-        L.gemm(a.att, m._w(blk.attn.proj.weight), a.t_mid, bias=blk.attn.proj.bias, residual=a.t_in)
+        L.gemm(a.att, m._w(blk.attn.proj.weight), a.t_mid, bias=blk.attn.proj.bias, residual=a.t_in, row_scale=a.rs_attn)
         a.h2 = torch.empty(M, D, dtype=dt, device=dev)
         L.layernorm(a.t_mid, blk.norm2.weight, blk.norm2.bias, a.h2, 1e-6)
         a.pre = torch.empty(M, hidden, dtype=dt, device=dev)
@@ -80,7 +96,7 @@ def vit_forward_train(m, x):
         a.hid = torch.empty_like(a.pre)
         L.gelu_fwd(a.pre, a.hid)
         t = torch.empty(M, D, **f32)
-        L.gemm(a.hid, m._w(blk.mlp.fc2.weight), t, bias=blk.mlp.fc2.bias, residual=a.t_mid)
+        L.gemm(a.hid, m._w(blk.mlp.fc2.weight), t, bias=blk.mlp.fc2.bias, residual=a.t_mid, row_scale=a.rs_mlp)
         s.layers.append(a)
     s.t_last = t
     out = torch.empty(M, D, **f32)
@@ -149,7 +165,9 @@ def vit_backward(m, s, dout):
     grads[m.last_norm.weight], grads[m.last_norm.bias] = dg, db
     for blk, a in zip(reversed(list(m.blocks)), reversed(s.layers)):
         # t_out = t_mid + fc2(gelu(fc1(LN2(t_mid))))
-        d_hid = linear_bwd(_op(dt_grad, dt), a.hid, blk.mlp.fc2, dx_dtype=dt)             # only feeds the GELU backward: compute dtype
+        # (stochastic depth: the branch sees mask / keep_prob * d t_out; the skip path sees d t_out unchanged)
+        dy = _op(dt_grad, dt) if a.rs_mlp is None else L.scale_rows_cast(dt_grad, a.rs_mlp, dt)
+        d_hid = linear_bwd(dy, a.hid, blk.mlp.fc2, dx_dtype=dt)                            # only feeds the GELU backward: compute dtype
         d_pre = torch.empty(M, a.pre.shape[1], dtype=dt, device=dev)
         L.gelu_bwd(a.pre, d_hid, d_pre)
         d_h2 = linear_bwd(d_pre, a.h2, blk.mlp.fc1)
@@ -157,7 +175,8 @@ def vit_backward(m, s, dout):
         L.layernorm_bwd(a.t_mid, d_h2, blk.norm2.weight, dt_grad, dt_grad, dg, db, 1e-6)   # dt_grad now = d t_mid
         grads[blk.norm2.weight], grads[blk.norm2.bias] = dg, db
         # t_mid = t_in + proj(attention(qkv(LN1(t_in))))
-        d_att = linear_bwd(_op(dt_grad, dt), a.att, blk.attn.proj)
+        dy = _op(dt_grad, dt) if a.rs_attn is None else L.scale_rows_cast(dt_grad, a.rs_attn, dt)
+        d_att = linear_bwd(dy, a.att, blk.attn.proj)
         if a.lse is not None:
             d_qkv = torch.empty_like(a.qkv)
             L.attention_bwd(a.qkv, a.att, d_att, a.lse, d_qkv, B, N, m.num_heads, D // m.num_heads, m.scale)
