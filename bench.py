@@ -29,10 +29,10 @@ VIT_FLOP_PER_IMG = {'vit224': 34.94e9, 'vit256x192': 34.20e9, 'vitl256x192': 119
                     'whmr_train': 3 * (34.20e9 + 9.26e9 + 1.98e9 + 5.10e9)}        # + IUV head: 4 3x3 convs, 90 channels on the 128x96 map
 METRIC = {'vit224': 'images/sec ViT-B 224^2 batch-64 fwd', 'vit256x192': 'images/sec ViT-B 256x192 batch-64 fwd',
           'vitl256x192': 'images/sec ViT-L 256x192 fwd',
-          'whmr': 'images/sec full W-HMR fwd (ViT-B + 3-iter MAF loop + orientation) batch-64',
+          'whmr': 'images/sec full W-HMR fwd (ViT-B + 3-iter MAF loop + cam_model + orientation) batch-64',
           'whmr_train': 'images/sec W-HMR train step (fwd + bwd + DP gradient all-reduce + Adam) batch-64 per GPU'}
 WORKLOAD = {'vit224': 'ViT-B/16 backbone forward', 'vit256x192': 'ViT-B/16 backbone forward', 'vitl256x192': 'ViT-L/16 backbone forward',
-            'whmr': 'full W-HMR forward (ViT-B + deconv pyramid + Tz head + 3-iteration MAF/regressor/SMPL loop + global orientation)',
+            'whmr': 'full W-HMR forward (ViT-B + deconv pyramid + Tz head + 3-iteration MAF/regressor/SMPL loop + cam_model ResNet-50 + global orientation)',
             'whmr_train': 'W-HMR training step: WHMR.forward(is_train=True), synthetic loss on the supervised outputs, HIP backward, gradient buckets, fused Adam'}
 
 
@@ -46,6 +46,10 @@ def parse(argv=None):
     ap.add_argument('--numerics', default='bf16')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
     ap.add_argument('--graph', action='store_true', help='whmr_train on one GPU: replay the whole step from one HIP graph')
+    ap.add_argument('--eager', action='store_true', help='whmr: time the eager module call instead of the HIP-graph replay (default: graph)')
+    ap.add_argument('--full-x', default='hoisted', choices=('hoisted', 'per-crop', 'none'),
+                    help='whmr (BASELINE configs[2]): full-frame input of cam_model -- one [1,3,600,800] frame shared by the batch (default), one frame per '
+                         'crop [B,3,600,800] as demo/tester.py:161 replicates it, or none (camera rotation = identity given)')
     ap.add_argument('--ref-1gpu', type=float, default=None, help='images/sec of the same workload on 1 GPU: adds efficiency_vs_1gpu to the line')
     ap.add_argument('--master-port', type=int, default=None, help='rendezvous port of the self-launched ranks (default: a free port)')
     ap.add_argument('--dryrun-cpu', action='store_true', help='tests only: gloo/CPU stand-in step (launcher + rank bookkeeping), not a measurement')
@@ -67,17 +71,32 @@ def build_workload(args, dev):
         x = synth.make_inputs(args.batch, 7, size)['x'].to(dev)
         return (lambda: m(x)), sd, x, size
     if args.workload == 'whmr':
-        # BASELINE configs[2]: full W-HMR forward (ViT-B + deconvs + Tz head + 3-iteration MAF/regressor/SMPL loop +
-        # global orientation), 256x192 crops, camera rotation given (the cam_model ResNet-50 is not a hot-path kernel row)
+        # BASELINE configs[2]: full W-HMR forward = ViT-B + deconvs + Tz head + 3-iteration MAF/regressor/SMPL loop + cam_model (ResNet-50 on
+        # the full frame, whmr.py:509-522) + global orientation, 256x192 crops, 600x800 frames.  The step is replayed from ONE HIP
+        # graph (GraphedForward); the instrumented roofline step and --eager run the plain module call.
         from whmr_amd.models import whmr_net
+        from whmr_amd.graph import GraphedForward
         assets = synth.make_assets(0)
         sd = synth.make_state_dict(0, assets)
         m = whmr_net(None, assets=assets, numerics=args.numerics)
-        m.load_state_dict(sd, strict=False)
+        m.load_state_dict(sd, strict=True)
         m = m.to(dev).eval()
         inp = {k: v.to(dev) for k, v in synth.make_inputs(args.batch, 7).items()}
         a = (inp['x'], None, inp['center'], inp['scale'], inp['bbox_height'], inp['orig_shape'], inp['bbox_info'])
-        return (lambda: m(*a)), None, inp['x'], (256, 192)
+        nf = {'hoisted': 1, 'per-crop': args.batch, 'none': 0}[args.full_x]
+        kw = {}
+        if nf:
+            kw['full_x'] = torch.randn(nf, 3, 600, 800, generator=torch.Generator().manual_seed(11)).to(dev)
+        args.full_x_note = {'hoisted': 'cam_model on ONE 600x800 frame shared by the batch (hoisted: identical result to the per-crop replication of demo/tester.py:161)',
+                            'per-crop': 'cam_model on %d 600x800 frames (one per crop, as demo/tester.py:161 replicates the frame)' % args.batch,
+                            'none': 'no full frame: camera rotation identity (cam_model not in the step)'}[args.full_x]
+        args.parity_ctx = (m, sd, assets, inp, kw)
+        eager = lambda: m(*a, **kw)
+        if args.eager:
+            return eager, None, inp['x'], (256, 192)
+        g = GraphedForward(m, *a, **kw)
+        args.eager_step = eager
+        return (lambda: g.graph.replay()), None, inp['x'], (256, 192)
     if args.workload == 'whmr_train':
         # BASELINE configs[3] (train.py pymaf_net step, batch 64 per GPU, DP gradient all-reduce over RCCL): forward in training mode,
         # a synthetic L2 loss on the tensors core/trainer.py:500-600 supervises, backward through the HIP autograd nodes, bucketed
@@ -201,6 +220,69 @@ def cpu_train_baseline(n_img=4):
     return {'value': n_img / best, 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
             'sample': 'oracle.train.whmr_forward_train + autograd backward + Adam (CPU restatement of the reference training step, fp32), one '
                       'step on %d 256x192 crops (%.1f s), torch threads = %d' % (n_img, best, threads)}
+
+
+def whmr_parity_and_fp32(args, dev, n_sample=2):
+    """whmr workload extras: (1) max-rel error of theta / vertices / projected 2-D joints of the HIP forward against the CPU oracle on the
+    first ``n_sample`` crops of the benchmark batch, in the benchmark numerics and in the fp32 parity mode; (2) ms per step of the fp32 mode."""
+    from oracle import whmr as OW
+    m, sd, assets, inp, kw = args.parity_ctx
+    cpu = {k: v[:n_sample].cpu() for k, v in inp.items()}
+    full = kw['full_x'].cpu() if 'full_x' in kw else None
+    if full is not None:                            # the oracle does not hoist: one frame per crop (the hoisted frame replicated)
+        full = full[:n_sample] if full.shape[0] > 1 else full.expand(n_sample, -1, -1, -1)
+    with torch.no_grad():
+        ref_out, _ = OW.whmr_forward(sd, assets, cpu['x'], cpu['center'], cpu['scale'], cpu['bbox_height'], cpu['orig_shape'], cpu['bbox_info'], full_x=full,
+                                     view='train')
+    ref = ref_out['smpl_out'][-1]
+    res = {}
+
+    def rel(a, b):
+        return ((a.double().cpu() - b.double()).abs().max() / b.double().abs().max()).item()
+    from whmr_amd.models import whmr_net
+    m32 = whmr_net(None, assets=assets, numerics='fp32')
+    m32.load_state_dict(sd, strict=True)
+    m32 = m32.to(dev).eval()
+    for tag, mod in ((args.numerics, m), ('fp32', m32)):
+        d = {k: v[:n_sample] for k, v in inp.items()}
+        k2 = dict(kw)
+        if 'full_x' in k2 and k2['full_x'].shape[0] > 1:
+            k2['full_x'] = k2['full_x'][:n_sample]
+        with torch.no_grad():
+            out, _ = mod(d['x'], None, d['center'], d['scale'], d['bbox_height'], d['orig_shape'], d['bbox_info'], view='train', **k2)
+        o = out['smpl_out'][-1]
+        res[tag] = {k: rel(o[k], ref[k]) for k in ('theta', 'verts', 'kp_2d')}
+    a = (inp['x'], None, inp['center'], inp['scale'], inp['bbox_height'], inp['orig_shape'], inp['bbox_info'])
+    with torch.no_grad():
+        for _ in range(2):
+            m32(*a, **kw)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            m32(*a, **kw)
+        torch.cuda.synchronize()
+    return res, (time.perf_counter() - t0) / 3 * 1e3
+
+
+def cpu_whmr_baseline(args, n_img=4):
+    """CPU leg of the whmr workload: the oracle's full forward (oracle/whmr.py, incl. the ResNet-50 of cam_model on one 600x800 frame) on a
+    bounded sample of ``n_img`` crops"""
+    from oracle import whmr as OW
+    m, sd, assets, inp, kw = args.parity_ctx
+    threads = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    cpu = {k: v[:n_img].cpu() for k, v in inp.items()}
+    full = kw['full_x'][:1].cpu().expand(n_img, -1, -1, -1) if 'full_x' in kw else None     # the reference runs cam_model once per crop
+    best = None
+    with torch.no_grad():
+        for _ in range(2):
+            t0 = time.perf_counter()
+            OW.whmr_forward(sd, assets, cpu['x'], cpu['center'], cpu['scale'], cpu['bbox_height'], cpu['orig_shape'], cpu['bbox_info'], full_x=full)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+    return {'value': n_img / best, 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
+            'sample': 'oracle.whmr.whmr_forward fp32 (CPU restatement of WHMR.forward incl. cam_model on a 600x800 frame per crop, as the reference runs it), %d 256x192 crops (%.1f s), '
+                      'torch threads = %d' % (n_img, best, threads)}
 
 
 def gemm_source_digest():
@@ -398,8 +480,10 @@ def main(argv=None):
             'unit': 'images/sec', 'n_gpus': n_ranks, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': args.numerics, 'data': 'dryrun' if dry else 'synthetic',
-            'config': {'workload': ('%s (%s), %dx%d crops, batch %d per GPU, random-init weights'
-                                    % (WORKLOAD[args.workload], args.workload, size[0], size[1], args.batch)) if not dry else 'dryrun-cpu stand-in',
+            'config': {'workload': ('%s (%s), %dx%d crops, batch %d per GPU, random-init weights%s'
+                                    % (WORKLOAD[args.workload], args.workload, size[0], size[1], args.batch,
+                                       ('; ' + args.full_x_note + ('; eager module call' if args.eager else '; replayed from one HIP graph'))
+                                       if args.workload == 'whmr' else '')) if not dry else 'dryrun-cpu stand-in',
                        'global_batch': n_ranks * args.batch, 'parallelism': par},
         }
         if args.ref_1gpu:
@@ -411,7 +495,13 @@ def main(argv=None):
                                'flops_per_launch': flops_per_launch, 'avg_launch_us': avg_s * 1e6,
                                'traffic': traffic['bytes_per_launch'] if traffic else None,
                                'traffic_note': traffic['note'] if traffic else 'no PMC pass of the current GEMM sources committed'}
-            if not args.no_cpu and n_ranks == 1 and training:
+            if args.workload == 'whmr' and n_ranks == 1:
+                res['parity'], res['fp32_ms_per_step'] = whmr_parity_and_fp32(args, dev)
+                res['parity_note'] = 'max-rel error of the last regressor stage (theta [B,85], vertices [B,6890,3], kp_2d [B,49,2]) vs the CPU oracle on the ' \
+                                     'first 2 crops of the batch; fp32_ms_per_step = the same step in the fp32 parity numerics (eager)'
+            if not args.no_cpu and n_ranks == 1 and args.workload == 'whmr':
+                res['cpu_baseline'] = cpu_whmr_baseline(args)
+            elif not args.no_cpu and n_ranks == 1 and training:
                 res['cpu_baseline'] = cpu_train_baseline()
             elif not args.no_cpu and n_ranks == 1 and sd is not None:
                 res['cpu_baseline'] = cpu_baseline(sd, x.cpu(), size, 16 if args.workload == 'vitl256x192' else 12)

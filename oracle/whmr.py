@@ -187,14 +187,20 @@ PITCH_RANGE = (-0.6, 0.6)        # utils/cam_utils.py:38
 ROLL_RANGE = (-0.6, 0.6)         # utils/cam_utils.py:139
 
 
-def cam_model_forward(sd, full_x):
-    """cam_model.py:72-81 + cam_utils.py:121-145 (softargmax_l2) + whmr.py:515-522 -> (cam_rotmat, render_rotmat)."""
+def cam_model_forward(sd, full_x, taps=None):
+    """cam_model.py:72-81 + cam_utils.py:121-145 (softargmax_l2) + whmr.py:515-522 -> (cam_rotmat, render_rotmat).
+    ``taps`` (dict) receives the pooled features [B,2048], the three [B,256] logit vectors and the angles."""
     f = resnet50_features(sd, full_x, 'cam_model.backbone.')
     f = f.mean(dim=(2, 3))
     ang = []
+    if taps is not None:
+        taps['feat'] = f
     for name, (lo, hi) in (('vfov', VFOV_RANGE), ('pitch', PITCH_RANGE), ('roll', ROLL_RANGE)):
-        sidx = softargmax1d(F.linear(f, sd['cam_model.fc_%s.weight' % name], sd['cam_model.fc_%s.bias' % name]))
+        logits = F.linear(f, sd['cam_model.fc_%s.weight' % name], sd['cam_model.fc_%s.bias' % name])
+        sidx = softargmax1d(logits)
         ang.append((hi - lo) * ((sidx + 1) / 2) + lo)
+        if taps is not None:
+            taps['logits_' + name], taps['angle_' + name] = logits, ang[-1]
     pitch, roll = ang[1].unsqueeze(-1), ang[2].unsqueeze(-1)
     z = torch.zeros_like(pitch)
     return (G.batch_euler2matrix(torch.cat([pitch, z, roll], 1).float()),

@@ -83,6 +83,37 @@ def test_reference_checkpoint_adapter(assets, state_dict):
         load_reference_state_dict(m, bad, verbose=False)
 
 
+def test_strict_load_of_a_reference_shaped_checkpoint(assets, state_dict):
+    """demo/tester.py:64-65: ``model.load_state_dict(ckpt['model'], strict=True)`` unchanged, on a checkpoint that also carries the
+    smplx / pare internals of the reference's Regressor (regressor.N.smpl.*, regressor.N.vertex_joint_selector.*)"""
+    from whmr_amd.models import whmr_net
+    m = whmr_net(None, assets=assets)
+    ckpt = {k: v.clone() for k, v in state_dict.items()}
+    for n in range(3):
+        ckpt['regressor.%d.smpl.betas' % n] = torch.zeros(1, 10)
+        ckpt['regressor.%d.smpl.global_orient' % n] = torch.zeros(1, 3)
+        ckpt['regressor.%d.smpl.faces_tensor' % n] = torch.zeros(13776, 3, dtype=torch.long)
+        ckpt['regressor.%d.smpl.vertex_joint_selector.extra_joints_idxs' % n] = torch.zeros(21, dtype=torch.long)
+        ckpt['regressor.%d.vertex_joint_selector.extra_joints_idxs' % n] = torch.zeros(21, dtype=torch.long)
+    ckpt['regressor.1.fc1.weight'] = ckpt['regressor.1.fc1.weight'] + 1.0
+    res = m.load_state_dict(ckpt, strict=True)                      # must not raise
+    assert len(m.ignored_checkpoint_keys) == 15 and not res.unexpected_keys
+    assert torch.equal(m.regressor[1].fc1.weight, ckpt['regressor.1.fc1.weight'])
+    # still strict about own-code keys
+    bad = dict(ckpt)
+    del bad['regressor.0.fc2.bias']
+    with pytest.raises(RuntimeError, match='missing own-code keys'):
+        m.load_state_dict(bad, strict=True)
+    bad = dict(ckpt)
+    bad['regressor.0.not_a_real_key'] = torch.zeros(1)
+    with pytest.raises(RuntimeError, match='unexpected keys'):
+        m.load_state_dict(bad, strict=True)
+    bad = dict(ckpt)
+    bad['deconv_layers.0.weight'] = torch.zeros(3, 3)
+    with pytest.raises(RuntimeError):
+        m.load_state_dict(bad, strict=True)
+
+
 def test_cfg_object():
     from whmr_amd.core.cfgs import CfgNode, cfg
     assert cfg.MODEL.PyMAF.MLP_DIM == [256, 128, 64, 32] and cfg.IMG_RES.WIDTH == 256 and cfg.TRAIN.STAGE == 2

@@ -297,3 +297,31 @@ def test_maf_sampler_mfma_variant(dev, state_dict):
     ref3, _ = ext(p3, s_feat=fmap, cam=cam, want_point_feat=True)
     got3, _ = ext(p3, s_feat=fmap, cam=cam, want_point_feat=False)
     assert _rel(got3, ref3) < 2e-2
+
+
+def test_whmr_forward_batch64_fp32_vs_cpu_oracle(dev, assets, state_dict):
+    """BASELINE configs[2] at its full batch of 64 (only B=2 was tested): every vis_dict tensor of the fp32 parity mode against
+    the CPU oracle on the same 64 crops, within the north-star 1e-4; camera rotation from ONE hoisted 160x224 frame (the oracle runs the
+    same frame per crop).  ~30 s of CPU oracle."""
+    from oracle import synth
+    from oracle import whmr as OW
+    B = 64
+    inp = synth.make_inputs(B, 21)
+    full = torch.randn(1, 3, 160, 224, generator=torch.Generator().manual_seed(3))
+    torch.set_num_threads(min(16, torch.get_num_threads() * 2))
+    with torch.no_grad():
+        ref = OW.whmr_forward(state_dict, assets, inp['x'], inp['center'], inp['scale'], inp['bbox_height'], inp['orig_shape'], inp['bbox_info'],
+                              full_x=full.expand(B, -1, -1, -1))
+    m = _load_model(assets, state_dict, 'fp32', dev)
+    d = {k: v.to(dev) for k, v in inp.items()}
+    out = m(d['x'], None, d['center'], d['scale'], d['bbox_height'], d['orig_shape'], d['bbox_info'], full_x=full.to(dev))
+    for k, v in ref.items():
+        err = _rel(out[k], v.numpy())
+        print('B=64 %-22s max-rel %.2e' % (k, err))
+        assert out[k].shape == v.shape and err < 1e-4, (k, err)
+    # the bf16 perf mode at the same size: vertices / pose stay near 1e-4, reported (not gated at 1e-4: DESIGN 3)
+    m16 = _load_model(assets, state_dict, 'bf16', dev)
+    o16 = m16(d['x'], None, d['center'], d['scale'], d['bbox_height'], d['orig_shape'], d['bbox_info'], full_x=full.to(dev))
+    errs = {k: _rel(o16[k], v.numpy()) for k, v in ref.items()}
+    print('B=64 bf16 mode:', {k: '%.1e' % e for k, e in errs.items()})
+    assert errs['smpl_vertices'] < 2e-3 and errs['local_pose'] < 2e-3 and errs['shape'] < 2e-3

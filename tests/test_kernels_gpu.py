@@ -258,24 +258,34 @@ def test_nhwc_pools_and_stem_im2col(dev, dt):
 
 @pytest.mark.parametrize('numerics,tol', [('fp32', 1e-4), ('bf16', 4e-2)])
 def test_cam_model_resnet50(dev, numerics, tol):
-    """the HIP NHWC ResNet-50 of cam_model against the same module's plain-PyTorch forward."""
+    """SURVEY 8f N1 / 8(a17): the HIP NHWC ResNet-50 of cam_model against the CPU fp32 oracle (oracle/whmr.py::cam_model_forward: pooled
+    features, the three 256-bin logit vectors, the soft-argmax angles and the Rx(pitch).Rz(roll) rotation)."""
     from oracle import synth
-    from whmr_amd.models.cam_model import CameraRegressorNetwork
+    from oracle import whmr as OW
+    from whmr_amd.models.cam_model import CameraRegressorNetwork, batch_euler2matrix, convert_preds_to_angles
     sd = synth.make_state_dict(0, synth.make_assets(0))
     m = CameraRegressorNetwork()
     m.load_state_dict({k[len('cam_model.'):]: v for k, v in sd.items() if k.startswith('cam_model.')}, strict=True)
     m.numerics = numerics
     m = m.to(dev).eval()
-    x = torch.randn(2, 3, 160, 224, generator=torch.Generator().manual_seed(5)).to(dev)
+    x = torch.randn(2, 3, 160, 224, generator=torch.Generator().manual_seed(5))
+    taps = {}
     with torch.no_grad():
-        ref, rfeat = m.forward_torch(x)
-    out, feat = m(x)
-    assert _rel(feat, rfeat) < tol
-    for o, r in zip(out, ref):
-        assert o.shape == r.shape and _rel(o, r) < tol
+        R_ref, _ = OW.cam_model_forward(sd, x, taps=taps)
+    out, feat = m(x.to(dev))
+    assert _rel(feat.cpu(), taps['feat']) < tol
+    for o, name in zip(out, ('vfov', 'pitch', 'roll')):
+        assert o.shape == taps['logits_' + name].shape and _rel(o.cpu(), taps['logits_' + name]) < tol, name
+    vfov, pitch, roll = convert_preds_to_angles(*out)
+    assert _rel(pitch.cpu(), taps['angle_pitch']) < tol and _rel(roll.cpu(), taps['angle_roll']) < tol and _rel(vfov.cpu(), taps['angle_vfov']) < tol
+    assert pitch.abs().min() > 0.2 and roll.abs().min() > 0.2             # the synthetic head is far from the mid-range (0, 0) case
+    R = batch_euler2matrix(torch.stack([pitch, torch.zeros_like(pitch), roll], 1).float())
+    assert _rel(R.cpu(), R_ref) < tol
     m.train()
     with pytest.raises(RuntimeError):
-        m(x)
+        m(x.to(dev))
+    with pytest.raises(RuntimeError):                                      # the module tree holds parameters only
+        m.backbone(x.to(dev))
 
 
 @pytest.mark.parametrize('out_bf16', [True, False])

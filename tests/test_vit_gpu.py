@@ -74,3 +74,23 @@ def test_vit_large_256x192_matches_oracle(dev):
         out = m.to(dev).eval()(x.to(dev))
         assert out.shape == (3, 1024, 16, 12)
         assert _rel(out.cpu(), ref) < tol, numerics
+
+
+def test_vit_large_full_depth_matches_oracle(dev):
+    """BASELINE config #5 backbone at FULL depth (ViT-L/16: dim 1024, depth 24, 16 heads, 256x192), B=2: fp32 parity mode within 1e-4 of the
+    CPU oracle, bf16 (blocked-layout pipeline) within its error budget"""
+    from oracle import synth
+    from oracle.vit import vit_forward
+    from whmr_amd.models.pose_vit import ViT
+    sd = synth.make_vit_state(5, (256, 192), embed_dim=1024, depth=24)
+    x = synth.make_inputs(2, 13, (256, 192))['x']
+    with torch.no_grad():
+        ref = vit_forward(sd, x, num_heads=16)
+    for numerics, tol in (('fp32', 1e-4), ('bf16', 8e-2)):
+        m = ViT(img_size=(256, 192), patch_size=16, embed_dim=1024, depth=24, num_heads=16, ratio=1, mlp_ratio=4,
+                qkv_bias=True, drop_path_rate=0.5, numerics=numerics)
+        m.load_state_dict(sd, strict=True)
+        out = m.to(dev).eval()(x.to(dev))
+        err = _rel(out.cpu(), ref)
+        print('ViT-L depth 24 %s max-rel %.2e' % (numerics, err))
+        assert out.shape == (2, 1024, 16, 12) and err < tol, numerics

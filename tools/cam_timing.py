@@ -13,6 +13,20 @@ B = 64
 inp = {k: v.to(dev) for k, v in synth.make_inputs(B, 0).items()}
 args = (inp['x'], None, inp['center'], inp['scale'], inp['bbox_height'], inp['orig_shape'], inp['bbox_info'])
 full1 = torch.randn(1, 3, 600, 800, device=dev)
+def torch_forward(cm, x):
+    """the same ResNet-50 on torch / MIOpen (timing reference only)"""
+    import torch.nn.functional as F
+    bb = cm.backbone
+    bn = lambda y, b: F.batch_norm(y, b.running_mean, b.running_var, b.weight, b.bias, False, 0.0, b.eps)
+    y = F.max_pool2d(F.relu(bn(bb.conv1(x), bb.bn1)), 3, 2, 1)
+    for li in range(1, 5):
+        for blk in getattr(bb, 'layer%d' % li):
+            z = F.relu(bn(blk.conv1(y), blk.bn1)); z = F.relu(bn(blk.conv2(z), blk.bn2)); z = bn(blk.conv3(z), blk.bn3)
+            y = F.relu(z + (y if blk.downsample is None else bn(blk.downsample[0](y), blk.downsample[1])))
+    f = y.mean((2, 3))
+    return cm.fc_vfov(f), cm.fc_pitch(f), cm.fc_roll(f)
+
+
 def t(fn, n=5):
     for _ in range(2): fn()
     torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -29,7 +43,7 @@ for nimg in (1, 8, 64):
     m.cam_model.numerics = 'bf16'
     if nimg < 64:
         with torch.no_grad():
-            print('cam_model %2d x 600x800  torch/MIOpen fp32: %.2f ms' % (nimg, t(lambda: m.cam_model.forward_torch(full))))
+            print('cam_model %2d x 600x800  torch/MIOpen fp32: %.2f ms' % (nimg, t(lambda: torch_forward(m.cam_model, full))))
     g = GraphedForward(m.cam_model, full)
     print('cam_model %2d x 600x800  HIP bf16, HIP graph: %.2f ms' % (nimg, t(lambda: g(full))))
 full = full1.expand(8, -1, -1, -1).contiguous()

@@ -7,11 +7,15 @@ bbox_info, is_train=False, J_regressor=None, full_x=None, cam_rotmat=None)`` and
   * three return views: ``view='vis'`` (released default, the 9-tensor vis_dict), ``'train'``
     ((out_list, vis_feat_list)), ``'eval'`` (({'global_output': ...}, None)); select per call or via ``self.return_view``;
   * ``full_x=None`` / ``cam_rotmat=...`` work (the release raises NameError, SURVEY 0.7): render_rotmat := cam_rotmat;
-  * inference only this round (is_train=True raises): Dropout/DropPath are identity, BN uses running stats;
-  * ``numerics``: 'bf16' (MFMA bf16 operands for ViT / deconv / Tz conv; everything after the feature maps is fp32)
-    or 'fp32' (exact-f32 MFMA everywhere; the 1e-4 parity mode).
-Every tensor op on the hot path is a kernel of this repo; the camera-calibration ResNet-50 stays on PyTorch-ROCm
- and a few O(batch)-sized scalar expressions (focal length, camera translation) are tensor arithmetic.
+  * ``is_train=True`` (module in ``.train()``) returns the train view with an autograd graph whose every stage has a hand-written HIP
+    backward (``whmr_amd.train``): Dropout and the ViT's stochastic depth draw fresh masks, BatchNorm uses batch statistics and updates
+    its running statistics; in eval mode they are identities / running statistics;
+  * ``numerics``: 'bf16' (MFMA bf16 operands for ViT / deconv / Tz conv / cam_model; everything after the feature maps is fp32)
+    or 'fp32' (exact-f32 MFMA everywhere; the 1e-4 parity mode);
+  * ``load_state_dict(ckpt['model'], strict=True)`` accepts a reference checkpoint unchanged (third-party smplx / pare keys without a
+    counterpart are listed in ``ignored_checkpoint_keys``).
+Every tensor op on the hot path is a kernel of this repo, including the camera-calibration ResNet-50 (``cam_model.py``: NHWC implicit
+GEMMs); a few O(batch)-sized scalar expressions (focal length, camera translation) are tensor arithmetic.
 """
 import os
 
@@ -527,6 +531,13 @@ class WHMR(nn.Module):
                 'global_pose': g_pose, 'local_pose': smpl_output['pose']}
 
 
+THIRD_PARTY_KEY_PARTS = ('.smpl.', '.vertex_joint_selector.')     # smplx / pare internals inside regressor.N; 'transformer.' = HF leftovers
+
+
+def _is_third_party_key(k):
+    return any(t in k for t in THIRD_PARTY_KEY_PARTS) or k.startswith('transformer.')
+
+
 def load_reference_state_dict(model, state_dict, verbose=True):
     """Load a reference checkpoint's ``ckpt['model']`` (demo/tester.py:64-65, utils/saver.py:26-64) into ``model``.
 
@@ -551,6 +562,34 @@ def load_reference_state_dict(model, state_dict, verbose=True):
         print('loaded %d tensors; %d third-party keys skipped; %d smpl buffers kept from the SMPL model file'
               % (len(load), len(skipped), len(res.missing_keys)))
     return res.missing_keys, res.unexpected_keys, skipped
+
+
+def _whmr_load_state_dict(self, state_dict, strict=True, assign=False):
+    """``model.load_state_dict(torch.load(ckpt)['model'], strict=True)`` exactly as the reference's callers write it (demo/tester.py:64-65,
+    evaluate/val_results.py:70).  A reference checkpoint carries, besides the own-code keys (identical here), tensors that
+    live inside third-party classes there: ``regressor.N.smpl.*`` / ``regressor.N.vertex_joint_selector.*`` (smplx / pare) and possibly
+    ``transformer.*``.  Those with a same-named, same-shaped buffer here are loaded; the others have no counterpart (this package reads the
+    SMPL model from its own file) and are listed in ``self.ignored_checkpoint_keys`` instead of failing the strict check.  Conversely this
+    package's ``.smpl.`` buffers that a checkpoint does not carry keep their values.  Everything else stays strict: a missing or
+    shape-mismatched own-code key raises like nn.Module.load_state_dict would."""
+    own = nn.Module.state_dict(self)
+    load, ignored = {}, []
+    for k, v in state_dict.items():
+        if _is_third_party_key(k) and not (k in own and tuple(own[k].shape) == tuple(v.shape)):
+            ignored.append(k)
+        else:
+            load[k] = v
+    res = nn.Module.load_state_dict(self, load, strict=False, assign=assign)
+    self.ignored_checkpoint_keys = ignored
+    if strict:
+        missing = [k for k in res.missing_keys if not _is_third_party_key(k)]
+        if missing or res.unexpected_keys:
+            raise RuntimeError('Error(s) in loading state_dict for WHMR: missing own-code keys %s, unexpected keys %s'
+                               % (missing[:8], list(res.unexpected_keys)[:8]))
+    return res
+
+
+WHMR.load_state_dict = _whmr_load_state_dict
 
 
 def whmr_net(smpl_mean_params, pretrained=True, **kwargs):
