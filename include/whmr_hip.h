@@ -77,6 +77,11 @@ struct whmr_gemm_blk_desc {
     int32_t epi;          /* 0: bf16(acc + bias); 1: bf16(gelu(acc + bias)); 2 / 3: fp32(acc + bias + res) */
     int32_t res_rows;
     int32_t tile;         /* 0 = chooser, else (MI0 << 4) | MI1 row blocks of the two wave rows: 0x44 = 256 x 256, 0x55 = 320, 0x43 = 224, ... */
+    /* LayerNorm folding (vit.py:125,133 never run as their own pass): a producer (epi 2 / 3, xhat != null) also writes xhat = bf16(C) in the
+     * blocked operand layout and per row and 256-column tile the partial sums (sum x, sum x^2): stats_out [rows][N/256][2] (N <= 1024).  A consumer (epi 0 / 1,
+     * stats_in != null) multiplies A = xhat by W = bf16(gamma o W) and applies out = rstd[m] * (acc - mean[m] * colsum[n]) + bias[n], with
+     * bias = b + W.beta, colsum[n] = sum_k W'[n,k], mean / rstd of row m from its K/256 partial pairs. */
+    void* xhat; float* stats_out; const float* stats_in; const float* colsum; float ln_eps;
 };
 int whmr_gemm_blk(const struct whmr_gemm_blk_desc* p, void* stream);
 int whmr_gemm_blk_tile(const struct whmr_gemm_blk_desc* p, int tile, void* stream);

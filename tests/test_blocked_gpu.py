@@ -189,3 +189,61 @@ def test_vit_blocked_full_size_properties(dev):
     assert torch.equal(full, torch.cat([a, b]))
     assert torch.isfinite(full).all()
     assert full.data_ptr() != a.data_ptr() and a.data_ptr() != b.data_ptr()
+
+
+@pytest.mark.parametrize('tile', [0, 0x44, 0x32, 0x55])
+def test_gemm_blk_layernorm_fold(dev, tile):
+    """LayerNorm folded into the GEMM pair (vit.py:125-126,133-134): the producer (epi 2) also emits bf16(stream) + per-row partial sums, the
+    consumer (epi 0 / 1) multiplies the raw copy by gamma-scaled weights and normalises in its epilogue -- against LayerNorm + Linear in fp32 torch"""
+    from whmr_amd import _lib as L
+    g = torch.Generator().manual_seed(9 + tile)
+    M, C, N2 = 1000, 768, 2304
+    att = torch.randn(M, C, generator=g).bfloat16()
+    wp = (torch.randn(C, C, generator=g) / math.sqrt(C)).bfloat16()
+    bp = torch.randn(C, generator=g)
+    t0 = torch.randn(M, C, generator=g) * 2 + 0.7                       # residual stream with a non-zero mean
+    gamma, beta = torch.randn(C, generator=g) * 0.3 + 1, torch.randn(C, generator=g) * 0.2
+    w2 = torch.randn(N2, C, generator=g) / math.sqrt(C)
+    b2 = torch.randn(N2, generator=g)
+    # reference: t1 = t0 + att.wp^T + bp ; out = LN(t1).w2^T + b2
+    t1 = t0 + att.float() @ wp.float().t() + bp
+    ref = F.layer_norm(t1, (C,), gamma, beta, 1e-6) @ w2.t() + b2
+    tb = L.to_blocked(t0.to(dev))
+    nb = tb.shape[0]
+    xhat = torch.full((nb, C // 8, 32, 8), float('nan'), device=dev, dtype=torch.bfloat16)
+    stats = torch.full((nb * 32, C // 256, 2), float('nan'), device=dev)
+    L.gemm_blk(L.to_blocked(att.to(dev)), L.to_blocked(wp.to(dev)), tb, M, bias=bp.to(dev), epi=L.EPI_F32_RES, res=tb, tile=tile, xhat=xhat, stats_out=stats)
+    got_t1 = L.from_blocked(tb, M).cpu()
+    assert _rel(got_t1, t1) < 1e-5
+    assert torch.equal(L.from_blocked(xhat, M).cpu(), got_t1.bfloat16())                      # the emitted operand is exactly bf16(stream)
+    st = stats[:M].cpu().double().sum(1)
+    assert _rel(st[:, 0], got_t1.double().sum(1)) < 1e-5 and _rel(st[:, 1], (got_t1.double() ** 2).sum(1)) < 1e-5
+    wf = (w2 * gamma[None, :]).bfloat16()
+    s = wf.float().sum(1)
+    c = b2 + w2 @ beta
+    out = torch.full((nb, N2 // 8, 32, 8), float('nan'), device=dev, dtype=torch.bfloat16)
+    L.gemm_blk(xhat, L.to_blocked(wf.to(dev)), out, M, bias=c.to(dev), epi=L.EPI_BF16, tile=tile, stats_in=stats, colsum=s.to(dev), ln_eps=1e-6)
+    err = _rel(L.from_blocked(out, M).float().cpu(), ref)
+    # same error class as the unfolded bf16 path: LayerNorm output rounded to bf16, then a bf16 GEMM
+    h_ref = F.layer_norm(t1, (C,), gamma, beta, 1e-6).bfloat16().float() @ w2.bfloat16().float().t() + b2
+    print('folded LayerNorm + qkv: max-rel %.2e (unfolded bf16 pipeline: %.2e)' % (err, _rel(h_ref, ref)))
+    assert err < 1.5e-2
+    L.gemm_blk(xhat, L.to_blocked(wf.to(dev)), out, M, bias=c.to(dev), epi=L.EPI_BF16_GELU, tile=tile, stats_in=stats, colsum=s.to(dev), ln_eps=1e-6)
+    assert _rel(L.from_blocked(out, M).float().cpu(), F.gelu(ref)) < 1.5e-2
+
+
+def test_vit_ln_fold_matches_unfolded(dev):
+    """ViT-B 224^2 bf16: the folded pipeline against the blocked pipeline with explicit LayerNorm passes and against the reference fixture"""
+    from oracle import synth
+    g = np.load(os.path.join(GOLDEN, 'vit224_b2.npz'))
+    sd = synth.make_vit_state(1, (224, 224))
+    x = torch.from_numpy(g['x']).to(dev)
+    ref = torch.from_numpy(g['s_feat'])
+    m = _vit(sd, (224, 224), dev, True)
+    assert m.ln_fold
+    out_f = m(x)
+    m.ln_fold = False
+    out_u = m(x)
+    ef, eu = _rel(out_f.cpu(), ref), _rel(out_u.cpu(), ref)
+    print('bf16 ViT vs fp32 reference fixture: LayerNorm folded %.3e, explicit %.3e, folded vs explicit %.3e' % (ef, eu, _rel(out_f, out_u)))
+    assert ef < 5e-2 and _rel(out_f, out_u) < 2e-2

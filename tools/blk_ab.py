@@ -44,3 +44,9 @@ for name, f, e0, e1 in prof:
 print('GEMM launches by GFLOP: ' + '  '.join('%.1f GF: %.1f us (%.0f TF) x%d' % (k, sum(v) / len(v), k * 1e3 / (sum(v) / len(v)), len(v)) for k, v in sorted(per.items())))
 tot_f = sum(f for _, f, _, _ in prof); tot_t = sum(e0.elapsed_time(e1) for _, _, e0, e1 in prof) * 1e-3
 print('all GEMM launches: %.0f TF = %.3f of 2500' % (tot_f / tot_t / 1e12, tot_f / tot_t / 2.5e15))
+# LayerNorm folding on / off
+for rnd in range(3):
+    m.ln_fold = True; a = fwd_ms()
+    m.ln_fold = False; b = fwd_ms()
+    print('round %d: LayerNorm folded %.3f ms   explicit LayerNorm passes %.3f ms' % (rnd, a, b), flush=True)
+m.ln_fold = True

@@ -31,7 +31,8 @@ class WhmrGemm(C.Structure):
 class WhmrGemmBlk(C.Structure):
     """struct whmr_gemm_blk_desc (include/whmr_hip.h): blocked-layout bf16 GEMM of the ViT inference path"""
     _fields_ = [('A', C.c_void_p), ('W', C.c_void_p), ('C', C.c_void_p), ('bias', C.c_void_p), ('res', C.c_void_p),
-                ('M', C.c_int32), ('N', C.c_int32), ('K', C.c_int32), ('epi', C.c_int32), ('res_rows', C.c_int32), ('tile', C.c_int32)]
+                ('M', C.c_int32), ('N', C.c_int32), ('K', C.c_int32), ('epi', C.c_int32), ('res_rows', C.c_int32), ('tile', C.c_int32),
+                ('xhat', C.c_void_p), ('stats_out', C.c_void_p), ('stats_in', C.c_void_p), ('colsum', C.c_void_p), ('ln_eps', C.c_float)]
 
 
 class WhmrSmplModel(C.Structure):
@@ -263,7 +264,8 @@ def from_blocked(t, R):
     return t.permute(0, 2, 1, 3).reshape(nb * 32, nu * E)[:R].contiguous()
 
 
-def gemm_blk(a, w, out, M, bias=None, epi=EPI_BF16, res=None, res_rows=0, tile=0):
+def gemm_blk(a, w, out, M, bias=None, epi=EPI_BF16, res=None, res_rows=0, tile=0, xhat=None, stats_out=None, stats_in=None, colsum=None,
+             ln_eps=1e-6):
     """out = epi(a . w^T + bias [+ res]) on blocked operands: a [M/32][K/8][32][8] bf16, w [N/32][K/8][32][8] bf16,
     out bf16 [M/32][N/8][32][8] (epi 0/1) or fp32 [M/32][N/4][32][4] (epi 2: + blocked res, may be `out`; epi 3: + res[m % res_rows] row-major)."""
     _dev(a, w, out, bias, res)
@@ -280,6 +282,15 @@ def gemm_blk(a, w, out, M, bias=None, epi=EPI_BF16, res=None, res_rows=0, tile=0
         assert res.dtype == torch.float32 and res.is_contiguous()
         p.res = res.data_ptr()
     p.M, p.N, p.K, p.epi, p.res_rows, p.tile = M, N, K, epi, res_rows, tile
+    if xhat is not None:                     # LayerNorm folding, producer side: bf16 copy of the stream + row partial sums [rows, N/64, 2]
+        _dev(xhat, stats_out)
+        assert epi >= 2 and xhat.dtype == torch.bfloat16 and xhat.is_contiguous() and xhat.shape[0] * 32 >= M and xhat.shape[1] * 8 == N
+        assert stats_out.dtype == torch.float32 and stats_out.is_contiguous() and stats_out.numel() >= a.shape[0] * 32 * (N // 256) * 2
+        p.xhat, p.stats_out = xhat.data_ptr(), stats_out.data_ptr()
+    if stats_in is not None:                 # consumer side: a = xhat of the raw stream, w = gamma-scaled weights, bias = b + W.beta
+        _dev(stats_in, colsum)
+        assert epi < 2 and stats_in.dtype == torch.float32 and colsum.dtype == torch.float32 and colsum.numel() == N and K % 256 == 0
+        p.stats_in, p.colsum, p.ln_eps = stats_in.data_ptr(), colsum.data_ptr(), ln_eps
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

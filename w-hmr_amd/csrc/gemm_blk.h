@@ -12,4 +12,14 @@ struct whmr_gemm_blk_desc {
     int32_t epi;          // 0: bf16(acc + bias)   1: bf16(gelu(acc + bias))   2 / 3: fp32(acc + bias + res)
     int32_t res_rows;
     int32_t tile;         // 0 = chooser; else (MI0 << 4) | MI1: 0x44 256 rows, 0x55 320, 0x43 224, 0x33 192, 0x32 160, 0x22 128, 0x54 288
+    // ---- LayerNorm folding (vit.py:125,133: the LayerNorm in front of qkv / fc1 never runs as its own pass) ---------------------------
+    // producer (epi 2 / 3, xhat != null): besides the fp32 stream C it writes xhat = bf16(C) in the blocked operand layout and, per row and
+    //   256-column tile, the partial sums (sum x, sum x^2) of the values it stored: stats_out [rows][N/256][2] fp32 (N <= 1024).
+    // consumer (epi 0 / 1, stats_in != null): A = xhat of the raw stream, W = bf16(gamma o W) packed, bias = b + W.beta, colsum[n] = sum_k W'[n,k];
+    //   out = rstd[m] * (acc - mean[m] * colsum[n]) + bias[n], mean / rstd of row m from its K/256 partial pairs (fixed summation order).
+    void* xhat;
+    float* stats_out;
+    const float* stats_in;
+    const float* colsum;
+    float ln_eps;
 };

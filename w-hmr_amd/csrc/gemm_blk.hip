@@ -42,8 +42,9 @@ struct blk_cfg {
     static constexpr int SLOT = (MB + 8) * 2048;         // one half K tile (32 deep) of A and W: 2 KiB per row block
     static constexpr int HU = (MB + 8) * 2;              // 1-KiB DMA units per half tile
     static constexpr int HUPW = (HU + 7) / 8;            // units per wave (waves >= HU % 8 issue one less when HU % 8 != 0)
-    static constexpr int BIAS_OFF = 4 * SLOT;            // [256] floats behind the ring
-    static constexpr int LDS = 4 * SLOT + 1024;
+    static constexpr int BIAS_OFF = 4 * SLOT;            // [256] floats behind the ring, then [256] floats of the LayerNorm-fold column sums
+    static constexpr int STAT_OFF = BIAS_OFF + 2048;     // LayerNorm folding: [BM][4][2] floats -- row statistics (consumer) / per-wave-column partial sums (producer)
+    static constexpr int LDS = 4 * SLOT + 2048 + BM * 32;
     static constexpr int MIMAX = MI0 > MI1 ? MI0 : MI1;
 };
 
@@ -68,6 +69,18 @@ __global__ __launch_bounds__(512, 2) void gemm_blk_kernel(const whmr_gemm_blk_de
 
     // this tile's bias slice -> LDS (one float per thread, in flight under the whole main loop)
     if (tid < BN) ((float*)(smem + cfg::BIAS_OFF))[tid] = p.bias ? p.bias[n0 + tid] : 0.f;
+    else if (tid < 2 * BN && p.stats_in) ((float*)(smem + cfg::BIAS_OFF))[tid] = p.colsum[n0 + tid - BN];
+    if (p.stats_in) {
+        // consumer of a folded LayerNorm: this tile's row statistics (K/256 partial (sum, sum of squares) pairs per row, written by the producer
+        // GEMM's column tiles) -> LDS now, so that the epilogue finds them without a global round trip
+        const int S3 = p.K >> 8;
+        for (int r = tid; r < BM; r += 512) {
+            int m = m0 + r;
+            if (m > rb_last * 32 + 31) m = rb_last * 32 + 31;
+            for (int t = 0; t < S3; ++t)
+                *(float2*)(smem + cfg::STAT_OFF + (r * 4 + t) * 8) = *(const float2*)(p.stats_in + ((size_t)m * S3 + t) * 2);
+        }
+    }
 
     // ---- DMA units of this wave: u = wave + 8 i -> row block u >> 1 (A blocks first, then the 8 W blocks), 1-KiB half u & 1
     const bool dma_full = (HU % 8 == 0) || (wave < HU % 8);          // this wave issues HUPW units (else HUPW - 1)
@@ -194,19 +207,42 @@ __global__ __launch_bounds__(512, 2) void gemm_blk_kernel(const whmr_gemm_blk_de
     const float* sBias = (const float*)(smem + cfg::BIAS_OFF) + wn * 64;
     if constexpr (EPI == 0 || EPI == 1) {
         const int NC8 = p.N >> 3;
+        const bool fold = p.stats_in != nullptr;                        // LayerNorm folded into this GEMM: per-row (rstd, rstd * mean)
+        float rs[cfg::MIMAX], rm[cfg::MIMAX];
+#pragma unroll
+        for (int i = 0; i < cfg::MIMAX; ++i) { rs[i] = 1.f; rm[i] = 0.f; }
+        if (fold) {
+            const int S3 = p.K >> 8;                                     // partial pairs per row (one per 256-column tile of the producer)
+            const float invC = 1.0f / (float)p.K;
+#pragma unroll
+            for (int i = 0; i < cfg::MIMAX; ++i) {
+                if (i >= miw) continue;
+                const float2* sp = (const float2*)(smem + cfg::STAT_OFF) + ((wm == 0 ? 0 : MI0 * 32) + i * 32 + l31) * 4;
+                float sx = 0.f, sxx = 0.f;
+                for (int t = 0; t < S3; ++t) { const float2 v = sp[t]; sx += v.x; sxx += v.y; }
+                const float mean = sx * invC;
+                const float var = fmaxf(fmaf(-mean, mean, sxx * invC), 0.f);
+                rs[i] = 1.0f / sqrtf(var + p.ln_eps);
+                rm[i] = rs[i] * mean;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            float4 bq[4];
+            float4 bq[4], cq[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) bq[q] = *(const float4*)(sBias + j * 32 + 8 * q + 4 * hi);
+            for (int q = 0; q < 4; ++q) {
+                bq[q] = *(const float4*)(sBias + j * 32 + 8 * q + 4 * hi);
+                cq[q] = fold ? *(const float4*)(sBias + BN + j * 32 + 8 * q + 4 * hi) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
 #pragma unroll
             for (int i = 0; i < cfg::MIMAX; ++i) {
                 if (i >= miw || rb0 + i > rb_last) continue;
                 uint32_t pk[4][2];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    f32x2_t v0 = {acc[i][j][4 * q] + bq[q].x, acc[i][j][4 * q + 1] + bq[q].y};
-                    f32x2_t v1 = {acc[i][j][4 * q + 2] + bq[q].z, acc[i][j][4 * q + 3] + bq[q].w};
+                    // plain: acc + bias;  folded LayerNorm: rstd * acc + (bias' - rstd * mean * colsum)   (rs = 1, rm = 0, cq = 0 when not folded)
+                    f32x2_t v0 = {fmaf(acc[i][j][4 * q], rs[i], fmaf(-rm[i], cq[q].x, bq[q].x)), fmaf(acc[i][j][4 * q + 1], rs[i], fmaf(-rm[i], cq[q].y, bq[q].y))};
+                    f32x2_t v1 = {fmaf(acc[i][j][4 * q + 2], rs[i], fmaf(-rm[i], cq[q].z, bq[q].z)), fmaf(acc[i][j][4 * q + 3], rs[i], fmaf(-rm[i], cq[q].w, bq[q].w))};
                     if constexpr (EPI == 1) { v0 = gelu_fast2(v0); v1 = gelu_fast2(v1); }
                     pk[q][0] = pack_bf16x2(v0.x, v0.y); pk[q][1] = pack_bf16x2(v1.x, v1.y);
                 }
@@ -222,6 +258,10 @@ __global__ __launch_bounds__(512, 2) void gemm_blk_kernel(const whmr_gemm_blk_de
         }
     } else {
         const int NC4 = p.N >> 2;
+        const bool emit = p.xhat != nullptr;                            // also write bf16(C) as the next GEMM's operand + row partial sums
+        float sx[cfg::MIMAX], sxx[cfg::MIMAX];
+#pragma unroll
+        for (int i = 0; i < cfg::MIMAX; ++i) { sx[i] = 0.f; sxx[i] = 0.f; }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             float4 bq[4];
@@ -241,13 +281,47 @@ __global__ __launch_bounds__(512, 2) void gemm_blk_kernel(const whmr_gemm_blk_de
 #pragma unroll
                     for (int q = 0; q < 4; ++q) rv[q] = *(const float4*)(rr + 8 * q);
                 }
+                uint32_t pk[4][2];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     float4 o;
                     o.x = acc[i][j][4 * q] + bq[q].x + rv[q].x; o.y = acc[i][j][4 * q + 1] + bq[q].y + rv[q].y;
                     o.z = acc[i][j][4 * q + 2] + bq[q].z + rv[q].z; o.w = acc[i][j][4 * q + 3] + bq[q].w + rv[q].w;
                     *(float4*)((char*)p.C + off + q * 1024) = o;
+                    if (emit) {
+                        // explicit order / explicit fma: every tile instantiation must produce the same bits for a row (batch-independence tests)
+                        sx[i] += o.x; sx[i] += o.y; sx[i] += o.z; sx[i] += o.w;
+                        sxx[i] = fmaf(o.x, o.x, sxx[i]); sxx[i] = fmaf(o.y, o.y, sxx[i]); sxx[i] = fmaf(o.z, o.z, sxx[i]); sxx[i] = fmaf(o.w, o.w, sxx[i]);
+                        pk[q][0] = pack_bf16x2(o.x, o.y); pk[q][1] = pack_bf16x2(o.z, o.w);
+                    }
                 }
+                if (emit) {
+                    char* rowp = (char*)p.xhat + ((size_t)(rb0 + i) * (p.N >> 3) + ((nb0 + j * 32) >> 3)) * 512 + l31 * 16;
+#pragma unroll
+                    for (int q = 0; q < 4; q += 2) {
+                        const auto r0 = __builtin_amdgcn_permlane32_swap(pk[q][0], pk[q + 1][0], false, false);
+                        const auto r1 = __builtin_amdgcn_permlane32_swap(pk[q][1], pk[q + 1][1], false, false);
+                        *(uint4*)(rowp + (q + hi) * 512) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+                    }
+                }
+            }
+        }
+        if (emit) {      // block-uniform
+            // per row: (sum x, sum x^2) of the stored fp32 values over this tile's 256 columns = the 4 wave columns combined through LDS in a
+            // fixed order (deterministic); one pair per row and column tile goes to stats_out [rows][N/256][2]
+            float2* sRed = (float2*)(smem + cfg::STAT_OFF);
+#pragma unroll
+            for (int i = 0; i < cfg::MIMAX; ++i) {
+                if (i >= miw) continue;
+                const float a = sx[i] + __shfl_xor(sx[i], 32, 64), b = sxx[i] + __shfl_xor(sxx[i], 32, 64);
+                if (hi == 0) sRed[((wm == 0 ? 0 : MI0 * 32) + i * 32 + l31) * 4 + wn] = make_float2(a, b);
+            }
+            __syncthreads();
+            const int S3 = p.N >> 8;
+            for (int r = tid; r < BM; r += 512) {
+                if ((m0 >> 5) + (r >> 5) > rb_last) continue;
+                const float2 v0 = sRed[r * 4], v1 = sRed[r * 4 + 1], v2 = sRed[r * 4 + 2], v3 = sRed[r * 4 + 3];
+                *(float2*)(p.stats_out + ((size_t)(m0 + r) * S3 + tn) * 2) = make_float2((v0.x + v1.x) + (v2.x + v3.x), (v0.y + v1.y) + (v2.y + v3.y));
             }
         }
     }
@@ -294,6 +368,9 @@ extern "C" int whmr_gemm_blk_tile(const whmr_gemm_blk_desc* pp, int tile, void* 
     const whmr_gemm_blk_desc& p = *pp;
     if (p.M <= 0 || p.N <= 0 || (p.N % 256) || p.K < 32 || (p.K % 32) || p.epi < 0 || p.epi > 3) return (int)hipErrorInvalidValue;
     if ((p.epi >= 2) && !p.res) return (int)hipErrorInvalidValue;
+    if (p.xhat && (p.epi < 2 || !p.stats_out)) return (int)hipErrorInvalidValue;
+    if (p.stats_in && (p.epi >= 2 || !p.colsum || (p.K % 256) || p.K > 1024)) return (int)hipErrorInvalidValue;
+    if (p.xhat && p.N > 1024) return (int)hipErrorInvalidValue;
     if (p.epi == 3 && p.res_rows <= 0) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
     switch (tile) {

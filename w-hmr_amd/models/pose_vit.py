@@ -94,6 +94,7 @@ class ViT(nn.Module):
         self._wcache = {}
         self._ws = {}
         self.blocked = True                 # bf16 inference on the blocked-layout kernels when the shapes allow it
+        self.ln_fold = True                 # ... with norm1 / norm2 folded into the qkv / fc1 GEMMs (no LayerNorm pass inside the blocks)
 
     # ------------------------------------------------------------------ weight / workspace caches
     def _w(self, p, shape=None):
@@ -116,6 +117,25 @@ class ViT(nn.Module):
         if ent is None or ent[0] != p._version or ent[1].device != p.device:
             w = L.cast_bf16(p.detach())
             ent = (p._version, L.to_blocked(w.reshape(shape) if shape is not None else w))
+            self._wcache[key] = ent
+        return ent[1]
+
+    def _wfold(self, lin, ln):
+        """LayerNorm folded into the Linear that follows it (vit.py:125-126,133-134: lin(LN(x))):
+            lin(LN(x))[m, n] = rstd_m * (sum_k x_mk W'_nk - mean_m * s_n) + c_n,   W' = gamma o W,  s_n = sum_k W'_nk,  c_n = b_n + sum_k beta_k W_nk.
+        Returns (W' bf16 in the blocked operand layout, s from the ROUNDED W' so that the mean term cancels exactly, c) -- rebuilt when a source changes."""
+        srcs = [lin.weight, ln.weight, ln.bias] + ([lin.bias] if lin.bias is not None else [])
+        key = ('fold', id(lin.weight))
+        ver = tuple((t._version, t.device) for t in srcs)
+        ent = self._wcache.get(key)
+        if ent is None or ent[0] != ver:
+            w = lin.weight.detach().float()
+            wp = L.cast_bf16((w * ln.weight.detach().float()[None, :]).contiguous())
+            s = wp.float().sum(1).contiguous()
+            c = (w.double() @ ln.bias.detach().double()).float()
+            if lin.bias is not None:
+                c = c + lin.bias.detach().float()
+            ent = (ver, (L.to_blocked(wp), s, c.contiguous()))
             self._wcache[key] = ent
         return ent[1]
 
@@ -179,13 +199,36 @@ class ViT(nn.Module):
         pos = self._buf('pos', (N, D), f32, dev)
         torch.add(self.pos_embed[0, 1:], self.pos_embed[0, :1], out=pos)              # vit.py:320
         t = self._buf('t_blk', (nb, D // 4, 32, 4), f32, dev)
-        L.gemm_blk(cols, self._wblk(self.patch_embed.proj.weight, (D, K0)), t, M, bias=self.patch_embed.proj.bias, epi=L.EPI_F32_POS,
-                   res=pos, res_rows=N)
+        fold = self.ln_fold and D <= 1024
+        if not fold:
+            L.gemm_blk(cols, self._wblk(self.patch_embed.proj.weight, (D, K0)), t, M, bias=self.patch_embed.proj.bias, epi=L.EPI_F32_POS,
+                       res=pos, res_rows=N)
         h = self._buf('h_blk', (nb, D // 8, 32, 8), bf, dev)
         qkv = self._buf('qkv_blk', (nb, 3 * D // 8, 32, 8), bf, dev)
         att = self._buf('att_blk', (nb, D // 8, 32, 8), bf, dev)
         hd = self.blocks[0].mlp.fc1.weight.shape[0] if self.depth else D
         hid = self._buf('hid_blk', (nb, hd // 8, 32, 8), bf, dev)
+        if fold:
+            # LayerNorm folding: the GEMM that produces the residual stream (patch embed, proj, fc2) also writes its bf16 copy h and per-row
+            # partial sums; qkv / fc1 multiply that raw copy by gamma-scaled weights and finish the normalisation in their epilogue.  Saves the
+            # 2 x depth LayerNorm passes (57.8 MB each at batch 64) for 19 MB of extra stores per producer.
+            stats = self._buf('stats', (nb * 32, D // 256, 2), f32, dev)
+            nblk = len(self.blocks)
+            L.gemm_blk(cols, self._wblk(self.patch_embed.proj.weight, (D, K0)), t, M, bias=self.patch_embed.proj.bias, epi=L.EPI_F32_POS,
+                       res=pos, res_rows=N, xhat=h if nblk else None, stats_out=stats if nblk else None)
+            for bi, blk in enumerate(self.blocks):
+                wq, sq, cq = self._wfold(blk.attn.qkv, blk.norm1)
+                L.gemm_blk(h, wq, qkv, M, bias=cq, epi=L.EPI_BF16, stats_in=stats, colsum=sq, ln_eps=1e-6)
+                L.attention_blk(qkv, att, B, N, heads, self.scale)
+                L.gemm_blk(att, self._wblk(blk.attn.proj.weight), t, M, bias=blk.attn.proj.bias, epi=L.EPI_F32_RES, res=t, xhat=h, stats_out=stats)
+                w1, s1, c1 = self._wfold(blk.mlp.fc1, blk.norm2)
+                L.gemm_blk(h, w1, hid, M, bias=c1, epi=L.EPI_BF16_GELU, stats_in=stats, colsum=s1, ln_eps=1e-6)
+                last = bi + 1 == nblk
+                L.gemm_blk(hid, self._wblk(blk.mlp.fc2.weight), t, M, bias=blk.mlp.fc2.bias, epi=L.EPI_F32_RES, res=t,
+                           xhat=None if last else h, stats_out=None if last else stats)
+            out = torch.empty((M, D), dtype=f32, device=dev)
+            L.layernorm_blk(t, self.last_norm.weight, self.last_norm.bias, out, M, 1e-6, out_std=True)
+            return out
         for blk in self.blocks:
             L.layernorm_blk(t, blk.norm1.weight, blk.norm1.bias, h, M, 1e-6)
             L.gemm_blk(h, self._wblk(blk.attn.qkv.weight), qkv, M, bias=blk.attn.qkv.bias, epi=L.EPI_BF16)
