@@ -128,13 +128,23 @@ def build_workload(args, dev):
         # multi-tensor Adam -- not a path kernel, but a training number without the update would be incomplete.  Its in-place update bumps
         # the parameter versions, so the bf16 operand copies of the weights are re-cast every step, as in a real run.
         opt = torch.optim.Adam(params, lr=5e-5, fused=True)
+        # ground truth of the auxiliary (IUV) supervision: synthetic DensePose tables of the real sizes (7829 vertices, 13774 faces; the licensed
+        # UV_Processed.mat is not shipped) on the synthetic SMPL mesh, rendered on the device every step like the reference does with pytorch3d
+        from whmr_amd.train.aux_supervision import aux_supervision_loss, render_iuv_targets
+        from whmr_amd.utils.renderer import IUV_Renderer
+        iuv_maker = IUV_Renderer(orig_size=(256, 256), output_size=(128, 128), dp=synth.make_densepose_tables(0, assets))
+        gt_cam = torch.tensor([[0.9, 0.0, 0.0]], device=dev).expand(args.batch, -1).contiguous()
 
         def fwd_bwd():
             for p in params:
                 p.grad = None
             out, _ = m(*a, is_train=True)
             loss = sum(out['smpl_out'][l][k].float().pow(2).mean() for l in range(1, 4) for k in keys)
-            loss = loss + sum(v.pow(2).mean() for v in (out['dp_out'][0].values() if out['dp_out'] else ()))     # IUV head (AUX_SUPV_ON)
+            if out['dp_out']:
+                # IUV head (AUX_SUPV_ON): the reference's dense-correspondence losses against ground truth RENDERED THIS STEP from the fitted mesh
+                # (core/trainer.py:442-482) -- here the HIP rasteriser (whmr_amd.utils.renderer.IUV_Renderer) on the stage-3 mesh, detached
+                _, uvia = render_iuv_targets(iuv_maker, out['smpl_out'][-1]['verts'].detach(), gt_cam)
+                loss = loss + aux_supervision_loss(out['dp_out'], uvia)
             loss.backward()
             if red is not None:
                 red.finish()

@@ -317,6 +317,14 @@ int whmr_regressor_post_train_bwd(const float* joints, const float* cam, const f
 /* dst[m, :] = scale[m] * src[m, :] (fp32 -> fp32 / bf16): stochastic-depth mask on the gradient entering a branch (autograd of vit.py:132-139). */
 int whmr_scale_rows_cast(const float* src, const float* scale, void* dst, int M, int C, int out_bf16, void* stream);
 
+/* ---- training-step ground truth: IUV rasteriser = pytorch3d MeshRasterizer(faces_per_pixel 1, blur 0) + HardFlatShader over
+ * TexturesVertex as utils/renderer.py:296-446 (IUV_Renderer.verts2iuvimg) uses it from core/trainer.py:442-464.  verts [B, Vsrc, 3]; vmap [V]
+ * int64 or null (DensePose vertex duplication); faces [F, 3] int32; tex [V, 3] = (I/24, U, V); cam [B, 3] = (s, tx, ty); K of the orig_h x orig_w
+ * image (renderer.py:362-380); scratch scr [B, V, 3] fp32 + zbuf [B, H, W] uint64; out [B, 3, H, W] fp32 (background 0); face_out [B, H, W] int32 or null. */
+int whmr_iuv_rasterize(const float* verts, int B, int Vsrc, const int64_t* vmap, int V, const int32_t* faces, int F, const float* tex,
+                       const float* cam, float fx, float fy, float px, float py, float focal, int orig_h, int orig_w, int H, int W, float* scr,
+                       void* zbuf, float* out, int32_t* face_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

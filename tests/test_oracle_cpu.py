@@ -243,3 +243,65 @@ def test_train_oracle_matches_reference_fixture(assets, state_dict, droppath):
             k = name.split('/', 1)[1]
             ref = torch.from_numpy(fx[name])
             assert ((stats[k] - ref).abs().max() / ref.abs().max().clamp_min(1e-12)).item() < 2e-5, k
+
+
+def test_raster_oracle_known_answers():
+    """oracle/raster.py (pytorch3d restatement, parity unpinned): camera formula, single-triangle coverage with the strict-interior rule,
+    barycentric texture interpolation (perspective-correct), depth order, shared edges"""
+    from oracle import raster as OR
+    # camera: a vertex on the optical axis lands on the image centre + the (px - W/2) offset the reference's K scaling introduces
+    K = OR.camera_K(1000.0, (256, 256))
+    assert np.allclose(K, (1000 * 256 / 224, 1000 * 256 / 224, 128 * 256 / 224, 128 * 256 / 224))
+    cam = np.array([[0.9, 0.0, 0.0]])
+    tz = 2 * 1000.0 / (256 * 0.9 + 1e-9)
+    scr = OR.project(np.zeros((1, 1, 3)), cam, K, 1000.0, (256, 256), (128, 128))
+    assert np.allclose(scr[0, 0], [64 + 0.5 * (K[2] - 128), 64 + 0.5 * (K[3] - 128), tz])
+    assert np.allclose(OR.project(np.zeros((1, 1, 3)), cam, OR.camera_K(1000.0, (224, 224)), 1000.0, (224, 224), (56, 56))[0, 0, :2], [28, 28])
+    # single fronto-parallel triangle built in screen space: choose vertices whose projection is known (orig 224 -> K unscaled, out 56)
+    f, tz = 1000.0, 2 * 1000.0 / (224 * 1.0 + 1e-9)
+
+    def world(u, v, z):                     # inverse of project() for cam = (1, 0, 0)
+        zz = z + tz
+        return [(u - 28) * 4 * zz / f, (v - 28) * 4 * zz / f, z]
+    tri = np.array([[world(10.0, 10.0, 0.0), world(30.0, 10.0, 0.0), world(10.0, 30.0, 0.0)]])
+    tex = np.array([[1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]])
+    out, fid = OR.rasterize(tri, [[0, 1, 2]], tex, np.array([[1.0, 0, 0]]), 1000.0, (224, 224), (56, 56))
+    yy, xx = np.mgrid[0:56, 0:56] + 0.5
+    expect = (xx > 10) & (yy > 10) & ((xx - 10) + (yy - 10) < 20)           # strictly inside: centres ON the hypotenuse x + y = 40 are not covered
+    assert np.array_equal(fid[0] >= 0, expect)
+    assert not (fid[0][(xx - 10) + (yy - 10) == 20] >= 0).any()
+    # barycentric interpolation = the affine coordinates of the pixel centre (equal depths: perspective correction is the identity)
+    j, i = 15, 12
+    assert np.allclose(out[0, :, j, i], [1 - (i + 0.5 - 10) / 20 - (j + 0.5 - 10) / 20, (i + 0.5 - 10) / 20, (j + 0.5 - 10) / 20])
+    assert np.allclose(out[0].sum(0)[fid[0] >= 0], 1.0) and not out[0][:, fid[0] < 0].any()
+    # depth order: a nearer triangle over the same pixels wins regardless of the face order; equal depth -> the smaller face index
+    near = np.array([world(10.0, 10.0, -0.5), world(30.0, 10.0, -0.5), world(10.0, 30.0, -0.5)])
+    v2 = np.concatenate([tri[0], near])[None]
+    tex2 = np.concatenate([tex, 0.5 * tex])
+    for faces in ([[0, 1, 2], [3, 4, 5]], [[3, 4, 5], [0, 1, 2]]):
+        o2, f2 = OR.rasterize(v2, faces, tex2, np.array([[1.0, 0, 0]]), 1000.0, (224, 224), (56, 56))
+        nearest = faces.index([3, 4, 5])
+        assert (f2[0][expect] == nearest).all() and np.allclose(o2[0].sum(0)[expect], 0.5)
+    o3, f3 = OR.rasterize(np.concatenate([tri[0], tri[0]])[None], [[0, 1, 2], [3, 4, 5]], tex2, np.array([[1.0, 0, 0]]), 1000.0, (224, 224), (56, 56))
+    assert (f3[0][expect] == 0).all()
+    # two triangles sharing the diagonal of a square: pixel centres exactly on the shared edge belong to neither (pytorch3d blur 0)
+    sq = np.array([[world(10.0, 10.0, 0.0), world(30.0, 10.0, 0.0), world(30.0, 30.0, 0.0), world(10.0, 30.0, 0.0)]])
+    o4, f4 = OR.rasterize(sq, [[0, 1, 2], [0, 2, 3]], np.ones((4, 3)), np.array([[1.0, 0, 0]]), 1000.0, (224, 224), (56, 56))
+    inside_sq = (xx > 10) & (xx < 30) & (yy > 10) & (yy < 30)
+    assert np.array_equal(f4[0] >= 0, inside_sq & (xx != yy))
+    # perspective-correct interpolation: a triangle tilted in depth -- the value at a pixel is the texture at the 3-D point the ray hits
+    tilt = np.array([[world(10.0, 10.0, 0.0), world(30.0, 10.0, 3.0), world(10.0, 30.0, 0.0)]])
+    o5, f5 = OR.rasterize(tilt, [[0, 1, 2]], tex, np.array([[1.0, 0, 0]]), 1000.0, (224, 224), (56, 56))
+    z0, z1 = tz, 3.0 + tz
+    w1 = (20.5 - 10) / 20                                                 # screen-space weight of vertex 1 at pixel centre (20.5, 10.5)
+    w2 = 0.5 / 20
+    w0 = 1 - w1 - w2
+    b1 = (w1 / z1) / (w0 / z0 + w1 / z1 + w2 / z0)
+    assert abs(o5[0, 1, 10, 20] - b1) < 1e-12 and b1 < w1
+    # iuv_img2map: indicator maps and the 15 annotation groups
+    uv = np.zeros((1, 3, 2, 2))
+    uv[0, :, 0, 0] = [7 / 24, 0.3, 0.6]
+    uv[0, :, 1, 1] = [24 / 24, 0.1, 0.2]
+    U, V, I, A = OR.iuv_img2map(uv)
+    assert I[0, 7, 0, 0] == 1 and I[0, 0, 0, 1] == 1 and I[0, 24, 1, 1] == 1 and I.sum() == 4
+    assert U[0, 7, 0, 0] == 0.3 and V[0, 24, 1, 1] == 0.2 and A[0, 6, 0, 0] == 1 and A[0, 14, 1, 1] == 1 and A.sum() == 4

@@ -102,6 +102,7 @@ _SIGS = {
     'whmr_regressor_post_train': [_P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P],
     'whmr_regressor_post_train_bwd': [_P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     'whmr_scale_rows_cast': [_P, _P, _P, _I, _I, _I, _P],
+    'whmr_iuv_rasterize': [_P, _I, _I, _P, _I, _P, _I, _P, _P, _F, _F, _F, _F, _F, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     'whmr_maxpool_nhwc': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'whmr_avgpool_nhwc': [_P, _P, _I, _I, _I, _I, _P],
 }
@@ -337,6 +338,29 @@ def scale_rows_cast(src, scale, dtype):
     _check(lib().whmr_scale_rows_cast(src.data_ptr(), scale.data_ptr(), dst.data_ptr(), src.shape[0], src.shape[1], int(dtype == torch.bfloat16),
                                       _stream()), 'whmr_scale_rows_cast')
     return dst
+
+
+def iuv_rasterize(verts, faces, tex, cam, K, focal, orig_size, out_size, vmap=None, want_faces=False):
+    """IUV image [B, 3, H, W] of the meshes ``verts`` [B, Vsrc, 3] (see include/whmr_hip.h: whmr_iuv_rasterize).  K = (fx, fy, px, py)."""
+    _dev(verts, faces, tex, cam, vmap)
+    verts, cam, tex = _f32c(verts.contiguous()), _f32c(cam.contiguous()), _f32c(tex.contiguous())
+    assert faces.dtype == torch.int32 and faces.is_contiguous() and faces.shape[1] == 3
+    B, Vsrc = verts.shape[0], verts.shape[1]
+    V = tex.shape[0]
+    if vmap is not None:
+        assert vmap.dtype == torch.int64 and vmap.numel() == V
+    else:
+        assert V == Vsrc
+    H, W = out_size
+    dev = verts.device
+    scr = torch.empty(B, V, 3, dtype=torch.float32, device=dev)
+    zbuf = torch.empty(B, H, W, dtype=torch.int64, device=dev)
+    out = torch.empty(B, 3, H, W, dtype=torch.float32, device=dev)
+    fo = torch.empty(B, H, W, dtype=torch.int32, device=dev) if want_faces else None
+    _check(lib().whmr_iuv_rasterize(verts.data_ptr(), B, Vsrc, _ptr(vmap), V, faces.data_ptr(), faces.shape[0], tex.data_ptr(), cam.data_ptr(),
+                                    K[0], K[1], K[2], K[3], focal, orig_size[0], orig_size[1], H, W, scr.data_ptr(), zbuf.data_ptr(), out.data_ptr(),
+                                    _ptr(fo), _stream()), 'whmr_iuv_rasterize')
+    return (out, fo) if want_faces else out
 
 
 def layernorm(x, weight, bias, out, eps):

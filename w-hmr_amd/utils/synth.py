@@ -223,6 +223,22 @@ def make_state_dict(seed=0, assets=None, img_size=(256, 192), with_cam_model=Tru
     return sd
 
 
+def make_densepose_tables(seed=0, assets=None):
+    """Synthetic stand-in for the DensePose tables of data/UV_data/UV_Processed.mat (licensed, not shipped): 7829 vertices = the 6890 SMPL
+    ones + 939 seam duplicates, 13774 small faces from two spatial orderings of the synthetic rest pose, per-vertex (part / 24, U, V) textures
+    with the part index constant per face neighbourhood."""
+    assets = assets if assets is not None else make_assets(seed)
+    vt = assets['smpl']['v_template']
+    r = _rng(seed, 'densepose')
+    vmap = torch.cat([torch.arange(6890), _t(r.integers(0, 6890, 939)).long()])
+    o1 = torch.argsort((vt[:, 1] * 20).floor() * 1000 + vt[:, 0] * 10)
+    o2 = torch.argsort((vt[:, 1] * 20).floor() * 1000 + vt[:, 2] * 10)
+    faces = torch.cat([torch.stack([o1[:-2], o1[1:-1], o1[2:]], 1), torch.stack([o2[:-2], o2[2:], o2[1:-1]], 1)])[:13774].to(torch.int32).contiguous()
+    part = ((vt[vmap, 1] - vt[:, 1].min()) / (vt[:, 1].max() - vt[:, 1].min() + 1e-6) * 23.99).floor() + 1        # 24 horizontal bands
+    tex = torch.stack([part / 24.0, _t(r.uniform(0, 1, 7829)), _t(r.uniform(0, 1, 7829))], 1).float()
+    return dict(vert_mapping=vmap, faces=faces, textures_vts=tex)
+
+
 def make_hmr_state(seed=0, assets=None):
     """HMR (models/hmr.py:164-213) weights: torchvision-style R50 trunk + fc1/fc2/decpose/decshape/deccam + init buffers."""
     assets = assets if assets is not None else make_assets(seed)
