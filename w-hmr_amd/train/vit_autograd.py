@@ -66,7 +66,10 @@ def vit_forward_train(m, x):
     if m.training and m.drop_path_rate > 0.0:
         masks = m.drop_masks.to(dev).float() if m.drop_masks is not None else None
         if masks is None:
-            keep = 1.0 - torch.tensor(m.dpr, **f32).repeat_interleave(2).view(-1, 1)
+            cache = m.__dict__.setdefault('_keep_prob', {})          # built once per device, outside any graph capture (an H2D copy is not capturable)
+            keep = cache.get(dev)
+            if keep is None:
+                keep = cache[dev] = (1.0 - torch.tensor(m.dpr, **f32)).repeat_interleave(2).view(-1, 1)
             masks = torch.floor(keep + torch.rand(2 * m.depth, B, **f32))
     for li, blk in enumerate(m.blocks):
         a = _Saved()
