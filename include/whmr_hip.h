@@ -314,6 +314,9 @@ int whmr_regressor_post_train_bwd(const float* joints, const float* cam, const f
                                   const float* d_kp2d, const float* d_kp2d_w, const float* d_cam_t, const float* d_focal, float* d_joints,
                                   float* d_cam, float* d_Tz, void* stream);
 
+/* fp32 backward of the attention core (autograd of vit.py:102-111 in the fp32 parity mode; the timm Block of the Tz head, whmr.py:423,574): qkv
+ * [B, N, 3, H, d] + dout [B, N, H*d] -> dqkv [B, N, 3, H, d], N <= 256, any head dim; scratch >= B*H*2*N*N floats; deterministic. */
+int whmr_attention_bwd_f32(const float* qkv, const float* dout, float* dqkv, float* scratch, int B, int N, int H, int d, float scale, void* stream);
 /* dst[m, :] = scale[m] * src[m, :] (fp32 -> fp32 / bf16): stochastic-depth mask on the gradient entering a branch (autograd of vit.py:132-139). */
 int whmr_scale_rows_cast(const float* src, const float* scale, void* dst, int M, int C, int out_bf16, void* stream);
 

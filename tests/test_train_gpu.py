@@ -709,3 +709,52 @@ def test_whmr_train_step_stochastic_depth_matches_oracle(dev, assets, state_dict
     for k in ('feature_extractor.backbone.blocks.5.attn.proj.weight', 'feature_extractor.backbone.blocks.11.mlp.fc2.bias',
               'feature_extractor.backbone.blocks.0.attn.qkv.weight', 'feature_extractor.backbone.pos_embed', 'regressor.2.deccam.weight'):
         assert _rms(named[k].grad.cpu(), p[k].grad) < 1e-2, k
+
+
+@pytest.mark.parametrize('B,N,H,d', [(2, 196, 12, 64), (3, 5, 2, 108), (2, 192, 3, 64), (1, 70, 2, 32)])
+def test_attention_backward_f32_kernel(dev, B, N, H, d):
+    """whmr_attention_bwd_f32 (fp32 parity mode of the ViT, the Tz head's 5-token timm Block) against torch autograd of softmax(scale q k^T) v"""
+    from whmr_amd import _lib as L
+    g = torch.Generator().manual_seed(N + d)
+    qkv = (torch.randn(B, N, 3, H, d, generator=g) * 1.2).requires_grad_(True)
+    do = torch.randn(B, N, H * d, generator=g)
+    q, k, v = qkv.permute(2, 0, 3, 1, 4)
+    out = (((q * d ** -0.5) @ k.transpose(-2, -1)).softmax(-1) @ v).transpose(1, 2).reshape(B, N, H * d)
+    (out * do).sum().backward()
+    got = L.attention_bwd_f32(qkv.detach().reshape(B * N, 3 * H * d).to(dev), do.reshape(B * N, H * d).to(dev), B, N, H, d, d ** -0.5)
+    assert _rel(got.cpu().view_as(qkv), qkv.grad) < 2e-5
+    again = L.attention_bwd_f32(qkv.detach().reshape(B * N, 3 * H * d).to(dev), do.reshape(B * N, H * d).to(dev), B, N, H, d, d ** -0.5)
+    assert torch.equal(got, again)                                                     # deterministic
+
+
+def test_tz_block_autograd_nodes(dev):
+    """LayerNormFn / GeluFn / AttentionF32Fn (HIP forward + backward) of the Tz head's timm Block against torch autograd of the same ops"""
+    import torch.nn.functional as F
+    from whmr_amd.train.heads_autograd import AttentionF32Fn, GeluFn, LayerNormFn
+    g = torch.Generator().manual_seed(0)
+    B, N, H, d = 4, 5, 2, 108
+    D = H * d
+    x = torch.randn(B * N, D, generator=g)
+    w, b = torch.randn(D, generator=g) * 0.2 + 1, torch.randn(D, generator=g) * 0.1
+    wq = torch.randn(3 * D, D, generator=g) / D ** 0.5
+    G = torch.randn(B * N, D, generator=g)
+
+    def run(xx, ww, bb, wqq, hip):
+        h = LayerNormFn.apply(xx, ww, bb, 1e-5) if hip else F.layer_norm(xx, (D,), ww, bb, 1e-5)
+        qkv = h @ wqq.t()
+        if hip:
+            a = AttentionF32Fn.apply(qkv, B, N, H, d, d ** -0.5)
+            y = GeluFn.apply(a)
+        else:
+            q, k, v = qkv.view(B, N, 3, H, d).permute(2, 0, 3, 1, 4)
+            a = (((q * d ** -0.5) @ k.transpose(-2, -1)).softmax(-1) @ v).transpose(1, 2).reshape(B * N, D)
+            y = F.gelu(a)
+        return y
+    ref_in = [t.clone().requires_grad_(True) for t in (x, w, b, wq)]
+    (run(*ref_in, hip=False) * G).sum().backward()
+    dev_in = [t.clone().to(dev).requires_grad_(True) for t in (x, w, b, wq)]
+    out = run(*dev_in, hip=True)
+    (out * G.to(dev)).sum().backward()
+    assert _rel(out.detach().cpu(), run(x, w, b, wq, hip=False)) < 1e-5
+    for a, r, name in zip(dev_in, ref_in, ('x', 'ln.weight', 'ln.bias', 'qkv.weight')):
+        assert _rel(a.grad.cpu(), r.grad) < 5e-5, name

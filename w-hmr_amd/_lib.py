@@ -101,6 +101,7 @@ _SIGS = {
     'whmr_csr_apply3': [_P, _P, _P, _P, _I, _P, _I, _I, _I, _P],
     'whmr_regressor_post_train': [_P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P],
     'whmr_regressor_post_train_bwd': [_P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P, _P],
+    'whmr_attention_bwd_f32': [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
     'whmr_scale_rows_cast': [_P, _P, _P, _I, _I, _I, _P],
     'whmr_iuv_rasterize': [_P, _I, _I, _P, _I, _P, _I, _P, _P, _F, _F, _F, _F, _F, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     'whmr_maxpool_nhwc': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
@@ -692,6 +693,17 @@ def attention_bwd(qkv, o, dout, lse, dqkv, B, N, H, d, scale):
         assert t.is_contiguous()
     _check(lib().whmr_attention_bwd(qkv.data_ptr(), o.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), B, N, H, d, scale,
                                     _stream()), 'whmr_attention_bwd')
+    return dqkv
+
+
+def attention_bwd_f32(qkv, dout, B, N, H, d, scale):
+    """fp32 attention backward: qkv [B*N, 3*H*d], dout [B*N, H*d] -> dqkv like qkv (P recomputed; deterministic)"""
+    _dev(qkv, dout)
+    qkv, dout = _f32c(qkv.contiguous()), _f32c(dout.contiguous())
+    dqkv = torch.empty_like(qkv)
+    scratch = torch.empty(B * H * 2 * N * N, dtype=torch.float32, device=qkv.device)
+    _check(lib().whmr_attention_bwd_f32(qkv.data_ptr(), dout.data_ptr(), dqkv.data_ptr(), scratch.data_ptr(), B, N, H, d, scale, _stream()),
+           'whmr_attention_bwd_f32')
     return dqkv
 
 

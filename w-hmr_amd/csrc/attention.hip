@@ -751,3 +751,123 @@ extern "C" int whmr_attention_bwd(const void* qkv, const void* o, const float* d
     return (int)hipErrorInvalidValue;
 }
 
+
+// ---- fp32 backward of the attention core (parity mode of the ViT, the 5-token timm Block of the Tz head: any head dim, N <= 256): autograd of
+// vit.py:102-111 / timm Attention.  One workgroup per (image, head), deterministic (fixed loop orders, no atomics):
+//   phase 1, one wave per query row i:  s_ij = scale q_i.k_j -> p_ij = softmax_j;  dp_ij = dO_i.v_j;  D_i = sum_j p_ij dp_ij;
+//            ds_ij = scale p_ij (dp_ij - D_i);  dQ_i = sum_j ds_ij k_j;  the rows p_i, ds_i go to a global scratch [2][N][N] of this (b, h)
+//   phase 2, one wave per key row j:    dK_j = sum_i ds_ij q_i,  dV_j = sum_i p_ij dO_i
+// K, V (phase 1) and Q, dO (phase 2) sit in LDS with rows padded to d + 1 floats (conflict-free when lane = row).
+__global__ __launch_bounds__(256) void attention_bwd_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ dout, float* __restrict__ dqkv,
+                                                                float* __restrict__ scratch, int N, int H, int d, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int ds1 = d + 1;
+    float* A = (float*)smem;                     // [N][d+1]: K, then Q
+    float* Bm = A + (size_t)N * ds1;             // [N][d+1]: V, then dO
+    float* rowbuf = Bm + (size_t)N * ds1;        // [4 waves][N]: ds row of the wave's current query
+    float* qbuf = rowbuf + 4 * N;                // [4 waves][2][d]: q_i and dO_i of the wave's current query
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int C = H * d, ld = 3 * C;
+    const float* base = qkv + (size_t)b * N * ld + h * d;
+    const float* dob = dout + (size_t)b * N * C + h * d;
+    float* dbase = dqkv + (size_t)b * N * ld + h * d;
+    float* P = scratch + (size_t)blockIdx.x * 2 * N * N;
+    float* DS = P + (size_t)N * N;
+    for (int e = tid; e < N * d; e += 256) {
+        const int r = e / d, c = e - r * d;
+        A[r * ds1 + c] = base[(size_t)r * ld + C + c];
+        Bm[r * ds1 + c] = base[(size_t)r * ld + 2 * C + c];
+    }
+    __syncthreads();
+    float* myrow = rowbuf + wave * N;
+    float* myq = qbuf + wave * 2 * d;
+    constexpr int KPL = 4;                       // keys per lane (N <= 256)
+    for (int i = wave; i < N; i += 4) {
+        for (int c = lane; c < d; c += 64) { myq[c] = base[(size_t)i * ld + c]; myq[d + c] = dob[(size_t)i * C + c]; }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        float s[KPL], dp[KPL];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < KPL; ++t) {
+            const int j = lane + 64 * t;
+            float a = 0.f, g = 0.f;
+            if (j < N) {
+                const float* kr = A + j * ds1;
+                const float* vr = Bm + j * ds1;
+                for (int c = 0; c < d; ++c) { a = fmaf(myq[c], kr[c], a); g = fmaf(myq[d + c], vr[c], g); }
+                a *= scale;
+                mx = fmaxf(mx, a);
+            }
+            s[t] = a; dp[t] = g;
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < KPL; ++t) {
+            const int j = lane + 64 * t;
+            s[t] = j < N ? expf(s[t] - mx) : 0.f;
+            sum += s[t];
+        }
+        sum = wave_sum(sum);
+        const float inv = 1.0f / sum;
+        float dsum = 0.f;
+#pragma unroll
+        for (int t = 0; t < KPL; ++t) { s[t] *= inv; dsum = fmaf(s[t], dp[t], dsum); }
+        dsum = wave_sum(dsum);
+#pragma unroll
+        for (int t = 0; t < KPL; ++t) {
+            const int j = lane + 64 * t;
+            if (j < N) {
+                const float dsv = scale * s[t] * (dp[t] - dsum);
+                myrow[j] = dsv;
+                P[(size_t)i * N + j] = s[t];
+                DS[(size_t)i * N + j] = dsv;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int c = lane; c < d; c += 64) {
+            float acc = 0.f;
+            for (int j = 0; j < N; ++j) acc = fmaf(myrow[j], A[j * ds1 + c], acc);
+            dbase[(size_t)i * ld + c] = acc;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();                             // phase-1 scratch rows of this block are complete and visible to the block
+    for (int e = tid; e < N * d; e += 256) {
+        const int r = e / d, c = e - r * d;
+        A[r * ds1 + c] = base[(size_t)r * ld + c];
+        Bm[r * ds1 + c] = dob[(size_t)r * C + c];
+    }
+    __syncthreads();
+    for (int j = wave; j < N; j += 4) {
+        for (int c = lane; c < d; c += 64) {
+            float ak = 0.f, av = 0.f;
+            for (int i = 0; i < N; ++i) {
+                ak = fmaf(DS[(size_t)i * N + j], A[i * ds1 + c], ak);
+                av = fmaf(P[(size_t)i * N + j], Bm[i * ds1 + c], av);
+            }
+            dbase[(size_t)j * ld + C + c] = ak;
+            dbase[(size_t)j * ld + 2 * C + c] = av;
+        }
+    }
+}
+
+// qkv [B, N, 3, H, d] fp32, dout [B, N, H*d] fp32 -> dqkv [B, N, 3, H, d] fp32; scratch >= B*H*2*N*N floats.
+extern "C" int whmr_attention_bwd_f32(const float* qkv, const float* dout, float* dqkv, float* scratch, int B, int N, int H, int d, float scale,
+                                      void* stream) {
+    if (B <= 0 || N <= 0 || N > 256 || H <= 0 || d <= 0) return (int)hipErrorInvalidValue;
+    const size_t lds = ((size_t)2 * N * (d + 1) + 4 * N + 8 * d) * sizeof(float);
+    if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)attention_bwd_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(attention_bwd_f32_kernel, dim3(B * H), dim3(256), lds, (hipStream_t)stream, qkv, dout, dqkv, scratch, N, H, d, scale);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}

@@ -51,6 +51,71 @@ class LinearFn(torch.autograd.Function):
         return dx, dw, db
 
 
+class LayerNormFn(torch.autograd.Function):
+    """y = LayerNormFn.apply(x [R, C] fp32, weight, bias, eps): whmr_layernorm forward, whmr_layernorm_bwd backward (timm Block of the Tz head)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        if not x.is_cuda:
+            raise RuntimeError('whmr_amd runs on a HIP device only (no CPU fallback)')
+        x = _f32(x.detach())
+        y = torch.empty_like(x)
+        L.layernorm(x, _f32(weight.detach()), _f32(bias.detach()), y, eps)
+        ctx.saved, ctx.eps = (x, weight), eps
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved
+        ctx.saved = None
+        C = x.shape[-1]
+        dx = torch.empty_like(x)
+        dg = torch.empty(C, dtype=torch.float32, device=x.device)
+        db = torch.empty(C, dtype=torch.float32, device=x.device)
+        L.layernorm_bwd(x, _f32(dy), _f32(weight.detach()), None, dx, dg, db, ctx.eps)
+        return dx, dg, db, None
+
+
+class GeluFn(torch.autograd.Function):
+    """exact-erf GELU: whmr_gelu_fwd / whmr_gelu_bwd (fp32)"""
+
+    @staticmethod
+    def forward(ctx, pre):
+        pre = _f32(pre.detach())
+        out = torch.empty_like(pre)
+        L.gelu_fwd(pre, out)
+        ctx.saved = pre
+        return out
+
+    @staticmethod
+    def backward(ctx, dh):
+        pre = ctx.saved
+        ctx.saved = None
+        dpre = torch.empty_like(pre)
+        L.gelu_bwd(pre, _f32(dh), dpre)
+        return dpre
+
+
+class AttentionF32Fn(torch.autograd.Function):
+    """att [B*N, H*d] = AttentionF32Fn.apply(qkv [B*N, 3*H*d] fp32, B, N, H, d, scale): softmax(scale q k^T) v per (image, head) on the fp32
+    kernels (forward whmr_attention, backward whmr_attention_bwd_f32) -- the timm Attention of the Tz head's Block (whmr.py:423,574)."""
+
+    @staticmethod
+    def forward(ctx, qkv, B, N, H, d, scale):
+        qkv = _f32(qkv.detach())
+        out = torch.empty(B * N, H * d, dtype=torch.float32, device=qkv.device)
+        L.attention(qkv, out, B, N, H, d, scale)
+        ctx.saved, ctx.dims = qkv, (B, N, H, d, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv = ctx.saved
+        ctx.saved = None
+        B, N, H, d, scale = ctx.dims
+        return L.attention_bwd_f32(qkv, _f32(dout), B, N, H, d, scale), None, None, None, None, None
+
+
 class ConvNHWCFn(torch.autograd.Function):
     """y [B,OH,OW,Cout] (dt) = ConvNHWCFn.apply(x [B,IH,IW,Cin] (dt), weight [Cout,Cin,KH,KW], stride, dt, padding=0, bias=None): Conv2d on a
     channels-last map (Tz head: 7x7 s3 / s2 without bias or padding, whmr.py:419-420; IUV head: 3x3 s1 p1 with bias, iuv_predictor.py:71-91)."""

@@ -10,7 +10,7 @@ driven by ``core/trainer.py:410-470`` (loss.backward()).  Here the backward pass
     (``train_ops.hip``), all deterministic (two-stage reductions, no atomics);
   * the attention core's backward is the MFMA kernel ``whmr_attention_bwd`` (bf16 mode, head dim 64, 64 < N <= 224; P is
     recomputed from the saved qkv and the log-sum-exp the training forward writes); the fp32 parity mode and other shapes
-    use a handful of batched PyTorch matmuls on the device instead.
+    run the fp32 HIP kernel ``whmr_attention_bwd_f32`` (any head dim, N <= 256).
 
 ``numerics='fp32'`` (exact-f32 MFMA) is the parity mode against the CPU reference's autograd; ``'bf16'`` casts GEMM operands
 to bf16 and keeps the residual-stream gradient, LayerNorm statistics and all weight gradients in fp32.
@@ -113,18 +113,11 @@ def _hip_attention_bwd(m, N):
 
 
 def _attention_bwd(qkv, d_att, B, N, H, dh, scale, dt):
-    """Backward of softmax(q k^T * scale) v per (image, head): recompute P from the saved qkv (batched matmuls on the device;
-    bf16 operands / fp32 softmax in the bf16 mode, all fp32 in the parity mode)."""
-    q, k, v = qkv.view(B, N, 3, H, dh).permute(2, 0, 3, 1, 4)                        # [B, H, N, dh] views
-    do = d_att.view(B, N, H, dh).permute(0, 2, 1, 3).to(dt)
-    p = torch.softmax((q @ k.transpose(-1, -2)).float() * scale, dim=-1)               # fp32 probabilities
-    pc = p.to(dt)
-    dv = pc.transpose(-1, -2) @ do
-    dp = (do @ v.transpose(-1, -2)).float()
-    ds = (p * (dp - (dp * p).sum(-1, keepdim=True)) * scale).to(dt)
-    dq = ds @ k
-    dk = ds.transpose(-1, -2) @ q
-    return torch.stack((dq, dk, dv), 0).permute(1, 3, 0, 2, 4).reshape(B * N, 3 * H * dh).contiguous()
+    """Backward of softmax(q k^T * scale) v per (image, head) outside the MFMA kernel's envelope (fp32 parity mode, or a bf16 run with N outside
+    (64, 224]): the fp32 HIP kernel ``whmr_attention_bwd_f32`` (P recomputed from the saved qkv, deterministic); bf16 operands are widened first."""
+    dq = L.attention_bwd_f32(qkv.float() if qkv.dtype != torch.float32 else qkv, d_att.float() if d_att.dtype != torch.float32 else d_att,
+                             B, N, H, dh, scale)
+    return dq if dt == torch.float32 else L.cast_bf16(dq)
 
 
 @torch.no_grad()

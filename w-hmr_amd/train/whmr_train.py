@@ -31,7 +31,7 @@ from .. import _lib as L
 from ..core.cfgs import cfg
 from ..core.constants import FOCAL_LENGTH
 from .deconv_autograd import DeconvBNReLUFn
-from .heads_autograd import ConvNHWCFn, DownsampleFn, LinearFn, RegressorPostFn
+from .heads_autograd import AttentionF32Fn, ConvNHWCFn, DownsampleFn, GeluFn, LayerNormFn, LinearFn, RegressorPostFn
 from .maf_autograd import MAFSampleFn
 from .smpl_autograd import SMPLFn
 
@@ -63,18 +63,19 @@ def tz_head_train(model, f_nhwc):
     B = f_nhwc.shape[0]
     y0 = ConvNHWCFn.apply(f_nhwc, model.conv[0].weight, 3, dt)
     y1 = ConvNHWCFn.apply(y0, model.conv[1].weight, 2, dt)                            # [B, 18, 12, 5]
-    t = y1.float().permute(0, 3, 1, 2).reshape(B, 5, -1)                               # == conv(...).reshape(B, 5, -1) on NCHW, whmr.py:571
+    t = y1.float().permute(0, 3, 1, 2).reshape(B * 5, -1).contiguous()                 # == conv(...).reshape(B, 5, -1) on NCHW, whmr.py:571
     D = t.shape[-1]
     td = model.transformer_decoder                                                     # timm Block(dim 216, 2 heads, qkv_bias False)
     nh, hd = 2, D // 2
-    h = F.layer_norm(t, (D,), td.norm1.weight, td.norm1.bias, 1e-5)
-    qkv = _linear(h.reshape(B * 5, D), td.attn.qkv).reshape(B, 5, 3, nh, hd).permute(2, 0, 3, 1, 4)
-    a = ((qkv[0] @ qkv[1].transpose(-2, -1)) * hd ** -0.5).softmax(dim=-1)
-    h = (a @ qkv[2]).transpose(1, 2).reshape(B * 5, D)
-    t = t + _linear(h, td.attn.proj).view(B, 5, D)
-    h = F.layer_norm(t, (D,), td.norm2.weight, td.norm2.bias, 1e-5)
-    h = F.gelu(_linear(h.reshape(B * 5, D), td.mlp.fc1))
-    t = t + _linear(h, td.mlp.fc2).view(B, 5, D)
+    # every op of the Block is an autograd node with a HIP forward and backward (LayerNorm, Linear, the fp32 attention core, exact GELU);
+    # only the two residual adds are element-wise tensor arithmetic
+    h = LayerNormFn.apply(t, td.norm1.weight, td.norm1.bias, 1e-5)
+    qkv = _linear(h, td.attn.qkv)                                                      # [B*5, 3*D] = [B, 5, 3, heads, hd]
+    h = AttentionF32Fn.apply(qkv, B, 5, nh, hd, hd ** -0.5)
+    t = t + _linear(h, td.attn.proj)
+    h = LayerNormFn.apply(t, td.norm2.weight, td.norm2.bias, 1e-5)
+    h = GeluFn.apply(_linear(h, td.mlp.fc1))
+    t = (t + _linear(h, td.mlp.fc2)).view(B, 5, D)
     s = t.mean(dim=1)                                                                  # transpose + AvgPool1d(5) + squeeze, whmr.py:574-575
     e = model.est_Tz
     y = _linear(_linear(s, e[0]), e[1])
