@@ -236,6 +236,7 @@ def whmr_parity_and_fp32(args, dev, n_sample=2):
     """whmr workload extras: (1) max-rel error of theta / vertices / projected 2-D joints of the HIP forward against the CPU oracle on the
     first ``n_sample`` crops of the benchmark batch, in the benchmark numerics and in the fp32 parity mode; (2) ms per step of the fp32 mode."""
     from oracle import whmr as OW
+    n_sample = min(n_sample, args.batch)
     m, sd, assets, inp, kw = args.parity_ctx
     cpu = {k: v[:n_sample].cpu() for k, v in inp.items()}
     full = kw['full_x'].cpu() if 'full_x' in kw else None

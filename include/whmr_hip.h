@@ -320,6 +320,17 @@ int whmr_attention_bwd_f32(const float* qkv, const float* dout, float* dqkv, flo
 /* dst[m, :] = scale[m] * src[m, :] (fp32 -> fp32 / bf16): stochastic-depth mask on the gradient entering a branch (autograd of vit.py:132-139). */
 int whmr_scale_rows_cast(const float* src, const float* scale, void* dst, int M, int C, int out_bf16, void* stream);
 
+/* Tail of one regressor stage (whmr.py:142-209 after the skinning) in two launches: dense joint regression over the mesh (9 extra rows, or 33 with
+ * J_regressor for smpl_joints45; B x R workgroups), then per image the 54 -> 49 joint gather, markers, and -- when `state` is given -- theta / kp_2d / kp_2d_w / cam_t / focal
+ * (whmr.py:142-173,190) plus -- when `xc_next` is given -- the next stage's input state [bbox_info | rotmat | shape | cam] (whmr.py:105,119). */
+struct whmr_stage_tail {
+    const float* verts; const float* posed_joints; const float* regd /* internal */; float* joints49; float* smpl_joints45; float* markers; int32_t R;
+    const float* state; int64_t state_stride; const float* aa; const float* Tz; const float* bbox_h; const float* center; const float* orig_shape;
+    float focal0, res_w, res_h; float* theta; float* kp2d; float* kp2d_w; float* cam_t; float* focal;
+    const float* bbox_info; const float* rotmat; float* xc_next; int64_t ld_next; int32_t F_next;
+};
+int whmr_smpl_stage_tail(const struct whmr_smpl_model* m, const struct whmr_stage_tail* t, int B, float* scratch /* >= B*33*3 floats */, void* stream);
+
 /* ---- training-step ground truth: IUV rasteriser = pytorch3d MeshRasterizer(faces_per_pixel 1, blur 0) + HardFlatShader over
  * TexturesVertex as utils/renderer.py:296-446 (IUV_Renderer.verts2iuvimg) uses it from core/trainer.py:442-464.  verts [B, Vsrc, 3]; vmap [V]
  * int64 or null (DensePose vertex duplication); faces [F, 3] int32; tex [V, 3] = (I/24, U, V); cam [B, 3] = (s, tx, ty); K of the orig_h x orig_w

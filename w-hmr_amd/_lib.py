@@ -43,6 +43,15 @@ class WhmrSmplModel(C.Structure):
                 ('n_markers', C.c_int32)]
 
 
+class WhmrStageTail(C.Structure):
+    _fields_ = [('verts', C.c_void_p), ('posed_joints', C.c_void_p), ('regd', C.c_void_p), ('joints49', C.c_void_p), ('smpl_joints45', C.c_void_p),
+                ('markers', C.c_void_p), ('R', C.c_int32),
+                ('state', C.c_void_p), ('state_stride', C.c_int64), ('aa', C.c_void_p), ('Tz', C.c_void_p), ('bbox_h', C.c_void_p),
+                ('center', C.c_void_p), ('orig_shape', C.c_void_p), ('focal0', C.c_float), ('res_w', C.c_float), ('res_h', C.c_float),
+                ('theta', C.c_void_p), ('kp2d', C.c_void_p), ('kp2d_w', C.c_void_p), ('cam_t', C.c_void_p), ('focal', C.c_void_p),
+                ('bbox_info', C.c_void_p), ('rotmat', C.c_void_p), ('xc_next', C.c_void_p), ('ld_next', C.c_int64), ('F_next', C.c_int32)]
+
+
 class WhmrMafWeights(C.Structure):
     _fields_ = [('w0t', C.c_void_p), ('b0', C.c_void_p), ('w1t', C.c_void_p), ('b1', C.c_void_p),
                 ('w2t', C.c_void_p), ('b2', C.c_void_p), ('w0b', C.c_void_p), ('w1b', C.c_void_p), ('w2b', C.c_void_p)]
@@ -73,6 +82,7 @@ _SIGS = {
     'whmr_smpl_pose_chain': [C.POINTER(WhmrSmplModel), _P, _L, _P, _L, _I, _I, _P, _P, _P, _P, _P, _P],
     'whmr_regressor_post': [_P, _L, _P, _P, _P, _P, _P, _P, _I, _F, _F, _F, _P, _P, _P, _P, _P, _P],
     'whmr_smpl_skin': [C.POINTER(WhmrSmplModel), _P, _L, _P, _P, _P, _I, _P, _P],
+    'whmr_smpl_stage_tail': [C.POINTER(WhmrSmplModel), C.POINTER(WhmrStageTail), _I, _P, _P],
     'whmr_smpl_joints': [C.POINTER(WhmrSmplModel), _P, _P, _I, _P, _P, _P, _P, _P],
     'whmr_maf_sample': [_P, _I, _L, _L, _L, _L, _I, _I, _P, _P, _P, _L, _F, _F, _F, C.POINTER(WhmrMafWeights), _I, _I, _P, _L, _P, _P],
     'whmr_crop_normalize': [_P, _I, _I, _L, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
@@ -498,6 +508,35 @@ def regressor_post(state, aa, joints49, Tz, bbox_h, center, orig_shape, focal0=1
                                      focal0, res_w, res_h, theta.data_ptr(), kp.data_ptr(), kpw.data_ptr(), cam_t.data_ptr(),
                                      focal.data_ptr(), _stream()), 'whmr_regressor_post')
     return theta, kp, kpw, cam_t, focal
+
+
+def smpl_stage_tail(model, verts, posed_joints, joints49, smpl_joints45, markers, post=None, nxt=None):
+    """One launch for the tail of a regressor stage (whmr_smpl_stage_tail).  post = dict(state, aa, Tz, bbox_h, center, orig_shape, focal0, res_w, res_h)
+    -> returns (theta, kp_2d, kp_2d_w, cam_t, focal); nxt = dict(bbox_info, rotmat, xc, F): the next stage's input buffer gets its state columns."""
+    _dev(verts, posed_joints, joints49, smpl_joints45, markers)
+    B = verts.shape[0]
+    t = WhmrStageTail()
+    t.verts, t.posed_joints, t.joints49 = verts.data_ptr(), posed_joints.data_ptr(), _ptr(joints49)
+    t.smpl_joints45, t.markers, t.R = _ptr(smpl_joints45), _ptr(markers), 33 if smpl_joints45 is not None else 9
+    out = None
+    if post is not None:
+        st = post['state']
+        _dev(st, post['aa'], post['Tz'], post['bbox_h'], post['center'], post['orig_shape'])
+        sp, ss = _rows(st, 229)
+        f32 = dict(dtype=torch.float32, device=verts.device)
+        out = (torch.empty(B, 85, **f32), torch.empty(B, 49, 2, **f32), torch.empty(B, 49, 2, **f32), torch.empty(B, 3, **f32), torch.empty(B, **f32))
+        t.state, t.state_stride, t.aa, t.Tz = sp, ss, _f32c(post['aa']).data_ptr(), _f32c(post['Tz']).data_ptr()
+        t.bbox_h, t.center, t.orig_shape = _f32c(post['bbox_h']).data_ptr(), _f32c(post['center']).data_ptr(), _f32c(post['orig_shape']).data_ptr()
+        t.focal0, t.res_w, t.res_h = post['focal0'], post['res_w'], post['res_h']
+        t.theta, t.kp2d, t.kp2d_w, t.cam_t, t.focal = (o.data_ptr() for o in out)
+        if nxt is not None:
+            _dev(nxt['bbox_info'], nxt['rotmat'], nxt['xc'])
+            assert nxt['xc'].dtype == torch.float32 and nxt['xc'].stride(1) == 1 and nxt['xc'].shape[1] >= nxt['F'] + 234
+            t.bbox_info, t.rotmat = _f32c(nxt['bbox_info']).data_ptr(), _f32c(nxt['rotmat']).data_ptr()
+            t.xc_next, t.ld_next, t.F_next = nxt['xc'].data_ptr(), nxt['xc'].stride(0), nxt['F']
+    scratch = torch.empty(B * 33 * 3, dtype=torch.float32, device=verts.device)
+    _check(lib().whmr_smpl_stage_tail(C.byref(model), C.byref(t), B, scratch.data_ptr(), _stream()), 'whmr_smpl_stage_tail')
+    return out
 
 
 def smpl_joints(model, verts, posed_joints, joints49, smpl_joints45, markers):

@@ -289,6 +289,97 @@ extern "C" int whmr_smpl_joints(const whmr_smpl_model* m, const float* verts, co
     return 0;
 }
 
+// ---- fused tail of one regressor stage: joint regression + gather + projections + the next stage's input state, ONE launch --------------
+// smpl_joints + regressor_post + regressor_state (+ a strided-copy of the camera) were dependent launches of ~5 us each on a chain that is
+// pure latency (PyMAF loop, whmr.py:580-627).  One workgroup per image, right behind smpl_regress_kernel: the 54-joint superset is gathered
+// through LDS, the first wave projects the 49 joints (whmr.py:142-173) and all threads write [bbox_info | rotmat | shape | cam] into the
+// NEXT stage's input buffer (whmr.py:105,119).
+struct whmr_stage_tail {
+    // always
+    const float* verts; const float* posed_joints; const float* regd; float* joints49; float* smpl_joints45; float* markers; int32_t R;
+    // projections (state != null): state rows [pose(216) | shape(10) | cam(3)]
+    const float* state; int64_t state_stride; const float* aa; const float* Tz; const float* bbox_h; const float* center; const float* orig_shape;
+    float focal0, res_w, res_h; float* theta; float* kp2d; float* kp2d_w; float* cam_t; float* focal;
+    // next stage input (xc_next != null): xc_next[b*ld + F .. F+234) = [bbox_info(5) | rotmat(216) | shape(10) | cam(3)]
+    const float* bbox_info; const float* rotmat; float* xc_next; int64_t ld_next; int32_t F_next;
+};
+
+__global__ __launch_bounds__(256) void smpl_stage_tail_kernel(const whmr_smpl_model m, const whmr_stage_tail t) {
+    __shared__ float sReg[36][3];
+    __shared__ float sJ[49][3];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* vb = t.verts + (size_t)b * NV * 3;
+    const int R = t.R;
+    // ---- regressed rows of this image (smpl_regress_kernel: B x R workgroups -- a per-image block walking the 33 dense rows itself was 5x slower)
+    if (tid < R * 3) sReg[tid / 3][tid % 3] = t.regd[(size_t)b * R * 3 + tid];
+    __syncthreads();
+    // ---- 54-joint superset -> JOINT_MAP (models/smpl.py:61-83), smpl_joints45 (whmr.py:186-187), markers (whmr.py:184)
+    if (tid < 49 * 3) {
+        const int j = tid / 3, c = tid % 3;
+        const int s = m.joint_map[j];
+        float v;
+        if (s < 24) v = t.posed_joints[((size_t)b * NJ + s) * 3 + c];
+        else if (s < 45) v = vb[3 * m.extra_vertex_ids[s - 24] + c];
+        else v = sReg[s - 45][c];
+        sJ[j][c] = v;
+        if (t.joints49) t.joints49[((size_t)b * 49 + j) * 3 + c] = v;
+    }
+    if (t.smpl_joints45 && tid < 45 * 3) {
+        const int j = tid / 3, c = tid % 3;
+        t.smpl_joints45[((size_t)b * 45 + j) * 3 + c] = j < 24 ? sReg[9 + j][c] : vb[3 * m.extra_vertex_ids[j - 24] + c];
+    }
+    if (t.markers)
+        for (int e = tid; e < m.n_markers * 3; e += 256) t.markers[((size_t)b * m.n_markers) * 3 + e] = vb[3 * m.marker_ids[e / 3] + e % 3];
+    __syncthreads();
+    if (t.state) {
+        const float* st = t.state + (size_t)b * t.state_stride;
+        const float s = st[226], tx = st[227], ty = st[228];
+        const float h = t.bbox_h[b], tz = t.Tz[b];
+        const float focal = s * h * tz / 2.f;
+        const float H = t.orig_shape[2 * b], W = t.orig_shape[2 * b + 1];
+        const float ctx = tx + 2.f * (t.center[2 * b] - W / 2.f) / (s * h);
+        const float cty = ty + 2.f * (t.center[2 * b + 1] - H / 2.f) / (s * h);
+        if (tid == 0) { t.cam_t[3 * b] = ctx; t.cam_t[3 * b + 1] = cty; t.cam_t[3 * b + 2] = tz; t.focal[b] = focal; }
+        if (tid >= 64 && tid < 64 + 85) {
+            const int e = tid - 64;
+            t.theta[(size_t)b * 85 + e] = e < 3 ? st[226 + e] : (e < 13 ? st[216 + e - 3] : t.aa[(size_t)b * 72 + e - 13]);
+        }
+        if (tid < 49) {
+            const float tzw = 2.f * t.focal0 / (t.res_h * s + 1e-9f);
+            const float cxw = W / 2.f, cyw = H / 2.f;
+            const float x = sJ[tid][0], y = sJ[tid][1], z = sJ[tid][2];
+            const float zw = z + tzw;
+            t.kp2d[((size_t)b * 49 + tid) * 2] = (t.focal0 * ((x + tx) / zw)) / (t.res_w / 2.f);
+            t.kp2d[((size_t)b * 49 + tid) * 2 + 1] = (t.focal0 * ((y + ty) / zw)) / (t.res_h / 2.f);
+            const float zf = z + tz;
+            t.kp2d_w[((size_t)b * 49 + tid) * 2] = (focal * ((x + ctx) / zf) + cxw) / cxw - 1.f;
+            t.kp2d_w[((size_t)b * 49 + tid) * 2 + 1] = (focal * ((y + cty) / zf) + cyw) / cyw - 1.f;
+        }
+        if (t.xc_next) {
+            float* row = t.xc_next + (size_t)b * t.ld_next + t.F_next;
+            if (tid < 216) row[5 + tid] = t.rotmat[(size_t)b * 216 + tid];
+            else if (tid < 229) row[5 + tid] = st[tid];                       // shape(10) | cam(3) sit at state[216..229)
+            else if (tid < 234) row[tid - 229] = t.bbox_info[b * 5 + tid - 229];
+        }
+    }
+}
+
+// scratch: >= B*33*3 floats (the regressed rows); two launches: smpl_regress_kernel (B x R workgroups) + the tail.
+extern "C" int whmr_smpl_stage_tail(const whmr_smpl_model* m, const whmr_stage_tail* tt, int B, float* scratch, void* stream) {
+    whmr_stage_tail tv = *tt;
+    const whmr_stage_tail* t = &tv;
+    if (B <= 0 || !t->verts || !t->posed_joints || !scratch) return (int)hipErrorInvalidValue;
+    if (t->R != 9 && t->R != 33) return (int)hipErrorInvalidValue;
+    if (t->R == 33 && m->J_regressor != m->J_regressor_extra + 9 * NV) return (int)hipErrorInvalidValue;
+    if (t->smpl_joints45 && t->R != 33) return (int)hipErrorInvalidValue;
+    if (t->xc_next && (!t->state || !t->rotmat || !t->bbox_info)) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(smpl_regress_kernel, dim3(B * t->R), dim3(256), 0, (hipStream_t)stream, m->J_regressor_extra, t->R, t->verts, B, scratch);
+    tv.regd = scratch;
+    hipLaunchKernelGGL(smpl_stage_tail_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, *m, tv);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}
+
 // Tail of Regressor.forward (whmr.py:142-174) in one launch per batch: weak-perspective key points (geometry.py:289-307),
 // focal length s*h*Tz/2 (whmr.py:147-149), full-image camera translation (geometry.py:139-157), perspective key points in the
 // full image normalised by the image centre (whmr.py:165-173) and theta = [cam | shape | angle-axis] (whmr.py:190).

@@ -70,6 +70,68 @@ def resnet50(pretrained=False):
     return ResNet50()
 
 
+def fold_resnet50(bb, dt):
+    """Eval-mode BatchNorm folded into the conv weights of a torchvision-layout ResNet-50 trunk ``bb`` (conv1 / bn1 / layer1-4), weights laid out
+    [N, (ky, kx, ci)] in the compute dtype ``dt`` -- the operand set of ``run_resnet50``."""
+    def fold(conv, bn, stem_cols=False):
+        s = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach().float()
+        w = conv.weight.detach().float() * s[:, None, None, None]
+        b = (bn.bias - bn.running_mean * s).detach().float().contiguous()
+        if stem_cols:                                          # whmr_conv_im2col column order (ci, ky, kx 7->8), K 168 -> 192
+            w = F.pad(F.pad(w, (0, 1)).reshape(w.shape[0], -1), (0, 192 - 3 * 7 * 8))
+        else:
+            w = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
+        return w.to(dt).contiguous(), b
+
+    prep = {'stem': fold(bb.conv1, bb.bn1, stem_cols=(dt == torch.bfloat16)), 'blocks': []}
+    for li in range(1, 5):
+        for blk in getattr(bb, 'layer%d' % li):
+            prep['blocks'].append(dict(c1=fold(blk.conv1, blk.bn1), c2=fold(blk.conv2, blk.bn2), c3=fold(blk.conv3, blk.bn3),
+                                       stride=blk.conv2.stride[0],
+                                       down=fold(blk.downsample[0], blk.downsample[1]) if blk.downsample is not None else None))
+    return prep
+
+
+@torch.no_grad()
+def run_resnet50(P, images, dt):
+    """NCHW fp32 images -> the layer4 map in NHWC [B, H/32, W/32, 2048] (dtype ``dt``) on the HIP implicit-GEMM kernels."""
+    dev = images.device
+    B, _, H, W = images.shape
+    w, b = P['stem']
+    if dt == torch.bfloat16:
+        cols, OH, OW = L.conv_im2col(images.float(), 7, 7, 2, 3, 192)
+        x = torch.empty(B, OH, OW, 64, dtype=dt, device=dev)
+        L.gemm(cols, w, x, bias=b, act=L.ACT_RELU)
+    else:
+        OH, OW = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+        x = torch.empty(B, OH, OW, 64, dtype=dt, device=dev)
+        L.gemm(images.float().permute(0, 2, 3, 1).contiguous(), w, x, bias=b, act=L.ACT_RELU,
+               conv=dict(IH=H, IW=W, Cin=3, OH=OH, OW=OW, KW=7, SH=2, SW=2, PH=3, PW=3))
+    x = L.maxpool_nhwc(x, 3, 2, 1)
+    for blk in P['blocks']:
+        _, IH, IW, Cin = x.shape
+        s = blk['stride']
+        OH, OW = (IH - 1) // s + 1, (IW - 1) // s + 1
+        planes = blk['c1'][0].shape[0]
+        y1 = torch.empty(B, IH, IW, planes, dtype=dt, device=dev)
+        L.gemm(x, blk['c1'][0], y1, bias=blk['c1'][1], act=L.ACT_RELU)
+        y2 = torch.empty(B, OH, OW, planes, dtype=dt, device=dev)
+        L.gemm(y1, blk['c2'][0], y2, bias=blk['c2'][1], act=L.ACT_RELU,
+               conv=dict(IH=IH, IW=IW, Cin=planes, OH=OH, OW=OW, KW=3, SH=s, SW=s, PH=1, PW=1))
+        if blk['down'] is None:
+            skip = x
+        else:
+            skip = torch.empty(B, OH, OW, planes * 4, dtype=dt, device=dev)
+            if s == 1:
+                L.gemm(x, blk['down'][0], skip, bias=blk['down'][1])
+            else:
+                L.gemm(x, blk['down'][0], skip, bias=blk['down'][1],
+                       conv=dict(IH=IH, IW=IW, Cin=Cin, OH=OH, OW=OW, KW=1, SH=s, SW=s, PH=0, PW=0))
+        x = torch.empty(B, OH, OW, planes * 4, dtype=dt, device=dev)
+        L.gemm(y2, blk['c3'][0], x, bias=blk['c3'][1], act=L.ACT_RELU, residual=skip.view(-1, planes * 4), res_first=True)
+    return x
+
+
 class CameraRegressorNetwork(nn.Module):
     def __init__(self, backbone='resnet50', num_fc_layers=1, num_fc_channels=1024, num_out_channels=256):
         super().__init__()
@@ -96,24 +158,8 @@ class CameraRegressorNetwork(nn.Module):
         if self._prep is not None and self._prep['key'] == key:
             return self._prep
         dt = torch.float32 if self.numerics == 'fp32' else torch.bfloat16
-
-        def fold(conv, bn, stem_cols=False):
-            s = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach().float()
-            w = conv.weight.detach().float() * s[:, None, None, None]
-            b = (bn.bias - bn.running_mean * s).detach().float().contiguous()
-            if stem_cols:                                          # whmr_conv_im2col column order (ci, ky, kx 7->8), K 168 -> 192
-                w = F.pad(F.pad(w, (0, 1)).reshape(w.shape[0], -1), (0, 192 - 3 * 7 * 8))
-            else:
-                w = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
-            return w.to(dt).contiguous(), b
-
-        bb = self.backbone
-        prep = {'key': key, 'stem': fold(bb.conv1, bb.bn1, stem_cols=(dt == torch.bfloat16)), 'blocks': []}
-        for li in range(1, 5):
-            for blk in getattr(bb, 'layer%d' % li):
-                prep['blocks'].append(dict(c1=fold(blk.conv1, blk.bn1), c2=fold(blk.conv2, blk.bn2), c3=fold(blk.conv3, blk.bn3),
-                                           stride=blk.conv2.stride[0],
-                                           down=fold(blk.downsample[0], blk.downsample[1]) if blk.downsample is not None else None))
+        prep = fold_resnet50(self.backbone, dt)
+        prep['key'] = key
         prep['fc_w'] = torch.cat([self.fc_vfov.weight, self.fc_pitch.weight, self.fc_roll.weight], 0).detach().float().contiguous()
         prep['fc_b'] = torch.cat([self.fc_vfov.bias, self.fc_pitch.bias, self.fc_roll.bias], 0).detach().float().contiguous()
         self._prep = prep
@@ -128,39 +174,8 @@ class CameraRegressorNetwork(nn.Module):
         P = self._prepare()
         dt = torch.float32 if self.numerics == 'fp32' else torch.bfloat16
         dev = images.device
-        B, _, H, W = images.shape
-        w, b = P['stem']
-        if dt == torch.bfloat16:
-            cols, OH, OW = L.conv_im2col(images.float(), 7, 7, 2, 3, 192)
-            x = torch.empty(B, OH, OW, 64, dtype=dt, device=dev)
-            L.gemm(cols, w, x, bias=b, act=L.ACT_RELU)
-        else:
-            OH, OW = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
-            x = torch.empty(B, OH, OW, 64, dtype=dt, device=dev)
-            L.gemm(images.float().permute(0, 2, 3, 1).contiguous(), w, x, bias=b, act=L.ACT_RELU,
-                   conv=dict(IH=H, IW=W, Cin=3, OH=OH, OW=OW, KW=7, SH=2, SW=2, PH=3, PW=3))
-        x = L.maxpool_nhwc(x, 3, 2, 1)
-        for blk in P['blocks']:
-            _, IH, IW, Cin = x.shape
-            s = blk['stride']
-            OH, OW = (IH - 1) // s + 1, (IW - 1) // s + 1
-            planes = blk['c1'][0].shape[0]
-            y1 = torch.empty(B, IH, IW, planes, dtype=dt, device=dev)
-            L.gemm(x, blk['c1'][0], y1, bias=blk['c1'][1], act=L.ACT_RELU)
-            y2 = torch.empty(B, OH, OW, planes, dtype=dt, device=dev)
-            L.gemm(y1, blk['c2'][0], y2, bias=blk['c2'][1], act=L.ACT_RELU,
-                   conv=dict(IH=IH, IW=IW, Cin=planes, OH=OH, OW=OW, KW=3, SH=s, SW=s, PH=1, PW=1))
-            if blk['down'] is None:
-                skip = x
-            else:
-                skip = torch.empty(B, OH, OW, planes * 4, dtype=dt, device=dev)
-                if s == 1:
-                    L.gemm(x, blk['down'][0], skip, bias=blk['down'][1])
-                else:
-                    L.gemm(x, blk['down'][0], skip, bias=blk['down'][1],
-                           conv=dict(IH=IH, IW=IW, Cin=Cin, OH=OH, OW=OW, KW=1, SH=s, SW=s, PH=0, PW=0))
-            x = torch.empty(B, OH, OW, planes * 4, dtype=dt, device=dev)
-            L.gemm(y2, blk['c3'][0], x, bias=blk['c3'][1], act=L.ACT_RELU, residual=skip.view(-1, planes * 4), res_first=True)
+        B = images.shape[0]
+        x = run_resnet50(P, images, dt)
         feat = L.avgpool_nhwc(x)
         logits = torch.empty(B, P['fc_w'].shape[0], dtype=torch.float32, device=dev)
         L.gemm(feat, P['fc_w'], logits, bias=P['fc_b'])

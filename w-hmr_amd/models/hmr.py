@@ -2,9 +2,9 @@
 
 ``hmr(smpl_mean_params, pretrained)`` -> module whose ``forward(x, init_pose, init_shape, init_cam, n_iter=3)`` returns
 ``(pred_rotmat [B,24,3,3], pred_shape [B,10], pred_cam [B,3])``; state_dict keys as in the reference (conv1/bn1/layer1-4,
-fc1, fc2, decpose, decshape, deccam, init_*).  The convolutional trunk runs on PyTorch-ROCm (like the camera model, it is
-not one of the hand-written-kernel rows); the iterative FC loop runs on the fp32 split-K GEMM kernel and the final
-rot6d_to_rotmat on the geometry kernel.  Device tensors only.
+fc1, fc2, decpose, decshape, deccam, init_*).  The convolutional trunk runs on the same HIP NHWC implicit-GEMM kernels as the camera model
+(``cam_model.fold_resnet50`` / ``run_resnet50``; ``numerics`` 'fp32' by default: the 1e-4 parity mode), the iterative FC loop on the fp32
+split-K GEMM kernel and the final rot6d_to_rotmat on the geometry kernel.  Device tensors only.
 """
 import numpy as np
 import torch
@@ -13,7 +13,7 @@ import torch.nn.functional as F
 
 from .. import _lib as L
 from ..utils.geometry import rot6d_to_rotmat
-from .cam_model import ResNet50
+from .cam_model import ResNet50, fold_resnet50, run_resnet50
 
 
 class HMR(ResNet50):
@@ -34,13 +34,20 @@ class HMR(ResNet50):
         self.register_buffer('init_pose', torch.from_numpy(np.asarray(mp['pose'], dtype=np.float32)).unsqueeze(0))
         self.register_buffer('init_shape', torch.from_numpy(np.asarray(mp['shape'], dtype=np.float32)).unsqueeze(0))
         self.register_buffer('init_cam', torch.from_numpy(np.asarray(mp['cam'], dtype=np.float32)).unsqueeze(0))
+        self.numerics = 'fp32'
+        self._prep = None
         self.eval()
 
+    @torch.no_grad()
     def features(self, x):
-        """pose_resnet.py:200-217 global_mode view of the same trunk: (feature map, pooled feature)."""
-        f = ResNet50.forward(self, x)
-        g = self.avgpool(f)
-        return f, g.view(g.size(0), -1)
+        """pose_resnet.py:200-217 global_mode view of the same trunk: (feature map [B,2048,H/32,W/32] as an NCHW view, pooled feature [B,2048])."""
+        dt = torch.float32 if self.numerics == 'fp32' else torch.bfloat16
+        ver = tuple(t._version for t in list(self.parameters()) + list(self.buffers())) + (self.numerics, str(x.device))
+        if self._prep is None or self._prep[0] != ver:
+            self._prep = (ver, fold_resnet50(self, dt))
+        f = run_resnet50(self._prep[1], x, dt)                                     # NHWC
+        assert f.shape[1] == 7 and f.shape[2] == 7, 'AvgPool2d(7) of hmr.py:177 expects a 224 x 224 crop'
+        return f.permute(0, 3, 1, 2), L.avgpool_nhwc(f)
 
     @torch.no_grad()
     def forward(self, x, init_pose=None, init_shape=None, init_cam=None, n_iter=3):

@@ -22,7 +22,7 @@ JOINT_REGRESSOR_TRAIN_EXTRA = 'data/J_regressor_extra.npy'
 H36M_TO_J17 = K.H36M_TO_J17
 H36M_TO_J14 = K.H36M_TO_J14
 
-ModelOutput = namedtuple('ModelOutput', ['vertices', 'joints', 'smpl_joints', 'rotmat', 'pose_aa', 'markers'])
+ModelOutput = namedtuple('ModelOutput', ['vertices', 'joints', 'smpl_joints', 'rotmat', 'pose_aa', 'markers', 'post'], defaults=(None,))
 
 
 def _np(a):
@@ -93,8 +93,10 @@ class SMPL(nn.Module):
         return self._dev_cache[1]
 
     @torch.no_grad()
-    def run(self, betas, rotmats, gram_schmidt=False, want_aa=False, want_smpl_joints=False, want_markers=False):
-        """betas [B,10], rotmats [B,24,3,3] (raw 3x3 blocks when gram_schmidt=True) -> ModelOutput."""
+    def run(self, betas, rotmats, gram_schmidt=False, want_aa=False, want_smpl_joints=False, want_markers=False, post=None, nxt=None):
+        """betas [B,10], rotmats [B,24,3,3] (raw 3x3 blocks when gram_schmidt=True) -> ModelOutput.
+        ``post`` / ``nxt`` (Regressor stages, see ``_lib.smpl_stage_tail``): the joint regression, the 49-joint gather, the stage's projections and
+        the next stage's input state leave in ONE launch; the projections come back as ``ModelOutput.post``."""
         if not betas.is_cuda:
             raise RuntimeError('whmr_amd.SMPL runs on a HIP device only (no CPU fallback)')
         B, dev = betas.shape[0], betas.device
@@ -118,8 +120,12 @@ class SMPL(nn.Module):
         joints = torch.empty(B, 49, 3, **f32)
         sj = torch.empty(B, 45, 3, **f32) if want_smpl_joints else None
         mk = torch.empty(B, m.n_markers, 3, **f32) if (want_markers and m.n_markers) else None
-        L.smpl_joints(m, verts, pj, joints, sj, mk)
-        return ModelOutput(verts, joints, sj, rot, aa, mk)
+        tail = None
+        if post is not None:
+            tail = L.smpl_stage_tail(m, verts, pj, joints, sj, mk, post=dict(post, aa=aa), nxt=None if nxt is None else dict(nxt, rotmat=rot))
+        else:
+            L.smpl_stage_tail(m, verts, pj, joints, sj, mk)
+        return ModelOutput(verts, joints, sj, rot, aa, mk, tail)
 
     def forward(self, betas=None, body_pose=None, global_orient=None, pose2rot=False, **kwargs):
         """pare.models.SMPL.forward call shape (whmr.py:132-137).  pose2rot=True takes axis-angle [B,69] / [B,3]."""

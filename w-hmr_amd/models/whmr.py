@@ -146,9 +146,9 @@ class Regressor(nn.Module):
         d = {'verts': verts, 'kp_3d': joints, 'smpl_kp_3d': out.smpl_joints, 'rotmat': out.rotmat, 'pred_cam': cam,
              'pred_shape': shape, 'pred_pose': pose_flat, 'pose': out.pose_aa,
              'pelvis': out.smpl_joints[:, :1] if out.smpl_joints is not None else None, 'markers': out.markers}
-        if Tz is not None:      # one fused launch: theta, kp_2d, focal (whmr.py:147-149), cam_t, kp_2d_w (whmr.py:165-173)
-            theta, kp_2d, kp_w, cam_t, focal = L.regressor_post(state, out.pose_aa, joints, Tz, bbox_height, center, orig_shape,
-                                                                1000.0, float(cfg.IMG_RES.WIDTH), float(cfg.IMG_RES.HEIGHT))
+        if Tz is not None:      # theta, kp_2d, focal (whmr.py:147-149), cam_t, kp_2d_w (whmr.py:165-173): computed by the stage-tail launch
+            theta, kp_2d, kp_w, cam_t, focal = out.post if out.post is not None else L.regressor_post(
+                state, out.pose_aa, joints, Tz, bbox_height, center, orig_shape, 1000.0, float(cfg.IMG_RES.WIDTH), float(cfg.IMG_RES.HEIGHT))
             d.update(theta=theta, kp_2d=kp_2d, kp_2d_w=kp_w, pred_cam_t=cam_t, scale=scale, focal_length=focal)
         else:
             d['theta'] = torch.cat([cam, shape, out.pose_aa], dim=1)
@@ -160,7 +160,7 @@ class Regressor(nn.Module):
         return d
 
     def forward(self, x, bbox_info, Tz, orig_shape, center, scale, bbox_height, init_pose=None, init_shape=None,
-                init_cam=None, is_train=False, n_iter=1, J_regressor=None, with_aux=True, xc=None):
+                init_cam=None, is_train=False, n_iter=1, J_regressor=None, with_aux=True, xc=None, xc_next=None, state_ready=False):
         """x [B, feat] (or pre-filled xc buffer [B, feat+5+229] whose first ``feat`` columns hold x) -> (dict, body_feat)."""
         if is_train:       # whmr.py:102-209 in training: autograd nodes with HIP forward + backward (whmr_amd.train.whmr_train)
             from ..train.whmr_train import regressor_train
@@ -173,10 +173,12 @@ class Regressor(nn.Module):
                                    cam, self.__dict__.setdefault('_train_cache', {}))
         with torch.no_grad():
             return self._forward_eval(x, bbox_info, Tz, orig_shape, center, scale, bbox_height, init_pose, init_shape, init_cam, n_iter,
-                                      J_regressor, with_aux, xc)
+                                      J_regressor, with_aux, xc, xc_next, state_ready)
 
     def _forward_eval(self, x, bbox_info, Tz, orig_shape, center, scale, bbox_height, init_pose, init_shape, init_cam, n_iter, J_regressor,
-                      with_aux, xc):
+                      with_aux, xc, xc_next=None, state_ready=False):
+        """``xc_next`` = (buffer, F) of the NEXT stage: its state columns [bbox_info | rotmat | shape | cam] are written by this stage's tail launch;
+        ``state_ready``: this stage's own state columns were written that way by the previous stage (no regressor_state launch)."""
         B = bbox_info.shape[0]
         dev = bbox_info.device
         F = self.fc1.in_features - 229 - 5
@@ -188,15 +190,22 @@ class Regressor(nn.Module):
         cam = self.init_cam.expand(B, -1) if init_cam is None else init_cam
         if pose.stride(-1) != 1 or pose.dtype != torch.float32:
             pose = pose.float().contiguous()
-        L.regressor_state(xc, F, bbox_info.float().contiguous(), pose, shape.float(), cam.float())     # whmr.py:105,119, one launch
+        if not state_ready:
+            L.regressor_state(xc, F, bbox_info.float().contiguous(), pose, shape.float(), cam.float())     # whmr.py:105,119, one launch
         new = torch.empty(B, 229, dtype=torch.float32, device=dev)
         w_eff, b_eff = self._collapsed()
         for _ in range(n_iter):
             L.gemm(xc, w_eff, new, bias=b_eff, residual=xc[:, F + 5:])                # whmr.py:118-126 as one affine map (+ residual state)
             if n_iter > 1:
                 xc[:, F + 5:] = new
+        post = nxt = None
+        if Tz is not None:
+            post = dict(state=new, Tz=Tz, bbox_h=bbox_height, center=center, orig_shape=orig_shape, focal0=1000.0,
+                        res_w=float(cfg.IMG_RES.WIDTH), res_h=float(cfg.IMG_RES.HEIGHT))
+            if xc_next is not None:
+                nxt = dict(bbox_info=bbox_info, xc=xc_next[0], F=xc_next[1])
         out = self.smpl.run(new[:, 216:226], new[:, :216], gram_schmidt=True, want_aa=True, want_smpl_joints=True,
-                            want_markers=True)                                        # whmr.py:128-137,174,184-187
+                            want_markers=True, post=post, nxt=nxt)                    # whmr.py:128-137,174,184-187
         d = self._outputs(out, new, scale, J_regressor, with_aux, Tz, orig_shape, center, bbox_height)
         return d, xc[:, :F + 5]
 
@@ -495,19 +504,22 @@ class WHMR(nn.Module):
         body_feat = None
         center, scale, bbox_height = center.float().contiguous(), scale.float(), bbox_height.float().contiguous()
         orig_shape, bbox_info = orig_shape.float().contiguous(), bbox_info.float().contiguous()
+        # one input buffer per stage, allocated up front: stage i's tail launch writes stage i+1's state columns (whmr.py:105,119)
+        Fs = [self.regressor[i].fc1.in_features - 234 for i in range(3)]
+        xcs = [torch.empty(B, Fs[i] + 234, dtype=torch.float32, device=dev) for i in range(3)]
         for i in range(3):                                                            # whmr.py:580-627
             reg, ext = self.regressor[i], self.maf_extractor[i]
             cam, shp, pose = smpl_output['pred_cam'], smpl_output['pred_shape'], smpl_output['rotmat']
             ext.cam = cam
-            F = reg.fc1.in_features - 234
-            xc = torch.empty(B, F + 234, dtype=torch.float32, device=dev)
+            xc = xcs[i]
             if i == 0:
                 pts = self.points_grid.expand(B, -1, -1).transpose(1, 2).contiguous()
                 ext.sampling(pts, out=xc, want_point_feat=False)
             else:
-                ext(smpl_output['markers'].contiguous(), cam=cam.contiguous(), out=xc, want_point_feat=False)
+                ext(smpl_output['markers'], cam=cam, out=xc, want_point_feat=False)   # cam: a strided column slice of the state (no copy)
             smpl_output, body_feat = reg(None, bbox_info, Tz, orig_shape, center, scale, bbox_height, pose, shp, cam,
-                                         is_train=False, n_iter=1, J_regressor=J_regressor, with_aux=with_aux, xc=xc)
+                                         is_train=False, n_iter=1, J_regressor=J_regressor, with_aux=with_aux, xc=xc,
+                                         xc_next=(xcs[i + 1], Fs[i + 1]) if i < 2 else None, state_ready=i > 0)
             outs.append(smpl_output)
 
         g_rot = self.global_orient(body_feat, cam_rotmat, smpl_output['rotmat'][:, 0], False, xc=xc)     # whmr.py:630-654
