@@ -506,6 +506,18 @@ def main(argv=None):
                                'flops_per_launch': flops_per_launch, 'avg_launch_us': avg_s * 1e6,
                                'traffic': traffic['bytes_per_launch'] if traffic else None,
                                'traffic_note': traffic['note'] if traffic else 'no PMC pass of the current GEMM sources committed'}
+            if args.workload == 'whmr':
+                # the HBM-bound rows of the north star: MAF sampler and SMPL (LBS) call, events around each call of the instrumented step
+                hbm = {}
+                for kname in ('maf_sample', 'smpl_call'):
+                    ev = [(w, e0.elapsed_time(e1) * 1e-3) for (nm, w, e0, e1) in prof if nm == kname]
+                    if ev:
+                        byt, sec = sum(w for w, _ in ev) / len(ev), sum(t for _, t in ev) / len(ev)
+                        hbm[kname] = {'calls_per_step': len(ev), 'avg_us': sec * 1e6, 'algorithmic_bytes': byt, 'achieved_GBps': byt / sec / 1e9,
+                                      'frac_of_8TBps': byt / sec / 8e12}
+                res['hbm_rows'] = hbm
+                res['hbm_rows_note'] = 'maf_sample = one fused launch (projection + bilinear gather + point MLP); smpl_call = pose chain + pose-corrective ' \
+                                       'GEMM + skinning + joint regression + stage tail (5 launches); both are latency-bound at these sizes (SURVEY 8d)'
             if args.workload == 'whmr' and n_ranks == 1:
                 res['parity'], res['fp32_ms_per_step'] = whmr_parity_and_fp32(args, dev)
                 res['parity_note'] = 'max-rel error of the last regressor stage (theta [B,85], vertices [B,6890,3], kp_2d [B,49,2]) vs the CPU oracle on the ' \

@@ -48,8 +48,15 @@ class MAF_Extractor(nn.Module):
         if out is None:
             out = torch.empty(B, 32 * P, dtype=torch.float32, device=im_feat.device)
         pf = torch.empty(B, 256, P, dtype=torch.float32, device=im_feat.device) if want_point_feat else None
+        prof = L.PROFILE is not None and (pts2d is not None or pts3d is not None)
+        if prof:                                   # bench.py's instrumented step: algorithmic bytes = P x 4 texels x 256 channels gathered + P x 32 fp32 written
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         L.maf_sample(im_feat, self._weights(), out, pts2d=pts2d, pts3d=pts3d, cam=cam, point_feat=pf, focal=FOCAL_LENGTH,
                      res_w=float(cfg.IMG_RES.WIDTH), res_h=float(cfg.IMG_RES.HEIGHT))
+        if prof:
+            e1.record()
+            L.PROFILE.append(('maf_sample', B * P * (4 * 256 * im_feat.element_size() + 32 * 4.0), e0, e1))
         return out, pf
 
     @torch.no_grad()

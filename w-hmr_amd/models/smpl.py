@@ -99,6 +99,19 @@ class SMPL(nn.Module):
         the next stage's input state leave in ONE launch; the projections come back as ``ModelOutput.post``."""
         if not betas.is_cuda:
             raise RuntimeError('whmr_amd.SMPL runs on a HIP device only (no CPU fallback)')
+        if L.PROFILE is not None and not getattr(self, '_in_profile', False):
+            # bench.py's instrumented step: HIP events around the whole call; algorithmic bytes per SURVEY 8(d): 84 172 B per image of I/O
+            # (betas, rotmats, vertices, joints) + 19.6 MB of model constants per call
+            self._in_profile = True
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            try:
+                out = self.run(betas, rotmats, gram_schmidt, want_aa, want_smpl_joints, want_markers, post, nxt)
+            finally:
+                self._in_profile = False
+            e1.record()
+            L.PROFILE.append(('smpl_call', betas.shape[0] * 84172.0 + 19.6e6, e0, e1))
+            return out
         B, dev = betas.shape[0], betas.device
         f32 = dict(dtype=torch.float32, device=dev)
         m = self._model()
