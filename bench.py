@@ -45,6 +45,7 @@ def parse(argv=None):
     ap.add_argument('--workload', default='vit224')
     ap.add_argument('--numerics', default='bf16')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
+    ap.add_argument('--no-parity', action='store_true', help='whmr: skip the parity / fp32-mode leg (rocprofv3 runs: keeps the kernel table to the timed path)')
     ap.add_argument('--graph', action='store_true', help='whmr_train on one GPU: replay the whole step from one HIP graph')
     ap.add_argument('--eager', action='store_true', help='whmr: time the eager module call instead of the HIP-graph replay (default: graph)')
     ap.add_argument('--full-x', default='hoisted', choices=('hoisted', 'per-crop', 'none'),
@@ -518,7 +519,7 @@ def main(argv=None):
                 res['hbm_rows'] = hbm
                 res['hbm_rows_note'] = 'maf_sample = one fused launch (projection + bilinear gather + point MLP); smpl_call = pose chain + pose-corrective ' \
                                        'GEMM + skinning + joint regression + stage tail (5 launches); both are latency-bound at these sizes (SURVEY 8d)'
-            if args.workload == 'whmr' and n_ranks == 1:
+            if args.workload == 'whmr' and n_ranks == 1 and not args.no_parity:
                 res['parity'], res['fp32_ms_per_step'] = whmr_parity_and_fp32(args, dev)
                 res['parity_note'] = 'max-rel error of the last regressor stage (theta [B,85], vertices [B,6890,3], kp_2d [B,49,2]) vs the CPU oracle on the ' \
                                      'first 2 crops of the batch; fp32_ms_per_step = the same step in the fp32 parity numerics (eager)'

@@ -334,6 +334,10 @@ def _train_model(assets, state_dict, numerics, dev):
     return m
 
 
+# constants added in front of the Tz head's batch-statistics BatchNorm1d: true gradient zero, both sides hold rounding noise (see the fp32 test)
+ZERO_GRAD_KEYS = ('est_Tz.0.bias', 'est_Tz.1.bias', 'transformer_decoder.mlp.fc2.bias')
+
+
 def _grad_keys(sd):
     skip = ('running', 'cam_model', 'smpl', 'Dmap', 'points_grid', 'init_', 'num_batches', 'global_orient')
     return [k for k, v in sd.items() if v.is_floating_point() and not any(s in k for s in skip)]
@@ -378,7 +382,12 @@ def test_whmr_train_step_fp32_matches_oracle_autograd(dev, assets, state_dict, s
         g = named[k].grad
         assert g is not None and g.shape == p[k].grad.shape, k
         ref = p[k].grad
-        if ref.abs().max() < 1e-8:           # a bias in front of a batch-statistics BatchNorm: the true gradient is zero
+        # A constant added in front of a batch-statistics BatchNorm has a true gradient of exactly zero: the deconv BatchNorm biases' convolutions
+        # have none, but the Tz head ends in Linear -> Linear -> BatchNorm1d(1) (whmr.py:424-427), so est_Tz.{0,1}.bias and the bias of the last
+        # Linear before the token mean (transformer_decoder.mlp.fc2.bias) only shift the BatchNorm input.  Both sides then hold fp32 rounding noise
+        # (~1e-7, and the CPU side's noise depends on torch's thread partitioning): gate those on an absolute bound, not on a ratio of two noises.
+        if ref.abs().max() < 1e-8 or k in ZERO_GRAD_KEYS:
+            assert ref.abs().max().item() < 1e-5, (k, 'the oracle says this gradient is not zero')
             if g.abs().max().item() > 1e-5:
                 bad[k] = ('zero-grad', g.abs().max().item())
             continue
@@ -478,7 +487,7 @@ def test_whmr_train_step_bf16_error_report(dev, assets, state_dict):
     named = dict(m.named_parameters())
     rep = {}
     for k in keys:
-        if p[k].grad.abs().max() < 1e-8:
+        if p[k].grad.abs().max() < 1e-8 or k in ZERO_GRAD_KEYS:
             continue
         rep[k] = _rms(named[k].grad.cpu(), p[k].grad)
     bad = {k: v for k, v in rep.items() if not v < 0.35}

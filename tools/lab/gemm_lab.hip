@@ -48,6 +48,7 @@ struct GemmP {
     int M, N, K;
     int tiles_m, tiles_n;
     unsigned long long* ts;      // timestamps [block][wave][slot]
+    int stagger;                 // VAR 7: start delay of the second workgroup of a CU (shader cycles)
     int abl;                     // ablation bits: 1 = no DMA in loop, 2 = no ds_read in loop, 4 = no MFMA, 8 = no epilogue stores
 };
 
@@ -425,6 +426,343 @@ __global__ __launch_bounds__(512, 2) void gemm_blk_kernel(const GemmP p) {
     if constexpr (VAR == 2) { if (wm == 0) __builtin_amdgcn_s_barrier(); }      // G0's count catches up with G1's extra barrier
 }
 
+// ------------------------------------------------------------------------------------------------ VAR 6
+// 4-wave workgroups (1 x 4 waves, wave tile (32 MB) x 64), ring of 3 half-K-tile slots, TWO workgroups per CU: the second workgroup plays the
+// part of the second wave group of VAR 3/5 without sharing anything with the first one -- its main loop runs under the other one's epilogue /
+// prologue, and the tile grid is twice as fine (dynamic balance by the dispatcher).  Price: W is staged once per workgroup.
+template <int MB, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_q4_kernel(const GemmP p) {
+    constexpr int BM = MB * 32, BN = 256, MI = MB, NJ = 2;
+    constexpr int SLOT = (MB + 8) * 2048, HU = (MB + 8) * 2;     // 1-KiB DMA units per half tile
+    constexpr int HUPW = (HU + 3) / 4;
+    constexpr int REM = HU % 4;                                  // waves < REM issue HUPW units, the others HUPW - 1 (REM == 0: all HUPW)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int lid = xcd_remap(blockIdx.x, ntiles);
+    const int tm = lid / p.tiles_n, tn = lid % p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int KC = p.K >> 3;
+    const int H = p.K >> 5;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)smem;
+    const bool dma_full = (REM == 0) || (wave < REM);
+    const char* hsrc[HUPW];
+#pragma unroll
+    for (int i = 0; i < HUPW; ++i) {
+        int u = wave + 4 * i;
+        if (u >= HU) u = HU - 1;
+        const int b = u >> 1, half = u & 1;
+        if (b < MB) {
+            int rb = (m0 >> 5) + b;
+            const int rbmax = ((p.M + 31) >> 5) - 1;
+            if (rb > rbmax) rb = rbmax;
+            hsrc[i] = (const char*)p.A + ((size_t)rb * KC) * 512 + half * 1024 + lane * 16;
+        } else {
+            hsrc[i] = (const char*)p.W + ((size_t)((n0 >> 5) + b - MB) * KC) * 512 + half * 1024 + lane * 16;
+        }
+    }
+    auto hstage = [&](int h) {
+        const int slot = h % 3;
+#pragma unroll
+        for (int i = 0; i < HUPW; ++i)
+            if (i < HUPW - 1 || dma_full)
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)(hsrc[i] + (size_t)h * 2048), (lds_void_t*)(smem + slot * SLOT + (wave + 4 * i) * 1024), 16, 0, 0);
+    };
+    auto wait_dma = [&](int young) {                 // own DMA groups still allowed in flight
+        if (young >= 1) { if (dma_full) wait_vmcnt<HUPW>(); else wait_vmcnt<HUPW - 1>(); }
+        else wait_vmcnt<0>();
+    };
+    f32x16_t acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const uint32_t a_b = lds0 + hi * 512 + l31 * 16;
+    const uint32_t b_b = lds0 + (MB + wn * 2) * 2048 + hi * 512 + l31 * 16;
+    bf16x8_t fa[MI][2], fb[NJ][2];
+    hstage(0);
+    if (H > 1) hstage(1);
+    wait_dma(H > 1 ? 1 : 0);
+    __builtin_amdgcn_s_barrier();
+    int slot = 0;
+    for (int k = 0; k < H; ++k) {
+        // MEM(k)
+        const uint32_t sa = a_b + slot * SLOT, sb = b_b + slot * SLOT;
+        fb[0][0] = lds_read128<0>(sb); fb[1][0] = lds_read128<2048>(sb);
+        fa[0][0] = lds_read128<0>(sa);
+        if constexpr (MI > 1) fa[1][0] = lds_read128<2048>(sa);
+        if constexpr (MI > 2) fa[2][0] = lds_read128<4096>(sa);
+        if constexpr (MI > 3) fa[3][0] = lds_read128<6144>(sa);
+        fb[0][1] = lds_read128<1024>(sb); fb[1][1] = lds_read128<2048 + 1024>(sb);
+        fa[0][1] = lds_read128<1024>(sa);
+        if constexpr (MI > 1) fa[1][1] = lds_read128<2048 + 1024>(sa);
+        if constexpr (MI > 2) fa[2][1] = lds_read128<4096 + 1024>(sa);
+        if constexpr (MI > 3) fa[3][1] = lds_read128<6144 + 1024>(sa);
+        if (k + 2 < H) hstage(k + 2);                       // into the slot read in MEM(k-1), i.e. before the previous barrier
+        wait_dma(H - 2 - k);                                // own share of half tile k + 1 landed (k + 2 may fly)
+        wait_lgkmcnt<0>();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j][kk], fa[i][kk], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        slot = slot == 2 ? 0 : slot + 1;
+    }
+    if (p.abl & 8) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+        if (t == 12345.678f) ((float*)p.C)[0] = t;
+        return;
+    }
+    const int nb0 = n0 + wn * 64;
+    if constexpr (EPI == 0 || EPI == 1) {
+        const int NC8 = p.N >> 3;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            float4 bq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bq[q] = p.bias ? *(const float4*)(p.bias + nb0 + j * 32 + 8 * q + 4 * hi) : make_float4(0, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int m = m0 + i * 32;
+                if (m >= p.M) continue;
+                uint32_t pk[4][2];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v0 = acc[i][j][4 * q] + bq[q].x, v1 = acc[i][j][4 * q + 1] + bq[q].y, v2 = acc[i][j][4 * q + 2] + bq[q].z, v3 = acc[i][j][4 * q + 3] + bq[q].w;
+                    if constexpr (EPI == 1) {
+                        auto g = [](float x) { const float s = __builtin_amdgcn_fmed3f(x, -4.0f, 4.0f), t = s * s;
+                            float r = fmaf(t, 2.258814658e-08f, -1.588823733e-06f); r = fmaf(r, t, 4.776381398e-05f); r = fmaf(r, t, -8.121867222e-04f);
+                            r = fmaf(r, t, 8.763687250e-03f); r = fmaf(r, t, -6.455440501e-02f); r = fmaf(r, t, 3.978702657e-01f); return x * fmaf(s, r, 0.5f); };
+                        v0 = g(v0); v1 = g(v1); v2 = g(v2); v3 = g(v3);
+                    }
+                    pk[q][0] = pack_bf16x2(v0, v1); pk[q][1] = pack_bf16x2(v2, v3);
+                }
+                char* rowp = (char*)p.C + ((size_t)(m >> 5) * NC8 + ((nb0 + j * 32) >> 3)) * 512 + l31 * 16;
+#pragma unroll
+                for (int q = 0; q < 4; q += 2) {
+                    auto r0 = __builtin_amdgcn_permlane32_swap(pk[q][0], pk[q + 1][0], false, false);
+                    auto r1 = __builtin_amdgcn_permlane32_swap(pk[q][1], pk[q + 1][1], false, false);
+                    *(uint4*)(rowp + (q + hi) * 512) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+                }
+            }
+        }
+    } else {
+        const int NC4 = p.N >> 2;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            float4 bq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bq[q] = p.bias ? *(const float4*)(p.bias + nb0 + j * 32 + 8 * q + 4 * hi) : make_float4(0, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int m = m0 + i * 32;
+                if (m >= p.M) continue;
+                const size_t off = ((size_t)(m >> 5) * NC4 + ((nb0 + j * 32) >> 2) + hi) * 512 + l31 * 16;
+                float4 rv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rv[q] = *(const float4*)((const char*)p.res + off + q * 1024);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float4 o;
+                    o.x = acc[i][j][4 * q] + bq[q].x + rv[q].x; o.y = acc[i][j][4 * q + 1] + bq[q].y + rv[q].y;
+                    o.z = acc[i][j][4 * q + 2] + bq[q].z + rv[q].z; o.w = acc[i][j][4 * q + 3] + bq[q].w + rv[q].w;
+                    *(float4*)((char*)p.C + off + q * 1024) = o;
+                }
+            }
+        }
+    }
+}
+
+template <int MB, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_q4p_kernel(const GemmP p) {
+    constexpr int BM = MB * 32, BN = 256, MI = MB, NJ = 2;
+    constexpr int SLOT = (MB + 8) * 2048, HU = (MB + 8) * 2;     // 1-KiB DMA units per half tile
+    constexpr int HUPW = (HU + 3) / 4;
+    constexpr int REM = HU % 4;                                  // waves < REM issue HUPW units, the others HUPW - 1 (REM == 0: all HUPW)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int KC = p.K >> 3;
+    const int H = p.K >> 5;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)smem;
+    const bool dma_full = (REM == 0) || (wave < REM);
+    const char* hsrc[HUPW];
+    // stagger (abl bits 32 / 64): the second workgroup of a CU starts half a tile late so that its epilogues fall into the other one's main loops
+    if (((p.abl & 32) && blockIdx.x >= gridDim.x / 2) || ((p.abl & 64) && (blockIdx.x & 8))) {
+        const uint64_t t0 = memtime();
+        while (memtime() - t0 < (uint64_t)p.stagger) __builtin_amdgcn_s_sleep(8);
+    }
+    auto set_tile = [&](int t, int& m0, int& n0) {
+        // tile order: consecutive ids of one XCD share the A rows (tn fastest)
+        const int lid = xcd_remap(t % ntiles, ntiles);
+        m0 = (lid / p.tiles_n) * BM; n0 = (lid % p.tiles_n) * BN;
+    };
+    int m0, n0;
+    bool first = true;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    set_tile(tile, m0, n0);
+#pragma unroll
+    for (int i = 0; i < HUPW; ++i) {
+        int u = wave + 4 * i;
+        if (u >= HU) u = HU - 1;
+        const int b = u >> 1, half = u & 1;
+        if (b < MB) {
+            int rb = (m0 >> 5) + b;
+            const int rbmax = ((p.M + 31) >> 5) - 1;
+            if (rb > rbmax) rb = rbmax;
+            hsrc[i] = (const char*)p.A + ((size_t)rb * KC) * 512 + half * 1024 + lane * 16;
+        } else {
+            hsrc[i] = (const char*)p.W + ((size_t)((n0 >> 5) + b - MB) * KC) * 512 + half * 1024 + lane * 16;
+        }
+    }
+    auto hstage = [&](int h) {
+        const int slot = h % 3;
+#pragma unroll
+        for (int i = 0; i < HUPW; ++i)
+            if (i < HUPW - 1 || dma_full)
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)(hsrc[i] + (size_t)h * 2048), (lds_void_t*)(smem + slot * SLOT + (wave + 4 * i) * 1024), 16, 0, 0);
+    };
+    auto wait_dma = [&](int young) {                 // own DMA groups still allowed in flight
+        if (young >= 1) { if (dma_full) wait_vmcnt<HUPW>(); else wait_vmcnt<HUPW - 1>(); }
+        else wait_vmcnt<0>();
+    };
+    f32x16_t acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const uint32_t a_b = lds0 + hi * 512 + l31 * 16;
+    const uint32_t b_b = lds0 + (MB + wn * 2) * 2048 + hi * 512 + l31 * 16;
+    bf16x8_t fa[MI][2], fb[NJ][2];
+    hstage(0);
+    if (H > 1) hstage(1);
+    if (first) wait_dma(H > 1 ? 1 : 0); else wait_vmcnt<0>();
+    first = false;
+    __builtin_amdgcn_s_barrier();
+    int slot = 0;
+    for (int k = 0; k < H; ++k) {
+        // MEM(k)
+        const uint32_t sa = a_b + slot * SLOT, sb = b_b + slot * SLOT;
+        fb[0][0] = lds_read128<0>(sb); fb[1][0] = lds_read128<2048>(sb);
+        fa[0][0] = lds_read128<0>(sa);
+        if constexpr (MI > 1) fa[1][0] = lds_read128<2048>(sa);
+        if constexpr (MI > 2) fa[2][0] = lds_read128<4096>(sa);
+        if constexpr (MI > 3) fa[3][0] = lds_read128<6144>(sa);
+        fb[0][1] = lds_read128<1024>(sb); fb[1][1] = lds_read128<2048 + 1024>(sb);
+        fa[0][1] = lds_read128<1024>(sa);
+        if constexpr (MI > 1) fa[1][1] = lds_read128<2048 + 1024>(sa);
+        if constexpr (MI > 2) fa[2][1] = lds_read128<4096 + 1024>(sa);
+        if constexpr (MI > 3) fa[3][1] = lds_read128<6144 + 1024>(sa);
+        if (k + 2 < H) hstage(k + 2);                       // into the slot read in MEM(k-1), i.e. before the previous barrier
+        wait_dma(H - 2 - k);                                // own share of half tile k + 1 landed (k + 2 may fly)
+        wait_lgkmcnt<0>();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j][kk], fa[i][kk], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        slot = slot == 2 ? 0 : slot + 1;
+    }
+    if (p.abl & 8) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+        if (t == 12345.678f) ((float*)p.C)[0] = t;
+        continue;
+    }
+    const int nb0 = n0 + wn * 64;
+    if constexpr (EPI == 0 || EPI == 1) {
+        const int NC8 = p.N >> 3;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            float4 bq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bq[q] = p.bias ? *(const float4*)(p.bias + nb0 + j * 32 + 8 * q + 4 * hi) : make_float4(0, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int m = m0 + i * 32;
+                if (m >= p.M) continue;
+                uint32_t pk[4][2];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v0 = acc[i][j][4 * q] + bq[q].x, v1 = acc[i][j][4 * q + 1] + bq[q].y, v2 = acc[i][j][4 * q + 2] + bq[q].z, v3 = acc[i][j][4 * q + 3] + bq[q].w;
+                    if constexpr (EPI == 1) {
+                        auto g = [](float x) { const float s = __builtin_amdgcn_fmed3f(x, -4.0f, 4.0f), t = s * s;
+                            float r = fmaf(t, 2.258814658e-08f, -1.588823733e-06f); r = fmaf(r, t, 4.776381398e-05f); r = fmaf(r, t, -8.121867222e-04f);
+                            r = fmaf(r, t, 8.763687250e-03f); r = fmaf(r, t, -6.455440501e-02f); r = fmaf(r, t, 3.978702657e-01f); return x * fmaf(s, r, 0.5f); };
+                        v0 = g(v0); v1 = g(v1); v2 = g(v2); v3 = g(v3);
+                    }
+                    pk[q][0] = pack_bf16x2(v0, v1); pk[q][1] = pack_bf16x2(v2, v3);
+                }
+                char* rowp = (char*)p.C + ((size_t)(m >> 5) * NC8 + ((nb0 + j * 32) >> 3)) * 512 + l31 * 16;
+#pragma unroll
+                for (int q = 0; q < 4; q += 2) {
+                    auto r0 = __builtin_amdgcn_permlane32_swap(pk[q][0], pk[q + 1][0], false, false);
+                    auto r1 = __builtin_amdgcn_permlane32_swap(pk[q][1], pk[q + 1][1], false, false);
+                    *(uint4*)(rowp + (q + hi) * 512) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+                }
+            }
+        }
+    } else {
+        const int NC4 = p.N >> 2;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            float4 bq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bq[q] = p.bias ? *(const float4*)(p.bias + nb0 + j * 32 + 8 * q + 4 * hi) : make_float4(0, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int m = m0 + i * 32;
+                if (m >= p.M) continue;
+                const size_t off = ((size_t)(m >> 5) * NC4 + ((nb0 + j * 32) >> 2) + hi) * 512 + l31 * 16;
+                float4 rv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rv[q] = *(const float4*)((const char*)p.res + off + q * 1024);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float4 o;
+                    o.x = acc[i][j][4 * q] + bq[q].x + rv[q].x; o.y = acc[i][j][4 * q + 1] + bq[q].y + rv[q].y;
+                    o.z = acc[i][j][4 * q + 2] + bq[q].z + rv[q].z; o.w = acc[i][j][4 * q + 3] + bq[q].w + rv[q].w;
+                    *(float4*)((char*)p.C + off + q * 1024) = o;
+                }
+            }
+        }
+    }
+    }   // tile loop
+}
+
 // ------------------------------------------------------------------------------------------------ host
 static inline bf16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fff + ((u >> 16) & 1); return (bf16_t)(u >> 16); }
 static inline float bf2f(bf16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; }
@@ -451,7 +789,54 @@ static void launch_epi(const GemmP& p, int epi, hipStream_t st) {
     else launch<BM, VAR, 2, TS>(p, st);
 }
 
+template <int MB, int EPI>
+static void launch_q4(const GemmP& p, hipStream_t st) {
+    constexpr int LDS = 3 * (MB + 8) * 2048;
+    auto kern = gemm_q4_kernel<MB, EPI>;
+    static bool done = false;
+    if (!done) { CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); done = true; }
+    GemmP q = p;
+    q.tiles_m = (p.M + MB * 32 - 1) / (MB * 32); q.tiles_n = p.N / 256;
+    hipLaunchKernelGGL(kern, dim3(q.tiles_m * q.tiles_n), dim3(256), LDS, st, q);
+}
+template <int MB>
+static void launch_q4_epi(const GemmP& p, int epi, hipStream_t st) {
+    if (epi == 0) launch_q4<MB, 0>(p, st);
+    else if (epi == 1) launch_q4<MB, 1>(p, st);
+    else launch_q4<MB, 2>(p, st);
+}
+
+template <int MB, int EPI>
+static void launch_q4p(const GemmP& p, hipStream_t st) {
+    constexpr int LDS = 3 * (MB + 8) * 2048;
+    auto kern = gemm_q4p_kernel<MB, EPI>;
+    static bool done = false;
+    if (!done) { CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); done = true; }
+    GemmP q = p;
+    q.tiles_m = (p.M + MB * 32 - 1) / (MB * 32); q.tiles_n = p.N / 256;
+    const int nt = q.tiles_m * q.tiles_n;
+    hipLaunchKernelGGL(kern, dim3(nt < 512 ? nt : 512), dim3(256), LDS, st, q);
+}
+template <int MB>
+static void launch_q4p_epi(const GemmP& p, int epi, hipStream_t st) {
+    if (epi == 0) launch_q4p<MB, 0>(p, st);
+    else if (epi == 1) launch_q4p<MB, 1>(p, st);
+    else launch_q4p<MB, 2>(p, st);
+}
+
 static void launch_any(const GemmP& p, int bm, int var, int epi, hipStream_t st) {
+    if (var == 7) {
+        if (bm == 128) launch_q4p_epi<4>(p, epi, st);
+        else if (bm == 96) launch_q4p_epi<3>(p, epi, st);
+        else if (bm == 64) launch_q4p_epi<2>(p, epi, st);
+        return;
+    }
+    if (var == 6) {
+        if (bm == 128) launch_q4_epi<4>(p, epi, st);
+        else if (bm == 96) launch_q4_epi<3>(p, epi, st);
+        else if (bm == 64) launch_q4_epi<2>(p, epi, st);
+        return;
+    }
     if (var == 0) {
         if (bm == 256) launch_epi<256, 0, 0>(p, epi, st);
         else if (bm == 192) launch_epi<192, 0, 0>(p, epi, st);
@@ -515,7 +900,7 @@ int main(int argc, char** argv) {
         return 0;
     }
     struct Cfg { int var, bm; };
-    const Cfg cfgs[] = {{2, 256}, {3, 256}, {4, 256}, {5, 256}};
+    const Cfg cfgs[] = {{5, 256}, {6, 128}, {7, 128}, {7, 96}};
     // ---- correctness: sampled outputs vs a host fp64 dot product on the blocked data
     for (const Shape& s : shapes) {
         for (const Cfg& c : cfgs) {
@@ -558,6 +943,23 @@ int main(int argc, char** argv) {
         }
     }
 
+
+    // ---- VAR 7 stagger sweep
+    for (const Shape& s : shapes) {
+        const double gf = 2.0 * M * s.N * s.K / 1e6;
+        for (int bm : {128, 96}) {
+            GemmP p{}; p.A = dA; p.W = dW; p.C = dC; p.bias = dB; p.res = (const float*)dC; p.M = M; p.N = s.N; p.K = s.K; p.ts = dTs;
+            printf("%-4s var 7 BM %3d stagger:", s.name, bm);
+            for (int mode : {0, 32, 64}) for (int sg : {4000, 8000, 16000}) {
+                if (mode == 0 && sg != 4000) continue;
+                p.abl = mode; p.stagger = sg;
+                float t = 1e9f;
+                for (int rnd = 0; rnd < 3; ++rnd) t = std::min(t, timeit([&] { launch_any(p, bm, 7, s.epi, st); }, 10, 2));
+                printf("  [%s %5d] %5.1f us (%4.0f TF)", mode == 0 ? "none" : mode == 32 ? "half" : "xcd8", sg, t, gf / t);
+            }
+            printf("\n");
+        }
+    }
     // ---- timestamps of one launch (qkv, 256)
     if (argc > 1 && !strcmp(argv[1], "ts")) {
         GemmP p{}; p.A = dA; p.W = dW; p.C = dC; p.bias = dB; p.M = M; p.N = 2304; p.K = 768; p.ts = dTs;
