@@ -143,6 +143,7 @@ def _vit(sd, size, dev, blocked, dim=768, depth=12, heads=12):
     m.load_state_dict(sd, strict=True)
     m = m.to(dev).eval()
     m.blocked = blocked
+    m.blocked_min_tokens = 0              # these tests exercise the blocked path at small batch (the product switches to it from ~2k tokens)
     return m
 
 

@@ -1,4 +1,5 @@
-"""Attention core timing at the two ViT-B shapes (batch 64, 12 heads): chunked kernel vs the single-pass variant."""
+"""Attention core timing at the two ViT-B shapes (batch 64, 12 heads): row-major chunked / single-pass kernels, the blocked-layout kernel and
+its staging-only / key-loop-only ablations (wrong results, timing only)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -18,5 +19,10 @@ for N in (196, 192):
     att = torch.empty(B, N, 768, device=dev, dtype=torch.bfloat16)
     for var in (1, 0):
         L.attention_set_variant(var)
-        print('N=%d %s: %.1f us' % (N, 'chunked' if var else 'single-pass', timeit(lambda: L.attention(qkv, att, B, N, 12, 64, 0.125))))
+        print('N=%d row-major %s: %.1f us' % (N, 'chunked' if var else 'single-pass', timeit(lambda: L.attention(qkv, att, B, N, 12, 64, 0.125))))
+    qb = L.to_blocked(qkv.view(B * N, 2304))
+    ob = torch.empty((B * N + 31) // 32, 96, 32, 8, device=dev, dtype=torch.bfloat16)
+    for var, name in ((1, 'full'), (1 | 4, 'staging only (no key loop)'), (1 | 2, 'key loop only (no staging)'), (1 | 2 | 4, 'neither (launch + Q load + store)')):
+        L.attention_set_variant(var)
+        print('N=%d blocked %s: %.1f us' % (N, name, timeit(lambda: L.attention_blk(qb, ob, B, N, 12, 0.125))))
 L.attention_set_variant(1)

@@ -43,6 +43,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+__device__ __forceinline__ void store16_policy(void* ptr, u32x4_t v, int pol) {
+    if (pol == 1) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(ptr), "v"(v) : "memory");
+    else if (pol == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory");
+    else if (pol == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(ptr), "v"(v) : "memory");
+    else if (pol == 4) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(ptr), "v"(v) : "memory");
+    else *(u32x4_t*)ptr = v;
+}
+
 struct GemmP {
     const bf16_t* A; const bf16_t* W; void* C; const float* bias; const float* res;
     int M, N, K;
@@ -275,7 +285,7 @@ __global__ __launch_bounds__(512, 2) void gemm_blk_kernel(const GemmP p) {
         auto hstage1 = [&](int h, int i) {
             __builtin_amdgcn_global_load_lds((gbl_void_t*)(hsrc[i] + (size_t)h * 2048), (lds_void_t*)(smem + (h & 3) * SLOT + (wave + 8 * i) * 1024), 16, 0, 0);
         };
-        constexpr int LATE = (VAR == 4) ? 1 : 0;        // DMA units issued inside the MFMA block
+        constexpr int LATE = (VAR == 4) ? 1 : (VAR == 8) ? HUPW : 0;        // DMA units issued inside the MFMA block (VAR 8: all of them, spread)
         const uint32_t a_b2 = lds0 + (wm * MI) * 2048 + hi * 512 + l31 * 16;
         const uint32_t b_b2 = lds0 + (MB + wn * 2) * 2048 + hi * 512 + l31 * 16;
         bf16x8_t fa[MI][2], fb[NJ][2];
@@ -314,6 +324,22 @@ __global__ __launch_bounds__(512, 2) void gemm_blk_kernel(const GemmP p) {
         };
         auto MFMA = [&](int x) {          // x = half tile whose MEM ran last (its late DMA units are issued here)
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (VAR == 8) {
+                // all HUPW DMA units of half tile x + 3 ride inside the MFMA stream: one after every (2 MI NJ / HUPW) MFMAs
+                constexpr int NM = 2 * MI * NJ, STEP = NM / HUPW;
+#pragma unroll
+                for (int n = 0; n < NM; ++n) {
+                    const int kk = n / (MI * NJ), i = (n / NJ) % MI, j = n % NJ;
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j][kk], fa[i][kk], acc[i][j], 0, 0, 0);
+                    if (n % STEP == 1 && n / STEP < HUPW) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (x + 3 < H) hstage1(x + 3, n / STEP);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                return;
+            }
             if constexpr (VAR != 5) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
@@ -393,7 +419,7 @@ __global__ __launch_bounds__(512, 2) void gemm_blk_kernel(const GemmP p) {
                     auto r0 = __builtin_amdgcn_permlane32_swap(pk[q][0], pk[q + 1][0], false, false);
                     auto r1 = __builtin_amdgcn_permlane32_swap(pk[q][1], pk[q + 1][1], false, false);
                     // lanes 0-31: cols 8q..8q+7 (block q); lanes 32-63: cols 8(q+1).. (block q+1)
-                    *(uint4*)(rowp + (q + hi) * 512) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+                    store16_policy(rowp + (q + hi) * 512, (u32x4_t){r0[0], r1[0], r0[1], r1[1]}, (p.abl >> 7) & 7);
                 }
             }
         }
@@ -848,6 +874,7 @@ static void launch_any(const GemmP& p, int bm, int var, int epi, hipStream_t st)
     } else if (var == 3) { launch_epi<256, 3, 0>(p, epi, st);
     } else if (var == 4) { launch_epi<256, 4, 0>(p, epi, st);
     } else if (var == 5) { launch_epi<256, 5, 0>(p, epi, st);
+    } else if (var == 8) { launch_epi<256, 8, 0>(p, epi, st);
     }
 }
 
@@ -900,7 +927,7 @@ int main(int argc, char** argv) {
         return 0;
     }
     struct Cfg { int var, bm; };
-    const Cfg cfgs[] = {{5, 256}, {6, 128}, {7, 128}, {7, 96}};
+    const Cfg cfgs[] = {{5, 256}, {8, 256}, {4, 256}};
     // ---- correctness: sampled outputs vs a host fp64 dot product on the blocked data
     for (const Shape& s : shapes) {
         for (const Cfg& c : cfgs) {
@@ -944,6 +971,21 @@ int main(int argc, char** argv) {
     }
 
 
+
+    // ---- store cache-policy sweep (VAR 5, bf16 epilogues)
+    for (const Shape& s : shapes) {
+        if (s.epi == 2) continue;
+        const double gf = 2.0 * M * s.N * s.K / 1e6;
+        GemmP p{}; p.A = dA; p.W = dW; p.C = dC; p.bias = dB; p.res = (const float*)dC; p.M = M; p.N = s.N; p.K = s.K; p.ts = dTs;
+        printf("%-4s var 5 BM 256 store policy:", s.name);
+        for (int pol = 0; pol < 5; ++pol) {
+            p.abl = pol << 7;
+            float t = 1e9f;
+            for (int rnd = 0; rnd < 3; ++rnd) t = std::min(t, timeit([&] { launch_any(p, 256, 5, s.epi, st); }, 10, 2));
+            printf("  [%s] %5.1f us (%4.0f TF)", pol == 0 ? "default" : pol == 1 ? "nt" : pol == 2 ? "sc1" : pol == 3 ? "sc0 sc1" : "sc0 sc1 nt", t, gf / t);
+        }
+        printf("\n");
+    }
     // ---- VAR 7 stagger sweep
     for (const Shape& s : shapes) {
         const double gf = 2.0 * M * s.N * s.K / 1e6;

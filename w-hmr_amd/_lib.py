@@ -640,12 +640,19 @@ def attention_set_variant(chunked):
 
 # ----------------------------------------------------------------------------- backward-pass helpers (train_ops.hip)
 _train_scratch = {}
+_train_scratch_retired = []        # outgrown buffers: kept alive for the graphs that recorded their pointers
 
 
 def train_scratch(device, nfloats):
-    t = _train_scratch.get(device)
+    """fp32 scratch of the two-stage reductions (column sums, LayerNorm backward): one buffer per (device, stream) -- two streams may reduce
+    concurrently -- that only ever GROWS by allocating a new buffer while the old ones stay alive: a captured HIP graph (capture_train_step,
+    GraphedForward) keeps the raw pointer it was recorded with, so a buffer is never handed back to the allocator."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    t = _train_scratch.get(key)
     if t is None or t.numel() < nfloats:
-        t = _train_scratch[device] = torch.empty(max(nfloats, 1 << 20), dtype=torch.float32, device=device)
+        if t is not None:
+            _train_scratch_retired.append(t)
+        t = _train_scratch[key] = torch.empty(max(nfloats, 1 << 20), dtype=torch.float32, device=device)
     return t
 
 

@@ -159,7 +159,7 @@ __device__ __forceinline__ size_t blk_elem(int m, int col8, int ld8) { return ((
 
 template <int NKT, bool BLK = false>
 __global__ __launch_bounds__(NKT * 64, 4) void attention_bf16_chunk_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                                           int N, int H, float scale, float* __restrict__ lse) {
+                                                                           int N, int H, float scale, float* __restrict__ lse, int abl = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NPAD = NKT * 32;
     constexpr int VS = NPAD + 4;
@@ -172,6 +172,7 @@ __global__ __launch_bounds__(NKT * 64, 4) void attention_bf16_chunk_kernel(const
     const bf16_t* base = qkv + (size_t)b * N * ld + h * 64;
     const int ld8 = ld >> 3, m_img = b * N;
     if constexpr (BLK) {
+        if (!(abl & 2)) {
         for (int c = tid; c < NPAD * 8; c += NKT * 64) {
             const int key = c % NPAD, ch = c / NPAD;
             uint4 v = make_uint4(0, 0, 0, 0);
@@ -190,6 +191,7 @@ __global__ __launch_bounds__(NKT * 64, 4) void attention_bf16_chunk_kernel(const
                 *(uint32_t*)(Vt + (ch * 8 + 2 * i) * VS + k0) = (a[i] & 0xffffu) | (bb[i] << 16);
                 *(uint32_t*)(Vt + (ch * 8 + 2 * i + 1) * VS + k0) = (a[i] >> 16) | (bb[i] & 0xffff0000u);
             }
+        }
         }
     } else {
     for (int c = tid; c < NPAD * 8; c += NKT * 64) {
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(NKT * 64, 4) void attention_bf16_chunk_kernel(const
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dh][r] = 0.f;
 #pragma unroll 1
-    for (int c0 = 0; c0 < NKT; c0 += 2) {
+    for (int c0 = (abl & 4) ? NKT : 0; c0 < NKT; c0 += 2) {
         const int nt = (NKT - c0) < 2 ? (NKT - c0) : 2;
         f32x16_t s[2];
 #pragma unroll
@@ -631,8 +633,9 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
     }
 }
 
-static int g_attn_chunked = 1;      // whmr_attention_set_variant: 1 = chunked online-softmax kernel (default), 0 = single pass
-extern "C" int whmr_attention_set_variant(int chunked) { g_attn_chunked = chunked; return 0; }
+static int g_attn_chunked = 1;      // whmr_attention_set_variant: bit 0: 1 = chunked online-softmax kernel (default), 0 = single pass
+static int g_attn_abl = 0;          // bits 1-2 (timing probes only, wrong results): 2 = skip the K / V staging, 4 = skip the key loop
+extern "C" int whmr_attention_set_variant(int v) { g_attn_chunked = v & 1; g_attn_abl = v & 6; return 0; }
 
 template <int NKT>
 static int launch_bf16(const void* qkv, void* out, int B, int N, int H, float scale, hipStream_t st, float* lse = nullptr) {
@@ -653,7 +656,7 @@ static int launch_bf16_blk(const void* qkv, void* out, int B, int N, int H, floa
     constexpr int NPAD = NKT * 32;
     const size_t lds = (size_t)NPAD * 128 + 64 * (NPAD + 4) * 2;
     hipLaunchKernelGGL((attention_bf16_chunk_kernel<NKT, true>), dim3(B * H), dim3(NKT * 64), lds, st, (const bf16_t*)qkv, (bf16_t*)out, N, H, scale,
-                       (float*)nullptr);
+                       (float*)nullptr, g_attn_abl);
     WHMR_CHECK_LAUNCH();
     return 0;
 }

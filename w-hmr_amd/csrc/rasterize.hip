@@ -36,43 +36,102 @@ __device__ __forceinline__ float edge_fn(float ax, float ay, float bx, float by,
     return (px - ax) * (by - ay) - (py - ay) * (bx - ax);
 }
 
-// barycentrics of pixel centre (px, py) w.r.t. the screen triangle; returns false when the centre is not strictly inside
-__device__ __forceinline__ bool raster_bary(const float* v0, const float* v1, const float* v2, float px, float py, float eps, float& b0, float& b1,
-                                            float& b2, float& pz) {
-    const float area = edge_fn(v0[0], v0[1], v1[0], v1[1], v2[0], v2[1]);       // eps: pytorch3d's kEpsilon = 1e-8 NDC units^2, in pixels^2
-    if (area <= eps && area >= -eps) return false;
-    const float w0 = edge_fn(v1[0], v1[1], v2[0], v2[1], px, py) / area;
-    const float w1 = edge_fn(v2[0], v2[1], v0[0], v0[1], px, py) / area;
-    const float w2 = edge_fn(v0[0], v0[1], v1[0], v1[1], px, py) / area;
-    if (!(w0 > 0.f && w1 > 0.f && w2 > 0.f)) return false;
-    const float q0 = w0 / v0[2], q1 = w1 / v1[2], q2 = w2 / v2[2];
-    const float den = (q0 + q1) + q2;
-    b0 = q0 / den; b1 = q1 / den; b2 = q2 / den;
-    pz = (b0 * v0[2] + b1 * v1[2]) + b2 * v2[2];
+// Per-face setup + per-pixel test.  raster_setup: signed doubled area (|area| <= eps: degenerate, skipped; eps = pytorch3d's kEpsilon = 1e-8 NDC
+// units^2 in pixels^2) and the four reciprocals the barycentrics need (1 / area, 1 / z_i: v_rcp_f32, 1 ulp -- the float64 oracle comparison is
+// gated at 1e-3).  raster_bary: the coverage test compares the SIGNS of the three edge functions with the sign of the area (w_i = e_i / area > 0:
+// most centres of a face's pixel box lie outside); covered pixels cost one more reciprocal.  Both kernels (z-buffer pass and resolve pass)
+// run this one code path, so coverage and depth agree bit for bit between them.
+struct raster_tri { float v[9]; float area, ra, rz0, rz1, rz2; };
+__device__ __forceinline__ bool raster_setup(raster_tri& t, float eps) {
+    t.area = edge_fn(t.v[0], t.v[1], t.v[3], t.v[4], t.v[6], t.v[7]);
+    t.ra = __builtin_amdgcn_rcpf(t.area);
+    t.rz0 = __builtin_amdgcn_rcpf(t.v[2]); t.rz1 = __builtin_amdgcn_rcpf(t.v[5]); t.rz2 = __builtin_amdgcn_rcpf(t.v[8]);
+    return !(t.area <= eps && t.area >= -eps);
+}
+__device__ __forceinline__ bool raster_bary(const raster_tri& t, float px, float py, float& b0, float& b1, float& b2, float& pz) {
+    const float e0 = edge_fn(t.v[3], t.v[4], t.v[6], t.v[7], px, py);
+    const float e1 = edge_fn(t.v[6], t.v[7], t.v[0], t.v[1], px, py);
+    const float e2 = edge_fn(t.v[0], t.v[1], t.v[3], t.v[4], px, py);
+    const bool in = t.area > 0.f ? (e0 > 0.f && e1 > 0.f && e2 > 0.f) : (e0 < 0.f && e1 < 0.f && e2 < 0.f);
+    if (!in) return false;
+    const float q0 = (e0 * t.ra) * t.rz0, q1 = (e1 * t.ra) * t.rz1, q2 = (e2 * t.ra) * t.rz2;
+    const float rden = __builtin_amdgcn_rcpf((q0 + q1) + q2);
+    b0 = q0 * rden; b1 = q1 * rden; b2 = q2 * rden;
+    pz = (b0 * t.v[2] + b1 * t.v[5]) + b2 * t.v[8];
     return pz >= 0.f;
+}
+
+// One lane per (image, face) finds the face's pixel box; boxes of at most RASTER_SMALL pixels (a real SMPL mesh at 128 x 128: 1-4 pixels per
+// face) are walked by that lane, larger ones by the WHOLE wave, 64 pixels at a time (the face's setup is broadcast with readlane): a mesh with
+// a few large triangles -- or the synthetic benchmark mesh, whose random skinning weights stretch every face over a good part of the image --
+// costs sum(box) / 64 per wave instead of max(box).  Same per-pixel arithmetic on both paths (bit-identical coverage).
+#define RASTER_SMALL 16
+__device__ __forceinline__ void raster_pixel(const raster_tri& t, int x, int y, int f, unsigned long long* __restrict__ zrow0, int W) {
+    float b0, b1, b2, pz;
+    if (!raster_bary(t, x + 0.5f, y + 0.5f, b0, b1, b2, pz)) return;
+    const unsigned long long key = ((unsigned long long)__float_as_uint(pz) << 32) | (unsigned)f;
+    // the z-buffer only ever decreases: a plain (L2-scope) look first drops the faces that are already hidden -- with n faces over a pixel in
+    // random depth order ~ln(n) of them still need the atomic
+    unsigned long long* z = zrow0 + (size_t)y * W + x;
+    if (__hip_atomic_load(z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > key) atomicMin(z, key);
 }
 
 __global__ __launch_bounds__(256) void raster_faces_kernel(const float* __restrict__ scr, const int32_t* __restrict__ faces, unsigned long long* __restrict__ zbuf,
                                                            int B, int V, int F, int H, int W) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long)B * F) return;
-    const int b = (int)(idx / F), f = (int)(idx - (long)b * F);
-    const float* s = scr + (size_t)b * V * 3;
-    const float* v0 = s + faces[f * 3] * 3;
-    const float* v1 = s + faces[f * 3 + 1] * 3;
-    const float* v2 = s + faces[f * 3 + 2] * 3;
-    const float xmin = fminf(v0[0], fminf(v1[0], v2[0])), xmax = fmaxf(v0[0], fmaxf(v1[0], v2[0]));
-    const float ymin = fminf(v0[1], fminf(v1[1], v2[1])), ymax = fmaxf(v0[1], fmaxf(v1[1], v2[1]));
-    if (!(xmax >= 0.f && ymax >= 0.f && xmin <= (float)W && ymin <= (float)H)) return;          // also drops NaN vertices
-    int x0 = (int)floorf(xmin - 0.5f), x1 = (int)ceilf(xmax - 0.5f), y0 = (int)floorf(ymin - 0.5f), y1 = (int)ceilf(ymax - 0.5f);
-    x0 = x0 < 0 ? 0 : x0; y0 = y0 < 0 ? 0 : y0; x1 = x1 > W - 1 ? W - 1 : x1; y1 = y1 > H - 1 ? H - 1 : y1;
-    for (int y = y0; y <= y1; ++y)
-        for (int x = x0; x <= x1; ++x) {
-            float b0, b1, b2, pz;
-            if (!raster_bary(v0, v1, v2, x + 0.5f, y + 0.5f, 1e-8f * 0.25f * H * W, b0, b1, b2, pz)) continue;
-            const unsigned long long key = ((unsigned long long)__float_as_uint(pz) << 32) | (unsigned)f;
-            atomicMin(zbuf + ((size_t)b * H + y) * W + x, key);
+    const int lane = threadIdx.x & 63;
+    const float eps = 1e-8f * 0.25f * H * W;
+    raster_tri t;
+    int x0 = 0, x1 = -1, y0 = 0, y1 = -1, f = 0, b = 0;
+    if (idx < (long)B * F) {
+        b = (int)(idx / F); f = (int)(idx - (long)b * F);
+        const float* s = scr + (size_t)b * V * 3;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float* vp = s + faces[f * 3 + k] * 3;
+            t.v[3 * k] = vp[0]; t.v[3 * k + 1] = vp[1]; t.v[3 * k + 2] = vp[2];
         }
+        const float xmin = fminf(t.v[0], fminf(t.v[3], t.v[6])), xmax = fmaxf(t.v[0], fmaxf(t.v[3], t.v[6]));
+        const float ymin = fminf(t.v[1], fminf(t.v[4], t.v[7])), ymax = fmaxf(t.v[1], fmaxf(t.v[4], t.v[7]));
+        if (xmax >= 0.f && ymax >= 0.f && xmin <= (float)W && ymin <= (float)H) {                  // also drops NaN vertices
+            x0 = (int)floorf(xmin - 0.5f); x1 = (int)ceilf(xmax - 0.5f); y0 = (int)floorf(ymin - 0.5f); y1 = (int)ceilf(ymax - 0.5f);
+            x0 = x0 < 0 ? 0 : x0; y0 = y0 < 0 ? 0 : y0; x1 = x1 > W - 1 ? W - 1 : x1; y1 = y1 > H - 1 ? H - 1 : y1;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) t.v[k] = 1.f;
+    }
+    const bool ok = raster_setup(t, eps);
+    const int bw = x1 - x0 + 1, bh = y1 - y0 + 1;
+    const int npx = (bw > 0 && bh > 0 && ok) ? bw * bh : 0;
+    if (npx > 0 && npx <= RASTER_SMALL) {
+        unsigned long long* z0 = zbuf + (size_t)b * H * W;
+        for (int y = y0; y <= y1; ++y)
+            for (int x = x0; x <= x1; ++x) raster_pixel(t, x, y, f, z0, W);
+    }
+    unsigned long long big = __ballot(npx > RASTER_SMALL);
+    while (big) {
+        const int L = __ffsll((long long)big) - 1;
+        big &= big - 1;
+        raster_tri u;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) u.v[k] = __shfl(t.v[k], L, 64);
+        u.area = __shfl(t.area, L, 64); u.ra = __shfl(t.ra, L, 64);
+        u.rz0 = __shfl(t.rz0, L, 64); u.rz1 = __shfl(t.rz1, L, 64); u.rz2 = __shfl(t.rz2, L, 64);
+        const int ux0 = __shfl(x0, L, 64), uy0 = __shfl(y0, L, 64), ux1 = __shfl(x1, L, 64), uy1 = __shfl(y1, L, 64);
+        const int uf = __shfl(f, L, 64), ub = __shfl(b, L, 64);
+        unsigned long long* z0 = zbuf + (size_t)ub * H * W;
+        // the box in 64-pixel tiles shaped after its height (64 x 1 ... 8 x 8), lane = pixel of the tile: no per-pixel index division
+        const int uh = uy1 - uy0 + 1;
+        const int lw = uh <= 1 ? 6 : uh <= 2 ? 5 : uh <= 4 ? 4 : 3;               // log2 of the tile width
+        const int tw = 1 << lw, th = 64 >> lw;
+        const int lx = lane & (tw - 1), ly = lane >> lw;
+        for (int ty = uy0; ty <= uy1; ty += th)
+            for (int tx = ux0; tx <= ux1; tx += tw) {
+                const int x = tx + lx, y = ty + ly;
+                if (x <= ux1 && y <= uy1) raster_pixel(u, x, y, uf, z0, W);
+            }
+    }
 }
 
 __global__ __launch_bounds__(256) void raster_resolve_kernel(const float* __restrict__ scr, const int32_t* __restrict__ faces, const float* __restrict__ tex,
@@ -89,8 +148,12 @@ __global__ __launch_bounds__(256) void raster_resolve_kernel(const float* __rest
         fid = (int)(key & 0xffffffffu);
         const float* s = scr + (size_t)b * V * 3;
         const int i0 = faces[fid * 3], i1 = faces[fid * 3 + 1], i2 = faces[fid * 3 + 2];
+        raster_tri t;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { t.v[k] = s[i0 * 3 + k]; t.v[3 + k] = s[i1 * 3 + k]; t.v[6 + k] = s[i2 * 3 + k]; }
+        raster_setup(t, 0.f);
         float b0, b1, b2, pz;
-        if (raster_bary(s + i0 * 3, s + i1 * 3, s + i2 * 3, x + 0.5f, y + 0.5f, 1e-8f * 0.25f * H * W, b0, b1, b2, pz)) {
+        if (raster_bary(t, x + 0.5f, y + 0.5f, b0, b1, b2, pz)) {
             o0 = (b0 * tex[i0 * 3] + b1 * tex[i1 * 3]) + b2 * tex[i2 * 3];
             o1 = (b0 * tex[i0 * 3 + 1] + b1 * tex[i1 * 3 + 1]) + b2 * tex[i2 * 3 + 1];
             o2 = (b0 * tex[i0 * 3 + 2] + b1 * tex[i1 * 3 + 2]) + b2 * tex[i2 * 3 + 2];

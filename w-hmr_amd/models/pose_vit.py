@@ -94,6 +94,7 @@ class ViT(nn.Module):
         self._wcache = {}
         self._ws = {}
         self.blocked = True                 # bf16 inference on the blocked-layout kernels when the shapes allow it
+        self.blocked_min_tokens = 2048      # ... and the batch has at least this many tokens (set 0 to force the blocked path)
         self.ln_fold = True                 # ... with norm1 / norm2 folded into the qkv / fc1 GEMMs (no LayerNorm pass inside the blocks)
 
     # ------------------------------------------------------------------ weight / workspace caches
@@ -160,7 +161,9 @@ class ViT(nn.Module):
         dt = torch.float32 if self.numerics == 'fp32' else torch.bfloat16
         dev = x.device
         hid_dim = self.blocks[0].mlp.fc1.weight.shape[0] if self.depth else D
-        if (self.blocked and self.numerics == 'bf16' and D % 256 == 0 and hid_dim % 256 == 0 and D // self.num_heads == 64
+        # below ~2k tokens (batch <= 10 at 192 tokens) the launches are latency-bound and the row-major kernels' smaller tiles + split-K win
+        # (ViT-B 256x192 under a HIP graph, tools/smallbatch_probe.py: batch 1 0.85 vs 1.14 ms, batch 8 1.15 vs 1.22, batch 16 1.50 vs 1.32)
+        if (self.blocked and M >= self.blocked_min_tokens and self.numerics == 'bf16' and D % 256 == 0 and hid_dim % 256 == 0 and D // self.num_heads == 64
                 and 64 < N <= 256 and P % 8 == 0 and (Cin * P * P) % 32 == 0 and D in (256, 768, 1024, 1280)):
             return self._forward_tokens_blocked(x, B, Hp, Wp), (B, Hp, Wp)
         cols = self._buf('cols', (M, Cin * P * P), dt, dev)

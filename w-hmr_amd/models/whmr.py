@@ -328,6 +328,8 @@ class WHMR(nn.Module):
         self.global_orient = Global_Orient_Regressor(smpl_mean_params, assets)
         self._cache = _Cache()
         self._init_cache = None
+        self.overlap_camera = True          # cam_model on a side stream beside the backbone (joined before the global-orientation head)
+        self._cam_streams = {}
         self.eval()
 
     def _make_deconv_layer(self, num_layers, num_filters, num_kernels):
@@ -447,6 +449,12 @@ class WHMR(nn.Module):
             self._init_cache = (key, reg.forward_init(x1, with_aux=with_aux))
         return expand(self._init_cache[1])
 
+    def _camera_stream(self, dev):
+        st = self._cam_streams.get(dev)
+        if st is None:
+            st = self._cam_streams[dev] = torch.cuda.Stream(device=dev)
+        return st
+
     @torch.no_grad()
     def _camera(self, full_x, cam_rotmat, B, dev):
         """whmr.py:509-524: camera-calibration head on the full image -> (cam_rotmat, render_rotmat); detached in the reference too."""
@@ -485,7 +493,18 @@ class WHMR(nn.Module):
         view = view or self.return_view
         with_aux = view == 'train'
         B, dev = x.shape[0], x.device
-        cam_rotmat, render_rotmat = self._camera(full_x, cam_rotmat, B, dev)
+        # The camera-calibration ResNet-50 (whmr.py:509-522) only feeds the global-orientation head at the very end (whmr.py:630): it runs on a
+        # SIDE stream beside the backbone / deconvs / regressor loop and is joined just before that head.  Its few-tile launches slot into the CUs
+        # the big GEMM grids leave idle (tile-grid tails); under GraphedForward the fork / join become two branches of the captured graph.
+        side = None
+        if full_x is not None and cam_rotmat is None and self.overlap_camera:
+            main = torch.cuda.current_stream(dev)
+            side = self._camera_stream(dev)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                cam_rotmat, render_rotmat = self._camera(full_x, None, B, dev)
+        else:
+            cam_rotmat, render_rotmat = self._camera(full_x, cam_rotmat, B, dev)
 
         # backbone (tokens are NHWC already) -> deconv pyramid in NHWC
         vit = self.feature_extractor.backbone
@@ -522,6 +541,11 @@ class WHMR(nn.Module):
                                          xc_next=(xcs[i + 1], Fs[i + 1]) if i < 2 else None, state_ready=i > 0)
             outs.append(smpl_output)
 
+        if side is not None:                                                          # join: the camera rotation is needed from here on
+            main.wait_stream(side)
+            if not torch.cuda.is_current_stream_capturing():                          # (a capture's private pool never recycles)
+                for t in (cam_rotmat, render_rotmat):
+                    t.record_stream(main)                                             # allocated on the side stream, read (and returned) on the main one
         g_rot = self.global_orient(body_feat, cam_rotmat, smpl_output['rotmat'][:, 0], False, xc=xc)     # whmr.py:630-654
         g_aa = rotation_matrix_to_angle_axis(g_rot.reshape(-1, 3, 3)).reshape(-1, 3)
         g_pose = torch.cat([g_aa, smpl_output['pose'][:, 3:]], dim=1)
