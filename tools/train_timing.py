@@ -33,3 +33,15 @@ with torch.no_grad():
     torch.cuda.synchronize()
 print('inference forward for scale: %.2f ms' % ((time.perf_counter() - t0) / steps * 1e3))
 print('peak memory: %.1f GB' % (torch.cuda.max_memory_allocated() / 2**30))
+# A/B: weight-gradient branch on a side stream
+if len(sys.argv) > 3 and sys.argv[3] == 'ab':
+    from whmr_amd.train import vit_autograd as VA
+    m.train()
+    for rnd in range(3):
+        for ov in (False, True):
+            VA.OVERLAP_DW = ov
+            for _ in range(2): step()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(steps): step()
+            torch.cuda.synchronize()
+            print('round %d: dW on a side stream = %-5s  %.2f ms / step' % (rnd, ov, (time.perf_counter() - t0) / steps * 1e3), flush=True)
