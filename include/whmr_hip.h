@@ -99,6 +99,9 @@ int whmr_attention_blk(const void* qkv, void* out, int B, int N, int H, float sc
  * Regressor fc1/fc2/decpose/decshape/deccam (whmr.py:118-126), Global_Orient_Regressor (whmr.py:295-301),
  * est_Tz linears (whmr.py:425-427), second Tz conv (whmr.py:420), the timm Block linears (whmr.py:423). */
 int whmr_gemm_f32(const struct whmr_gemm* p, int flags, void* stream);
+/* A/B switch of the large-M 128x128 double-buffered kernel behind whmr_gemm_f32 (1 = on, the default; 0 = always the 64x64 kernel): the two
+ * produce the same bits (same k order of the MFMA chain). */
+int whmr_gemm_f32_set_big(int on);
 
 /* LayerNorm over the last dim (C % 4 == 0, C <= 2048), fp32 in, fp32 or bf16 out.  vit.py:125,133,212,242. */
 int whmr_layernorm(const float* x, const float* gamma, const float* beta, void* y, int rows, int C, float eps,

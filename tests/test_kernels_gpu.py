@@ -81,6 +81,72 @@ def test_gemm_f32(dev, M, N, K):
     assert _rel(out.cpu(), ref) < 2e-6
 
 
+@pytest.mark.parametrize('M,N,K', [(12544, 768, 768), (2049, 2304, 772), (1100, 3072, 40), (4100, 200, 3076), (1024, 1030, 16)])
+def test_gemm_f32_big_kernel(dev, M, N, K):
+    """large-M fp32 GEMM (128x128 double-buffered kernel, gemm_f32.hip): ragged M / N, K not a multiple of the 16-deep step, every epilogue option;
+    against float64 and BITWISE against the 64x64 kernel (same k order of the exact-f32 MFMA chain)"""
+    from whmr_amd import _lib as L
+    g = torch.Generator().manual_seed(M + 3 * N + K)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    ad, wd, bd, rd = a.to(dev), w.to(dev), bias.to(dev), res.to(dev)
+    out = torch.empty(M, N, device=dev)
+    L.gemm(ad, wd, out, bias=bd, residual=rd, act=L.ACT_GELU)
+    ref = (torch.nn.functional.gelu(a.double() @ w.double().t() + bias) + res).float()
+    assert _rel(out.cpu(), ref) < 3e-6
+    try:
+        L.gemm_f32_set_big(0)
+        small = torch.empty(M, N, device=dev)
+        L.gemm(ad, wd, small, bias=bd, residual=rd, act=L.ACT_GELU)
+    finally:
+        L.gemm_f32_set_big(1)
+    assert torch.equal(out, small)
+    # positional residual (row = m % R) into a bf16 output, ReLU before the skip
+    R = 7
+    pos = torch.randn(R, N, generator=g).to(dev)
+    o16 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    L.gemm(ad, wd, o16, residual=pos, res_row_mod=R, act=L.ACT_RELU)
+    ref2 = torch.relu(a.double() @ w.double().t()).float() + pos.cpu().repeat((M + R - 1) // R, 1)[:M]
+    assert _rel(o16.float().cpu(), ref2) < 1e-2
+
+
+def test_gemm_f32_big_kernel_conv_gather_and_scatter(dev):
+    """the same kernel as an implicit GEMM: NHWC gather (7x7 s3 conv, 3x3 s1 p1 conv) and the sub-pixel deconv phase with scattered rows"""
+    from whmr_amd import _lib as L
+    g = torch.Generator().manual_seed(5)
+    for (B, Cin, IH, IW, Cout, KH, S, P) in ((3, 64, 70, 60, 128, 7, 3, 0), (2, 32, 40, 36, 72, 3, 1, 1)):
+        x = torch.randn(B, Cin, IH, IW, generator=g)
+        w = torch.randn(Cout, Cin, KH, KH, generator=g) / math.sqrt(Cin * KH * KH)
+        ref = F.conv2d(x.double(), w.double(), stride=S, padding=P).float()
+        OH, OW = ref.shape[2:]
+        assert B * OH * OW >= 1024
+        xn = x.permute(0, 2, 3, 1).contiguous().to(dev)
+        w2 = w.permute(0, 2, 3, 1).reshape(Cout, KH * KH * Cin).contiguous().to(dev)
+        out = torch.empty(B, OH, OW, Cout, device=dev)
+        L.gemm(xn, w2, out.view(-1, Cout), conv=dict(IH=IH, IW=IW, Cin=Cin, OH=OH, OW=OW, KW=KH, SH=S, SW=S, PH=P, PW=P))
+        assert _rel(out.permute(0, 3, 1, 2).cpu(), ref) < 3e-6
+        try:
+            L.gemm_f32_set_big(0)
+            small = torch.empty_like(out)
+            L.gemm(xn, w2, small.view(-1, Cout), conv=dict(IH=IH, IW=IW, Cin=Cin, OH=OH, OW=OW, KW=KH, SH=S, SW=S, PH=P, PW=P))
+        finally:
+            L.gemm_f32_set_big(1)
+        assert torch.equal(out, small)
+    # scatter: rows (b, oy, ox) land at every second pixel of a [B, 2H, 2W, C] map (deconv phase, whmr.py:488-495)
+    B, H, W, Cin, Cout = 2, 24, 24, 32, 64
+    x = torch.randn(B, H, W, Cin, generator=g).to(dev)
+    w = (torch.randn(Cout, 4 * Cin, generator=g) / math.sqrt(4 * Cin)).to(dev)
+    big = torch.zeros(B, 2 * H, 2 * W, Cout, device=dev)
+    conv = dict(IH=H, IW=W, Cin=Cin, OH=H, OW=W, KW=2, SH=1, SW=1, PH=1, PW=1)
+    sc = dict(c_off=(2 * W + 1) * Cout, osb=4 * H * W * Cout, osy=4 * W * Cout, osx=2 * Cout)
+    L.gemm(x, w, big, conv=conv, scatter=sc)
+    dense = torch.empty(B * H * W, Cout, device=dev)
+    L.gemm(x, w, dense, conv=conv)
+    assert torch.equal(big[:, 1::2, 1::2], dense.view(B, H, W, Cout)) and not big[:, 0::2].any() and not big[:, :, 0::2].any()
+
+
 def _conv_case(dev, dtype, tol):
     """implicit GEMM: Conv2d k7 s3 (Tz head conv, whmr.py:419) on an NHWC image"""
     from whmr_amd import _lib as L

@@ -61,6 +61,7 @@ _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_long
 _SIGS = {
     'whmr_gemm_bf16': [C.POINTER(WhmrGemm), _I, _P],
     'whmr_gemm_f32': [C.POINTER(WhmrGemm), _I, _P],
+    'whmr_gemm_f32_set_big': [_I],
     'whmr_gemm_bf16_big': [C.POINTER(WhmrGemm), _I, _P],
     'whmr_gemm_bf16_split': [C.POINTER(WhmrGemm), _I, _I, _P],
     'whmr_set_option': [_I, _I],
@@ -605,6 +606,11 @@ def avgpool_nhwc(x):
     _check(lib().whmr_avgpool_nhwc(x.data_ptr(), y.data_ptr(), B, H * W, Cc, int(x.dtype == torch.bfloat16), _stream()),
            'whmr_avgpool_nhwc')
     return y
+
+
+def gemm_f32_set_big(on):
+    """A/B: 128x128 large-M fp32 GEMM kernel on (default) / off"""
+    _check(lib().whmr_gemm_f32_set_big(int(on)), 'whmr_gemm_f32_set_big')
 
 
 def set_option(key, value):

@@ -134,6 +134,162 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const whmr_gemm p, int k_
     }
 }
 
+// ---- large-M variant (the ViT / deconv / conv GEMMs of the fp32 parity mode: M = all tokens or pixels).  128x128x16 block tile, 4 waves
+// (2x2), wave tile 64x64 = 2x2 accumulators; 16-B global loads of the NEXT K step are in flight under the 32 MFMAs of the current one
+// (register-staged, two LDS buffers, one barrier per step).  LDS rows hold the 16 k of a step permuted so that the four operands a lane
+// feeds to four consecutive v_mfma_f32_32x32x2_f32 (k = 8g + 2j + hi, j = 0..3) are ONE ds_read_b128: position of k in its row =
+// 8 (k / 8) + 4 (k % 2) + (k % 8) / 2.  The K order of the MFMA chain is unchanged (0, 1, 2, ...): same bits as the 64x64 kernel.
+// Requires K % 4 == 0 and 16-B aligned operand rows (plain: lda % 4 == 0; gather: Cin % 4 == 0); the launcher falls back otherwise.
+#define GBM 128
+#define GBN 128
+#define GLD 20
+template <bool GATHER>
+__global__ __launch_bounds__(256, 2) void gemm_f32_big_kernel(const whmr_gemm p) {
+    __shared__ __attribute__((aligned(16))) float sA[2][GBM * GLD];
+    __shared__ __attribute__((aligned(16))) float sB[2][GBN * GLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_n = (p.N + GBN - 1) / GBN;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    const int m0 = tm * GBM, n0 = tn * GBN;
+    const float* __restrict__ A = (const float*)p.A;
+    const float* __restrict__ W = (const float*)p.W;
+    // staging: thread -> rows (tid >> 2) and (tid >> 2) + 64, 4 consecutive k at (tid & 3) * 4
+    const int srow = tid >> 2, sk = (tid & 3) * 4;
+    const float* a_base[2];
+    const float* b_base[2];
+    bool a_ok[2], b_ok[2];
+    int ay[2] = {0, 0}, ax[2] = {0, 0};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int am = m0 + srow + 64 * h, bn = n0 + srow + 64 * h;
+        a_ok[h] = am < p.M; b_ok[h] = bn < p.N;
+        a_base[h] = A;
+        if (a_ok[h]) {
+            if constexpr (GATHER) {
+                const int ohw = p.OH * p.OW;
+                const int b = am / ohw, rem = am - b * ohw;
+                const int oy = rem / p.OW, ox = rem - oy * p.OW;
+                ay[h] = oy * p.SH - p.PH; ax[h] = ox * p.SW - p.PW;
+                a_base[h] = A + (size_t)b * p.IH * p.IW * p.Cin;
+            } else {
+                a_base[h] = A + (size_t)am * p.lda;
+            }
+        }
+        b_base[h] = W + (size_t)(b_ok[h] ? bn : 0) * p.K;
+    }
+    float4 ra[2], rb[2];
+    auto fetch = [&](int k0) {
+        const int k = k0 + sk;
+        const bool k_ok = k < p.K;                               // K % 4 == 0: a 16-B group is inside or outside as a whole
+        int ky = 0, kx = 0, ci = k;
+        if constexpr (GATHER) {
+            const int tap = k / p.Cin;
+            ci = k - tap * p.Cin;
+            ky = tap / p.KW; kx = tap - ky * p.KW;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+            if (k_ok) {
+                if (a_ok[h]) {
+                    if constexpr (GATHER) {
+                        const int iy = ay[h] + ky, ix = ax[h] + kx;
+                        if ((unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW)
+                            a = *(const float4*)(a_base[h] + ((size_t)iy * p.IW + ix) * p.Cin + ci);
+                    } else {
+                        a = *(const float4*)(a_base[h] + k);
+                    }
+                }
+                if (b_ok[h]) b = *(const float4*)(b_base[h] + k);
+            }
+            ra[h] = a; rb[h] = b;
+        }
+    };
+    // k = sk + e (e = 0..3) -> position 8 (k / 8) + 4 (k % 2) + (k % 8) / 2
+    const int pbase = (sk >> 3) * 8 + ((sk & 4) >> 1);           // sk % 8 == 0: positions 0,4,1,5;  sk % 8 == 4: positions 2,6,3,7
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float* da = &sA[buf][(srow + 64 * h) * GLD + pbase];
+            float* db = &sB[buf][(srow + 64 * h) * GLD + pbase];
+            da[0] = ra[h].x; da[4] = ra[h].y; da[1] = ra[h].z; da[5] = ra[h].w;
+            db[0] = rb[h].x; db[4] = rb[h].y; db[1] = rb[h].z; db[5] = rb[h].w;
+        }
+    };
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hi = lane >> 5;
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < p.K; k0 += 16) {
+        const bool more = k0 + 16 < p.K;
+        if (more) fetch(k0 + 16);                                // in flight under the MFMAs below
+        const float* pa = &sA[buf][(wm * 64 + l31) * GLD + hi * 4];
+        const float* pb = &sB[buf][(wn * 64 + l31) * GLD + hi * 4];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const float4 a0 = *(const float4*)(pa + g * 8), a1 = *(const float4*)(pa + 32 * GLD + g * 8);
+            const float4 b0 = *(const float4*)(pb + g * 8), b1 = *(const float4*)(pb + 32 * GLD + g * 8);
+            const float av[2][4] = {{a0.x, a0.y, a0.z, a0.w}, {a1.x, a1.y, a1.z, a1.w}};
+            const float bv[2][4] = {{b0.x, b0.y, b0.z, b0.w}, {b1.x, b1.y, b1.z, b1.w}};
+#pragma unroll
+            for (int j4 = 0; j4 < 4; ++j4)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][j4], bv[j][j4], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            stash(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + l31;
+        if (n >= p.N) continue;
+        const float bvs = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (m >= p.M) continue;
+                float v = acc[i][j][r] + bvs;
+                float rv = 0.f;
+                if (p.residual) {
+                    const int rr = p.res_row_mod > 0 ? m % p.res_row_mod : m;
+                    rv = p.residual[(size_t)rr * p.ldr + n];
+                }
+                if (p.epi_flags & 2) v += rv;
+                if (p.act == 1) v = gelu_erf(v);
+                else if (p.act == 2) v = fmaxf(v, 0.f);
+                if (p.row_scale) v *= p.row_scale[m];
+                if (!(p.epi_flags & 2)) v += rv;
+                size_t off;
+                if (p.c_mode == 1) {
+                    const int ohw = p.OH * p.OW;
+                    const int b = m / ohw, rem = m - b * ohw;
+                    const int oy = rem / p.OW, ox = rem - oy * p.OW;
+                    off = (size_t)(p.c_off + b * p.osb + oy * p.osy + ox * p.osx) + n;
+                } else {
+                    off = (size_t)m * p.ldc + n;
+                }
+                if (p.out_bf16) ((bf16_t*)p.C)[off] = f32_to_bf16(v);
+                else ((float*)p.C)[off] = v;
+            }
+    }
+}
+
 // ---- skinny variant (M <= 1024, typically M = batch: regressor / global-orient / Tz linears, SMPL pose-corrective product; whmr.py:118-126,295-301).
 // These GEMMs stream a weight matrix (9-17 MB) past 64 activation rows: the job is to keep HBM busy, not the matrix pipes.
 // Same 64x64 tile and exact-f32 MFMA as above, but K steps of 32 with the NEXT step's global loads (4 x 16 B per thread)
@@ -266,6 +422,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const whmr_gemm p, i
     else ((float*)p.C)[off] = v;
 }
 
+static int g_f32_big = 1;       // whmr_gemm_f32_set_big(0): A/B and tests against the 64x64 kernel
+extern "C" int whmr_gemm_f32_set_big(int on) { g_f32_big = on; return 0; }
+
 extern "C" int whmr_gemm_f32(const whmr_gemm* pp, int flags, void* stream) {
     (void)flags;
     const whmr_gemm& p = *pp;
@@ -293,6 +452,18 @@ extern "C" int whmr_gemm_f32(const whmr_gemm* pp, int flags, void* stream) {
         }
         WHMR_CHECK_LAUNCH();
         return 0;
+    }
+    // large M with aligned rows: the 128x128 double-buffered kernel (5x the 64x64 kernel's rate on the ViT shapes)
+    {
+        const bool aligned = !(p.K & 3) && !((uintptr_t)p.A & 15) && !((uintptr_t)p.W & 15) &&
+                             (p.a_mode == 1 ? !(p.Cin & 3) : !(p.lda & 3));
+        const long big_tiles = (long)((p.M + GBM - 1) / GBM) * ((p.N + GBN - 1) / GBN);
+        if (aligned && p.M >= 1024 && p.N >= 64 && big_tiles >= 128 && g_f32_big) {
+            if (p.a_mode == 1) hipLaunchKernelGGL((gemm_f32_big_kernel<true>), dim3((unsigned)big_tiles), dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((gemm_f32_big_kernel<false>), dim3((unsigned)big_tiles), dim3(256), 0, st, p);
+            WHMR_CHECK_LAUNCH();
+            return 0;
+        }
     }
     // Skinny shapes (M = batch: regressor / global-orient / Tz linears) leave most CUs idle and are weight-streaming bound:
     // split K across blocks so that ~2 blocks per CU stream the weight matrix concurrently.
