@@ -271,3 +271,16 @@ def test_grad_reducer_unused_and_misuse():
     with pytest.raises(RuntimeError, match='classified as unused'):
         c(b(a(x))).sum().backward()
     red.remove()
+
+
+def test_integration_doc_lists_every_entry_point():
+    """INTEGRATION.md's entry-point table names every symbol include/whmr_hip.h declares (and nothing the header lacks)"""
+    import re
+    header = open(os.path.join(ROOT, 'include', 'whmr_hip.h')).read()
+    declared = set(re.findall(r'\b(whmr_[a-z0-9_]+)\s*\(', header))
+    doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    missing = sorted(s for s in declared if s not in doc)
+    assert not missing, 'INTEGRATION.md does not mention: %s' % missing
+    table = doc[doc.index('| C entry point |'):]
+    ghosts = sorted(s for s in set(re.findall(r'`(whmr_[a-z0-9_]+)`', table)) if s not in declared and not s.startswith('whmr_amd'))
+    assert not ghosts, 'INTEGRATION.md names entry points the header does not declare: %s' % ghosts
