@@ -147,6 +147,62 @@ def test_gemm_f32_big_kernel_conv_gather_and_scatter(dev):
     assert torch.equal(big[:, 1::2, 1::2], dense.view(B, H, W, Cout)) and not big[:, 0::2].any() and not big[:, :, 0::2].any()
 
 
+@pytest.mark.parametrize('K,Mo,No,splits', [(12544, 768, 768, 0), (4096, 2304, 768, 0), (96, 128, 256, 1), (32, 256, 256, 0), (1056, 384, 512, 3),
+                                            (12288, 3072, 768, 0), (2048, 768, 3072, 1)])
+def test_gemm_tn(dev, K, Mo, No, splits):
+    """weight-gradient product straight from reduction-major operands (gemm_tn.hip: transposing LDS reads): C = A^T . B against float64,
+    bitwise repeatable, strided rows (operands that are column slices of wider buffers)"""
+    from whmr_amd import _lib as L
+    g = torch.Generator().manual_seed(K + Mo + No)
+    a = (torch.randn(K, Mo + 64, generator=g) * 0.5).bfloat16()
+    b = (torch.randn(K, No, generator=g) * 0.5).bfloat16()
+    ad, bd = a.to(dev)[:, 32:32 + Mo], b.to(dev)                          # a: a 64-B-offset column slice (row stride Mo + 64)
+    assert L.gemm_tn_ok(ad, bd)
+    out = torch.full((Mo, No), float('nan'), device=dev)
+    L.gemm_tn(ad, bd, out, splits=splits)
+    ref = (a[:, 32:32 + Mo].double().t() @ b.double()).float()
+    assert _rel(out.cpu(), ref) < 2e-5
+    out2 = torch.empty_like(out)
+    L.gemm_tn(ad, bd, out2, splits=splits)
+    assert torch.equal(out, out2)
+    assert not L.gemm_tn_ok(ad[:, :100], bd) and not L.gemm_tn_ok(ad[:-1], bd[:-1])
+
+
+def test_conv_dw_tn(dev):
+    """convolution weight gradients from the gathering TN kernel (no column matrix) against torch autograd on the CPU: 3x3 s1 p1 (IUV head),
+    7x7 s3 p0 (Tz head) and ConvTranspose2d k4 s2 p1 (deconv stages), incl. forced split-K"""
+    from whmr_amd import _lib as L
+    g = torch.Generator().manual_seed(3)
+    for (B, Cin, IH, IW, Cout, KH, S, P, splits) in ((2, 256, 16, 12, 128, 3, 1, 1, 0), (2, 256, 34, 25, 128, 7, 3, 0, 5), (4, 512, 8, 8, 256, 3, 1, 1, 1)):
+        x = (torch.randn(B, Cin, IH, IW, generator=g) * 0.5).bfloat16().float()
+        w = torch.zeros(Cout, Cin, KH, KH, requires_grad=True)
+        y = F.conv2d(x, w, stride=S, padding=P)
+        OH, OW = y.shape[2:]
+        dy = (torch.randn(y.shape, generator=g) * 0.5).bfloat16().float()
+        if (B * OH * OW) % 32:
+            continue
+        y.backward(dy)
+        a = dy.permute(0, 2, 3, 1).reshape(-1, Cout).bfloat16().contiguous().to(dev)
+        img = x.permute(0, 2, 3, 1).bfloat16().contiguous().to(dev)
+        assert L.conv_dw_tn_ok(a, img)
+        out = torch.empty(Cout, KH * KH * Cin, device=dev)
+        L.conv_dw_tn(a, img, out, OH, OW, KH, KH, S, P, splits=splits)
+        got = out.view(Cout, KH, KH, Cin).permute(0, 3, 1, 2).cpu()
+        assert _rel(got, w.grad) < 2e-5, (KH, S, P)
+    # ConvTranspose2d(k4, s2, p1): dW[ci, co, ky, kx] = sum x[b, iy, ix, ci] dz[b, 2 iy - 1 + ky, 2 ix - 1 + kx, co]
+    B, Cin, H, W, Cout = 2, 256, 8, 6, 256
+    x = (torch.randn(B, Cin, H, W, generator=g) * 0.5).bfloat16().float()
+    wt = torch.zeros(Cin, Cout, 4, 4, requires_grad=True)
+    z = F.conv_transpose2d(x, wt, stride=2, padding=1)
+    dz = (torch.randn(z.shape, generator=g) * 0.5).bfloat16().float()
+    z.backward(dz)
+    a = x.permute(0, 2, 3, 1).reshape(-1, Cin).bfloat16().contiguous().to(dev)
+    img = dz.permute(0, 2, 3, 1).bfloat16().contiguous().to(dev)
+    out = torch.empty(Cin, 16 * Cout, device=dev)
+    L.conv_dw_tn(a, img, out, H, W, 4, 4, 2, 1)
+    assert _rel(out.view(Cin, 4, 4, Cout).permute(0, 3, 1, 2).cpu(), wt.grad) < 2e-5
+
+
 def _conv_case(dev, dtype, tol):
     """implicit GEMM: Conv2d k7 s3 (Tz head conv, whmr.py:419) on an NHWC image"""
     from whmr_amd import _lib as L

@@ -45,3 +45,14 @@ if len(sys.argv) > 3 and sys.argv[3] == 'ab':
             for _ in range(steps): step()
             torch.cuda.synchronize()
             print('round %d: dW on a side stream = %-5s  %.2f ms / step' % (rnd, ov, (time.perf_counter() - t0) / steps * 1e3), flush=True)
+if len(sys.argv) > 3 and sys.argv[3] == 'tn':
+    from whmr_amd.train import vit_autograd as VA
+    m.train()
+    for rnd in range(3):
+        for tn in (False, True):
+            VA.USE_TN = tn
+            for _ in range(2): step()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(steps): step()
+            torch.cuda.synchronize()
+            print('round %d: TN weight-gradient GEMM = %-5s  %.2f ms / step' % (rnd, tn, (time.perf_counter() - t0) / steps * 1e3), flush=True)

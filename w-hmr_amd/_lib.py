@@ -62,6 +62,8 @@ _SIGS = {
     'whmr_gemm_bf16': [C.POINTER(WhmrGemm), _I, _P],
     'whmr_gemm_f32': [C.POINTER(WhmrGemm), _I, _P],
     'whmr_gemm_f32_set_big': [_I],
+    'whmr_gemm_tn_bf16': [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _P, _L, _P],
+    'whmr_conv_dw_tn_bf16': [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _L, _P],
     'whmr_gemm_bf16_big': [C.POINTER(WhmrGemm), _I, _P],
     'whmr_gemm_bf16_split': [C.POINTER(WhmrGemm), _I, _I, _P],
     'whmr_set_option': [_I, _I],
@@ -606,6 +608,43 @@ def avgpool_nhwc(x):
     _check(lib().whmr_avgpool_nhwc(x.data_ptr(), y.data_ptr(), B, H * W, Cc, int(x.dtype == torch.bfloat16), _stream()),
            'whmr_avgpool_nhwc')
     return y
+
+
+def gemm_tn_ok(a, b):
+    """shape / alignment envelope of whmr_gemm_tn_bf16 for a [K, Mo], b [K, No] (row strides free)"""
+    return (a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.dim() == 2 and b.dim() == 2 and a.shape[0] == b.shape[0]
+            and a.stride(1) == 1 and b.stride(1) == 1 and a.shape[0] % 32 == 0 and a.shape[1] % 128 == 0 and b.shape[1] % 256 == 0
+            and a.stride(0) % 8 == 0 and b.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0)
+
+
+def gemm_tn(a, b, out, splits=0):
+    """out [Mo, No] fp32 = a^T . b for reduction-major bf16 operands a [K, Mo], b [K, No] (weight gradients: dW = dY^T . X, no transposed copies)"""
+    _dev(a, b, out)
+    assert gemm_tn_ok(a, b) and out.dtype == torch.float32 and out.shape == (a.shape[1], b.shape[1]) and out.stride(1) == 1
+    ws = splitk_workspace(a.device)
+    _check(lib().whmr_gemm_tn_bf16(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0), a.shape[1], b.shape[1],
+                                   a.shape[0], int(splits), ws.data_ptr(), ws.numel(), _stream()), 'whmr_gemm_tn_bf16')
+    return out
+
+
+def conv_dw_tn_ok(a, img):
+    """envelope of whmr_conv_dw_tn_bf16 for a [K, Mo] (2-D, rows dense) and an NHWC image [B, IH, IW, C]"""
+    return (a.dtype == torch.bfloat16 and img.dtype == torch.bfloat16 and a.dim() == 2 and img.dim() == 4 and a.stride(1) == 1 and img.is_contiguous()
+            and a.shape[0] % 32 == 0 and a.shape[1] % 128 == 0 and img.shape[3] % 256 == 0 and a.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0
+            and img.data_ptr() % 16 == 0)
+
+
+def conv_dw_tn(a, img, out, OH, OW, KH, KW, S, P, splits=0):
+    """out [Mo, KH*KW*C] fp32 = a^T . col(img): convolution weight gradient without a column matrix (see include/whmr_hip.h).  a [B*OH*OW, Mo] bf16,
+    img [B, IH, IW, C] bf16 NHWC."""
+    _dev(a, img, out)
+    Bn, IH, IW, Cc = img.shape
+    assert conv_dw_tn_ok(a, img) and a.shape[0] == Bn * OH * OW and out.dtype == torch.float32 and out.shape == (a.shape[1], KH * KW * Cc) and out.stride(1) == 1
+    ws = splitk_workspace(a.device)
+    _check(lib().whmr_conv_dw_tn_bf16(a.data_ptr(), a.stride(0), img.data_ptr(), img.stride(2), out.data_ptr(), out.stride(0), a.shape[1], a.shape[0], Bn,
+                                      OH, OW, IH, IW, Cc, KH, KW, S, P, zero_page(a.device).data_ptr(), int(splits), ws.data_ptr(), ws.numel(), _stream()),
+           'whmr_conv_dw_tn_bf16')
+    return out
 
 
 def gemm_f32_set_big(on):

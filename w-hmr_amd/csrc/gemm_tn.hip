@@ -1,0 +1,257 @@
+// whmr_gemm_tn_bf16: C[Mo, No] (fp32) = A^T . B with BOTH operands stored reduction-major: A [K, lda >= Mo], B [K, ldb >= No] (bf16 rows of
+// one reduction index).  This is the shape of every weight gradient of the training step (autograd of nn.Linear / Conv2d / ConvTranspose2d:
+// vit.py:66-68,93,96,157; whmr.py:419-420,488-498 as run by loss.backward() in core/trainer.py:410-470):
+//     dW[n_out, k_in] = sum_m dY[m, n_out] . X[m, k_in]
+// with dY and X exactly as the forward / backward kernels leave them (token- or pixel-major) -- the NT kernels (gemm_bf16_big.hip) need both
+// operands K-contiguous, i.e. two transposed copies per product (4.4 ms of a 31 ms step went into whmr_transpose_* / whmr_im2col_t).
+//
+// Tile: BM (128 | 256) x 256 outputs, 32 reduction rows per step, 8 waves (2 x 4, wave tile BM/2 x 64 on v_mfma_f32_32x32x16_bf16).  A step's
+// operand rows go global -> LDS by LDS-DMA (global_load_lds, 16 B per lane, whole 512-B rows) into a 3-slot ring, two steps ahead, counted
+// vmcnt, one barrier per step.  The MFMA fragments need, per lane, 8 consecutive REDUCTION indices of one output row / column -- a column of the
+// LDS tile: ds_read_b64_tr_b16 delivers 4 of them per read (the 16 lanes of a group read a 4-row x 16-column block and get it transposed).
+// Fragment k-slot e of half-wave hi holds tile row R0 + 4 hi + (e & 3) + 8 (e >> 2) for BOTH operands, so the products pair up correctly.
+// Bank conflicts: the 4 rows one half-wave reads sit one row pitch (512 B = all 64 banks, twice) apart; the 16-B chunk index of row r is XORed
+// with 4 (r & 3), which spreads them over four distinct 64-B windows.  The swizzle is applied on the DMA's SOURCE side (LDS destinations of
+// a wave instruction are linear).
+//
+// Split-K over blockIdx.z (a weight gradient is a few dozen tiles deep in K = all tokens): partial tiles go to the fp32 workspace and
+// tn_reduce_kernel sums them in slice order (deterministic).
+#include "common.h"
+
+typedef __attribute__((address_space(3))) void tn_lds_void_t;
+typedef const __attribute__((address_space(1))) void tn_gbl_void_t;
+
+template <int N> __device__ __forceinline__ void tn_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// 8 reduction rows (R0 + 4 hi + {0..3, 8..11}) of column c0 + (lane & 31) of a swizzled [32][CH * 8] bf16 tile (CH 16-B chunks per row): two
+// transposing reads, ISSUED here and hidden from hipcc's waitcnt bookkeeping -- the caller waits once (lgkmcnt(0) + sched_barrier) for all
+// fragments of a K step before the MFMAs.
+struct tn_raw { uint2 x, y; };
+template <int CH>
+__device__ __forceinline__ void tn_frag_issue(tn_raw& f, uint32_t tile, int R0, int c0, int lane) {
+    const int g = lane >> 4, i = lane & 15;
+    const int col = c0 + 16 * (g & 1) + 4 * (i & 3);
+    const int row = R0 + 4 * (g >> 1) + (i >> 2);
+    const uint32_t a0 = tile + row * (CH * 16) + ((((col >> 3) ^ (4 * (row & 3)))) << 4) + (col & 7) * 2;
+    // second read: row + 8 -- same (row & 3), same swizzle
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3" : "=&v"(f.x), "=&v"(f.y) : "v"(a0), "n"(8 * CH * 16) : "memory");
+}
+__device__ __forceinline__ bf16x8_t tn_frag_value(const tn_raw& f) {
+    union { bf16x8_t v; uint32_t u[4]; } o;
+    o.u[0] = f.x.x; o.u[1] = f.x.y; o.u[2] = f.y.x; o.u[3] = f.y.y;
+    return o.v;
+}
+
+struct tn_params {
+    const bf16_t* A; const bf16_t* B; float* C;
+    long lda, ldb, ldc;
+    int Mo, No, K;
+    int k_per_split;          // reduction rows per blockIdx.z slice (multiple of 32)
+    float* ws;                // split-K partials [splits][Mo][No] (null: direct store)
+    // B gather (convolution weight gradients): reduction index k = (b, oy, ox) over an OH x OW grid, column n = (tap, c) with c < GC
+    // (GC % 256 == 0, so a 256-column tile lies inside ONE tap): B[k][n] = img[b, oy * S + ky - P, ox * S + kx - P, c] (NHWC, pixel stride
+    // ldb elements), zero outside the IH x IW image.  The rows of a tile then are 512 contiguous bytes of one source pixel -- or of `zeros`.
+    int gather, OH, OW, IH, IW, GC, KW, S, P;
+    const bf16_t* zeros;      // >= 512 B of zeros
+};
+
+template <int MI, bool GATHER>   // wave rows own MI 32-row blocks: BM = 64 MI
+__global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const tn_params p) {
+    constexpr int BM = 64 * MI, BN = 256, BK = 32;
+    constexpr int CHA = BM / 8, CHB = BN / 8;                 // 16-B chunks per tile row
+    constexpr int A_BYTES = BK * BM * 2, B_BYTES = BK * BN * 2, SLOT = A_BYTES + B_BYTES;
+    constexpr int UNITS = SLOT / 1024, UPW = UNITS / 8;       // 1-KiB DMA units per step, per wave (BM 256: 4, BM 128: 3)
+    static_assert(UNITS % 8 == 0, "every wave issues the same number of DMA units (counted vmcnt)");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int tiles_n = p.No / BN;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int k_begin = blockIdx.z * p.k_per_split;
+    const int k_end = min(p.K, k_begin + p.k_per_split);
+    const int nkt = (k_end - k_begin) / BK;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(tn_lds_void_t*)smem;
+
+    // DMA unit u = wave + 8 i: 1 KiB of the slot, linear.  A units first (A_BYTES / 1024), then B.  Inside an operand the unit covers
+    // 1024 / (row bytes) rows; lane L -> linear byte L * 16 of the unit -> (row, chunk position) -> source chunk = position ^ 4 (row & 3).
+    const bf16_t* usrc[UPW];
+    int urow[UPW], uchunk[UPW];
+#pragma unroll
+    for (int i = 0; i < UPW; ++i) {
+        const int u = wave + 8 * i;
+        const bool isA = u < A_BYTES / 1024;
+        const int off = (isA ? u : u - A_BYTES / 1024) * 1024 + lane * 16;       // byte offset inside the operand tile
+        const int rowb = isA ? BM * 2 : BN * 2;
+        const int row = off / rowb, pos = (off % rowb) >> 4;
+        const int chunk = pos ^ (4 * (row & 3));
+        urow[i] = row; uchunk[i] = chunk;
+        usrc[i] = isA ? p.A + (size_t)(k_begin + row) * p.lda + m0 + chunk * 8
+                      : p.B + (size_t)(k_begin + row) * p.ldb + n0 + chunk * 8;
+    }
+    const size_t stepA = (size_t)BK * p.lda, stepB = (size_t)BK * p.ldb;
+    // gather: this tile's tap and channel offset
+    const int g_tap = GATHER ? n0 / p.GC : 0, g_c0 = GATHER ? n0 - g_tap * p.GC : 0;
+    const int g_ky = GATHER ? g_tap / p.KW : 0, g_kx = GATHER ? g_tap - g_ky * p.KW : 0;
+    auto stage = [&](int kt) {
+        const int slot = kt % 3;
+#pragma unroll
+        for (int i = 0; i < UPW; ++i) {
+            const int u = wave + 8 * i;
+            const bool isA = u < A_BYTES / 1024;
+            const bf16_t* src;
+            if (GATHER && !isA) {
+                const int k = k_begin + kt * BK + urow[i];
+                const int ohw = p.OH * p.OW;
+                const int b = k / ohw, rem = k - b * ohw;
+                const int oy = rem / p.OW, ox = rem - oy * p.OW;
+                const int iy = oy * p.S + g_ky - p.P, ix = ox * p.S + g_kx - p.P;
+                const bool in = (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+                src = in ? p.B + ((size_t)(b * p.IH + iy) * p.IW + ix) * p.ldb + g_c0 + uchunk[i] * 8 : p.zeros + uchunk[i] * 8;
+            } else {
+                src = usrc[i] + (size_t)kt * (isA ? stepA : stepB);
+            }
+            __builtin_amdgcn_global_load_lds((tn_gbl_void_t*)src, (tn_lds_void_t*)(smem + slot * SLOT + u * 1024), 16, 0, 0);
+        }
+    };
+    f32x16_t acc[MI][2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (nkt > 0) stage(0);
+    if (nkt > 1) stage(1);
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) tn_wait_vmcnt<UPW>(); else tn_wait_vmcnt<0>();       // own share of step kt has landed (step kt + 1 may fly)
+        __builtin_amdgcn_s_barrier();                                          // everyone's share landed; everyone is done with slot (kt - 1) % 3
+        if (kt + 2 < nkt) stage(kt + 2);
+        const uint32_t ta = lds0 + (kt % 3) * SLOT, tb = ta + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            tn_raw rb[2], ra[MI];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) tn_frag_issue<CHB>(rb[j], tb, ks * 16, wn * 64 + j * 32, lane);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) tn_frag_issue<CHA>(ra[i], ta, ks * 16, wm * (32 * MI) + i * 32, lane);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            bf16x8_t fb[2], fa[MI];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = tn_frag_value(rb[j]);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) fa[i] = tn_frag_value(ra[i]);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // D[row = (r & 3) + 8 (r >> 2) + 4 hi][col = l31]: for a fixed r the 32 lanes of a half-wave write 128 contiguous bytes
+    float* out = p.ws ? p.ws + (size_t)blockIdx.z * p.Mo * p.No : p.C;
+    const long ldo = p.ws ? p.No : p.ldc;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * (32 * MI) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                out[(size_t)m * ldo + n] = acc[i][j][r];
+            }
+        }
+}
+
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ ws, int splits, int Mo, int No, float* __restrict__ C, long ldc) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int n4 = No >> 2;
+    if (idx >= (long)Mo * n4) return;
+    const int m = (int)(idx / n4), n = (int)(idx - (long)m * n4) * 4;
+    const size_t stride = (size_t)Mo * No;
+    const float* w = ws + (size_t)m * No + n;
+    float4 a = *(const float4*)w;
+    for (int s = 1; s < splits; ++s) {
+        const float4 b = *(const float4*)(w + s * stride);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    *(float4*)(C + (size_t)m * ldc + n) = a;
+}
+
+template <int MI, bool GATHER>
+static int launch_tn(const tn_params& p, int tiles, int splits, hipStream_t st) {
+    constexpr int LDS = 3 * (32 * 64 * MI * 2 + 32 * 256 * 2);
+    auto kern = gemm_tn_kernel<MI, GATHER>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles, 1, splits), dim3(512), LDS, st, p);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+static int tn_run(tn_params p, int splits, void* workspace, long workspace_bytes, hipStream_t st) {
+    const int MI = (p.Mo % 256 == 0) ? 4 : 2;
+    const int tiles = (p.Mo / (64 * MI)) * (p.No / 256);
+    const int steps = p.K / 32;
+    if (splits <= 0) {
+        splits = tiles >= 192 ? 1 : (256 + tiles / 2) / tiles;          // ~one tile per CU
+        if (splits > steps / 8) splits = steps / 8 > 0 ? steps / 8 : 1;  // at least 8 steps per slice
+    }
+    if (splits > steps) splits = steps;
+    while (splits > 1 && (!workspace || (long)splits * p.Mo * p.No * 4 > workspace_bytes)) --splits;
+    const int sps = (steps + splits - 1) / splits;                       // steps per slice
+    splits = (steps + sps - 1) / sps;
+    p.k_per_split = sps * 32;
+    p.ws = splits > 1 ? (float*)workspace : nullptr;
+    int rc;
+    if (p.gather) rc = MI == 4 ? launch_tn<4, true>(p, tiles, splits, st) : launch_tn<2, true>(p, tiles, splits, st);
+    else rc = MI == 4 ? launch_tn<4, false>(p, tiles, splits, st) : launch_tn<2, false>(p, tiles, splits, st);
+    if (rc) return rc;
+    if (splits > 1) {
+        hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)(((long)p.Mo * (p.No >> 2) + 255) / 256)), dim3(256), 0, st, (const float*)workspace, splits,
+                           p.Mo, p.No, p.C, p.ldc);
+        WHMR_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+// A [K, lda], B [K, ldb] bf16 (16-B aligned rows: lda, ldb multiples of 8), C [Mo, ldc] fp32.  Mo % 128 == 0, No % 256 == 0, K % 32 == 0.
+// workspace (fp32, workspace_bytes) holds the split-K partials; splits = 0 picks the slice count (about one tile per CU), splits = 1 needs
+// no workspace.  Returns hipErrorInvalidValue for shapes outside the envelope (the caller keeps the transposed-copy path for those).
+extern "C" int whmr_gemm_tn_bf16(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int Mo, int No, int K, int splits,
+                                 void* workspace, long workspace_bytes, void* stream) {
+    if (Mo <= 0 || No <= 0 || K <= 0 || (Mo % 128) || (No % 256) || (K % 32) || (lda % 8) || (ldb % 8) || (ldc % 4) ||
+        ((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)C & 15) || lda < Mo || ldb < No || ldc < No)
+        return (int)hipErrorInvalidValue;
+    tn_params p{};
+    p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.Mo = Mo; p.No = No; p.K = K;
+    return tn_run(p, splits, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// Convolution weight gradient without a column matrix: C [Mo, KH*KW*GC] = A^T . col(img), A [K = B*OH*OW, lda] bf16 (dY or X, one row per
+// position of the OH x OW grid), img [B, IH, IW, (pixel stride ldp)] bf16 NHWC; column (tap = ky*KW + kx, c) of reduction row (b, oy, ox) is
+// img[b, oy*S + ky - P, ox*S + kx - P, c] or 0 outside the image.  Covers the autograd of Conv2d (A = dY over the OUTPUT grid, img = X:
+// dW[co, (ky,kx,ci)], whmr.py:419-420, iuv_predictor.py) and of ConvTranspose2d(k4, s2, p1) (A = X over the INPUT grid, img = dZ, S = 2, P = 1:
+// dW[ci, (ky,kx,co)], whmr.py:488-498).  GC % 256 == 0, Mo % 128 == 0, K % 32 == 0; zeros: >= 512 B of zeros on the device.
+extern "C" int whmr_conv_dw_tn_bf16(const void* A, long lda, const void* img, long ldp, float* C, long ldc, int Mo, int K, int nB, int OH, int OW,
+                                    int IH, int IW, int GC, int KH, int KW, int S, int P, const void* zeros, int splits, void* workspace,
+                                    long workspace_bytes, void* stream) {
+    const long No = (long)KH * KW * GC;
+    if (Mo <= 0 || K <= 0 || (Mo % 128) || (GC % 256) || GC <= 0 || (K % 32) || (lda % 8) || (ldp % 8) || (ldc % 4) || ((uintptr_t)A & 15) ||
+        ((uintptr_t)img & 15) || ((uintptr_t)C & 15) || ((uintptr_t)zeros & 15) || !zeros || lda < Mo || ldp < GC || ldc < No ||
+        (long)nB * OH * OW != K || No > (1L << 30))
+        return (int)hipErrorInvalidValue;
+    tn_params p{};
+    p.A = (const bf16_t*)A; p.B = (const bf16_t*)img; p.C = C; p.lda = lda; p.ldb = ldp; p.ldc = ldc; p.Mo = Mo; p.No = (int)No; p.K = K;
+    p.gather = 1; p.OH = OH; p.OW = OW; p.IH = IH; p.IW = IW; p.GC = GC; p.KW = KW; p.S = S; p.P = P; p.zeros = (const bf16_t*)zeros;
+    return tn_run(p, splits, workspace, workspace_bytes, (hipStream_t)stream);
+}

@@ -89,6 +89,9 @@ class _Cache:
         return ent[1]
 
 
+_CAM_STREAMS = {}
+
+
 class Regressor(nn.Module):
     """whmr.py:42-269.  fc1 -> fc2 (no nonlinearity) -> decpose/decshape/deccam residual heads -> SMPL -> projections."""
 
@@ -329,7 +332,6 @@ class WHMR(nn.Module):
         self._cache = _Cache()
         self._init_cache = None
         self.overlap_camera = True          # cam_model on a side stream beside the backbone (joined before the global-orientation head)
-        self._cam_streams = {}
         self.eval()
 
     def _make_deconv_layer(self, num_layers, num_filters, num_kernels):
@@ -449,10 +451,11 @@ class WHMR(nn.Module):
             self._init_cache = (key, reg.forward_init(x1, with_aux=with_aux))
         return expand(self._init_cache[1])
 
-    def _camera_stream(self, dev):
-        st = self._cam_streams.get(dev)
+    @staticmethod
+    def _camera_stream(dev):
+        st = _CAM_STREAMS.get(dev)                 # module-level: a Stream inside the module would break copy.deepcopy(model) / pickling
         if st is None:
-            st = self._cam_streams[dev] = torch.cuda.Stream(device=dev)
+            st = _CAM_STREAMS[dev] = torch.cuda.Stream(device=dev)
         return st
 
     @torch.no_grad()

@@ -14,7 +14,11 @@ autograd as driven by ``core/trainer.py:410-470``.  Maps are channels-last (NHWC
 """
 import torch
 
+import os
+
 from .. import _lib as L
+
+USE_TN = os.environ.get('WHMR_TN_GEMM', '1') != '0'      # weight gradients on the gathering TN kernel (A/B switch)
 
 
 def _phase_weights(w, dt):
@@ -75,12 +79,17 @@ def deconv_backward(saved, weight, dy, dt, need_dx=True, dx_dtype=None):
     M = B * H * W
     # dW[ci, (ky,kx,co)] = sum_m x[m, ci] * dz[b, 2iy-1+ky, 2ix-1+kx, co]
     pad = 64 if dt == torch.bfloat16 else 8          # the bf16 GEMM needs K % 64 == 0; rows are zero-padded up to it
-    xt = L.transpose_cast(x.view(M, Cin), dt, pad_to=pad)                                  # [Cin, Mpad]
-    colt = L.im2col_t(dz, H, W, 4, 4, 2, 1, pad_to=pad)                                    # [16*Cout, Mpad]
     dwm = torch.empty(Cin, 16 * Cout, dtype=torch.float32, device=dev)
-    L.gemm(xt, colt, dwm)
+    x2 = x.view(M, Cin)
+    if USE_TN and L.conv_dw_tn_ok(x2, dz):
+        # the gathering TN kernel reads X and dZ as they are (no transposed X, no 16-tap transposed column matrix of dZ: 1.6 GB at stage 3)
+        L.conv_dw_tn(x2, dz, dwm, H, W, 4, 4, 2, 1)
+    else:
+        xt = L.transpose_cast(x2, dt, pad_to=pad)                                          # [Cin, Mpad]
+        colt = L.im2col_t(dz, H, W, 4, 4, 2, 1, pad_to=pad)                                # [16*Cout, Mpad]
+        L.gemm(xt, colt, dwm)
+        del colt, xt
     dW = dwm.view(Cin, 4, 4, Cout).permute(0, 3, 1, 2)
-    del colt, xt
     dx = None
     if need_dx:
         wd = weight.detach().float().permute(0, 2, 3, 1).reshape(Cin, 16 * Cout).contiguous()       # [ci, (ky,kx,co)]

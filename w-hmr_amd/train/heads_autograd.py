@@ -10,7 +10,11 @@
 """
 import torch
 
+import os
+
 from .. import _lib as L
+
+USE_TN = os.environ.get('WHMR_TN_GEMM', '1') != '0'      # weight gradients on the (gathering) TN kernel (A/B switch)
 
 
 def _f32(t):
@@ -160,7 +164,19 @@ class ConvNHWCFn(torch.autograd.Function):
         pad = 64 if dt == torch.bfloat16 else 8
         dx = dw = db = None
         same = S == 1 and OH == IH and OW == IW
-        if ctx.needs_input_grad[1] and same and npad % 64 == 0 and npad < Cin:
+        if ctx.needs_input_grad[1] and USE_TN and dt == torch.bfloat16 and Cin % 256 == 0 and M % 32 == 0 and x.is_contiguous():
+            # gathering TN kernel: dW[co, (ky, kx, ci)] = sum_m dY[m, co] . X[pixel(m) + tap, ci] from dY and X as they are -- no transposed
+            # dY, no (transposed) column matrix of X.  dY is widened to a multiple of 128 columns (the kernel's row-tile height).
+            na = (npad + 127) // 128 * 128
+            if na != npad:
+                dya = torch.zeros(M, na, dtype=dt, device=dev)
+                dya[:, :npad] = dyp
+            else:
+                dya = dyp
+            dwm = torch.empty(na, K, dtype=torch.float32, device=dev)
+            L.conv_dw_tn(dya, x, dwm, OH, OW, KH, KW, S, P)
+            dw = dwm[:Cout].view(Cout, KH, KW, Cin).permute(0, 3, 1, 2)
+        elif ctx.needs_input_grad[1] and same and npad % 64 == 0 and npad < Cin:
             # stride-1 'same' convolution with fewer output than input channels (IUV head: 128 padded vs 256): gather the SMALLER operand.
             # dW[co, ci, ky, kx] = sum_m' dY[m' - shift(ky, kx), co] . X[m', ci]: the transposed column matrix is built from dY with the
             # flipped taps (KH*KW*npad rows instead of KH*KW*Cin) and X is transposed once.

@@ -122,10 +122,12 @@ def _attention_bwd(qkv, d_att, B, N, H, dh, scale, dt):
     return dq if dt == torch.float32 else L.cast_bf16(dq)
 
 
-# weight-gradient branch of the ViT backward on a side stream (A/B switch).  Measured: backbone-only training step (224^2, batch 64) 15.25 -> 14.23 ms;
-# neutral inside the full W-HMR step (256x192: 31.2 ms either way, eager and graph-replayed); the same treatment of the deconv / conv nodes'
-# dW branches (transposed im2col beside the data-gradient GEMM) measured neutral to -3 % and is not in the tree.
-OVERLAP_DW = os.environ.get('WHMR_OVERLAP_DW', '1') != '0'
+# weight-gradient branch of the ViT backward on a side stream (A/B switch, OFF by default).  With the transposed-copy dW path it hid the
+# memory-bound transposes beside the dX GEMMs (backbone-only step, 224^2, batch 64: 15.25 -> 14.23 ms); the TN kernel removes those
+# transposes altogether (15.16 -> 14.15 ms in line) and then the second stream buys nothing (14.08) -- and inside the full W-HMR step it costs
+# 0.3-0.6 ms (256x192, eager and graph-replayed).  The same treatment of the deconv / conv nodes measured neutral to -3 % and is not in the tree.
+OVERLAP_DW = os.environ.get('WHMR_OVERLAP_DW', '0') != '0'
+USE_TN = os.environ.get('WHMR_TN_GEMM', '1') != '0'          # weight gradients on whmr_gemm_tn_bf16 (A/B switch; fp32 mode and odd shapes keep the transposed-copy path)
 _side_streams = {}
 
 
@@ -164,6 +166,18 @@ def vit_backward(m, s, dout):
     def dw_branch(dy_op, x_saved, lin):
         w = lin.weight
         n_out, k_in = dy_op.shape[1], x_saved.shape[1]
+        if USE_TN and L.gemm_tn_ok(dy_op, x_saved):
+            # dW = dY^T . X straight from the token-major operands (gemm_tn.hip: transposing LDS reads) -- no transposed copies
+            if lin.bias is not None:
+                db = torch.empty(n_out, **f32)
+                L.colsum(dy_op, db)
+                grads[lin.bias] = db
+                side_made.append(db)
+            dw = torch.empty(n_out, k_in, **f32)
+            L.gemm_tn(dy_op, x_saved, dw)
+            grads[w] = dw.view_as(w)
+            side_made.append(dw)
+            return
         if lin.bias is not None:                                                       # db from the same pass that transposes dY
             db = torch.empty(n_out, **f32)
             dyt = L.transpose_colsum(dy_op, db, pad_to=mpad)                           # [Nout, Mpad]
