@@ -107,8 +107,9 @@ int whmr_gemm_f32_set_big(int on);
  * bf16 -- dW[n_out, k_in] = sum_m dY[m, n_out] . X[m, k_in] straight from the token- / pixel-major tensors the forward and backward kernels
  * leave (autograd of nn.Linear at vit.py:66-68,93,96,157 as run by core/trainer.py:410-470); no transposed operand copies.  Mo % 128 == 0,
  * No % 256 == 0, K % 32 == 0, 16-B aligned rows; splits = 0 lets the launcher slice K (deterministic fixed-order reduction through `workspace`,
- * fp32, >= splits * Mo * No * 4 bytes), splits = 1 needs no workspace.  hipErrorInvalidValue outside that envelope. */
-int whmr_gemm_tn_bf16(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int Mo, int No, int K, int splits,
+ * fp32, >= splits * Mo * (No + 1) * 4 bytes), splits = 1 needs no workspace.  db (nullable) [Mo] receives the column sums of A in the same pass:
+ * the bias gradient when A is dY.  hipErrorInvalidValue outside that envelope. */
+int whmr_gemm_tn_bf16(const void* A, long lda, const void* B, long ldb, float* C, long ldc, float* db, int Mo, int No, int K, int splits,
                       void* workspace, long workspace_bytes, void* stream);
 
 /* Convolution weight gradient without a column matrix (same kernel, the B operand gathered): C [Mo, KH*KW*GC] (fp32) = A^T . col(img) with
@@ -116,10 +117,11 @@ int whmr_gemm_tn_bf16(const void* A, long lda, const void* B, long ldb, float* C
  * reduction row (b, oy, ox) is img[b, oy*S + ky - P, ox*S + kx - P, c], zero outside the image.  Autograd of Conv2d (A = dY over the output
  * grid, img = X -> dW[co, (ky,kx,ci)]: whmr.py:419-420, models/iuv_predictor.py:71-91) and of ConvTranspose2d(k4, s2, p1) (A = X over the input
  * grid, img = dZ, S = 2, P = 1 -> dW[ci, (ky,kx,co)]: whmr.py:488-498) as core/trainer.py:410-470 runs them; replaces whmr_im2col_t + the operand
- * transposes + the NT GEMM.  Mo % 128 == 0, GC % 256 == 0, K % 32 == 0; zeros: >= 512 B of device zeros. */
+ * transposes + the NT GEMM.  Mo % 128 == 0, GC % 256 == 0, K % 32 == 0; zeros: >= 512 B of device zeros; db (nullable) [Mo] = column sums of A
+ * (the convolution's bias gradient when A is dY). */
 int whmr_conv_dw_tn_bf16(const void* A, long lda, const void* img, long ldp, float* C, long ldc, int Mo, int K, int nB, int OH, int OW,
                          int IH, int IW, int GC, int KH, int KW, int S, int P, const void* zeros, int splits, void* workspace,
-                         long workspace_bytes, void* stream);
+                         long workspace_bytes, float* db, void* stream);
 
 /* LayerNorm over the last dim (C % 4 == 0, C <= 2048), fp32 in, fp32 or bf16 out.  vit.py:125,133,212,242. */
 int whmr_layernorm(const float* x, const float* gamma, const float* beta, void* y, int rows, int C, float eps,

@@ -159,9 +159,11 @@ def test_gemm_tn(dev, K, Mo, No, splits):
     ad, bd = a.to(dev)[:, 32:32 + Mo], b.to(dev)                          # a: a 64-B-offset column slice (row stride Mo + 64)
     assert L.gemm_tn_ok(ad, bd)
     out = torch.full((Mo, No), float('nan'), device=dev)
-    L.gemm_tn(ad, bd, out, splits=splits)
+    db = torch.full((Mo,), float('nan'), device=dev)
+    L.gemm_tn(ad, bd, out, splits=splits, db=db)
     ref = (a[:, 32:32 + Mo].double().t() @ b.double()).float()
     assert _rel(out.cpu(), ref) < 2e-5
+    assert _rel(db.cpu(), a[:, 32:32 + Mo].double().sum(0).float()) < 2e-5             # column sums of A in the same pass (bias gradient)
     out2 = torch.empty_like(out)
     L.gemm_tn(ad, bd, out2, splits=splits)
     assert torch.equal(out, out2)
@@ -186,9 +188,11 @@ def test_conv_dw_tn(dev):
         img = x.permute(0, 2, 3, 1).bfloat16().contiguous().to(dev)
         assert L.conv_dw_tn_ok(a, img)
         out = torch.empty(Cout, KH * KH * Cin, device=dev)
-        L.conv_dw_tn(a, img, out, OH, OW, KH, KH, S, P, splits=splits)
+        db = torch.empty(Cout, device=dev)
+        L.conv_dw_tn(a, img, out, OH, OW, KH, KH, S, P, splits=splits, db=db)
         got = out.view(Cout, KH, KH, Cin).permute(0, 3, 1, 2).cpu()
         assert _rel(got, w.grad) < 2e-5, (KH, S, P)
+        assert _rel(db.cpu(), dy.sum((0, 2, 3))) < 2e-5
     # ConvTranspose2d(k4, s2, p1): dW[ci, co, ky, kx] = sum x[b, iy, ix, ci] dz[b, 2 iy - 1 + ky, 2 ix - 1 + kx, co]
     B, Cin, H, W, Cout = 2, 256, 8, 6, 256
     x = (torch.randn(B, Cin, H, W, generator=g) * 0.5).bfloat16().float()

@@ -62,8 +62,8 @@ _SIGS = {
     'whmr_gemm_bf16': [C.POINTER(WhmrGemm), _I, _P],
     'whmr_gemm_f32': [C.POINTER(WhmrGemm), _I, _P],
     'whmr_gemm_f32_set_big': [_I],
-    'whmr_gemm_tn_bf16': [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _P, _L, _P],
-    'whmr_conv_dw_tn_bf16': [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _L, _P],
+    'whmr_gemm_tn_bf16': [_P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _I, _P, _L, _P],
+    'whmr_conv_dw_tn_bf16': [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _L, _P, _P],
     'whmr_gemm_bf16_big': [C.POINTER(WhmrGemm), _I, _P],
     'whmr_gemm_bf16_split': [C.POINTER(WhmrGemm), _I, _I, _P],
     'whmr_set_option': [_I, _I],
@@ -617,12 +617,13 @@ def gemm_tn_ok(a, b):
             and a.stride(0) % 8 == 0 and b.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0)
 
 
-def gemm_tn(a, b, out, splits=0):
+def gemm_tn(a, b, out, splits=0, db=None):
     """out [Mo, No] fp32 = a^T . b for reduction-major bf16 operands a [K, Mo], b [K, No] (weight gradients: dW = dY^T . X, no transposed copies)"""
     _dev(a, b, out)
     assert gemm_tn_ok(a, b) and out.dtype == torch.float32 and out.shape == (a.shape[1], b.shape[1]) and out.stride(1) == 1
     ws = splitk_workspace(a.device)
-    _check(lib().whmr_gemm_tn_bf16(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0), a.shape[1], b.shape[1],
+    assert db is None or (db.dtype == torch.float32 and db.is_contiguous() and db.numel() == a.shape[1])
+    _check(lib().whmr_gemm_tn_bf16(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0), _ptr(db), a.shape[1], b.shape[1],
                                    a.shape[0], int(splits), ws.data_ptr(), ws.numel(), _stream()), 'whmr_gemm_tn_bf16')
     return out
 
@@ -634,7 +635,7 @@ def conv_dw_tn_ok(a, img):
             and img.data_ptr() % 16 == 0)
 
 
-def conv_dw_tn(a, img, out, OH, OW, KH, KW, S, P, splits=0):
+def conv_dw_tn(a, img, out, OH, OW, KH, KW, S, P, splits=0, db=None):
     """out [Mo, KH*KW*C] fp32 = a^T . col(img): convolution weight gradient without a column matrix (see include/whmr_hip.h).  a [B*OH*OW, Mo] bf16,
     img [B, IH, IW, C] bf16 NHWC."""
     _dev(a, img, out)
@@ -642,7 +643,7 @@ def conv_dw_tn(a, img, out, OH, OW, KH, KW, S, P, splits=0):
     assert conv_dw_tn_ok(a, img) and a.shape[0] == Bn * OH * OW and out.dtype == torch.float32 and out.shape == (a.shape[1], KH * KW * Cc) and out.stride(1) == 1
     ws = splitk_workspace(a.device)
     _check(lib().whmr_conv_dw_tn_bf16(a.data_ptr(), a.stride(0), img.data_ptr(), img.stride(2), out.data_ptr(), out.stride(0), a.shape[1], a.shape[0], Bn,
-                                      OH, OW, IH, IW, Cc, KH, KW, S, P, zero_page(a.device).data_ptr(), int(splits), ws.data_ptr(), ws.numel(), _stream()),
+                                      OH, OW, IH, IW, Cc, KH, KW, S, P, zero_page(a.device).data_ptr(), int(splits), ws.data_ptr(), ws.numel(), _ptr(db), _stream()),
            'whmr_conv_dw_tn_bf16')
     return out
 

@@ -47,7 +47,8 @@ struct tn_params {
     long lda, ldb, ldc;
     int Mo, No, K;
     int k_per_split;          // reduction rows per blockIdx.z slice (multiple of 32)
-    float* ws;                // split-K partials [splits][Mo][No] (null: direct store)
+    float* ws;                // split-K partials [splits][Mo][No] (null: direct store), then the column-sum partials [splits][Mo]
+    float* db;                // optional [Mo]: db[m] = sum_k A[k][m] (bias gradient of the same Linear: column sums of dY), or null
     // B gather (convolution weight gradients): reduction index k = (b, oy, ox) over an OH x OW grid, column n = (tap, c) with c < GC
     // (GC % 256 == 0, so a 256-column tile lies inside ONE tap): B[k][n] = img[b, oy * S + ky - P, ox * S + kx - P, c] (NHWC, pixel stride
     // ldb elements), zero outside the IH x IW image.  The rows of a tile then are 512 contiguous bytes of one source pixel -- or of `zeros`.
@@ -124,6 +125,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const tn_params p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // bias gradient rides along: the waves of the first column tile that own wave column 0 add up their A fragments (8 reduction rows of one
+    // output row per lane and fragment) on the VALU, beside the matrix pipe
+    const bool do_db = p.db != nullptr && tn == 0 && wn == 0;
+    float dbs[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) dbs[i] = 0.f;
+
     if (nkt > 0) stage(0);
     if (nkt > 1) stage(1);
     for (int kt = 0; kt < nkt; ++kt) {
@@ -150,6 +158,24 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const tn_params p) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            if (do_db) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const uint32_t w[4] = {ra[i].x.x, ra[i].x.y, ra[i].y.x, ra[i].y.y};
+                    float t = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t += __uint_as_float(w[e] << 16) + __uint_as_float(w[e] & 0xffff0000u);
+                    dbs[i] += t;
+                }
+            }
+        }
+    }
+    if (do_db) {
+        float* dbo = p.ws ? p.ws + (size_t)gridDim.z * p.Mo * p.No + (size_t)blockIdx.z * p.Mo : p.db;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const float v = dbs[i] + __shfl_xor(dbs[i], 32, 64);
+            if (hi == 0) dbo[m0 + wm * (32 * MI) + i * 32 + l31] = v;
         }
     }
     // D[row = (r & 3) + 8 (r >> 2) + 4 hi][col = l31]: for a fixed r the 32 lanes of a half-wave write 128 contiguous bytes
@@ -168,9 +194,16 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const tn_params p) {
         }
 }
 
-__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ ws, int splits, int Mo, int No, float* __restrict__ C, long ldc) {
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ ws, int splits, int Mo, int No, float* __restrict__ C, long ldc,
+                                                        float* __restrict__ db) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     const int n4 = No >> 2;
+    if (db && idx < Mo) {                                   // column-sum partials sit behind the tile partials
+        const float* wd = ws + (size_t)splits * Mo * No + idx;
+        float a = wd[0];
+        for (int s = 1; s < splits; ++s) a += wd[(size_t)s * Mo];
+        db[idx] = a;
+    }
     if (idx >= (long)Mo * n4) return;
     const int m = (int)(idx / n4), n = (int)(idx - (long)m * n4) * 4;
     const size_t stride = (size_t)Mo * No;
@@ -207,7 +240,7 @@ static int tn_run(tn_params p, int splits, void* workspace, long workspace_bytes
         if (splits > steps / 8) splits = steps / 8 > 0 ? steps / 8 : 1;  // at least 8 steps per slice
     }
     if (splits > steps) splits = steps;
-    while (splits > 1 && (!workspace || (long)splits * p.Mo * p.No * 4 > workspace_bytes)) --splits;
+    while (splits > 1 && (!workspace || (long)splits * p.Mo * (p.No + 1) * 4 > workspace_bytes)) --splits;
     const int sps = (steps + splits - 1) / splits;                       // steps per slice
     splits = (steps + sps - 1) / sps;
     p.k_per_split = sps * 32;
@@ -218,22 +251,23 @@ static int tn_run(tn_params p, int splits, void* workspace, long workspace_bytes
     if (rc) return rc;
     if (splits > 1) {
         hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)(((long)p.Mo * (p.No >> 2) + 255) / 256)), dim3(256), 0, st, (const float*)workspace, splits,
-                           p.Mo, p.No, p.C, p.ldc);
+                           p.Mo, p.No, p.C, p.ldc, p.db);
         WHMR_CHECK_LAUNCH();
     }
     return 0;
 }
 
 // A [K, lda], B [K, ldb] bf16 (16-B aligned rows: lda, ldb multiples of 8), C [Mo, ldc] fp32.  Mo % 128 == 0, No % 256 == 0, K % 32 == 0.
+// db (nullable) [Mo] fp32 = column sums of A = the bias gradient when A is dY.
 // workspace (fp32, workspace_bytes) holds the split-K partials; splits = 0 picks the slice count (about one tile per CU), splits = 1 needs
 // no workspace.  Returns hipErrorInvalidValue for shapes outside the envelope (the caller keeps the transposed-copy path for those).
-extern "C" int whmr_gemm_tn_bf16(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int Mo, int No, int K, int splits,
+extern "C" int whmr_gemm_tn_bf16(const void* A, long lda, const void* B, long ldb, float* C, long ldc, float* db, int Mo, int No, int K, int splits,
                                  void* workspace, long workspace_bytes, void* stream) {
     if (Mo <= 0 || No <= 0 || K <= 0 || (Mo % 128) || (No % 256) || (K % 32) || (lda % 8) || (ldb % 8) || (ldc % 4) ||
         ((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)C & 15) || lda < Mo || ldb < No || ldc < No)
         return (int)hipErrorInvalidValue;
     tn_params p{};
-    p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.Mo = Mo; p.No = No; p.K = K;
+    p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.Mo = Mo; p.No = No; p.K = K; p.db = db;
     return tn_run(p, splits, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
@@ -244,7 +278,7 @@ extern "C" int whmr_gemm_tn_bf16(const void* A, long lda, const void* B, long ld
 // dW[ci, (ky,kx,co)], whmr.py:488-498).  GC % 256 == 0, Mo % 128 == 0, K % 32 == 0; zeros: >= 512 B of zeros on the device.
 extern "C" int whmr_conv_dw_tn_bf16(const void* A, long lda, const void* img, long ldp, float* C, long ldc, int Mo, int K, int nB, int OH, int OW,
                                     int IH, int IW, int GC, int KH, int KW, int S, int P, const void* zeros, int splits, void* workspace,
-                                    long workspace_bytes, void* stream) {
+                                    long workspace_bytes, float* db, void* stream) {
     const long No = (long)KH * KW * GC;
     if (Mo <= 0 || K <= 0 || (Mo % 128) || (GC % 256) || GC <= 0 || (K % 32) || (lda % 8) || (ldp % 8) || (ldc % 4) || ((uintptr_t)A & 15) ||
         ((uintptr_t)img & 15) || ((uintptr_t)C & 15) || ((uintptr_t)zeros & 15) || !zeros || lda < Mo || ldp < GC || ldc < No ||
@@ -252,6 +286,6 @@ extern "C" int whmr_conv_dw_tn_bf16(const void* A, long lda, const void* img, lo
         return (int)hipErrorInvalidValue;
     tn_params p{};
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)img; p.C = C; p.lda = lda; p.ldb = ldp; p.ldc = ldc; p.Mo = Mo; p.No = (int)No; p.K = K;
-    p.gather = 1; p.OH = OH; p.OW = OW; p.IH = IH; p.IW = IW; p.GC = GC; p.KW = KW; p.S = S; p.P = P; p.zeros = (const bf16_t*)zeros;
+    p.db = db; p.gather = 1; p.OH = OH; p.OW = OW; p.IH = IH; p.IW = IW; p.GC = GC; p.KW = KW; p.S = S; p.P = P; p.zeros = (const bf16_t*)zeros;
     return tn_run(p, splits, workspace, workspace_bytes, (hipStream_t)stream);
 }

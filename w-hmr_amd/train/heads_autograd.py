@@ -174,8 +174,11 @@ class ConvNHWCFn(torch.autograd.Function):
             else:
                 dya = dyp
             dwm = torch.empty(na, K, dtype=torch.float32, device=dev)
-            L.conv_dw_tn(dya, x, dwm, OH, OW, KH, KW, S, P)
+            dba = torch.empty(na, dtype=torch.float32, device=dev) if (ctx.has_bias and ctx.needs_input_grad[5]) else None
+            L.conv_dw_tn(dya, x, dwm, OH, OW, KH, KW, S, P, db=dba)                    # bias gradient = column sums of dY, same pass
             dw = dwm[:Cout].view(Cout, KH, KW, Cin).permute(0, 3, 1, 2)
+            if dba is not None:
+                db = dba[:Cout]
         elif ctx.needs_input_grad[1] and same and npad % 64 == 0 and npad < Cin:
             # stride-1 'same' convolution with fewer output than input channels (IUV head: 128 padded vs 256): gather the SMALLER operand.
             # dW[co, ci, ky, kx] = sum_m' dY[m' - shift(ky, kx), co] . X[m', ci]: the transposed column matrix is built from dY with the
@@ -193,7 +196,7 @@ class ConvNHWCFn(torch.autograd.Function):
             L.gemm(dyt, colt, dwm)
             dw = dwm[:Cout].view(Cout, KH, KW, Cin).permute(0, 3, 1, 2)
             del colt, dyt
-        if ctx.has_bias and ctx.needs_input_grad[5]:
+        if db is None and ctx.has_bias and ctx.needs_input_grad[5]:
             dbp = torch.empty(npad, dtype=torch.float32, device=dev)
             L.colsum(dyp, dbp)
             db = dbp[:Cout]

@@ -168,13 +168,13 @@ def vit_backward(m, s, dout):
         n_out, k_in = dy_op.shape[1], x_saved.shape[1]
         if USE_TN and L.gemm_tn_ok(dy_op, x_saved):
             # dW = dY^T . X straight from the token-major operands (gemm_tn.hip: transposing LDS reads) -- no transposed copies
-            if lin.bias is not None:
+            db = None
+            if lin.bias is not None:                                                   # column sums of dY ride along in the same kernel
                 db = torch.empty(n_out, **f32)
-                L.colsum(dy_op, db)
                 grads[lin.bias] = db
                 side_made.append(db)
             dw = torch.empty(n_out, k_in, **f32)
-            L.gemm_tn(dy_op, x_saved, dw)
+            L.gemm_tn(dy_op, x_saved, dw, db=db)
             grads[w] = dw.view_as(w)
             side_made.append(dw)
             return
