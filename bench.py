@@ -500,7 +500,7 @@ def main(argv=None):
             res['efficiency_vs_1gpu'] = value / (n_ranks * args.ref_1gpu)
         if not dry:
             res['model_tflops'] = VIT_FLOP_PER_IMG[args.workload] * n_ranks * args.batch * args.steps / dt / 1e12
-            res['roofline'] = {'bound': 'mfma', 'kernel': 'bf16 MFMA GEMM launches of one step (%d: gemm_blk_kernel on the blocked ViT path, gemm_bf16_big_kernel elsewhere)' % len(gemm),
+            res['roofline'] = {'bound': 'mfma', 'kernel': 'bf16 MFMA GEMM launches of one step (%d: gemm_blk_kernel on the blocked ViT path, gemm_tn_kernel for the weight gradients, gemm_bf16_big_kernel elsewhere)' % len(gemm),
                                'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
                                'flops_per_launch': flops_per_launch, 'avg_launch_us': avg_s * 1e6,
                                'traffic': traffic['bytes_per_launch'] if traffic else None,

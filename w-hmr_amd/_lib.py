@@ -610,6 +610,21 @@ def avgpool_nhwc(x):
     return y
 
 
+def _profile_begin():
+    if PROFILE is None:
+        return None
+    e0 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    return e0
+
+
+def _profile_end(e0, name, work):
+    if e0 is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        PROFILE.append((name, work, e0, e1))
+
+
 def gemm_tn_ok(a, b):
     """shape / alignment envelope of whmr_gemm_tn_bf16 for a [K, Mo], b [K, No] (row strides free)"""
     return (a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.dim() == 2 and b.dim() == 2 and a.shape[0] == b.shape[0]
@@ -623,8 +638,10 @@ def gemm_tn(a, b, out, splits=0, db=None):
     assert gemm_tn_ok(a, b) and out.dtype == torch.float32 and out.shape == (a.shape[1], b.shape[1]) and out.stride(1) == 1
     ws = splitk_workspace(a.device)
     assert db is None or (db.dtype == torch.float32 and db.is_contiguous() and db.numel() == a.shape[1])
+    ev = _profile_begin()
     _check(lib().whmr_gemm_tn_bf16(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0), _ptr(db), a.shape[1], b.shape[1],
                                    a.shape[0], int(splits), ws.data_ptr(), ws.numel(), _stream()), 'whmr_gemm_tn_bf16')
+    _profile_end(ev, 'gemm_bf16', 2.0 * a.shape[0] * a.shape[1] * b.shape[1])
     return out
 
 
@@ -642,9 +659,11 @@ def conv_dw_tn(a, img, out, OH, OW, KH, KW, S, P, splits=0, db=None):
     Bn, IH, IW, Cc = img.shape
     assert conv_dw_tn_ok(a, img) and a.shape[0] == Bn * OH * OW and out.dtype == torch.float32 and out.shape == (a.shape[1], KH * KW * Cc) and out.stride(1) == 1
     ws = splitk_workspace(a.device)
+    ev = _profile_begin()
     _check(lib().whmr_conv_dw_tn_bf16(a.data_ptr(), a.stride(0), img.data_ptr(), img.stride(2), out.data_ptr(), out.stride(0), a.shape[1], a.shape[0], Bn,
                                       OH, OW, IH, IW, Cc, KH, KW, S, P, zero_page(a.device).data_ptr(), int(splits), ws.data_ptr(), ws.numel(), _ptr(db), _stream()),
            'whmr_conv_dw_tn_bf16')
+    _profile_end(ev, 'gemm_bf16', 2.0 * a.shape[0] * a.shape[1] * KH * KW * Cc)
     return out
 
 
