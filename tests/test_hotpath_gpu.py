@@ -222,6 +222,25 @@ def test_whmr_hip_graph_replay_matches_eager(dev, assets, state_dict, gold):
         assert torch.allclose(out2[k], eager[k].flip(0), rtol=1e-4, atol=1e-5), k
 
 
+def test_camera_side_stream_is_bit_identical(dev, assets, state_dict, gold):
+    """cam_model runs on a side stream beside the backbone / loop and is joined before the global-orientation head (WHMR.overlap_camera): same
+    bits as the in-line order, per-crop frames and one hoisted frame, repeated calls (stream / allocator hygiene)"""
+    m = _load_model(assets, state_dict, 'bf16', dev)
+    kw = _inputs(gold, dev)
+    args = (kw['x'], None, kw['center'], kw['scale'], kw['bbox_height'], kw['orig_shape'], kw['bbox_info'])
+    for full in (kw['full_x'], kw['full_x'][:1].contiguous()):
+        m.overlap_camera = False
+        ref = {k: v.clone() for k, v in m(*args, full_x=full).items()}
+        m.overlap_camera = True
+        for _ in range(3):
+            out = m(*args, full_x=full)
+            junk = torch.randn(1 << 22, device=dev)               # allocator churn between the call and the comparison
+            del junk
+            for k in ref:
+                assert torch.equal(out[k], ref[k]), k
+    assert not torch.equal(ref['cam_rotmat'][0], torch.eye(3, device=dev))   # the frame did reach the camera head
+
+
 def test_whmr_eval_view_with_h36m_regressor_and_sliced_input(dev, assets, state_dict):
     """evaluate/eval.py:178-185 call shape: J_regressor given, eval view; crop passed as the non-contiguous slice
     inp[:, :, :, 32:-32] (demo/tester.py:152); batch of 1 and of 3 (odd sizes)"""
