@@ -105,7 +105,7 @@ int whmr_gemm_f32_set_big(int on);
 
 /* Weight-gradient product of the training step: C [Mo, No] (fp32, row stride ldc) = A^T . B with BOTH operands reduction-major, A [K, lda], B [K, ldb]
  * bf16 -- dW[n_out, k_in] = sum_m dY[m, n_out] . X[m, k_in] straight from the token- / pixel-major tensors the forward and backward kernels
- * leave (autograd of nn.Linear at vit.py:66-68,93,96,157 as run by core/trainer.py:410-470); no transposed operand copies.  Mo % 128 == 0,
+ * leave (autograd of nn.Linear at vit.py:66-68,93,96,157 as run by core/trainer.py:410-470); no transposed operand copies.  Mo % 64 == 0,
  * No % 256 == 0, K % 32 == 0, 16-B aligned rows; splits = 0 lets the launcher slice K (deterministic fixed-order reduction through `workspace`,
  * fp32, >= splits * Mo * (No + 1) * 4 bytes), splits = 1 needs no workspace.  db (nullable) [Mo] receives the column sums of A in the same pass:
  * the bias gradient when A is dY.  hipErrorInvalidValue outside that envelope. */
@@ -117,7 +117,7 @@ int whmr_gemm_tn_bf16(const void* A, long lda, const void* B, long ldb, float* C
  * reduction row (b, oy, ox) is img[b, oy*S + ky - P, ox*S + kx - P, c], zero outside the image.  Autograd of Conv2d (A = dY over the output
  * grid, img = X -> dW[co, (ky,kx,ci)]: whmr.py:419-420, models/iuv_predictor.py:71-91) and of ConvTranspose2d(k4, s2, p1) (A = X over the input
  * grid, img = dZ, S = 2, P = 1 -> dW[ci, (ky,kx,co)]: whmr.py:488-498) as core/trainer.py:410-470 runs them; replaces whmr_im2col_t + the operand
- * transposes + the NT GEMM.  Mo % 128 == 0, GC % 256 == 0, K % 32 == 0; zeros: >= 512 B of device zeros; db (nullable) [Mo] = column sums of A
+ * transposes + the NT GEMM.  Mo % 64 == 0, GC % 256 == 0, K % 32 == 0; zeros: >= 512 B of device zeros; db (nullable) [Mo] = column sums of A
  * (the convolution's bias gradient when A is dY). */
 int whmr_conv_dw_tn_bf16(const void* A, long lda, const void* img, long ldp, float* C, long ldc, int Mo, int K, int nB, int OH, int OW,
                          int IH, int IW, int GC, int KH, int KW, int S, int P, const void* zeros, int splits, void* workspace,

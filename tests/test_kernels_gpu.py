@@ -148,7 +148,7 @@ def test_gemm_f32_big_kernel_conv_gather_and_scatter(dev):
 
 
 @pytest.mark.parametrize('K,Mo,No,splits', [(12544, 768, 768, 0), (4096, 2304, 768, 0), (96, 128, 256, 1), (32, 256, 256, 0), (1056, 384, 512, 3),
-                                            (12288, 3072, 768, 0), (2048, 768, 3072, 1)])
+                                            (12288, 3072, 768, 0), (2048, 768, 3072, 1), (2080, 64, 512, 0), (640, 192, 256, 2)])
 def test_gemm_tn(dev, K, Mo, No, splits):
     """weight-gradient product straight from reduction-major operands (gemm_tn.hip: transposing LDS reads): C = A^T . B against float64,
     bitwise repeatable, strided rows (operands that are column slices of wider buffers)"""
@@ -167,7 +167,7 @@ def test_gemm_tn(dev, K, Mo, No, splits):
     out2 = torch.empty_like(out)
     L.gemm_tn(ad, bd, out2, splits=splits)
     assert torch.equal(out, out2)
-    assert not L.gemm_tn_ok(ad[:, :100], bd) and not L.gemm_tn_ok(ad[:-1], bd[:-1])
+    assert not L.gemm_tn_ok(ad[:, :40], bd) and not L.gemm_tn_ok(ad[:-1], bd[:-1])
 
 
 def test_conv_dw_tn(dev):
@@ -175,7 +175,7 @@ def test_conv_dw_tn(dev):
     7x7 s3 p0 (Tz head) and ConvTranspose2d k4 s2 p1 (deconv stages), incl. forced split-K"""
     from whmr_amd import _lib as L
     g = torch.Generator().manual_seed(3)
-    for (B, Cin, IH, IW, Cout, KH, S, P, splits) in ((2, 256, 16, 12, 128, 3, 1, 1, 0), (2, 256, 34, 25, 128, 7, 3, 0, 5), (4, 512, 8, 8, 256, 3, 1, 1, 1)):
+    for (B, Cin, IH, IW, Cout, KH, S, P, splits) in ((2, 256, 16, 12, 128, 3, 1, 1, 0), (2, 256, 34, 25, 128, 7, 3, 0, 5), (4, 512, 8, 8, 256, 3, 1, 1, 1), (2, 256, 34, 25, 64, 7, 3, 0, 0)):
         x = (torch.randn(B, Cin, IH, IW, generator=g) * 0.5).bfloat16().float()
         w = torch.zeros(Cout, Cin, KH, KH, requires_grad=True)
         y = F.conv2d(x, w, stride=S, padding=P)

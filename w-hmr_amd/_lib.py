@@ -628,7 +628,7 @@ def _profile_end(e0, name, work):
 def gemm_tn_ok(a, b):
     """shape / alignment envelope of whmr_gemm_tn_bf16 for a [K, Mo], b [K, No] (row strides free)"""
     return (a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.dim() == 2 and b.dim() == 2 and a.shape[0] == b.shape[0]
-            and a.stride(1) == 1 and b.stride(1) == 1 and a.shape[0] % 32 == 0 and a.shape[1] % 128 == 0 and b.shape[1] % 256 == 0
+            and a.stride(1) == 1 and b.stride(1) == 1 and a.shape[0] % 32 == 0 and a.shape[1] % 64 == 0 and b.shape[1] % 256 == 0
             and a.stride(0) % 8 == 0 and b.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0)
 
 
@@ -648,7 +648,7 @@ def gemm_tn(a, b, out, splits=0, db=None):
 def conv_dw_tn_ok(a, img):
     """envelope of whmr_conv_dw_tn_bf16 for a [K, Mo] (2-D, rows dense) and an NHWC image [B, IH, IW, C]"""
     return (a.dtype == torch.bfloat16 and img.dtype == torch.bfloat16 and a.dim() == 2 and img.dim() == 4 and a.stride(1) == 1 and img.is_contiguous()
-            and a.shape[0] % 32 == 0 and a.shape[1] % 128 == 0 and img.shape[3] % 256 == 0 and a.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0
+            and a.shape[0] % 32 == 0 and a.shape[1] % 64 == 0 and img.shape[3] % 256 == 0 and a.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0
             and img.data_ptr() % 16 == 0)
 
 

@@ -5,13 +5,13 @@
 // with dY and X exactly as the forward / backward kernels leave them (token- or pixel-major) -- the NT kernels (gemm_bf16_big.hip) need both
 // operands K-contiguous, i.e. two transposed copies per product (4.4 ms of a 31 ms step went into whmr_transpose_* / whmr_im2col_t).
 //
-// Tile: BM (128 | 256) x 256 outputs, 32 reduction rows per step, 8 waves (2 x 4, wave tile BM/2 x 64 on v_mfma_f32_32x32x16_bf16).  A step's
+// Tile: BM (64 | 128 | 256) x 256 outputs, 32 reduction rows per step, 8 waves (2 x 4, wave tile BM/2 x 64 on v_mfma_f32_32x32x16_bf16).  A step's
 // operand rows go global -> LDS by LDS-DMA (global_load_lds, 16 B per lane, whole 512-B rows) into a 3-slot ring, two steps ahead, counted
 // vmcnt, one barrier per step.  The MFMA fragments need, per lane, 8 consecutive REDUCTION indices of one output row / column -- a column of the
 // LDS tile: ds_read_b64_tr_b16 delivers 4 of them per read (the 16 lanes of a group read a 4-row x 16-column block and get it transposed).
 // Fragment k-slot e of half-wave hi holds tile row R0 + 4 hi + (e & 3) + 8 (e >> 2) for BOTH operands, so the products pair up correctly.
 // Bank conflicts: the 4 rows one half-wave reads sit one row pitch (512 B = all 64 banks, twice) apart; the 16-B chunk index of row r is XORed
-// with 4 (r & 3), which spreads them over four distinct 64-B windows.  The swizzle is applied on the DMA's SOURCE side (LDS destinations of
+// with 4 (r & 3) (128-B rows: 4 ((r >> 1) & 1)), which spreads them over four distinct 64-B windows.  The swizzle is applied on the DMA's SOURCE side (LDS destinations of
 // a wave instruction are linear).
 //
 // Split-K over blockIdx.z (a weight gradient is a few dozen tiles deep in K = all tokens): partial tiles go to the fp32 workspace and
@@ -26,14 +26,19 @@ template <int N> __device__ __forceinline__ void tn_wait_vmcnt() { asm volatile(
 // 8 reduction rows (R0 + 4 hi + {0..3, 8..11}) of column c0 + (lane & 31) of a swizzled [32][CH * 8] bf16 tile (CH 16-B chunks per row): two
 // transposing reads, ISSUED here and hidden from hipcc's waitcnt bookkeeping -- the caller waits once (lgkmcnt(0) + sched_barrier) for all
 // fragments of a K step before the MFMAs.
+// chunk-index XOR of tile row `row` (CH 16-B chunks per row).  The 4 rows a half-wave's transposing read touches must land in 4 distinct 64-B
+// bank windows: rows of >= 256 B all start at bank 0 -> XOR 4 (row & 3); 128-B rows (BM = 64) alternate between the two halves of the banks
+// already, rows r and r + 2 collide -> XOR 4 ((row >> 1) & 1).
+template <int CH> __device__ __forceinline__ int tn_swz(int row) { return CH >= 16 ? 4 * (row & 3) : 4 * ((row >> 1) & 1); }
+
 struct tn_raw { uint2 x, y; };
 template <int CH>
 __device__ __forceinline__ void tn_frag_issue(tn_raw& f, uint32_t tile, int R0, int c0, int lane) {
     const int g = lane >> 4, i = lane & 15;
     const int col = c0 + 16 * (g & 1) + 4 * (i & 3);
     const int row = R0 + 4 * (g >> 1) + (i >> 2);
-    const uint32_t a0 = tile + row * (CH * 16) + ((((col >> 3) ^ (4 * (row & 3)))) << 4) + (col & 7) * 2;
-    // second read: row + 8 -- same (row & 3), same swizzle
+    const uint32_t a0 = tile + row * (CH * 16) + ((((col >> 3) ^ tn_swz<CH>(row))) << 4) + (col & 7) * 2;
+    // second read: row + 8 -- same (row & 3) and ((row >> 1) & 1): same swizzle
     asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3" : "=&v"(f.x), "=&v"(f.y) : "v"(a0), "n"(8 * CH * 16) : "memory");
 }
 __device__ __forceinline__ bf16x8_t tn_frag_value(const tn_raw& f) {
@@ -61,8 +66,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const tn_params p) {
     constexpr int BM = 64 * MI, BN = 256, BK = 32;
     constexpr int CHA = BM / 8, CHB = BN / 8;                 // 16-B chunks per tile row
     constexpr int A_BYTES = BK * BM * 2, B_BYTES = BK * BN * 2, SLOT = A_BYTES + B_BYTES;
-    constexpr int UNITS = SLOT / 1024, UPW = UNITS / 8;       // 1-KiB DMA units per step, per wave (BM 256: 4, BM 128: 3)
-    static_assert(UNITS % 8 == 0, "every wave issues the same number of DMA units (counted vmcnt)");
+    constexpr int UNITS = SLOT / 1024, UPW = (UNITS + 7) / 8; // 1-KiB DMA units per step; per wave 4 (BM 256), 3 (BM 128), 3 or 2 (BM 64: 20 units)
+    constexpr int REM = UNITS % 8;                            // waves < REM issue UPW units, the others UPW - 1 (REM == 0: all UPW)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -75,6 +80,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const tn_params p) {
     const int k_end = min(p.K, k_begin + p.k_per_split);
     const int nkt = (k_end - k_begin) / BK;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(tn_lds_void_t*)smem;
+    const bool dma_full = (REM == 0) || (wave < REM);
 
     // DMA unit u = wave + 8 i: 1 KiB of the slot, linear.  A units first (A_BYTES / 1024), then B.  Inside an operand the unit covers
     // 1024 / (row bytes) rows; lane L -> linear byte L * 16 of the unit -> (row, chunk position) -> source chunk = position ^ 4 (row & 3).
@@ -82,12 +88,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const tn_params p) {
     int urow[UPW], uchunk[UPW];
 #pragma unroll
     for (int i = 0; i < UPW; ++i) {
-        const int u = wave + 8 * i;
+        int u = wave + 8 * i;
+        if (u >= UNITS) u = UNITS - 1;                                           // never issued (dma_full is false); keeps the address valid
         const bool isA = u < A_BYTES / 1024;
         const int off = (isA ? u : u - A_BYTES / 1024) * 1024 + lane * 16;       // byte offset inside the operand tile
         const int rowb = isA ? BM * 2 : BN * 2;
         const int row = off / rowb, pos = (off % rowb) >> 4;
-        const int chunk = pos ^ (4 * (row & 3));
+        const int chunk = pos ^ (isA ? tn_swz<CHA>(row) : tn_swz<CHB>(row));
         urow[i] = row; uchunk[i] = chunk;
         usrc[i] = isA ? p.A + (size_t)(k_begin + row) * p.lda + m0 + chunk * 8
                       : p.B + (size_t)(k_begin + row) * p.ldb + n0 + chunk * 8;
@@ -100,6 +107,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const tn_params p) {
         const int slot = kt % 3;
 #pragma unroll
         for (int i = 0; i < UPW; ++i) {
+            if (i == UPW - 1 && !dma_full) continue;
             const int u = wave + 8 * i;
             const bool isA = u < A_BYTES / 1024;
             const bf16_t* src;
@@ -135,7 +143,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const tn_params p) {
     if (nkt > 0) stage(0);
     if (nkt > 1) stage(1);
     for (int kt = 0; kt < nkt; ++kt) {
-        if (kt + 1 < nkt) tn_wait_vmcnt<UPW>(); else tn_wait_vmcnt<0>();       // own share of step kt has landed (step kt + 1 may fly)
+        if (kt + 1 < nkt) { if (dma_full) tn_wait_vmcnt<UPW>(); else tn_wait_vmcnt<UPW - 1>(); }      // own share of step kt has landed (step kt + 1 may fly)
+        else tn_wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();                                          // everyone's share landed; everyone is done with slot (kt - 1) % 3
         if (kt + 2 < nkt) stage(kt + 2);
         const uint32_t ta = lds0 + (kt % 3) * SLOT, tb = ta + A_BYTES;
@@ -232,7 +241,7 @@ static int launch_tn(const tn_params& p, int tiles, int splits, hipStream_t st) 
 }
 
 static int tn_run(tn_params p, int splits, void* workspace, long workspace_bytes, hipStream_t st) {
-    const int MI = (p.Mo % 256 == 0) ? 4 : 2;
+    const int MI = (p.Mo % 256 == 0) ? 4 : (p.Mo % 128 == 0) ? 2 : 1;
     const int tiles = (p.Mo / (64 * MI)) * (p.No / 256);
     const int steps = p.K / 32;
     if (splits <= 0) {
@@ -246,8 +255,8 @@ static int tn_run(tn_params p, int splits, void* workspace, long workspace_bytes
     p.k_per_split = sps * 32;
     p.ws = splits > 1 ? (float*)workspace : nullptr;
     int rc;
-    if (p.gather) rc = MI == 4 ? launch_tn<4, true>(p, tiles, splits, st) : launch_tn<2, true>(p, tiles, splits, st);
-    else rc = MI == 4 ? launch_tn<4, false>(p, tiles, splits, st) : launch_tn<2, false>(p, tiles, splits, st);
+    if (p.gather) rc = MI == 4 ? launch_tn<4, true>(p, tiles, splits, st) : MI == 2 ? launch_tn<2, true>(p, tiles, splits, st) : launch_tn<1, true>(p, tiles, splits, st);
+    else rc = MI == 4 ? launch_tn<4, false>(p, tiles, splits, st) : MI == 2 ? launch_tn<2, false>(p, tiles, splits, st) : launch_tn<1, false>(p, tiles, splits, st);
     if (rc) return rc;
     if (splits > 1) {
         hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)(((long)p.Mo * (p.No >> 2) + 255) / 256)), dim3(256), 0, st, (const float*)workspace, splits,
@@ -257,13 +266,13 @@ static int tn_run(tn_params p, int splits, void* workspace, long workspace_bytes
     return 0;
 }
 
-// A [K, lda], B [K, ldb] bf16 (16-B aligned rows: lda, ldb multiples of 8), C [Mo, ldc] fp32.  Mo % 128 == 0, No % 256 == 0, K % 32 == 0.
+// A [K, lda], B [K, ldb] bf16 (16-B aligned rows: lda, ldb multiples of 8), C [Mo, ldc] fp32.  Mo % 64 == 0, No % 256 == 0, K % 32 == 0.
 // db (nullable) [Mo] fp32 = column sums of A = the bias gradient when A is dY.
 // workspace (fp32, workspace_bytes) holds the split-K partials; splits = 0 picks the slice count (about one tile per CU), splits = 1 needs
 // no workspace.  Returns hipErrorInvalidValue for shapes outside the envelope (the caller keeps the transposed-copy path for those).
 extern "C" int whmr_gemm_tn_bf16(const void* A, long lda, const void* B, long ldb, float* C, long ldc, float* db, int Mo, int No, int K, int splits,
                                  void* workspace, long workspace_bytes, void* stream) {
-    if (Mo <= 0 || No <= 0 || K <= 0 || (Mo % 128) || (No % 256) || (K % 32) || (lda % 8) || (ldb % 8) || (ldc % 4) ||
+    if (Mo <= 0 || No <= 0 || K <= 0 || (Mo % 64) || (No % 256) || (K % 32) || (lda % 8) || (ldb % 8) || (ldc % 4) ||
         ((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)C & 15) || lda < Mo || ldb < No || ldc < No)
         return (int)hipErrorInvalidValue;
     tn_params p{};
@@ -280,7 +289,7 @@ extern "C" int whmr_conv_dw_tn_bf16(const void* A, long lda, const void* img, lo
                                     int IH, int IW, int GC, int KH, int KW, int S, int P, const void* zeros, int splits, void* workspace,
                                     long workspace_bytes, float* db, void* stream) {
     const long No = (long)KH * KW * GC;
-    if (Mo <= 0 || K <= 0 || (Mo % 128) || (GC % 256) || GC <= 0 || (K % 32) || (lda % 8) || (ldp % 8) || (ldc % 4) || ((uintptr_t)A & 15) ||
+    if (Mo <= 0 || K <= 0 || (Mo % 64) || (GC % 256) || GC <= 0 || (K % 32) || (lda % 8) || (ldp % 8) || (ldc % 4) || ((uintptr_t)A & 15) ||
         ((uintptr_t)img & 15) || ((uintptr_t)C & 15) || ((uintptr_t)zeros & 15) || !zeros || lda < Mo || ldp < GC || ldc < No ||
         (long)nB * OH * OW != K || No > (1L << 30))
         return (int)hipErrorInvalidValue;

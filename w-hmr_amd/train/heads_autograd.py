@@ -166,8 +166,8 @@ class ConvNHWCFn(torch.autograd.Function):
         same = S == 1 and OH == IH and OW == IW
         if ctx.needs_input_grad[1] and USE_TN and dt == torch.bfloat16 and Cin % 256 == 0 and M % 32 == 0 and x.is_contiguous():
             # gathering TN kernel: dW[co, (ky, kx, ci)] = sum_m dY[m, co] . X[pixel(m) + tap, ci] from dY and X as they are -- no transposed
-            # dY, no (transposed) column matrix of X.  dY is widened to a multiple of 128 columns (the kernel's row-tile height).
-            na = (npad + 127) // 128 * 128
+            # dY, no (transposed) column matrix of X.  dY is widened to a multiple of 64 columns (the kernel's smallest row tile) if need be.
+            na = (npad + 63) // 64 * 64
             if na != npad:
                 dya = torch.zeros(M, na, dtype=dt, device=dev)
                 dya[:, :npad] = dyp
