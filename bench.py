@@ -120,6 +120,8 @@ def build_workload(args, dev):
         # (core/trainer.py:84-91); GradReducer drops them at its first finish().  The backbone is one autograd node, so its parameters get
         # their own buckets: the head buckets are exchanged while the ViT backward still runs.
         red = None if use_graph else GradReducer(params, groups=[n.startswith('feature_extractor') for n, _ in named])
+        if red is not None:
+            red.attach(m.feature_extractor.backbone)          # the ViT node publishes its gradients block by block: buckets exchange under its backward
         rank = int(os.environ.get('RANK', '0'))
         inp = {k: v.to(dev) for k, v in synth.make_inputs(args.batch, 7 + rank).items()}
         a = (inp['x'], None, inp['center'], inp['scale'], inp['bbox_height'], inp['orig_shape'], inp['bbox_info'])

@@ -196,6 +196,70 @@ dist.destroy_process_group()
     assert res['n_buffers'] == 2 and res['buffers_equal']
 
 
+def test_grad_reducer_early_publish_two_ranks_gloo(tmp_path):
+    """GradReducer.publish: a hand-driven backward node (like ViTFn) delivers its parameters' gradients itself, block by block, and returns
+    None for them; the buckets fill and exchange as with hooks.  World size 2 on CPU/gloo against the single-process gradient."""
+    import json
+    script = tmp_path / 'pub.py'
+    script.write_text('''
+import json, os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from whmr_amd.parallel import GradReducer, shard_batch
+dist.init_process_group('gloo')
+rank, world = dist.get_rank(), dist.get_world_size()
+torch.manual_seed(0)
+
+class Body(torch.nn.Module):                                 # two "blocks" whose backward is ONE hand-driven node
+    def __init__(self):
+        super().__init__()
+        self.w1 = torch.nn.Parameter(torch.randn(16, 16) * 0.3)
+        self.w2 = torch.nn.Parameter(torch.randn(16, 16) * 0.3)
+        self.grad_sink = None
+    def forward(self, x):
+        return BodyFn.apply(x, self, self.w1, self.w2)
+
+class BodyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mod, w1, w2):
+        h = torch.tanh(x @ w1.t())
+        ctx.save_for_backward(x, h, w1, w2)
+        ctx.mod = mod
+        return h @ w2.t()
+    @staticmethod
+    def backward(ctx, dy):
+        x, h, w1, w2 = ctx.saved_tensors
+        sink = ctx.mod.grad_sink
+        g2 = dy.t() @ h                                      # last block first
+        pub2 = sink is not None and sink(ctx.mod.w2, g2)
+        dh = (dy @ w2) * (1 - h * h)
+        g1 = dh.t() @ x
+        pub1 = sink is not None and sink(ctx.mod.w1, g1)
+        return dh @ w1, None, (None if pub1 else g1), (None if pub2 else g2)
+
+body, head = Body(), torch.nn.Linear(16, 4)
+params = list(body.parameters()) + list(head.parameters())
+x, y = torch.randn(12, 16), torch.randn(12, 4)
+ref = torch.autograd.grad(((head(body(x)) - y) ** 2).mean(), params)
+red = GradReducer(params, bucket_bytes=600, groups=[0, 0, 1, 1]).attach(body)
+lo, hi = shard_batch(12, world, rank)
+for step in range(2):
+    for p in params:
+        p.grad = None
+    ((head(body(x[lo:hi])) - y[lo:hi]) ** 2).mean().backward()
+    red.finish()
+err = max((p.grad - g).abs().max().item() for p, g in zip(params, ref))
+if rank == 0:
+    print(json.dumps({'err': err, 'buckets': len(red.buckets)}))
+dist.destroy_process_group()
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1')
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+                          '--master-port', '29541', str(script)], capture_output=True, text=True, timeout=240, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    assert res['err'] < 1e-6 and res['buckets'] >= 2
+
+
 def _run_bench(*extra, timeout=300):
     import json
     env = dict(os.environ)

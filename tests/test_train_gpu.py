@@ -767,3 +767,35 @@ def test_tz_block_autograd_nodes(dev):
     assert _rel(out.detach().cpu(), run(x, w, b, wq, hip=False)) < 1e-5
     for a, r, name in zip(dev_in, ref_in, ('x', 'ln.weight', 'ln.bias', 'qkv.weight')):
         assert _rel(a.grad.cpu(), r.grad) < 5e-5, name
+
+
+def test_vit_node_publishes_gradients_to_the_reducer(dev):
+    """the ViT backward hands every block's gradients to GradReducer.publish as soon as they are enqueued (buckets exchange under the backward
+    of the earlier blocks at world size > 1); here always_bucket=True exercises the same path on one GPU: identical gradients, every
+    backbone parameter delivered early, none through the accumulate hooks"""
+    from oracle import synth
+    from whmr_amd.models.pose_vit import ViT
+    from whmr_amd.parallel import GradReducer
+    sd = synth.make_vit_state(2, (256, 192), depth=3)
+    x = synth.make_inputs(2, 3, (256, 192))['x'].to(dev)
+    cot = torch.randn(2, 768, 16, 12, generator=torch.Generator().manual_seed(4)).to(dev)
+
+    def run(with_reducer):
+        m = ViT(img_size=(256, 192), depth=3, qkv_bias=True, numerics='bf16', drop_path_rate=0.0)
+        m.load_state_dict(sd, strict=True)
+        m = m.to(dev).train()
+        red = GradReducer(m.parameters(), bucket_bytes=24 << 20, always_bucket=True).attach(m) if with_reducer else None
+        for _ in range(2):                                                     # twice: buckets re-arm after finish()
+            for p in m.parameters():
+                p.grad = None
+            (m(x) * cot).sum().backward()
+            if red is not None:
+                assert len(red._published) == sum(1 for _ in m.parameters())
+                red.finish()
+        return [p.grad.clone() for p in m.parameters()], red
+
+    ref, _ = run(False)
+    got, red = run(True)
+    assert len(red.buckets) >= 3
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)

@@ -18,6 +18,7 @@ them); a used parameter whose gradient is missing in a later step travels as zer
 gradient raises, and so does a second backward pass before ``finish()``.
 
     reducer = GradReducer(model.parameters())
+    reducer.attach(model.feature_extractor.backbone)     # optional: the ViT node publishes its gradients block by block (see publish())
     loss.backward()            # hooks copy finished gradients into their bucket and launch full buckets
     reducer.finish()           # wait, divide by world size, gradients point into the reduced buckets
     optimizer.step()
@@ -49,6 +50,7 @@ class GradReducer:
         self._skipped_ids = set()
         self._resolved = False                   # the used/unused census has run
         self._fired = set()                      # id(param) of the gradients that arrived since the last finish()
+        self._published = set()                  # ... of those, the ones delivered through publish() (their accumulate hook is ignored)
         self._stream = None
         self._build(self.params, self.groups)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
@@ -85,9 +87,11 @@ class GradReducer:
     def _active(self):
         return self.world > 1 or self.always_bucket
 
-    def _on_grad(self, p):
+    def _on_grad(self, p, published=False):
         if not self._active():
             return                               # single process: nothing to exchange, the gradients stay where autograd put them
+        if not published and id(p) in self._published:
+            return                               # the engine still visits the accumulate node of a parameter whose node returned None
         if id(p) in self._skipped_ids:
             raise RuntimeError('GradReducer: a parameter of shape %s received a gradient after it was classified as unused at the first '
                                'finish(); the set of used parameters must be static (rebuild the reducer)' % (tuple(p.shape),))
@@ -99,6 +103,26 @@ class GradReducer:
         b['pending'] -= 1
         if b['pending'] == 0:
             self._pack_and_launch(b)
+
+    def publish(self, p, grad):
+        """Early delivery from INSIDE an autograd node: the W-HMR backbone is one node (ViTFn), so the hooks above would see all of its ~150
+        gradients at once, after its whole backward.  ``vit_backward`` hands each block's gradients over as soon as they are enqueued
+        (``module.grad_sink = reducer.publish``): ``p.grad`` is set here, the bucket bookkeeping runs, a full bucket starts its all-reduce
+        while the earlier blocks are still being back-propagated -- and the node returns None for that parameter.  Returns False when there
+        is nothing to exchange (single process): the caller then lets autograd deliver the gradient as usual."""
+        if not self._active() or id(p) not in self._slot:
+            return False
+        if p.grad is not None and id(p) not in self._fired:
+            raise RuntimeError('GradReducer.publish: the parameter already holds a gradient (accumulation over several backward passes is not supported)')
+        p.grad = grad
+        self._published.add(id(p))
+        self._on_grad(p, published=True)
+        return True
+
+    def attach(self, module):
+        """route the early deliveries of a module whose backward is hand-driven (whmr_amd.train.vit_autograd) into this reducer"""
+        module.grad_sink = self.publish
+        return self
 
     def _pack_and_launch(self, b):
         # the bucket's last gradient has arrived: ONE multi-tensor copy packs all of them (a copy per hook was ~225 small launches
@@ -177,6 +201,7 @@ class GradReducer:
         for b in self.buckets:
             b['flat'] = None
         self._fired.clear()
+        self._published.clear()
         if used is not None and self.skipped:                    # from the next step on the buckets hold used parameters only
             keep = [i for i in range(len(self.params)) if used[i]]
             self.groups = [self.groups[i] for i in keep] if self.groups is not None else None

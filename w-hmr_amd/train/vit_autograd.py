@@ -211,6 +211,22 @@ def vit_backward(m, s, dout):
         L.gemm(dy_op, wt(w, wshape), dx)                                               # W^T: [Kin, Nout]
         return dx
 
+    # Early delivery to the data-parallel reducer (GradReducer.publish): everything in ``grads`` that belongs to finished blocks is handed over
+    # in the order the parameters were registered (reverse = backward order inside a block), so that a full bucket's all-reduce runs on
+    # RCCL's stream beside the backward of the earlier blocks.  Only when the gradients are produced on the node's own stream.
+    sink = getattr(m, 'grad_sink', None) if side is None else None
+    published = set()
+    order = {id(q): i for i, q in enumerate(m.parameters())}
+
+    def flush():
+        if sink is None:
+            return
+        ready = sorted((q for q in grads if id(q) not in published), key=lambda q: -order[id(q)])
+        for q in ready:
+            g = grads[q]
+            if sink(q, g if g.shape == q.shape else g.view_as(q)):
+                published.add(id(q))
+
     dt_grad = torch.empty(M, D, **f32)                                                 # gradient of the fp32 residual stream
     dg, db = torch.empty(D, **f32), torch.empty(D, **f32)
     L.layernorm_bwd(s.t_last, dout.contiguous().float(), m.last_norm.weight, None, dt_grad, dg, db, 1e-6)
@@ -238,6 +254,7 @@ def vit_backward(m, s, dout):
         dg, db = torch.empty(D, **f32), torch.empty(D, **f32)
         L.layernorm_bwd(a.t_in, d_h1, blk.norm1.weight, dt_grad, dt_grad, dg, db, 1e-6)    # dt_grad now = d t_in
         grads[blk.norm1.weight], grads[blk.norm1.bias] = dg, db
+        flush()                                                                            # this block's gradients may start their exchange
     # t_0 = cols . Wp^T + b + (pos_embed[1:] + pos_embed[:1])
     pe = m.patch_embed.proj
     linear_bwd(_op(dt_grad, dt), s.cols, pe, need_dx=False)
@@ -248,6 +265,10 @@ def vit_backward(m, s, dout):
     gpe[0, 1:] = dpos
     gpe[0, 0] = dpos.sum(0)
     grads[m.pos_embed] = gpe
+    flush()
+    for q in list(grads):                                                              # delivered already: the node returns None for them
+        if id(q) in published:
+            grads[q] = None
     if side is not None:                                                               # join: the gradients are consumed on the main stream
         main.wait_stream(side)
         if not capturing:
