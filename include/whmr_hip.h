@@ -135,9 +135,11 @@ int whmr_patch_im2col(const float* x, void* cols, int B, int Cin, int H, int W, 
 int whmr_cast_f32_bf16(const float* src, void* dst, long n, void* stream);
 
 /* softmax(scale * Q K^T) V per (image, head) on qkv [B, N, 3, H, d] -> out [B, N, H*d].  vit.py:102-111.
- * is_bf16 = 1: MFMA kernel (d == 64, N <= 256); 0: fp32 kernel (N <= 256, any d). */
+ * is_bf16 = 1: bf16 MFMA kernel (d == 64, N <= 256); 0: fp32 -- exact-f32 MFMA kernel with an online softmax for d == 64, 32 < N <= 256 (the backbone
+ * in the parity mode), VALU kernel for any other d / N <= 256 (the 5-token timm Block of the Tz head). */
 int whmr_attention(const void* qkv, void* out, int B, int N, int H, int d, float scale, int is_bf16, void* stream);
-/* A/B switch of the bf16 kernel: 1 = chunked online-softmax variant (2 workgroups / CU, default), 0 = single pass. */
+/* A/B switches: bit 0: 1 = chunked online-softmax bf16 variant (2 workgroups / CU, default), 0 = single pass; bits 1-2: timing ablations of the
+ * blocked kernel (wrong results); bit 3 set: fp32 attention always on the VALU kernel. */
 int whmr_attention_set_variant(int chunked);
 
 /* ---- rotation / projection helpers: utils/geometry.py ------------------------------------------------------------ */

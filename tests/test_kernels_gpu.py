@@ -308,18 +308,27 @@ def test_attention_bf16(dev, N):
     assert _rel(out.float().cpu(), ref) < 2e-2
 
 
-@pytest.mark.parametrize('N,H,d', [(196, 12, 64), (5, 2, 108), (192, 12, 64), (70, 3, 32)])
+@pytest.mark.parametrize('N,H,d', [(196, 12, 64), (5, 2, 108), (192, 12, 64), (70, 3, 32), (33, 2, 64), (256, 3, 64), (100, 16, 64)])
 def test_attention_f32(dev, N, H, d):
+    """fp32 attention core: the matrix-pipe kernel (d = 64, 32 < N <= 256: exact-f32 MFMA, online softmax) and the VALU kernel (other shapes,
+    and as the A/B partner: whmr_attention_set_variant bit 3) against float64"""
     from whmr_amd import _lib as L
     g = torch.Generator().manual_seed(N + d)
     B = 2
     qkv = torch.randn(B, N, 3, H, d, generator=g) * 1.5
-    q, k, v = qkv.permute(2, 0, 3, 1, 4)
+    q, k, v = qkv.double().permute(2, 0, 3, 1, 4)
     ref = ((q * d ** -0.5) @ k.transpose(-2, -1)).softmax(-1) @ v
-    ref = ref.transpose(1, 2).reshape(B, N, H * d)
+    ref = ref.transpose(1, 2).reshape(B, N, H * d).float()
     out = torch.empty(B, N, H * d, device=dev)
     L.attention(qkv.to(dev).view(B, N, 3 * H * d), out, B, N, H, d, d ** -0.5)
     assert _rel(out.cpu(), ref) < 5e-6
+    try:
+        L.attention_set_variant(1 | 8)                                  # VALU kernel
+        valu = torch.empty_like(out)
+        L.attention(qkv.to(dev).view(B, N, 3 * H * d), valu, B, N, H, d, d ** -0.5)
+    finally:
+        L.attention_set_variant(1)
+    assert _rel(valu.cpu(), ref) < 5e-6 and _rel(out, valu) < 5e-6
 
 
 def test_patch_im2col(dev):

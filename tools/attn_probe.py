@@ -26,3 +26,10 @@ for N in (196, 192):
         L.attention_set_variant(var)
         print('N=%d blocked %s: %.1f us' % (N, name, timeit(lambda: L.attention_blk(qb, ob, B, N, 12, 0.125))))
 L.attention_set_variant(1)
+for N in (196, 192):
+    q32 = torch.randn(B, N, 2304, device=dev)
+    a32 = torch.empty(B, N, 768, device=dev)
+    for var, name in ((1, 'matrix-pipe kernel'), (1 | 8, 'VALU kernel')):
+        L.attention_set_variant(var)
+        print('N=%d fp32 attention, %s: %.1f us' % (N, name, timeit(lambda: L.attention(q32, a32, B, N, 12, 64, 0.125), n=10, w=2)))
+L.attention_set_variant(1)

@@ -699,7 +699,8 @@ def crop_normalize(frame, inv_affine, patch_w, patch_h, x0, x1, out, raw, mean, 
 
 
 def attention_set_variant(chunked):
-    """1 = chunked online-softmax bf16 attention kernel (default), 0 = single-pass kernel (A/B measurements)."""
+    """bit 0: 1 = chunked online-softmax bf16 attention kernel (default), 0 = single-pass kernel; bits 1-2: timing ablations of the blocked kernel
+    (wrong results); bit 3 set: fp32 attention on the VALU kernel instead of the matrix-pipe one (A/B measurements, tests)."""
     _check(lib().whmr_attention_set_variant(int(chunked)), 'whmr_attention_set_variant')
 
 

@@ -572,6 +572,124 @@ __global__ __launch_bounds__(NKT * 64) void attention_bwd_bf16_kernel(const bf16
         }
 }
 
+// ---- fp32 attention on the matrix pipes (parity mode, d = 64, N <= 256): v_mfma_f32_32x32x2_f32 is exact f32 arithmetic, so this is the VALU
+// kernel below at ~10x its rate.  One workgroup per (image, head), wave w owns queries 32 w .. 32 w + 31 and walks the key tiles with an online
+// softmax.  S^T tile = K_t . Q^T (A operand = K rows from LDS, one float per lane and step; B operand = the wave's Q row, 32 registers, scaled by
+// scale * log2 e) lands in the C layout with lane = query, so row max / sum are lane-local (+ one exchange between the half-waves), and the
+// probabilities feed the second product straight from the accumulator registers: step r of O^T += V_t^T . P_t^T pairs the keys the two half-waves
+// hold in register r ((r & 3) + 8 (r >> 2) + 4 hi), whose V rows are the A operand.  K rows are padded to 66 floats and V rows to 72 so that both
+// fragment reads are conflict-free; O goes back through LDS for 256-B row stores.
+#define AF_KLD 66
+#define AF_VLD 72
+template <int NKT>
+__global__ __launch_bounds__(NKT * 64) void attention_f32_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ out, int N, int H, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NPAD = NKT * 32;
+    float* Ks = (float*)smem;                     // [NPAD][AF_KLD]
+    float* Vs = Ks + NPAD * AF_KLD;               // [NPAD][AF_VLD]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int C = H * 64, ld = 3 * C;
+    const float* base = qkv + (size_t)b * N * ld + h * 64;
+    for (int c = tid; c < NPAD * 16; c += NKT * 64) {
+        const int key = c >> 4, ch = (c & 15) * 4;
+        float4 k = make_float4(0.f, 0.f, 0.f, 0.f), v = k;
+        if (key < N) {
+            k = *(const float4*)(base + (size_t)key * ld + C + ch);
+            v = *(const float4*)(base + (size_t)key * ld + 2 * C + ch);
+        }
+        float* kd = Ks + key * AF_KLD + ch;
+        kd[0] = k.x; kd[1] = k.y; kd[2] = k.z; kd[3] = k.w;                     // rows are 8-byte aligned only (66 floats)
+        *(float4*)(Vs + key * AF_VLD + ch) = v;
+    }
+    const int q0 = wave * 32;
+    const int qrow = min(q0 + l31, N - 1);
+    const float sc = scale * LOG2E;
+    float q[32];                                   // q[s] = Q[qrow][2 s + hi] * scale * log2(e)
+#pragma unroll
+    for (int s4 = 0; s4 < 16; ++s4) {
+        // lanes of one half-wave need the even (hi = 0) or odd (hi = 1) elements: read pairs, keep one
+        const float4 t = *(const float4*)(base + (size_t)qrow * ld + s4 * 4);
+        q[2 * s4] = (hi ? t.y : t.x) * sc;
+        q[2 * s4 + 1] = (hi ? t.w : t.z) * sc;
+    }
+    __syncthreads();
+    float m = -INFINITY, l = 0.f;
+    f32x16_t o[2];
+#pragma unroll
+    for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dh][r] = 0.f;
+#pragma unroll 1
+    for (int t = 0; t < NKT; ++t) {
+        f32x16_t sacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+        const float* kr = Ks + (t * 32 + l31) * AF_KLD + hi;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kr[2 * s], q[s], sacc, 0, 0, 0);
+        // sacc[r] = S^T[key = 32 t + (r & 3) + 8 (r >> 2) + 4 hi][query = l31]  (already in log2 units)
+        float cm = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (key >= N) sacc[r] = -INFINITY;
+            cm = fmaxf(cm, sacc[r]);
+        }
+        cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
+        const float m_new = fmaxf(m, cm);
+        const float alpha = __builtin_amdgcn_exp2f(m - m_new);                  // 0 on the first tile (m = -inf)
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sacc[r] = __builtin_amdgcn_exp2f(sacc[r] - m_new); ps += sacc[r]; }
+        l = fmaf(l, alpha, ps);
+        m = m_new;
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dh][r] *= alpha;
+        // O^T[d][q] += sum over the tile's keys of V[key][d] P[key][q]: step r pairs keys (r & 3) + 8 (r >> 2) (+ 4 in the upper half-wave)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float* vr = Vs + (t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * AF_VLD + l31;
+            o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[0], sacc[r], o[0], 0, 0, 0);
+            o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[32], sacc[r], o[1], 0, 0, 0);
+        }
+    }
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    // o[dh][r] = O[q = l31][d = 32 dh + (r & 3) + 8 (r >> 2) + 4 hi]: through LDS (K / V are free now) for 256-B row stores
+    __syncthreads();
+    float* tile = (float*)smem + wave * (32 * 65);
+#pragma unroll
+    for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tile[l31 * 65 + dh * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi] = o[dh][r] * inv;
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float* ob = out + (size_t)b * N * C + h * 64;
+    for (int row = 0; row < 32; ++row) {
+        const int qq = q0 + row;
+        if (qq < N) ob[(size_t)qq * C + lane] = tile[row * 65 + lane];
+    }
+}
+
+template <int NKT>
+static int launch_f32_mfma(const float* qkv, float* out, int B, int N, int H, float scale, hipStream_t st) {
+    constexpr size_t lds = (size_t)NKT * 32 * (AF_KLD + AF_VLD) * sizeof(float);
+    auto kern = attention_f32_mfma_kernel<NKT>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(B * H), dim3(NKT * 64), lds, st, qkv, out, N, H, scale);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}
+
 // fp32, reference operation order: q*scale, dot over d, softmax(expf), weighted sum over keys.
 __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                             int N, int H, int d, float scale) {
@@ -635,7 +753,8 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
 
 static int g_attn_chunked = 1;      // whmr_attention_set_variant: bit 0: 1 = chunked online-softmax kernel (default), 0 = single pass
 static int g_attn_abl = 0;          // bits 1-2 (timing probes only, wrong results): 2 = skip the K / V staging, 4 = skip the key loop
-extern "C" int whmr_attention_set_variant(int v) { g_attn_chunked = v & 1; g_attn_abl = v & 6; return 0; }
+static int g_attn_f32_mfma = 1;     // bit 3 SET switches the fp32 attention back to the VALU kernel (A/B, tests)
+extern "C" int whmr_attention_set_variant(int v) { g_attn_chunked = v & 1; g_attn_abl = v & 6; g_attn_f32_mfma = !(v & 8); return 0; }
 
 template <int NKT>
 static int launch_bf16(const void* qkv, void* out, int B, int N, int H, float scale, hipStream_t st, float* lse = nullptr) {
@@ -693,6 +812,17 @@ extern "C" int whmr_attention(const void* qkv, void* out, int B, int N, int H, i
             case 8: return launch_bf16<8>(qkv, out, B, N, H, scale, st);
         }
         return (int)hipErrorInvalidValue;
+    }
+    if (d == 64 && N > 32 && N <= 256 && scale > 0.f && g_attn_f32_mfma) {       // matrix-pipe form (same exact-f32 arithmetic, ~10x the rate)
+        switch ((N + 31) / 32) {
+            case 2: return launch_f32_mfma<2>((const float*)qkv, (float*)out, B, N, H, scale, st);
+            case 3: return launch_f32_mfma<3>((const float*)qkv, (float*)out, B, N, H, scale, st);
+            case 4: return launch_f32_mfma<4>((const float*)qkv, (float*)out, B, N, H, scale, st);
+            case 5: return launch_f32_mfma<5>((const float*)qkv, (float*)out, B, N, H, scale, st);
+            case 6: return launch_f32_mfma<6>((const float*)qkv, (float*)out, B, N, H, scale, st);
+            case 7: return launch_f32_mfma<7>((const float*)qkv, (float*)out, B, N, H, scale, st);
+            case 8: return launch_f32_mfma<8>((const float*)qkv, (float*)out, B, N, H, scale, st);
+        }
     }
     const size_t lds = ((size_t)2 * N * (d + 1) + 4 * d + 4 * N) * sizeof(float);
     if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
