@@ -472,13 +472,14 @@ def main(argv=None):
     dt = reduce_max_time(dt, dist, dev)
     n_ranks = count_ranks(dist, dev)
 
-    gemm = [(f, e0.elapsed_time(e1) * 1e-3) for (name, f, e0, e1) in prof if name == 'gemm_bf16']
-    traffic = gemm_traffic() if (args.workload == 'vit224' and not dry) else None
+    fp32_mode = args.numerics == 'fp32'                               # parity numerics: exact-f32 MFMA (v_mfma_f32_32x32x2_f32) GEMMs
+    gemm = [(f, e0.elapsed_time(e1) * 1e-3) for (name, f, e0, e1) in prof if name == ('gemm_f32' if fp32_mode else 'gemm_bf16')]
+    traffic = gemm_traffic() if (args.workload == 'vit224' and not dry and not fp32_mode) else None        # the PMC passes measured the bf16 kernels
     n_launch = max(len(gemm), 1)
     flops_per_launch = sum(f for f, _ in gemm) / n_launch
     avg_s = sum(t for _, t in gemm) / n_launch
     achieved = flops_per_launch / avg_s / 1e12 if gemm else 0.0
-    peak = 2500.0                                                     # dense bf16 MFMA, MI355X_MICROARCH.md
+    peak = 157.3 if fp32_mode else 2500.0                             # dense MFMA peak of the operand type, MI355X_MICROARCH.md (fp32 = the VALU rate)
     if rank == 0:
         value = aggregate_value(n_ranks, args.batch, args.steps, dt)
         if training:
@@ -502,7 +503,8 @@ def main(argv=None):
             res['efficiency_vs_1gpu'] = value / (n_ranks * args.ref_1gpu)
         if not dry:
             res['model_tflops'] = VIT_FLOP_PER_IMG[args.workload] * n_ranks * args.batch * args.steps / dt / 1e12
-            res['roofline'] = {'bound': 'mfma', 'kernel': 'bf16 MFMA GEMM launches of one step (%d: gemm_blk_kernel on the blocked ViT path, gemm_tn_kernel for the weight gradients, gemm_bf16_big_kernel elsewhere)' % len(gemm),
+            res['roofline'] = {'bound': 'mfma', 'kernel': ('fp32 (exact-f32 MFMA) GEMM launches of one step (%d: gemm_f32_big_kernel for large M, the 64x64 / skinny kernels elsewhere)' % len(gemm)) if fp32_mode else
+                               'bf16 MFMA GEMM launches of one step (%d: gemm_blk_kernel on the blocked ViT path, gemm_tn_kernel for the weight gradients, gemm_bf16_big_kernel elsewhere)' % len(gemm),
                                'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
                                'flops_per_launch': flops_per_launch, 'avg_launch_us': avg_s * 1e6,
                                'traffic': traffic['bytes_per_launch'] if traffic else None,
