@@ -12,7 +12,7 @@ from conftest import GOLDEN
 
 pytestmark = pytest.mark.gpu
 
-TILES = [0x44, 0x55, 0x43, 0x33, 0x32, 0x22, 0x54]
+TILES = [0x44, 0x55, 0x43, 0x33, 0x32, 0x22, 0x54, 0x21]
 
 
 def _rel(a, b):

@@ -362,7 +362,7 @@ static int launch_blk_epi(const whmr_gemm_blk_desc& p, hipStream_t st) {
 }
 
 // Tile heights (x 256 columns): the wave rows own MI0 and MI1 row blocks.  The chooser minimises (rounds over 256 CUs) x (tile rows).
-static const int kBlkTiles[][2] = {{4, 4}, {5, 5}, {4, 3}, {3, 3}, {3, 2}, {2, 2}, {5, 4}};
+static const int kBlkTiles[][2] = {{4, 4}, {5, 5}, {4, 3}, {3, 3}, {3, 2}, {2, 2}, {5, 4}, {2, 1}};
 
 extern "C" int whmr_gemm_blk_tile(const whmr_gemm_blk_desc* pp, int tile, void* stream) {
     const whmr_gemm_blk_desc& p = *pp;
@@ -381,6 +381,7 @@ extern "C" int whmr_gemm_blk_tile(const whmr_gemm_blk_desc* pp, int tile, void* 
         case 0x32: return launch_blk_epi<3, 2>(p, st);      // 160 x 256
         case 0x22: return launch_blk_epi<2, 2>(p, st);      // 128 x 256
         case 0x54: return launch_blk_epi<5, 4>(p, st);      // 288 x 256
+        case 0x21: return launch_blk_epi<2, 1>(p, st);      // 96 x 256: ViT-L at 32 crops (6144 tokens) x N = 1024 is exactly 256 such tiles
     }
     return (int)hipErrorInvalidValue;
 }
