@@ -223,15 +223,22 @@ def test_whmr_hip_graph_replay_matches_eager(dev, assets, state_dict, gold):
 
 
 def test_camera_side_stream_is_bit_identical(dev, assets, state_dict, gold):
-    """cam_model runs on a side stream beside the backbone / loop and is joined before the global-orientation head (WHMR.overlap_camera): same
-    bits as the in-line order, per-crop frames and one hoisted frame, repeated calls (stream / allocator hygiene)"""
+    """cam_model runs on a side stream beside the backbone / loop and is joined before the global-orientation head (WHMR.overlap_camera); deconv
+    2 / 3 and the Tz head run on another one beside the regressor loop (WHMR.overlap_tz): same bits as the in-line order in the vis and train
+    views, per-crop frames and one hoisted frame, repeated calls (stream / allocator hygiene)"""
     m = _load_model(assets, state_dict, 'bf16', dev)
     kw = _inputs(gold, dev)
     args = (kw['x'], None, kw['center'], kw['scale'], kw['bbox_height'], kw['orig_shape'], kw['bbox_info'])
     for full in (kw['full_x'], kw['full_x'][:1].contiguous()):
-        m.overlap_camera = False
+        m.overlap_camera = m.overlap_tz = False
         ref = {k: v.clone() for k, v in m(*args, full_x=full).items()}
-        m.overlap_camera = True
+        ref_tr = m(*args, full_x=full, view='train')[0]['smpl_out']
+        ref_tr = [{k: v.clone() for k, v in d.items() if torch.is_tensor(v)} for d in ref_tr]
+        m.overlap_camera = m.overlap_tz = True           # + deconv 2 / 3 and the Tz head beside the regressor loop, Tz outputs finalized after the join
+        tr = m(*args, full_x=full, view='train')[0]['smpl_out']
+        for d, r in zip(tr, ref_tr):
+            for k in r:
+                assert torch.equal(d[k], r[k]), k
         for _ in range(3):
             out = m(*args, full_x=full)
             junk = torch.randn(1 << 22, device=dev)               # allocator churn between the call and the comparison

@@ -210,6 +210,7 @@ class Regressor(nn.Module):
         out = self.smpl.run(new[:, 216:226], new[:, :216], gram_schmidt=True, want_aa=True, want_smpl_joints=True,
                             want_markers=True, post=post, nxt=nxt)                    # whmr.py:128-137,174,184-187
         d = self._outputs(out, new, scale, J_regressor, with_aux, Tz, orig_shape, center, bbox_height)
+        self._last_stage = (new, out.pose_aa, out.joints)          # for WHMR's deferred Tz finalize (Tz head on a side stream)
         return d, xc[:, :F + 5]
 
     @torch.no_grad()
@@ -332,6 +333,8 @@ class WHMR(nn.Module):
         self._cache = _Cache()
         self._init_cache = None
         self.overlap_camera = True          # cam_model on a side stream beside the backbone (joined before the global-orientation head)
+        self.overlap_tz = True              # Tz head on a side stream beside the regressor loop (its outputs finalized after the join)
+        self._tz_ones = {}
         self.eval()
 
     def _make_deconv_layer(self, num_layers, num_filters, num_kernels):
@@ -451,6 +454,12 @@ class WHMR(nn.Module):
             self._init_cache = (key, reg.forward_init(x1, with_aux=with_aux))
         return expand(self._init_cache[1])
 
+    def _tz_placeholder(self, B, dev):
+        t = self._tz_ones.get((dev, B))
+        if t is None:
+            t = self._tz_ones[(dev, B)] = torch.ones(B, dtype=torch.float32, device=dev)
+        return t
+
     @staticmethod
     def _camera_stream(dev):
         st = _CAM_STREAMS.get(dev)                 # module-level: a Stream inside the module would break copy.deepcopy(model) / pickling
@@ -515,11 +524,34 @@ class WHMR(nn.Module):
         s_feat = tok.view(B, Hp, Wp, vit.embed_dim)
         f = s_feat if self._dt == torch.float32 else L.cast_bf16(s_feat)
         fmaps = []
-        for i in range(3):
-            f = self._deconv(i, f)
+        # Regressor iteration i only needs feature map i, and the Tz head (7x7 s3 conv over the last map + the timm Block, ~0.45 ms at batch 64)
+        # only enters a stage's OUTPUTS (focal length, pred_cam_t, kp_2d_w: whmr.py:147-173), never the next stage's input.  So after the first
+        # deconv stage the heavy chain (deconv 2, deconv 3, Tz head) moves to a side stream and the regressor loop -- a chain of small
+        # latency-bound launches -- runs beside it on the main stream, waiting for map i before iteration i; the loop's tail kernels see a
+        # placeholder Tz and the Tz-dependent outputs of the stages a view returns are (re)computed by one small launch each after the join.
+        tz_side, map_ready = None, [None, None, None]
+        if self.overlap_tz and B >= 4:          # (one or two crops: every launch is latency-bound, the extra finalize launch costs more than it hides)
+            f = self._deconv(0, f)
             fmaps.append(f)
-            self.maf_extractor[i].im_feat = f.permute(0, 3, 1, 2)                     # logical NCHW view (whmr.py:564)
-        Tz = self._tz_head(fmaps[-1])
+            main_tz = torch.cuda.current_stream(dev)
+            tz_side = self._camera_stream((dev, 'tz'))
+            tz_side.wait_stream(main_tz)
+            with torch.cuda.stream(tz_side):
+                for i in (1, 2):
+                    f = self._deconv(i, f)
+                    fmaps.append(f)
+                    map_ready[i] = torch.cuda.Event()
+                    map_ready[i].record(tz_side)
+                Tz_true = self._tz_head(fmaps[-1])
+            Tz = self._tz_placeholder(B, dev)
+        else:
+            for i in range(3):
+                f = self._deconv(i, f)
+                fmaps.append(f)
+            Tz = Tz_true = self._tz_head(fmaps[-1])
+        for i in range(3):
+            self.maf_extractor[i].im_feat = fmaps[i].permute(0, 3, 1, 2)              # logical NCHW view (whmr.py:564)
+        stage_state = []
 
         smpl_output = self._init_mesh(B, J_regressor, with_aux)
         outs = [smpl_output]
@@ -531,6 +563,8 @@ class WHMR(nn.Module):
         xcs = [torch.empty(B, Fs[i] + 234, dtype=torch.float32, device=dev) for i in range(3)]
         for i in range(3):                                                            # whmr.py:580-627
             reg, ext = self.regressor[i], self.maf_extractor[i]
+            if map_ready[i] is not None:
+                torch.cuda.current_stream(dev).wait_event(map_ready[i])               # feature map i comes from the side stream
             cam, shp, pose = smpl_output['pred_cam'], smpl_output['pred_shape'], smpl_output['rotmat']
             ext.cam = cam
             xc = xcs[i]
@@ -543,7 +577,18 @@ class WHMR(nn.Module):
                                          is_train=False, n_iter=1, J_regressor=J_regressor, with_aux=with_aux, xc=xc,
                                          xc_next=(xcs[i + 1], Fs[i + 1]) if i < 2 else None, state_ready=i > 0)
             outs.append(smpl_output)
+            stage_state.append(reg._last_stage)
 
+        if tz_side is not None:                                                       # join the Tz head; finalize the stages this view returns
+            main_tz.wait_stream(tz_side)
+            if not torch.cuda.is_current_stream_capturing():
+                for t in (Tz_true, fmaps[1], fmaps[2]):                                # allocated on the side stream, read (or returned) on the main one
+                    t.record_stream(main_tz)
+            for i in (range(3) if view == 'train' else (2,)):
+                st, aa, joints = stage_state[i]
+                theta, kp_2d, kp_w, cam_t, focal = L.regressor_post(st, aa, joints, Tz_true, bbox_height, center, orig_shape, 1000.0,
+                                                                    float(cfg.IMG_RES.WIDTH), float(cfg.IMG_RES.HEIGHT))
+                outs[i + 1].update(theta=theta, kp_2d=kp_2d, kp_2d_w=kp_w, pred_cam_t=cam_t, focal_length=focal)
         if side is not None:                                                          # join: the camera rotation is needed from here on
             main.wait_stream(side)
             if not torch.cuda.is_current_stream_capturing():                          # (a capture's private pool never recycles)
