@@ -24,6 +24,8 @@ Not differentiated here (outputs only): the angle-axis copy of the pose in ``the
 are not part of core/trainer.py:500-600; computed without dropout).  The IUV head ``dp_head`` IS part of the graph (``dp_out``, whmr.py:656-658);
 its ground truth comes from the pytorch3d rasteriser in the reference, which this package does not provide.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -47,6 +49,17 @@ def _projection(joints, cam):
     x = FOCAL_LENGTH * ((joints[..., 0] + cam[:, 1:2]) / z) / (float(cfg.IMG_RES.WIDTH) / 2.0)
     y = FOCAL_LENGTH * ((joints[..., 1] + cam[:, 2:3]) / z) / (float(cfg.IMG_RES.HEIGHT) / 2.0)
     return torch.stack([x, y], dim=-1)
+
+
+OVERLAP_HEAVY = os.environ.get('WHMR_TRAIN_OVERLAP', '1') != '0'      # deconv 2 / 3 + Tz head + IUV head on a side stream beside the regressor loop
+_heavy_streams = {}
+
+
+def _heavy_stream(dev):
+    st = _heavy_streams.get(dev)
+    if st is None:
+        st = _heavy_streams[dev] = torch.cuda.Stream(device=dev)
+    return st
 
 
 def _perspective_norm(joints, cam_t, focal, cam_center):
@@ -96,6 +109,12 @@ def dp_head_train(model, f_nhwc):
     return {'predict_uv_index': nchw(idx), 'predict_ann_index': nchw(ann), 'predict_u': nchw(u), 'predict_v': nchw(v)}
 
 
+def regressor_post_train(joints, cam_n, Tz, bbox_height, center, orig_shape):
+    """whmr.py:142-173 in one launch (and one for the backward): kp_2d, focal = s.detach()*h*Tz/2, cam_t from pred_cam.detach(), kp_2d_w"""
+    return RegressorPostFn.apply(joints, cam_n, Tz, bbox_height, center, orig_shape, int(cfg.TRAIN.STAGE),
+                                 (FOCAL_LENGTH, float(cfg.IMG_RES.WIDTH), float(cfg.IMG_RES.HEIGHT)))
+
+
 def regressor_train(reg, ref, bbox_info, Tz, orig_shape, center, scale, bbox_height, pose, shape, cam, cache):
     """Regressor.forward(is_train=True, n_iter=1), whmr.py:102-209.  pose / shape / cam: the previous stage's (detached) estimates."""
     B = ref.shape[0]
@@ -114,8 +133,10 @@ def regressor_train(reg, ref, bbox_info, Tz, orig_shape, center, scale, bbox_hei
     rotmat = pose_n.view(B, 24, 3, 3)                                                  # no Gram-Schmidt in training (whmr.py:129)
     verts, joints, smpl_j, markers = SMPLFn.apply(shape_n, rotmat, reg.smpl)
     # whmr.py:142-173 in one launch (and one for the backward): kp_2d, focal = s.detach()*h*Tz/2, cam_t from pred_cam.detach(), kp_2d_w
-    kp_2d, kp_w, cam_t, focal = RegressorPostFn.apply(joints, cam_n, Tz, bbox_height, center, orig_shape, stage,
-                                                      (FOCAL_LENGTH, float(cfg.IMG_RES.WIDTH), float(cfg.IMG_RES.HEIGHT)))
+    if Tz is not None:
+        kp_2d, kp_w, cam_t, focal = regressor_post_train(joints, cam_n, Tz, bbox_height, center, orig_shape)
+    else:                                         # deferred: whmr_forward_train fills these four once the Tz head (on its side stream) has been joined
+        kp_2d = kp_w = cam_t = focal = None
     with torch.no_grad():
         aa = L.mat_to_aa(rotmat.detach().reshape(-1, 9).contiguous()).reshape(B, 72)   # whmr.py:174 (no gradient, see module docstring)
     sub, temp = DownsampleFn.apply(verts, reg.Dmap0, reg.Dmap1, cache)
@@ -140,14 +161,36 @@ def whmr_forward_train(model, x, center, scale, bbox_height, orig_shape, bbox_in
 
     s_feat = model.feature_extractor(x)                                               # [B,768,Hp,Wp] view of NHWC tokens, ViTFn node
     f = s_feat.permute(0, 2, 3, 1).contiguous().to(dt)
-    fmaps = []
-    for i in range(3):
+    def deconv(i, f):
         ct, bn = model.deconv_layers[3 * i], model.deconv_layers[3 * i + 1]
         assert ct.bias is None
-        f = DeconvBNReLUFn.apply(f, ct.weight, bn.weight, bn.bias, bn, dt)
-        fmaps.append(f)
-        model.maf_extractor[i].im_feat = f.detach().permute(0, 3, 1, 2)
-    Tz = tz_head_train(model, fmaps[-1].detach() if int(cfg.TRAIN.STAGE) == 1 else fmaps[-1])
+        return DeconvBNReLUFn.apply(f, ct.weight, bn.weight, bn.bias, bn, dt)
+
+    aux = bool(cfg.MODEL.PyMAF.AUX_SUPV_ON and hasattr(model, 'dp_head'))
+    # Stage i of the regressor loop only reads feature map i, and the Tz head only enters the stages' projections (whmr.py:142-173), not the
+    # next stage's input: after the first deconv stage the HEAVY chain (deconv 2, deconv 3, Tz head, IUV head: a few large launches) runs on a
+    # side stream and the loop (hundreds of small launches) beside it on the main one; the Tz-dependent projections of the three stages follow
+    # the join.  autograd runs every node's backward on the stream of its forward, so the backward pass overlaps the same way.
+    fmaps, dp_out, map_ready = [deconv(0, f)], [], [None, None, None]
+    heavy = None
+    if OVERLAP_HEAVY:
+        main = torch.cuda.current_stream(dev)
+        heavy = _heavy_stream(dev)
+        heavy.wait_stream(main)
+        with torch.cuda.stream(heavy):
+            for i in (1, 2):
+                fmaps.append(deconv(i, fmaps[-1]))
+                map_ready[i] = torch.cuda.Event()
+                map_ready[i].record(heavy)
+            Tz = tz_head_train(model, fmaps[-1].detach() if int(cfg.TRAIN.STAGE) == 1 else fmaps[-1])
+            if aux:
+                dp_out = [dp_head_train(model, fmaps[-1])]                                 # whmr.py:656-658
+    else:
+        for i in (1, 2):
+            fmaps.append(deconv(i, fmaps[-1]))
+        Tz = tz_head_train(model, fmaps[-1].detach() if int(cfg.TRAIN.STAGE) == 1 else fmaps[-1])
+    for i in range(3):
+        model.maf_extractor[i].im_feat = fmaps[i].detach().permute(0, 3, 1, 2)
 
     smpl_output = model._init_mesh(B, None, True)                                      # constant mean-pose mesh (whmr.py:548-550)
     outs = [smpl_output]
@@ -155,6 +198,8 @@ def whmr_forward_train(model, x, center, scale, bbox_height, orig_shape, bbox_in
     cache = model.__dict__.setdefault('_train_cache', {})
     for i in range(3):                                                                 # whmr.py:580-627
         reg, ext = model.regressor[i], model.maf_extractor[i]
+        if map_ready[i] is not None:
+            torch.cuda.current_stream(dev).wait_event(map_ready[i])                    # feature map i comes from the side stream
         cam, shp = smpl_output['pred_cam'].detach(), smpl_output['pred_shape'].detach()
         pose, markers = smpl_output['rotmat'].detach(), smpl_output['markers'].detach()
         ext.cam = cam
@@ -165,9 +210,17 @@ def whmr_forward_train(model, x, center, scale, bbox_height, orig_shape, bbox_in
             ref = MAFSampleFn.apply(fm, *ps, ext, pts, None, None)
         else:
             ref = MAFSampleFn.apply(fm, *ps, ext, None, markers.contiguous(), cam.contiguous())
-        smpl_output, body_feat = regressor_train(reg, ref, bbox_info, Tz, orig_shape, center, scale, bbox_height, pose, shp, cam,
-                                                 cache.setdefault(i, {}))
+        smpl_output, body_feat = regressor_train(reg, ref, bbox_info, None if heavy is not None else Tz, orig_shape, center, scale, bbox_height,
+                                                 pose, shp, cam, cache.setdefault(i, {}))
         outs.append(smpl_output)
+    if heavy is not None:                                                              # join; the stages' Tz-dependent projections
+        main.wait_stream(heavy)
+        if not torch.cuda.is_current_stream_capturing():
+            for t in [Tz, fmaps[1], fmaps[2]] + [v for d in dp_out for v in d.values()]:
+                t.record_stream(main)                                                  # allocated on the side stream, read on the main one
+        for d in outs[1:]:
+            d['kp_2d'], d['kp_2d_w'], d['pred_cam_t'], d['focal_length'] = regressor_post_train(d['kp_3d'], d['pred_cam'], Tz, bbox_height, center,
+                                                                                              orig_shape)
 
     with torch.no_grad():                                                              # whmr.py:630-654, outputs only
         go = model.global_orient
@@ -182,6 +235,7 @@ def whmr_forward_train(model, x, center, scale, bbox_height, orig_shape, bbox_in
         g = model.regressor[0].smpl.run(smpl_output['pred_shape'], g_rotmat)
         g_out = {'global_pose': torch.cat([g_aa, smpl_output['pose'][:, 3:]], dim=1), 'global_shape': smpl_output['pred_shape'],
                  'global_rotmat': g_rotmat, 'global_kp_3d': g.joints, 'global_verts': g.vertices}
-    dp_out = [dp_head_train(model, fmaps[-1])] if (cfg.MODEL.PyMAF.AUX_SUPV_ON and hasattr(model, 'dp_head')) else []     # whmr.py:656-658
+    if heavy is None and aux:
+        dp_out = [dp_head_train(model, fmaps[-1])]                                     # whmr.py:656-658
     vis_feat = [s_feat.detach()] + [m.detach().permute(0, 3, 1, 2) for m in fmaps]
     return {'smpl_out': outs, 'dp_out': dp_out, 'dpth_out': [], 'global_output': g_out}, vis_feat
