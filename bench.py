@@ -93,10 +93,18 @@ def build_workload(args, dev):
                             'none': 'no full frame: camera rotation identity (cam_model not in the step)'}[args.full_x]
         args.parity_ctx = (m, sd, assets, inp, kw)
         eager = lambda: m(*a, **kw)
+
+        def eager_serial():                     # the instrumented (per-launch event) step: the side streams folded back into the main one, so
+            ov = (m.overlap_camera, m.overlap_tz)      # that an event pair brackets ITS launch alone, not whatever runs beside it
+            m.overlap_camera = m.overlap_tz = False
+            try:
+                return m(*a, **kw)
+            finally:
+                m.overlap_camera, m.overlap_tz = ov
+        args.eager_step = eager_serial
         if args.eager:
             return eager, None, inp['x'], (256, 192)
         g = GraphedForward(m, *a, **kw)
-        args.eager_step = eager
         return (lambda: g.graph.replay()), None, inp['x'], (256, 192)
     if args.workload == 'whmr_train':
         # BASELINE configs[3] (train.py pymaf_net step, batch 64 per GPU, DP gradient all-reduce over RCCL): forward in training mode,
@@ -158,6 +166,15 @@ def build_workload(args, dev):
             loss = fwd_bwd()
             opt.step()
             return loss
+
+        def train_step_serial():                 # the instrumented (per-launch event) step: no side stream, an event pair brackets its launch alone
+            from whmr_amd.train import whmr_train as WT
+            ov, WT.OVERLAP_HEAVY = WT.OVERLAP_HEAVY, False
+            try:
+                return train_step()
+            finally:
+                WT.OVERLAP_HEAVY = ov
+        args.eager_step = train_step_serial
         if use_graph:
             from whmr_amd.train import capture_train_step
             with torch.enable_grad():
@@ -166,7 +183,6 @@ def build_workload(args, dev):
             def graph_step():
                 replay()
                 opt.step()
-            args.eager_step = train_step                       # the instrumented (per-GEMM event) step cannot come from a graph replay
             return graph_step, None, inp['x'], (256, 192)
         return train_step, None, inp['x'], (256, 192)
     raise SystemExit('unknown workload %s' % args.workload)
