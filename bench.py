@@ -292,6 +292,47 @@ def whmr_parity_and_fp32(args, dev, n_sample=2):
     return res, (time.perf_counter() - t0) / 3 * 1e3
 
 
+def whmr_hbm_rows(args, dev, n=20):
+    """achieved HBM GB/s of the sampler launch and of one SMPL call: n back-to-back calls captured in a HIP graph (pure GPU time), inputs taken from a
+    real forward of the benchmark batch; algorithmic bytes per SURVEY 8(d)"""
+    m, sd, assets, inp, kw = args.parity_ctx
+    B = inp['x'].shape[0]
+    with torch.no_grad():
+        out, _ = m(inp['x'], None, inp['center'], inp['scale'], inp['bbox_height'], inp['orig_shape'], inp['bbox_info'], view='train', **kw)
+        last = out['smpl_out'][2]
+        markers, cam = last['markers'].contiguous(), last['pred_cam'].contiguous()
+        betas, rot = last['pred_shape'].contiguous(), last['rotmat'].reshape(B, 216).contiguous()
+        ext, smpl = m.maf_extractor[2], m.regressor[2].smpl
+        xc = torch.empty(B, m.regressor[2].fc1.in_features, dtype=torch.float32, device=dev)
+        calls = {'maf_sample': (lambda: ext(markers, cam=cam, out=xc, want_point_feat=False),
+                                B * markers.shape[1] * (4 * 256 * ext.im_feat.element_size() + 32 * 4.0)),
+                 'smpl_call': (lambda: smpl.run(betas, rot, gram_schmidt=True, want_aa=True, want_smpl_joints=True, want_markers=True),
+                               B * 84172.0 + 19.6e6)}
+        rows = {}
+        for name, (fn, byt) in calls.items():
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    fn()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for _ in range(n):
+                    fn()
+            g.replay()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            g.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            sec = e0.elapsed_time(e1) * 1e-3 / n
+            rows[name] = {'avg_us': sec * 1e6, 'algorithmic_bytes': byt, 'achieved_GBps': byt / sec / 1e9, 'frac_of_8TBps': byt / sec / 8e12}
+    return rows
+
+
 def cpu_whmr_baseline(args, n_img=4):
     """CPU leg of the whmr workload: the oracle's full forward (oracle/whmr.py, incl. the ResNet-50 of cam_model on one 600x800 frame) on a
     bounded sample of ``n_img`` crops"""
@@ -526,17 +567,12 @@ def main(argv=None):
                                'traffic': traffic['bytes_per_launch'] if traffic else None,
                                'traffic_note': traffic['note'] if traffic else 'no PMC pass of the current GEMM sources committed'}
             if args.workload == 'whmr':
-                # the HBM-bound rows of the north star: MAF sampler and SMPL (LBS) call, events around each call of the instrumented step
-                hbm = {}
-                for kname in ('maf_sample', 'smpl_call'):
-                    ev = [(w, e0.elapsed_time(e1) * 1e-3) for (nm, w, e0, e1) in prof if nm == kname]
-                    if ev:
-                        byt, sec = sum(w for w, _ in ev) / len(ev), sum(t for _, t in ev) / len(ev)
-                        hbm[kname] = {'calls_per_step': len(ev), 'avg_us': sec * 1e6, 'algorithmic_bytes': byt, 'achieved_GBps': byt / sec / 1e9,
-                                      'frac_of_8TBps': byt / sec / 8e12}
-                res['hbm_rows'] = hbm
-                res['hbm_rows_note'] = 'maf_sample = one fused launch (projection + bilinear gather + point MLP); smpl_call = pose chain + pose-corrective ' \
-                                       'GEMM + skinning + joint regression + stage tail (5 launches); both are latency-bound at these sizes (SURVEY 8d)'
+                # the HBM-bound rows of the north star: MAF sampler and SMPL (LBS) call
+                res['hbm_rows'] = whmr_hbm_rows(args, dev)
+                res['hbm_rows_note'] = 'GPU time of ONE call, 20 calls replayed from a HIP graph on the tensors of a real forward (an eager call is host-launch ' \
+                                       'bound and would time the interpreter); maf_sample = one fused launch (projection + bilinear gather of 256 channels at 67 ' \
+                                       'points + point MLP); smpl_call = pose chain + pose-corrective GEMM + skinning + joint regression + stage tail (5 dependent ' \
+                                       'launches); both are latency-bound at these sizes (SURVEY 8d)'
             if args.workload == 'whmr' and n_ranks == 1 and not args.no_parity:
                 res['parity'], res['fp32_ms_per_step'] = whmr_parity_and_fp32(args, dev)
                 res['parity_note'] = 'max-rel error of the last regressor stage (theta [B,85], vertices [B,6890,3], kp_2d [B,49,2]) of the full-batch device forward vs the CPU oracle on the ' \
