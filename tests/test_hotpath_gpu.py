@@ -351,3 +351,27 @@ def test_whmr_forward_batch64_fp32_vs_cpu_oracle(dev, assets, state_dict):
     errs = {k: _rel(o16[k], v.numpy()) for k, v in ref.items()}
     print('B=64 bf16 mode:', {k: '%.1e' % e for k, e in errs.items()})
     assert errs['smpl_vertices'] < 2e-3 and errs['local_pose'] < 2e-3 and errs['shape'] < 2e-3
+
+
+@pytest.mark.parametrize('B', [1, 7])
+def test_whmr_forward_odd_batches_fp32_vs_cpu_oracle(dev, assets, state_dict, B):
+    """ragged sizes: one crop (every launch in its small-M regime, no side streams for the heads) and seven (1344 tokens: the large-M fp32 GEMM
+    with a partial row tile, the side-stream arrangement of the heads) against the CPU oracle, all vis_dict tensors within 1e-4; then the bf16
+    mode's vertices / pose inside their budget at the same sizes (row-major small-batch kernels at these token counts)"""
+    from oracle import synth
+    from oracle import whmr as OW
+    inp = synth.make_inputs(B, 40 + B)
+    full = torch.randn(1, 3, 160, 224, generator=torch.Generator().manual_seed(B))
+    with torch.no_grad():
+        ref = OW.whmr_forward(state_dict, assets, inp['x'], inp['center'], inp['scale'], inp['bbox_height'], inp['orig_shape'], inp['bbox_info'],
+                              full_x=full.expand(B, -1, -1, -1))
+    d = {k: v.to(dev) for k, v in inp.items()}
+    m = _load_model(assets, state_dict, 'fp32', dev)
+    out = m(d['x'], None, d['center'], d['scale'], d['bbox_height'], d['orig_shape'], d['bbox_info'], full_x=full.to(dev))
+    for k, v in ref.items():
+        err = _rel(out[k], v.numpy())
+        assert out[k].shape == v.shape and err < 1e-4, (B, k, err)
+    m16 = _load_model(assets, state_dict, 'bf16', dev)
+    o16 = m16(d['x'], None, d['center'], d['scale'], d['bbox_height'], d['orig_shape'], d['bbox_info'], full_x=full.to(dev))
+    errs = {k: _rel(o16[k], v.numpy()) for k, v in ref.items()}
+    assert errs['smpl_vertices'] < 2e-3 and errs['local_pose'] < 2e-3 and errs['shape'] < 2e-3, errs

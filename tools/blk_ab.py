@@ -6,7 +6,7 @@ import torch
 from whmr_amd import _lib as L
 from whmr_amd.models.pose_vit import ViT
 dev = torch.device('cuda:0')
-B, res = 64, 224
+B, res = 64, ((256, 192) if os.environ.get('BLK_AB_RES') == '256x192' else 224)
 def timeit(fn, n=10, w=3):
     for _ in range(w): fn()
     torch.cuda.synchronize()
@@ -16,7 +16,7 @@ def timeit(fn, n=10, w=3):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
 m = ViT(img_size=res, qkv_bias=True, numerics='bf16').to(dev).eval()
-x = torch.randn(B, 3, res, res, device=dev)
+x = torch.randn(B, 3, *(res if isinstance(res, tuple) else (res, res)), device=dev)
 def fwd_ms(): return min(timeit(lambda: m(x)) for _ in range(3))
 def setcfg(cfg):
     for s in range(4): L.lib().whmr_gemm_blk_set_tile(s, 0)
