@@ -579,16 +579,6 @@ class WHMR(nn.Module):
             outs.append(smpl_output)
             stage_state.append(reg._last_stage)
 
-        if tz_side is not None:                                                       # join the Tz head; finalize the stages this view returns
-            main_tz.wait_stream(tz_side)
-            if not torch.cuda.is_current_stream_capturing():
-                for t in (Tz_true, fmaps[1], fmaps[2]):                                # allocated on the side stream, read (or returned) on the main one
-                    t.record_stream(main_tz)
-            for i in (range(3) if view == 'train' else (2,)):
-                st, aa, joints = stage_state[i]
-                theta, kp_2d, kp_w, cam_t, focal = L.regressor_post(st, aa, joints, Tz_true, bbox_height, center, orig_shape, 1000.0,
-                                                                    float(cfg.IMG_RES.WIDTH), float(cfg.IMG_RES.HEIGHT))
-                outs[i + 1].update(theta=theta, kp_2d=kp_2d, kp_2d_w=kp_w, pred_cam_t=cam_t, focal_length=focal)
         if side is not None:                                                          # join: the camera rotation is needed from here on
             main.wait_stream(side)
             if not torch.cuda.is_current_stream_capturing():                          # (a capture's private pool never recycles)
@@ -602,6 +592,17 @@ class WHMR(nn.Module):
         g_joints = g.joints
         if J_regressor is not None:
             g_joints = h36m_joints(g.vertices, J_regressor)
+        if tz_side is not None:                                                       # join the Tz head LAST (the global-orientation head above does not need it
+        # and runs beside the heavy chain too); finalize the stages this view returns
+            main_tz.wait_stream(tz_side)
+            if not torch.cuda.is_current_stream_capturing():
+                for t in (Tz_true, fmaps[1], fmaps[2]):                                # allocated on the side stream, read (or returned) on the main one
+                    t.record_stream(main_tz)
+            for i in (range(3) if view == 'train' else (2,)):
+                st, aa, joints = stage_state[i]
+                theta, kp_2d, kp_w, cam_t, focal = L.regressor_post(st, aa, joints, Tz_true, bbox_height, center, orig_shape, 1000.0,
+                                                                    float(cfg.IMG_RES.WIDTH), float(cfg.IMG_RES.HEIGHT))
+                outs[i + 1].update(theta=theta, kp_2d=kp_2d, kp_2d_w=kp_w, pred_cam_t=cam_t, focal_length=focal)
         g_out = {'global_pose': g_pose, 'global_shape': smpl_output['pred_shape'], 'global_rotmat': g_rotmat,
                  'global_kp_3d': g_joints, 'global_verts': g.vertices}
         if view == 'eval':
