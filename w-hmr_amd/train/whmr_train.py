@@ -183,6 +183,8 @@ def whmr_forward_train(model, x, center, scale, bbox_height, orig_shape, bbox_in
                 map_ready[i] = torch.cuda.Event()
                 map_ready[i].record(heavy)
             Tz = tz_head_train(model, fmaps[-1].detach() if int(cfg.TRAIN.STAGE) == 1 else fmaps[-1])
+            tz_ready = torch.cuda.Event()
+            tz_ready.record(heavy)
             if aux:
                 dp_out = [dp_head_train(model, fmaps[-1])]                                 # whmr.py:656-658
     else:
@@ -213,10 +215,10 @@ def whmr_forward_train(model, x, center, scale, bbox_height, orig_shape, bbox_in
         smpl_output, body_feat = regressor_train(reg, ref, bbox_info, None if heavy is not None else Tz, orig_shape, center, scale, bbox_height,
                                                  pose, shp, cam, cache.setdefault(i, {}))
         outs.append(smpl_output)
-    if heavy is not None:                                                              # join; the stages' Tz-dependent projections
-        main.wait_stream(heavy)
+    if heavy is not None:                                                              # the stages' Tz-dependent projections wait for the Tz head only
+        main.wait_event(tz_ready)                                                      # (the IUV head keeps running on the side stream)
         if not torch.cuda.is_current_stream_capturing():
-            for t in [Tz, fmaps[1], fmaps[2]] + [v for d in dp_out for v in d.values()]:
+            for t in [Tz, fmaps[1], fmaps[2]]:
                 t.record_stream(main)                                                  # allocated on the side stream, read on the main one
         for d in outs[1:]:
             d['kp_2d'], d['kp_2d_w'], d['pred_cam_t'], d['focal_length'] = regressor_post_train(d['kp_3d'], d['pred_cam'], Tz, bbox_height, center,
@@ -237,5 +239,10 @@ def whmr_forward_train(model, x, center, scale, bbox_height, orig_shape, bbox_in
                  'global_rotmat': g_rotmat, 'global_kp_3d': g.joints, 'global_verts': g.vertices}
     if heavy is None and aux:
         dp_out = [dp_head_train(model, fmaps[-1])]                                     # whmr.py:656-658
+    if heavy is not None:                                                              # join
+        main.wait_stream(heavy)
+        if not torch.cuda.is_current_stream_capturing():
+            for v in (v for d in dp_out for v in d.values()):
+                v.record_stream(main)
     vis_feat = [s_feat.detach()] + [m.detach().permute(0, 3, 1, 2) for m in fmaps]
     return {'smpl_out': outs, 'dp_out': dp_out, 'dpth_out': [], 'global_output': g_out}, vis_feat
