@@ -154,8 +154,9 @@ def build_workload(args, dev):
             if out['dp_out']:
                 # IUV head (AUX_SUPV_ON): the reference's dense-correspondence losses against ground truth RENDERED THIS STEP from the fitted mesh
                 # (core/trainer.py:442-482) -- here the HIP rasteriser (whmr_amd.utils.renderer.IUV_Renderer) on the stage-3 mesh, detached
-                _, uvia = render_iuv_targets(iuv_maker, out['smpl_out'][-1]['verts'].detach(), gt_cam)
-                loss = loss + aux_supervision_loss(out['dp_out'], uvia)
+                # and the fused loss kernels (csrc/iuv_loss.hip) on the head's channels-last logits: same values as body_uv_losses on the target maps
+                img, _ = render_iuv_targets(iuv_maker, out['smpl_out'][-1]['verts'].detach(), gt_cam, maps=False)
+                loss = loss + aux_supervision_loss(out['dp_out'], None, iuv_image_gt=img)
             loss.backward()
             if red is not None:
                 red.finish()

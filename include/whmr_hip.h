@@ -364,6 +364,19 @@ int whmr_iuv_rasterize(const float* verts, int B, int Vsrc, const int64_t* vmap,
                        const float* cam, float fx, float fy, float px, float py, float focal, int orig_h, int orig_w, int H, int W, float* scr,
                        void* zbuf, float* out, int32_t* face_out, void* stream);
 
+/* Dense-correspondence losses of the AUX supervision, fused: core/trainer.py:255-298 (body_uv_losses, has_iuv = None) on the targets
+ * utils/iuvmap.py:67-110 (iuv_img2map, uv_rois = None) derives from the rendered IUV image (core/trainer.py:464-482).  y [B*H*W, ld]: the IUV head's
+ * channels-last logits (predict_u 25 | predict_v 25 | predict_uv_index 25 | predict_ann_index 15; models/iuv_predictor.py:71-91), bf16 (y_bf16,
+ * ld even) or fp32; iuv [B, 3, H, W] fp32 = (I/24, U, V) with element strides sb, sc, sh, sw.  losses[4] = (loss_U, loss_V, loss_IndexUV,
+ * loss_segAnn), U / V already scaled by point_weight (LOSS.POINT_REGRESSION_WEIGHTS) / B.  partial: >= ceil(B*H*W/128)*4 floats of scratch.
+ * Deterministic (fixed-order sums). */
+int whmr_iuv_losses(const void* y, int y_bf16, long ld, const float* iuv, long sb, long sc, long sh, long sw, int B, int H, int W,
+                    float point_weight, float* partial, float* losses, void* stream);
+/* Backward of the above: dy [B*H*W, ldg] (y's dtype; columns 90 .. ldg-1 are zeroed: the padded operand ConvNHWCFn's weight gradient reads) =
+ * d(g[0] loss_U + g[1] loss_V + g[2] loss_IndexUV + g[3] loss_segAnn) / dy, g [4] on the device. */
+int whmr_iuv_losses_bwd(const void* y, int y_bf16, long ld, const float* iuv, long sb, long sc, long sh, long sw, int B, int H, int W,
+                        float point_weight, const float* g, void* dy, long ldg, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

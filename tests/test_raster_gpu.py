@@ -140,3 +140,91 @@ def test_aux_supervision_targets_and_losses(dev, assets):
     ref_loss = (idx + ann + lu + lv).item()
     assert abs(loss.item() - ref_loss) < 2e-3 * abs(ref_loss), (loss.item(), ref_loss)
     assert all(v.grad is not None and torch.isfinite(v.grad).all() for v in dpd.values())
+
+
+def _iuv_loss_reference(logits, img, w):
+    """core/trainer.py:273-297 on utils/iuvmap.py:67-110 targets (the oracle's maps), float64 on the host: the reference's boolean-index form"""
+    import torch.nn.functional as F
+    from oracle import raster as OR
+    U, V, I, A = (torch.from_numpy(a) for a in OR.iuv_img2map(img.double().numpy()))
+    y = logits.double().requires_grad_(True)
+    u, v, idx, ann = (t.permute(0, 3, 1, 2) for t in torch.split(y, [25, 25, 25, 15], dim=-1))
+    B = y.shape[0]
+    li = F.cross_entropy(idx.permute(0, 2, 3, 1).reshape(-1, 25), I.argmax(1).view(-1))
+    la = F.cross_entropy(ann.permute(0, 2, 3, 1).reshape(-1, 15), A.argmax(1).view(-1))
+    fg = I > 0
+    lu = F.smooth_l1_loss(u[fg], U[fg], reduction='sum') / B * w
+    lv = F.smooth_l1_loss(v[fg], V[fg], reduction='sum') / B * w
+    return y, torch.stack([lu, lv, li, la])
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_iuv_losses_fused_kernel_matches_the_map_form(dev, dtype):
+    """csrc/iuv_loss.hip (whmr_iuv_losses / whmr_iuv_losses_bwd) against body_uv_losses' formulas on iuv_img2map targets in float64: every part
+    id incl. background, a value outside 0..24 (no indicator: counts as class 0, no U / V term), |u_pred - U| on both sides of the smooth-L1 knee,
+    a cropped (strided) image view, a ragged last block (P % 128 != 0), non-uniform upstream gradients; bf16 logits in the padded [P, 128] layout."""
+    from whmr_amd import _lib as L
+    from whmr_amd.train.aux_supervision import IUVLossFn
+    g = torch.Generator().manual_seed(5)
+    B, H, W, w = 3, 13, 11, 0.125
+    part = torch.randint(0, 25, (B, H, W + 8), generator=g).float()
+    part[0, 0, 4:9] = torch.tensor([25.0, 0.0, 24.0, 26.0, 12.0])                         # 25, 26: outside the indicator range
+    full = torch.stack([part / 24.0, torch.rand(B, H, W + 8, generator=g), torch.rand(B, H, W + 8, generator=g)], 1)
+    img = full[:, :, :, 4:-4]                                                            # strided view, like the vitpose crop
+    logits = torch.randn(B, H, W, 90, generator=g) * 1.5
+    if dtype == 'bf16':
+        logits = logits.bfloat16().float()
+        buf = torch.zeros(B * H * W, 128, dtype=torch.bfloat16, device=dev)
+        buf[:, :90] = logits.view(-1, 90).to(dev)
+        y = buf.view(B, H, W, 128)[..., :90]
+    else:
+        y = logits.to(dev)
+    y = y.detach().requires_grad_(True)
+    imgd = full.to(dev)[:, :, :, 4:-4]
+    assert not imgd.is_contiguous()
+    ref_y, ref = _iuv_loss_reference(logits, img, w)
+    out = IUVLossFn.apply(y, imgd, w)
+    assert out.shape == (4,) and torch.allclose(out.cpu().double(), ref.detach(), rtol=2e-6, atol=0)
+    up = torch.tensor([2.0, 0.5, 3.0, 1.5])
+    (ref * up.double()).sum().backward()
+    (out * up.to(dev)).sum().backward()
+    got, want = y.grad.float().cpu().double(), ref_y.grad
+    scale = want.abs().max()
+    tol = 2e-6 if dtype == 'fp32' else 2.0 ** -8                                        # bf16 gradient: one rounding of each entry
+    assert ((got - want).abs() <= tol * want.abs() + 1e-7 * scale).all(), (got - want).abs().max() / scale
+    # the raw kernel output: padded columns are zero, and the same bits on a second run (fixed-order sums)
+    dyp = L.iuv_losses_bwd(y.detach(), imgd, w, up.to(dev), 128)
+    assert dyp.shape == (B * H * W, 128) and not dyp[:, 90:].any() and torch.equal(dyp[:, :90].reshape(B, H, W, 90), y.grad)
+    assert torch.equal(L.iuv_losses(y.detach(), imgd, w), out.detach())
+    with pytest.raises(AssertionError):
+        L.iuv_losses(y.detach()[..., :89], imgd, w)
+
+
+def test_iuv_losses_fused_path_through_the_head_convolution(dev):
+    """IUV head conv (ConvNHWCFn, one implicit GEMM over 90 channels) -> losses: the fused node (its padded gradient handed to the convolution's
+    backward as is) against the map form (lazy NCHW fp32 views -> body_uv_losses through torch autograd) on the same weights and features."""
+    from whmr_amd.train import heads_autograd as HA
+    from whmr_amd.train.aux_supervision import IUVHeadOutput, aux_supervision_loss
+    from whmr_amd.utils.iuvmap import iuv_img2map
+    g = torch.Generator().manual_seed(7)
+    B, H, W, Cin = 2, 16, 12, 256
+    x = (torch.randn(B, H, W, Cin, generator=g) * 0.5).to(dev).bfloat16()
+    part = torch.randint(0, 25, (B, H, W), generator=g).float()
+    img = torch.stack([part / 24.0, torch.rand(B, H, W, generator=g), torch.rand(B, H, W, generator=g)], 1).to(dev)
+    res = []
+    for fused in (True, False):
+        wt = (torch.randn(90, Cin, 3, 3, generator=torch.Generator().manual_seed(9)) * 0.02).to(dev).requires_grad_(True)
+        bs = torch.zeros(90, device=dev).requires_grad_(True)
+        xin = x.clone().requires_grad_(True)
+        d = IUVHeadOutput(HA.ConvNHWCFn.apply(xin, wt, 1, torch.bfloat16, 1, bs))
+        assert set(d) == set(IUVHeadOutput.KEYS) and dict.__len__(d) == 0              # nothing materialised yet
+        loss = aux_supervision_loss([d], None if fused else iuv_img2map(img), iuv_image_gt=img if fused else None)
+        assert dict.__len__(d) == (0 if fused else 4)
+        loss.backward()
+        assert not HA._PADDED_GRADS                                                     # the handed-over operand was consumed
+        res.append((loss.item(), wt.grad.clone(), bs.grad.clone(), xin.grad.float().clone()))
+    assert d['predict_u'].shape == (B, 25, H, W) and d['predict_ann_index'].shape == (B, 15, H, W) and d['predict_u'].dtype == torch.float32
+    (lf, wf, bf, xf), (lm, wm, bm, xm) = res
+    assert abs(lf - lm) < 1e-5 * abs(lm)
+    for a, b in ((wf, wm), (bf, bm), (xf, xm)):                                          # same bf16 operand roundings up to the order of one sum
+        assert (a - b).abs().max() <= 2e-2 * b.abs().max() and (a - b).norm() <= 5e-3 * b.norm()

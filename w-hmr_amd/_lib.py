@@ -117,6 +117,8 @@ _SIGS = {
     'whmr_attention_bwd_f32': [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
     'whmr_scale_rows_cast': [_P, _P, _P, _I, _I, _I, _P],
     'whmr_iuv_rasterize': [_P, _I, _I, _P, _I, _P, _I, _P, _P, _F, _F, _F, _F, _F, _I, _I, _I, _I, _P, _P, _P, _P, _P],
+    'whmr_iuv_losses': [_P, _I, _L, _P, _L, _L, _L, _L, _I, _I, _I, _F, _P, _P, _P],
+    'whmr_iuv_losses_bwd': [_P, _I, _L, _P, _L, _L, _L, _L, _I, _I, _I, _F, _P, _P, _L, _P],
     'whmr_maxpool_nhwc': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'whmr_avgpool_nhwc': [_P, _P, _I, _I, _I, _I, _P],
 }
@@ -375,6 +377,39 @@ def iuv_rasterize(verts, faces, tex, cam, K, focal, orig_size, out_size, vmap=No
                                     K[0], K[1], K[2], K[3], focal, orig_size[0], orig_size[1], H, W, scr.data_ptr(), zbuf.data_ptr(), out.data_ptr(),
                                     _ptr(fo), _stream()), 'whmr_iuv_rasterize')
     return (out, fo) if want_faces else out
+
+
+def _iuv_loss_args(y, iuv):
+    """y [B, H, W, 90] logits whose pixels are rows of one [B*H*W, ld] matrix (ConvNHWCFn's padded output view); iuv [B, 3, H, W] fp32, any strides"""
+    _dev(y, iuv)
+    B, H, W, Cc = y.shape
+    ld = y.stride(2)
+    assert Cc == 90 and y.stride(3) == 1 and y.stride(1) == W * ld and y.stride(0) == H * W * ld and y.dtype in (torch.float32, torch.bfloat16)
+    assert iuv.dtype == torch.float32 and tuple(iuv.shape) == (B, 3, H, W)
+    return (y.data_ptr(), int(y.dtype == torch.bfloat16), ld, iuv.data_ptr()) + tuple(iuv.stride()) + (B, H, W)
+
+
+def iuv_losses(y, iuv, point_weight):
+    """(loss_U, loss_V, loss_IndexUV, loss_segAnn) [4] of core/trainer.py:255-298 from the IUV head's channels-last logits (u 25 | v 25 | index 25 |
+    ann 15) and the rendered ground-truth IUV image (include/whmr_hip.h: whmr_iuv_losses)."""
+    a = _iuv_loss_args(y, iuv)
+    P = y.shape[0] * y.shape[1] * y.shape[2]
+    partial = torch.empty((P + 127) // 128 * 4, dtype=torch.float32, device=y.device)
+    out = torch.empty(4, dtype=torch.float32, device=y.device)
+    _check(lib().whmr_iuv_losses(*a, float(point_weight), partial.data_ptr(), out.data_ptr(), _stream()), 'whmr_iuv_losses')
+    return out
+
+
+def iuv_losses_bwd(y, iuv, point_weight, g, ldg):
+    """gradient of sum_k g[k] * loss_k with respect to y -> [B*H*W, ldg] in y's dtype, columns >= 90 zero"""
+    a = _iuv_loss_args(y, iuv)
+    _dev(g)
+    g = _f32c(g.contiguous())
+    assert g.numel() == 4 and ldg >= 90
+    P = y.shape[0] * y.shape[1] * y.shape[2]
+    dy = torch.empty(P, ldg, dtype=y.dtype, device=y.device)
+    _check(lib().whmr_iuv_losses_bwd(*a, float(point_weight), g.data_ptr(), dy.data_ptr(), ldg, _stream()), 'whmr_iuv_losses_bwd')
+    return dy
 
 
 def layernorm(x, weight, bias, out, eps):

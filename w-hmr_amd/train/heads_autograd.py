@@ -120,6 +120,17 @@ class AttentionF32Fn(torch.autograd.Function):
         return L.attention_bwd_f32(qkv, _f32(dout), B, N, H, d, scale), None, None, None, None, None
 
 
+# A producer that already holds the gradient of a ConvNHWCFn output as the zero-padded [M, npad] matrix (IUVLossFn: csrc/iuv_loss.hip writes it
+# that way) leaves it here, keyed by the address of the [..., :Cout] view it returns to autograd; the convolution's backward then skips the
+# zero-fill + copy that rebuilds that operand.  At most one entry is alive (a new offer drops the previous one).
+_PADDED_GRADS = {}
+
+
+def offer_padded_grad(view, padded):
+    _PADDED_GRADS.clear()
+    _PADDED_GRADS[view.data_ptr()] = padded
+
+
 class ConvNHWCFn(torch.autograd.Function):
     """y [B,OH,OW,Cout] (dt) = ConvNHWCFn.apply(x [B,IH,IW,Cin] (dt), weight [Cout,Cin,KH,KW], stride, dt, padding=0, bias=None): Conv2d on a
     channels-last map (Tz head: 7x7 s3 / s2 without bias or padding, whmr.py:419-420; IUV head: 3x3 s1 p1 with bias, iuv_predictor.py:71-91)."""
@@ -156,7 +167,12 @@ class ConvNHWCFn(torch.autograd.Function):
         B, IH, IW, Cin, Cout, KH, KW, OH, OW, S, P, npad, dt = ctx.dims
         dev = x.device
         M, K = B * OH * OW, KH * KW * Cin
-        if npad != Cout:
+        dyp = _PADDED_GRADS.pop(dy.data_ptr(), None) if npad != Cout else None
+        if dyp is not None and (tuple(dyp.shape) != (M, npad) or dyp.dtype != dt or dy.stride(-2) != npad or dyp.device != dev):
+            dyp = None
+        if dyp is not None:
+            pass
+        elif npad != Cout:
             dyp = torch.zeros(M, npad, dtype=dt, device=dev)
             dyp[:, :Cout] = dy.reshape(M, Cout)
         else:

@@ -32,6 +32,7 @@ import torch.nn.functional as F
 from .. import _lib as L
 from ..core.cfgs import cfg
 from ..core.constants import FOCAL_LENGTH
+from .aux_supervision import IUVHeadOutput
 from .deconv_autograd import DeconvBNReLUFn
 from .heads_autograd import AttentionF32Fn, ConvNHWCFn, DownsampleFn, GeluFn, LayerNormFn, LinearFn, RegressorPostFn
 from .maf_autograd import MAFSampleFn
@@ -103,10 +104,8 @@ def dp_head_train(model, f_nhwc):
     convs = (h.predict_u, h.predict_v, h.predict_uv_index, h.predict_ann_index)
     w = torch.cat([c.weight for c in convs], 0)
     b = torch.cat([c.bias for c in convs], 0)
-    y = ConvNHWCFn.apply(f_nhwc, w, 1, model._dt, convs[0].padding[0], b).float()
-    u, v, idx, ann = torch.split(y, [c.out_channels for c in convs], dim=-1)
-    nchw = lambda t: t.permute(0, 3, 1, 2)
-    return {'predict_uv_index': nchw(idx), 'predict_ann_index': nchw(ann), 'predict_u': nchw(u), 'predict_v': nchw(v)}
+    y = ConvNHWCFn.apply(f_nhwc, w, 1, model._dt, convs[0].padding[0], b)
+    return IUVHeadOutput(y, [c.out_channels for c in convs])                           # the four NCHW fp32 views appear on first access
 
 
 def regressor_post_train(joints, cam_n, Tz, bbox_height, center, orig_shape):
@@ -242,7 +241,7 @@ def whmr_forward_train(model, x, center, scale, bbox_height, orig_shape, bbox_in
     if heavy is not None:                                                              # join
         main.wait_stream(heavy)
         if not torch.cuda.is_current_stream_capturing():
-            for v in (v for d in dp_out for v in d.values()):
-                v.record_stream(main)
+            for d in dp_out:
+                d.nhwc.record_stream(main)
     vis_feat = [s_feat.detach()] + [m.detach().permute(0, 3, 1, 2) for m in fmaps]
     return {'smpl_out': outs, 'dp_out': dp_out, 'dpth_out': [], 'global_output': g_out}, vis_feat
