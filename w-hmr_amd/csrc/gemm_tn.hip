@@ -217,10 +217,16 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
     const int m = (int)(idx / n4), n = (int)(idx - (long)m * n4) * 4;
     const size_t stride = (size_t)Mo * No;
     const float* w = ws + (size_t)m * No + n;
+    // slices are added in slice order (same bits whatever the batching); 8 loads are in flight at a time -- one dependent load per slice made
+    // this pass latency-bound (13.5 us for the 9 slices of a 768 x 2304 gradient)
     float4 a = *(const float4*)w;
-    for (int s = 1; s < splits; ++s) {
-        const float4 b = *(const float4*)(w + s * stride);
-        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    for (int s0 = 1; s0 < splits; s0 += 8) {
+        float4 b[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) b[j] = s0 + j < splits ? *(const float4*)(w + (size_t)(s0 + j) * stride) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (s0 + j < splits) { a.x += b[j].x; a.y += b[j].y; a.z += b[j].z; a.w += b[j].w; }
     }
     *(float4*)(C + (size_t)m * ldc + n) = a;
 }

@@ -283,23 +283,31 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     }
 }
 
-__global__ __launch_bounds__(256) void layernorm_bwd_final_kernel(const float* __restrict__ partial, int nparts, int C, float* __restrict__ dgamma,
-                                                                  float* __restrict__ dbeta, int accumulate) {
-    __shared__ float red[4][64];
-    const int i = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
-    const int per = (nparts + 3) / 4;
+// 16 waves per 64 columns: each adds a contiguous 1/16 of the partial rows (64 loads deep, was 256 with 4 waves: 13.5 us, latency-bound), then a
+// fixed-order tree over the 16 sums
+__global__ __launch_bounds__(1024) void layernorm_bwd_final_kernel(const float* __restrict__ partial, int nparts, int C, float* __restrict__ dgamma,
+                                                                   float* __restrict__ dbeta, int accumulate) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, i = blockIdx.x * 64 + lane, part = threadIdx.x >> 6;
+    const int per = (nparts + 15) / 16;
     float a = 0.f;
     if (i < 2 * C) {
         const int p1 = min(nparts, (part + 1) * per);
-#pragma unroll 8
+#pragma unroll 16
         for (int p = part * per; p < p1; ++p) a += partial[(size_t)p * 2 * C + i];
     }
-    red[part][threadIdx.x & 63] = a;
+    red[part][lane] = a;
     __syncthreads();
     if (part == 0 && i < 2 * C) {
-        const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        float v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = red[k][lane];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1)
+#pragma unroll
+            for (int k = 0; k < o; ++k) v[k] += v[k + o];
         float* dst = i < C ? dgamma + i : dbeta + (i - C);
-        *dst = accumulate ? *dst + v : v;
+        *dst = accumulate ? *dst + v[0] : v[0];
     }
 }
 
@@ -313,7 +321,7 @@ extern "C" int whmr_layernorm_bwd(const float* x, const float* dy, const float* 
     const size_t lds = (size_t)8 * C * sizeof(float);
     if (C <= 64 * 4 * 3) hipLaunchKernelGGL(layernorm_bwd_kernel<3>, dim3(nblk), dim3(256), lds, st, x, dy, gamma, dres, dx, scratch, rows, C, eps);
     else hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(nblk), dim3(256), lds, st, x, dy, gamma, dres, dx, scratch, rows, C, eps);
-    hipLaunchKernelGGL(layernorm_bwd_final_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, st, scratch, nblk, C, dgamma, dbeta, accumulate);
+    hipLaunchKernelGGL(layernorm_bwd_final_kernel, dim3((2 * C + 63) / 64), dim3(1024), 0, st, scratch, nblk, C, dgamma, dbeta, accumulate);
     WHMR_CHECK_LAUNCH();
     return 0;
 }

@@ -21,14 +21,23 @@ from .. import _lib as L
 USE_TN = os.environ.get('WHMR_TN_GEMM', '1') != '0'      # weight gradients on the gathering TN kernel (A/B switch)
 
 
+_PHASE_INDEX = {}
+
+
 def _phase_weights(w, dt):
-    """ConvTranspose2d weight [Cin, Cout, 4, 4] -> 4 sub-pixel phase matrices [4, Cout, 4*Cin], k = (a, b, ci) (whmr.py:488-495)."""
-    phases = []
-    for py in range(2):
-        for px in range(2):
-            taps = [w[:, :, 3 - py - 2 * a, 3 - px - 2 * b] for a in range(2) for b in range(2)]          # each [Cin, Cout]
-            phases.append(torch.stack(taps, 0).permute(2, 0, 1).reshape(w.shape[1], -1))
-    p = torch.stack(phases, 0).contiguous()
+    """ConvTranspose2d weight [Cin, Cout, 4, 4] -> 4 sub-pixel phase matrices [4, Cout, 4*Cin], k = (a, b, ci) (whmr.py:488-495):
+    wp[2 py + px, co, (a, b, ci)] = w[ci, co, 3 - py - 2a, 3 - px - 2b].  ONE gather (cached index arrays) + the cast -- the weights change every
+    step, and the stack-of-slices form was ~20 launches per deconv."""
+    Cout = w.shape[1]
+    key = (w.device, Cout)
+    idx = _PHASE_INDEX.get(key)
+    if idx is None:
+        two = torch.arange(2, device=w.device)
+        ky = (3 - two.view(2, 1, 1, 1, 1) - 2 * two.view(1, 1, 1, 2, 1)).expand(2, 2, Cout, 2, 2)      # [py, px, co, a, b]
+        kx = (3 - two.view(1, 2, 1, 1, 1) - 2 * two.view(1, 1, 1, 1, 2)).expand(2, 2, Cout, 2, 2)
+        co = torch.arange(Cout, device=w.device).view(1, 1, Cout, 1, 1).expand(2, 2, Cout, 2, 2)
+        idx = _PHASE_INDEX[key] = (ky.contiguous(), kx.contiguous(), co.contiguous())
+    p = w.permute(2, 3, 1, 0)[idx].reshape(4, Cout, -1)             # [py, px, co, a, b, ci] -> [4, Cout, 4 * Cin]
     return L.cast_bf16(p) if dt == torch.bfloat16 else p
 
 
