@@ -40,6 +40,9 @@ struct whmr_gemm {
      * phase = 2*py + px: W += phase*phase_w_stride; PH -= py; PW -= px; c_off += py*phase_cy + px*phase_cx. */
     int32_t n_phase;
     int32_t epi_flags;      /* bit 0: residual is bf16 (else fp32); bit 1: residual is added BEFORE the activation (ResNet blocks);
+                             * bit 2 (bf16 kernel, c_mode 1, bf16 residual and output): the residual is addressed like C (c_off / osb / osy / osx) --
+                             * with residual == C the scattered result is ACCUMULATED in place (data gradient of a strided convolution added to
+                             * the gradient other consumers of the same map already left there);
                              * bit 3 (bf16 gather): K is ordered (ci chunk of 64, ky, kx, ci in chunk) instead of (ky, kx, ci): all taps of one
                              * 64-channel slice are walked before the next slice, so the window overlap of a large-kernel conv on a map that
                              * exceeds the Infinity Cache is re-read from cache instead of HBM (Tz-head 7x7 s3 conv) */

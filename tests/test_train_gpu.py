@@ -799,3 +799,41 @@ def test_vit_node_publishes_gradients_to_the_reducer(dev):
     assert len(red.buckets) >= 3
     for a, b in zip(got, ref):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float32])
+def test_passthrough_nodes_accumulate_the_data_gradient_in_place(dev, dt):
+    """ConvNHWCFn / DeconvBNReLUFn with ``passthrough``: the input map is handed on as a second output, and the gradient that comes back on it
+    receives the node's own data gradient in the GEMM epilogue (row-major: residual == C; strided convolution: the scattered in-place
+    accumulate, epi_flags bit 2; fp32 strided: the separate-tensor fallback).  Same input gradient as the two-consumer graph autograd sums."""
+    from whmr_amd.train.deconv_autograd import DeconvBNReLUFn
+    from whmr_amd.train.heads_autograd import ConvNHWCFn
+    g = torch.Generator().manual_seed(3)
+    B, Cin = 2, 256
+    tol = 2.0 ** -6 if dt == torch.bfloat16 else 1e-5
+    bn = torch.nn.BatchNorm2d(256).to(dev).train()
+    ctw = (torch.randn(Cin, 256, 4, 4, generator=g) * 0.03).to(dev)
+    cases = [('tz 7x7 s3', lambda x, pt: ConvNHWCFn.apply(x, cw7, 3, dt, 0, None, pt), (31, 25)),
+             ('iuv 3x3 same', lambda x, pt: ConvNHWCFn.apply(x, cw3, 1, dt, 1, cb3, pt), (16, 12)),
+             ('deconv', lambda x, pt: DeconvBNReLUFn.apply(x, ctw, bn.weight, bn.bias, bn, dt, pt), (8, 6))]
+    cw7 = (torch.randn(64, Cin, 7, 7, generator=g) * 0.02).to(dev)
+    cw3 = (torch.randn(90, Cin, 3, 3, generator=g) * 0.02).to(dev)
+    cb3 = torch.zeros(90, device=dev)
+    for name, fn, (H, W) in cases:
+        x0 = (torch.randn(B, H, W, Cin, generator=g) * 0.5).to(dev).to(dt)
+        gx = torch.randn(B, H, W, Cin, generator=g).to(dev)
+        grads = []
+        for pt in (True, False):
+            x = x0.clone().requires_grad_(True)
+            out = fn(x, pt)
+            y, x2 = out if pt else (out, x)
+            assert not pt or (x2.data_ptr() == x.data_ptr() and x2.shape == x.shape)       # the same map, no copy
+            gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(11)).to(dev)
+            ((y.float() * gy).sum() + (x2.float() * gx).sum()).backward()
+            grads.append(x.grad.float())
+        a, b = grads
+        assert (a - b).abs().max() <= tol * b.abs().max(), (name, ((a - b).abs().max() / b.abs().max()).item())
+        # the handed-on map alone (its first output unused): the gradient passes through untouched
+        x = x0.clone().requires_grad_(True)
+        (fn(x, True)[1].float() * gx).sum().backward()
+        assert torch.equal(x.grad.float(), gx.to(dt).float()), name

@@ -182,12 +182,17 @@ PROFILE = None        # bench.py sets this to a list: (kernel, flops, start_even
 
 
 def gemm(a, w, out, bias=None, residual=None, res_row_mod=0, act=ACT_NONE, conv=None, scatter=None, M=None,
-         lda=None, glds=True, tile=None, phases=None, res_first=False, splits=None, row_scale=None):
+         lda=None, glds=True, tile=None, phases=None, res_first=False, splits=None, row_scale=None, accumulate=False):
     """out = act(a . w^T + bias) + residual.  a/w dtype selects the kernel (bf16 MFMA or exact-fp32 MFMA).
 
     conv = dict(IH, IW, Cin, OH, OW, KW, SH, SW, PH, PW): a is an NHWC image [B, IH, IW, Cin], rows are output pixels.
     scatter = dict(c_off, osb, osy, osx): row (b, oy, ox) is written at that offset of ``out`` (needs conv dims).
+    accumulate: out += a . w^T (+ bias) in place -- ``out`` is its own residual, also in scatter mode (bf16 kernel: epi_flags bit 2).
     """
+    if accumulate:
+        assert residual is None and row_scale is None and act == ACT_NONE and out.dtype == a.dtype
+        assert scatter is None or a.dtype == torch.bfloat16, 'the scattered in-place accumulate exists in the bf16 kernel only'
+        residual = out
     _dev(a, w, out, bias, residual)
     assert a.dtype == w.dtype and a.dtype in (torch.bfloat16, torch.float32)
     assert a.is_contiguous() or lda is not None
@@ -203,6 +208,8 @@ def gemm(a, w, out, bias=None, residual=None, res_row_mod=0, act=ACT_NONE, conv=
         assert residual.dtype in (torch.float32, torch.bfloat16) and residual.stride(-1) == 1
         p.ldr = residual.stride(-2)
         p.epi_flags = (1 if residual.dtype == torch.bfloat16 else 0) | (2 if res_first else 0)
+        if accumulate and scatter is not None:
+            p.ldr, p.epi_flags = 8, p.epi_flags | 4                     # the residual is addressed like the scattered output
         assert residual.dtype == torch.float32 or a.dtype == torch.bfloat16, 'bf16 residuals exist in the bf16 kernel only'
     p.res_row_mod = res_row_mod
     p.act = act

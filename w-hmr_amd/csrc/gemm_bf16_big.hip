@@ -485,7 +485,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
                         const int m = m0 + (within >> 5) * cfg::WTM + (i0 + pi) * 32 + (within & 31);
                         if (m >= m_end || col >= p.N) continue;
                         const uint4 v = *(const uint4*)(smem + lr * ROWB + chunk * 16);
-                        const uint4 sk = *(const uint4*)((const bf16_t*)p.residual + (size_t)m * p.ldr + col);
+                        // epi_flags bit 2: the skip tensor is laid out like C (scatter mode: the in-place accumulate of a data gradient)
+                        const uint4 sk = *(const uint4*)((const bf16_t*)p.residual + ((p.epi_flags & 4) ? row_addr(m) : (size_t)m * p.ldr) + col);
                         const uint32_t a[4] = {v.x, v.y, v.z, v.w}, b[4] = {sk.x, sk.y, sk.z, sk.w};
                         uint32_t o[4];
 #pragma unroll
@@ -730,6 +731,10 @@ extern "C" int whmr_gemm_bf16_big(const whmr_gemm* pp, int tile, void* stream) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % 64)) return (int)hipErrorInvalidValue;
     if (p.a_mode == 1 && (p.Cin % 64 || !p.zeros)) return (int)hipErrorInvalidValue;
     if (p.a_mode == 0 && (p.lda % 8)) return (int)hipErrorInvalidValue;
+    // a skip tensor addressed like a scattered C exists on the packed bf16 epilogue only (bf16 in, bf16 out, no split-K, no row factors)
+    if ((p.epi_flags & 4) && !(p.residual && (p.epi_flags & 1) && p.out_bf16 && p.c_mode == 1 && !(p.N & 7) && !(p.ldr & 7) && p.res_row_mod == 0 &&
+                               !p.row_scale && !p.split_k && !(p.act == 1 && (p.epi_flags & 2))))
+        return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
     switch (tile) {
         case 65: return launch_big_mode<128, 64, 64, 2, 1, 2, 2, 0>(p, st);       // 48 KiB, 2 waves: narrow-N convs (N <= 64), 3 blocks / CU

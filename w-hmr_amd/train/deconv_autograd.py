@@ -73,8 +73,9 @@ def deconv_forward_train(x_nhwc, weight, gamma, beta, bn, dt, update_running=Tru
 
 
 @torch.no_grad()
-def deconv_backward(saved, weight, dy, dt, need_dx=True, dx_dtype=None):
-    """dy [B,2H,2W,Cout] (dt or fp32) -> (dx [B,H,W,Cin] or None, dW [Cin,Cout,4,4] fp32, dgamma [Cout], dbeta [Cout])."""
+def deconv_backward(saved, weight, dy, dt, need_dx=True, dx_dtype=None, dx_into=None):
+    """dy [B,2H,2W,Cout] (dt or fp32) -> (dx [B,H,W,Cin] or None, dW [Cin,Cout,4,4] fp32, dgamma [Cout], dbeta [Cout]).
+    ``dx_into`` [B,H,W,Cin] (contiguous, the dx dtype): the data gradient is ADDED to it in the GEMM epilogue and it is returned as dx."""
     x, z, stats = saved
     B, H, W, Cin = x.shape
     Cout = z.shape[-1]
@@ -104,23 +105,33 @@ def deconv_backward(saved, weight, dy, dt, need_dx=True, dx_dtype=None):
         wd = weight.detach().float().permute(0, 2, 3, 1).reshape(Cin, 16 * Cout).contiguous()       # [ci, (ky,kx,co)]
         if dt == torch.bfloat16:
             wd = L.cast_bf16(wd)
-        dx = torch.empty(B, H, W, Cin, dtype=dx_dtype or dt, device=dev)
-        L.gemm(dz, wd, dx.view(M, Cin), conv=dict(IH=2 * H, IW=2 * W, Cin=Cout, OH=H, OW=W, KW=4, SH=2, SW=2, PH=1, PW=1))
+        acc = dx_into is not None and dx_into.dtype == dt and dx_into.is_contiguous() and tuple(dx_into.shape) == (B, H, W, Cin)
+        dx = dx_into if acc else torch.empty(B, H, W, Cin, dtype=dx_dtype or dt, device=dev)
+        L.gemm(dz, wd, dx.view(M, Cin), conv=dict(IH=2 * H, IW=2 * W, Cin=Cout, OH=H, OW=W, KW=4, SH=2, SW=2, PH=1, PW=1), accumulate=acc)
+        if dx_into is not None and not acc:
+            dx = dx + dx_into.to(dx.dtype)
+    elif dx_into is not None:
+        dx = dx_into
     return dx, dW, dg, db
 
 
 class DeconvBNReLUFn(torch.autograd.Function):
-    """y = DeconvBNReLUFn.apply(x_nhwc, ct.weight, bn.weight, bn.bias, bn, dt): autograd node of one deconv stage."""
+    """y = DeconvBNReLUFn.apply(x_nhwc, ct.weight, bn.weight, bn.bias, bn, dt): autograd node of one deconv stage.
+    ``passthrough=True`` -> (y, x): the input map is handed on to its other consumer (the MAF sampler of that stage), whose gradient then arrives
+    here and receives this stage's data gradient in the GEMM epilogue -- no zero-filled map per consumer, no full-size add by autograd."""
 
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, bn, dt):
+    def forward(ctx, x, weight, gamma, beta, bn, dt, passthrough=False):
+        ctx.set_materialize_grads(False)
         y, saved = deconv_forward_train(x, weight, gamma, beta, bn, dt)
         ctx.saved, ctx.weight, ctx.dt = saved, weight, dt
         ctx.need_dx = ctx.needs_input_grad[0]
-        return y
+        return (y, x.detach().view_as(x)) if passthrough else y
 
     @staticmethod
-    def backward(ctx, dy):
-        dx, dW, dg, db = deconv_backward(ctx.saved, ctx.weight, dy, ctx.dt, need_dx=ctx.need_dx)
+    def backward(ctx, dy, dx_in=None):
+        if dy is None:
+            return dx_in, None, None, None, None, None, None
+        dx, dW, dg, db = deconv_backward(ctx.saved, ctx.weight, dy, ctx.dt, need_dx=ctx.need_dx, dx_into=dx_in if ctx.need_dx else None)
         ctx.saved = None
-        return dx, dW, dg, db, None, None
+        return dx, dW, dg, db, None, None, None

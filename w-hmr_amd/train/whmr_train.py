@@ -52,6 +52,7 @@ def _projection(joints, cam):
     return torch.stack([x, y], dim=-1)
 
 
+CHAIN_GRADS = os.environ.get('WHMR_CHAIN_GRADS', '1') != '0'      # feature maps handed from consumer to consumer (A/B switch), see whmr_forward_train
 OVERLAP_HEAVY = os.environ.get('WHMR_TRAIN_OVERLAP', '1') != '0'      # deconv 2 / 3 + Tz head + IUV head on a side stream beside the regressor loop
 _heavy_streams = {}
 
@@ -71,11 +72,16 @@ def _perspective_norm(joints, cam_t, focal, cam_center):
     return torch.stack([x, y], dim=-1) / cam_center[:, None, :] - 1.0
 
 
-def tz_head_train(model, f_nhwc):
-    """whmr.py:567-577 in training mode.  f_nhwc [B,128,96,256] in the compute dtype (detached by the caller when TRAIN.STAGE == 1)."""
+def tz_head_train(model, f_nhwc, passthrough=False):
+    """whmr.py:567-577 in training mode.  f_nhwc [B,128,96,256] in the compute dtype (detached by the caller when TRAIN.STAGE == 1).
+    ``passthrough``: -> (Tz, f_nhwc handed on by the first convolution's node, see ConvNHWCFn)."""
     dt = model._dt
     B = f_nhwc.shape[0]
-    y0 = ConvNHWCFn.apply(f_nhwc, model.conv[0].weight, 3, dt)
+    f_next = None
+    if passthrough:
+        y0, f_next = ConvNHWCFn.apply(f_nhwc, model.conv[0].weight, 3, dt, 0, None, True)
+    else:
+        y0 = ConvNHWCFn.apply(f_nhwc, model.conv[0].weight, 3, dt)
     y1 = ConvNHWCFn.apply(y0, model.conv[1].weight, 2, dt)                            # [B, 18, 12, 5]
     t = y1.float().permute(0, 3, 1, 2).reshape(B * 5, -1).contiguous()                 # == conv(...).reshape(B, 5, -1) on NCHW, whmr.py:571
     D = t.shape[-1]
@@ -94,18 +100,22 @@ def tz_head_train(model, f_nhwc):
     e = model.est_Tz
     y = _linear(_linear(s, e[0]), e[1])
     y = e[2](y)                                                                        # BatchNorm1d(1): batch statistics in train mode
-    return 10.0 * torch.sigmoid(y).squeeze(-1)
+    Tz = 10.0 * torch.sigmoid(y).squeeze(-1)
+    return (Tz, f_next) if passthrough else Tz
 
 
-def dp_head_train(model, f_nhwc):
+def dp_head_train(model, f_nhwc, passthrough=False):
     """IUV_predict_layer.forward (models/iuv_predictor.py:71-91, called at whmr.py:656-658 when AUX_SUPV_ON): four 3x3 convolutions of the last
-    feature map, run as ONE implicit GEMM over the concatenated output channels (25 + 25 + 25 + 15); NCHW views of the NHWC result."""
+    feature map, run as ONE implicit GEMM over the concatenated output channels (25 + 25 + 25 + 15); NCHW views of the NHWC result.
+    ``passthrough``: -> (outputs, f_nhwc handed on by the convolution's node, see ConvNHWCFn)."""
     h = model.dp_head
     convs = (h.predict_u, h.predict_v, h.predict_uv_index, h.predict_ann_index)
     w = torch.cat([c.weight for c in convs], 0)
     b = torch.cat([c.bias for c in convs], 0)
-    y = ConvNHWCFn.apply(f_nhwc, w, 1, model._dt, convs[0].padding[0], b)
-    return IUVHeadOutput(y, [c.out_channels for c in convs])                           # the four NCHW fp32 views appear on first access
+    y = ConvNHWCFn.apply(f_nhwc, w, 1, model._dt, convs[0].padding[0], b, passthrough)
+    y, f_next = y if passthrough else (y, None)
+    out = IUVHeadOutput(y, [c.out_channels for c in convs])                            # the four NCHW fp32 views appear on first access
+    return (out, f_next) if passthrough else out
 
 
 def regressor_post_train(joints, cam_n, Tz, bbox_height, center, orig_shape):
@@ -160,36 +170,52 @@ def whmr_forward_train(model, x, center, scale, bbox_height, orig_shape, bbox_in
 
     s_feat = model.feature_extractor(x)                                               # [B,768,Hp,Wp] view of NHWC tokens, ViTFn node
     f = s_feat.permute(0, 2, 3, 1).contiguous().to(dt)
-    def deconv(i, f):
+    aux = bool(cfg.MODEL.PyMAF.AUX_SUPV_ON and hasattr(model, 'dp_head'))
+    tz_grad = int(cfg.TRAIN.STAGE) != 1                                               # stage 1 trains the Tz head on a detached map
+
+    # Every feature map has two or three consumers (the next deconv stage or the two heads, and the stage's sampler).  With CHAIN_GRADS a map is
+    # handed from one consumer's node to the next (deconv / head convolution -> sampler; DeconvBNReLUFn / ConvNHWCFn ``passthrough``): in the
+    # backward pass each data gradient is then added, in the GEMM epilogue, to the gradient the consumers behind it left on the map, instead of
+    # autograd summing full-size maps (two 0.2 ms adds on the last map alone at batch 64).
+    def deconv(i, f, chain=True):
         ct, bn = model.deconv_layers[3 * i], model.deconv_layers[3 * i + 1]
         assert ct.bias is None
-        return DeconvBNReLUFn.apply(f, ct.weight, bn.weight, bn.bias, bn, dt)
+        if chain and CHAIN_GRADS:
+            return DeconvBNReLUFn.apply(f, ct.weight, bn.weight, bn.bias, bn, dt, True)            # (y, f handed on)
+        return DeconvBNReLUFn.apply(f, ct.weight, bn.weight, bn.bias, bn, dt), f
 
-    aux = bool(cfg.MODEL.PyMAF.AUX_SUPV_ON and hasattr(model, 'dp_head'))
+    def tz_head(fm):
+        if not tz_grad:
+            return tz_head_train(model, fm.detach()), fm
+        return tz_head_train(model, fm, True) if CHAIN_GRADS else (tz_head_train(model, fm), fm)
+
+    def dp_head(fm):                                                                   # whmr.py:656-658
+        return dp_head_train(model, fm, True) if CHAIN_GRADS else (dp_head_train(model, fm), fm)
+
     # Stage i of the regressor loop only reads feature map i, and the Tz head only enters the stages' projections (whmr.py:142-173), not the
     # next stage's input: after the first deconv stage the HEAVY chain (deconv 2, deconv 3, Tz head, IUV head: a few large launches) runs on a
     # side stream and the loop (hundreds of small launches) beside it on the main one; the Tz-dependent projections of the three stages follow
     # the join.  autograd runs every node's backward on the stream of its forward, so the backward pass overlaps the same way.
-    fmaps, dp_out, map_ready = [deconv(0, f)], [], [None, None, None]
+    fmaps, dp_out, map_ready = [deconv(0, f, chain=False)[0]], [], [None, None, None]
     heavy = None
     if OVERLAP_HEAVY:
         main = torch.cuda.current_stream(dev)
         heavy = _heavy_stream(dev)
         heavy.wait_stream(main)
-        with torch.cuda.stream(heavy):
-            for i in (1, 2):
-                fmaps.append(deconv(i, fmaps[-1]))
+    with torch.cuda.stream(heavy if heavy is not None else torch.cuda.current_stream(dev)):
+        for i in (1, 2):
+            y, fmaps[-1] = deconv(i, fmaps[-1])
+            fmaps.append(y)
+            if heavy is not None:
                 map_ready[i] = torch.cuda.Event()
                 map_ready[i].record(heavy)
-            Tz = tz_head_train(model, fmaps[-1].detach() if int(cfg.TRAIN.STAGE) == 1 else fmaps[-1])
+        Tz, fmaps[-1] = tz_head(fmaps[-1])
+        if heavy is not None:
             tz_ready = torch.cuda.Event()
             tz_ready.record(heavy)
-            if aux:
-                dp_out = [dp_head_train(model, fmaps[-1])]                                 # whmr.py:656-658
-    else:
-        for i in (1, 2):
-            fmaps.append(deconv(i, fmaps[-1]))
-        Tz = tz_head_train(model, fmaps[-1].detach() if int(cfg.TRAIN.STAGE) == 1 else fmaps[-1])
+        if aux:
+            d, fmaps[-1] = dp_head(fmaps[-1])
+            dp_out = [d]
     for i in range(3):
         model.maf_extractor[i].im_feat = fmaps[i].detach().permute(0, 3, 1, 2)
 
@@ -236,8 +262,6 @@ def whmr_forward_train(model, x, center, scale, bbox_height, orig_shape, bbox_in
         g = model.regressor[0].smpl.run(smpl_output['pred_shape'], g_rotmat)
         g_out = {'global_pose': torch.cat([g_aa, smpl_output['pose'][:, 3:]], dim=1), 'global_shape': smpl_output['pred_shape'],
                  'global_rotmat': g_rotmat, 'global_kp_3d': g.joints, 'global_verts': g.vertices}
-    if heavy is None and aux:
-        dp_out = [dp_head_train(model, fmaps[-1])]                                     # whmr.py:656-658
     if heavy is not None:                                                              # join
         main.wait_stream(heavy)
         if not torch.cuda.is_current_stream_capturing():
