@@ -11,7 +11,7 @@ from torch.profiler import profile, ProfilerActivity
 
 import bench
 
-top = int(sys.argv[1]) if len(sys.argv) > 1 else 70
+top = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 70
 args = bench.parse(['--workload', 'whmr_train', '--no-cpu'])
 dev = torch.device('cuda:0')
 step = bench.build_workload(args, dev)[0]
@@ -36,5 +36,13 @@ for e in prof.events():
     agg[k][1] += 1
     total += t
 print('torch ops with device time in one training step: %.2f ms' % (total / 1e3))
+if '--by-count' in sys.argv:
+    byname = defaultdict(lambda: [0.0, 0])
+    for (name, shapes, where), (t, n) in agg.items():
+        byname[(name, shapes)][0] += t
+        byname[(name, shapes)][1] += n
+    for (name, shapes), (t, n) in sorted(byname.items(), key=lambda kv: -kv[1][1])[:top]:
+        print('x%-4d %8.1f us  %-34s %s' % (n, t, name[:34], shapes))
+    raise SystemExit(0)
 for (name, shapes, where), (t, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:top]:
     print('%8.1f us x%-3d %-28s %-70s %s' % (t, n, name[:28], shapes, where))
