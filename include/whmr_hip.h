@@ -43,6 +43,8 @@ struct whmr_gemm {
                              * bit 2 (bf16 kernel, c_mode 1, bf16 residual and output): the residual is addressed like C (c_off / osb / osy / osx) --
                              * with residual == C the scattered result is ACCUMULATED in place (data gradient of a strided convolution added to
                              * the gradient other consumers of the same map already left there);
+                             * bits 4 / 5 (whmr_gemm_f32, at most 1024 output rows, a_mode = c_mode = 0): A / W is given REDUCTION-MAJOR -- A as [K, lda >= M],
+                             * W as [K, N] dense -- the backward products of nn.Linear (dX = dY . W, dW = dY^T . X) without transposed copies;
                              * bit 3 (bf16 gather): K is ordered (ci chunk of 64, ky, kx, ci in chunk) instead of (ky, kx, ci): all taps of one
                              * 64-channel slice are walked before the next slice, so the window overlap of a large-kernel conv on a map that
                              * exceeds the Infinity Cache is re-read from cache instead of HBM (Tz-head 7x7 s3 conv) */

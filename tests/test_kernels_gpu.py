@@ -518,3 +518,32 @@ def test_gemm_bf16_staged_epilogue(dev, tile, act):
     L.gemm(a.to(dev), w.to(dev), out[:M], bias=bias.to(dev), act=act, tile=tile)
     assert _rel(out[:M].float().cpu(), ref) < 1e-2
     assert (out[M:] == 7.0).all()                                      # rows past M untouched
+
+
+@pytest.mark.parametrize('M,N,K', [(64, 1024, 2149), (229, 1024, 64), (70, 229, 207), (320, 216, 864), (1024, 2149, 64), (5, 3, 1)])
+def test_gemm_f32_reduction_major_operands(dev, M, N, K):
+    """whmr_gemm_f32 with epi_flags bits 4 / 5 (L.gemm trans_a / trans_w): the operand is given as [K, M] / [K, N] -- the forms dY, X and W
+    have in the backward products of nn.Linear -- against the float64 product, every combination, incl. rows that are only 4-byte aligned,
+    ragged tile edges in every dimension, the split-K route (K >= 256) and a bias"""
+    from whmr_amd import _lib as L
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g)
+    b = torch.randn(N, generator=g)
+    ref = (a.double() @ w.double().t() + b.double()).float()
+    ad, wd, bd = a.to(dev), w.to(dev), b.to(dev)
+    at, wt = ad.t().contiguous(), wd.t().contiguous()
+    base = L.gemm(ad, wd, torch.empty(M, N, device=dev), bias=bd)
+    for ta, tw in ((True, False), (False, True), (True, True)):
+        out = L.gemm(at if ta else ad, wt if tw else wd, torch.empty(M, N, device=dev), bias=bd, trans_a=ta, trans_w=tw)
+        err = (out.cpu() - ref).abs().max() / ref.abs().max()
+        assert err < 2e-6, (ta, tw, err.item())
+        assert torch.equal(out, base), (ta, tw)                        # same k order of the MFMA chain: the same bits as the row-major call
+    # a strided reduction-major A (a column block of a wider matrix, as dY of a fused multi-head Linear would be)
+    if M >= 8:
+        wide = torch.randn(K, M + 8, generator=g).to(dev)
+        out = L.gemm(wide[:, 4:4 + M], wd, torch.empty(M, N, device=dev), trans_a=True)
+        ref2 = (wide[:, 4:4 + M].t().double().cpu() @ w.double().t()).float()
+        assert (out.cpu() - ref2).abs().max() / ref2.abs().max() < 2e-6
+    with pytest.raises(RuntimeError):                                   # more than 1024 output rows: no reduction-major route
+        L.gemm(torch.randn(K, 1100, device=dev), wd, torch.empty(1100, N, device=dev), trans_a=True)

@@ -182,22 +182,29 @@ PROFILE = None        # bench.py sets this to a list: (kernel, flops, start_even
 
 
 def gemm(a, w, out, bias=None, residual=None, res_row_mod=0, act=ACT_NONE, conv=None, scatter=None, M=None,
-         lda=None, glds=True, tile=None, phases=None, res_first=False, splits=None, row_scale=None, accumulate=False):
+         lda=None, glds=True, tile=None, phases=None, res_first=False, splits=None, row_scale=None, accumulate=False,
+         trans_a=False, trans_w=False):
     """out = act(a . w^T + bias) + residual.  a/w dtype selects the kernel (bf16 MFMA or exact-fp32 MFMA).
 
     conv = dict(IH, IW, Cin, OH, OW, KW, SH, SW, PH, PW): a is an NHWC image [B, IH, IW, Cin], rows are output pixels.
     scatter = dict(c_off, osb, osy, osx): row (b, oy, ox) is written at that offset of ``out`` (needs conv dims).
     accumulate: out += a . w^T (+ bias) in place -- ``out`` is its own residual, also in scatter mode (bf16 kernel: epi_flags bit 2).
+    trans_a / trans_w (fp32, at most 1024 output rows): the operand is given REDUCTION-MAJOR -- a as [K, M], w as [K, N] (dense) -- so the
+    backward products of nn.Linear (dX = dY . W, dW = dY^T . X) read dY / X / W as they are (epi_flags bits 4 / 5, skinny kernel).
     """
+    if trans_a or trans_w:
+        assert a.dtype == torch.float32 and conv is None and scatter is None and phases is None and tile is None and lda is None and M is None
+        assert a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.is_contiguous()
+        assert (a.shape[0] if trans_a else a.shape[1]) == (w.shape[0] if trans_w else w.shape[1])
     if accumulate:
         assert residual is None and row_scale is None and act == ACT_NONE and out.dtype == a.dtype
         assert scatter is None or a.dtype == torch.bfloat16, 'the scattered in-place accumulate exists in the bf16 kernel only'
         residual = out
     _dev(a, w, out, bias, residual)
     assert a.dtype == w.dtype and a.dtype in (torch.bfloat16, torch.float32)
-    assert a.is_contiguous() or lda is not None
+    assert a.is_contiguous() or lda is not None or trans_a or trans_w
     assert w.is_contiguous() and w.dim() == (3 if phases else 2)
-    N, K = w.shape[-2:]
+    N, K = (w.shape[1], w.shape[0]) if trans_w else w.shape[-2:]
     p = WhmrGemm()
     p.A, p.W, p.C = a.data_ptr(), w.data_ptr(), out.data_ptr()
     p.bias = bias.data_ptr() if bias is not None else None
@@ -230,11 +237,14 @@ def gemm(a, w, out, bias=None, residual=None, res_row_mod=0, act=ACT_NONE, conv=
             assert a.dtype == torch.bfloat16
             p.epi_flags |= 8
         p.zeros = zero_page(a.device).data_ptr()
+    elif trans_a:
+        p.M, p.lda = a.shape[1], a.stride(0)
     else:
         p.M = (a.numel() // a.shape[-1]) if M is None else M
         p.lda = a.stride(-2) if lda is None else lda
         assert a.shape[-1] == K
     p.N, p.K = N, K
+    p.epi_flags |= (16 if trans_a else 0) | (32 if trans_w else 0)
     if phases is not None:                  # dict(cy, cx): 4 stacked phase matrices w[4, N, K] (sub-pixel deconv)
         assert a.dtype == torch.bfloat16 and conv is not None and scatter is not None and w.shape[0] == 4
         p.n_phase, p.phase_w_stride, p.phase_cy, p.phase_cx = 4, N * K, phases['cy'], phases['cx']

@@ -299,7 +299,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_big_kernel(const whmr_gemm p)
 #define SLD 33
 typedef float f32x4u_t __attribute__((ext_vector_type(4), aligned(4)));
 
-template <bool SPLIT>
+// TR: operands given REDUCTION-MAJOR (epi_flags bits 4 / 5): bit 0 -> A is [K, lda >= M], bit 1 -> W is [K, N] (dense).  The backward products of
+// nn.Linear (dX = dY . W: W as stored is the reduction-major operand; dW = dY^T . X: both are) then need no transposed copies -- the
+// tile is transposed on its way into LDS (16-B loads along the contiguous m / n, scalar LDS stores down a column of the padded tile).
+template <bool SPLIT, int TR = 0>
 __global__ __launch_bounds__(256) void gemm_f32_skinny_kernel(const whmr_gemm p, int k_per_split) {
     __shared__ float sA[64 * SLD];
     __shared__ float sB[64 * SLD];
@@ -323,23 +326,41 @@ __global__ __launch_bounds__(256) void gemm_f32_skinny_kernel(const whmr_gemm p,
         b_ptr[h] = W + (size_t)(b_ok[h] ? n0 + r : 0) * p.K + sk;
     }
     float ra[2][4], rb[2][4];
-    auto fetch = [&](int k0) {
+    // reduction-major operand: thread -> k rows (tid >> 4) and (tid >> 4) + 16, 4 consecutive m (or n) at (tid & 15) * 4
+    const int tk = tid >> 4, tc = (tid & 15) * 4;
+    auto fetch_t = [&](const float* __restrict__ src, long ld, int c0, int cmax, int k0, float (*r)[4]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = k0 + tk + 16 * h;
+            const float* q = src + (size_t)(k < k_end ? k : 0) * ld + c0 + tc;
+            if (k < k_end && c0 + tc + 4 <= cmax) {
+                const f32x4u_t v = *(const f32x4u_t*)q;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[h][e] = v[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[h][e] = (k < k_end && c0 + tc + e < cmax) ? q[e] : 0.f;
+            }
+        }
+    };
+    auto fetch_rm = [&](const float* const* ptr, const bool* ok, int k0, float (*r)[4]) {      // row-major operand: 4 consecutive k of one row
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             if (k0 + sk + 4 <= k_end) {                          // whole 16-B group inside the slice
-                const f32x4u_t va = a_ok[h] ? *(const f32x4u_t*)(a_ptr[h] + k0) : f32x4u_t{0.f, 0.f, 0.f, 0.f};
-                const f32x4u_t vb = b_ok[h] ? *(const f32x4u_t*)(b_ptr[h] + k0) : f32x4u_t{0.f, 0.f, 0.f, 0.f};
+                const f32x4u_t v = ok[h] ? *(const f32x4u_t*)(ptr[h] + k0) : f32x4u_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { ra[h][e] = va[e]; rb[h][e] = vb[e]; }
+                for (int e = 0; e < 4; ++e) r[h][e] = v[e];
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const bool in = k0 + sk + e < k_end;
-                    ra[h][e] = (in && a_ok[h]) ? a_ptr[h][k0 + e] : 0.f;
-                    rb[h][e] = (in && b_ok[h]) ? b_ptr[h][k0 + e] : 0.f;
-                }
+                for (int e = 0; e < 4; ++e) r[h][e] = (k0 + sk + e < k_end && ok[h]) ? ptr[h][k0 + e] : 0.f;
             }
         }
+    };
+    auto fetch = [&](int k0) {
+        if constexpr (TR & 1) fetch_t(A, p.lda, m0, p.M, k0, ra);
+        else fetch_rm(a_ptr, a_ok, k0, ra);
+        if constexpr (TR & 2) fetch_t(W, p.N, n0, p.N, k0, rb);
+        else fetch_rm(b_ptr, b_ok, k0, rb);
     };
     const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hi = lane >> 5;
     f32x16_t acc;
@@ -352,8 +373,10 @@ __global__ __launch_bounds__(256) void gemm_f32_skinny_kernel(const whmr_gemm p,
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                sA[(srow + 32 * h) * SLD + sk + e] = ra[h][e];
-                sB[(srow + 32 * h) * SLD + sk + e] = rb[h][e];
+                if constexpr (TR & 1) sA[(tc + e) * SLD + tk + 16 * h] = ra[h][e];
+                else sA[(srow + 32 * h) * SLD + sk + e] = ra[h][e];
+                if constexpr (TR & 2) sB[(tc + e) * SLD + tk + 16 * h] = rb[h][e];
+                else sB[(srow + 32 * h) * SLD + sk + e] = rb[h][e];
             }
         __syncthreads();
         if (k0 + SBK < k_end) fetch(k0 + SBK);                   // in flight under the MFMAs below
@@ -431,6 +454,8 @@ extern "C" int whmr_gemm_f32(const whmr_gemm* pp, int flags, void* stream) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return (int)hipErrorInvalidValue;
     const int tiles = ((p.M + FBM - 1) / FBM) * ((p.N + FBN - 1) / FBN);
     hipStream_t st = (hipStream_t)stream;
+    const int tr = (p.epi_flags >> 4) & 3;                  // reduction-major operands: the skinny kernel only
+    if (tr && !(p.M <= 1024 && p.a_mode == 0 && p.c_mode == 0)) return (int)hipErrorInvalidValue;
     if (p.M <= 1024 && p.a_mode == 0 && p.c_mode == 0) {
         // weight-streaming regime: ~2 blocks per CU so that the whole weight matrix is in flight at once
         const int tiles_n = (p.N + 63) / 64, tiles_m = (p.M + 63) / 64, tiles = tiles_n * tiles_m;
@@ -445,10 +470,18 @@ extern "C" int whmr_gemm_f32(const whmr_gemm* pp, int flags, void* stream) {
             int kps = (p.K + splits - 1) / splits;
             kps = (kps + SBK - 1) / SBK * SBK;
             splits = (p.K + kps - 1) / kps;
-            hipLaunchKernelGGL((gemm_f32_skinny_kernel<true>), dim3(tiles_n, splits, tiles_m), dim3(256), 0, st, p, kps);
+            const dim3 g(tiles_n, splits, tiles_m);
+            if (tr == 0) hipLaunchKernelGGL((gemm_f32_skinny_kernel<true, 0>), g, dim3(256), 0, st, p, kps);
+            else if (tr == 1) hipLaunchKernelGGL((gemm_f32_skinny_kernel<true, 1>), g, dim3(256), 0, st, p, kps);
+            else if (tr == 2) hipLaunchKernelGGL((gemm_f32_skinny_kernel<true, 2>), g, dim3(256), 0, st, p, kps);
+            else hipLaunchKernelGGL((gemm_f32_skinny_kernel<true, 3>), g, dim3(256), 0, st, p, kps);
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((long)p.M * p.N + 255) / 256)), dim3(256), 0, st, p, splits);
         } else {
-            hipLaunchKernelGGL((gemm_f32_skinny_kernel<false>), dim3(tiles_n, 1, tiles_m), dim3(256), 0, st, p, 0);
+            const dim3 g(tiles_n, 1, tiles_m);
+            if (tr == 0) hipLaunchKernelGGL((gemm_f32_skinny_kernel<false, 0>), g, dim3(256), 0, st, p, 0);
+            else if (tr == 1) hipLaunchKernelGGL((gemm_f32_skinny_kernel<false, 1>), g, dim3(256), 0, st, p, 0);
+            else if (tr == 2) hipLaunchKernelGGL((gemm_f32_skinny_kernel<false, 2>), g, dim3(256), 0, st, p, 0);
+            else hipLaunchKernelGGL((gemm_f32_skinny_kernel<false, 3>), g, dim3(256), 0, st, p, 0);
         }
         WHMR_CHECK_LAUNCH();
         return 0;

@@ -43,12 +43,21 @@ class LinearFn(torch.autograd.Function):
         dy = _f32(dy)
         dev = dy.device
         dx = dw = db = None
+        # dX = dY . W and dW = dY^T . X straight from dY / X / W as stored (reduction-major operands of the skinny fp32 kernel): no transposed
+        # copies -- three launches fewer per Linear, and the heads' backward is a chain of small launches on the critical stream
+        direct = w.shape[0] <= 1024 and x.shape[0] <= 1024
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            L.gemm(dy, L.transpose_cast(w, torch.float32, pad_to=1), dx)
+            if direct:
+                L.gemm(dy, w, dx, trans_w=True)
+            else:
+                L.gemm(dy, L.transpose_cast(w, torch.float32, pad_to=1), dx)
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
-            L.gemm(L.transpose_cast(dy, torch.float32, pad_to=1), L.transpose_cast(x, torch.float32, pad_to=1), dw)
+            if direct:
+                L.gemm(dy, x, dw, trans_a=True, trans_w=True)
+            else:
+                L.gemm(L.transpose_cast(dy, torch.float32, pad_to=1), L.transpose_cast(x, torch.float32, pad_to=1), dw)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = torch.empty(w.shape[0], dtype=torch.float32, device=dev)
             L.colsum(dy, db)

@@ -118,6 +118,24 @@ def dp_head_train(model, f_nhwc, passthrough=False):
     return (out, f_next) if passthrough else out
 
 
+class ResidualSplitFn(torch.autograd.Function):
+    """(a, b, c) = column blocks of ``dec + prev`` (whmr.py:122-126: pred_pose / pred_shape / pred_cam = the decoders' output + the previous stage's
+    estimate; ``prev`` is detached in the reference, whmr.py:586-592).  One add forward and one concatenation backward instead of three adds and,
+    per block, autograd's zero-filled [B, 229] map + copy + accumulation (24 small launches per step on the stream the loop's backward waits on)."""
+
+    @staticmethod
+    def forward(ctx, dec, prev, sizes):
+        ctx.set_materialize_grads(False)
+        ctx.sizes = sizes
+        return torch.split(dec.detach() + prev.detach(), sizes, dim=1)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        ref = next(g for g in gs if g is not None)
+        parts = [g if g is not None else ref.new_zeros(ref.shape[0], n) for g, n in zip(gs, ctx.sizes)]
+        return torch.cat(parts, dim=1), None, None
+
+
 def regressor_post_train(joints, cam_n, Tz, bbox_height, center, orig_shape):
     """whmr.py:142-173 in one launch (and one for the backward): kp_2d, focal = s.detach()*h*Tz/2, cam_t from pred_cam.detach(), kp_2d_w"""
     return RegressorPostFn.apply(joints, cam_n, Tz, bbox_height, center, orig_shape, int(cfg.TRAIN.STAGE),
@@ -136,9 +154,7 @@ def regressor_train(reg, ref, bbox_info, Tz, orig_shape, center, scale, bbox_hei
     # the three residual heads as ONE [229, 1024] Linear node (a third of the launches; torch.cat routes the gradients back to the three modules)
     dec = LinearFn.apply(h, torch.cat([reg.decpose.weight, reg.decshape.weight, reg.deccam.weight], 0),
                          torch.cat([reg.decpose.bias, reg.decshape.bias, reg.deccam.bias], 0))
-    pose_n = dec[:, :216] + pose
-    shape_n = dec[:, 216:226] + shape
-    cam_n = dec[:, 226:] + cam
+    pose_n, shape_n, cam_n = ResidualSplitFn.apply(dec, xc[:, x.shape[1]:], (216, 10, 3))       # dec + [pose | shape | cam], whmr.py:122-126
     rotmat = pose_n.view(B, 24, 3, 3)                                                  # no Gram-Schmidt in training (whmr.py:129)
     verts, joints, smpl_j, markers = SMPLFn.apply(shape_n, rotmat, reg.smpl)
     # whmr.py:142-173 in one launch (and one for the backward): kp_2d, focal = s.detach()*h*Tz/2, cam_t from pred_cam.detach(), kp_2d_w
