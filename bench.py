@@ -588,7 +588,9 @@ def main(argv=None):
             'config': {'workload': ('%s (%s), %dx%d crops, batch %d per GPU, random-init weights%s'
                                     % (WORKLOAD[args.workload], args.workload, size[0], size[1], args.batch,
                                        ('; ' + args.full_x_note + ('; eager module call' if args.eager else '; replayed from one HIP graph'))
-                                       if args.workload == 'whmr' else '')) if not dry else 'dryrun-cpu stand-in',
+                                       if args.workload == 'whmr' else
+                                       ('; synthetic L2 loss over the 27 supervised tensors as %s' % ('multi-tensor launches' if args.loss == 'multi-tensor' else '27 x (pow, mean, add) expressions'))
+                                       if args.workload == 'whmr_train' else '')) if not dry else 'dryrun-cpu stand-in',
                        'global_batch': n_ranks * args.batch, 'parallelism': par},
         }
         if args.ref_1gpu:
