@@ -45,6 +45,8 @@ struct whmr_gemm {
                              * the gradient other consumers of the same map already left there);
                              * bits 4 / 5 (whmr_gemm_f32, at most 1024 output rows, a_mode = c_mode = 0): A / W is given REDUCTION-MAJOR -- A as [K, lda >= M],
                              * W as [K, N] dense -- the backward products of nn.Linear (dX = dY . W, dW = dY^T . X) without transposed copies;
+                             * bit 7 (bf16 kernel, bf16 residual and output, row-major C): the residual is the pre-activation Z of a GELU and the output is
+                             * bf16(acc + bias) * gelu'(Z) instead of a sum -- fc2's data gradient and the GELU backward in one pass (autograd of vit.py:66-68);
                              * bit 3 (bf16 gather): K is ordered (ci chunk of 64, ky, kx, ci in chunk) instead of (ky, kx, ci): all taps of one
                              * 64-channel slice are walked before the next slice, so the window overlap of a large-kernel conv on a map that
                              * exceeds the Infinity Cache is re-read from cache instead of HBM (Tz-head 7x7 s3 conv) */
@@ -52,6 +54,8 @@ struct whmr_gemm {
     int64_t split_k;        /* internal (set by the bf16 launcher, pass 0): K elements per split-K slice, blockIdx.z = slice */
     const float* row_scale; /* optional [M]: act(acc + bias) is multiplied by row_scale[m] BEFORE the (post-activation) residual is added --
                              * stochastic depth of the training ViT (vit.py:132-139: x + drop_path(branch), per-sample mask / keep_prob) */
+    void* C2;               /* optional second output of the bf16 kernel (act = GELU, bf16 C, no residual): C2 = bf16(acc + bias), the PRE-activation,
+                             * next to C = gelu(that value) -- the training forward of fc1 keeps both (vit.py:66-68) without a separate GELU pass */
 };
 
 /* bf16 MFMA GEMM (v_mfma_f32_32x32x16_bf16, fp32 accumulate).  Needs K % 64 == 0 (and Cin % 64 == 0 for a_mode 1).

@@ -547,3 +547,36 @@ def test_gemm_f32_reduction_major_operands(dev, M, N, K):
         assert (out.cpu() - ref2).abs().max() / ref2.abs().max() < 2e-6
     with pytest.raises(RuntimeError):                                   # more than 1024 output rows: no reduction-major route
         L.gemm(torch.randn(K, 1100, device=dev), wd, torch.empty(1100, N, device=dev), trans_a=True)
+
+
+@pytest.mark.parametrize('M,N,K', [(12288, 3072, 768), (392, 3072, 768), (1000, 256, 128)])
+def test_gemm_bf16_gelu_epilogues_of_the_training_step(dev, M, N, K):
+    """fc1 of the training forward: C = gelu(z) and C2 = z = a . w^T + b from one launch (whmr_gemm.C2); fc2's data gradient times the GELU
+    derivative of the saved pre-activation in the epilogue (epi_flags bit 7).  z must be the bits of the plain launch; gelu / gelu' are the
+    polynomial forms (|error| <= 1.9e-4 / 2.6e-4) of the exact erf expressions, applied to the bf16-rounded values."""
+    from whmr_amd import _lib as L
+    g = torch.Generator().manual_seed(M + N + K)
+    a = (torch.randn(M, K, generator=g) * 0.5).to(dev).bfloat16()
+    w = (torch.randn(N, K, generator=g) * 0.08).to(dev).bfloat16()
+    b = torch.randn(N, generator=g).to(dev)
+    plain = L.gemm(a, w, torch.empty(M, N, dtype=torch.bfloat16, device=dev), bias=b)
+    hid, pre = torch.empty_like(plain), torch.empty_like(plain)
+    L.gemm(a, w, hid, bias=b, act=L.ACT_GELU, pre_out=pre)
+    assert torch.equal(pre, plain)
+    z = pre.float()
+    want = torch.nn.functional.gelu(z)
+    err = (hid.float() - want).abs()
+    assert (err <= 2.0e-4 + 2.0 ** -8 * want.abs()).all(), err.max().item()
+    assert (z.abs() > 1.0).float().mean() > 0.1                                        # the test data reaches the curved part and the tails
+    # backward: (a2 . w2^T) * gelu'(z)
+    a2 = (torch.randn(M, K, generator=g) * 0.5).to(dev).bfloat16()
+    lin = L.gemm(a2, w, torch.empty(M, N, dtype=torch.bfloat16, device=dev))
+    out = L.gemm(a2, w, torch.empty(M, N, dtype=torch.bfloat16, device=dev), gelu_bwd_of=pre)
+    zd = z.double()
+    dgelu = 0.5 * (1 + torch.erf(zd / 2 ** 0.5)) + zd * torch.exp(-0.5 * zd * zd) / (2 * torch.pi) ** 0.5
+    want = lin.double() * dgelu
+    err = (out.double() - want).abs()
+    assert (err <= 2.0 ** -8 * want.abs() + 2.7e-4 * lin.double().abs() + 1e-30).all(), (err / (want.abs() + 1e-3)).max().item()
+    # outside the envelope: fp32 output / a residual next to the second output
+    with pytest.raises((RuntimeError, AssertionError)):
+        L.gemm(a, w, torch.empty(M, N, device=dev), bias=b, act=L.ACT_GELU, pre_out=torch.empty(M, N, device=dev))

@@ -25,7 +25,8 @@ class WhmrGemm(C.Structure):
                 ('c_off', C.c_int64), ('osb', C.c_int64), ('osy', C.c_int64), ('osx', C.c_int64),
                 ('workspace', C.c_void_p), ('workspace_bytes', C.c_int64),
                 ('n_phase', C.c_int32), ('epi_flags', C.c_int32),
-                ('phase_w_stride', C.c_int64), ('phase_cy', C.c_int64), ('phase_cx', C.c_int64), ('split_k', C.c_int64), ('row_scale', C.c_void_p)]
+                ('phase_w_stride', C.c_int64), ('phase_cy', C.c_int64), ('phase_cx', C.c_int64), ('split_k', C.c_int64), ('row_scale', C.c_void_p),
+                ('C2', C.c_void_p)]
 
 
 class WhmrGemmBlk(C.Structure):
@@ -183,7 +184,7 @@ PROFILE = None        # bench.py sets this to a list: (kernel, flops, start_even
 
 def gemm(a, w, out, bias=None, residual=None, res_row_mod=0, act=ACT_NONE, conv=None, scatter=None, M=None,
          lda=None, glds=True, tile=None, phases=None, res_first=False, splits=None, row_scale=None, accumulate=False,
-         trans_a=False, trans_w=False):
+         trans_a=False, trans_w=False, pre_out=None, gelu_bwd_of=None):
     """out = act(a . w^T + bias) + residual.  a/w dtype selects the kernel (bf16 MFMA or exact-fp32 MFMA).
 
     conv = dict(IH, IW, Cin, OH, OW, KW, SH, SW, PH, PW): a is an NHWC image [B, IH, IW, Cin], rows are output pixels.
@@ -192,6 +193,14 @@ def gemm(a, w, out, bias=None, residual=None, res_row_mod=0, act=ACT_NONE, conv=
     trans_a / trans_w (fp32, at most 1024 output rows): the operand is given REDUCTION-MAJOR -- a as [K, M], w as [K, N] (dense) -- so the
     backward products of nn.Linear (dX = dY . W, dW = dY^T . X) read dY / X / W as they are (epi_flags bits 4 / 5, skinny kernel).
     """
+    if pre_out is not None:                 # bf16 kernel, act = GELU: out = gelu(z), pre_out = z = a . w^T + bias (the training forward keeps both)
+        _dev(pre_out)
+        assert act == ACT_GELU and residual is None and out.dtype == torch.bfloat16 and pre_out.dtype == torch.bfloat16
+        assert pre_out.shape == out.shape and pre_out.stride() == out.stride() and conv is None and scatter is None
+    if gelu_bwd_of is not None:             # bf16 kernel: out = (a . w^T) * gelu'(z), z = gelu_bwd_of (the GELU backward inside fc2's data gradient)
+        assert residual is None and act == ACT_NONE and out.dtype == torch.bfloat16 and gelu_bwd_of.dtype == torch.bfloat16
+        assert gelu_bwd_of.shape == out.shape and conv is None and scatter is None and not accumulate
+        residual = gelu_bwd_of
     if trans_a or trans_w:
         assert a.dtype == torch.float32 and conv is None and scatter is None and phases is None and tile is None and lda is None and M is None
         assert a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.is_contiguous()
@@ -244,7 +253,8 @@ def gemm(a, w, out, bias=None, residual=None, res_row_mod=0, act=ACT_NONE, conv=
         p.lda = a.stride(-2) if lda is None else lda
         assert a.shape[-1] == K
     p.N, p.K = N, K
-    p.epi_flags |= (16 if trans_a else 0) | (32 if trans_w else 0)
+    p.epi_flags |= (16 if trans_a else 0) | (32 if trans_w else 0) | (128 if gelu_bwd_of is not None else 0)
+    p.C2 = pre_out.data_ptr() if pre_out is not None else None
     if phases is not None:                  # dict(cy, cx): 4 stacked phase matrices w[4, N, K] (sub-pixel deconv)
         assert a.dtype == torch.bfloat16 and conv is not None and scatter is not None and w.shape[0] == 4
         p.n_phase, p.phase_w_stride, p.phase_cy, p.phase_cx = 4, N * K, phases['cy'], phases['cx']

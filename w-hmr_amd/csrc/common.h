@@ -70,6 +70,27 @@ __device__ __forceinline__ float gelu_fast(float x) {
     return x * fmaf(s, r, 0.5f);
 }
 
+// d/dx gelu(x) = Phi(x) + x phi(x) for the training backward's bf16 path: 0.5 + s u(s^2), s = clamp(x, -4.5, 4.5), u = degree-9 least-squares fit
+// on Chebyshev nodes of (gelu'(s) - 0.5) / s (an even function).  |error| <= 2.6e-4 absolute in fp32 Horner form over all x (the tails are
+// 1.00007 and -7e-5 instead of 1 and 0), a tenth of the bf16 rounding of the gradient it multiplies; full-rate packed VALU like gelu_fast2
+// (the erf + exp form is ~40 instructions per element and made the GELU backward VALU-bound).
+__device__ __forceinline__ f32x2_t gelu_grad_fast2(f32x2_t x) {
+    f32x2_t s;
+    s.x = __builtin_amdgcn_fmed3f(x.x, -4.5f, 4.5f);
+    s.y = __builtin_amdgcn_fmed3f(x.y, -4.5f, 4.5f);
+    const f32x2_t t = s * s;
+    f32x2_t r = t * -2.744070681e-11f + 3.034363388e-09f;
+    r = r * t + (-1.475886388e-07f);
+    r = r * t + 4.182379123e-06f;
+    r = r * t + (-7.728450434e-05f);
+    r = r * t + 9.887899513e-04f;
+    r = r * t + (-9.041428673e-03f);
+    r = r * t + 5.918059743e-02f;
+    r = r * t + (-2.655834586e-01f);
+    r = r * t + 7.978483487e-01f;
+    return s * r + 0.5f;
+}
+
 template <typename T> struct io;
 template <> struct io<float> {
     static __device__ __forceinline__ float ld(const float* p) { return *p; }

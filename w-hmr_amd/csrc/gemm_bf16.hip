@@ -69,6 +69,7 @@ extern "C" int whmr_set_option(int key, int value) {
 extern "C" int whmr_gemm_bf16_split(const whmr_gemm* pp, int tile, int splits_in, void* stream) {
     const whmr_gemm& p = *pp;
     if (!p.workspace || p.n_phase > 1 || p.c_mode != 0 || (p.N & 3) || (p.ldc & 3) || (p.ldr & 3) || (p.K % 64)) return (int)hipErrorInvalidValue;
+    if (p.C2 || (p.epi_flags & (4 | 128))) return (int)hipErrorInvalidValue;      // second output / gelu' product / C-addressed skip: packed epilogue of the unsplit kernel only
     long splits = splits_in;
     while (splits > 1 && splits * p.M * p.N * 4 > p.workspace_bytes) --splits;
     if (splits <= 1) return (int)hipErrorInvalidValue;

@@ -418,6 +418,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
         const bool skip16 = p.residual && (p.epi_flags & 1) && !(p.ldr & 7) && p.res_row_mod <= 0 && p.res_row_mod != -2003 && !(ACT == 1 && (p.epi_flags & 2));
         if ((!p.residual || skip16) && !p.row_scale && !p.split_k && !(p.N & 7) && (p.c_mode == 1 || !(p.ldc & 7))) {
             const bool act_late = skip16 && (p.epi_flags & 2);               // ResNet: the skip is added BEFORE the activation -> activate in the store loop
+            const bool dual = ACT == 1 && p.C2 && !p.residual && p.c_mode == 0;   // fc1 of the training forward: C2 = pre-activation, C = GELU of it (store loop)
+            const bool gelu_mul = ACT == 0 && skip16 && (p.epi_flags & 128);  // residual = pre-activation Z: C = value * gelu'(Z)
             constexpr int ROWB = cfg::EPI16_ROW, GP = cfg::GP16, CPRW = BN / 8, RPI2 = cfg::THREADS / CPRW;
             void* const Cout16 = p.C;
             const bool nostore16 = p.res_row_mod == -2003;
@@ -444,7 +446,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
                         for (int q = 0; q < 4; ++q) {
                             float v[4] = {acc[i][j][4 * q] + bq[j][q].x, acc[i][j][4 * q + 1] + bq[j][q].y, acc[i][j][4 * q + 2] + bq[j][q].z,
                                           acc[i][j][4 * q + 3] + bq[j][q].w};
-                            if (ACT == 1 && !act_late) {
+                            if (ACT == 1 && !act_late && !dual) {
                                 const f32x2_t g0 = gelu_fast2(f32x2_t{v[0], v[1]}), g1 = gelu_fast2(f32x2_t{v[2], v[3]});
                                 v[0] = g0.x; v[1] = g0.y; v[2] = g1.x; v[3] = g1.y;
                             }
@@ -469,7 +471,25 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
                     return (size_t)m * p.ldc;
                 };
                 const int chunk = tid % CPRW, col = n0 + chunk * 8;
-                if (!skip16) {                       // the hot loop (qkv, fc1, deconvs): LDS read -> global store, nothing else
+                if (dual) {                          // pre-activation to C2, GELU of the bf16-rounded value (what the backward differentiates) to C
+#pragma unroll 2
+                    for (int lr = tid / CPRW; lr < nrows; lr += RPI2) {
+                        const int pi = lr / cfg::CROWS, within = lr - pi * cfg::CROWS;
+                        const int m = m0 + (within >> 5) * cfg::WTM + (i0 + pi) * 32 + (within & 31);
+                        if (m >= m_end || col >= p.N) continue;
+                        const uint4 v = *(const uint4*)(smem + lr * ROWB + chunk * 16);
+                        const size_t off = (size_t)m * p.ldc + col;
+                        *(uint4*)((bf16_t*)p.C2 + off) = v;
+                        const uint32_t a[4] = {v.x, v.y, v.z, v.w};
+                        uint32_t o[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const f32x2_t g = gelu_fast2(f32x2_t{__uint_as_float(a[e] << 16), __uint_as_float(a[e] & 0xffff0000u)});
+                            o[e] = pack_bf16x2(g.x, g.y);
+                        }
+                        *(uint4*)((bf16_t*)Cout16 + off) = make_uint4(o[0], o[1], o[2], o[3]);
+                    }
+                } else if (!skip16) {                // the hot loop (qkv, fc1, deconvs): LDS read -> global store, nothing else
 #pragma unroll 4
                     for (int lr = tid / CPRW; lr < nrows; lr += RPI2) {
                         const int pi = lr / cfg::CROWS, within = lr - pi * cfg::CROWS;
@@ -489,12 +509,20 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
                         const uint4 sk = *(const uint4*)((const bf16_t*)p.residual + ((p.epi_flags & 4) ? row_addr(m) : (size_t)m * p.ldr) + col);
                         const uint32_t a[4] = {v.x, v.y, v.z, v.w}, b[4] = {sk.x, sk.y, sk.z, sk.w};
                         uint32_t o[4];
+                        if (gelu_mul) {              // d pre = d hid * gelu'(pre): fc2's data gradient and the GELU backward in one pass
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const f32x2_t d = gelu_grad_fast2(f32x2_t{__uint_as_float(b[e] << 16), __uint_as_float(b[e] & 0xffff0000u)});
+                                o[e] = pack_bf16x2(__uint_as_float(a[e] << 16) * d.x, __uint_as_float(a[e] & 0xffff0000u) * d.y);
+                            }
+                        } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             float lo = __uint_as_float(a[e] << 16) + __uint_as_float(b[e] << 16);
                             float hi2 = __uint_as_float(a[e] & 0xffff0000u) + __uint_as_float(b[e] & 0xffff0000u);
                             if (ACT == 2 && act_late) { lo = fmaxf(lo, 0.f); hi2 = fmaxf(hi2, 0.f); }
                             o[e] = pack_bf16x2(lo, hi2);
+                        }
                         }
                         *(uint4*)((bf16_t*)Cout16 + row_addr(m) + col) = make_uint4(o[0], o[1], o[2], o[3]);
                     }
@@ -731,6 +759,12 @@ extern "C" int whmr_gemm_bf16_big(const whmr_gemm* pp, int tile, void* stream) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % 64)) return (int)hipErrorInvalidValue;
     if (p.a_mode == 1 && (p.Cin % 64 || !p.zeros)) return (int)hipErrorInvalidValue;
     if (p.a_mode == 0 && (p.lda % 8)) return (int)hipErrorInvalidValue;
+    // the second output / the gelu' product exist on the packed bf16 epilogue only: bf16 output, row-major C with 16-B rows, no split-K, no row factors
+    if (p.C2 && !(p.act == 1 && p.out_bf16 && !p.residual && p.c_mode == 0 && !(p.N & 7) && !(p.ldc & 7) && !p.row_scale && !p.split_k && p.res_row_mod == 0))
+        return (int)hipErrorInvalidValue;
+    if ((p.epi_flags & 128) && !(p.residual && (p.epi_flags & 1) && !(p.epi_flags & 6) && p.act == 0 && p.out_bf16 && p.c_mode == 0 && !(p.N & 7) && !(p.ldc & 7) &&
+                                 !(p.ldr & 7) && !p.row_scale && !p.split_k && p.res_row_mod == 0))
+        return (int)hipErrorInvalidValue;
     // a skip tensor addressed like a scattered C exists on the packed bf16 epilogue only (bf16 in, bf16 out, no split-K, no row factors)
     if ((p.epi_flags & 4) && !(p.residual && (p.epi_flags & 1) && p.out_bf16 && p.c_mode == 1 && !(p.N & 7) && !(p.ldr & 7) && p.res_row_mod == 0 &&
                                !p.row_scale && !p.split_k && !(p.act == 1 && (p.epi_flags & 2))))

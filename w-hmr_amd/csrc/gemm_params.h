@@ -32,4 +32,6 @@ struct whmr_gemm {
     int64_t split_k;        /* internal (set by the bf16 launcher, pass 0): K elements per split-K slice, blockIdx.z = slice */
     const float* row_scale; /* optional [M]: act(acc + bias) is multiplied by row_scale[m] BEFORE the (post-activation) residual is added --
                              * stochastic depth of the training ViT (vit.py:132-139: x + drop_path(branch), per-sample mask / keep_prob) */
+    void* C2;               /* optional second output of the bf16 kernel (act = GELU, bf16 C, no residual): C2 = bf16(acc + bias), the PRE-activation,
+                             * next to C = gelu(that value) -- the training forward of fc1 keeps both (vit.py:66-68) without a separate GELU pass */
 };

@@ -96,9 +96,13 @@ def vit_forward_train(m, x):
         a.h2 = torch.empty(M, D, dtype=dt, device=dev)
         L.layernorm(a.t_mid, blk.norm2.weight, blk.norm2.bias, a.h2, 1e-6)
         a.pre = torch.empty(M, hidden, dtype=dt, device=dev)
-        L.gemm(a.h2, m._w(blk.mlp.fc1.weight), a.pre, bias=blk.mlp.fc1.bias)
         a.hid = torch.empty_like(a.pre)
-        L.gelu_fwd(a.pre, a.hid)
+        if FUSE_GELU and dt == torch.bfloat16:
+            # fc1's epilogue leaves both the pre-activation (the backward needs it) and its GELU: no separate pass over the [M, 4D] map
+            L.gemm(a.h2, m._w(blk.mlp.fc1.weight), a.hid, bias=blk.mlp.fc1.bias, act=L.ACT_GELU, pre_out=a.pre)
+        else:
+            L.gemm(a.h2, m._w(blk.mlp.fc1.weight), a.pre, bias=blk.mlp.fc1.bias)
+            L.gelu_fwd(a.pre, a.hid)
         t = torch.empty(M, D, **f32)
         L.gemm(a.hid, m._w(blk.mlp.fc2.weight), t, bias=blk.mlp.fc2.bias, residual=a.t_mid, row_scale=a.rs_mlp)
         s.layers.append(a)
@@ -126,6 +130,8 @@ def _attention_bwd(qkv, d_att, B, N, H, dh, scale, dt):
 # transposes altogether (15.16 -> 14.15 ms in line) and then the second stream buys nothing (14.08) -- and inside the full W-HMR step it costs
 # 0.3-0.6 ms (256x192, eager and graph-replayed).  The same treatment of the deconv / conv nodes measured neutral to -3 % and is not in the tree.
 OVERLAP_DW = os.environ.get('WHMR_OVERLAP_DW', '0') != '0'
+FUSE_GELU = os.environ.get('WHMR_FUSE_GELU', '1') != '0'      # bf16 mode: GELU inside fc1's epilogue (pre-activation kept as a second output) and its
+                                                               # backward inside fc2's data-gradient epilogue (A/B switch)
 USE_TN = os.environ.get('WHMR_TN_GEMM', '1') != '0'          # weight gradients on whmr_gemm_tn_bf16 (A/B switch; fp32 mode and odd shapes keep the transposed-copy path)
 _side_streams = {}
 
@@ -190,8 +196,9 @@ def vit_backward(m, s, dout):
         grads[w] = dw.view_as(w)
         side_made.append(dw)
 
-    def linear_bwd(dy_op, x_saved, lin, need_dx=True, wshape=None, dx_dtype=torch.float32):
-        """dy_op [M, Nout] (compute dtype), x_saved [M, Kin] -> dx [M, Kin] (fp32 unless dx_dtype); records dW, db."""
+    def linear_bwd(dy_op, x_saved, lin, need_dx=True, wshape=None, dx_dtype=torch.float32, gelu_bwd_of=None):
+        """dy_op [M, Nout] (compute dtype), x_saved [M, Kin] -> dx [M, Kin] (fp32 unless dx_dtype); records dW, db.
+        gelu_bwd_of: the pre-activation whose GELU produced x_saved -- dx is then multiplied by gelu'(pre) in the epilogue (= d pre)."""
         if side is None:
             dw_branch(dy_op, x_saved, lin)
         else:
@@ -207,7 +214,7 @@ def vit_backward(m, s, dout):
             return None
         w = lin.weight
         dx = torch.empty(M, x_saved.shape[1], dtype=dx_dtype, device=dev)
-        L.gemm(dy_op, wt(w, wshape), dx)                                               # W^T: [Kin, Nout]
+        L.gemm(dy_op, wt(w, wshape), dx, gelu_bwd_of=gelu_bwd_of)                      # W^T: [Kin, Nout]
         return dx
 
     # Early delivery to the data-parallel reducer (GradReducer.publish): everything in ``grads`` that belongs to finished blocks is handed over
@@ -234,9 +241,12 @@ def vit_backward(m, s, dout):
         # t_out = t_mid + fc2(gelu(fc1(LN2(t_mid))))
         # (stochastic depth: the branch sees mask / keep_prob * d t_out; the skip path sees d t_out unchanged)
         dy = _op(dt_grad, dt) if a.rs_mlp is None else L.scale_rows_cast(dt_grad, a.rs_mlp, dt)
-        d_hid = linear_bwd(dy, a.hid, blk.mlp.fc2, dx_dtype=dt)                            # only feeds the GELU backward: compute dtype
-        d_pre = torch.empty(M, a.pre.shape[1], dtype=dt, device=dev)
-        L.gelu_bwd(a.pre, d_hid, d_pre)
+        if FUSE_GELU and dt == torch.bfloat16:
+            d_pre = linear_bwd(dy, a.hid, blk.mlp.fc2, dx_dtype=dt, gelu_bwd_of=a.pre)        # fc2's data gradient * gelu'(pre) in one pass
+        else:
+            d_hid = linear_bwd(dy, a.hid, blk.mlp.fc2, dx_dtype=dt)                        # only feeds the GELU backward: compute dtype
+            d_pre = torch.empty(M, a.pre.shape[1], dtype=dt, device=dev)
+            L.gelu_bwd(a.pre, d_hid, d_pre)
         d_h2 = linear_bwd(d_pre, a.h2, blk.mlp.fc1)
         dg, db = torch.empty(D, **f32), torch.empty(D, **f32)
         L.layernorm_bwd(a.t_mid, d_h2, blk.norm2.weight, dt_grad, dt_grad, dg, db, 1e-6)   # dt_grad now = d t_mid

@@ -27,7 +27,6 @@ its ground truth comes from the pytorch3d rasteriser in the reference (SURVEY 8f
 import os
 
 import torch
-import torch.nn.functional as F
 
 from .. import _lib as L
 from ..core.cfgs import cfg
