@@ -257,9 +257,12 @@ int whmr_transpose_colsum(const void* src, long ld_src, void* dst, long ld_dst, 
                           float* scratch, void* stream);
 /* out[c] (+)= sum_r x[r,c]; deterministic two-stage sum; scratch >= max(64*C, 2^20) floats. */
 int whmr_colsum(const void* x, int is_bf16, long ld, int R, int C, float* out, int accumulate, float* scratch, void* stream);
-/* LayerNorm backward: dx = dLN(x; gamma)(dy) + dres (dres nullable, dx may alias it); dgamma/dbeta (+)=; scratch >= 2048*C floats. */
+/* LayerNorm backward: dx = dLN(x; gamma)(dy) + dres (dres nullable, dx may alias it); dgamma/dbeta (+)=; scratch >= 2048*C floats.
+ * cast_out (nullable) [rows, C] bf16 = dx * row_scale[row] (row_scale nullable): the operand of the next branch's backward GEMMs, stochastic-depth
+ * factor included (vit.py:132-139), written by the same pass. */
 int whmr_layernorm_bwd(const float* x, const float* dy, const float* gamma, const float* dres, float* dx, float* dgamma,
-                       float* dbeta, int accumulate, int rows, int C, float eps, float* scratch, void* stream);
+                       float* dbeta, int accumulate, int rows, int C, float eps, float* scratch, void* cast_out, const float* row_scale,
+                       void* stream);
 /* exact-erf GELU: forward as its own pass (training keeps the pre-activation) and backward d_pre = d_hid * gelu'(pre). */
 int whmr_gelu_fwd(const void* pre, void* out, int is_bf16, long n, void* stream);
 int whmr_gelu_bwd(const void* pre, int pre_bf16, const void* dhid, int dhid_bf16, void* dpre, int out_bf16, long n, void* stream);

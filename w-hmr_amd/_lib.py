@@ -97,7 +97,7 @@ _SIGS = {
     'whmr_transpose_cast': [_P, _I, _L, _P, _I, _L, _I, _I, _I, _P],
     'whmr_colsum': [_P, _I, _L, _I, _I, _P, _I, _P, _P],
     'whmr_transpose_colsum': [_P, _L, _P, _L, _I, _I, _I, _P, _I, _P, _P],
-    'whmr_layernorm_bwd': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P],
+    'whmr_layernorm_bwd': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P],
     'whmr_gelu_fwd': [_P, _P, _I, _L, _P],
     'whmr_gelu_bwd': [_P, _I, _P, _I, _P, _I, _L, _P],
     'whmr_regressor_state': [_P, _P, _L, _P, _L, _P, _L, _I, _P, _L, _I, _P],
@@ -823,16 +823,20 @@ def colsum(x, out, accumulate=False):
     return out
 
 
-def layernorm_bwd(x, dy, gamma, dres, dx, dgamma, dbeta, eps, accumulate=False):
-    """dx = LN'(x)(dy) (+ dres); dgamma / dbeta written or accumulated.  All fp32, rows contiguous."""
-    _dev(x, dy, gamma, dres, dx, dgamma, dbeta)
+def layernorm_bwd(x, dy, gamma, dres, dx, dgamma, dbeta, eps, accumulate=False, cast_out=None, row_scale=None):
+    """dx = LN'(x)(dy) (+ dres); dgamma / dbeta written or accumulated.  All fp32, rows contiguous.  cast_out (bf16, same shape) also receives
+    dx * row_scale[row] (row_scale [rows] fp32 or None)."""
+    _dev(x, dy, gamma, dres, dx, dgamma, dbeta, cast_out, row_scale)
+    assert cast_out is None or (cast_out.dtype == torch.bfloat16 and cast_out.is_contiguous() and cast_out.numel() == x.numel())
+    assert row_scale is None or (cast_out is not None and row_scale.dtype == torch.float32 and row_scale.is_contiguous()
+                                 and row_scale.numel() == x.numel() // x.shape[-1])
     for t in (x, dy, dx, dres):
         assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
     Cc = x.shape[-1]
     rows = x.numel() // Cc
     sc = train_scratch(x.device, 2048 * Cc)
     _check(lib().whmr_layernorm_bwd(x.data_ptr(), dy.data_ptr(), gamma.data_ptr(), _ptr(dres), dx.data_ptr(), dgamma.data_ptr(),
-                                    dbeta.data_ptr(), int(accumulate), rows, Cc, eps, sc.data_ptr(), _stream()), 'whmr_layernorm_bwd')
+                                    dbeta.data_ptr(), int(accumulate), rows, Cc, eps, sc.data_ptr(), _ptr(cast_out), _ptr(row_scale), _stream()), 'whmr_layernorm_bwd')
     return dx
 
 

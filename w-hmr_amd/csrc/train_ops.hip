@@ -201,7 +201,8 @@ extern "C" int whmr_colsum(const void* x, int is_bf16, long ld, int R, int C, fl
 template <int MAXV>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             const float* __restrict__ gamma, const float* __restrict__ dres,
-                                                            float* __restrict__ dx, float* __restrict__ partial, int rows, int C, float eps) {
+                                                            float* __restrict__ dx, float* __restrict__ partial, int rows, int C, float eps,
+                                                            bf16_t* __restrict__ cast_out, const float* __restrict__ row_scale) {
     extern __shared__ float red[];                 // [4 waves][2][C]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = C >> 2;
@@ -263,6 +264,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                     o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
                 }
                 *(float4*)(dxr + c4 * 4) = o;
+                if (cast_out) {                        // the bf16 GEMM operand of the next branch's backward, stochastic-depth row factor applied
+                    const float rs = row_scale ? row_scale[row] : 1.0f;
+                    *(uint2*)(cast_out + (size_t)row * C + c4 * 4) = make_uint2(pack_bf16x2(o.x * rs, o.y * rs), pack_bf16x2(o.z * rs, o.w * rs));
+                }
             }
         }
     }
@@ -313,14 +318,17 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_final_kernel(const float* 
 
 #define LNB_BLOCKS 1024
 // dx may alias dres.  scratch: >= LNB_BLOCKS * 2 * C floats (2048 * C).
+// cast_out (nullable) [rows, C] bf16 = dx * row_scale[row] (row_scale nullable = 1): the compute-dtype copy of the residual-stream gradient that
+// the NEXT branch's backward multiplies (whmr_scale_rows_cast / the plain cast as a by-product of this pass).
 extern "C" int whmr_layernorm_bwd(const float* x, const float* dy, const float* gamma, const float* dres, float* dx, float* dgamma,
-                                  float* dbeta, int accumulate, int rows, int C, float eps, float* scratch, void* stream) {
+                                  float* dbeta, int accumulate, int rows, int C, float eps, float* scratch, void* cast_out,
+                                  const float* row_scale, void* stream) {
     if (rows <= 0 || C <= 0 || (C & 3) || C > 64 * 4 * 4) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
     const int nblk = rows < LNB_BLOCKS * 4 ? (rows + 3) / 4 : LNB_BLOCKS;
     const size_t lds = (size_t)8 * C * sizeof(float);
-    if (C <= 64 * 4 * 3) hipLaunchKernelGGL(layernorm_bwd_kernel<3>, dim3(nblk), dim3(256), lds, st, x, dy, gamma, dres, dx, scratch, rows, C, eps);
-    else hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(nblk), dim3(256), lds, st, x, dy, gamma, dres, dx, scratch, rows, C, eps);
+    if (C <= 64 * 4 * 3) hipLaunchKernelGGL(layernorm_bwd_kernel<3>, dim3(nblk), dim3(256), lds, st, x, dy, gamma, dres, dx, scratch, rows, C, eps, (bf16_t*)cast_out, row_scale);
+    else hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(nblk), dim3(256), lds, st, x, dy, gamma, dres, dx, scratch, rows, C, eps, (bf16_t*)cast_out, row_scale);
     hipLaunchKernelGGL(layernorm_bwd_final_kernel, dim3((2 * C + 63) / 64), dim3(1024), 0, st, scratch, nblk, C, dgamma, dbeta, accumulate);
     WHMR_CHECK_LAUNCH();
     return 0;

@@ -235,12 +235,26 @@ def vit_backward(m, s, dout):
 
     dt_grad = torch.empty(M, D, **f32)                                                 # gradient of the fp32 residual stream
     dg, db = torch.empty(D, **f32), torch.empty(D, **f32)
-    L.layernorm_bwd(s.t_last, dout.contiguous().float(), m.last_norm.weight, None, dt_grad, dg, db, 1e-6)
+    # bf16 mode: every LayerNorm backward also writes the compute-dtype operand of the NEXT branch's backward GEMMs (dx times that branch's
+    # stochastic-depth row factor) -- the cast / scale_rows_cast pass per branch (22 launches of 10 us per step) is a by-product of a pass that
+    # holds the row in registers anyway
+    fuse_cast = FUSE_GELU and dt == torch.bfloat16
+    rev = list(zip(reversed(list(m.blocks)), reversed(s.layers)))
+
+    def operand():
+        return torch.empty(M, D, dtype=dt, device=dev) if fuse_cast else None
+
+    dy_next = operand()
+    L.layernorm_bwd(s.t_last, dout.contiguous().float(), m.last_norm.weight, None, dt_grad, dg, db, 1e-6, cast_out=dy_next,
+                    row_scale=rev[0][1].rs_mlp if (fuse_cast and rev) else None)
     grads[m.last_norm.weight], grads[m.last_norm.bias] = dg, db
-    for blk, a in zip(reversed(list(m.blocks)), reversed(s.layers)):
+    for bi, (blk, a) in enumerate(rev):
         # t_out = t_mid + fc2(gelu(fc1(LN2(t_mid))))
         # (stochastic depth: the branch sees mask / keep_prob * d t_out; the skip path sees d t_out unchanged)
-        dy = _op(dt_grad, dt) if a.rs_mlp is None else L.scale_rows_cast(dt_grad, a.rs_mlp, dt)
+        if fuse_cast:
+            dy = dy_next
+        else:
+            dy = _op(dt_grad, dt) if a.rs_mlp is None else L.scale_rows_cast(dt_grad, a.rs_mlp, dt)
         if FUSE_GELU and dt == torch.bfloat16:
             d_pre = linear_bwd(dy, a.hid, blk.mlp.fc2, dx_dtype=dt, gelu_bwd_of=a.pre)        # fc2's data gradient * gelu'(pre) in one pass
         else:
@@ -249,10 +263,15 @@ def vit_backward(m, s, dout):
             L.gelu_bwd(a.pre, d_hid, d_pre)
         d_h2 = linear_bwd(d_pre, a.h2, blk.mlp.fc1)
         dg, db = torch.empty(D, **f32), torch.empty(D, **f32)
-        L.layernorm_bwd(a.t_mid, d_h2, blk.norm2.weight, dt_grad, dt_grad, dg, db, 1e-6)   # dt_grad now = d t_mid
+        dy_attn = operand()
+        L.layernorm_bwd(a.t_mid, d_h2, blk.norm2.weight, dt_grad, dt_grad, dg, db, 1e-6, cast_out=dy_attn,
+                        row_scale=a.rs_attn if fuse_cast else None)                      # dt_grad now = d t_mid
         grads[blk.norm2.weight], grads[blk.norm2.bias] = dg, db
         # t_mid = t_in + proj(attention(qkv(LN1(t_in))))
-        dy = _op(dt_grad, dt) if a.rs_attn is None else L.scale_rows_cast(dt_grad, a.rs_attn, dt)
+        if fuse_cast:
+            dy = dy_attn
+        else:
+            dy = _op(dt_grad, dt) if a.rs_attn is None else L.scale_rows_cast(dt_grad, a.rs_attn, dt)
         d_att = linear_bwd(dy, a.att, blk.attn.proj)
         if a.lse is not None:
             d_qkv = torch.empty_like(a.qkv)
@@ -261,12 +280,14 @@ def vit_backward(m, s, dout):
             d_qkv = _attention_bwd(a.qkv, d_att, B, N, m.num_heads, D // m.num_heads, m.scale, dt)
         d_h1 = linear_bwd(d_qkv, a.h1, blk.attn.qkv)
         dg, db = torch.empty(D, **f32), torch.empty(D, **f32)
-        L.layernorm_bwd(a.t_in, d_h1, blk.norm1.weight, dt_grad, dt_grad, dg, db, 1e-6)    # dt_grad now = d t_in
+        dy_next = operand()                                                                # for the next (earlier) block's MLP branch, or the patch embedding
+        L.layernorm_bwd(a.t_in, d_h1, blk.norm1.weight, dt_grad, dt_grad, dg, db, 1e-6, cast_out=dy_next,
+                        row_scale=rev[bi + 1][1].rs_mlp if (fuse_cast and bi + 1 < len(rev)) else None)   # dt_grad now = d t_in
         grads[blk.norm1.weight], grads[blk.norm1.bias] = dg, db
         flush()                                                                            # this block's gradients may start their exchange
     # t_0 = cols . Wp^T + b + (pos_embed[1:] + pos_embed[:1])
     pe = m.patch_embed.proj
-    linear_bwd(_op(dt_grad, dt), s.cols, pe, need_dx=False)
+    linear_bwd(dy_next if fuse_cast else _op(dt_grad, dt), s.cols, pe, need_dx=False)
     dpos = torch.empty(N * D, **f32)
     L.colsum(dt_grad.view(B, N * D), dpos)                                            # sum over the batch
     dpos = dpos.view(N, D)
