@@ -257,6 +257,12 @@ int whmr_transpose_colsum(const void* src, long ld_src, void* dst, long ld_dst, 
                           float* scratch, void* stream);
 /* out[c] (+)= sum_r x[r,c]; deterministic two-stage sum; scratch >= max(64*C, 2^20) floats. */
 int whmr_colsum(const void* x, int is_bf16, long ld, int R, int C, float* out, int accumulate, float* scratch, void* stream);
+/* bf16 operand copies of ALL weights of a module in one launch (training: the optimizer rewrites every weight every step).  Item = fp32 matrix
+ * src [N, K] (nn.Linear layout: vit.py:66-68,93,96,157), dst [N, K] bf16 (W operand of y = x . W^T) and dst_t [K, N] bf16 (W operand of the data
+ * gradient dX = dY . W); either may be null.  items: DEVICE array sorted by tile_begin; item i owns ceil(N/64) * tiles_k 64x64 tiles, tiles_k =
+ * ceil(K/64); total_tiles = their sum.  Same bits as whmr_cast_bf16 / whmr_transpose_cast. */
+struct whmr_wprep_item { const float* src; void* dst; void* dst_t; int32_t N, K, tile_begin, tiles_k; };
+int whmr_weights_prepare(const void* items, int n_items, int total_tiles, void* stream);
 /* LayerNorm backward: dx = dLN(x; gamma)(dy) + dres (dres nullable, dx may alias it); dgamma/dbeta (+)=; scratch >= 2048*C floats.
  * cast_out (nullable) [rows, C] bf16 = dx * row_scale[row] (row_scale nullable): the operand of the next branch's backward GEMMs, stochastic-depth
  * factor included (vit.py:132-139), written by the same pass. */

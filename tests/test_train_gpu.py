@@ -837,3 +837,28 @@ def test_passthrough_nodes_accumulate_the_data_gradient_in_place(dev, dt):
         x = x0.clone().requires_grad_(True)
         (fn(x, True)[1].float() * gx).sum().backward()
         assert torch.equal(x.grad.float(), gx.to(dt).float()), name
+
+
+def test_weight_operands_one_launch_matches_the_per_weight_casts(dev):
+    """whmr_weights_prepare (L.WeightOperands): W and W^T bf16 copies of a list of fp32 matrices -- ragged sizes, a 4-D conv weight viewed as
+    [N, K] -- are the bits of whmr_cast_bf16 / whmr_transpose_cast; a second refresh without a version change launches nothing, an in-place
+    update re-makes the copies in the SAME buffers."""
+    from whmr_amd import _lib as L
+    g = torch.Generator().manual_seed(2)
+    ps = [torch.randn(*sh, generator=g).to(dev) for sh in ((768, 3, 16, 16), (2304, 768), (70, 130), (64, 64), (1, 5), (3072, 768))]
+    wo = L.WeightOperands(ps, {id(ps[0]): (768, 768)})
+    ops = wo.refresh()
+    for p in ps:
+        w2 = p.reshape(p.shape[0], -1)
+        w, wt = ops[id(p)]
+        assert torch.equal(w, L.cast_bf16(w2)) and torch.equal(wt, L.transpose_cast(w2, torch.bfloat16, pad_to=1))
+    ptrs = [(a.data_ptr(), b.data_ptr()) for a, b in ops.values()]
+    ops[id(ps[2])][0].zero_()
+    assert wo.refresh() is ops and not ops[id(ps[2])][0].any()                          # unchanged versions: nothing re-made
+    with torch.no_grad():
+        ps[2].mul_(2.0)
+    ops = wo.refresh()
+    assert torch.equal(ops[id(ps[2])][0], L.cast_bf16(ps[2])) and ptrs == [(a.data_ptr(), b.data_ptr()) for a, b in ops.values()]
+    assert not wo.stale()
+    ps[1].data = ps[1].data.clone()
+    assert wo.stale()

@@ -120,6 +120,7 @@ _SIGS = {
     'whmr_iuv_rasterize': [_P, _I, _I, _P, _I, _P, _I, _P, _P, _F, _F, _F, _F, _F, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     'whmr_iuv_losses': [_P, _I, _L, _P, _L, _L, _L, _L, _I, _I, _I, _F, _P, _P, _P],
     'whmr_iuv_losses_bwd': [_P, _I, _L, _P, _L, _L, _L, _L, _I, _I, _I, _F, _P, _P, _L, _P],
+    'whmr_weights_prepare': [_P, _I, _I, _P],
     'whmr_maxpool_nhwc': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'whmr_avgpool_nhwc': [_P, _P, _I, _I, _I, _I, _P],
 }
@@ -821,6 +822,41 @@ def colsum(x, out, accumulate=False):
     _check(lib().whmr_colsum(x.data_ptr(), int(x.dtype == torch.bfloat16), x.stride(0), R, Cc, out.data_ptr(), int(accumulate),
                              sc.data_ptr(), _stream()), 'whmr_colsum')
     return out
+
+
+class WeightOperands:
+    """bf16 operand copies (W [N, K] and W^T [K, N]) of a fixed list of fp32 weight matrices, all re-made by ONE launch (whmr_weights_prepare)
+    whenever a parameter's version moved -- the buffers (and so the pointers a captured graph holds) never change."""
+
+    def __init__(self, params, shapes=None):
+        import struct
+        self.params = list(params)
+        dev = self.params[0].device
+        shapes = shapes or {}
+        self.copies, rows, tb = {}, [], 0
+        for p in self.params:
+            N, K = shapes.get(id(p), (p.shape[0], p.numel() // p.shape[0]))
+            assert p.dtype == torch.float32 and p.is_contiguous()
+            w = torch.empty(N, K, dtype=torch.bfloat16, device=dev)
+            wt = torch.empty(K, N, dtype=torch.bfloat16, device=dev)
+            self.copies[id(p)] = (w, wt)
+            tk = (K + 63) // 64
+            rows.append(struct.pack('<QQQiiii', p.data_ptr(), w.data_ptr(), wt.data_ptr(), N, K, tb, tk))
+            tb += ((N + 63) // 64) * tk
+        self.total = tb
+        self.table = torch.frombuffer(bytearray(b''.join(rows)), dtype=torch.uint8).to(dev)
+        self.ptrs = [p.data_ptr() for p in self.params]
+        self.versions = None
+
+    def stale(self):
+        return self.ptrs != [p.data_ptr() for p in self.params]       # parameter storage replaced (e.g. .to(), load with assign): rebuild
+
+    def refresh(self):
+        v = [p._version for p in self.params]
+        if v != self.versions:
+            _check(lib().whmr_weights_prepare(self.table.data_ptr(), len(self.params), self.total, _stream()), 'whmr_weights_prepare')
+            self.versions = v
+        return self.copies
 
 
 def layernorm_bwd(x, dy, gamma, dres, dx, dgamma, dbeta, eps, accumulate=False, cast_out=None, row_scale=None):

@@ -113,6 +113,48 @@ extern "C" int whmr_transpose_cast(const void* src, int src_bf16, long ld_src, v
     return 0;
 }
 
+// ---- bf16 operand copies of ALL weights of a module in one launch: item i = an fp32 matrix [N, K] (nn.Linear layout), its bf16 copy (the W
+// operand of the forward GEMM, y = x . W^T) and its bf16 transpose [K, N] (the W operand of the data-gradient GEMM, dX = dY . W).  The
+// optimizer rewrites every weight every step, so a training step re-made these 2 x 49 copies of the ViT-B with 68 small launches; here a
+// workgroup finds its matrix by its first-tile index (64 x 64 tiles, items sorted by tile_begin) and does both copies from one read.
+struct whmr_wprep_item { const float* src; bf16_t* dst; bf16_t* dst_t; int32_t N, K, tile_begin, tiles_k; };
+
+__global__ __launch_bounds__(256) void weights_prepare_kernel(const whmr_wprep_item* __restrict__ items, int n_items) {
+    __shared__ float tile[64][65];
+    int lo = 0, hi = n_items - 1;                    // last item whose tile_begin <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[mid].tile_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const whmr_wprep_item it = items[lo];
+    const int t = blockIdx.x - it.tile_begin;
+    const int n0 = (t / it.tiles_k) * 64, k0 = (t % it.tiles_k) * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;          // 64 columns x 4 rows per pass
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+        const int n = n0 + ty + 4 * i, k = k0 + tx;
+        const float v = (n < it.N && k < it.K) ? it.src[(size_t)n * it.K + k] : 0.f;
+        tile[ty + 4 * i][tx] = v;
+        if (it.dst && n < it.N && k < it.K) it.dst[(size_t)n * it.K + k] = f32_to_bf16(v);
+    }
+    __syncthreads();
+    if (!it.dst_t) return;
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+        const int k = k0 + ty + 4 * i, n = n0 + tx;
+        if (k < it.K && n < it.N) it.dst_t[(size_t)k * it.N + n] = f32_to_bf16(tile[tx][ty + 4 * i]);
+    }
+}
+
+// items: DEVICE array of n_items descriptors sorted by tile_begin (item i owns tiles [tile_begin_i, tile_begin_{i+1}), ceil(N/64) * ceil(K/64) of them,
+// tiles_k = ceil(K/64)); total_tiles = their sum.  dst / dst_t may be null.
+extern "C" int whmr_weights_prepare(const void* items, int n_items, int total_tiles, void* stream) {
+    if (!items || n_items <= 0 || total_tiles <= 0) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(weights_prepare_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, (const whmr_wprep_item*)items, n_items);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}
+
 // ---- column sums: partial[chunk][c] over row chunks, then a fixed-order sum of the partials (+= into out when accumulate)
 #define CS_CHUNKS 64
 template <typename T>

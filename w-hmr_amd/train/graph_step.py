@@ -28,6 +28,8 @@ def capture_train_step(model, fn, warmup=3):
     torch.cuda.synchronize()
     if vit is not None and hasattr(vit, '_wcache'):
         vit._wcache.clear()
+    if vit is not None and vit.__dict__.get('_train_operands') is not None:
+        vit.__dict__['_train_operands'].versions = None
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
         loss = fn()

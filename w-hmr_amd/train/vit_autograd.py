@@ -60,7 +60,12 @@ def vit_forward_train(m, x):
     L.patch_im2col(x.float(), s.cols, P, pad)
     pos = m.pos_embed[0, 1:] + m.pos_embed[0, :1]
     t = torch.empty(M, D, **f32)
-    L.gemm(s.cols, m._w(m.patch_embed.proj.weight, (D, Cin * P * P)), t, bias=m.patch_embed.proj.bias, residual=pos, res_row_mod=N)
+    s.ops = ops = _weight_operands(m) if dt == torch.bfloat16 else None
+
+    def wop(p, shape=None):                      # W in the compute dtype: the weight operand of y = x . W^T
+        return ops[id(p)][0] if ops is not None else m._w(p, shape)
+
+    L.gemm(s.cols, wop(m.patch_embed.proj.weight, (D, Cin * P * P)), t, bias=m.patch_embed.proj.bias, residual=pos, res_row_mod=N)
     s.layers = []
     hidden = m.blocks[0].mlp.fc1.weight.shape[0] if m.depth else 0
     # stochastic depth: one [2*depth, B] draw per forward (timm drop_path: mask = floor(keep_prob + U[0,1))), expanded to token rows
@@ -83,7 +88,7 @@ def vit_forward_train(m, x):
         a.h1 = torch.empty(M, D, dtype=dt, device=dev)
         L.layernorm(a.t_in, blk.norm1.weight, blk.norm1.bias, a.h1, 1e-6)
         a.qkv = torch.empty(M, 3 * D, dtype=dt, device=dev)
-        L.gemm(a.h1, m._w(blk.attn.qkv.weight), a.qkv, bias=blk.attn.qkv.bias)
+        L.gemm(a.h1, wop(blk.attn.qkv.weight), a.qkv, bias=blk.attn.qkv.bias)
         a.att = torch.empty(M, D, dtype=dt, device=dev)
         a.lse = None
         if _hip_attention_bwd(m, N):
@@ -92,24 +97,35 @@ def vit_forward_train(m, x):
         else:
             L.attention(a.qkv, a.att, B, N, m.num_heads, D // m.num_heads, m.scale)
         a.t_mid = torch.empty(M, D, **f32)
-        L.gemm(a.att, m._w(blk.attn.proj.weight), a.t_mid, bias=blk.attn.proj.bias, residual=a.t_in, row_scale=a.rs_attn)
+        L.gemm(a.att, wop(blk.attn.proj.weight), a.t_mid, bias=blk.attn.proj.bias, residual=a.t_in, row_scale=a.rs_attn)
         a.h2 = torch.empty(M, D, dtype=dt, device=dev)
         L.layernorm(a.t_mid, blk.norm2.weight, blk.norm2.bias, a.h2, 1e-6)
         a.pre = torch.empty(M, hidden, dtype=dt, device=dev)
         a.hid = torch.empty_like(a.pre)
         if FUSE_GELU and dt == torch.bfloat16:
             # fc1's epilogue leaves both the pre-activation (the backward needs it) and its GELU: no separate pass over the [M, 4D] map
-            L.gemm(a.h2, m._w(blk.mlp.fc1.weight), a.hid, bias=blk.mlp.fc1.bias, act=L.ACT_GELU, pre_out=a.pre)
+            L.gemm(a.h2, wop(blk.mlp.fc1.weight), a.hid, bias=blk.mlp.fc1.bias, act=L.ACT_GELU, pre_out=a.pre)
         else:
-            L.gemm(a.h2, m._w(blk.mlp.fc1.weight), a.pre, bias=blk.mlp.fc1.bias)
+            L.gemm(a.h2, wop(blk.mlp.fc1.weight), a.pre, bias=blk.mlp.fc1.bias)
             L.gelu_fwd(a.pre, a.hid)
         t = torch.empty(M, D, **f32)
-        L.gemm(a.hid, m._w(blk.mlp.fc2.weight), t, bias=blk.mlp.fc2.bias, residual=a.t_mid, row_scale=a.rs_mlp)
+        L.gemm(a.hid, wop(blk.mlp.fc2.weight), t, bias=blk.mlp.fc2.bias, residual=a.t_mid, row_scale=a.rs_mlp)
         s.layers.append(a)
     s.t_last = t
     out = torch.empty(M, D, **f32)
     L.layernorm(t, m.last_norm.weight, m.last_norm.bias, out, 1e-6)
     return out, s
+
+
+def _weight_operands(m):
+    """bf16 mode: the W and W^T operand copies of every matmul weight of the backbone, re-made by one launch per optimizer step
+    (L.WeightOperands / whmr_weights_prepare) instead of a cast or a transposing cast per weight and direction (68 launches per step for ViT-B)"""
+    wo = m.__dict__.get('_train_operands')
+    if wo is None or wo.stale():
+        pe = m.patch_embed.proj.weight
+        ps = [pe] + [w for blk in m.blocks for w in (blk.attn.qkv.weight, blk.attn.proj.weight, blk.mlp.fc1.weight, blk.mlp.fc2.weight)]
+        wo = m.__dict__['_train_operands'] = L.WeightOperands(ps, {id(pe): (pe.shape[0], pe.numel() // pe.shape[0])})
+    return wo.refresh()
 
 
 def _hip_attention_bwd(m, N):
@@ -154,6 +170,8 @@ def vit_backward(m, s, dout):
     mpad = 64 if dt == torch.bfloat16 else 1     # the bf16 kernel needs K % 64 == 0; the token dimension is zero-padded up to it
 
     def wt(p, shape=None):                       # W^T in the compute dtype: the weight operand of dX = dY . W
+        if getattr(s, 'ops', None) is not None:
+            return s.ops[id(p)][1]
         w = p.detach()
         return L.transpose_cast(w.reshape(shape) if shape is not None else w, dt, pad_to=1)
 
