@@ -7,7 +7,7 @@ kt = [t for t in tabs if t == 'kernels'][0]
 cols = [r[1] for r in cur.execute('pragma table_info(%s)' % kt)]
 key = 'stream_id' if 'stream_id' in cols else 'queue_id'
 rows = cur.execute('select start, end, name, %s from %s order by start' % (key, kt)).fetchall()
-adam = [i for i, r in enumerate(rows) if 'multi_tensor_apply' in r[2]]
+adam = [i for i, r in enumerate(rows) if 'multi_tensor_apply' in r[2] and 'Adam' in r[2]]
 # steps end with the last Adam kernel of a group; take the last complete step
 ends = [adam[i] for i in range(len(adam)) if i + 1 == len(adam) or adam[i + 1] - adam[i] > 50]
 lo, hi = ends[-2] + 1, ends[-1] + 1
@@ -17,7 +17,7 @@ first = lambda pat: next(r for r in step if pat in r[2])
 last = lambda pat: [r for r in step if pat in r[2]][-1]
 a = last('attention_bf16_chunk')[1]                 # end of the ViT forward's last attention (+ ~4 launches)
 b = first('attention_bwd_bf16')[0]                  # ViT backward's first attention backward (- ~4 launches)
-c = first('multi_tensor_apply')[0]
+c = next(r for r in step if 'multi_tensor_apply' in r[2] and 'Adam' in r[2])[0]
 names = (('ViT forward', t0, a), ('heads fwd + loss + heads bwd', a, b), ('ViT backward', b, c), ('optimizer', c, step[-1][1]))
 print('step: %d kernels, %.2f ms' % (len(step), (step[-1][1] - t0) / 1e6))
 for nm, s, e in names:
