@@ -5,6 +5,9 @@ Follows datasets/data_utils/img_utils.py:53-101 (gen_trans_from_patch_cv, genera
 (cv2.getAffineTransform / cv2.warpAffine, 8-bit INTER_LINEAR, BORDER_CONSTANT), a third-party dependency that is NOT installed in
 this image: **parity unpinned** -- the algorithm below restates OpenCV's imgwarp.cpp fixed-point scheme (AB_BITS 10, 1/32-pixel
 coordinates, 15-bit weights, (sum + 2^14) >> 15) from its published source; the HIP kernel is checked bit-exactly against THIS.
+Its geometry and interpolation (pixel-centre convention, inverse map, zero border blended in at the frame edge) are pinned against an independent
+implementation -- scipy.ndimage.map_coordinates at the exact inverse-affine coordinates, agreement within the quantisation of the fixed-point
+scheme (tests/test_oracle_cpu.py::test_crop_oracle_against_an_independent_bilinear_warp); the bit-level rounding rule remains unpinned.
 """
 import numpy as np
 

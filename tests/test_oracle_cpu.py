@@ -202,6 +202,32 @@ def test_crop_oracle_known_answers():
     assert np.allclose(t[0], (img[..., 0] / 255.0 - 0.485) / 0.229, atol=1e-6)
 
 
+def test_crop_oracle_against_an_independent_bilinear_warp():
+    """cv2 is not installed, so oracle/crop.py cannot be pinned bit for bit; this pins its GEOMETRY and interpolation against an independent
+    implementation: scipy.ndimage.map_coordinates (order 1, zero padding blended in at the frame edge: 'grid-constant') evaluated at the exact inverse-affine coordinates of every output
+    pixel.  OpenCV's scheme quantises coordinates to 1/32 pixel and the weights to 5 bits, so on a smooth image the two agree to a couple of grey
+    levels -- a wrong pixel-centre convention, transposed axes, a flipped inverse or a border rule would be off by tens."""
+    import numpy as np
+    from scipy import ndimage
+    from oracle import crop as OC
+    yy, xx = np.mgrid[0:240, 0:320].astype(np.float64)
+    img = np.stack([127.5 + 100 * np.sin(xx / 23.0) * np.cos(yy / 31.0), 127.5 + 90 * np.cos(xx / 17.0 + yy / 41.0), 60 + 0.5 * xx + 0.2 * yy], -1)
+    img = np.clip(np.rint(img), 0, 255).astype(np.uint8)
+    for (cx, cy, bw, bh, pw, ph, scale) in ((160.3, 120.7, 150.0, 150.0, 224, 224, 1.2), (40.0, 200.0, 120.0, 160.0, 192, 256, 1.0), (300.5, 20.25, 90.0, 90.0, 64, 64, 1.3)):
+        patch, trans = OC.generate_patch_image_cv(img, cx, cy, bw, bh, pw, ph, False, scale, 0)
+        inv = OC.invert_affine(trans)
+        oy, ox = np.mgrid[0:ph, 0:pw].astype(np.float64)
+        sx = inv[0, 0] * ox + inv[0, 1] * oy + inv[0, 2]
+        sy = inv[1, 0] * ox + inv[1, 1] * oy + inv[1, 2]
+        ref = np.stack([ndimage.map_coordinates(img[..., c].astype(np.float64), [sy, sx], order=1, mode='grid-constant', cval=0.0) for c in range(3)], -1)
+        diff = np.abs(patch.astype(np.float64) - ref)
+        assert diff.max() <= 4.0 and (diff > 2.0).mean() < 2e-3, (diff.max(), (diff > 2.0).mean())
+        assert patch.shape == (ph, pw, 3)
+        outside = (sx < -1) | (sx > 320) | (sy < -1) | (sy > 240)
+        assert not patch[outside].any()                                                   # BORDER_CONSTANT: nothing outside the frame
+        assert outside.any() or scale < 1.25
+
+
 @pytest.mark.parametrize('droppath', [False, True])
 def test_train_oracle_matches_reference_fixture(assets, state_dict, droppath):
     """oracle/train.py (training-mode forward + torch autograd) against tests/golden/whmr_train_b2.npz, which holds the imported
