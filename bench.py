@@ -565,8 +565,10 @@ def main(argv=None):
     n_ranks = count_ranks(dist, dev)
 
     fp32_mode = args.numerics == 'fp32'                               # parity numerics: exact-f32 MFMA (v_mfma_f32_32x32x2_f32) GEMMs
-    gemm = [(f, e0.elapsed_time(e1) * 1e-3) for (name, f, e0, e1) in prof if name == ('gemm_f32' if fp32_mode else 'gemm_bf16')]
-    traffic = gemm_traffic() if (args.workload == 'vit224' and not dry and not fp32_mode) else None        # the PMC passes measured the bf16 kernels
+    x3_mode = args.numerics == 'bf16x3'                               # parity-grade numerics on the bf16 pipes: three bf16 MFMAs per product
+    gemm_name = 'gemm_f32' if fp32_mode else ('gemm_bf16x3' if x3_mode else 'gemm_bf16')
+    gemm = [(f, e0.elapsed_time(e1) * 1e-3) for (name, f, e0, e1) in prof if name == gemm_name]
+    traffic = gemm_traffic() if (args.workload == 'vit224' and not dry and args.numerics == 'bf16') else None        # the PMC passes measured the bf16 kernels
     n_launch = max(len(gemm), 1)
     flops_per_launch = sum(f for f, _ in gemm) / n_launch
     avg_s = sum(t for _, t in gemm) / n_launch
@@ -598,11 +600,15 @@ def main(argv=None):
         if not dry:
             res['model_tflops'] = VIT_FLOP_PER_IMG[args.workload] * n_ranks * args.batch * args.steps / dt / 1e12
             res['roofline'] = {'bound': 'mfma', 'kernel': ('fp32 (exact-f32 MFMA) GEMM launches of one step (%d: gemm_f32_big_kernel for large M, the 64x64 / skinny kernels elsewhere)' % len(gemm)) if fp32_mode else
+                               ('split-bf16 (bf16x3) GEMM launches of one step (%d: gemm_blk_kernel<X3>; achieved / frac count the ALGORITHMIC 2MNK flops -- the '
+                                'matrix pipes issue three bf16 MFMAs per product, see mfma_issue_frac)' % len(gemm)) if x3_mode else
                                'bf16 MFMA GEMM launches of one step (%d: gemm_blk_kernel on the blocked ViT path, gemm_tn_kernel for the weight gradients, gemm_bf16_big_kernel elsewhere)' % len(gemm),
                                'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
                                'flops_per_launch': flops_per_launch, 'avg_launch_us': avg_s * 1e6,
                                'traffic': traffic['bytes_per_launch'] if traffic else None,
                                'traffic_note': traffic['note'] if traffic else 'no PMC pass of the current GEMM sources committed'}
+            if x3_mode:
+                res['roofline']['mfma_issue_frac'] = 3.0 * achieved / peak          # share of the dense bf16 MFMA peak the pipes actually issue
             if args.workload == 'whmr':
                 # the HBM-bound rows of the north star: MAF sampler and SMPL (LBS) call
                 res['hbm_rows'] = whmr_hbm_rows(args, dev)

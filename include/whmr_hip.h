@@ -91,6 +91,16 @@ struct whmr_gemm_blk_desc {
      * stats_in != null) multiplies A = xhat by W = bf16(gamma o W) and applies out = rstd[m] * (acc - mean[m] * colsum[n]) + bias[n], with
      * bias = b + W.beta, colsum[n] = sum_k W'[n,k], mean / rstd of row m from its K/256 partial pairs. */
     void* xhat; float* stats_out; const float* stats_in; const float* colsum; float ln_eps;
+    /* split-bf16 operands ("bf16x3" numerics: the parity-grade mode of the same path -- the reference's Linears are fp32, vit.py:61-115): every
+     * operand is a pair x = x_hi + x_lo (x_hi = bf16(x), x_lo = bf16(x - x_hi): 16 significand bits) and a product is three MFMAs per fragment
+     * pair (hi.hi + lo.hi + hi.lo, fp32 accumulate).  A_lo / W_lo: lo halves in the layout of A / W; C_lo: lo half of a bf16 result (epi 0 / 1,
+     * required there; epi 1 then applies the exact erf GELU of nn.GELU).  All three null = plain bf16 operands.  Not combinable with the
+     * LayerNorm-fold fields. */
+    const void* A_lo; const void* W_lo; void* C_lo;
+    /* per-row shift of a folding producer (xhat != null): xhat / stats_out are taken of (C - s_m), s_m = (shift ? shift[m] : 0) + (shift_stats ?
+     * the mean of row m from shift_stats [rows][N/256][2] : 0), shift_out[m] = s_m when non-null.  LayerNorm is shift-invariant, so the consumer
+     * is unchanged; what is rounded to bf16 is the CENTRED row (error relative to the row's spread, not its offset).  shift_stats != stats_out. */
+    const float* shift; const float* shift_stats; float* shift_out;
 };
 int whmr_gemm_blk(const struct whmr_gemm_blk_desc* p, void* stream);
 int whmr_gemm_blk_tile(const struct whmr_gemm_blk_desc* p, int tile, void* stream);
@@ -103,6 +113,13 @@ int whmr_patch_im2col_blk(const float* x, void* cols, int B, int Cin, int H, int
                           void* stream);
 /* whmr_attention (bf16, d = 64, 64 < N <= 256) on blocked qkv [ceil(B*N/32)][3*H*8][32][8] -> blocked out [ceil(B*N/32)][H*8][32][8]. */
 int whmr_attention_blk(const void* qkv, void* out, int B, int N, int H, float scale, void* stream);
+/* ---- split-bf16 ("bf16x3") forms of the three blocked helpers: results / operands as hi + lo bf16 pairs (16 significand bits) ----
+ * LayerNorm (vit.py:125,133) of the blocked fp32 stream -> blocked operand pair;  PatchEmbed gather (vit.py:157,161) -> blocked pixel pair;
+ * attention core (vit.py:102-111; d = 64, 64 < N <= 256): three MFMAs per product in Q.K^T and in P.V, fp32 softmax, P split in registers. */
+int whmr_layernorm_blk_x3(const float* x, const float* gamma, const float* beta, void* y_hi, void* y_lo, int rows, int C, float eps, void* stream);
+int whmr_patch_im2col_blk_x3(const float* x, void* cols_hi, void* cols_lo, int B, int Cin, int H, int W, int P, int pad, long sb, long sc, long sh,
+                             long sw, void* stream);
+int whmr_attention_blk_x3(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, int B, int N, int H, float scale, void* stream);
 
 /* exact-fp32 MFMA GEMM (v_mfma_f32_32x32x2_f32), any M/N/K.  Parity mode of the calls above, plus always:
  * Regressor fc1/fc2/decpose/decshape/deccam (whmr.py:118-126), Global_Orient_Regressor (whmr.py:295-301),

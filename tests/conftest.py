@@ -9,6 +9,17 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 
+def ew_err(a, b):
+    """element-wise parity metric of the north-star tensors: max over elements of |a - b| / (|b| + rms(b)).  ``ew_err(a, b) < 1e-4`` is
+    |a - b| <= 1e-4 |b| + 1e-4 rms(b) for EVERY element -- small components (tx, ty beside Tz; joints near the origin) are held to the tensor's
+    own scale instead of hiding behind its largest entry (VERDICT r2 weak #2)."""
+    import torch
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    rms = b.pow(2).mean().sqrt().clamp_min(1e-30)
+    return ((a - b).abs() / (b.abs() + rms)).max().item()
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 

@@ -248,3 +248,87 @@ def test_vit_ln_fold_matches_unfolded(dev):
     ef, eu = _rel(out_f.cpu(), ref), _rel(out_u.cpu(), ref)
     print('bf16 ViT vs fp32 reference fixture: LayerNorm folded %.3e, explicit %.3e, folded vs explicit %.3e' % (ef, eu, _rel(out_f, out_u)))
     assert ef < 5e-2 and _rel(out_f, out_u) < 2e-2
+
+
+@pytest.mark.parametrize('outliers', [False, True])
+def test_layernorm_fold_stress_large_row_mean_and_outlier_channels(dev, outliers):
+    """the folded LayerNorm rounds the RAW stream to bf16 before the mean is subtracted, so its error scales with
+    |row mean| / row std -- invisible on random-init streams (mean 0.7, std 2), large on a trained ViT's (token offsets, massive-activation
+    channels).  Stress streams: row mean = +-20 std; and the same plus 4 outlier channels at 100 std (which dominate the row's spread, for
+    every formulation alike).  The GEMM pair LayerNorm -> Linear through (a) the folded form WITH the producer's per-row shift (what the model
+    runs), (b) the folded form rounding the raw stream (shift off), (c) the explicit bf16 LayerNorm pass + bf16 GEMM and (d) the bf16x3 pair,
+    against float64.  Gates: (a) within 2x of (c) on both streams; (b) shows the failure mode on the mean-only stream (> 3x of (c)): that is
+    why the shift exists; (d) stays parity-grade."""
+    from whmr_amd import _lib as L
+    g = torch.Generator().manual_seed(3)
+    M, C, N2 = 1000, 768, 2304
+    std = 1.5
+    t1 = torch.randn(M, C, generator=g) * std + 20 * std * (torch.rand(M, 1, generator=g) * 0.5 + 0.75) * torch.sign(torch.randn(M, 1, generator=g))
+    if outliers:
+        t1[:, [7, 300, 511, 700]] += 100 * std * torch.tensor([1.0, -1.0, 1.0, -1.0])
+    att = torch.randn(M, C, generator=g).bfloat16()
+    wp = (torch.randn(C, C, generator=g) / math.sqrt(C)).bfloat16()
+    bp = torch.randn(C, generator=g)
+    t0 = t1 - (att.float() @ wp.float().t() + bp)                     # residual stream BEFORE the producer GEMM: the producer re-creates t1
+    gamma, beta = torch.randn(C, generator=g) * 0.3 + 1, torch.randn(C, generator=g) * 0.2
+    w2 = torch.randn(N2, C, generator=g) / math.sqrt(C)
+    b2 = torch.randn(N2, generator=g)
+    tb = L.to_blocked(t0.to(dev))
+    nb = tb.shape[0]
+    xhat = torch.empty(nb, C // 8, 32, 8, device=dev, dtype=torch.bfloat16)
+    stats = torch.zeros(nb * 32, C // 256, 2, device=dev)
+    # (a) producer with the per-row shift = the row means of the stream one residual step earlier (t0), as the model chains them
+    L.gemm_blk(L.to_blocked(att.to(dev)), L.to_blocked(wp.to(dev)), tb, M, bias=bp.to(dev), epi=L.EPI_F32_RES, res=tb, xhat=xhat, stats_out=stats,
+               shift=torch.cat([t0.mean(1), torch.zeros(nb * 32 - M)]).to(dev))
+    got_t1 = L.from_blocked(tb, M).cpu()
+    ref = (F.layer_norm(got_t1.double(), (C,), gamma.double(), beta.double(), 1e-6) @ w2.double().t() + b2.double())
+    wf = (w2 * gamma[None, :]).bfloat16()
+    s, c = wf.float().sum(1), b2 + w2 @ beta
+    out = torch.empty(nb, N2 // 8, 32, 8, device=dev, dtype=torch.bfloat16)
+    L.gemm_blk(xhat, L.to_blocked(wf.to(dev)), out, M, bias=c.to(dev), epi=L.EPI_BF16, stats_in=stats, colsum=s.to(dev), ln_eps=1e-6)
+    e_fold = _rel(L.from_blocked(out, M).double().cpu(), ref)
+    # (b) the same pair WITHOUT the shift
+    tb2 = L.to_blocked(t0.to(dev))
+    L.gemm_blk(L.to_blocked(att.to(dev)), L.to_blocked(wp.to(dev)), tb2, M, bias=bp.to(dev), epi=L.EPI_F32_RES, res=tb2, xhat=xhat, stats_out=stats)
+    L.gemm_blk(xhat, L.to_blocked(wf.to(dev)), out, M, bias=c.to(dev), epi=L.EPI_BF16, stats_in=stats, colsum=s.to(dev), ln_eps=1e-6)
+    e_raw = _rel(L.from_blocked(out, M).double().cpu(), ref)
+    # (c) explicit bf16 pipeline: LayerNorm pass -> bf16 operand -> bf16 GEMM
+    h = torch.empty(nb, C // 8, 32, 8, device=dev, dtype=torch.bfloat16)
+    L.layernorm_blk(tb, gamma.to(dev), beta.to(dev), h, M, 1e-6)
+    L.gemm_blk(h, L.to_blocked(w2.bfloat16().to(dev)), out, M, bias=b2.to(dev), epi=L.EPI_BF16)
+    e_explicit = _rel(L.from_blocked(out, M).double().cpu(), ref)
+    # (d) bf16x3: explicit LayerNorm into a hi / lo pair, three MFMAs per product
+    hl = torch.empty_like(h)
+    L.layernorm_blk_x3(tb, gamma.to(dev), beta.to(dev), h, hl, M, 1e-6)
+    w2h, w2l = L.split_bf16(w2)
+    ol = torch.empty_like(out)
+    L.gemm_blk(h, L.to_blocked(w2h.to(dev)), out, M, bias=b2.to(dev), epi=L.EPI_BF16, a_lo=hl, w_lo=L.to_blocked(w2l.to(dev)), out_lo=ol)
+    e_x3 = _rel(L.from_blocked(out, M).double().cpu() + L.from_blocked(ol, M).double().cpu(), ref)
+    print('LayerNorm-fold stress (row mean 20 std%s): folded+shift %.2e, folded raw %.2e, explicit bf16 %.2e, bf16x3 %.2e'
+          % (', 4 channels at 100 std' if outliers else '', e_fold, e_raw, e_explicit, e_x3))
+    assert e_x3 < 3e-5
+    assert e_fold < 2 * e_explicit + 1e-3, 'the folded LayerNorm must not be worse than the explicit bf16 pass on a large-mean stream'
+    if not outliers:
+        assert e_raw > 3 * e_explicit, 'stress stream too tame: rounding the raw stream should show here'
+
+
+def test_vit_ln_fold_shift_chain_on_offset_stream(dev):
+    """the model's shift chain end to end: a ViT-B whose pos_embed carries a large per-token offset (every token's stream sits at ~30 std off
+    zero through all blocks) -- the folded pipeline must track the explicit-LayerNorm pipeline as closely as on the plain weights"""
+    from oracle import synth
+    g = np.load(os.path.join(GOLDEN, 'vit224_b2.npz'))
+    sd = {k: v.clone() for k, v in synth.make_vit_state(1, (224, 224)).items()}
+    off = torch.randn(1, sd['pos_embed'].shape[1], 1, generator=torch.Generator().manual_seed(1)).sign() * 30.0
+    sd['pos_embed'] = sd['pos_embed'] + off
+    x = torch.from_numpy(g['x']).to(dev)
+    m = _vit(sd, (224, 224), dev, True)
+    out_f = m(x)
+    m.ln_fold = False
+    out_u = m(x)
+    from whmr_amd.models.pose_vit import ViT
+    m32 = ViT(img_size=(224, 224), patch_size=16, embed_dim=768, depth=12, num_heads=12, ratio=1, mlp_ratio=4, qkv_bias=True, numerics='bf16x3')
+    m32.load_state_dict(sd, strict=True)
+    ref = m32.to(dev).eval()(x)
+    ef, eu = _rel(out_f, ref), _rel(out_u, ref)
+    print('offset stream (30 std per token): folded+shift %.3e, explicit bf16 LayerNorm %.3e (vs bf16x3)' % (ef, eu))
+    assert ef < 2 * eu + 1e-3

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN
+from conftest import GOLDEN, ew_err
 
 pytestmark = pytest.mark.gpu
 
@@ -131,16 +131,21 @@ def _inputs(gold, dev):
                 orig_shape=t('orig_shape'), bbox_info=t('bbox_info'), is_train=False, J_regressor=None, full_x=t('full_x'))
 
 
-def test_whmr_forward_fp32_matches_reference_fixture(dev, assets, state_dict, gold):
-    """north_star parity gate: pose/shape/cam, 6890x3 vertices, projected 2-D joints within 1e-4 rel (fp32 mode)"""
-    m = _load_model(assets, state_dict, 'fp32', dev)
+PARITY_MODES = ['fp32', 'bf16x3']       # the two parity-grade numerics: exact-f32 MFMA, and split-bf16 (three bf16 MFMAs per product)
+
+
+@pytest.mark.parametrize('numerics', PARITY_MODES)
+def test_whmr_forward_fp32_matches_reference_fixture(dev, assets, state_dict, gold, numerics):
+    """north_star parity gate: pose/shape/cam, 6890x3 vertices, projected 2-D joints within 1e-4 of the reference fixture, ELEMENT-WISE
+    (|a - b| <= 1e-4 |b| + 1e-4 rms(b) for every element) -- in the fp32 mode and in the bf16x3 mode"""
+    m = _load_model(assets, state_dict, numerics, dev)
     out = m(**_inputs(gold, dev))
     assert set(out) == {'local_smpl_vertices', 'smpl_vertices', 'pred_cam_t', 'focal_length', 'cam_rotmat',
                         'render_rotmat', 'shape', 'global_pose', 'local_pose'}
     for k, v in out.items():
-        err = _rel(v, gold['out_' + k])
-        print('%-22s max-rel %.2e' % (k, err))
-        assert err < 1e-4, k
+        err, ew = _rel(v, gold['out_' + k]), ew_err(v, gold['out_' + k])
+        print('%-7s %-22s max-rel %.2e element-wise %.2e' % (numerics, k, err, ew))
+        assert err < 1e-4 and ew < 1e-4, k
     (tr, feats) = m(**_inputs(gold, dev), view='train')
     assert len(tr['smpl_out']) == 4 and len(feats) == 4
     assert _rel(feats[0], gold['s_feat']) < 1e-4
@@ -149,8 +154,8 @@ def test_whmr_forward_fp32_matches_reference_fixture(dev, assets, state_dict, go
         assert _rel(flat[torch.from_numpy(gold['fmap%d_idx' % i])], gold['fmap%d_val' % i]) < 1e-4
         so = tr['smpl_out'][i + 1]
         for k in ('theta', 'verts', 'kp_2d', 'kp_2d_w', 'kp_3d', 'rotmat', 'pred_cam_t', 'focal_length', 'pose'):
-            err = _rel(so[k], gold['iter%d_%s' % (i, k)])
-            assert err < 1e-4, (i, k, err)
+            err, ew = _rel(so[k], gold['iter%d_%s' % (i, k)]), ew_err(so[k], gold['iter%d_%s' % (i, k)])
+            assert err < 1e-4 and ew < 1e-4, (numerics, i, k, err, ew)
         assert so['sub_verts'].shape == (2, 1723, 3) and so['temp_verts'].shape == (2, 431, 3)
     ev, _ = m(**_inputs(gold, dev), view='eval')
     assert _rel(ev['global_output']['global_verts'], gold['out_smpl_vertices']) < 1e-4
@@ -167,12 +172,20 @@ def test_whmr_forward_fp32_matches_reference_fixture(dev, assets, state_dict, go
     assert torch.allclose(o3['cam_rotmat'][1], o3['cam_rotmat'][0]) and _rel(o3['cam_rotmat'][:1], gold['out_cam_rotmat'][:1]) < 1e-4
 
 
+# error budget of the bf16 THROUGHPUT mode against the fp32 reference (max-rel; measured on the synthetic weights: vertices 1e-4, pose 1.3e-4,
+# shape 7e-5, pred_cam_t / focal_length 2.6e-3 -- the Tz head reads the bf16 feature map through a bf16 7x7 conv).  Every vis_dict
+# tensor is gated; the parity-grade modes are 'fp32' and 'bf16x3' (1e-4, element-wise, above).
+BF16_BUDGET = {'local_smpl_vertices': 2e-3, 'smpl_vertices': 2e-3, 'pred_cam_t': 8e-3, 'focal_length': 8e-3, 'cam_rotmat': 2e-2, 'render_rotmat': 2e-2,
+               'shape': 2e-3, 'global_pose': 2e-3, 'local_pose': 2e-3}
+
+
 def test_whmr_forward_bf16_error_report(dev, assets, state_dict, gold):
     m = _load_model(assets, state_dict, 'bf16', dev)
     out = m(**_inputs(gold, dev))
     errs = {k: _rel(v, gold['out_' + k]) for k, v in out.items()}
     print('bf16 perf-mode error vs fp32 reference:', {k: '%.2e' % e for k, e in errs.items()})
-    assert errs['smpl_vertices'] < 5e-2 and errs['local_pose'] < 1e-1
+    for k, e in errs.items():
+        assert e < BF16_BUDGET[k], (k, e)
     assert all(torch.isfinite(v).all() for v in out.values())
 
 
@@ -325,32 +338,41 @@ def test_maf_sampler_mfma_variant(dev, state_dict):
     assert _rel(got3, ref3) < 2e-2
 
 
-def test_whmr_forward_batch64_fp32_vs_cpu_oracle(dev, assets, state_dict):
-    """BASELINE configs[2] at its full batch of 64 (only B=2 was tested): every vis_dict tensor of the fp32 parity mode against
-    the CPU oracle on the same 64 crops, within the north-star 1e-4; camera rotation from ONE hoisted 160x224 frame (the oracle runs the
-    same frame per crop).  ~30 s of CPU oracle."""
+_B64_REF = {}
+
+
+@pytest.mark.parametrize('numerics', PARITY_MODES)
+def test_whmr_forward_batch64_fp32_vs_cpu_oracle(dev, assets, state_dict, numerics):
+    """BASELINE configs[2] at its full batch of 64 (only B=2 was tested): every vis_dict tensor of the parity-grade modes (fp32,
+    bf16x3) against the CPU oracle on the same 64 crops, within the north-star 1e-4 ELEMENT-WISE; camera rotation from ONE hoisted 160x224
+    frame (the oracle runs the same frame per crop).  ~30 s of CPU oracle (computed once for both modes)."""
     from oracle import synth
     from oracle import whmr as OW
     B = 64
     inp = synth.make_inputs(B, 21)
     full = torch.randn(1, 3, 160, 224, generator=torch.Generator().manual_seed(3))
-    torch.set_num_threads(min(16, torch.get_num_threads() * 2))
-    with torch.no_grad():
-        ref = OW.whmr_forward(state_dict, assets, inp['x'], inp['center'], inp['scale'], inp['bbox_height'], inp['orig_shape'], inp['bbox_info'],
-                              full_x=full.expand(B, -1, -1, -1))
-    m = _load_model(assets, state_dict, 'fp32', dev)
+    if 'ref' not in _B64_REF:
+        torch.set_num_threads(min(16, torch.get_num_threads() * 2))
+        with torch.no_grad():
+            _B64_REF['ref'] = OW.whmr_forward(state_dict, assets, inp['x'], inp['center'], inp['scale'], inp['bbox_height'], inp['orig_shape'],
+                                              inp['bbox_info'], full_x=full.expand(B, -1, -1, -1))
+    ref = _B64_REF['ref']
+    m = _load_model(assets, state_dict, numerics, dev)
     d = {k: v.to(dev) for k, v in inp.items()}
     out = m(d['x'], None, d['center'], d['scale'], d['bbox_height'], d['orig_shape'], d['bbox_info'], full_x=full.to(dev))
     for k, v in ref.items():
-        err = _rel(out[k], v.numpy())
-        print('B=64 %-22s max-rel %.2e' % (k, err))
-        assert out[k].shape == v.shape and err < 1e-4, (k, err)
-    # the bf16 perf mode at the same size: vertices / pose stay near 1e-4, reported (not gated at 1e-4: DESIGN 3)
+        err, ew = _rel(out[k], v.numpy()), ew_err(out[k], v.numpy())
+        print('B=64 %-7s %-22s max-rel %.2e element-wise %.2e' % (numerics, k, err, ew))
+        assert out[k].shape == v.shape and err < 1e-4 and ew < 1e-4, (k, err, ew)
+    if numerics != 'fp32':
+        return
+    # the bf16 throughput mode at the same size: every vis_dict tensor inside its budget (DESIGN 3)
     m16 = _load_model(assets, state_dict, 'bf16', dev)
     o16 = m16(d['x'], None, d['center'], d['scale'], d['bbox_height'], d['orig_shape'], d['bbox_info'], full_x=full.to(dev))
     errs = {k: _rel(o16[k], v.numpy()) for k, v in ref.items()}
     print('B=64 bf16 mode:', {k: '%.1e' % e for k, e in errs.items()})
-    assert errs['smpl_vertices'] < 2e-3 and errs['local_pose'] < 2e-3 and errs['shape'] < 2e-3
+    for k, e in errs.items():
+        assert e < BF16_BUDGET[k], (k, e)
 
 
 @pytest.mark.parametrize('B', [1, 7])
@@ -366,11 +388,12 @@ def test_whmr_forward_odd_batches_fp32_vs_cpu_oracle(dev, assets, state_dict, B)
         ref = OW.whmr_forward(state_dict, assets, inp['x'], inp['center'], inp['scale'], inp['bbox_height'], inp['orig_shape'], inp['bbox_info'],
                               full_x=full.expand(B, -1, -1, -1))
     d = {k: v.to(dev) for k, v in inp.items()}
-    m = _load_model(assets, state_dict, 'fp32', dev)
-    out = m(d['x'], None, d['center'], d['scale'], d['bbox_height'], d['orig_shape'], d['bbox_info'], full_x=full.to(dev))
-    for k, v in ref.items():
-        err = _rel(out[k], v.numpy())
-        assert out[k].shape == v.shape and err < 1e-4, (B, k, err)
+    for numerics in PARITY_MODES:
+        m = _load_model(assets, state_dict, numerics, dev)
+        out = m(d['x'], None, d['center'], d['scale'], d['bbox_height'], d['orig_shape'], d['bbox_info'], full_x=full.to(dev))
+        for k, v in ref.items():
+            err, ew = _rel(out[k], v.numpy()), ew_err(out[k], v.numpy())
+            assert out[k].shape == v.shape and err < 1e-4 and ew < 1e-4, (numerics, B, k, err, ew)
     m16 = _load_model(assets, state_dict, 'bf16', dev)
     o16 = m16(d['x'], None, d['center'], d['scale'], d['bbox_height'], d['orig_shape'], d['bbox_info'], full_x=full.to(dev))
     errs = {k: _rel(o16[k], v.numpy()) for k, v in ref.items()}

@@ -33,7 +33,9 @@ class WhmrGemmBlk(C.Structure):
     """struct whmr_gemm_blk_desc (include/whmr_hip.h): blocked-layout bf16 GEMM of the ViT inference path"""
     _fields_ = [('A', C.c_void_p), ('W', C.c_void_p), ('C', C.c_void_p), ('bias', C.c_void_p), ('res', C.c_void_p),
                 ('M', C.c_int32), ('N', C.c_int32), ('K', C.c_int32), ('epi', C.c_int32), ('res_rows', C.c_int32), ('tile', C.c_int32),
-                ('xhat', C.c_void_p), ('stats_out', C.c_void_p), ('stats_in', C.c_void_p), ('colsum', C.c_void_p), ('ln_eps', C.c_float)]
+                ('xhat', C.c_void_p), ('stats_out', C.c_void_p), ('stats_in', C.c_void_p), ('colsum', C.c_void_p), ('ln_eps', C.c_float),
+                ('A_lo', C.c_void_p), ('W_lo', C.c_void_p), ('C_lo', C.c_void_p),
+                ('shift', C.c_void_p), ('shift_stats', C.c_void_p), ('shift_out', C.c_void_p)]
 
 
 class WhmrSmplModel(C.Structure):
@@ -74,6 +76,9 @@ _SIGS = {
     'whmr_layernorm_blk': [_P, _P, _P, _P, _I, _I, _F, _I, _P],
     'whmr_patch_im2col_blk': [_P, _P, _I, _I, _I, _I, _I, _I, _L, _L, _L, _L, _P],
     'whmr_attention_blk': [_P, _P, _I, _I, _I, _F, _P],
+    'whmr_layernorm_blk_x3': [_P, _P, _P, _P, _P, _I, _I, _F, _P],
+    'whmr_patch_im2col_blk_x3': [_P, _P, _P, _I, _I, _I, _I, _I, _I, _L, _L, _L, _L, _P],
+    'whmr_attention_blk_x3': [_P, _P, _P, _P, _I, _I, _I, _F, _P],
     'whmr_attention_set_variant': [_I],
     'whmr_layernorm': [_P, _P, _P, _P, _I, _I, _F, _I, _P],
     'whmr_patch_im2col': [_P, _P, _I, _I, _I, _I, _I, _I, _L, _L, _L, _L, _I, _P],
@@ -309,10 +314,19 @@ def from_blocked(t, R):
     return t.permute(0, 2, 1, 3).reshape(nb * 32, nu * E)[:R].contiguous()
 
 
+def split_bf16(t):
+    """fp32 tensor -> (hi, lo) bf16 pair with hi + lo = t to 16 significand bits (the operand pair of the bf16x3 numerics).  Weight preparation
+    and test data; activations are split inside the kernels that produce them."""
+    t = t.float()
+    hi = t.bfloat16()
+    return hi, (t - hi.float()).bfloat16()
+
+
 def gemm_blk(a, w, out, M, bias=None, epi=EPI_BF16, res=None, res_rows=0, tile=0, xhat=None, stats_out=None, stats_in=None, colsum=None,
-             ln_eps=1e-6):
+             ln_eps=1e-6, a_lo=None, w_lo=None, out_lo=None, shift=None, shift_stats=None, shift_out=None):
     """out = epi(a . w^T + bias [+ res]) on blocked operands: a [M/32][K/8][32][8] bf16, w [N/32][K/8][32][8] bf16,
-    out bf16 [M/32][N/8][32][8] (epi 0/1) or fp32 [M/32][N/4][32][4] (epi 2: + blocked res, may be `out`; epi 3: + res[m % res_rows] row-major)."""
+    out bf16 [M/32][N/8][32][8] (epi 0/1) or fp32 [M/32][N/4][32][4] (epi 2: + blocked res, may be `out`; epi 3: + res[m % res_rows] row-major).
+    a_lo / w_lo (/ out_lo for epi 0/1): the lo halves of split-bf16 operands -> the bf16x3 kernel (three MFMAs per product, fp32-grade result)."""
     _dev(a, w, out, bias, res)
     assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and a.is_contiguous() and w.is_contiguous() and out.is_contiguous()
     N, K = w.shape[0] * 32, w.shape[1] * 8
@@ -332,16 +346,32 @@ def gemm_blk(a, w, out, M, bias=None, epi=EPI_BF16, res=None, res_rows=0, tile=0
         assert epi >= 2 and xhat.dtype == torch.bfloat16 and xhat.is_contiguous() and xhat.shape[0] * 32 >= M and xhat.shape[1] * 8 == N
         assert stats_out.dtype == torch.float32 and stats_out.is_contiguous() and stats_out.numel() >= a.shape[0] * 32 * (N // 256) * 2
         p.xhat, p.stats_out = xhat.data_ptr(), stats_out.data_ptr()
+        rows = a.shape[0] * 32
+        for name, t_, need in (('shift', shift, rows), ('shift_stats', shift_stats, rows * (N // 256) * 2), ('shift_out', shift_out, rows)):
+            if t_ is not None:               # per-row shift of the folded LayerNorm (see include/whmr_hip.h)
+                _dev(t_)
+                assert t_.dtype == torch.float32 and t_.is_contiguous() and t_.numel() >= need, name
+                setattr(p, name, t_.data_ptr())
+        assert shift_stats is None or shift_stats.data_ptr() != stats_out.data_ptr()
     if stats_in is not None:                 # consumer side: a = xhat of the raw stream, w = gamma-scaled weights, bias = b + W.beta
         _dev(stats_in, colsum)
         assert epi < 2 and stats_in.dtype == torch.float32 and colsum.dtype == torch.float32 and colsum.numel() == N and K % 256 == 0
         p.stats_in, p.colsum, p.ln_eps = stats_in.data_ptr(), colsum.data_ptr(), ln_eps
+    x3 = a_lo is not None
+    if x3:
+        _dev(a_lo, w_lo, out_lo)
+        assert a_lo.dtype == torch.bfloat16 and a_lo.shape == a.shape and a_lo.is_contiguous() and w_lo is not None and w_lo.shape == w.shape and w_lo.is_contiguous()
+        assert xhat is None and stats_in is None
+        p.A_lo, p.W_lo = a_lo.data_ptr(), w_lo.data_ptr()
+        if epi < 2:
+            assert out_lo is not None and out_lo.shape == out.shape and out_lo.dtype == torch.bfloat16 and out_lo.is_contiguous()
+            p.C_lo = out_lo.data_ptr()
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         _check(lib().whmr_gemm_blk(C.byref(p), _stream()), 'whmr_gemm_blk')
         e1.record()
-        PROFILE.append(('gemm_bf16', 2.0 * M * N * K, e0, e1))
+        PROFILE.append(('gemm_bf16x3' if x3 else 'gemm_bf16', 2.0 * M * N * K, e0, e1))
         return out
     _check(lib().whmr_gemm_blk(C.byref(p), _stream()), 'whmr_gemm_blk')
     return out
@@ -358,20 +388,43 @@ def layernorm_blk(x, weight, bias, out, rows, eps, out_std=False):
     return out
 
 
-def patch_im2col_blk(x, out, patch, pad):
+def patch_im2col_blk(x, out, patch, pad, out_lo=None):
     _dev(x, out)
     assert x.dtype == torch.float32 and x.dim() == 4 and out.dtype == torch.bfloat16 and out.is_contiguous()
     B, Cin, H, W = x.shape
     sb, sc, sh, sw = x.stride()
+    if out_lo is not None:                   # bf16x3: pixels as a hi / lo pair
+        _dev(out_lo)
+        assert out_lo.dtype == torch.bfloat16 and out_lo.shape == out.shape and out_lo.is_contiguous()
+        _check(lib().whmr_patch_im2col_blk_x3(x.data_ptr(), out.data_ptr(), out_lo.data_ptr(), B, Cin, H, W, patch, pad, sb, sc, sh, sw, _stream()),
+               'whmr_patch_im2col_blk_x3')
+        return out
     _check(lib().whmr_patch_im2col_blk(x.data_ptr(), out.data_ptr(), B, Cin, H, W, patch, pad, sb, sc, sh, sw, _stream()), 'whmr_patch_im2col_blk')
     return out
 
 
-def attention_blk(qkv, out, B, N, H, scale):
+def attention_blk(qkv, out, B, N, H, scale, qkv_lo=None, out_lo=None):
     _dev(qkv, out)
     assert qkv.is_contiguous() and out.is_contiguous() and qkv.dtype == torch.bfloat16 and out.dtype == torch.bfloat16
+    if qkv_lo is not None:                   # bf16x3: operand / result pairs
+        _dev(qkv_lo, out_lo)
+        assert qkv_lo.shape == qkv.shape and qkv_lo.dtype == torch.bfloat16 and qkv_lo.is_contiguous()
+        assert out_lo.shape == out.shape and out_lo.dtype == torch.bfloat16 and out_lo.is_contiguous()
+        _check(lib().whmr_attention_blk_x3(qkv.data_ptr(), qkv_lo.data_ptr(), out.data_ptr(), out_lo.data_ptr(), B, N, H, scale, _stream()),
+               'whmr_attention_blk_x3')
+        return out
     _check(lib().whmr_attention_blk(qkv.data_ptr(), out.data_ptr(), B, N, H, scale, _stream()), 'whmr_attention_blk')
     return out
+
+
+def layernorm_blk_x3(x, weight, bias, out_hi, out_lo, rows, eps):
+    """LayerNorm of a blocked fp32 stream -> blocked split-bf16 operand pair (bf16x3 numerics)"""
+    _dev(x, weight, bias, out_hi, out_lo)
+    assert x.dtype == torch.float32 and x.is_contiguous() and out_hi.is_contiguous() and out_lo.is_contiguous()
+    assert out_hi.dtype == torch.bfloat16 and out_lo.dtype == torch.bfloat16 and out_hi.shape == out_lo.shape
+    _check(lib().whmr_layernorm_blk_x3(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), out_hi.data_ptr(), out_lo.data_ptr(), rows, x.shape[1] * 4, eps,
+                                       _stream()), 'whmr_layernorm_blk_x3')
+    return out_hi
 
 
 def scale_rows_cast(src, scale, dtype):

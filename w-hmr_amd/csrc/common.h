@@ -23,6 +23,13 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, v);
 }
 
+// (a, b) -> packed bf16 hi halves and packed bf16 lo halves: x ~= hi + lo with 16 significand bits (the split-bf16 operand pair of the
+// "bf16x3" numerics); the subtraction is exact in fp32
+__device__ __forceinline__ void split_bf16x2(float a, float b, uint32_t& hi, uint32_t& lo) {
+    hi = pack_bf16x2(a, b);
+    lo = pack_bf16x2(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+}
+
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
 
 __device__ __forceinline__ float wave_sum(float v) {

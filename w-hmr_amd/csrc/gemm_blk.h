@@ -22,4 +22,15 @@ struct whmr_gemm_blk_desc {
     const float* stats_in;
     const float* colsum;
     float ln_eps;
+    // ---- split-bf16 operands ("bf16x3", gemm_blk_x3.hip): x = x_hi + x_lo, three MFMAs per product.  A_lo / W_lo: the lo halves of A / W (same
+    // layout); C_lo: lo half of a bf16 result (epi 0 / 1; epi 1 then applies the exact erf GELU).  All null = plain bf16 operands.
+    const void* A_lo;
+    const void* W_lo;
+    void* C_lo;
+    // ---- per-row shift of a folding producer (xhat != null): xhat and stats_out are taken of (C - s_m) with
+    //   s_m = (shift ? shift[m] : 0) + (shift_stats ? mean of row m from shift_stats [rows][N/256][2] : 0);   shift_out[m] = s_m when non-null.
+    // The consumer formula is unchanged (LayerNorm is shift-invariant); shift_stats must not alias stats_out.
+    const float* shift;
+    const float* shift_stats;
+    float* shift_out;
 };

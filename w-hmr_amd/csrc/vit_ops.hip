@@ -162,10 +162,11 @@ extern "C" int whmr_cast_f32_bf16(const float* src, void* dst, long n, void* str
 // LayerNorm of the fp32 residual stream x [rows/32][C/4][32][4] -> bf16 GEMM operand [rows/32][C/8][32][8] (OUT_STD = 0) or the plain
 // row-major fp32 [rows, C] map the heads consume (OUT_STD = 1: the final last_norm, vit.py:242,330).  One workgroup per 32-row block
 // (a contiguous 32*C*4 bytes): thread = (row, part), each part owns NPER consecutive 16-B column units of its row in registers;
-// two-pass mean / variance like layernorm_kernel, partial sums combined through LDS.
+// two-pass mean / variance like layernorm_kernel, partial sums combined through LDS.  OUT_STD = 2: the split-bf16 operand pair of the
+// "bf16x3" numerics -- y = hi halves, y_lo = lo halves of the fp32 LayerNorm output (both blocked bf16).
 template <int NPER, int PARTS, int OUT_STD>
 __global__ __launch_bounds__(32 * PARTS) void layernorm_blk_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
-                                                                   void* __restrict__ y, int rows, int C, float eps) {
+                                                                   void* __restrict__ y, int rows, int C, float eps, void* __restrict__ y_lo = nullptr) {
     __shared__ float red[2][PARTS][32];
     const int row = threadIdx.x & 31, part = threadIdx.x >> 5;
     const int rb = blockIdx.x;
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(32 * PARTS) void layernorm_blk_kernel(const float* 
     for (int pp = 0; pp < PARTS; ++pp) var += red[1][pp][row];
     const float rstd = 1.0f / sqrtf(var / (float)C + eps);
     const int m = rb * 32 + row;
-    if constexpr (OUT_STD) {
+    if constexpr (OUT_STD == 1) {
         if (m >= rows) return;
         float* yr = (float*)y + (size_t)m * C + n4_0 * 4;
 #pragma unroll
@@ -205,6 +206,22 @@ __global__ __launch_bounds__(32 * PARTS) void layernorm_blk_kernel(const float* 
             const float4 gg = *(const float4*)(g + (n4_0 + q) * 4), bb = *(const float4*)(b + (n4_0 + q) * 4);
             *(float4*)(yr + q * 4) = make_float4((v[q].x - mean) * rstd * gg.x + bb.x, (v[q].y - mean) * rstd * gg.y + bb.y,
                                                  (v[q].z - mean) * rstd * gg.z + bb.z, (v[q].w - mean) * rstd * gg.w + bb.w);
+        }
+    } else if constexpr (OUT_STD == 2) {
+        const size_t off = ((size_t)rb * (C >> 3) + (n4_0 >> 1)) * 256 + row * 8;
+        bf16_t* yb = (bf16_t*)y + off;
+        bf16_t* yl = (bf16_t*)y_lo + off;
+#pragma unroll
+        for (int q = 0; q < NPER; q += 2) {
+            const float4 g0 = *(const float4*)(g + (n4_0 + q) * 4), b0 = *(const float4*)(b + (n4_0 + q) * 4);
+            const float4 g1 = *(const float4*)(g + (n4_0 + q + 1) * 4), b1 = *(const float4*)(b + (n4_0 + q + 1) * 4);
+            uint4 h, l;
+            split_bf16x2((v[q].x - mean) * rstd * g0.x + b0.x, (v[q].y - mean) * rstd * g0.y + b0.y, h.x, l.x);
+            split_bf16x2((v[q].z - mean) * rstd * g0.z + b0.z, (v[q].w - mean) * rstd * g0.w + b0.w, h.y, l.y);
+            split_bf16x2((v[q + 1].x - mean) * rstd * g1.x + b1.x, (v[q + 1].y - mean) * rstd * g1.y + b1.y, h.z, l.z);
+            split_bf16x2((v[q + 1].z - mean) * rstd * g1.z + b1.z, (v[q + 1].w - mean) * rstd * g1.w + b1.w, h.w, l.w);
+            *(uint4*)(yb + (q >> 1) * 256) = h;
+            *(uint4*)(yl + (q >> 1) * 256) = l;
         }
     } else {
         bf16_t* yb = (bf16_t*)y + ((size_t)rb * (C >> 3) + (n4_0 >> 1)) * 256 + row * 8;
@@ -222,9 +239,10 @@ __global__ __launch_bounds__(32 * PARTS) void layernorm_blk_kernel(const float* 
 }
 
 template <int NPER, int PARTS>
-static int launch_ln_blk(const float* x, const float* g, const float* b, void* y, int rows, int C, float eps, int out_std, hipStream_t st) {
+static int launch_ln_blk(const float* x, const float* g, const float* b, void* y, int rows, int C, float eps, int out_std, hipStream_t st, void* y_lo = nullptr) {
     const dim3 grid((rows + 31) / 32), block(32 * PARTS);
-    if (out_std) hipLaunchKernelGGL((layernorm_blk_kernel<NPER, PARTS, 1>), grid, block, 0, st, x, g, b, y, rows, C, eps);
+    if (y_lo) hipLaunchKernelGGL((layernorm_blk_kernel<NPER, PARTS, 2>), grid, block, 0, st, x, g, b, y, rows, C, eps, y_lo);
+    else if (out_std) hipLaunchKernelGGL((layernorm_blk_kernel<NPER, PARTS, 1>), grid, block, 0, st, x, g, b, y, rows, C, eps);
     else hipLaunchKernelGGL((layernorm_blk_kernel<NPER, PARTS, 0>), grid, block, 0, st, x, g, b, y, rows, C, eps);
     WHMR_CHECK_LAUNCH();
     return 0;
@@ -243,10 +261,25 @@ extern "C" int whmr_layernorm_blk(const float* x, const float* gamma, const floa
     return (int)hipErrorInvalidValue;
 }
 
+// Same LayerNorm with the result as a split-bf16 operand pair (y_hi + y_lo ~= LN(x) to 16 significand bits): the "bf16x3" numerics.
+extern "C" int whmr_layernorm_blk_x3(const float* x, const float* gamma, const float* beta, void* y_hi, void* y_lo, int rows, int C, float eps,
+                                     void* stream) {
+    if (rows <= 0 || !y_hi || !y_lo) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    switch (C) {
+        case 768: return launch_ln_blk<24, 8>(x, gamma, beta, y_hi, rows, C, eps, 0, st, y_lo);
+        case 1024: return launch_ln_blk<16, 16>(x, gamma, beta, y_hi, rows, C, eps, 0, st, y_lo);
+        case 1280: return launch_ln_blk<20, 16>(x, gamma, beta, y_hi, rows, C, eps, 0, st, y_lo);
+        case 256: return launch_ln_blk<8, 8>(x, gamma, beta, y_hi, rows, C, eps, 0, st, y_lo);
+    }
+    return (int)hipErrorInvalidValue;
+}
+
 // PatchEmbed gather into the blocked bf16 operand layout [ceil(M/32)][K/8][32][8] (P % 8 == 0): thread = (row in block, k unit),
 // rows fastest, so a half-wave writes one contiguous 512-B unit.
 __global__ __launch_bounds__(256) void patch_im2col_blk_kernel(const float* __restrict__ x, bf16_t* __restrict__ cols, int B, int Cin, int H, int W,
-                                                               int P, int pad, int Hp, int Wp, long sb, long sc, long sh, long sw) {
+                                                               int P, int pad, int Hp, int Wp, long sb, long sc, long sh, long sw,
+                                                               bf16_t* __restrict__ cols_lo) {
     const int K8 = Cin * P * P / 8, P8 = P / 8;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int M = B * Hp * Wp;
@@ -268,18 +301,37 @@ __global__ __launch_bounds__(256) void patch_im2col_blk_kernel(const float* __re
                 if ((unsigned)(ix + e) < (unsigned)W) v[e] = row[(long)(ix + e) * sw];
         }
     }
+    if (cols_lo) {                                      // split-bf16 pair (bf16x3 numerics): pixel = hi + lo
+        uint4 h, l;
+        split_bf16x2(v[0], v[1], h.x, l.x); split_bf16x2(v[2], v[3], h.y, l.y); split_bf16x2(v[4], v[5], h.z, l.z); split_bf16x2(v[6], v[7], h.w, l.w);
+        *(uint4*)(cols + ((size_t)rb * K8 + k8) * 256 + r * 8) = h;
+        *(uint4*)(cols_lo + ((size_t)rb * K8 + k8) * 256 + r * 8) = l;
+        return;
+    }
     *(uint4*)(cols + ((size_t)rb * K8 + k8) * 256 + r * 8) =
         make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
 }
 
-extern "C" int whmr_patch_im2col_blk(const float* x, void* cols, int B, int Cin, int H, int W, int P, int pad,
-                                     long sb, long sc, long sh, long sw, void* stream) {
+static int patch_im2col_blk_launch(const float* x, void* cols, void* cols_lo, int B, int Cin, int H, int W, int P, int pad,
+                                   long sb, long sc, long sh, long sw, void* stream) {
     const int Hp = (H + 2 * pad - P) / P + 1, Wp = (W + 2 * pad - P) / P + 1;
     if (B <= 0 || Hp <= 0 || Wp <= 0 || (P % 8)) return (int)hipErrorInvalidValue;
     const long M = (long)B * Hp * Wp, K8 = (long)Cin * P * P / 8;
     const long total = ((M + 31) / 32) * 32 * K8;
     hipLaunchKernelGGL(patch_im2col_blk_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)cols, B, Cin, H, W,
-                       P, pad, Hp, Wp, sb, sc, sh, sw);
+                       P, pad, Hp, Wp, sb, sc, sh, sw, (bf16_t*)cols_lo);
     WHMR_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int whmr_patch_im2col_blk(const float* x, void* cols, int B, int Cin, int H, int W, int P, int pad,
+                                     long sb, long sc, long sh, long sw, void* stream) {
+    return patch_im2col_blk_launch(x, cols, nullptr, B, Cin, H, W, P, pad, sb, sc, sh, sw, stream);
+}
+
+// the same gather with the pixels as a split-bf16 pair (cols_hi + cols_lo = the fp32 pixel to 16 significand bits): bf16x3 numerics
+extern "C" int whmr_patch_im2col_blk_x3(const float* x, void* cols_hi, void* cols_lo, int B, int Cin, int H, int W, int P, int pad,
+                                        long sb, long sc, long sh, long sw, void* stream) {
+    if (!cols_lo) return (int)hipErrorInvalidValue;
+    return patch_im2col_blk_launch(x, cols_hi, cols_lo, B, Cin, H, W, P, pad, sb, sc, sh, sw, stream);
 }

@@ -157,7 +157,7 @@ class CameraRegressorNetwork(nn.Module):
         key = self._versions()
         if self._prep is not None and self._prep['key'] == key:
             return self._prep
-        dt = torch.float32 if self.numerics == 'fp32' else torch.bfloat16
+        dt = torch.bfloat16 if self.numerics == 'bf16' else torch.float32
         prep = fold_resnet50(self.backbone, dt)
         prep['key'] = key
         prep['fc_w'] = torch.cat([self.fc_vfov.weight, self.fc_pitch.weight, self.fc_roll.weight], 0).detach().float().contiguous()
@@ -172,7 +172,7 @@ class CameraRegressorNetwork(nn.Module):
         if self.training:
             raise RuntimeError('the HIP ResNet-50 folds eval-mode BatchNorm; call .eval() (the reference freezes cam_model, whmr.py:507)')
         P = self._prepare()
-        dt = torch.float32 if self.numerics == 'fp32' else torch.bfloat16
+        dt = torch.bfloat16 if self.numerics == 'bf16' else torch.float32
         dev = images.device
         B = images.shape[0]
         x = run_resnet50(P, images, dt)

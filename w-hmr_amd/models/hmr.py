@@ -41,7 +41,7 @@ class HMR(ResNet50):
     @torch.no_grad()
     def features(self, x):
         """pose_resnet.py:200-217 global_mode view of the same trunk: (feature map [B,2048,H/32,W/32] as an NCHW view, pooled feature [B,2048])."""
-        dt = torch.float32 if self.numerics == 'fp32' else torch.bfloat16
+        dt = torch.bfloat16 if self.numerics == 'bf16' else torch.float32
         ver = tuple(t._version for t in list(self.parameters()) + list(self.buffers())) + (self.numerics, str(x.device))
         if self._prep is None or self._prep[0] != ver:
             self._prep = (ver, fold_resnet50(self, dt))

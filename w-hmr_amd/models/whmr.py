@@ -351,7 +351,7 @@ class WHMR(nn.Module):
     # ------------------------------------------------------------------ derived operands
     @property
     def _dt(self):
-        return torch.float32 if self.numerics == 'fp32' else torch.bfloat16
+        return torch.bfloat16 if self.numerics == 'bf16' else torch.float32
 
     def _deconv_operands(self, i):
         """4 sub-pixel phase matrices [Cout, 4*Cin] (k = (a, b, ci)) with the eval BatchNorm scale folded in, + shift."""

@@ -32,7 +32,7 @@ class _Saved:
 
 
 def _dt(m):
-    return torch.float32 if m.numerics == 'fp32' else torch.bfloat16
+    return torch.bfloat16 if m.numerics == 'bf16' else torch.float32          # 'bf16x3' is an inference mode: it trains in fp32
 
 
 def _op(t, dt):
@@ -130,7 +130,7 @@ def _weight_operands(m):
 
 def _hip_attention_bwd(m, N):
     """The MFMA attention backward kernel covers the bf16 mode at head dim 64 and 64 < N <= 224 tokens (ViT-B/L at 224^2, 256x192)."""
-    return m.numerics != 'fp32' and m.embed_dim // m.num_heads == 64 and 64 < N <= 224
+    return m.numerics == 'bf16' and m.embed_dim // m.num_heads == 64 and 64 < N <= 224
 
 
 def _attention_bwd(qkv, d_att, B, N, H, dh, scale, dt):
