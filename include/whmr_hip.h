@@ -108,11 +108,18 @@ int whmr_gemm_blk_tile(const struct whmr_gemm_blk_desc* p, int tile, void* strea
 int whmr_gemm_blk_set_tile(int slot, int tile);
 /* LayerNorm on the blocked fp32 residual stream -> blocked bf16 GEMM operand (out_std 0) or row-major fp32 [rows, C] (out_std 1: last_norm). */
 int whmr_layernorm_blk(const float* x, const float* gamma, const float* beta, void* y, int rows, int C, float eps, int out_std, void* stream);
+/* The same (out_std 0) + the row means mean_out [ceil(rows/32)*32]: the first LayerNorm of the folded chain (vit.py:125 of block 0) runs explicitly and
+ * seeds the per-row shift of the folding producers behind it (whmr_gemm_blk_desc.shift). */
+int whmr_layernorm_blk_mean(const float* x, const float* gamma, const float* beta, void* y, float* mean_out, int rows, int C, float eps, void* stream);
 /* PatchEmbed gather (vit.py:157,161) into the blocked bf16 operand layout. */
 int whmr_patch_im2col_blk(const float* x, void* cols, int B, int Cin, int H, int W, int P, int pad, long sb, long sc, long sh, long sw,
                           void* stream);
 /* whmr_attention (bf16, d = 64, 64 < N <= 256) on blocked qkv [ceil(B*N/32)][3*H*8][32][8] -> blocked out [ceil(B*N/32)][H*8][32][8]. */
 int whmr_attention_blk(const void* qkv, void* out, int B, int N, int H, float scale, void* stream);
+/* bf16x3 numerics for the row-major / convolution GEMMs (whmr.py:419,488-498): fp32 rows [rows, C] -> bf16 rows [rows, 3C] = [hi | lo | hi]; with the
+ * weights laid out [W_hi | W_hi | W_lo] along the same (per-tap channel) axis ONE whmr_gemm_bf16 launch with Cin' = 3 Cin accumulates the three
+ * split products in fp32. */
+int whmr_split3_bf16(const float* src, void* dst, long rows, int C, void* stream);
 /* ---- split-bf16 ("bf16x3") forms of the three blocked helpers: results / operands as hi + lo bf16 pairs (16 significand bits) ----
  * LayerNorm (vit.py:125,133) of the blocked fp32 stream -> blocked operand pair;  PatchEmbed gather (vit.py:157,161) -> blocked pixel pair;
  * attention core (vit.py:102-111; d = 64, 64 < N <= 256): three MFMAs per product in Q.K^T and in P.V, fp32 softmax, P split in registers. */

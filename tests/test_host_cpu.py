@@ -348,3 +348,17 @@ def test_integration_doc_lists_every_entry_point():
     table = doc[doc.index('| C entry point |'):]
     ghosts = sorted(s for s in set(re.findall(r'`(whmr_[a-z0-9_]+)`', table)) if s not in declared and not s.startswith('whmr_amd'))
     assert not ghosts, 'INTEGRATION.md names entry points the header does not declare: %s' % ghosts
+
+
+def test_bench_launcher_kills_hung_ranks_and_exits_nonzero():
+    """a rank that never finishes must end as a non-zero exit of the launcher, not as a hang of the driver -- the children
+    run in their own process group, which a watchdog kills after --rank-timeout (here: shorter than the ranks' import time)"""
+    import subprocess
+    import sys
+    import time
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dryrun-cpu', '--rank-timeout', '0.3'],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 124, (r.returncode, r.stderr[-400:])
+    assert 'were killed' in r.stderr and '"metric"' not in r.stdout
+    assert time.time() - t0 < 60

@@ -76,7 +76,9 @@ _SIGS = {
     'whmr_layernorm_blk': [_P, _P, _P, _P, _I, _I, _F, _I, _P],
     'whmr_patch_im2col_blk': [_P, _P, _I, _I, _I, _I, _I, _I, _L, _L, _L, _L, _P],
     'whmr_attention_blk': [_P, _P, _I, _I, _I, _F, _P],
+    'whmr_split3_bf16': [_P, _P, _L, _I, _P],
     'whmr_layernorm_blk_x3': [_P, _P, _P, _P, _P, _I, _I, _F, _P],
+    'whmr_layernorm_blk_mean': [_P, _P, _P, _P, _P, _I, _I, _F, _P],
     'whmr_patch_im2col_blk_x3': [_P, _P, _P, _I, _I, _I, _I, _I, _I, _L, _L, _L, _L, _P],
     'whmr_attention_blk_x3': [_P, _P, _P, _P, _I, _I, _I, _F, _P],
     'whmr_attention_set_variant': [_I],
@@ -377,12 +379,19 @@ def gemm_blk(a, w, out, M, bias=None, epi=EPI_BF16, res=None, res_rows=0, tile=0
     return out
 
 
-def layernorm_blk(x, weight, bias, out, rows, eps, out_std=False):
-    """LayerNorm of a blocked fp32 stream -> blocked bf16 operand (out_std False) or row-major fp32 [rows, C] (out_std True)"""
+def layernorm_blk(x, weight, bias, out, rows, eps, out_std=False, mean_out=None):
+    """LayerNorm of a blocked fp32 stream -> blocked bf16 operand (out_std False) or row-major fp32 [rows, C] (out_std True);
+    mean_out (bf16 operand form only): fp32 [ceil(rows/32)*32] receives the row means"""
     _dev(x, weight, bias, out)
     assert x.dtype == torch.float32 and x.is_contiguous() and out.is_contiguous()
     Cdim = x.shape[1] * 4
     assert out.dtype == (torch.float32 if out_std else torch.bfloat16)
+    if mean_out is not None:
+        _dev(mean_out)
+        assert not out_std and mean_out.dtype == torch.float32 and mean_out.is_contiguous() and mean_out.numel() >= x.shape[0] * 32
+        _check(lib().whmr_layernorm_blk_mean(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), out.data_ptr(), mean_out.data_ptr(), rows, Cdim, eps,
+                                             _stream()), 'whmr_layernorm_blk_mean')
+        return out
     _check(lib().whmr_layernorm_blk(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), out.data_ptr(), rows, Cdim, eps, int(out_std), _stream()),
            'whmr_layernorm_blk')
     return out
@@ -415,6 +424,23 @@ def attention_blk(qkv, out, B, N, H, scale, qkv_lo=None, out_lo=None):
         return out
     _check(lib().whmr_attention_blk(qkv.data_ptr(), out.data_ptr(), B, N, H, scale, _stream()), 'whmr_attention_blk')
     return out
+
+
+def split3(x):
+    """fp32 [..., C] (contiguous) -> bf16 [..., 3C] = [hi | lo | hi]: the K-concatenated activation operand of the bf16x3 numerics for the
+    row-major / convolution GEMMs (weights: ``split3_weight``)"""
+    _dev(x)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    Cc = x.shape[-1]
+    out = torch.empty(*x.shape[:-1], 3 * Cc, dtype=torch.bfloat16, device=x.device)
+    _check(lib().whmr_split3_bf16(x.data_ptr(), out.data_ptr(), x.numel() // Cc, Cc, _stream()), 'whmr_split3_bf16')
+    return out
+
+
+def split3_weight(w):
+    """fp32 weight [..., C] -> bf16 [..., 3C] = [W_hi | W_hi | W_lo] along the last axis (the partner of ``split3``)"""
+    hi, lo = split_bf16(w)
+    return torch.cat([hi, hi, lo], dim=-1).contiguous()
 
 
 def layernorm_blk_x3(x, weight, bias, out_hi, out_lo, rows, eps):

@@ -158,6 +158,33 @@ extern "C" int whmr_cast_f32_bf16(const float* src, void* dst, long n, void* str
     return 0;
 }
 
+// fp32 rows [rows, C] -> bf16 rows [rows, 3C] = [hi | lo | hi], x = hi + lo to 16 significand bits: the K-CONCATENATED operand of the bf16x3 numerics
+// for the row-major / convolution GEMMs (whmr.py:419,488-498 deconvs and the Tz head's 7x7 conv in numerics 'bf16x3').  Against weights laid
+// out [W_hi | W_hi | W_lo] along the same axis, ONE plain bf16 GEMM (K' = 3K, per convolution tap: Cin' = 3 Cin) accumulates
+// x_hi.W_hi + x_lo.W_hi + x_hi.W_lo in fp32 -- the three-MFMA product of gemm_blk_x3.hip without touching the row-major kernel.
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long rows, int C4) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * C4) return;
+    const long r = idx / C4;
+    const int c = (int)(idx - r * C4) * 4;
+    const float4 v = *(const float4*)(src + idx * 4);
+    uint2 h, l;
+    split_bf16x2(v.x, v.y, h.x, l.x);
+    split_bf16x2(v.z, v.w, h.y, l.y);
+    bf16_t* d = dst + r * (long)(12 * C4) + c;
+    *(uint2*)d = h;
+    *(uint2*)(d + 4 * C4) = l;
+    *(uint2*)(d + 8 * C4) = h;
+}
+
+extern "C" int whmr_split3_bf16(const float* src, void* dst, long rows, int C, void* stream) {
+    if (rows <= 0 || C <= 0 || (C & 3) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 7)) return (int)hipErrorInvalidValue;
+    const long n = rows * (C / 4);
+    hipLaunchKernelGGL(split3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, rows, C / 4);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}
+
 // ---- blocked-layout variants (the bf16 inference path of the ViT keeps its activations in the 512-B units of gemm_blk.hip) ----------
 // LayerNorm of the fp32 residual stream x [rows/32][C/4][32][4] -> bf16 GEMM operand [rows/32][C/8][32][8] (OUT_STD = 0) or the plain
 // row-major fp32 [rows, C] map the heads consume (OUT_STD = 1: the final last_norm, vit.py:242,330).  One workgroup per 32-row block
@@ -166,7 +193,8 @@ extern "C" int whmr_cast_f32_bf16(const float* src, void* dst, long n, void* str
 // "bf16x3" numerics -- y = hi halves, y_lo = lo halves of the fp32 LayerNorm output (both blocked bf16).
 template <int NPER, int PARTS, int OUT_STD>
 __global__ __launch_bounds__(32 * PARTS) void layernorm_blk_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
-                                                                   void* __restrict__ y, int rows, int C, float eps, void* __restrict__ y_lo = nullptr) {
+                                                                   void* __restrict__ y, int rows, int C, float eps, void* __restrict__ y_lo = nullptr,
+                                                                   float* __restrict__ mean_out = nullptr) {
     __shared__ float red[2][PARTS][32];
     const int row = threadIdx.x & 31, part = threadIdx.x >> 5;
     const int rb = blockIdx.x;
@@ -185,6 +213,7 @@ __global__ __launch_bounds__(32 * PARTS) void layernorm_blk_kernel(const float* 
 #pragma unroll
     for (int pp = 0; pp < PARTS; ++pp) tot += red[0][pp][row];
     const float mean = tot / (float)C;
+    if (mean_out && part == 0) mean_out[rb * 32 + row] = mean;       // row means: the first per-row shift of the folded-LayerNorm chain (gemm_blk `shift`)
     float qs = 0.f;
 #pragma unroll
     for (int q = 0; q < NPER; ++q) {
@@ -239,11 +268,12 @@ __global__ __launch_bounds__(32 * PARTS) void layernorm_blk_kernel(const float* 
 }
 
 template <int NPER, int PARTS>
-static int launch_ln_blk(const float* x, const float* g, const float* b, void* y, int rows, int C, float eps, int out_std, hipStream_t st, void* y_lo = nullptr) {
+static int launch_ln_blk(const float* x, const float* g, const float* b, void* y, int rows, int C, float eps, int out_std, hipStream_t st, void* y_lo = nullptr,
+                         float* mean_out = nullptr) {
     const dim3 grid((rows + 31) / 32), block(32 * PARTS);
-    if (y_lo) hipLaunchKernelGGL((layernorm_blk_kernel<NPER, PARTS, 2>), grid, block, 0, st, x, g, b, y, rows, C, eps, y_lo);
-    else if (out_std) hipLaunchKernelGGL((layernorm_blk_kernel<NPER, PARTS, 1>), grid, block, 0, st, x, g, b, y, rows, C, eps);
-    else hipLaunchKernelGGL((layernorm_blk_kernel<NPER, PARTS, 0>), grid, block, 0, st, x, g, b, y, rows, C, eps);
+    if (y_lo) hipLaunchKernelGGL((layernorm_blk_kernel<NPER, PARTS, 2>), grid, block, 0, st, x, g, b, y, rows, C, eps, y_lo, mean_out);
+    else if (out_std) hipLaunchKernelGGL((layernorm_blk_kernel<NPER, PARTS, 1>), grid, block, 0, st, x, g, b, y, rows, C, eps, (void*)nullptr, mean_out);
+    else hipLaunchKernelGGL((layernorm_blk_kernel<NPER, PARTS, 0>), grid, block, 0, st, x, g, b, y, rows, C, eps, (void*)nullptr, mean_out);
     WHMR_CHECK_LAUNCH();
     return 0;
 }
@@ -257,6 +287,21 @@ extern "C" int whmr_layernorm_blk(const float* x, const float* gamma, const floa
         case 1024: return launch_ln_blk<16, 16>(x, gamma, beta, y, rows, C, eps, out_std, st);     // ViT-L
         case 1280: return launch_ln_blk<20, 16>(x, gamma, beta, y, rows, C, eps, out_std, st);     // ViT-H
         case 256: return launch_ln_blk<8, 8>(x, gamma, beta, y, rows, C, eps, out_std, st);
+    }
+    return (int)hipErrorInvalidValue;
+}
+
+// whmr_layernorm_blk (out_std 0) that also writes the row means [ceil(rows/32)*32]: the first LayerNorm of the folded chain runs as an explicit pass
+// (the patch-embed producer has no earlier statistics to centre its bf16 copy with) and seeds the per-row shift of the producers behind it.
+extern "C" int whmr_layernorm_blk_mean(const float* x, const float* gamma, const float* beta, void* y, float* mean_out, int rows, int C, float eps,
+                                       void* stream) {
+    if (rows <= 0 || !mean_out) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    switch (C) {
+        case 768: return launch_ln_blk<24, 8>(x, gamma, beta, y, rows, C, eps, 0, st, nullptr, mean_out);
+        case 1024: return launch_ln_blk<16, 16>(x, gamma, beta, y, rows, C, eps, 0, st, nullptr, mean_out);
+        case 1280: return launch_ln_blk<20, 16>(x, gamma, beta, y, rows, C, eps, 0, st, nullptr, mean_out);
+        case 256: return launch_ln_blk<8, 8>(x, gamma, beta, y, rows, C, eps, 0, st, nullptr, mean_out);
     }
     return (int)hipErrorInvalidValue;
 }

@@ -227,16 +227,22 @@ class ViT(nn.Module):
             # a producer's column tiles read the previous pair while they write the next one.
             st = [self._buf('stats%d' % i, (nb * 32, D // 256, 2), f32, dev) for i in (0, 1)]
             sh = [self._buf('shift%d' % i, (nb * 32,), f32, dev) for i in (0, 1)]
+            # The FIRST LayerNorm (block 0's norm1) runs as an explicit pass: the patch-embed producer has no earlier statistics to centre its
+            # copy with (pos_embed can carry any per-token offset), and that pass hands the chain its first row means.
             nblk = len(self.blocks)
             cur = 0
             L.gemm_blk(cols, self._wblk(self.patch_embed.proj.weight, (D, K0)), t, M, bias=self.patch_embed.proj.bias, epi=L.EPI_F32_POS,
-                       res=pos, res_rows=N, xhat=h if nblk else None, stats_out=st[cur] if nblk else None, shift_out=sh[cur] if nblk else None)
+                       res=pos, res_rows=N)
             for bi, blk in enumerate(self.blocks):
-                wq, sq, cq = self._wfold(blk.attn.qkv, blk.norm1)
-                L.gemm_blk(h, wq, qkv, M, bias=cq, epi=L.EPI_BF16, stats_in=st[cur], colsum=sq, ln_eps=1e-6)
+                if bi == 0:
+                    L.layernorm_blk(t, blk.norm1.weight, blk.norm1.bias, h, M, 1e-6, mean_out=sh[cur])
+                    L.gemm_blk(h, self._wblk(blk.attn.qkv.weight), qkv, M, bias=blk.attn.qkv.bias, epi=L.EPI_BF16)
+                else:
+                    wq, sq, cq = self._wfold(blk.attn.qkv, blk.norm1)
+                    L.gemm_blk(h, wq, qkv, M, bias=cq, epi=L.EPI_BF16, stats_in=st[cur], colsum=sq, ln_eps=1e-6)
                 L.attention_blk(qkv, att, B, N, heads, self.scale)
                 L.gemm_blk(att, self._wblk(blk.attn.proj.weight), t, M, bias=blk.attn.proj.bias, epi=L.EPI_F32_RES, res=t, xhat=h,
-                           stats_out=st[cur ^ 1], shift=sh[cur], shift_stats=st[cur], shift_out=sh[cur ^ 1])
+                           stats_out=st[cur ^ 1], shift=sh[cur], shift_stats=None if bi == 0 else st[cur], shift_out=sh[cur ^ 1])
                 cur ^= 1
                 w1, s1, c1 = self._wfold(blk.mlp.fc1, blk.norm2)
                 L.gemm_blk(h, w1, hid, M, bias=c1, epi=L.EPI_BF16_GELU, stats_in=st[cur], colsum=s1, ln_eps=1e-6)

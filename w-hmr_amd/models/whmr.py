@@ -370,6 +370,10 @@ class WHMR(nn.Module):
                     taps = [w[:, :, 3 - py - 2 * a, 3 - px - 2 * b] for a in range(2) for b in range(2)]   # each [Cin, Cout]
                     wp = torch.stack(taps, 0).permute(2, 0, 1).reshape(w.shape[1], -1) * s[:, None]
                     phases.append(wp.contiguous())
+            if self.numerics == 'bf16x3':
+                # per tap [W_hi | W_hi | W_lo] against the activation's [x_hi | x_lo | x_hi] (L.split3): one bf16 launch, three split products
+                ph = torch.stack(phases, 0).reshape(4, w.shape[1], 4, w.shape[0])
+                return L.split3_weight(ph).reshape(4, w.shape[1], 12 * w.shape[0]).contiguous(), t.float().contiguous()
             if self._dt == torch.float32:
                 return phases, t.float().contiguous()
             return L.cast_bf16(torch.stack(phases, 0).contiguous()), t.float().contiguous()        # [4, Cout, 4*Cin]
@@ -380,7 +384,11 @@ class WHMR(nn.Module):
 
         def build():
             w0 = c0.detach().permute(0, 2, 3, 1)                                             # [64, ky, kx, ci]
-            if self._dt == torch.float32:
+            if self.numerics == 'bf16x3':            # [W_hi | W_hi | W_lo] per tap, then the chunk-major K order of the bf16 kernel
+                w3 = L.split3_weight(w0.float().contiguous())
+                n, kh, kw, ci = w3.shape
+                w0 = w3.reshape(n, kh * kw, ci // 64, 64).permute(0, 2, 1, 3).reshape(n, -1).contiguous()
+            elif self._dt == torch.float32:
                 w0 = w0.reshape(c0.shape[0], -1).contiguous()                              # [64, (ky,kx,ci)]
             else:   # chunk-major K order (epi_flags bit 3): (ci chunk of 64, ky, kx, ci in chunk) -- window overlap re-read from cache
                 n, kh, kw, ci = w0.shape
@@ -398,6 +406,12 @@ class WHMR(nn.Module):
         phases, shift = self._deconv_operands(i)
         Cout = phases[0].shape[0]
         out = torch.empty(B, 2 * H, 2 * W, Cout, dtype=self._dt, device=x_nhwc.device)
+        if self.numerics == 'bf16x3':          # fp32 map in, fp32 map out; the bf16 kernel on the K-concatenated split operands (Cin' = 3 Cin)
+            L.gemm(L.split3(x_nhwc), phases, out, bias=shift, act=L.ACT_RELU,
+                   conv=dict(IH=H, IW=W, Cin=3 * Cin, OH=H, OW=W, KW=2, SH=1, SW=1, PH=1, PW=1),
+                   scatter=dict(c_off=0, osb=4 * H * W * Cout, osy=4 * W * Cout, osx=2 * Cout),
+                   phases=dict(cy=2 * W * Cout, cx=Cout))
+            return out
         if self._dt != torch.float32:          # all 4 sub-pixel phases in one launch (4x the tiles to fill the CUs)
             L.gemm(x_nhwc, phases, out, bias=shift, act=L.ACT_RELU,
                    conv=dict(IH=H, IW=W, Cin=Cin, OH=H, OW=W, KW=2, SH=1, SW=1, PH=1, PW=1),
@@ -419,8 +433,11 @@ class WHMR(nn.Module):
         assert (C, self.conv[1].weight.shape[0], self.conv[0].weight.shape[0]) == (256, 5, 64)
         H1, W1 = (H - 7) // 3 + 1, (W - 7) // 3 + 1
         y0 = torch.empty(B, H1, W1, 64, dtype=self._dt, device=dev)                  # NHWC, mode dtype (feeds the 2nd conv)
-        L.gemm(f_nhwc, w0, y0.view(-1, 64), conv=dict(IH=H, IW=W, Cin=C, OH=H1, OW=W1, KW=7, SH=3, SW=3, PH=0, PW=0,
-                                                      chunk_major=self._dt != torch.float32))
+        if self.numerics == 'bf16x3':
+            L.gemm(L.split3(f_nhwc), w0, y0.view(-1, 64), conv=dict(IH=H, IW=W, Cin=3 * C, OH=H1, OW=W1, KW=7, SH=3, SW=3, PH=0, PW=0, chunk_major=True))
+        else:
+            L.gemm(f_nhwc, w0, y0.view(-1, 64), conv=dict(IH=H, IW=W, Cin=C, OH=H1, OW=W1, KW=7, SH=3, SW=3, PH=0, PW=0,
+                                                          chunk_major=self._dt != torch.float32))
         H2, W2 = (H1 - 7) // 2 + 1, (W1 - 7) // 2 + 1
         D = H2 * W2
         t = torch.empty(B * 5, D, dtype=torch.float32, device=dev)                  # == conv1(...).reshape(B, 5, -1), whmr.py:571
@@ -461,10 +478,10 @@ class WHMR(nn.Module):
         return t
 
     @staticmethod
-    def _camera_stream(dev):
-        st = _CAM_STREAMS.get(dev)                 # module-level: a Stream inside the module would break copy.deepcopy(model) / pickling
+    def _camera_stream(dev, tag=None):
+        st = _CAM_STREAMS.get((dev, tag))          # module-level: a Stream inside the module would break copy.deepcopy(model) / pickling
         if st is None:
-            st = _CAM_STREAMS[dev] = torch.cuda.Stream(device=dev)
+            st = _CAM_STREAMS[(dev, tag)] = torch.cuda.Stream(device=dev)        # created ON dev, whatever the current device is
         return st
 
     @torch.no_grad()
@@ -534,7 +551,7 @@ class WHMR(nn.Module):
             f = self._deconv(0, f)
             fmaps.append(f)
             main_tz = torch.cuda.current_stream(dev)
-            tz_side = self._camera_stream((dev, 'tz'))
+            tz_side = self._camera_stream(dev, 'tz')
             tz_side.wait_stream(main_tz)
             with torch.cuda.stream(tz_side):
                 for i in (1, 2):

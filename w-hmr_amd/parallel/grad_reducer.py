@@ -81,7 +81,7 @@ class GradReducer:
         for p in ps:
             offs.append(n)
             n += p.numel()
-        self.buckets.append(dict(params=ps, offsets=offs, numel=n, flat=None, pending=len(ps), work=None, event=None))
+        self.buckets.append(dict(params=ps, offsets=offs, numel=n, flat=None, pending=len(ps), work=None, events=[]))
 
     # ---- backward side
     def _active(self):
@@ -100,6 +100,14 @@ class GradReducer:
                                'per backward (gradient accumulation over several backward passes is not supported)')
         self._fired.add(id(p))
         b, i = self._slot[id(p)]
+        if p.grad is not None and p.grad.is_cuda:
+            # The gradient was produced on WHATEVER stream this hook / publish runs on (the heavy chain of the W-HMR step back-propagates on a
+            # side stream and autograd runs a node's backward -- and its AccumulateGrad -- on the stream of its forward).  Record WHERE: the pack
+            # below waits for every gradient of its bucket, not only for the stream the last one arrived on (a smaller bucket or
+            # another parameter order would otherwise pack half-written gradients with no error).
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(p.grad.device))
+            b['events'].append(ev)
         b['pending'] -= 1
         if b['pending'] == 0:
             self._pack_and_launch(b)
@@ -130,6 +138,11 @@ class GradReducer:
         have = [(q, off) for q, off in zip(b['params'], b['offsets']) if q.grad is not None]
         dev = have[0][0].grad.device if have else b['params'][0].device
         full = len(have) == len(b['params'])
+        if dev.type == 'cuda':
+            cur = torch.cuda.current_stream(dev)
+            for ev in b['events']:                   # every gradient of the bucket is complete before the pack reads it, whichever stream made it
+                cur.wait_event(ev)
+        b['events'] = []
         flat = b['flat'] = (torch.empty if full else torch.zeros)(b['numel'], dtype=torch.float32, device=dev)
         if have:
             views = [flat[off:off + q.numel()].view_as(q) for q, off in have]

@@ -13,7 +13,6 @@ import torch.nn.functional as F
 from .. import _lib as L
 from ..core.cfgs import cfg
 from ..utils.iuvmap import iuv_img2map
-from . import heads_autograd
 
 
 def gt_camera_from_translation(cam_t, focal_length=5000.0, img_res=None):
@@ -101,9 +100,8 @@ class IUVLossFn(torch.autograd.Function):
         B, H, W, Cc = y.shape
         ld = y.stride(2)
         dyp = L.iuv_losses_bwd(y, iuv, ctx.w, g, ld)
-        dy = dyp.view(B, H, W, ld)[..., :Cc]
-        heads_autograd.offer_padded_grad(dy, dyp)
-        return dy, None, None
+        # dy is a VIEW of the padded [B*H*W, ld] operand: ConvNHWCFn.backward finds the whole buffer through dy._base (no side channel)
+        return dyp.view(B, H, W, ld)[..., :Cc], None, None
 
 
 def body_uv_losses(u_pred, v_pred, index_pred, ann_pred, uvia_list):

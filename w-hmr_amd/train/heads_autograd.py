@@ -129,15 +129,16 @@ class AttentionF32Fn(torch.autograd.Function):
         return L.attention_bwd_f32(qkv, _f32(dout), B, N, H, d, scale), None, None, None, None, None
 
 
-# A producer that already holds the gradient of a ConvNHWCFn output as the zero-padded [M, npad] matrix (IUVLossFn: csrc/iuv_loss.hip writes it
-# that way) leaves it here, keyed by the address of the [..., :Cout] view it returns to autograd; the convolution's backward then skips the
-# zero-fill + copy that rebuilds that operand.  At most one entry is alive (a new offer drops the previous one).
-_PADDED_GRADS = {}
-
-
-def offer_padded_grad(view, padded):
-    _PADDED_GRADS.clear()
-    _PADDED_GRADS[view.data_ptr()] = padded
+def _padded_base(dy, M, npad, dt):
+    """A producer that already holds the gradient of a ConvNHWCFn output as the zero-padded [M, npad] matrix (IUVLossFn: csrc/iuv_loss.hip writes it
+    that way) returns the [..., :Cout] VIEW of it; the convolution's backward then takes the whole buffer from the view's base and skips the
+    zero-fill + copy that would rebuild that operand.  (Was a process-global dict keyed by data_ptr: ADVICE r2.)"""
+    base = dy._base
+    if base is None or base.dtype != dt or base.numel() != M * npad or not base.is_contiguous() or base.data_ptr() != dy.data_ptr():
+        return None
+    if dy.dim() < 2 or dy.stride(-1) != 1 or dy.stride(-2) != npad:
+        return None
+    return base.view(M, npad)
 
 
 class ConvNHWCFn(torch.autograd.Function):
@@ -184,9 +185,7 @@ class ConvNHWCFn(torch.autograd.Function):
         B, IH, IW, Cin, Cout, KH, KW, OH, OW, S, P, npad, dt = ctx.dims
         dev = x.device
         M, K = B * OH * OW, KH * KW * Cin
-        dyp = _PADDED_GRADS.pop(dy.data_ptr(), None) if npad != Cout else None
-        if dyp is not None and (tuple(dyp.shape) != (M, npad) or dyp.dtype != dt or dy.stride(-2) != npad or dyp.device != dev):
-            dyp = None
+        dyp = _padded_base(dy, M, npad, dt) if npad != Cout else None
         if dyp is not None:
             pass
         elif npad != Cout:
