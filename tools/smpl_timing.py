@@ -1,0 +1,44 @@
+"""One SMPL call (regressor-stage form) at several batch sizes: the one-launch kernel vs the five per-phase launches, 20 calls per HIP graph."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from whmr_amd.utils import synth
+from whmr_amd.models.smpl import SMPL
+
+dev = torch.device('cuda:0')
+assets = synth.make_assets(0)
+m = SMPL(arrays=assets['smpl'], marker_ids=assets['ssm']).to(dev)
+for B in (1, 8, 64, 256):
+    g = torch.Generator().manual_seed(B)
+    betas = torch.randn(B, 10, generator=g).to(dev)
+    rot = (torch.eye(3).expand(B, 24, 3, 3) + 0.1 * torch.randn(B, 24, 3, 3, generator=g)).contiguous().to(dev)
+    res = {}
+    for fused in (False, True, 'csr'):
+        m.fused, m.csr_tail = fused is True, fused == 'csr'
+        fn = lambda: m.run(betas, rot, gram_schmidt=True, want_aa=True, want_smpl_joints=True, want_markers=True)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(3):
+                fn()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            for _ in range(20):
+                fn()
+        gr.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); gr.replay(); e1.record()
+        torch.cuda.synchronize()
+        res[fused] = e0.elapsed_time(e1) / 20 * 1e3
+    from whmr_amd import _lib as L
+    fn = lambda: m.run(betas, rot, gram_schmidt=True, want_aa=True, want_smpl_joints=True, want_markers=True)
+    m.fused = True
+    fn(); torch.cuda.synchronize()
+    st = L.smpl_barrier(dev).cpu()[2:14].view(torch.int64).tolist()
+    print('      phase stamps of workgroup 0 (us): chain %.1f | barrier %.1f | blend+skin %.1f | barrier %.1f | regress+tail %.1f'
+          % tuple((st[i + 1] - st[i]) / 100.0 for i in range(5)))
+    byt = B * 84172.0 + 19.6e6
+    print('B %4d: five launches (dense regression) %.1f us, four launches (CSR tail) %.1f us = %.1f %% of 8 TB/s, one launch %.1f us' % (B, res[False], res['csr'], byt / res['csr'] / 1e6 / 8 * 100, res[True]), flush=True)

@@ -12,80 +12,19 @@
 //   2. smpl_skin       : vertex-parallel, HBM/L2-bound -- v_shaped, + posedirs^T.pose_feature (the 17 MB operand is
 //      read coalesced, once per block for BT images), T = sum_j w_vj A_j, v = T [v_posed; 1].
 //   3. smpl_joints     : per image -- extra-joint regressors over the skinned mesh, vertex picks, JOINT_MAP gather.
-#include "geometry_dev.h"
-
-#define NV 6890
-#define NJ 24
-#define NPF 207
-
-struct whmr_smpl_model {
-    const float* v_template;     // [6890,3]
-    const float* shapedirs;      // [30,6890]   = shapedirs[v][c][l] transposed to [(c*10+l)][v] by the host: coalesced over vertices
-    const float* posedirs;       // [207, 20670]  (smplx layout)
-    const float* lbs_weights;    // [24,6890]   = lbs_weights transposed by the host
-    const float* J_template;     // [24,3]      = J_regressor . v_template
-    const float* J_shapedirs;    // [24,3,10]   = J_regressor . shapedirs
-    const float* J_regressor;    // [24,6890]   (whmr.py:186 smpl_joints; may be null if never requested)
-    const float* J_regressor_extra;  // [9,6890]
-    const int32_t* parents;      // [24]
-    const int32_t* extra_vertex_ids; // [21]
-    const int32_t* joint_map;    // [49] into the 54-joint superset
-    const int32_t* marker_ids;   // [n_markers]
-    int32_t n_markers;
-};
+// Floating-point contraction per EXPRESSION (the language rule), not across statements after inlining (hipcc's default "fast"): whether a product
+// is fused into an fma then depends on the source expression only, not on the kernel it was inlined into -- the per-phase kernels and the
+// one-launch kernel share smpl_dev.h / geometry_dev.h and must produce the same bits.
+#pragma clang fp contract(on)
+#include "smpl_dev.h"
 
 __global__ __launch_bounds__(64) void smpl_pose_chain_kernel(const whmr_smpl_model m, const float* __restrict__ pose9, long pose_stride,
                                                              const float* __restrict__ betas, long beta_stride, int do_gs,
                                                              float* __restrict__ rotmat, float* __restrict__ aa,
                                                              float* __restrict__ A, float* __restrict__ posed_joints,
                                                              float* __restrict__ pose_feat) {
-    __shared__ float sR[NJ][9];
-    __shared__ float sJ[NJ][3];
-    __shared__ float sG[NJ][12];
-    const int b = blockIdx.x, lane = threadIdx.x;
-    if (lane < NJ) {
-        float r[9], o[9];
-        for (int k = 0; k < 9; ++k) r[k] = pose9[(size_t)b * pose_stride + lane * 9 + k];
-        if (do_gs) gram_schmidt9(r, o); else for (int k = 0; k < 9; ++k) o[k] = r[k];
-        for (int k = 0; k < 9; ++k) { sR[lane][k] = o[k]; if (rotmat) rotmat[((size_t)b * NJ + lane) * 9 + k] = o[k]; }
-        if (aa) { float a3[3]; rotmat_to_aa3(o, a3); for (int k = 0; k < 3; ++k) aa[(size_t)b * 72 + lane * 3 + k] = a3[k]; }
-        if (lane >= 1 && pose_feat) {
-            for (int k = 0; k < 9; ++k)
-                pose_feat[(size_t)b * NPF + (lane - 1) * 9 + k] = o[k] - ((k == 0 || k == 4 || k == 8) ? 1.f : 0.f);
-        }
-        // joint locations of the shaped rest mesh
-        for (int c = 0; c < 3; ++c) {
-            float acc = 0.f;
-            for (int l = 0; l < 10; ++l) acc = fmaf(m.J_shapedirs[(lane * 3 + c) * 10 + l], betas[(size_t)b * beta_stride + l], acc);
-            sJ[lane][c] = m.J_template[lane * 3 + c] + acc;
-        }
-    }
-    __syncthreads();
-    // kinematic chain: G_0 = [R_0 | J_0], G_i = G_parent . [R_i | J_i - J_parent]   (lbs.py:41-49); lanes 0..11 own one entry
-    const int row = lane / 4, col = lane % 4;
-    if (lane < 12) sG[0][lane] = (col < 3) ? sR[0][row * 3 + col] : sJ[0][row];
-    __syncthreads();
-    for (int i = 1; i < NJ; ++i) {
-        const int p = m.parents[i];
-        if (lane < 12) {
-            const float g0 = sG[p][row * 4 + 0], g1 = sG[p][row * 4 + 1], g2 = sG[p][row * 4 + 2], g3 = sG[p][row * 4 + 3];
-            float v;
-            if (col < 3) v = g0 * sR[i][col] + g1 * sR[i][3 + col] + g2 * sR[i][6 + col];
-            else v = g0 * (sJ[i][0] - sJ[p][0]) + g1 * (sJ[i][1] - sJ[p][1]) + g2 * (sJ[i][2] - sJ[p][2]) + g3;
-            sG[i][lane] = v;
-        }
-        __syncthreads();
-    }
-    // A_i = G_i with translation  t_i - G_i[:, :3] . J_i   (lbs.py:51-55)
-    for (int e = lane; e < NJ * 12; e += 64) {
-        const int j = e / 12, k = e % 12, r = k / 4, c = k % 4;
-        float v = sG[j][k];
-        if (c == 3) {
-            v = v - (sG[j][r * 4] * sJ[j][0] + sG[j][r * 4 + 1] * sJ[j][1] + sG[j][r * 4 + 2] * sJ[j][2]);
-            if (posed_joints) posed_joints[((size_t)b * NJ + j) * 3 + r] = sG[j][k];
-        }
-        A[(size_t)b * NJ * 12 + e] = v;
-    }
+    __shared__ smpl_chain_lds L;
+    smpl_chain_image(m, pose9, pose_stride, betas, beta_stride, do_gs, rotmat, aa, A, posed_joints, pose_feat, blockIdx.x, threadIdx.x, true, L);
 }
 
 template <int BT>
@@ -120,15 +59,7 @@ __global__ __launch_bounds__(128) void smpl_skin_kernel(const whmr_smpl_model m,
 #pragma unroll
         for (int k = 0; k < 30; ++k) s[k] = m.shapedirs[(size_t)k * NV + v];
 #pragma unroll
-        for (int bb = 0; bb < BT; ++bb) {
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-#pragma unroll
-            for (int l = 0; l < 10; ++l) {
-                const float be = sBeta[l][bb];
-                a0 = fmaf(s[l], be, a0); a1 = fmaf(s[10 + l], be, a1); a2 = fmaf(s[20 + l], be, a2);
-            }
-            acc[bb][0] = t0 + a0; acc[bb][1] = t1 + a1; acc[bb][2] = t2 + a2;
-        }
+        for (int bb = 0; bb < BT; ++bb) smpl_shape_vertex(t0, t1, t2, s, &sBeta[0][bb], BT, acc[bb]);
     }
     if (pose_off) {   // pose-corrective offsets precomputed as one [B,207] x [207,20670] GEMM (whmr_gemm_f32): coalesced 12-B reads
 #pragma unroll
@@ -162,22 +93,7 @@ __global__ __launch_bounds__(128) void smpl_skin_kernel(const whmr_smpl_model m,
 #pragma unroll
     for (int bb = 0; bb < BT; ++bb) {
         if (b0 + bb >= B) break;
-        float T[12];
-#pragma unroll
-        for (int e = 0; e < 12; ++e) T[e] = 0.f;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const float4* a4 = (const float4*)&sA[bb][j * 12];
-            const float4 r0 = a4[0], r1 = a4[1], r2 = a4[2];
-            T[0] = fmaf(w[j], r0.x, T[0]); T[1] = fmaf(w[j], r0.y, T[1]); T[2] = fmaf(w[j], r0.z, T[2]); T[3] = fmaf(w[j], r0.w, T[3]);
-            T[4] = fmaf(w[j], r1.x, T[4]); T[5] = fmaf(w[j], r1.y, T[5]); T[6] = fmaf(w[j], r1.z, T[6]); T[7] = fmaf(w[j], r1.w, T[7]);
-            T[8] = fmaf(w[j], r2.x, T[8]); T[9] = fmaf(w[j], r2.y, T[9]); T[10] = fmaf(w[j], r2.z, T[10]); T[11] = fmaf(w[j], r2.w, T[11]);
-        }
-        const float x = acc[bb][0], y = acc[bb][1], z = acc[bb][2];
-        float* o = verts + ((size_t)(b0 + bb) * NV + v) * 3;
-        o[0] = T[0] * x + T[1] * y + T[2] * z + T[3];
-        o[1] = T[4] * x + T[5] * y + T[6] * z + T[7];
-        o[2] = T[8] * x + T[9] * y + T[10] * z + T[11];
+        smpl_skin_vertex(w, sA[bb], acc[bb][0], acc[bb][1], acc[bb][2], verts + ((size_t)(b0 + bb) * NV + v) * 3);
     }
 }
 
@@ -294,74 +210,15 @@ extern "C" int whmr_smpl_joints(const whmr_smpl_model* m, const float* verts, co
 // pure latency (PyMAF loop, whmr.py:580-627).  One workgroup per image, right behind smpl_regress_kernel: the 54-joint superset is gathered
 // through LDS, the first wave projects the 49 joints (whmr.py:142-173) and all threads write [bbox_info | rotmat | shape | cam] into the
 // NEXT stage's input buffer (whmr.py:105,119).
-struct whmr_stage_tail {
-    // always
-    const float* verts; const float* posed_joints; const float* regd; float* joints49; float* smpl_joints45; float* markers; int32_t R;
-    // projections (state != null): state rows [pose(216) | shape(10) | cam(3)]
-    const float* state; int64_t state_stride; const float* aa; const float* Tz; const float* bbox_h; const float* center; const float* orig_shape;
-    float focal0, res_w, res_h; float* theta; float* kp2d; float* kp2d_w; float* cam_t; float* focal;
-    // next stage input (xc_next != null): xc_next[b*ld + F .. F+234) = [bbox_info(5) | rotmat(216) | shape(10) | cam(3)]
-    const float* bbox_info; const float* rotmat; float* xc_next; int64_t ld_next; int32_t F_next;
-};
-
 __global__ __launch_bounds__(256) void smpl_stage_tail_kernel(const whmr_smpl_model m, const whmr_stage_tail t) {
     __shared__ float sReg[36][3];
     __shared__ float sJ[49][3];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* vb = t.verts + (size_t)b * NV * 3;
+    const int b = blockIdx.x, tid = threadIdx.x;
     const int R = t.R;
     // ---- regressed rows of this image (smpl_regress_kernel: B x R workgroups -- a per-image block walking the 33 dense rows itself was 5x slower)
     if (tid < R * 3) sReg[tid / 3][tid % 3] = t.regd[(size_t)b * R * 3 + tid];
     __syncthreads();
-    // ---- 54-joint superset -> JOINT_MAP (models/smpl.py:61-83), smpl_joints45 (whmr.py:186-187), markers (whmr.py:184)
-    if (tid < 49 * 3) {
-        const int j = tid / 3, c = tid % 3;
-        const int s = m.joint_map[j];
-        float v;
-        if (s < 24) v = t.posed_joints[((size_t)b * NJ + s) * 3 + c];
-        else if (s < 45) v = vb[3 * m.extra_vertex_ids[s - 24] + c];
-        else v = sReg[s - 45][c];
-        sJ[j][c] = v;
-        if (t.joints49) t.joints49[((size_t)b * 49 + j) * 3 + c] = v;
-    }
-    if (t.smpl_joints45 && tid < 45 * 3) {
-        const int j = tid / 3, c = tid % 3;
-        t.smpl_joints45[((size_t)b * 45 + j) * 3 + c] = j < 24 ? sReg[9 + j][c] : vb[3 * m.extra_vertex_ids[j - 24] + c];
-    }
-    if (t.markers)
-        for (int e = tid; e < m.n_markers * 3; e += 256) t.markers[((size_t)b * m.n_markers) * 3 + e] = vb[3 * m.marker_ids[e / 3] + e % 3];
-    __syncthreads();
-    if (t.state) {
-        const float* st = t.state + (size_t)b * t.state_stride;
-        const float s = st[226], tx = st[227], ty = st[228];
-        const float h = t.bbox_h[b], tz = t.Tz[b];
-        const float focal = s * h * tz / 2.f;
-        const float H = t.orig_shape[2 * b], W = t.orig_shape[2 * b + 1];
-        const float ctx = tx + 2.f * (t.center[2 * b] - W / 2.f) / (s * h);
-        const float cty = ty + 2.f * (t.center[2 * b + 1] - H / 2.f) / (s * h);
-        if (tid == 0) { t.cam_t[3 * b] = ctx; t.cam_t[3 * b + 1] = cty; t.cam_t[3 * b + 2] = tz; t.focal[b] = focal; }
-        if (tid >= 64 && tid < 64 + 85) {
-            const int e = tid - 64;
-            t.theta[(size_t)b * 85 + e] = e < 3 ? st[226 + e] : (e < 13 ? st[216 + e - 3] : t.aa[(size_t)b * 72 + e - 13]);
-        }
-        if (tid < 49) {
-            const float tzw = 2.f * t.focal0 / (t.res_h * s + 1e-9f);
-            const float cxw = W / 2.f, cyw = H / 2.f;
-            const float x = sJ[tid][0], y = sJ[tid][1], z = sJ[tid][2];
-            const float zw = z + tzw;
-            t.kp2d[((size_t)b * 49 + tid) * 2] = (t.focal0 * ((x + tx) / zw)) / (t.res_w / 2.f);
-            t.kp2d[((size_t)b * 49 + tid) * 2 + 1] = (t.focal0 * ((y + ty) / zw)) / (t.res_h / 2.f);
-            const float zf = z + tz;
-            t.kp2d_w[((size_t)b * 49 + tid) * 2] = (focal * ((x + ctx) / zf) + cxw) / cxw - 1.f;
-            t.kp2d_w[((size_t)b * 49 + tid) * 2 + 1] = (focal * ((y + cty) / zf) + cyw) / cyw - 1.f;
-        }
-        if (t.xc_next) {
-            float* row = t.xc_next + (size_t)b * t.ld_next + t.F_next;
-            if (tid < 216) row[5 + tid] = t.rotmat[(size_t)b * 216 + tid];
-            else if (tid < 229) row[5 + tid] = st[tid];                       // shape(10) | cam(3) sit at state[216..229)
-            else if (tid < 234) row[tid - 229] = t.bbox_info[b * 5 + tid - 229];
-        }
-    }
+    smpl_stage_tail_image(m, t, b, tid, sReg, sJ, m.joint_map, m.extra_vertex_ids, m.marker_ids);
 }
 
 // scratch: >= B*33*3 floats (the regressed rows); two launches: smpl_regress_kernel (B x R workgroups) + the tail.

@@ -58,6 +58,11 @@ class SMPL(nn.Module):
         ids = marker_ids if marker_ids is not None else torch.zeros(0, dtype=torch.long)
         self.marker_ids = torch.as_tensor(ids, dtype=torch.long)
         self._dev_cache = None
+        # fused = True: the whole call as ONE launch behind two grid barriers (csrc/smpl_fused.hip).  Same bits, but NOT faster on this part
+        # (77 vs 50 us at batch 64 -- every phase of the persistent grid pays its memory round trips alone, with one workgroup per CU),
+        # so the default is the per-phase form: pose chain -> pose-corrective GEMM -> skinning -> CSR joint regression + stage tail (4 launches)
+        self.fused = False
+        self.csr_tail = True        # False: the dense B x 33-workgroup regression + tail launch of round 2 (A/B)
 
     @property
     def faces(self):
@@ -80,6 +85,16 @@ class SMPL(nn.Module):
                     'J_shapedirs': torch.einsum('jv,vcl->jcl', Jreg64, self.shapedirs.double()).float().contiguous(),
                     'parents': i32(self.parents), 'extra': i32(self.extra_joints_idxs), 'jmap': i32(self.joint_map),
                     'markers': i32(self.marker_ids)}
+            regs = keep['regs']                          # CSR of the 33 regressor rows for the one-launch call (real regressors are > 99 % zeros)
+            nz = regs != 0
+            ptr = torch.zeros(regs.shape[0] + 1, dtype=torch.int32, device=dev)
+            ptr[1:] = nz.sum(1).cumsum(0).to(torch.int32)
+            keep['csr'] = (ptr, nz.nonzero()[:, 1].to(torch.int32).contiguous(), regs[nz].contiguous())
+            # posedirs per 64-vertex chunk, k-major inside the chunk, zero padded (k 207 -> 208, vertices 6890 -> 6912): one contiguous 160 KB
+            # tile per work item of the one-launch call
+            pt = torch.zeros(208, 108 * 192, dtype=torch.float32, device=dev)
+            pt[:207, :self.NUM_VERTS * 3] = self.posedirs
+            keep['posedirs_tiled'] = pt.view(208, 108, 192).permute(1, 0, 2).contiguous()
             m = L.WhmrSmplModel()
             m.v_template, m.shapedirs = self.v_template.data_ptr(), keep['shapedirs_t'].data_ptr()
             m.posedirs, m.lbs_weights = self.posedirs.data_ptr(), keep['lbs_weights_t'].data_ptr()
@@ -124,6 +139,14 @@ class SMPL(nn.Module):
         A = torch.empty(B, 24, 12, **f32)
         pj = torch.empty(B, 24, 3, **f32)
         pf = torch.empty(B, 207, **f32)
+        if self.fused:
+            verts = torch.empty(B, self.NUM_VERTS, 3, **f32)
+            joints = torch.empty(B, 49, 3, **f32)
+            sj = torch.empty(B, 45, 3, **f32) if want_smpl_joints else None
+            mk = torch.empty(B, m.n_markers, 3, **f32) if (want_markers and m.n_markers) else None
+            tail = L.smpl_fused(m, self._dev_cache[2]['csr'], self._dev_cache[2]['posedirs_tiled'], pose9, betas, gram_schmidt, rot, aa, A, pj, pf, verts, joints, sj, mk,
+                                post=None if post is None else dict(post, aa=aa), nxt=None if nxt is None else dict(nxt, rotmat=rot))
+            return ModelOutput(verts, joints, sj, rot, aa, mk, tail)
         L.smpl_pose_chain(m, pose9, betas, gram_schmidt, rot, aa, A, pj, pf)
         # pose-corrective offsets: one fp32 MFMA GEMM [B,207] x [207,20670] (verts.py:51-53), then blend + skin
         pose_off = torch.empty(B, self.NUM_VERTS * 3, **f32)
@@ -135,9 +158,10 @@ class SMPL(nn.Module):
         mk = torch.empty(B, m.n_markers, 3, **f32) if (want_markers and m.n_markers) else None
         tail = None
         if post is not None:
-            tail = L.smpl_stage_tail(m, verts, pj, joints, sj, mk, post=dict(post, aa=aa), nxt=None if nxt is None else dict(nxt, rotmat=rot))
+            tail = L.smpl_stage_tail(m, verts, pj, joints, sj, mk, post=dict(post, aa=aa), nxt=None if nxt is None else dict(nxt, rotmat=rot),
+                                     csr=self._dev_cache[2]['csr'] if self.csr_tail else None)
         else:
-            L.smpl_stage_tail(m, verts, pj, joints, sj, mk)
+            L.smpl_stage_tail(m, verts, pj, joints, sj, mk, csr=self._dev_cache[2]['csr'] if self.csr_tail else None)
         return ModelOutput(verts, joints, sj, rot, aa, mk, tail)
 
     def forward(self, betas=None, body_pose=None, global_orient=None, pose2rot=False, **kwargs):
