@@ -332,3 +332,35 @@ def test_vit_ln_fold_shift_chain_on_offset_stream(dev):
     ef, eu = _rel(out_f, ref), _rel(out_u, ref)
     print('offset stream (30 std per token): folded+shift %.3e, explicit bf16 LayerNorm %.3e (vs bf16x3)' % (ef, eu))
     assert ef < 2 * eu + 1e-3
+
+
+@pytest.mark.parametrize('M,N,K', [(392, 768, 768), (1001, 512, 64), (777, 256, 96), (1000, 256, 32), (12544, 2304, 768), (3000, 768, 3072), (6144, 1024, 1024)])
+def test_gemm_blk_w_direct_schedule_is_bit_identical(dev, M, N, K):
+    """the W-direct main loop (weight fragments straight from global memory into registers, three half tiles deep, counted vmcnt; schedule 2)
+    against the LDS-staged main loop on every tile and epilogue: the same MFMAs in the same order -> the same bits; K of 1 / 2 / 3 half tiles
+    (prologue edge cases), K not a multiple of the 3-set unroll (1024 -> 32 half tiles), M tails, and the bf16x3 form"""
+    from whmr_amd import _lib as L
+    g = torch.Generator().manual_seed(M + K)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(N, generator=g).to(dev)
+    res = torch.randn(M, N, generator=g)
+    (ah, al), (wh, wl) = [(L.to_blocked(h.to(dev)), L.to_blocked(l.to(dev))) for h, l in (L.split_bf16(a), L.split_bf16(w))]
+    nb = ah.shape[0]
+    try:
+        for tile in ([0] if M > 4000 else [0x44, 0x43, 0x33, 0x32, 0x22, 0x21, 0x55]):
+            outs = {}
+            for sched in (1, 2):
+                L.lib().whmr_gemm_blk_set_tile(4, sched)
+                o16 = torch.full((nb, N // 8, 32, 8), float('nan'), device=dev, dtype=torch.bfloat16)
+                L.gemm_blk(ah, wh, o16, M, bias=bias, epi=L.EPI_BF16_GELU, tile=tile)
+                t = L.to_blocked(res.to(dev))
+                L.gemm_blk(ah, wh, t, M, bias=bias, epi=L.EPI_F32_RES, res=t, tile=tile)
+                oh, ol = torch.full_like(o16, float('nan')), torch.full_like(o16, float('nan'))
+                L.gemm_blk(ah, wh, oh, M, bias=bias, epi=L.EPI_BF16, tile=tile, a_lo=al, w_lo=wl, out_lo=ol)
+                outs[sched] = (L.from_blocked(o16, M), L.from_blocked(t, M), L.from_blocked(oh, M), L.from_blocked(ol, M))
+            for x, y in zip(outs[1], outs[2]):
+                assert torch.equal(x, y), (hex(tile), M, N, K)
+            assert _rel(outs[2][1].cpu(), a.bfloat16().float() @ w.bfloat16().float().t() + bias.cpu() + res) < 1e-4
+    finally:
+        L.lib().whmr_gemm_blk_set_tile(4, 1)

@@ -157,6 +157,8 @@ def lib():
             fn.argtypes = args
             fn.restype = C.c_int
         _lib = l
+        if os.environ.get('WHMR_BLK_SCHED'):         # A/B switch of the blocked GEMM's main loop (0 / 1: W through LDS, 2: W direct), tools/r3_wd.sh
+            l.whmr_gemm_blk_set_tile(4, int(os.environ['WHMR_BLK_SCHED']))
     return _lib
 
 

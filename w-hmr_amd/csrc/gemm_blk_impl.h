@@ -26,12 +26,17 @@ template <int OFF> __device__ __forceinline__ bf16x8_t blk_lds_read128(uint32_t 
     return v;
 }
 
-template <int MI0, int MI1>
+// WD ("W direct"): the weight fragments never touch LDS -- each wave loads its own 64 columns of W straight from global memory / L2 into
+// registers (a blocked 1-KiB unit IS an MFMA operand: one coalesced global_load_dwordx4 per fragment), three half tiles deep.  The bf16 main loop
+// is co-limited by LDS bandwidth (per 32-deep half tile of a 256 x 256 tile: 8 waves x 12 ds_read_b128 = 768 clk + 256 clk of LDS-DMA writes
+// against 1024 MFMA clk); without the W half the LDS side drops to 512 + 128 clk and the ring holds only A.
+template <int MI0, int MI1, bool WD = false>
 struct blk_cfg {
     static constexpr int MB = MI0 + MI1;                 // A row blocks (32 rows) per tile
     static constexpr int BM = MB * 32, BN = 256;
-    static constexpr int SLOT = (MB + 8) * 2048;         // one half K tile (32 deep) of A and W: 2 KiB per row block
-    static constexpr int HU = (MB + 8) * 2;              // 1-KiB DMA units per half tile
+    static constexpr int NBL = WD ? 0 : 8;               // W row blocks staged through LDS
+    static constexpr int SLOT = (MB + NBL) * 2048;       // one half K tile (32 deep) of A (and W): 2 KiB per row block
+    static constexpr int HU = (MB + NBL) * 2;            // 1-KiB DMA units per half tile
     static constexpr int HUPW = (HU + 7) / 8;            // units per wave (waves >= HU % 8 issue one less when HU % 8 != 0)
     static constexpr int BIAS_OFF = 4 * SLOT;            // [256] floats behind the ring, then [256] floats of the LayerNorm-fold column sums
     static constexpr int STAT_OFF = BIAS_OFF + 2048;     // LayerNorm folding: [BM][4][2] floats -- row statistics (consumer) / per-wave-column partial sums (producer)
@@ -40,9 +45,9 @@ struct blk_cfg {
 };
 
 // SCHED 1: one barrier per half tile, groups in opposite order within a slot;  SCHED 0: two barriers per half tile (MEM | MFMA rendezvous)
-template <int MI0, int MI1, int EPI, int SCHED, bool X3 = false>
+template <int MI0, int MI1, int EPI, int SCHED, bool X3 = false, bool WD = false>
 __global__ __launch_bounds__(512, 2) void gemm_blk_kernel(const whmr_gemm_blk_desc p) {
-    using cfg = blk_cfg<MI0, MI1>;
+    using cfg = blk_cfg<MI0, MI1, WD>;
     constexpr int MB = cfg::MB, BM = cfg::BM, BN = cfg::BN, SLOT = cfg::SLOT, HU = cfg::HU, HUPW = cfg::HUPW, NJ = 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -112,11 +117,13 @@ __global__ __launch_bounds__(512, 2) void gemm_blk_kernel(const whmr_gemm_blk_de
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    hstage(0);
-    if (H > 1) hstage(1);
-    if (H > 2) hstage(2);
-    wait_dma(H > 2 ? 2 : H - 1);
-    __builtin_amdgcn_s_barrier();
+    if constexpr (!WD) {
+        hstage(0);
+        if (H > 1) hstage(1);
+        if (H > 2) hstage(2);
+        wait_dma(H > 2 ? 2 : H - 1);
+        __builtin_amdgcn_s_barrier();
+    }
 
     // ONE barrier per half K tile; the two groups walk a slot in opposite order:
     //   slot k:   group 0: MFMA(k), MEM(k+1)      group 1: MEM(k+1), MFMA(k+1)
@@ -124,6 +131,10 @@ __global__ __launch_bounds__(512, 2) void gemm_blk_kernel(const whmr_gemm_blk_de
     // costs MEM + MFMA, not 2 x max(MEM, MFMA) + a second barrier: qkv 53.9 -> 47.2 us in the lab).  Hazards: MEM(x) of both groups
     // lies in slot x-1: it reads ring slot x & 3 (DMA issued in slot x-4, own share awaited in slot x-2, then a barrier) and refills ring
     // slot (x-1) & 3, last read in slot x-2 by MEM(x-1) -- whose ds_reads are drained (lgkmcnt(0)) before the barrier that ends that slot.
+    // W direct: the wave's 64 weight columns, as an SGPR base + the lane's 16-B offset
+    const uint32_t lane16 = lane * 16;
+    const uint64_t wbase = (uint64_t)(uintptr_t)p.W + ((uint64_t)((n0 >> 5) + wn * NJ) * KC) * 512;
+    const uint64_t wbase_lo = X3 ? (uint64_t)(uintptr_t)p.W_lo + ((uint64_t)((n0 >> 5) + wn * NJ) * KC) * 512 : wbase;
     auto main_loop = [&](auto miw_tag) {
         constexpr int MIW = decltype(miw_tag)::value;
         const uint32_t a_b = lds0 + (wm * MI0) * 2048 + hi * 512 + l31 * 16;
@@ -170,7 +181,117 @@ __global__ __launch_bounds__(512, 2) void gemm_blk_kernel(const whmr_gemm_blk_de
             }
             __builtin_amdgcn_sched_barrier(0);
         };
-        if constexpr (SCHED == 1) {
+        if constexpr (WD) {
+            // ---- W direct: fbq[set] = the wave's W fragments of half tile h (set = h % 3), requested two half tiles ahead of their MFMA phase.
+            // vmcnt bookkeeping: a wave's loads in issue order are ... B(x+1) DMA(x+2) | B(x+2) DMA(x+3) at the end of MEM(x); everything older
+            // (DMA(x+1): its share of the next LDS slot, B(x): the operands of MFMA(x)) must have landed.
+            static_assert(SCHED == 1, "W direct runs the one-barrier schedule");
+            constexpr int NB4 = 2 * NJ;                                    // B loads per half tile and wave
+            bf16x8_t fbq[3][NJ][2];
+            // The loads are inline asm (SGPR base + the lane's 16-B offset), invisible to hipcc's waitcnt pass like the fragment ds_reads above: seen
+            // as ordinary loads it drains vmcnt to ZERO in front of every MFMA phase and in front of every reload of a set (the loads of a set
+            // cross the loop's back edge), i.e. it waits for the DMA three half tiles ahead.  The counted waits of MEMW cover them.
+            auto gload = [](bf16x8_t& dst, uint64_t base, uint32_t voff, auto off_tag) {
+                constexpr int OFF = decltype(off_tag)::value;
+                const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)base), hi32 = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+                const uint64_t sb = ((uint64_t)hi32 << 32) | lo;
+                asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sb), "n"(OFF));
+            };
+            auto loadB = [&](auto set_tag, int h) {
+                constexpr int SET = decltype(set_tag)::value;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    if constexpr (X3) {
+                        gload(fbq[SET][j][0], wbase + (uint64_t)j * KC * 512 + (uint64_t)h * 1024, lane16, std::integral_constant<int, 0>{});
+                        gload(fbq[SET][j][1], wbase_lo + (uint64_t)j * KC * 512 + (uint64_t)h * 1024, lane16, std::integral_constant<int, 0>{});
+                    } else {
+                        const uint64_t b = wbase + (uint64_t)j * KC * 512 + (uint64_t)h * 2048;
+                        gload(fbq[SET][j][0], b, lane16, std::integral_constant<int, 0>{});
+                        gload(fbq[SET][j][1], b, lane16, std::integral_constant<int, 1024>{});
+                    }
+                }
+            };
+            auto wait_young = [&](int nd, int nb) {                         // leave nd DMA groups + nb B groups (the youngest loads) in flight
+                constexpr int D1 = HUPW, D0 = HUPW - 1;
+                if (nb >= 2) {
+                    if (nd >= 2) { if (dma_full) blk_wait_vmcnt<2 * D1 + 2 * NB4>(); else blk_wait_vmcnt<2 * D0 + 2 * NB4>(); }
+                    else if (nd == 1) { if (dma_full) blk_wait_vmcnt<D1 + 2 * NB4>(); else blk_wait_vmcnt<D0 + 2 * NB4>(); }
+                    else blk_wait_vmcnt<2 * NB4>();
+                } else if (nb == 1) {
+                    if (nd >= 1) { if (dma_full) blk_wait_vmcnt<D1 + NB4>(); else blk_wait_vmcnt<D0 + NB4>(); }
+                    else blk_wait_vmcnt<NB4>();
+                } else blk_wait_vmcnt<0>();
+            };
+            auto wait_wd = [&](int x) {                                    // end of MEM(x): allow the loads issued in MEM(x-1) and MEM(x) only
+                const int nd = H - 2 - x, nb = H - 1 - x;                   // younger DMA groups (x+2, x+3) / B groups (x+1, x+2) that exist
+                wait_young(nd < 0 ? 0 : nd > 2 ? 2 : nd, nb < 0 ? 0 : nb > 2 ? 2 : nb);
+            };
+            auto MEMW = [&](auto set_tag, int x) {                          // MEM(x) with set = x % 3: A fragments from LDS, B(x+2) -> set (x+2) % 3
+                constexpr int SET = decltype(set_tag)::value;
+                const uint32_t sa = a_b + (x & 3) * SLOT;
+                fa[0][0] = blk_lds_read128<0>(sa);
+                if constexpr (MIW > 1) fa[1][0] = blk_lds_read128<2048>(sa);
+                if constexpr (MIW > 2) fa[2][0] = blk_lds_read128<4096>(sa);
+                if constexpr (MIW > 3) fa[3][0] = blk_lds_read128<6144>(sa);
+                if constexpr (MIW > 4) fa[4][0] = blk_lds_read128<8192>(sa);
+                fa[0][1] = blk_lds_read128<1024>(sa);
+                if constexpr (MIW > 1) fa[1][1] = blk_lds_read128<2048 + 1024>(sa);
+                if constexpr (MIW > 2) fa[2][1] = blk_lds_read128<4096 + 1024>(sa);
+                if constexpr (MIW > 3) fa[3][1] = blk_lds_read128<6144 + 1024>(sa);
+                if constexpr (MIW > 4) fa[4][1] = blk_lds_read128<8192 + 1024>(sa);
+                if (x + 2 < H) loadB(std::integral_constant<int, (SET + 2) % 3>{}, x + 2);
+                if (x + 3 < H) hstage(x + 3);
+                wait_wd(x);
+                blk_wait_lgkmcnt<0>();
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto MFMAW = [&](auto set_tag) {
+                constexpr int SET = decltype(set_tag)::value;
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (X3) {
+#pragma unroll
+                    for (int t = 0; t < 3; ++t)
+#pragma unroll
+                        for (int i = 0; i < MIW; ++i)
+#pragma unroll
+                            for (int j = 0; j < NJ; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fbq[SET][j][t == 1 ? 1 : 0], fa[i][t == 0 ? 1 : 0], acc[i][j], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                        for (int i = 0; i < MIW; ++i)
+#pragma unroll
+                            for (int j = 0; j < NJ; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fbq[SET][j][kk], fa[i][kk], acc[i][j], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto body = [&](auto set_tag, int k) {                          // slot k: group 0: MFMA(k), MEM(k+1);  group 1: MEM(k+1), MFMA(k+1)
+                constexpr int SET = decltype(set_tag)::value;
+                using next = std::integral_constant<int, (SET + 1) % 3>;
+                __builtin_amdgcn_s_barrier();
+                if (wm == 0) MFMAW(set_tag);
+                if (k + 1 < H) {
+                    MEMW(next{}, k + 1);
+                    if (wm == 1) MFMAW(next{});
+                }
+            };
+            // prologue in the steady-state issue order: DMA(0) | B(0) DMA(1) | B(1) DMA(2); then DMA(0) must have landed (barrier: everyone's share)
+            hstage(0);
+            loadB(std::integral_constant<int, 0>{}, 0);
+            if (H > 1) { hstage(1); loadB(std::integral_constant<int, 1>{}, 1); }
+            if (H > 2) hstage(2);
+            wait_young(H > 2 ? 2 : H - 1, H > 1 ? 2 : 1);
+            __builtin_amdgcn_s_barrier();
+            MEMW(std::integral_constant<int, 0>{}, 0);
+            if (wm == 1) MFMAW(std::integral_constant<int, 0>{});
+            for (int k = 0; k < H; k += 3) {
+                body(std::integral_constant<int, 0>{}, k);
+                if (k + 1 < H) body(std::integral_constant<int, 1>{}, k + 1);
+                if (k + 2 < H) body(std::integral_constant<int, 2>{}, k + 2);
+            }
+        } else if constexpr (SCHED == 1) {
             MEM(0);
             if (wm == 1) MFMA();                                           // group 1 is half a slot ahead
             for (int k = 0; k < H; ++k) {
@@ -367,10 +488,10 @@ __global__ __launch_bounds__(512, 2) void gemm_blk_kernel(const whmr_gemm_blk_de
     }
 }
 
-template <int MI0, int MI1, int EPI, int SCHED, bool X3>
+template <int MI0, int MI1, int EPI, int SCHED, bool X3, bool WD = false>
 static int launch_blk_s(const whmr_gemm_blk_desc& p, hipStream_t st) {
-    using cfg = blk_cfg<MI0, MI1>;
-    auto kern = gemm_blk_kernel<MI0, MI1, EPI, SCHED, X3>;
+    using cfg = blk_cfg<MI0, MI1, WD>;
+    auto kern = gemm_blk_kernel<MI0, MI1, EPI, SCHED, X3, WD>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, cfg::LDS);
@@ -385,8 +506,16 @@ static int launch_blk_s(const whmr_gemm_blk_desc& p, hipStream_t st) {
 
 template <int MI0, int MI1, int EPI, bool X3>
 static int launch_blk(const whmr_gemm_blk_desc& p, hipStream_t st, int sched) {
-    if constexpr (X3) return launch_blk_s<MI0, MI1, EPI, 1, true>(p, st);          // one schedule for the split-operand kernels (the A/B switch is a bf16 lab tool)
-    else return sched ? launch_blk_s<MI0, MI1, EPI, 1, false>(p, st) : launch_blk_s<MI0, MI1, EPI, 0, false>(p, st);
+    // sched: 0 two barriers per half tile, 1 one barrier (W through LDS), 2 one barrier + W direct (fragments straight from global memory)
+    // (the 288- / 320-row tiles keep W in LDS: 160 accumulator registers + three fragment sets do not fit the 256-register budget)
+    constexpr bool WD_OK = MI0 + MI1 <= 8;
+    if constexpr (X3) {
+        if constexpr (WD_OK) { if (sched == 2) return launch_blk_s<MI0, MI1, EPI, 1, true, true>(p, st); }
+        return launch_blk_s<MI0, MI1, EPI, 1, true>(p, st);
+    } else {
+        if constexpr (WD_OK) { if (sched == 2) return launch_blk_s<MI0, MI1, EPI, 1, false, true>(p, st); }
+        return sched ? launch_blk_s<MI0, MI1, EPI, 1, false>(p, st) : launch_blk_s<MI0, MI1, EPI, 0, false>(p, st);
+    }
 }
 
 template <int MI0, int MI1, bool X3>
@@ -417,4 +546,4 @@ static int blk_launch_tile(const whmr_gemm_blk_desc& p, int tile, hipStream_t st
 }
 
 // split-operand launcher (gemm_blk_x3.hip; library-internal), reached through whmr_gemm_blk / whmr_gemm_blk_tile when the descriptor carries lo halves
-__attribute__((visibility("hidden"))) int blk_x3_launch_tile(const whmr_gemm_blk_desc* pp, int tile, void* stream);
+__attribute__((visibility("hidden"))) int blk_x3_launch_tile(const whmr_gemm_blk_desc* pp, int tile, void* stream, int sched);

@@ -3,6 +3,6 @@
 // translation unit so that the 32 extra kernels compile beside the bf16 ones.
 #include "gemm_blk_impl.h"
 
-int blk_x3_launch_tile(const whmr_gemm_blk_desc* pp, int tile, void* stream) {
-    return blk_launch_tile<true>(*pp, tile, (hipStream_t)stream, 1);
+int blk_x3_launch_tile(const whmr_gemm_blk_desc* pp, int tile, void* stream, int sched) {
+    return blk_launch_tile<true>(*pp, tile, (hipStream_t)stream, sched == 2 ? 2 : 1);
 }
