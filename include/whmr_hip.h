@@ -72,6 +72,18 @@ int whmr_set_option(int key, int value);
 /* Same, K sliced over `splits` blocks per tile (fp32 partial sums in p->workspace, deterministic epilogue pass). */
 int whmr_gemm_bf16_split(const struct whmr_gemm* p, int tile, int splits, void* stream);
 
+/* ---- forward glue: the O(batch) arithmetic between the kernels of WHMR.forward, one launch each (geometry.hip) ----
+ * whmr_cam_head: camera-calibration head post-processing (whmr.py:513-522; utils/cam_utils.py:121-145; pare softargmax1d / batch_euler2matrix):
+ *   logits [Bf, ld >= 3 D] = [vfov | pitch | roll] bins (D <= 256) -> soft-argmax -> angles -> cam_rotmat = R([pitch, 0, roll]),
+ *   render_rotmat = R([-pitch, 0, roll]), [B, 3, 3] each; Bf == 1 broadcasts one frame to all B crops, else Bf == B.
+ * whmr_orient_state: input state of Global_Orient_Regressor (whmr.py:295-297): xc[b, F..F+15) = [rot6d(cam_rotmat[b]) | rotmat[b, 0]].
+ * whmr_orient_tail: its tail (whmr.py:301-305,630-640): r [B, 9] -> unbiased Gram-Schmidt -> g_rot, angle-axis;
+ *   g_pose [B, 72] = [aa | pose_aa[:, 3:]], g_rotmat [B, 216] = [g_rot | rotmat[:, 9:]]. */
+int whmr_cam_head(const float* logits, int ld, int D, float pitch_lo, float pitch_hi, float roll_lo, float roll_hi, int Bf, int B,
+                  float* cam_rotmat, float* render_rotmat, void* stream);
+int whmr_orient_state(const float* cam_rotmat, const float* rotmat, long ld_rot, float* xc, long ld, int F, int B, void* stream);
+int whmr_orient_tail(const float* r, const float* pose_aa, const float* rotmat, float* g_pose, float* g_rotmat, int B, void* stream);
+
 /* ---- blocked-layout bf16 GEMM: the ViT's bf16 inference path (vit.py:61-140 qkv / proj / fc1 + GELU / fc2, vit.py:157 patch embed).
  * A [R, C] matrix is stored as [ceil(R/32)][C/E][32][E], E = 8 (bf16) / 4 (fp32): 512-byte units of 32 rows x 16 bytes -- the unit a
  * half-wave of an MFMA 32x32x16 operand fetch reads AND a half-wave of its (operand-swapped) result owns.  LDS-DMA staging copies whole

@@ -580,3 +580,36 @@ def test_gemm_bf16_gelu_epilogues_of_the_training_step(dev, M, N, K):
     # outside the envelope: fp32 output / a residual next to the second output
     with pytest.raises((RuntimeError, AssertionError)):
         L.gemm(a, w, torch.empty(M, N, device=dev), bias=b, act=L.ACT_GELU, pre_out=torch.empty(M, N, device=dev))
+
+
+@pytest.mark.parametrize('Bf,B', [(1, 1), (1, 64), (5, 5)])
+def test_forward_glue_kernels_match_the_tensor_expressions(dev, Bf, B):
+    """whmr_cam_head / whmr_orient_state / whmr_orient_tail (one launch each) against the tensor expressions they replace -- the restatements of
+    utils/cam_utils.py:121-145 + pare softargmax1d / batch_euler2matrix in whmr_amd.models.cam_model (themselves checked against the CPU oracle
+    by test_cam_model_*), rotmat_to_rot6d / unbiased_gram_schmidt / rotation_matrix_to_angle_axis of whmr_amd.utils.geometry (fixture-pinned)"""
+    from whmr_amd import _lib as L
+    from whmr_amd.models.cam_model import PITCH_RANGE, ROLL_RANGE, batch_euler2matrix, convert_preds_to_angles
+    from whmr_amd.utils import geometry as G
+    g = torch.Generator().manual_seed(Bf * 100 + B)
+    logits = (torch.randn(Bf, 768, generator=g) * 3).to(dev)
+    _, pitch, roll = convert_preds_to_angles(logits[:, :256], logits[:, 256:512], logits[:, 512:])
+    if Bf == 1:
+        pitch, roll = pitch.expand(B), roll.expand(B)
+    z = torch.zeros(B, 1, device=dev)
+    ref_cam = batch_euler2matrix(torch.cat([pitch[:, None], z, roll[:, None]], 1))
+    ref_ren = batch_euler2matrix(torch.cat([-pitch[:, None], z, roll[:, None]], 1))
+    cam, ren = L.cam_head(logits, 256, PITCH_RANGE, ROLL_RANGE, B)
+    assert cam.shape == (B, 3, 3) and (cam - ref_cam).abs().max() < 2e-6 and (ren - ref_ren).abs().max() < 2e-6
+    # orientation head state + tail
+    rot = G.batch_rodrigues(torch.randn(B * 24, 3, generator=g).to(dev)).reshape(B, 24, 3, 3)
+    xc = torch.full((B, 2200), float('nan'), device=dev)
+    L.orient_state(cam, rot, xc, 2149)
+    assert torch.equal(xc[:, 2149:2155], cam[:, :, :2].reshape(B, 6)) and torch.equal(xc[:, 2155:2164], rot[:, 0].reshape(B, 9))
+    assert torch.isnan(xc[:, :2149]).all() and torch.isnan(xc[:, 2164:]).all()
+    r = (rot[:, 0] + 0.1 * torch.randn(B, 3, 3, generator=g).to(dev)).reshape(B, 9).contiguous()
+    aa = torch.randn(B, 72, generator=g).to(dev)
+    g_pose, g_rot = L.orient_tail(r, aa, rot.contiguous())
+    gs = G.unbiased_gram_schmidt(r.reshape(-1, 1, 3, 3))
+    assert torch.equal(g_rot[:, 1:], rot[:, 1:]) and torch.equal(g_pose[:, 3:], aa[:, 3:])
+    assert (g_rot[:, :1] - gs).abs().max() < 1e-6
+    assert (g_pose[:, :3] - G.rotation_matrix_to_angle_axis(gs.reshape(-1, 3, 3))).abs().max() < 1e-5

@@ -85,6 +85,9 @@ _SIGS = {
     'whmr_patch_im2col_blk': [_P, _P, _I, _I, _I, _I, _I, _I, _L, _L, _L, _L, _P],
     'whmr_attention_blk': [_P, _P, _I, _I, _I, _F, _P],
     'whmr_split3_bf16': [_P, _P, _L, _I, _P],
+    'whmr_cam_head': [_P, _I, _I, _F, _F, _F, _F, _I, _I, _P, _P, _P],
+    'whmr_orient_state': [_P, _P, _L, _P, _L, _I, _I, _P],
+    'whmr_orient_tail': [_P, _P, _P, _P, _P, _I, _P],
     'whmr_layernorm_blk_x3': [_P, _P, _P, _P, _P, _I, _I, _F, _P],
     'whmr_layernorm_blk_mean': [_P, _P, _P, _P, _P, _I, _I, _F, _P],
     'whmr_patch_im2col_blk_x3': [_P, _P, _P, _I, _I, _I, _I, _I, _I, _L, _L, _L, _L, _P],
@@ -436,6 +439,38 @@ def attention_blk(qkv, out, B, N, H, scale, qkv_lo=None, out_lo=None):
         return out
     _check(lib().whmr_attention_blk(qkv.data_ptr(), out.data_ptr(), B, N, H, scale, _stream()), 'whmr_attention_blk')
     return out
+
+
+def cam_head(logits, D, pitch_range, roll_range, B):
+    """logits [Bf, 3 D] fp32 (vfov | pitch | roll bins) -> (cam_rotmat, render_rotmat) [B, 3, 3]; Bf == 1 is broadcast (one launch)"""
+    _dev(logits)
+    assert logits.dtype == torch.float32 and logits.stride(1) == 1 and logits.shape[1] >= 3 * D
+    Bf = logits.shape[0]
+    cam = torch.empty(B, 3, 3, dtype=torch.float32, device=logits.device)
+    ren = torch.empty(B, 3, 3, dtype=torch.float32, device=logits.device)
+    _check(lib().whmr_cam_head(logits.data_ptr(), logits.stride(0), D, pitch_range[0], pitch_range[1], roll_range[0], roll_range[1], Bf, B,
+                               cam.data_ptr(), ren.data_ptr(), _stream()), 'whmr_cam_head')
+    return cam, ren
+
+
+def orient_state(cam_rotmat, rotmat, xc, F):
+    """xc[:, F:F+15] = [rot6d(cam_rotmat) | rotmat[:, 0]] (whmr.py:295-297), one launch; rotmat [B, 24, 3, 3] (any batch stride)"""
+    _dev(cam_rotmat, rotmat, xc)
+    B = xc.shape[0]
+    cam_rotmat = _f32c(cam_rotmat.contiguous())
+    assert rotmat.dtype == torch.float32 and rotmat[0].is_contiguous() and xc.dtype == torch.float32 and xc.stride(1) == 1 and xc.shape[1] >= F + 15
+    _check(lib().whmr_orient_state(cam_rotmat.data_ptr(), rotmat.data_ptr(), rotmat.stride(0), xc.data_ptr(), xc.stride(0), F, B, _stream()), 'whmr_orient_state')
+
+
+def orient_tail(r, pose_aa, rotmat):
+    """r [B, 9], pose_aa [B, 72], rotmat [B, 24, 3, 3] (contiguous) -> (g_pose [B, 72], g_rotmat [B, 24, 3, 3]) in one launch (whmr.py:301-305,630-640)"""
+    _dev(r, pose_aa, rotmat)
+    B = r.shape[0]
+    assert r.is_contiguous() and pose_aa.is_contiguous() and rotmat.is_contiguous() and r.dtype == pose_aa.dtype == rotmat.dtype == torch.float32
+    g_pose = torch.empty(B, 72, dtype=torch.float32, device=r.device)
+    g_rot = torch.empty(B, 24, 3, 3, dtype=torch.float32, device=r.device)
+    _check(lib().whmr_orient_tail(r.data_ptr(), pose_aa.data_ptr(), rotmat.data_ptr(), g_pose.data_ptr(), g_rot.data_ptr(), B, _stream()), 'whmr_orient_tail')
+    return g_pose, g_rot
 
 
 def split3(x):

@@ -149,3 +149,121 @@ extern "C" int whmr_estimate_translation(const float* S, const float* joints_2d,
     WHMR_CHECK_LAUNCH();
     return 0;
 }
+
+// ---- forward glue: the O(batch) arithmetic around the kernels of WHMR.forward, each a single launch (was ~170 framework element-wise launches
+// per forward: softmax / arange / cos / sin / stack / cat ... -- 10 % of the kernel time of a batch-64 forward and most of a batch-1 forward).
+
+// Camera-calibration head post-processing (whmr.py:513-522 over utils/cam_utils.py:121-145 and pare's softargmax1d / batch_euler2matrix):
+// logits [Bf, 3 D] = [vfov | pitch | roll] bins -> soft-argmax (expected bin under the softmax, mapped to [-1, 1]) -> angle in its range ->
+// cam_rotmat = euler2matrix([pitch, 0, roll]), render_rotmat = euler2matrix([-pitch, 0, roll]) (q = qx qy qz -> R).  One workgroup of D threads
+// per frame; Bf == 1 broadcasts the frame's matrices to all B crops (demo/tester.py:161 replicates the frame instead).
+__device__ __forceinline__ void euler_xz_to_mat(float px, float rz, float* R) {
+    // pare / DECA batch_euler2matrix with y = 0: quaternion (w, x, y, z) of qx . qy . qz, normalised, then the standard q -> R
+    const float cx = cosf(0.5f * px), sx = sinf(0.5f * px), cz = cosf(0.5f * rz), sz = sinf(0.5f * rz);
+    float w = cx * cz, x = cz * sx, y = -sx * sz, z = cx * sz;          // cy = 1, sy = 0
+    const float n = sqrtf(w * w + x * x + y * y + z * z);
+    w /= n; x /= n; y /= n; z /= n;
+    const float w2 = w * w, x2 = x * x, y2 = y * y, z2 = z * z, wx = w * x, wy = w * y, wz = w * z, xy = x * y, xz = x * z, yz = y * z;
+    R[0] = w2 + x2 - y2 - z2; R[1] = 2 * xy - 2 * wz; R[2] = 2 * wy + 2 * xz;
+    R[3] = 2 * wz + 2 * xy; R[4] = w2 - x2 + y2 - z2; R[5] = 2 * yz - 2 * wx;
+    R[6] = 2 * xz - 2 * wy; R[7] = 2 * wx + 2 * yz; R[8] = w2 - x2 - y2 + z2;
+}
+
+__global__ __launch_bounds__(256) void cam_head_kernel(const float* __restrict__ logits, int ld, int D, float p_lo, float p_hi, float r_lo, float r_hi,
+                                                       int Bf, int B, float* __restrict__ cam_rotmat, float* __restrict__ render_rotmat) {
+    __shared__ float red[2][3][4];
+    __shared__ float sR[18];
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float v[2], m[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {                                        // a = 0 pitch bins (columns D..2D), 1 roll bins (2D..3D)
+        v[a] = tid < D ? logits[(size_t)f * ld + (a + 1) * D + tid] : -INFINITY;
+        m[a] = wave_max(v[a]);
+        if (lane == 0) red[a][0][wave] = m[a];
+    }
+    __syncthreads();
+    float e[2], s[2], t[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const float mx = fmaxf(fmaxf(red[a][0][0], red[a][0][1]), fmaxf(red[a][0][2], red[a][0][3]));
+        e[a] = tid < D ? expf(v[a] - mx) : 0.f;
+        s[a] = wave_sum(e[a]);
+        t[a] = wave_sum(e[a] * (float)tid);
+        if (lane == 0) { red[a][1][wave] = s[a]; red[a][2][wave] = t[a]; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float ang[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const float sum = (red[a][1][0] + red[a][1][1]) + (red[a][1][2] + red[a][1][3]);
+            const float idx = ((red[a][2][0] + red[a][2][1]) + (red[a][2][2] + red[a][2][3])) / sum;   // E[bin] under softmax
+            const float soft = idx / (float)(D - 1) * 2.f - 1.f;
+            const float lo = a == 0 ? p_lo : r_lo, hi = a == 0 ? p_hi : r_hi;
+            ang[a] = (hi - lo) * ((soft + 1.f) / 2.f) + lo;
+        }
+        euler_xz_to_mat(ang[0], ang[1], sR);
+        euler_xz_to_mat(-ang[0], ang[1], sR + 9);
+    }
+    __syncthreads();
+    const int b0 = Bf == 1 ? 0 : f, nb = Bf == 1 ? B : 1;
+    for (int i = tid; i < nb * 9; i += 256) {
+        cam_rotmat[(size_t)b0 * 9 + i] = sR[i % 9];
+        render_rotmat[(size_t)b0 * 9 + i] = sR[9 + i % 9];
+    }
+}
+
+extern "C" int whmr_cam_head(const float* logits, int ld, int D, float pitch_lo, float pitch_hi, float roll_lo, float roll_hi, int Bf, int B,
+                             float* cam_rotmat, float* render_rotmat, void* stream) {
+    if (Bf <= 0 || B <= 0 || D <= 0 || D > 256 || ld < 3 * D || (Bf != 1 && Bf != B)) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(cam_head_kernel, dim3(Bf), dim3(256), 0, (hipStream_t)stream, logits, ld, D, pitch_lo, pitch_hi, roll_lo, roll_hi, Bf, B,
+                       cam_rotmat, render_rotmat);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+// Input state of the global-orientation head (whmr.py:295-297): xc[b, F .. F+15) = [rot6d(cam_rotmat[b]) (first two columns, row-major: geometry.py:275-286)
+// | local_orient[b] (the root joint's 3x3, the first 9 floats of the stage's rotmat row)] in one launch.
+__global__ void orient_state_kernel(const float* __restrict__ cam_rotmat, const float* __restrict__ rotmat, long ld_rot, float* __restrict__ xc, long ld,
+                                    int F, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * 15) return;
+    const int b = i / 15, e = i % 15;
+    float v;
+    if (e < 6) v = cam_rotmat[(size_t)b * 9 + (e >> 1) * 3 + (e & 1)];
+    else v = rotmat[(size_t)b * ld_rot + e - 6];
+    xc[(size_t)b * ld + F + e] = v;
+}
+
+extern "C" int whmr_orient_state(const float* cam_rotmat, const float* rotmat, long ld_rot, float* xc, long ld, int F, int B, void* stream) {
+    if (B <= 0) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(orient_state_kernel, dim3((B * 15 + 255) / 256), dim3(256), 0, (hipStream_t)stream, cam_rotmat, rotmat, ld_rot, xc, ld, F, B);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+// Tail of the global-orientation head (whmr.py:301-305,630-640): r [B, 9] (the head's residual output) -> unbiased Gram-Schmidt -> g_rot; its
+// angle-axis; global_pose [B, 72] = [aa(g_rot) | pose_aa[:, 3:]], global_rotmat [B, 24, 9] = [g_rot | rotmat[:, 1:]] in one launch.
+__global__ __launch_bounds__(256) void orient_tail_kernel(const float* __restrict__ r, const float* __restrict__ pose_aa, const float* __restrict__ rotmat,
+                                                          float* __restrict__ g_pose, float* __restrict__ g_rotmat) {
+    __shared__ float sO[9], sA[3];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) {
+        float m[9], o[9], a3[3];
+        for (int k = 0; k < 9; ++k) m[k] = r[(size_t)b * 9 + k];
+        gram_schmidt9(m, o);
+        rotmat_to_aa3(o, a3);
+        for (int k = 0; k < 9; ++k) sO[k] = o[k];
+        for (int k = 0; k < 3; ++k) sA[k] = a3[k];
+    }
+    __syncthreads();
+    if (tid < 72) g_pose[(size_t)b * 72 + tid] = tid < 3 ? sA[tid] : pose_aa[(size_t)b * 72 + tid];
+    if (tid < 216) g_rotmat[(size_t)b * 216 + tid] = tid < 9 ? sO[tid] : rotmat[(size_t)b * 216 + tid];
+}
+
+extern "C" int whmr_orient_tail(const float* r, const float* pose_aa, const float* rotmat, float* g_pose, float* g_rotmat, int B, void* stream) {
+    if (B <= 0) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(orient_tail_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, r, pose_aa, rotmat, g_pose, g_rotmat);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}

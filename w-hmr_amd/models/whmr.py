@@ -251,9 +251,10 @@ class Global_Orient_Regressor(nn.Module):
         return self._cache.get('collapsed', ws, build)
 
     @torch.no_grad()
-    def forward(self, x, cam_rotmat, local_orient, is_train=False, xc=None):
+    def forward(self, x, cam_rotmat, local_orient, is_train=False, xc=None, raw=False):
         """xc (optional): a buffer with >= 2164 columns whose first 2149 already hold x (the last regressor stage's input buffer);
-        columns 2149..2163 are overwritten in place instead of copying x."""
+        columns 2149..2163 are overwritten in place instead of copying x.  local_orient: [B, 3, 3] or the stage's whole rotmat [B, 24, 3, 3]
+        (its root block is read in place).  raw: return the head's output before the Gram-Schmidt step."""
         if is_train:
             raise NotImplementedError('inference-only this round')
         B, dev = cam_rotmat.shape[0], cam_rotmat.device
@@ -261,11 +262,13 @@ class Global_Orient_Regressor(nn.Module):
             xc = torch.empty(B, 2149 + 6 + 9, dtype=torch.float32, device=dev)
             xc[:, :2149] = x
         xc = xc[:, :2164]
-        xc[:, 2149:2155] = cam_rotmat[:, :, :2].reshape(B, 6)                          # rotmat_to_rot6d, geometry.py:275-286
-        xc[:, 2155:] = local_orient.reshape(B, 9)
+        rot = local_orient if local_orient.dim() == 4 else local_orient.reshape(B, 1, 3, 3)          # the stage's rotmat [B, 24, 3, 3] or its root block
+        L.orient_state(cam_rotmat, rot, xc, 2149)                                        # [rot6d(cam_rotmat) | local_orient], geometry.py:275-286
         r = torch.empty(B, 9, dtype=torch.float32, device=dev)
         w_eff, b_eff = self._collapsed()
         L.gemm(xc, w_eff, r, bias=b_eff, residual=xc[:, 2155:], lda=xc.stride(0))
+        if raw:
+            return r                                                                     # WHMR.forward finishes with L.orient_tail (one launch)
         return unbiased_gram_schmidt(r.reshape(-1, 1, 3, 3))
 
 
@@ -493,13 +496,11 @@ class WHMR(nn.Module):
                 # demo/tester.py:161 replicates the full image once per person; a batch-1 full_x is accepted here and its
                 # camera prediction broadcast (identical result, the ~80 GFLOP ResNet-50 runs once per image -- SURVEY 8f N1)
                 pred, _ = self.cam_model(full_x)
-                _, pitch, roll = convert_preds_to_angles(*pred, loss_type='softargmax_l2')
-                if pitch.shape[0] == 1 and B > 1:
-                    pitch, roll = pitch.expand(B), roll.expand(B)
-                pitch, roll = pitch.unsqueeze(-1), roll.unsqueeze(-1)
-                zeros = torch.zeros((B, 1), device=dev)
-                cam_rotmat = batch_euler2matrix(torch.cat([pitch, zeros, roll], dim=1).float())
-                render_rotmat = batch_euler2matrix(torch.cat([-pitch, zeros, roll], dim=1).float())
+                # soft-argmax -> (pitch, roll) -> R([pitch, 0, roll]), R([-pitch, 0, roll]) (whmr.py:513-522) in one launch
+                # (convert_preds_to_angles + 2 x batch_euler2matrix were ~160 element-wise launches)
+                logits = pred[0]._base if pred[0]._base is not None else torch.cat(pred, 1)
+                from .cam_model import PITCH_RANGE, ROLL_RANGE
+                cam_rotmat, render_rotmat = L.cam_head(logits, pred[0].shape[1], PITCH_RANGE, ROLL_RANGE, B)
             else:
                 cam_rotmat = torch.eye(3, device=dev).unsqueeze(0).expand(B, -1, -1).float()
         if render_rotmat is None:
@@ -601,10 +602,9 @@ class WHMR(nn.Module):
             if not torch.cuda.is_current_stream_capturing():                          # (a capture's private pool never recycles)
                 for t in (cam_rotmat, render_rotmat):
                     t.record_stream(main)                                             # allocated on the side stream, read (and returned) on the main one
-        g_rot = self.global_orient(body_feat, cam_rotmat, smpl_output['rotmat'][:, 0], False, xc=xc)     # whmr.py:630-654
-        g_aa = rotation_matrix_to_angle_axis(g_rot.reshape(-1, 3, 3)).reshape(-1, 3)
-        g_pose = torch.cat([g_aa, smpl_output['pose'][:, 3:]], dim=1)
-        g_rotmat = torch.cat([g_rot, smpl_output['rotmat'][:, 1:]], dim=1)
+        # whmr.py:630-654: state columns, the collapsed head, then Gram-Schmidt + angle-axis + the two concatenations as one launch
+        r9 = self.global_orient(body_feat, cam_rotmat, smpl_output['rotmat'], False, xc=xc, raw=True)
+        g_pose, g_rotmat = L.orient_tail(r9, smpl_output['pose'].contiguous(), smpl_output['rotmat'].contiguous())
         g = self.regressor[0].smpl.run(smpl_output['pred_shape'], g_rotmat)
         g_joints = g.joints
         if J_regressor is not None:
