@@ -106,13 +106,14 @@ struct whmr_gemm_blk_desc {
     /* split-bf16 operands ("bf16x3" numerics: the parity-grade mode of the same path -- the reference's Linears are fp32, vit.py:61-115): every
      * operand is a pair x = x_hi + x_lo (x_hi = bf16(x), x_lo = bf16(x - x_hi): 16 significand bits) and a product is three MFMAs per fragment
      * pair (hi.hi + lo.hi + hi.lo, fp32 accumulate).  A_lo / W_lo: lo halves in the layout of A / W; C_lo: lo half of a bf16 result (epi 0 / 1,
-     * required there; epi 1 then applies the exact erf GELU of nn.GELU).  All three null = plain bf16 operands.  Not combinable with the
-     * LayerNorm-fold fields. */
+     * required there; epi 1 then applies the exact erf GELU of nn.GELU).  All three null = plain bf16 operands.  The LayerNorm fold works in
+     * this numerics too: a producer then also needs xhat_lo, a consumer takes W = the hi / lo pair of gamma o W and colsum of their sum. */
     const void* A_lo; const void* W_lo; void* C_lo;
     /* per-row shift of a folding producer (xhat != null): xhat / stats_out are taken of (C - s_m), s_m = (shift ? shift[m] : 0) + (shift_stats ?
      * the mean of row m from shift_stats [rows][N/256][2] : 0), shift_out[m] = s_m when non-null.  LayerNorm is shift-invariant, so the consumer
      * is unchanged; what is rounded to bf16 is the CENTRED row (error relative to the row's spread, not its offset).  shift_stats != stats_out. */
     const float* shift; const float* shift_stats; float* shift_out;
+    void* xhat_lo;        /* split-bf16 producer (A_lo and xhat set): lo half of the centred-row operand pair (the fold in the bf16x3 numerics) */
 };
 int whmr_gemm_blk(const struct whmr_gemm_blk_desc* p, void* stream);
 int whmr_gemm_blk_tile(const struct whmr_gemm_blk_desc* p, int tile, void* stream);
@@ -135,7 +136,8 @@ int whmr_split3_bf16(const float* src, void* dst, long rows, int C, void* stream
 /* ---- split-bf16 ("bf16x3") forms of the three blocked helpers: results / operands as hi + lo bf16 pairs (16 significand bits) ----
  * LayerNorm (vit.py:125,133) of the blocked fp32 stream -> blocked operand pair;  PatchEmbed gather (vit.py:157,161) -> blocked pixel pair;
  * attention core (vit.py:102-111; d = 64, 64 < N <= 256): three MFMAs per product in Q.K^T and in P.V, fp32 softmax, P split in registers. */
-int whmr_layernorm_blk_x3(const float* x, const float* gamma, const float* beta, void* y_hi, void* y_lo, int rows, int C, float eps, void* stream);
+int whmr_layernorm_blk_x3(const float* x, const float* gamma, const float* beta, void* y_hi, void* y_lo, float* mean_out /* nullable: row means */,
+                          int rows, int C, float eps, void* stream);
 int whmr_patch_im2col_blk_x3(const float* x, void* cols_hi, void* cols_lo, int B, int Cin, int H, int W, int P, int pad, long sb, long sc, long sh,
                              long sw, void* stream);
 int whmr_attention_blk_x3(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, int B, int N, int H, float scale, void* stream);

@@ -209,6 +209,62 @@ def test_deconv_bn_relu_train_matches_autograd(dev, numerics, tol):
     assert _rel(dx_in.grad.float().cpu().permute(0, 3, 1, 2), rx.grad) < tol
 
 
+@pytest.mark.parametrize('numerics', ['fp32', 'bf16'])
+def test_deconv_gradient_error_is_relu_gate_flips(dev, numerics):
+    """the end-to-end training tests gate the deconv / ViT gradients at 1e-2 RMS "because of ReLU gate flips" -- this test shows
+    that the explanation holds.  Two chained deconv stages at a size where a few hundred pre-activations sit within rounding of zero, dense
+    white-noise cotangent: the HIP gradients against a float64 CPU evaluation (i) as is, and (ii) with the float64 run's ReLU gates REPLACED by
+    the gates the HIP forward took (mask = its output > 0).  With the same gates the two agree to the arithmetic's own resolution (fp32: < 2e-5
+    RMS; bf16 operands: < 1.5e-2); the gap between (i) and (ii) is the flipped gates alone, and their count is reported."""
+    import torch.nn.functional as F
+    from whmr_amd.train.deconv_autograd import DeconvBNReLUFn
+    dt = torch.float32 if numerics == 'fp32' else torch.bfloat16
+    g = torch.Generator().manual_seed(11)
+    B, H, W = 8, 16, 12
+    x = torch.randn(B, 768, H, W, generator=g)
+    ws = [torch.randn(768, 256, 4, 4, generator=g) * 0.02, torch.randn(256, 256, 4, 4, generator=g) * 0.03]
+    gam = [torch.rand(256, generator=g) + 0.5 for _ in range(2)]
+    bet = [torch.randn(256, generator=g) * 0.2 for _ in range(2)]
+    dy = torch.randn(B, 256, 4 * H, 4 * W, generator=g)
+    # HIP: keep both stage outputs (their > 0 pattern = the gates the device used)
+    bns = [torch.nn.BatchNorm2d(256, momentum=0.1).to(dev) for _ in range(2)]
+    dp = [[t.clone().to(dev).requires_grad_(True) for t in (ws[i], gam[i], bet[i])] for i in range(2)]
+    xin = x.permute(0, 2, 3, 1).contiguous().to(dev).to(dt).requires_grad_(True)
+    ys, hh = [], xin
+    for i in range(2):
+        hh = DeconvBNReLUFn.apply(hh, dp[i][0], dp[i][1], dp[i][2], bns[i], dt)
+        ys.append(hh)
+    hh.backward(dy.permute(0, 2, 3, 1).contiguous().to(dev).to(dt))
+    hip = [xin.grad.float().cpu().permute(0, 3, 1, 2)] + [t.grad.float().cpu() for r in dp for t in r]
+    gates = [(y.detach().float().cpu().permute(0, 3, 1, 2) > 0) for y in ys]
+
+    def f64_chain(masks):
+        rx = x.double().requires_grad_(True)
+        rp = [[t.double().requires_grad_(True) for t in (ws[i], gam[i], bet[i])] for i in range(2)]
+        h, own = rx, []
+        for i in range(2):
+            z = F.conv_transpose2d(h, rp[i][0], None, stride=2, padding=1)
+            z = F.batch_norm(z, None, None, rp[i][1], rp[i][2], training=True, eps=1e-5)
+            own.append(z.detach() > 0)
+            h = F.relu(z) if masks is None else z * masks[i].double()
+        h.backward(dy.double())
+        return [rx.grad] + [t.grad for r in rp for t in r], own
+    ref, own = f64_chain(None)
+    ref_m, _ = f64_chain(gates)
+    flips = [int((a != b).sum()) for a, b in zip(gates, own)]
+    names = ['dx', 'w0', 'g0', 'b0', 'w1', 'g1', 'b1']
+    plain = {n: _rms(a, b) for n, a, b in zip(names, hip, ref)}
+    same = {n: _rms(a, b) for n, a, b in zip(names, hip, ref_m)}
+    print('%s deconv chain: %d + %d of %d + %d gates differ from float64; RMS error vs float64 %s; with the device gates injected %s'
+          % (numerics, flips[0], flips[1], gates[0].numel(), gates[1].numel(), {k: '%.1e' % v for k, v in plain.items()}, {k: '%.1e' % v for k, v in same.items()}))
+    tight = 2e-5 if numerics == 'fp32' else 1.5e-2
+    assert all(v < tight for v in same.values()), same
+    if sum(flips) == 0:
+        pytest.skip('no gate flipped at this size in this numerics: nothing to attribute')
+    # the stage-1 quantities sit behind BOTH ReLUs: without the injected gates they carry the flip error, far above the same-gates figure
+    assert max(plain['dx'], plain['w0']) > 5 * max(same['dx'], same['w0']), (plain, same)
+
+
 def test_im2col_t_and_bn_kernels(dev):
     """whmr_im2col_t against F.unfold; BN statistics with a large common offset (the shifted two-stage sum must not cancel)."""
     from whmr_amd import _lib as L

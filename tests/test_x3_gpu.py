@@ -189,3 +189,26 @@ def test_vit_large_x3_full_depth_matches_oracle(dev):
     e, ew = _rel(out.cpu(), ref), ew_err(out, ref)
     print('bf16x3 ViT-L depth 24 vs oracle: max-rel %.2e element-wise %.2e' % (e, ew))
     assert out.shape == (2, 1024, 16, 12) and e < 1e-4 and ew < 1e-4
+
+
+def test_vit_x3_layernorm_fold_matches_explicit_passes(dev):
+    """bf16x3 with the LayerNorm folded into the GEMM pairs (the default: producers emit the centred row as a hi / lo pair + partial sums, consumers
+    normalise in their epilogue) against bf16x3 with explicit fp32 LayerNorm passes and against the exact-f32 mode -- on the fixture weights and on a
+    ViT whose tokens sit 30 std off zero (the stream the per-row shift exists for): all within 1e-4, element-wise"""
+    from oracle import synth
+    g = np.load(os.path.join(GOLDEN, 'vit224_b2.npz'))
+    x = torch.from_numpy(g['x']).to(dev)
+    base = synth.make_vit_state(1, (224, 224))
+    off = {k: v.clone() for k, v in base.items()}
+    off['pos_embed'] = off['pos_embed'] + torch.randn(1, off['pos_embed'].shape[1], 1, generator=torch.Generator().manual_seed(1)).sign() * 30.0
+    for name, sd in (('fixture weights', base), ('tokens 30 std off zero', off)):
+        ref = _vit(sd, (224, 224), dev, 'fp32')(x)
+        m = _vit(sd, (224, 224), dev, 'bf16x3')
+        assert m.ln_fold
+        folded = m(x)
+        m.ln_fold = False
+        explicit = m(x)
+        ef, ee = ew_err(folded, ref), ew_err(explicit, ref)
+        print('bf16x3 %s: LayerNorm folded %.2e, explicit %.2e (element-wise vs the exact-f32 mode)' % (name, ef, ee))
+        assert ef < 1e-4 and ee < 1e-4 and _rel(folded, ref) < 1e-4
+        assert not torch.equal(folded, explicit)                  # two different pipelines did run

@@ -35,7 +35,7 @@ class WhmrGemmBlk(C.Structure):
                 ('M', C.c_int32), ('N', C.c_int32), ('K', C.c_int32), ('epi', C.c_int32), ('res_rows', C.c_int32), ('tile', C.c_int32),
                 ('xhat', C.c_void_p), ('stats_out', C.c_void_p), ('stats_in', C.c_void_p), ('colsum', C.c_void_p), ('ln_eps', C.c_float),
                 ('A_lo', C.c_void_p), ('W_lo', C.c_void_p), ('C_lo', C.c_void_p),
-                ('shift', C.c_void_p), ('shift_stats', C.c_void_p), ('shift_out', C.c_void_p)]
+                ('shift', C.c_void_p), ('shift_stats', C.c_void_p), ('shift_out', C.c_void_p), ('xhat_lo', C.c_void_p)]
 
 
 class WhmrSmplModel(C.Structure):
@@ -88,7 +88,7 @@ _SIGS = {
     'whmr_cam_head': [_P, _I, _I, _F, _F, _F, _F, _I, _I, _P, _P, _P],
     'whmr_orient_state': [_P, _P, _L, _P, _L, _I, _I, _P],
     'whmr_orient_tail': [_P, _P, _P, _P, _P, _I, _P],
-    'whmr_layernorm_blk_x3': [_P, _P, _P, _P, _P, _I, _I, _F, _P],
+    'whmr_layernorm_blk_x3': [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P],
     'whmr_layernorm_blk_mean': [_P, _P, _P, _P, _P, _I, _I, _F, _P],
     'whmr_patch_im2col_blk_x3': [_P, _P, _P, _I, _I, _I, _I, _I, _I, _L, _L, _L, _L, _P],
     'whmr_attention_blk_x3': [_P, _P, _P, _P, _I, _I, _I, _F, _P],
@@ -340,7 +340,7 @@ def split_bf16(t):
 
 
 def gemm_blk(a, w, out, M, bias=None, epi=EPI_BF16, res=None, res_rows=0, tile=0, xhat=None, stats_out=None, stats_in=None, colsum=None,
-             ln_eps=1e-6, a_lo=None, w_lo=None, out_lo=None, shift=None, shift_stats=None, shift_out=None):
+             ln_eps=1e-6, a_lo=None, w_lo=None, out_lo=None, shift=None, shift_stats=None, shift_out=None, xhat_lo=None):
     """out = epi(a . w^T + bias [+ res]) on blocked operands: a [M/32][K/8][32][8] bf16, w [N/32][K/8][32][8] bf16,
     out bf16 [M/32][N/8][32][8] (epi 0/1) or fp32 [M/32][N/4][32][4] (epi 2: + blocked res, may be `out`; epi 3: + res[m % res_rows] row-major).
     a_lo / w_lo (/ out_lo for epi 0/1): the lo halves of split-bf16 operands -> the bf16x3 kernel (three MFMAs per product, fp32-grade result)."""
@@ -378,8 +378,11 @@ def gemm_blk(a, w, out, M, bias=None, epi=EPI_BF16, res=None, res_rows=0, tile=0
     if x3:
         _dev(a_lo, w_lo, out_lo)
         assert a_lo.dtype == torch.bfloat16 and a_lo.shape == a.shape and a_lo.is_contiguous() and w_lo is not None and w_lo.shape == w.shape and w_lo.is_contiguous()
-        assert xhat is None and stats_in is None
         p.A_lo, p.W_lo = a_lo.data_ptr(), w_lo.data_ptr()
+        if xhat is not None:
+            _dev(xhat_lo)
+            assert xhat_lo is not None and xhat_lo.shape == xhat.shape and xhat_lo.dtype == torch.bfloat16 and xhat_lo.is_contiguous()
+            p.xhat_lo = xhat_lo.data_ptr()
         if epi < 2:
             assert out_lo is not None and out_lo.shape == out.shape and out_lo.dtype == torch.bfloat16 and out_lo.is_contiguous()
             p.C_lo = out_lo.data_ptr()
@@ -490,13 +493,14 @@ def split3_weight(w):
     return torch.cat([hi, hi, lo], dim=-1).contiguous()
 
 
-def layernorm_blk_x3(x, weight, bias, out_hi, out_lo, rows, eps):
-    """LayerNorm of a blocked fp32 stream -> blocked split-bf16 operand pair (bf16x3 numerics)"""
-    _dev(x, weight, bias, out_hi, out_lo)
+def layernorm_blk_x3(x, weight, bias, out_hi, out_lo, rows, eps, mean_out=None):
+    """LayerNorm of a blocked fp32 stream -> blocked split-bf16 operand pair (bf16x3 numerics); mean_out: fp32 [ceil(rows/32)*32] row means"""
+    _dev(x, weight, bias, out_hi, out_lo, mean_out)
     assert x.dtype == torch.float32 and x.is_contiguous() and out_hi.is_contiguous() and out_lo.is_contiguous()
     assert out_hi.dtype == torch.bfloat16 and out_lo.dtype == torch.bfloat16 and out_hi.shape == out_lo.shape
-    _check(lib().whmr_layernorm_blk_x3(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), out_hi.data_ptr(), out_lo.data_ptr(), rows, x.shape[1] * 4, eps,
-                                       _stream()), 'whmr_layernorm_blk_x3')
+    assert mean_out is None or (mean_out.dtype == torch.float32 and mean_out.is_contiguous() and mean_out.numel() >= x.shape[0] * 32)
+    _check(lib().whmr_layernorm_blk_x3(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), out_hi.data_ptr(), out_lo.data_ptr(), _ptr(mean_out), rows,
+                                       x.shape[1] * 4, eps, _stream()), 'whmr_layernorm_blk_x3')
     return out_hi
 
 

@@ -33,4 +33,5 @@ struct whmr_gemm_blk_desc {
     const float* shift;
     const float* shift_stats;
     float* shift_out;
+    void* xhat_lo;        // split-bf16 producer (A_lo set, xhat set): lo half of the centred-row operand pair
 };

@@ -36,8 +36,8 @@ extern "C" int whmr_gemm_blk_tile(const whmr_gemm_blk_desc* pp, int tile, void* 
     if ((p.shift || p.shift_stats || p.shift_out) && (!p.xhat || p.shift_stats == p.stats_out)) return (int)hipErrorInvalidValue;
     if (p.epi == 3 && p.res_rows <= 0) return (int)hipErrorInvalidValue;
     if (p.A_lo || p.W_lo || p.C_lo) {
-        // split-bf16 operands: both lo halves, and a lo output for the bf16 epilogues; the LayerNorm-fold side outputs are a bf16-mode feature
-        if (!p.A_lo || !p.W_lo || (p.epi < 2 && !p.C_lo) || p.xhat || p.stats_in) return (int)hipErrorInvalidValue;
+        // split-bf16 operands: both lo halves, a lo output for the bf16 epilogues, a lo half of the folded-LayerNorm operand copy
+        if (!p.A_lo || !p.W_lo || (p.epi < 2 && !p.C_lo) || (p.xhat && !p.xhat_lo)) return (int)hipErrorInvalidValue;
         return blk_x3_launch_tile(pp, tile, stream, g_blk_sched);
     }
     return blk_launch_tile<false>(p, tile, (hipStream_t)stream, g_blk_sched);

@@ -441,7 +441,7 @@ __global__ __launch_bounds__(512, 2) void gemm_blk_kernel(const whmr_gemm_blk_de
 #pragma unroll
                     for (int q = 0; q < 4; ++q) rv[q] = *(const float4*)(rr + 8 * q);
                 }
-                uint32_t pk[4][2];
+                uint32_t pk[4][2], pl[4][2];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     float4 o;
@@ -453,16 +453,27 @@ __global__ __launch_bounds__(512, 2) void gemm_blk_kernel(const whmr_gemm_blk_de
                         o.x -= sh[i]; o.y -= sh[i]; o.z -= sh[i]; o.w -= sh[i];
                         sx[i] += o.x; sx[i] += o.y; sx[i] += o.z; sx[i] += o.w;
                         sxx[i] = fmaf(o.x, o.x, sxx[i]); sxx[i] = fmaf(o.y, o.y, sxx[i]); sxx[i] = fmaf(o.z, o.z, sxx[i]); sxx[i] = fmaf(o.w, o.w, sxx[i]);
-                        pk[q][0] = pack_bf16x2(o.x, o.y); pk[q][1] = pack_bf16x2(o.z, o.w);
+                        if constexpr (X3) { split_bf16x2(o.x, o.y, pk[q][0], pl[q][0]); split_bf16x2(o.z, o.w, pk[q][1], pl[q][1]); }
+                        else { pk[q][0] = pack_bf16x2(o.x, o.y); pk[q][1] = pack_bf16x2(o.z, o.w); }
                     }
                 }
                 if (emit) {
-                    char* rowp = (char*)p.xhat + ((size_t)(rb0 + i) * (p.N >> 3) + ((nb0 + j * 32) >> 3)) * 512 + l31 * 16;
+                    const size_t xoff = ((size_t)(rb0 + i) * (p.N >> 3) + ((nb0 + j * 32) >> 3)) * 512 + l31 * 16;
+                    char* rowp = (char*)p.xhat + xoff;
 #pragma unroll
                     for (int q = 0; q < 4; q += 2) {
                         const auto r0 = __builtin_amdgcn_permlane32_swap(pk[q][0], pk[q + 1][0], false, false);
                         const auto r1 = __builtin_amdgcn_permlane32_swap(pk[q][1], pk[q + 1][1], false, false);
                         *(uint4*)(rowp + (q + hi) * 512) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+                    }
+                    if constexpr (X3) {                                     // the centred row as an operand PAIR (bf16x3 fold)
+                        char* rowl = (char*)p.xhat_lo + xoff;
+#pragma unroll
+                        for (int q = 0; q < 4; q += 2) {
+                            const auto r0 = __builtin_amdgcn_permlane32_swap(pl[q][0], pl[q + 1][0], false, false);
+                            const auto r1 = __builtin_amdgcn_permlane32_swap(pl[q][1], pl[q + 1][1], false, false);
+                            *(uint4*)(rowl + (q + hi) * 512) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+                        }
                     }
                 }
             }

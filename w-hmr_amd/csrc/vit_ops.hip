@@ -307,15 +307,15 @@ extern "C" int whmr_layernorm_blk_mean(const float* x, const float* gamma, const
 }
 
 // Same LayerNorm with the result as a split-bf16 operand pair (y_hi + y_lo ~= LN(x) to 16 significand bits): the "bf16x3" numerics.
-extern "C" int whmr_layernorm_blk_x3(const float* x, const float* gamma, const float* beta, void* y_hi, void* y_lo, int rows, int C, float eps,
-                                     void* stream) {
+extern "C" int whmr_layernorm_blk_x3(const float* x, const float* gamma, const float* beta, void* y_hi, void* y_lo, float* mean_out, int rows, int C,
+                                     float eps, void* stream) {
     if (rows <= 0 || !y_hi || !y_lo) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
     switch (C) {
-        case 768: return launch_ln_blk<24, 8>(x, gamma, beta, y_hi, rows, C, eps, 0, st, y_lo);
-        case 1024: return launch_ln_blk<16, 16>(x, gamma, beta, y_hi, rows, C, eps, 0, st, y_lo);
-        case 1280: return launch_ln_blk<20, 16>(x, gamma, beta, y_hi, rows, C, eps, 0, st, y_lo);
-        case 256: return launch_ln_blk<8, 8>(x, gamma, beta, y_hi, rows, C, eps, 0, st, y_lo);
+        case 768: return launch_ln_blk<24, 8>(x, gamma, beta, y_hi, rows, C, eps, 0, st, y_lo, mean_out);
+        case 1024: return launch_ln_blk<16, 16>(x, gamma, beta, y_hi, rows, C, eps, 0, st, y_lo, mean_out);
+        case 1280: return launch_ln_blk<20, 16>(x, gamma, beta, y_hi, rows, C, eps, 0, st, y_lo, mean_out);
+        case 256: return launch_ln_blk<8, 8>(x, gamma, beta, y_hi, rows, C, eps, 0, st, y_lo, mean_out);
     }
     return (int)hipErrorInvalidValue;
 }

@@ -98,6 +98,8 @@ class ViT(nn.Module):
         self.blocked = True                 # bf16 inference on the blocked-layout kernels when the shapes allow it
         self.blocked_min_tokens = 2048      # ... and the batch has at least this many tokens (set 0 to force the blocked path)
         self.ln_fold = True                 # ... with norm1 / norm2 folded into the qkv / fc1 GEMMs (no LayerNorm pass inside the blocks)
+        import os
+        self.ln_fold_x3 = os.environ.get('WHMR_X3_FOLD', '1') != '0'      # the same fold in the bf16x3 pipeline (A/B: tools/r3_x3ab.sh)
 
     # ------------------------------------------------------------------ weight / workspace caches
     def _w(self, p, shape=None):
@@ -279,10 +281,27 @@ class ViT(nn.Module):
             self._wcache[key] = ent
         return ent[1]
 
+    def _wfold_x3(self, lin, ln):
+        """``_wfold`` for the bf16x3 numerics: W' = gamma o W as a hi / lo pair (blocked), s = row sums of hi + lo (what the MFMAs multiply), c"""
+        srcs = [lin.weight, ln.weight, ln.bias] + ([lin.bias] if lin.bias is not None else [])
+        key = ('fold_x3', id(lin.weight))
+        ver = tuple((t._version, t.device) for t in srcs)
+        ent = self._wcache.get(key)
+        if ent is None or ent[0] != ver:
+            w = lin.weight.detach().float()
+            hi, lo = L.split_bf16((w * ln.weight.detach().float()[None, :]).contiguous())
+            s = (hi.double() + lo.double()).sum(1).float().contiguous()
+            c = (w.double() @ ln.bias.detach().double()).float()
+            if lin.bias is not None:
+                c = c + lin.bias.detach().float()
+            ent = (ver, (L.to_blocked(hi.contiguous()), L.to_blocked(lo.contiguous()), s, c.contiguous()))
+            self._wcache[key] = ent
+        return ent[1]
+
     def _forward_tokens_x3(self, x, B, Hp, Wp):
         """numerics 'bf16x3': the blocked pipeline with every GEMM / attention operand a hi + lo bf16 pair (three MFMAs per product, fp32
-        accumulate), explicit fp32 LayerNorm passes (vit.py:125,133 -- no folding: the normalised value is what gets split), exact erf GELU,
-        fp32 residual stream.  Same launches as the unfolded bf16 path; every activation buffer between two kernels exists twice (hi, lo)."""
+        accumulate), exact erf GELU, fp32 residual stream, LayerNorm folded into the GEMM pairs (``ln_fold``; False = explicit fp32 LayerNorm
+        passes whose result is split).  Every activation buffer between two kernels exists twice (hi, lo)."""
         Cin, P, pad, D, heads = x.shape[1], self.patch_size, self.patch_pad, self.embed_dim, self.num_heads
         N, M = Hp * Wp, B * Hp * Wp
         nb = (M + 31) // 32
@@ -298,6 +317,38 @@ class ViT(nn.Module):
         L.gemm_blk(cols[0], w[0], t, M, bias=self.patch_embed.proj.bias, epi=L.EPI_F32_POS, res=pos, res_rows=N, a_lo=cols[1], w_lo=w[1])
         hd = self.blocks[0].mlp.fc1.weight.shape[0] if self.depth else D
         h, qkv, att, hid = pair('x3h', D), pair('x3qkv', 3 * D), pair('x3att', D), pair('x3hid', hd)
+        if self.ln_fold and self.ln_fold_x3 and D <= 1024 and self.depth:
+            # LayerNorm folded into the GEMM pair as in the bf16 pipeline, on operand PAIRS: the producers (proj, fc2) also emit the centred row
+            # (x - s_m) split into hi / lo + its partial sums, the consumers (qkv, fc1) multiply it by the hi / lo pair of gamma o W and normalise
+            # in their epilogue.  The first LayerNorm runs explicitly and seeds the shift.  Saves 2 x depth - 1 LayerNorm passes (13.5 us each).
+            st = [self._buf('stats%d' % i, (nb * 32, D // 256, 2), f32, dev) for i in (0, 1)]
+            sh = [self._buf('shift%d' % i, (nb * 32,), f32, dev) for i in (0, 1)]
+            cur, nblk = 0, len(self.blocks)
+            for bi, blk in enumerate(self.blocks):
+                if bi == 0:
+                    L.layernorm_blk_x3(t, blk.norm1.weight, blk.norm1.bias, h[0], h[1], M, 1e-6, mean_out=sh[cur])
+                    w = self._wblk_x3(blk.attn.qkv.weight)
+                    L.gemm_blk(h[0], w[0], qkv[0], M, bias=blk.attn.qkv.bias, epi=L.EPI_BF16, a_lo=h[1], w_lo=w[1], out_lo=qkv[1])
+                else:
+                    wh, wl, sq, cq = self._wfold_x3(blk.attn.qkv, blk.norm1)
+                    L.gemm_blk(h[0], wh, qkv[0], M, bias=cq, epi=L.EPI_BF16, a_lo=h[1], w_lo=wl, out_lo=qkv[1], stats_in=st[cur], colsum=sq, ln_eps=1e-6)
+                L.attention_blk(qkv[0], att[0], B, N, heads, self.scale, qkv_lo=qkv[1], out_lo=att[1])
+                w = self._wblk_x3(blk.attn.proj.weight)
+                L.gemm_blk(att[0], w[0], t, M, bias=blk.attn.proj.bias, epi=L.EPI_F32_RES, res=t, a_lo=att[1], w_lo=w[1], xhat=h[0], xhat_lo=h[1],
+                           stats_out=st[cur ^ 1], shift=sh[cur], shift_stats=None if bi == 0 else st[cur], shift_out=sh[cur ^ 1])
+                cur ^= 1
+                wh, wl, s1, c1 = self._wfold_x3(blk.mlp.fc1, blk.norm2)
+                L.gemm_blk(h[0], wh, hid[0], M, bias=c1, epi=L.EPI_BF16_GELU, a_lo=h[1], w_lo=wl, out_lo=hid[1], stats_in=st[cur], colsum=s1, ln_eps=1e-6)
+                w = self._wblk_x3(blk.mlp.fc2.weight)
+                if bi + 1 == nblk:
+                    L.gemm_blk(hid[0], w[0], t, M, bias=blk.mlp.fc2.bias, epi=L.EPI_F32_RES, res=t, a_lo=hid[1], w_lo=w[1])
+                else:
+                    L.gemm_blk(hid[0], w[0], t, M, bias=blk.mlp.fc2.bias, epi=L.EPI_F32_RES, res=t, a_lo=hid[1], w_lo=w[1], xhat=h[0], xhat_lo=h[1],
+                               stats_out=st[cur ^ 1], shift=sh[cur], shift_stats=st[cur], shift_out=sh[cur ^ 1])
+                    cur ^= 1
+            out = torch.empty((M, D), dtype=f32, device=dev)
+            L.layernorm_blk(t, self.last_norm.weight, self.last_norm.bias, out, M, 1e-6, out_std=True)
+            return out
         for blk in self.blocks:
             L.layernorm_blk_x3(t, blk.norm1.weight, blk.norm1.bias, h[0], h[1], M, 1e-6)
             w = self._wblk_x3(blk.attn.qkv.weight)
