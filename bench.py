@@ -57,6 +57,8 @@ def parse(argv=None):
     ap.add_argument('--ref-1gpu', type=float, default=None, help='images/sec of the same workload on 1 GPU: adds efficiency_vs_1gpu to the line')
     ap.add_argument('--master-port', type=int, default=None, help='rendezvous port of the self-launched ranks (default: a free port)')
     ap.add_argument('--dryrun-cpu', action='store_true', help='tests only: gloo/CPU stand-in step (launcher + rank bookkeeping), not a measurement')
+    ap.add_argument('--always-bucket', action='store_true',
+                    help='whmr_train: pack and exchange the gradient buckets even at world size 1 (one-rank RCCL smoke of the reducer on a 1-GPU box)')
     ap.add_argument('--no-secondary', action='store_true',
                     help='default run (vit224, 1 GPU): skip the short secondary legs (the same workload in bf16x3, BASELINE configs[2] whmr, configs[3] whmr_train)')
     ap.add_argument('--rank-timeout', type=float, default=1500.0,
@@ -134,7 +136,7 @@ def build_workload(args, dev):
         # global_orient.* (and dp_head.* without AUX supervision) never receive a gradient -- the reference asks DDP for find_unused_parameters
         # (core/trainer.py:84-91); GradReducer drops them at its first finish().  The backbone is one autograd node, so its parameters get
         # their own buckets: the head buckets are exchanged while the ViT backward still runs.
-        red = None if use_graph else GradReducer(params, groups=[n.startswith('feature_extractor') for n, _ in named])
+        red = None if use_graph else GradReducer(params, groups=[n.startswith('feature_extractor') for n, _ in named], always_bucket=args.always_bucket)
         if red is not None:
             red.attach(m.feature_extractor.backbone)          # the ViT node publishes its gradients block by block: buckets exchange under its backward
         rank = int(os.environ.get('RANK', '0'))
@@ -652,7 +654,7 @@ def main(argv=None):
         torch.cuda.set_device(local)
         dev = torch.device('cuda', local)
     dist = None
-    if world > 1:
+    if world > 1 or (args.always_bucket and 'MASTER_ADDR' in os.environ and 'RANK' in os.environ):    # (one-rank RCCL smoke under torch.distributed.run)
         import torch.distributed as dist
         import datetime
         tmo = datetime.timedelta(seconds=max(60.0, min(args.rank_timeout, 1800.0)))      # a rank that never arrives fails the collective instead of hanging it

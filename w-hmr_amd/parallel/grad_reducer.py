@@ -81,7 +81,7 @@ class GradReducer:
         for p in ps:
             offs.append(n)
             n += p.numel()
-        self.buckets.append(dict(params=ps, offsets=offs, numel=n, flat=None, pending=len(ps), work=None, events=[]))
+        self.buckets.append(dict(params=ps, offsets=offs, numel=n, flat=None, pending=len(ps), work=None, streams=set()))
 
     # ---- backward side
     def _active(self):
@@ -102,12 +102,11 @@ class GradReducer:
         b, i = self._slot[id(p)]
         if p.grad is not None and p.grad.is_cuda:
             # The gradient was produced on WHATEVER stream this hook / publish runs on (the heavy chain of the W-HMR step back-propagates on a
-            # side stream and autograd runs a node's backward -- and its AccumulateGrad -- on the stream of its forward).  Record WHERE: the pack
-            # below waits for every gradient of its bucket, not only for the stream the last one arrived on (a smaller bucket or
-            # another parameter order would otherwise pack half-written gradients with no error).
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(p.grad.device))
-            b['events'].append(ev)
+            # side stream and autograd runs a node's backward -- and its AccumulateGrad -- on the stream of its forward).  Remember WHICH: the
+            # pack below orders itself behind every stream that fed its bucket, not only the one the last gradient arrived on (a
+            # smaller bucket or another parameter order would otherwise pack half-written gradients with no error).  One event per (bucket,
+            # stream) at pack time -- an event per parameter cost ~230 host-side records per step (one-rank RCCL smoke: +3.8 ms).
+            b['streams'].add(torch.cuda.current_stream(p.grad.device))
         b['pending'] -= 1
         if b['pending'] == 0:
             self._pack_and_launch(b)
@@ -140,9 +139,12 @@ class GradReducer:
         full = len(have) == len(b['params'])
         if dev.type == 'cuda':
             cur = torch.cuda.current_stream(dev)
-            for ev in b['events']:                   # every gradient of the bucket is complete before the pack reads it, whichever stream made it
-                cur.wait_event(ev)
-        b['events'] = []
+            for st in b['streams']:                  # every gradient of the bucket is complete before the pack reads it, whichever stream made it:
+                if st != cur:                        # an event recorded NOW at the tail of that stream lies behind the kernels that wrote them
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    cur.wait_event(ev)
+        b['streams'] = set()
         flat = b['flat'] = (torch.empty if full else torch.zeros)(b['numel'], dtype=torch.float32, device=dev)
         if have:
             views = [flat[off:off + q.numel()].view_as(q) for q, off in have]
@@ -150,8 +152,9 @@ class GradReducer:
         self._launch(b)
 
     def _launch(self, b):
-        if self.world == 1:
-            return
+        if self.world == 1 and not (self.always_bucket and dist.is_initialized()):
+            return                               # (always_bucket on an initialised one-rank group still runs the collective: the hardware smoke of
+                                                 #  the exchange-stream choreography on a 1-GPU box, bench.py --always-bucket)
         flat = b['flat']
         if flat.is_cuda:
             # the exchange runs on a side stream so that the rest of the backward keeps the compute stream busy
@@ -235,11 +238,13 @@ def broadcast_buffers(module, src=0, process_group=None):
     named = [(n, b) for n, b in module.named_buffers() if b.is_floating_point() and 'running_' in n]
     if not named:
         return 0
-    flat = torch.cat([b.detach().reshape(-1).float() for _, b in named])
+    bufs = [b.detach() for _, b in named]
+    flat = torch.cat([b.reshape(-1).float() for b in bufs])
     dist.broadcast(flat, src=src, group=process_group)
-    off = 0
+    views, off = [], 0
+    for b in bufs:
+        views.append(flat[off:off + b.numel()].view_as(b))
+        off += b.numel()
     with torch.no_grad():
-        for _, b in named:
-            b.copy_(flat[off:off + b.numel()].view_as(b))
-            off += b.numel()
+        torch._foreach_copy_(bufs, views)            # one multi-tensor launch back (was one copy per buffer: 114 small launches per step)
     return len(named)
