@@ -362,3 +362,31 @@ def test_bench_launcher_kills_hung_ranks_and_exits_nonzero():
     assert r.returncode == 124, (r.returncode, r.stderr[-400:])
     assert 'were killed' in r.stderr and '"metric"' not in r.stdout
     assert time.time() - t0 < 60
+
+
+def test_split_bf16_operand_pairs_and_elementwise_metric():
+    """host side of the bf16x3 numerics: a hi / lo pair carries >= 16 significand bits, the K-concatenated weight layout pairs up with the
+    activation layout ([x_hi | x_lo | x_hi] . [W_hi | W_hi | W_lo] = x_hi W_hi + x_lo W_hi + x_hi W_lo), and the element-wise parity metric
+    holds small components to the tensor's own scale"""
+    from conftest import ew_err
+    from whmr_amd import _lib as L
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(64, 96, generator=g) * 3
+    w = torch.randn(32, 96, generator=g)
+    xh, xl = L.split_bf16(x)
+    assert xh.dtype == xl.dtype == torch.bfloat16
+    assert ((xh.double() + xl.double() - x.double()).abs() / x.double().abs()).max() < 2.0 ** -16
+    w3 = L.split3_weight(w)
+    assert w3.shape == (32, 288) and w3.dtype == torch.bfloat16
+    x3 = torch.cat([xh, xl, xh], 1)
+    wh, wl = L.split_bf16(w)
+    three = xh.double() @ wh.double().t() + xl.double() @ wh.double().t() + xh.double() @ wl.double().t()
+    assert torch.allclose(x3.double() @ w3.double().t(), three, rtol=0, atol=1e-9)
+    exact = x.double() @ w.double().t()
+    assert ((three - exact).abs().max() / exact.abs().max()) < 2e-5              # the dropped lo.lo term + the pairs' rounding
+    assert ((xh.double() @ wh.double().t() - exact).abs().max() / exact.abs().max()) > 1e-3     # plain bf16 for scale
+    # ew_err: a 1e-3 error on a component 1000x below the tensor's largest entry passes max-rel at 1e-6 but not the element-wise gate
+    b = torch.tensor([1000.0, 1.0, 1.0, 1.0])
+    a = b.clone()
+    a[1] += 1e-3
+    assert ((a - b).abs().max() / b.abs().max()) < 1e-5 and ew_err(a, b) > 1e-6 and ew_err(b, b) == 0.0

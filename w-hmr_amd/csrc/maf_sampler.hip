@@ -169,6 +169,13 @@ __global__ __launch_bounds__(256) void maf_sample_mfma_kernel(const bf16_t* __re
     __shared__ __attribute__((aligned(16))) char sY1b[32 * 128];      // Y1 [32][64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const long g0 = (long)blockIdx.x * 32, total = (long)B * P;
+    // Weight fragments are REQUESTED before they are needed (round 3): the layers are chains of MFMAs whose weight operand came from global
+    // memory four at a time, i.e. 4 + 6 + 5 dependent L2 round trips behind the gather -- most of the launch.  Layer 0's 16 fragments are in
+    // flight under the gather, layer 1's 24 under layer 0, layer 2's 20 under layer 1.
+    auto w_frag = [&](const bf16_t* w, int ld, int n0, int kk) { return *(const bf16x8_t*)(w + (size_t)(n0 + l31) * ld + kk * 16 + hi * 8); };
+    bf16x8_t w0f[16];
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) w0f[kk] = w_frag(wts.w0b, 256, wave * 32, kk);
     // ---- gather: 8 threads per point, 32 channels (4 x 16 B) each
     {
         const int r = tid >> 3, part = tid & 7;
@@ -221,7 +228,11 @@ __global__ __launch_bounds__(256) void maf_sample_mfma_kernel(const bf16_t* __re
     }
     __syncthreads();
     auto f_frag = [&](const char* base, int kk, int mask) { return *(const bf16x8_t*)(base + maf_f_addr(l31, kk * 2 + hi, mask)); };
-    auto w_frag = [&](const bf16_t* w, int ld, int n0, int kk) { return *(const bf16x8_t*)(w + (size_t)(n0 + l31) * ld + kk * 16 + hi * 8); };
+    bf16x8_t w1f[24];
+    if (wave < 2) {
+#pragma unroll
+        for (int kk = 0; kk < 24; ++kk) w1f[kk] = w_frag(wts.w1b, 384, wave * 32, kk);
+    }
     // rows (regs) = output channel n0 + (r&3) + 8(r>>2) + 4hi, column (lane) = point l31
     auto store_act = [&](char* dst, int mask, int n0, const f32x16_t& a, const float* bias) {
 #pragma unroll
@@ -240,19 +251,44 @@ __global__ __launch_bounds__(256) void maf_sample_mfma_kernel(const bf16_t* __re
         f32x16_t a;
 #pragma unroll
         for (int r = 0; r < 16; ++r) a[r] = 0.f;
-#pragma unroll 4
-        for (int kk = 0; kk < 16; ++kk) a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_frag(wts.w0b, 256, wave * 32, kk), f_frag(sFb, kk, 31), a, 0, 0, 0);
+        // two accumulators per layer: a chain of dependent MFMAs waits the full pipeline latency per step (16 / 24 / 20 steps here)
+        f32x16_t a2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a2[r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 16; kk += 2) {
+            a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0f[kk], f_frag(sFb, kk, 31), a, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0f[kk + 1], f_frag(sFb, kk + 1, 31), a2, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[r] += a2[r];
         store_act(sY0b, 15, wave * 32, a, wts.b0);
+    }
+    bf16x8_t w2f[20];
+    if (wave == 0) {
+#pragma unroll
+        for (int kk = 0; kk < 20; ++kk) w2f[kk] = w_frag(wts.w2b, 320, 0, kk);
     }
     __syncthreads();
     if (wave < 2) {   // layer 1: [Y0 (128) | F (256)] -> 64
         f32x16_t a;
 #pragma unroll
         for (int r = 0; r < 16; ++r) a[r] = 0.f;
-#pragma unroll 4
-        for (int kk = 0; kk < 8; ++kk) a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_frag(wts.w1b, 384, wave * 32, kk), f_frag(sY0b, kk, 15), a, 0, 0, 0);
-#pragma unroll 4
-        for (int kk = 0; kk < 16; ++kk) a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_frag(wts.w1b, 384, wave * 32, 8 + kk), f_frag(sFb, kk, 31), a, 0, 0, 0);
+        f32x16_t a2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a2[r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 8; kk += 2) {
+            a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[kk], f_frag(sY0b, kk, 15), a, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[kk + 1], f_frag(sY0b, kk + 1, 15), a2, 0, 0, 0);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 16; kk += 2) {
+            a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[8 + kk], f_frag(sFb, kk, 31), a, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[9 + kk], f_frag(sFb, kk + 1, 31), a2, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[r] += a2[r];
         store_act(sY1b, 7, wave * 32, a, wts.b1);
     }
     __syncthreads();
@@ -260,10 +296,21 @@ __global__ __launch_bounds__(256) void maf_sample_mfma_kernel(const bf16_t* __re
         f32x16_t a;
 #pragma unroll
         for (int r = 0; r < 16; ++r) a[r] = 0.f;
+        f32x16_t a2;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_frag(wts.w2b, 320, 0, kk), f_frag(sY1b, kk, 7), a, 0, 0, 0);
-#pragma unroll 4
-        for (int kk = 0; kk < 16; ++kk) a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_frag(wts.w2b, 320, 0, 4 + kk), f_frag(sFb, kk, 31), a, 0, 0, 0);
+        for (int r = 0; r < 16; ++r) a2[r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 4; kk += 2) {
+            a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2f[kk], f_frag(sY1b, kk, 7), a, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2f[kk + 1], f_frag(sY1b, kk + 1, 7), a2, 0, 0, 0);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 16; kk += 2) {
+            a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2f[4 + kk], f_frag(sFb, kk, 31), a, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2f[5 + kk], f_frag(sFb, kk + 1, 31), a2, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[r] += a2[r];
         const long g = g0 + l31;
         if (g < total) {
             const int b = (int)(g / P), p = (int)(g - (long)b * P);
