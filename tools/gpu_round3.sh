@@ -17,6 +17,8 @@ if [ "${3:-}" = "tests" ]; then
   timeout 2400 python -m pytest tests -m gpu -q > $OUT/${TAG}_gpu_tests.log 2>&1
   echo "gpu tests rc=$?"; tail -3 $OUT/${TAG}_gpu_tests.log
 fi
+python -c "import __graft_entry__ as g; g.smoke()" > $OUT/${TAG}_smoke.log 2>&1 || fail "smoke failed: $(tail -3 $OUT/${TAG}_smoke.log)"
+grep "smoke ok" $OUT/${TAG}_smoke.log
 bench() {  # name, args...
   local n=$1; shift
   python bench.py "$@" > $PROF/${TAG}_bench_$n.json 2> $OUT/${TAG}_bench_$n.err || fail "bench $n failed: $(tail -2 $OUT/${TAG}_bench_$n.err)"
