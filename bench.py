@@ -766,14 +766,21 @@ def main(argv=None):
                 res['cpu_baseline'] = cpu_train_baseline()
             elif not args.no_cpu and n_ranks == 1 and sd is not None:
                 res['cpu_baseline'] = cpu_baseline(sd, x.cpu(), size, 16 if args.workload == 'vitl256x192' else 12)
-                with torch.no_grad():
-                    res['parity'] = dict(parity_figures(step(), cpu_baseline.last_output), numerics=args.numerics,
-                                         note='backbone feature map [B, C, Hp, Wp] of the timed step vs the CPU oracle (oracle.vit.vit_forward, the '
-                                              'cpu_baseline leg) over the whole batch; the 1e-4 gate applies to the parity-grade numerics (fp32, bf16x3)')
+                try:
+                    with torch.no_grad():
+                        res['parity'] = dict(parity_figures(step(), cpu_baseline.last_output), numerics=args.numerics,
+                                             note='backbone feature map [B, C, Hp, Wp] of the timed step vs the CPU oracle (oracle.vit.vit_forward, the '
+                                                  'cpu_baseline leg) over the whole batch; the 1e-4 gate applies to the parity-grade numerics (fp32, bf16x3)')
+                except Exception as e:                  # noqa: BLE001
+                    res['parity'] = {'error': '%s: %s' % (type(e).__name__, e)}
             else:
                 res['cpu_baseline'] = None
             if args.workload == 'vit224' and n_ranks == 1 and args.numerics == 'bf16' and not args.no_secondary:
-                res['secondary'] = secondary_rows(args, dev, x)
+                try:                                    # the secondary legs never cost the headline line: a failure is reported inside it
+                    res['secondary'] = secondary_rows(args, dev, x)
+                except Exception as e:                  # noqa: BLE001
+                    import traceback
+                    res['secondary'] = {'error': '%s: %s' % (type(e).__name__, e), 'where': traceback.format_exc().strip().splitlines()[-3:]}
         else:
             st = getattr(args, 'dry_state', None)
             if st is not None:

@@ -160,6 +160,9 @@ def lib():
             fn.argtypes = args
             fn.restype = C.c_int
         _lib = l
+        for slot, key in enumerate(('WHMR_BLK_TILE_QKV', 'WHMR_BLK_TILE_PROJ', 'WHMR_BLK_TILE_FC1', 'WHMR_BLK_TILE_FC2')):     # A/B: force a tile per ViT shape
+            if os.environ.get(key):
+                l.whmr_gemm_blk_set_tile(slot, int(os.environ[key], 0))
         if os.environ.get('WHMR_BLK_SCHED'):         # A/B switch of the blocked GEMM's main loop (0 / 1: W through LDS, 2: W direct), tools/r3_wd.sh
             l.whmr_gemm_blk_set_tile(4, int(os.environ['WHMR_BLK_SCHED']))
     return _lib

@@ -7,8 +7,9 @@
 // accumulated in fp32 -- fp32-grade results at a third of the bf16 MFMA rate, several times the exact-f32 MFMA path.  The ring slot keeps
 // its size: a slot is a 16-deep K slice with the hi and the lo 1-KiB unit of a row block side by side where the bf16 kernel keeps two
 // consecutive 16-deep units, so the fragment reads are IDENTICAL (fa[i][0] = hi, fa[i][1] = lo) and only the DMA source addresses and the
-// MFMA phase differ: 24 MFMAs (MI = 4) against the same 12 ds_reads + DMA share per phase, i.e. the kernel moves from
-// LDS-bandwidth-co-limited to MFMA-bound.
+// MFMA phase differ: 24 MFMAs (MI = 4) against the same 12 ds_reads + DMA share per phase.  In the bf16 kernel a wave's MEM phase (12 fragment
+// reads + its 4 LDS-DMA pieces, each ~100-185 cycles to issue inside a busy phase: MI355X_MICROARCH.md, + the counted waits) outlasts its partner's
+// 512-cycle MFMA phase; here the MFMA phase is 768 cycles and covers it, so the loop is MFMA-bound.
 #pragma once
 #include <type_traits>
 #include "common.h"
@@ -27,9 +28,10 @@ template <int OFF> __device__ __forceinline__ bf16x8_t blk_lds_read128(uint32_t 
 }
 
 // WD ("W direct"): the weight fragments never touch LDS -- each wave loads its own 64 columns of W straight from global memory / L2 into
-// registers (a blocked 1-KiB unit IS an MFMA operand: one coalesced global_load_dwordx4 per fragment), three half tiles deep.  The bf16 main loop
-// is co-limited by LDS bandwidth (per 32-deep half tile of a 256 x 256 tile: 8 waves x 12 ds_read_b128 = 768 clk + 256 clk of LDS-DMA writes
-// against 1024 MFMA clk); without the W half the LDS side drops to 512 + 128 clk and the ring holds only A.
+// registers (a blocked 1-KiB unit IS an MFMA operand: one coalesced global_load_dwordx4 per fragment), three half tiles deep; the ring holds only A
+// and a wave issues 2 LDS-DMA pieces + 4 register loads per phase instead of 4 pieces, and reads 8 fragments from LDS instead of 12.  Measured
+// 3-4 % SLOWER than the LDS-staged loop: the texture path carries the same bytes either way, and two half tiles of prefetch distance do
+// not cover a global load's latency under load (a fourth register set does not fit).  Kept as schedule 2 for A/B runs; bit-identical results.
 template <int MI0, int MI1, bool WD = false>
 struct blk_cfg {
     static constexpr int MB = MI0 + MI1;                 // A row blocks (32 rows) per tile
