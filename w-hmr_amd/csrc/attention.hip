@@ -171,28 +171,51 @@ __global__ __launch_bounds__(NKT * 64, 4) void attention_bf16_chunk_kernel(const
     const int C = H * 64, ld = 3 * C;
     const bf16_t* base = qkv + (size_t)b * N * ld + h * 64;
     const int ld8 = ld >> 3, m_img = b * N;
+    bf16x8_t qf[4];
     if constexpr (BLK) {
+        // Every global load of the workgroup's prologue is ISSUED before the first one is consumed: K (4 pieces per thread: NPAD * 8 = 4 x the
+        // workgroup), V (2 x 2) and this lane's Q fragments (4) -- 12 x 16 B in flight per thread, ONE memory round trip.  As load -> LDS-store
+        // loops hipcc waits vmcnt(0) in every iteration and sinks the Q loads behind the barrier: 4 + 2 + 1 dependent round trips, most of a
+        // workgroup's lifetime (round 3: 24.9 -> see DESIGN 6).
+        uint4 kreg[4], vreg[2][2];
+        const int qr = (wave * 32 + l31 > N - 1) ? N - 1 : wave * 32 + l31;
         if (!(abl & 2)) {
-        for (int c = tid; c < NPAD * 8; c += NKT * 64) {
-            const int key = c % NPAD, ch = c / NPAD;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (key < N) v = *(const uint4*)(qkv + blk_elem(m_img + key, (C + h * 64) / 8 + ch, ld8));
-            *(uint4*)(Ks + key * 128 + ((ch ^ ((key >> 1) & 7)) << 4)) = v;
-        }
-        for (int c = tid; c < (NPAD / 2) * 8; c += NKT * 64) {
-            const int kp = c % (NPAD / 2), ch = c / (NPAD / 2);
-            const int k0 = 2 * kp;
-            uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0;
-            if (k0 < N) v0 = *(const uint4*)(qkv + blk_elem(m_img + k0, (2 * C + h * 64) / 8 + ch, ld8));
-            if (k0 + 1 < N) v1 = *(const uint4*)(qkv + blk_elem(m_img + k0 + 1, (2 * C + h * 64) / 8 + ch, ld8));
-            const uint32_t a[4] = {v0.x, v0.y, v0.z, v0.w}, bb[4] = {v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                *(uint32_t*)(Vt + (ch * 8 + 2 * i) * VS + k0) = (a[i] & 0xffffu) | (bb[i] << 16);
-                *(uint32_t*)(Vt + (ch * 8 + 2 * i + 1) * VS + k0) = (a[i] >> 16) | (bb[i] & 0xffff0000u);
+                const int c = tid + i * (NKT * 64), key = c % NPAD, ch = c / NPAD;
+                kreg[i] = make_uint4(0, 0, 0, 0);
+                if (key < N) kreg[i] = *(const uint4*)(qkv + blk_elem(m_img + key, (C + h * 64) / 8 + ch, ld8));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int c = tid + i * (NKT * 64), kp = c % (NPAD / 2), ch = c / (NPAD / 2), k0 = 2 * kp;
+                vreg[i][0] = vreg[i][1] = make_uint4(0, 0, 0, 0);
+                if (k0 < N) vreg[i][0] = *(const uint4*)(qkv + blk_elem(m_img + k0, (2 * C + h * 64) / 8 + ch, ld8));
+                if (k0 + 1 < N) vreg[i][1] = *(const uint4*)(qkv + blk_elem(m_img + k0 + 1, (2 * C + h * 64) / 8 + ch, ld8));
             }
         }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const bf16x8_t*)(qkv + blk_elem(m_img + qr, (h * 64) / 8 + kk * 2 + hi, ld8));
+        if (!(abl & 2)) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = tid + i * (NKT * 64), key = c % NPAD, ch = c / NPAD;
+                *(uint4*)(Ks + key * 128 + ((ch ^ ((key >> 1) & 7)) << 4)) = kreg[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int c = tid + i * (NKT * 64), kp = c % (NPAD / 2), ch = c / (NPAD / 2), k0 = 2 * kp;
+                const uint4 v0 = vreg[i][0], v1 = vreg[i][1];
+                const uint32_t a[4] = {v0.x, v0.y, v0.z, v0.w}, bb[4] = {v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    *(uint32_t*)(Vt + (ch * 8 + 2 * e) * VS + k0) = (a[e] & 0xffffu) | (bb[e] << 16);
+                    *(uint32_t*)(Vt + (ch * 8 + 2 * e + 1) * VS + k0) = (a[e] >> 16) | (bb[e] & 0xffff0000u);
+                }
+            }
         }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) asm volatile("" :: "v"(qf[kk]));        // the Q fragments have landed before the barrier (no sinking)
     } else {
     for (int c = tid; c < NPAD * 8; c += NKT * 64) {
         const int key = c >> 3, ch = c & 7;
@@ -217,11 +240,10 @@ __global__ __launch_bounds__(NKT * 64, 4) void attention_bf16_chunk_kernel(const
     const int q0 = wave * 32;
     int qrow = q0 + l31;
     if (qrow > N - 1) qrow = N - 1;
-    bf16x8_t qf[4];
+    if constexpr (!BLK) {
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
-        qf[kk] = BLK ? *(const bf16x8_t*)(qkv + blk_elem(m_img + qrow, (h * 64) / 8 + kk * 2 + hi, ld8))
-                     : *(const bf16x8_t*)(base + (size_t)qrow * ld + kk * 16 + hi * 8);
+        for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const bf16x8_t*)(base + (size_t)qrow * ld + kk * 16 + hi * 8);
+    }
     __syncthreads();
 
     const float sc = scale * LOG2E;

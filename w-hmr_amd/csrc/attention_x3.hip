@@ -25,38 +25,54 @@ __global__ __launch_bounds__(NKT * 64, 1) void attention_x3_blk_kernel(const bf1
     const int l31 = lane & 31, hi = lane >> 5;
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int C = H * 64, ld8 = (3 * C) >> 3, m_img = b * N;
+    // Prologue: every global load (K 2 x 4 pieces per thread, V 2 x 2 x 2, the lane's Q fragments 2 x 4) is issued before the first one is
+    // consumed -- one memory round trip instead of one per staging-loop iteration (this kernel runs ONE workgroup per CU: nothing else hides them).
+    const int q0 = wave * 32;
+    const int qrow = (q0 + l31 > N - 1) ? N - 1 : q0 + l31;
+    uint4 kreg[2][4], vreg[2][2][2];
+    bf16x8_t qf[2][4];
 #pragma unroll
     for (int part = 0; part < 2; ++part) {
         const bf16_t* qkv = src[part];
-        for (int c = tid; c < NPAD * 8; c += NKT * 64) {
-            const int key = c % NPAD, ch = c / NPAD;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (key < N) v = *(const uint4*)(qkv + x3_blk_elem(m_img + key, (C + h * 64) / 8 + ch, ld8));
-            *(uint4*)(Ks[part] + key * 128 + ((ch ^ ((key >> 1) & 7)) << 4)) = v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + i * (NKT * 64), key = c % NPAD, ch = c / NPAD;
+            kreg[part][i] = make_uint4(0, 0, 0, 0);
+            if (key < N) kreg[part][i] = *(const uint4*)(qkv + x3_blk_elem(m_img + key, (C + h * 64) / 8 + ch, ld8));
         }
-        for (int c = tid; c < (NPAD / 2) * 8; c += NKT * 64) {
-            const int kp = c % (NPAD / 2), ch = c / (NPAD / 2);
-            const int k0 = 2 * kp;
-            uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0;
-            if (k0 < N) v0 = *(const uint4*)(qkv + x3_blk_elem(m_img + k0, (2 * C + h * 64) / 8 + ch, ld8));
-            if (k0 + 1 < N) v1 = *(const uint4*)(qkv + x3_blk_elem(m_img + k0 + 1, (2 * C + h * 64) / 8 + ch, ld8));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + i * (NKT * 64), kp = c % (NPAD / 2), ch = c / (NPAD / 2), k0 = 2 * kp;
+            vreg[part][i][0] = vreg[part][i][1] = make_uint4(0, 0, 0, 0);
+            if (k0 < N) vreg[part][i][0] = *(const uint4*)(qkv + x3_blk_elem(m_img + k0, (2 * C + h * 64) / 8 + ch, ld8));
+            if (k0 + 1 < N) vreg[part][i][1] = *(const uint4*)(qkv + x3_blk_elem(m_img + k0 + 1, (2 * C + h * 64) / 8 + ch, ld8));
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) qf[part][kk] = *(const bf16x8_t*)(qkv + x3_blk_elem(m_img + qrow, (h * 64) / 8 + kk * 2 + hi, ld8));
+    }
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + i * (NKT * 64), key = c % NPAD, ch = c / NPAD;
+            *(uint4*)(Ks[part] + key * 128 + ((ch ^ ((key >> 1) & 7)) << 4)) = kreg[part][i];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + i * (NKT * 64), kp = c % (NPAD / 2), ch = c / (NPAD / 2), k0 = 2 * kp;
+            const uint4 v0 = vreg[part][i][0], v1 = vreg[part][i][1];
             const uint32_t a[4] = {v0.x, v0.y, v0.z, v0.w}, bb[4] = {v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                *(uint32_t*)(Vt[part] + (ch * 8 + 2 * i) * VS + k0) = (a[i] & 0xffffu) | (bb[i] << 16);
-                *(uint32_t*)(Vt[part] + (ch * 8 + 2 * i + 1) * VS + k0) = (a[i] >> 16) | (bb[i] & 0xffff0000u);
+            for (int e = 0; e < 4; ++e) {
+                *(uint32_t*)(Vt[part] + (ch * 8 + 2 * e) * VS + k0) = (a[e] & 0xffffu) | (bb[e] << 16);
+                *(uint32_t*)(Vt[part] + (ch * 8 + 2 * e + 1) * VS + k0) = (a[e] >> 16) | (bb[e] & 0xffff0000u);
             }
         }
     }
-    const int q0 = wave * 32;
-    int qrow = q0 + l31;
-    if (qrow > N - 1) qrow = N - 1;
-    bf16x8_t qf[2][4];
 #pragma unroll
     for (int part = 0; part < 2; ++part)
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-            qf[part][kk] = *(const bf16x8_t*)(src[part] + x3_blk_elem(m_img + qrow, (h * 64) / 8 + kk * 2 + hi, ld8));
+        for (int kk = 0; kk < 4; ++kk) asm volatile("" :: "v"(qf[part][kk]));   // landed before the barrier (no sinking behind it)
     __syncthreads();
 
     const float sc = scale * LOG2E;
