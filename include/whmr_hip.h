@@ -426,6 +426,13 @@ struct whmr_smpl_call {
     struct whmr_stage_tail tail;
 };
 int whmr_smpl_fused(const struct whmr_smpl_model* m, const struct whmr_smpl_call* f, void* stream);
+/* Pose-corrective blend shapes + skinning in ONE launch (verts.py:46-53, lbs.py:67-77): replaces the [B,207] x [207,20670] whmr_gemm_f32 into a [B,20670]
+ * buffer + whmr_smpl_skin.  posedirs_tiled: [108][208][192] (posedirs re-tiled per 64-vertex chunk, k-major, zero padded); pose_feat [B,207] and
+ * A [B,24,12] from whmr_smpl_pose_chain; verts [B,6890,3].  Same vertices, bit for bit. */
+int whmr_smpl_blend_skin(const struct whmr_smpl_model* m, const float* posedirs_tiled, const float* betas, long beta_stride, const float* pose_feat,
+                         const float* A, int B, float* verts, void* stream);
+/* tools: route four 64-bit 100 MHz phase stamps of workgroup 0 of whmr_smpl_blend_skin into buf[2..9] (16 uint32 device words; null = off). */
+int whmr_smpl_blend_skin_stamps(uint32_t* buf);
 /* whmr_smpl_stage_tail with the joint regression as a CSR gather (reg_*: CSR of the first t->R rows of [J_regressor_extra ; J_regressor]): ONE launch,
  * one workgroup per image -- the regressors are > 99 % zeros; replaces the dense B x R-workgroup regression + the tail launch. */
 int whmr_smpl_stage_tail_csr(const struct whmr_smpl_model* m, const struct whmr_stage_tail* t, const int32_t* reg_ptr, const int32_t* reg_col,

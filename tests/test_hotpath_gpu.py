@@ -419,7 +419,7 @@ def test_smpl_one_launch_call_matches_the_five_launch_form(dev, assets, B):
     F = 2144
     outs = {}
     for fused in (False, True, True):
-        m.fused, m.csr_tail = fused, False               # reference form: the dense regression + tail launches of round 2
+        m.fused, m.csr_tail, m.blend_skin = fused, False, False     # reference form: the five launches of round 2
         xc = torch.zeros(B, F + 234, device=dev)
         o = m.run(state[:, 216:226], state[:, :216], gram_schmidt=True, want_aa=True, want_smpl_joints=True, want_markers=True, post=dict(post),
                   nxt=dict(bbox_info=torch.ones(B, 5, device=dev), xc=xc, F=F))
@@ -436,7 +436,7 @@ def test_smpl_one_launch_call_matches_the_five_launch_form(dev, assets, B):
     for x, y in zip(a.post, b.post):
         assert _rel(y, x) < 1e-5
     # the product's default: per-phase launches with the CSR joint regression inside the tail launch
-    m.fused, m.csr_tail = False, True
+    m.fused, m.csr_tail, m.blend_skin = False, True, True             # chain | blend + skin | CSR regression + tail: three launches
     xc = torch.zeros(B, F + 234, device=dev)
     c = m.run(state[:, 216:226], state[:, :216], gram_schmidt=True, want_aa=True, want_smpl_joints=True, want_markers=True, post=dict(post),
               nxt=dict(bbox_info=torch.ones(B, 5, device=dev), xc=xc, F=F))

@@ -14,7 +14,7 @@ for B in (1, 8, 64, 256):
     rot = (torch.eye(3).expand(B, 24, 3, 3) + 0.1 * torch.randn(B, 24, 3, 3, generator=g)).contiguous().to(dev)
     res = {}
     for fused in (False, True, 'csr'):
-        m.fused, m.csr_tail = fused is True, fused == 'csr'
+        m.fused, m.csr_tail, m.blend_skin = fused is True, fused == 'csr', fused == 'csr'
         fn = lambda: m.run(betas, rot, gram_schmidt=True, want_aa=True, want_smpl_joints=True, want_markers=True)
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
@@ -40,5 +40,12 @@ for B in (1, 8, 64, 256):
     st = L.smpl_barrier(dev).cpu()[2:14].view(torch.int64).tolist()
     print('      phase stamps of workgroup 0 (us): chain %.1f | barrier %.1f | blend+skin %.1f | barrier %.1f | regress+tail %.1f'
           % tuple((st[i + 1] - st[i]) / 100.0 for i in range(5)))
+    m.fused, m.csr_tail, m.blend_skin = False, True, True
+    buf = torch.zeros(16, dtype=torch.int32, device=dev)
+    L.lib().whmr_smpl_blend_skin_stamps(buf.data_ptr())
+    fn(); torch.cuda.synchronize()
+    L.lib().whmr_smpl_blend_skin_stamps(None)
+    bs = buf.cpu()[2:10].view(torch.int64).tolist()
+    print('      blend+skin launch, workgroup 0 (us): loads + staging %.1f | fp32-MFMA offsets %.1f | shape blend + skinning %.1f' % tuple((bs[i + 1] - bs[i]) / 100.0 for i in range(3)))
     byt = B * 84172.0 + 19.6e6
-    print('B %4d: five launches (dense regression) %.1f us, four launches (CSR tail) %.1f us = %.1f %% of 8 TB/s, one launch %.1f us' % (B, res[False], res['csr'], byt / res['csr'] / 1e6 / 8 * 100, res[True]), flush=True)
+    print('B %4d: five launches (round 2) %.1f us, three launches (blend+skin, CSR tail) %.1f us = %.1f %% of 8 TB/s, one launch %.1f us' % (B, res[False], res['csr'], byt / res['csr'] / 1e6 / 8 * 100, res[True]), flush=True)

@@ -107,6 +107,8 @@ _SIGS = {
     'whmr_smpl_stage_tail': [C.POINTER(WhmrSmplModel), C.POINTER(WhmrStageTail), _I, _P, _P],
     'whmr_smpl_fused': [C.POINTER(WhmrSmplModel), C.POINTER(WhmrSmplFused), _P],
     'whmr_smpl_stage_tail_csr': [C.POINTER(WhmrSmplModel), C.POINTER(WhmrStageTail), _P, _P, _P, _I, _P],
+    'whmr_smpl_blend_skin': [C.POINTER(WhmrSmplModel), _P, _P, _L, _P, _P, _I, _P, _P],
+    'whmr_smpl_blend_skin_stamps': [_P],
     'whmr_smpl_joints': [C.POINTER(WhmrSmplModel), _P, _P, _I, _P, _P, _P, _P, _P],
     'whmr_maf_sample': [_P, _I, _L, _L, _L, _L, _I, _I, _P, _P, _P, _L, _F, _F, _F, C.POINTER(WhmrMafWeights), _I, _I, _P, _L, _P, _P],
     'whmr_crop_normalize': [_P, _I, _I, _L, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
@@ -686,6 +688,14 @@ def smpl_pose_chain(model, pose9, betas, do_gs, rotmat, aa, A, posed_joints, pos
     bp, bs = _rows(betas, 10)
     _check(lib().whmr_smpl_pose_chain(C.byref(model), pp, ps, bp, bs, B, int(do_gs), _ptr(rotmat), _ptr(aa), A.data_ptr(),
                                       _ptr(posed_joints), _ptr(pose_feat), _stream()), 'whmr_smpl_pose_chain')
+
+
+def smpl_blend_skin(model, posedirs_tiled, betas, pose_feat, A, verts):
+    """pose-corrective offsets (fp32 MFMA from the re-tiled posedirs) + shape blend + skinning in one launch"""
+    bp, bs = _rows(betas, 10)
+    assert posedirs_tiled.dtype == torch.float32 and posedirs_tiled.is_contiguous() and tuple(posedirs_tiled.shape) == (108, 208, 192)
+    _check(lib().whmr_smpl_blend_skin(C.byref(model), posedirs_tiled.data_ptr(), bp, bs, pose_feat.data_ptr(), A.data_ptr(), betas.shape[0],
+                                      verts.data_ptr(), _stream()), 'whmr_smpl_blend_skin')
 
 
 def smpl_skin(model, betas, pose_feat, A, verts, pose_off=None):

@@ -63,6 +63,9 @@ __device__ __forceinline__ void grid_barrier(uint32_t* ctr, uint32_t target) {
 #define P2_PO (P2_A + FUSED_IG * NJ * 12)
 #define P2_FLOATS (P2_PO + FUSED_IG * 3 * FUSED_VT)
 
+// COH: pose_feat / A were written by an earlier phase of the SAME kernel and the vertices are read by a later one (coherent sc1 accesses);
+// false: a separate launch (whmr_smpl_blend_skin) -- plain cached accesses.
+template <bool COH>
 __device__ __forceinline__ void fused_phase2_item(const whmr_smpl_model& m, const whmr_smpl_call& p, int vb, int b0, float* smem) {
     float* sPF = smem + P2_PF;
     float* sBeta = smem + P2_BETA;
@@ -71,6 +74,18 @@ __device__ __forceinline__ void fused_phase2_item(const whmr_smpl_model& m, cons
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, B = p.B;
     const int l31 = lane & 31, hi = lane >> 5;
     const int v0 = vb * FUSED_VT;
+    // this item's posedirs tile: 208 x 192 floats, CONTIGUOUS (the [207, 20670] original puts a chunk's k rows 82 KB apart: 208 DRAM pages and TLB
+    // entries per wave for 128-B pieces -- measured 26 us per item, 0.65 TB/s); zero padded, so no clamps.  All 104 k-steps of this lane's column
+    // are requested FIRST (104 registers), ahead of the staging loads below: the two latencies overlap and are paid once.
+    // (separate-launch form only: four 100 MHz stamps of workgroup 0 behind p.barrier, when given -- tools/smpl_timing.py)
+    uint64_t* stamps = (!COH && p.barrier && blockIdx.x == 0 && tid == 0) ? (uint64_t*)(p.barrier + 2) : nullptr;
+    if (stamps) stamps[0] = wall_clock64();
+    float pv[FUSED_KP / 2];
+    {
+        const float* pt = p.posedirs_tiled + (size_t)vb * (FUSED_KP * 3 * FUSED_VT) + hi * (3 * FUSED_VT) + 32 * wave + l31;
+#pragma unroll
+        for (int u = 0; u < FUSED_KP / 2; ++u) pv[u] = pt[(size_t)u * (2 * 3 * FUSED_VT)];
+    }
     // staging: every coherent (sc1) load of a thread is ISSUED before the first one is used -- a load-use pair per loop iteration would pay the
     // memory round trip once per element (18 + 24 of them)
     {
@@ -79,12 +94,12 @@ __device__ __forceinline__ void fused_phase2_item(const whmr_smpl_model& m, cons
 #pragma unroll
         for (int i = 0; i < NPFL; ++i) {
             const int e = tid + i * FUSED_NT, k = e / FUSED_IG, bb = e % FUSED_IG;
-            tpf[i] = (e < FUSED_KP * FUSED_IG && b0 + bb < B && k < NPF) ? ld_f<true>(p.pose_feat + (size_t)(b0 + bb) * NPF + k) : 0.f;
+            tpf[i] = (e < FUSED_KP * FUSED_IG && b0 + bb < B && k < NPF) ? ld_f<COH>(p.pose_feat + (size_t)(b0 + bb) * NPF + k) : 0.f;
         }
 #pragma unroll
         for (int i = 0; i < NAL; ++i) {
             const int e = tid + i * FUSED_NT, bb = e / (NJ * 12);
-            ta[i] = (e < FUSED_IG * NJ * 12 && b0 + bb < B) ? ld_f<true>(p.A + (size_t)(b0 + bb) * NJ * 12 + (e % (NJ * 12))) : 0.f;
+            ta[i] = (e < FUSED_IG * NJ * 12 && b0 + bb < B) ? ld_f<COH>(p.A + (size_t)(b0 + bb) * NJ * 12 + (e % (NJ * 12))) : 0.f;
         }
         for (int e = tid; e < 10 * FUSED_IG; e += FUSED_NT) {
             const int k = e / FUSED_IG, bb = e % FUSED_IG;
@@ -96,32 +111,32 @@ __device__ __forceinline__ void fused_phase2_item(const whmr_smpl_model& m, cons
         for (int i = 0; i < NAL; ++i) { const int e = tid + i * FUSED_NT; if (e < FUSED_IG * NJ * 12) sA[e] = ta[i]; }
     }
     __syncthreads();
+    if (stamps) stamps[1] = wall_clock64();
     // ---- pose-corrective offsets (verts.py:51-53) = pose_feature . posedirs on v_mfma_f32_32x32x2_f32 -- exact f32, a sequential fma chain over k:
     // the instruction the per-phase path's GEMM uses, hence the same bits.  Wave w owns columns 32 w .. 32 w + 31 of the item's 192 for all 32
     // images: A operand = pose features [image = lane & 31][k = k0 + (lane >> 5)] from LDS, B operand = posedirs [k][column] straight from global
     // memory (two 128-B row pieces per step, 13 steps in flight).
     {
-        // this item's posedirs tile: 208 x 192 floats, CONTIGUOUS (the [207, 20670] original puts a chunk's k rows 82 KB apart: 208 DRAM pages and
-        // TLB entries per wave for 128-B pieces -- measured 26 us per item, 0.65 TB/s); zero padded, so no clamps
-        const float* pt = p.posedirs_tiled + (size_t)vb * (FUSED_KP * 3 * FUSED_VT) + hi * (3 * FUSED_VT) + 32 * wave + l31;
         f32x16_t acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        // all 104 k-steps of this lane's column are requested up front (104 registers): latency is paid once
         constexpr int S = FUSED_KP / 2;
-        float pv[S];
+        // the pose-feature operands are read ahead in two halves (52 registers each): fetched one step at a time each ds_read's latency sat on
+        // the dependent MFMA chain (130 cycles per step measured, 64 for the instruction itself)
+        float av[S / 2];
 #pragma unroll
-        for (int u = 0; u < S; ++u) pv[u] = pt[(size_t)u * (2 * 3 * FUSED_VT)];
+        for (int half = 0; half < 2; ++half) {
 #pragma unroll
-        for (int u = 0; u < S; ++u) {
-            const float a = sPF[(2 * u + hi) * FUSED_IG + l31];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pv[u], acc, 0, 0, 0);
+            for (int u = 0; u < S / 2; ++u) av[u] = sPF[(2 * (half * (S / 2) + u) + hi) * FUSED_IG + l31];
+#pragma unroll
+            for (int u = 0; u < S / 2; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], pv[half * (S / 2) + u], acc, 0, 0, 0);
         }
         // C layout: register r of lane (l31, hi) = image (r & 3) + 8 (r >> 2) + 4 hi, column l31
 #pragma unroll
         for (int r = 0; r < 16; ++r) sPO[((r & 3) + 8 * (r >> 2) + 4 * hi) * (3 * FUSED_VT) + 32 * wave + l31] = acc[r];
     }
     __syncthreads();
+    if (stamps) stamps[2] = wall_clock64();
     // ---- blend + skin: thread = (vertex lv = tid & 63, image subset sub = tid >> 6): images bb = sub, sub + 6, ...
     {
         const int lv = tid & (FUSED_VT - 1), sub = tid >> 6;
@@ -139,11 +154,12 @@ __device__ __forceinline__ void fused_phase2_item(const whmr_smpl_model& m, cons
                 smpl_shape_vertex(t0, t1, t2, s, sBeta + bb, FUSED_IG, acc);
                 const float* po = sPO + bb * (3 * FUSED_VT) + 3 * lv;
                 acc[0] += po[0]; acc[1] += po[1]; acc[2] += po[2];
-                smpl_skin_vertex<true>(w, sA + bb * NJ * 12, acc[0], acc[1], acc[2], p.verts + ((size_t)(b0 + bb) * NV + v) * 3);
+                smpl_skin_vertex<COH>(w, sA + bb * NJ * 12, acc[0], acc[1], acc[2], p.verts + ((size_t)(b0 + bb) * NV + v) * 3);
             }
         }
     }
     __syncthreads();                                                              // LDS is reused by the next item
+    if (stamps) stamps[3] = wall_clock64();
 }
 
 // Joint regression as a CSR gather over the skinned mesh + the stage tail, one workgroup (NT threads) per image b = first, first + step, ...:
@@ -233,7 +249,7 @@ __global__ __launch_bounds__(FUSED_NT, 1) void smpl_fused_kernel(const whmr_smpl
     {
         const int nvb = (NV + FUSED_VT - 1) / FUSED_VT, ngrp = (B + FUSED_IG - 1) / FUSED_IG;
         for (int it = blockIdx.x; it < nvb * ngrp; it += G)
-            fused_phase2_item(m, p, it / ngrp, (it % ngrp) * FUSED_IG, (float*)smem);
+            fused_phase2_item<true>(m, p, it / ngrp, (it % ngrp) * FUSED_IG, (float*)smem);
     }
     STAMP(3);
     grid_barrier(p.barrier, (uint32_t)(2 * G));
@@ -307,6 +323,45 @@ extern "C" int whmr_smpl_stage_tail_csr(const whmr_smpl_model* m, const whmr_sta
     if (t.smpl_joints45 && t.R != 33) return (int)hipErrorInvalidValue;
     if (t.xc_next && (!t.state || !t.rotmat || !t.bbox_info)) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(smpl_tail_csr_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, *m, t, reg_ptr, reg_col, reg_val, B);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- pose-corrective blend shapes + skinning as ONE launch of the per-phase path (was the [B, 207] x [207, 20670] fp32 GEMM into a [B, 20670]
+// buffer + smpl_skin_kernel<1>: 16.5 + 17.5 us at batch 64): one workgroup per (64-vertex chunk, 32-image group) runs phase 2 of the one-launch
+// kernel above with plain cached accesses -- the offsets on v_mfma_f32_32x32x2_f32 from the re-tiled posedirs copy (same bits as the GEMM), through
+// LDS to the skinning layout.  The pose-offset buffer (5.3 MB written + read at batch 64) is gone.
+__global__ __launch_bounds__(FUSED_NT, 1) void smpl_blend_skin_kernel(const whmr_smpl_model m, const whmr_smpl_call p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // workgroup id -> (vertex chunk, image group) so that the image groups of ONE chunk are neighbours on the SAME XCD (ids with equal id % 8
+    // share an XCD and its L2): they fetch the chunk's 160 KB posedirs tile at the same time and the L2 merges the misses -- 17 MB from HBM per
+    // call instead of 17 MB per image group
+    const int ngrp = (p.B + FUSED_IG - 1) / FUSED_IG, nvb = (NV + FUSED_VT - 1) / FUSED_VT;
+    const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    const int vb = (k / ngrp) * 8 + xcd;
+    if (vb >= nvb) return;
+    fused_phase2_item<false>(m, p, vb, (k % ngrp) * FUSED_IG, (float*)smem);
+}
+
+static uint32_t* g_blend_stamps = nullptr;          // tools only: whmr_set_option(200, 1) routes workgroup 0's phase stamps into a 64-byte device buffer
+extern "C" int whmr_smpl_blend_skin_stamps(uint32_t* buf) { g_blend_stamps = buf; return 0; }
+
+extern "C" int whmr_smpl_blend_skin(const whmr_smpl_model* m, const float* posedirs_tiled, const float* betas, long beta_stride, const float* pose_feat,
+                                    const float* A, int B, float* verts, void* stream) {
+    if (B <= 0 || !posedirs_tiled || !betas || !pose_feat || !A || !verts) return (int)hipErrorInvalidValue;
+    whmr_smpl_call f = {};
+    f.betas = betas; f.beta_stride = beta_stride; f.B = B;
+    f.A = const_cast<float*>(A); f.pose_feat = const_cast<float*>(pose_feat); f.verts = verts; f.posedirs_tiled = posedirs_tiled;
+    f.barrier = g_blend_stamps;
+    const size_t lds = (size_t)P2_FLOATS * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)smpl_blend_skin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    const int nvb = (NV + FUSED_VT - 1) / FUSED_VT, ngrp = (B + FUSED_IG - 1) / FUSED_IG;
+    hipLaunchKernelGGL(smpl_blend_skin_kernel, dim3(8 * ((nvb + 7) / 8) * ngrp), dim3(FUSED_NT), lds, (hipStream_t)stream, *m, f);
     WHMR_CHECK_LAUNCH();
     return 0;
 }

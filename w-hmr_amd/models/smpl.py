@@ -59,10 +59,11 @@ class SMPL(nn.Module):
         self.marker_ids = torch.as_tensor(ids, dtype=torch.long)
         self._dev_cache = None
         # fused = True: the whole call as ONE launch behind two grid barriers (csrc/smpl_fused.hip).  Same bits, but NOT faster on this part
-        # (77 vs 50 us at batch 64 -- every phase of the persistent grid pays its memory round trips alone, with one workgroup per CU),
-        # so the default is the per-phase form: pose chain -> pose-corrective GEMM -> skinning -> CSR joint regression + stage tail (4 launches)
+        # (56 vs 42 us at batch 64 -- a persistent grid holds one workgroup per CU and pays every phase's memory round trips alone),
+        # so the default is the per-phase form: pose chain -> blend shapes + skinning -> CSR joint regression + stage tail (3 launches)
         self.fused = False
         self.csr_tail = True        # False: the dense B x 33-workgroup regression + tail launch of round 2 (A/B)
+        self.blend_skin = True      # pose-corrective offsets + skinning as one launch; False: fp32 GEMM into a [B, 20670] buffer + the skin kernel (A/B)
 
     @property
     def faces(self):
@@ -148,11 +149,13 @@ class SMPL(nn.Module):
                                 post=None if post is None else dict(post, aa=aa), nxt=None if nxt is None else dict(nxt, rotmat=rot))
             return ModelOutput(verts, joints, sj, rot, aa, mk, tail)
         L.smpl_pose_chain(m, pose9, betas, gram_schmidt, rot, aa, A, pj, pf)
-        # pose-corrective offsets: one fp32 MFMA GEMM [B,207] x [207,20670] (verts.py:51-53), then blend + skin
-        pose_off = torch.empty(B, self.NUM_VERTS * 3, **f32)
-        L.gemm(pf, self._dev_cache[2]['posedirs_t'], pose_off)
         verts = torch.empty(B, self.NUM_VERTS, 3, **f32)
-        L.smpl_skin(m, betas, pf, A, verts, pose_off)
+        if self.blend_skin:         # pose-corrective offsets (verts.py:51-53) on the matrix pipes + shape blend + skinning, one launch
+            L.smpl_blend_skin(m, self._dev_cache[2]['posedirs_tiled'], betas, pf, A, verts)
+        else:                       # one fp32 MFMA GEMM [B,207] x [207,20670], then blend + skin
+            pose_off = torch.empty(B, self.NUM_VERTS * 3, **f32)
+            L.gemm(pf, self._dev_cache[2]['posedirs_t'], pose_off)
+            L.smpl_skin(m, betas, pf, A, verts, pose_off)
         joints = torch.empty(B, 49, 3, **f32)
         sj = torch.empty(B, 45, 3, **f32) if want_smpl_joints else None
         mk = torch.empty(B, m.n_markers, 3, **f32) if (want_markers and m.n_markers) else None
