@@ -1,4 +1,5 @@
 #!/bin/bash
+# A/B of the blocked GEMM main loop: schedule 1 (W through LDS) vs 2 (W direct), bf16 and bf16x3, + the bit-identity test
 set -uo pipefail
 R=${GRAFT_REPO_ROOT:-$PWD}; OUT=$R/gpurun_out; mkdir -p $OUT; cd $R
 timeout 600 python -m pytest tests/test_blocked_gpu.py -m gpu -q -x -k "w_direct" > $OUT/r3g_wd.log 2>&1

@@ -1,4 +1,5 @@
 #!/bin/bash
+# A/B of forced tile heights for the bf16x3 GEMMs (WHMR_BLK_TILE_*): the chooser picks hold
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R
 run() { python bench.py --no-cpu --no-secondary --numerics bf16x3 --steps 20 --warmup 5 2>/dev/null | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$1 ms', round(d['ms_per_step'],4), 'issue', round(d['roofline']['mfma_issue_frac'],4))"; }
 run base

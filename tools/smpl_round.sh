@@ -1,4 +1,5 @@
 #!/bin/bash
+# SMPL call: bit-identity test of the launch forms, whmr bench (hbm_rows), per-batch timing + phase stamps (tools/smpl_timing.py)
 set -uo pipefail
 R=${GRAFT_REPO_ROOT:-$PWD}; OUT=$R/gpurun_out; mkdir -p $OUT; cd $R
 timeout 180 python -m pytest tests/test_hotpath_gpu.py -m gpu -q -x -s -k "one_launch or smpl" > $OUT/r3f_smpl.log 2>&1
