@@ -212,3 +212,44 @@ def test_vit_x3_layernorm_fold_matches_explicit_passes(dev):
         print('bf16x3 %s: LayerNorm folded %.2e, explicit %.2e (element-wise vs the exact-f32 mode)' % (name, ef, ee))
         assert ef < 1e-4 and ee < 1e-4 and _rel(folded, ref) < 1e-4
         assert not torch.equal(folded, explicit)                  # two different pipelines did run
+
+
+def test_vit_large_x3_32_crops_properties(dev):
+    """the per-GPU share of BASELINE configs[4] in the parity-grade numerics: ViT-L/16 256x192 at 32 crops (6144 tokens: the 96-row tile, K = 1024 / 4096
+    -> 64 / 256 sixteen-deep ring slots) in bf16x3 -- per-image independence bit for bit (32 == 16 + 16) and agreement of the first crops with the
+    exact-f32 mode of the same module to 1e-4, element-wise"""
+    from oracle import synth
+    sd = synth.make_vit_state(5, (256, 192), embed_dim=1024, depth=24)
+    m = _vit(sd, (256, 192), dev, 'bf16x3', 1024, 24, 16)
+    x = synth.make_inputs(32, 13, (256, 192))['x'].to(dev)
+    full = m(x)
+    assert torch.equal(full, torch.cat([m(x[:16]), m(x[16:])])) and torch.isfinite(full).all()
+    ref = _vit(sd, (256, 192), dev, 'fp32', 1024, 24, 16)(x[:4])
+    e, ew = _rel(full[:4], ref), ew_err(full[:4], ref)
+    print('bf16x3 ViT-L depth 24, 32 crops vs the exact-f32 mode: max-rel %.2e element-wise %.2e' % (e, ew))
+    assert e < 1e-4 and ew < 1e-4
+
+
+def test_whmr_x3_graph_replay_and_side_streams(dev, assets, state_dict):
+    """the full forward in bf16x3 (ViT on the split-operand blocked kernels, deconvs / Tz conv as K-concatenated split operands, fp32 heads): the HIP-graph
+    replay equals the eager call, and the side-stream arrangement (cam_model beside the backbone, deconv 2 / 3 + Tz head beside the regressor loop) gives
+    the same bits as the in-line order"""
+    from whmr_amd.graph import GraphedForward
+    from whmr_amd.models import whmr_net
+    from oracle import synth
+    m = whmr_net(None, assets=assets, numerics='bf16x3')
+    m.load_state_dict(state_dict, strict=False)
+    m = m.to(dev).eval()
+    inp = {k: v.to(dev) for k, v in synth.make_inputs(6, 31).items()}
+    full = torch.randn(1, 3, 160, 224, generator=torch.Generator().manual_seed(3)).to(dev)
+    args = (inp['x'], None, inp['center'], inp['scale'], inp['bbox_height'], inp['orig_shape'], inp['bbox_info'])
+    m.overlap_camera = m.overlap_tz = False
+    ref = {k: v.clone() for k, v in m(*args, full_x=full).items()}
+    m.overlap_camera = m.overlap_tz = True
+    out = m(*args, full_x=full)
+    for k in ref:
+        assert torch.equal(out[k], ref[k]), k
+    g = GraphedForward(m, *args, full_x=full)
+    rep = g(*args, full_x=full)
+    for k in ref:
+        assert torch.allclose(rep[k], ref[k], rtol=1e-5, atol=1e-6), k
