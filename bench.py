@@ -307,7 +307,7 @@ def secondary_rows(args, dev, x, budget_s=40.0):
     rows['vit224_bf16x3'] = {'ms_per_step': ms, 'images_per_sec': args.batch / ms * 1e3, 'gemm_algorithmic_TFLOPs': alg,
                              'mfma_issue_frac': 3.0 * alg / 2500.0,
                              'parity_vs_cpu_oracle': parity_figures(out3, ref) if ref is not None else None,
-                             'note': 'same step, numerics bf16x3 (three bf16 MFMAs per product on hi/lo operand pairs, fp32 accumulate, exact GELU, fp32 '
+                             'note': 'same step, numerics bf16x3 (three bf16 MFMAs per product on hi/lo operand pairs, fp32 accumulate, erf GELU, fp32 '
                                      'LayerNorm / softmax): the mode that meets the 1e-4 tolerance AND runs on the bf16 matrix pipes; mfma_issue_frac = share of '
                                      'the 2.5 PF dense bf16 peak the pipes issue (3 x algorithmic); parity over the whole batch of %d crops' % args.batch}
     del step3, out3

@@ -106,7 +106,7 @@ struct whmr_gemm_blk_desc {
     /* split-bf16 operands ("bf16x3" numerics: the parity-grade mode of the same path -- the reference's Linears are fp32, vit.py:61-115): every
      * operand is a pair x = x_hi + x_lo (x_hi = bf16(x), x_lo = bf16(x - x_hi): 16 significand bits) and a product is three MFMAs per fragment
      * pair (hi.hi + lo.hi + hi.lo, fp32 accumulate).  A_lo / W_lo: lo halves in the layout of A / W; C_lo: lo half of a bf16 result (epi 0 / 1,
-     * required there; epi 1 then applies the exact erf GELU of nn.GELU).  All three null = plain bf16 operands.  The LayerNorm fold works in
+     * required there; epi 1 then applies the erf GELU of nn.GELU to fp32 accuracy: A&S 7.1.28, 8.7e-7 of float64).  All three null = plain bf16 operands.  The LayerNorm fold works in
      * this numerics too: a producer then also needs xhat_lo, a consumer takes W = the hi / lo pair of gamma o W and colsum of their sum. */
     const void* A_lo; const void* W_lo; void* C_lo;
     /* per-row shift of a folding producer (xhat != null): xhat / stats_out are taken of (C - s_m), s_m = (shift ? shift[m] : 0) + (shift_stats ?

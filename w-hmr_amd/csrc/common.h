@@ -46,6 +46,23 @@ __device__ __forceinline__ float wave_max(float v) {
 // exact (erf) GELU, as torch.nn.GELU() default
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
+// GELU for the bf16x3 (parity-grade) epilogue: x * Phi(x) with erf from Abramowitz & Stegun 7.1.28, erf(t) = 1 - (1 + a1 t + ... + a6 t^6)^-16 for t >= 0
+// (|error| <= 3e-7), evaluated in fp32: max |gelu_as(x) - gelu(x)| = 8.7e-7 over [-8, 8] against float64 -- the fp32 erf-based GELU of the reference's
+// own framework measures 1.2e-6 on the same grid, so this is as exact as the arithmetic being reproduced.  6 FMAs + 4 squarings + one reciprocal:
+// about half the instructions of erff, which made the fc1 epilogue of the bf16x3 kernel VALU-bound.
+__device__ __forceinline__ float gelu_as(float x) {
+    const float t = fabsf(x) * 0.70710678118654752440f;
+    float p = fmaf(0.0000430638f, t, 0.0002765672f);
+    p = fmaf(p, t, 0.0001520143f);
+    p = fmaf(p, t, 0.0092705272f);
+    p = fmaf(p, t, 0.0422820123f);
+    p = fmaf(p, t, 0.0705230784f);
+    p = fmaf(p, t, 1.0f);
+    p = p * p; p = p * p; p = p * p; p = p * p;
+    const float e = 1.0f - __builtin_amdgcn_rcpf(p);                 // erf(|x| / sqrt 2)
+    return 0.5f * x * (1.0f + copysignf(e, x));
+}
+
 // GELU for the bf16 output path: x * Phi~(x), Phi~(x) = 0.5 + s r(s^2), s = clamp(x, -4, 4), r = degree-6 minimax polynomial
 // (LP fit of x*(Phi~ - Phi) on [-4, 4] with Phi~(4) = 1 pinned, so the tails are exact: gelu -> x and -> 0).
 // |gelu_fast - gelu_erf| <= 1.9e-4 absolute over all x (the tanh form the reference's accelerators use is 4.7e-4 off),

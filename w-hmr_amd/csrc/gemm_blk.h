@@ -23,7 +23,7 @@ struct whmr_gemm_blk_desc {
     const float* colsum;
     float ln_eps;
     // ---- split-bf16 operands ("bf16x3", gemm_blk_x3.hip): x = x_hi + x_lo, three MFMAs per product.  A_lo / W_lo: the lo halves of A / W (same
-    // layout); C_lo: lo half of a bf16 result (epi 0 / 1; epi 1 then applies the exact erf GELU).  All null = plain bf16 operands.
+    // layout); C_lo: lo half of a bf16 result (epi 0 / 1; epi 1 then applies the erf GELU to fp32 accuracy, common.h gelu_as).  All null = plain bf16 operands.
     const void* A_lo;
     const void* W_lo;
     void* C_lo;

@@ -369,8 +369,8 @@ __global__ __launch_bounds__(512, 2) void gemm_blk_kernel(const whmr_gemm_blk_de
                     f32x2_t v0 = {fmaf(acc[i][j][4 * q], rs[i], fmaf(-rm[i], cq[q].x, bq[q].x)), fmaf(acc[i][j][4 * q + 1], rs[i], fmaf(-rm[i], cq[q].y, bq[q].y))};
                     f32x2_t v1 = {fmaf(acc[i][j][4 * q + 2], rs[i], fmaf(-rm[i], cq[q].z, bq[q].z)), fmaf(acc[i][j][4 * q + 3], rs[i], fmaf(-rm[i], cq[q].w, bq[q].w))};
                     if constexpr (X3) {
-                        // parity-grade epilogue: exact (erf) GELU like nn.GELU (vit.py:66-68), result split into its hi / lo bf16 halves
-                        if constexpr (EPI == 1) { v0.x = gelu_erf(v0.x); v0.y = gelu_erf(v0.y); v1.x = gelu_erf(v1.x); v1.y = gelu_erf(v1.y); }
+                        // parity-grade epilogue: erf GELU like nn.GELU (vit.py:66-68; gelu_as: 8.7e-7 from float64, the fp32 framework GELU 1.2e-6), result split into hi / lo
+                        if constexpr (EPI == 1) { v0.x = gelu_as(v0.x); v0.y = gelu_as(v0.y); v1.x = gelu_as(v1.x); v1.y = gelu_as(v1.y); }
                         split_bf16x2(v0.x, v0.y, pk[q][0], pl[q][0]); split_bf16x2(v1.x, v1.y, pk[q][1], pl[q][1]);
                     } else {
                         if constexpr (EPI == 1) { v0 = gelu_fast2(v0); v1 = gelu_fast2(v1); }
