@@ -14,8 +14,13 @@
 // with 4 (r & 3) (128-B rows: 4 ((r >> 1) & 1)), which spreads them over four distinct 64-B windows.  The swizzle is applied on the DMA's SOURCE side (LDS destinations of
 // a wave instruction are linear).
 //
-// Split-K over blockIdx.z (a weight gradient is a few dozen tiles deep in K = all tokens): partial tiles go to the fp32 workspace and
-// tn_reduce_kernel sums them in slice order (deterministic).
+// Split-K (a weight gradient is a few dozen tiles deep in K = all tokens): partial tiles go to the fp32 workspace and tn_reduce_kernel sums
+// them in slice order (deterministic).  The grid is one-dimensional over (slice, tile) with the tile fastest, remapped so that every XCD owns
+// a contiguous range of it: the tiles of ONE K slice read the same dY / X rows (every output tile needs them; the nine taps of a convolution
+// weight gradient read the same pixels one shift apart), and the 32 CUs of an XCD walking ~1-4 slices side by side find them in their own
+// L2 -- dispatched round-robin, the tiles of a slice sat on 8 different XCDs and every one of them fetched the rows again (4.5x the unique
+// bytes for the 768 x 2304 gradient, 9x for the IUV head's).
+#include <cstdlib>
 #include "common.h"
 
 typedef __attribute__((address_space(3))) void tn_lds_void_t;
@@ -51,7 +56,9 @@ struct tn_params {
     const bf16_t* A; const bf16_t* B; float* C;
     long lda, ldb, ldc;
     int Mo, No, K;
-    int k_per_split;          // reduction rows per blockIdx.z slice (multiple of 32)
+    int k_per_split;          // reduction rows per K slice (multiple of 32)
+    int tiles, splits;        // grid = tiles * splits workgroups
+    int round_robin;          // A/B only (WHMR_TN_RR=1): dispatch order (slice, tile) without the XCD remap
     float* ws;                // split-K partials [splits][Mo][No] (null: direct store), then the column-sum partials [splits][Mo]
     float* db;                // optional [Mo]: db[m] = sum_k A[k][m] (bias gradient of the same Linear: column sums of dY), or null
     // B gather (convolution weight gradients): reduction index k = (b, oy, ox) over an OH x OW grid, column n = (tap, c) with c < GC
@@ -74,9 +81,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const tn_params p) {
     const int wm = wave >> 2, wn = wave & 3;
     const int l31 = lane & 31, hi = lane >> 5;
     const int tiles_n = p.No / BN;
-    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    const int lid = p.round_robin ? (int)blockIdx.x : xcd_remap(blockIdx.x, p.tiles * p.splits);
+    const int slice = lid / p.tiles, tile = lid - slice * p.tiles;
+    const int tm = tile / tiles_n, tn = tile % tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
-    const int k_begin = blockIdx.z * p.k_per_split;
+    const int k_begin = slice * p.k_per_split;
     const int k_end = min(p.K, k_begin + p.k_per_split);
     const int nkt = (k_end - k_begin) / BK;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(tn_lds_void_t*)smem;
@@ -103,6 +112,21 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const tn_params p) {
     // gather: this tile's tap and channel offset
     const int g_tap = GATHER ? n0 / p.GC : 0, g_c0 = GATHER ? n0 - g_tap * p.GC : 0;
     const int g_ky = GATHER ? g_tap / p.KW : 0, g_kx = GATHER ? g_tap - g_ky * p.KW : 0;
+    // gather: grid position (image, oy, ox) of each piece's reduction row, carried from step to step (stage() is called for kt = 0, 1, 2, ...
+    // in order; a step advances every row by 32 positions) -- two integer divisions per piece and step cost as much issue time as the
+    // step's MFMAs on the 128-row tile
+    int gb[UPW], goy[UPW], gox[UPW];
+    if constexpr (GATHER) {
+#pragma unroll
+        for (int i = 0; i < UPW; ++i) {
+            const int k = k_begin + urow[i];
+            const int ohw = p.OH * p.OW;
+            gb[i] = k / ohw;
+            const int rem = k - gb[i] * ohw;
+            goy[i] = rem / p.OW;
+            gox[i] = rem - goy[i] * p.OW;
+        }
+    }
     auto stage = [&](int kt) {
         const int slot = kt % 3;
 #pragma unroll
@@ -112,13 +136,14 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const tn_params p) {
             const bool isA = u < A_BYTES / 1024;
             const bf16_t* src;
             if (GATHER && !isA) {
-                const int k = k_begin + kt * BK + urow[i];
-                const int ohw = p.OH * p.OW;
-                const int b = k / ohw, rem = k - b * ohw;
-                const int oy = rem / p.OW, ox = rem - oy * p.OW;
-                const int iy = oy * p.S + g_ky - p.P, ix = ox * p.S + g_kx - p.P;
+                const int iy = goy[i] * p.S + g_ky - p.P, ix = gox[i] * p.S + g_kx - p.P;
                 const bool in = (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
-                src = in ? p.B + ((size_t)(b * p.IH + iy) * p.IW + ix) * p.ldb + g_c0 + uchunk[i] * 8 : p.zeros + uchunk[i] * 8;
+                src = in ? p.B + ((size_t)(gb[i] * p.IH + iy) * p.IW + ix) * p.ldb + g_c0 + uchunk[i] * 8 : p.zeros + uchunk[i] * 8;
+                gox[i] += BK;
+                while (gox[i] >= p.OW) {
+                    gox[i] -= p.OW;
+                    if (++goy[i] == p.OH) { goy[i] = 0; ++gb[i]; }
+                }
             } else {
                 src = usrc[i] + (size_t)kt * (isA ? stepA : stepB);
             }
@@ -180,7 +205,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const tn_params p) {
         }
     }
     if (do_db) {
-        float* dbo = p.ws ? p.ws + (size_t)gridDim.z * p.Mo * p.No + (size_t)blockIdx.z * p.Mo : p.db;
+        float* dbo = p.ws ? p.ws + (size_t)p.splits * p.Mo * p.No + (size_t)slice * p.Mo : p.db;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const float v = dbs[i] + __shfl_xor(dbs[i], 32, 64);
@@ -188,7 +213,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const tn_params p) {
         }
     }
     // D[row = (r & 3) + 8 (r >> 2) + 4 hi][col = l31]: for a fixed r the 32 lanes of a half-wave write 128 contiguous bytes
-    float* out = p.ws ? p.ws + (size_t)blockIdx.z * p.Mo * p.No : p.C;
+    float* out = p.ws ? p.ws + (size_t)slice * p.Mo * p.No : p.C;
     const long ldo = p.ws ? p.No : p.ldc;
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -232,7 +257,7 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
 }
 
 template <int MI, bool GATHER>
-static int launch_tn(const tn_params& p, int tiles, int splits, hipStream_t st) {
+static int launch_tn(tn_params p, int tiles, int splits, hipStream_t st) {
     constexpr int LDS = 3 * (32 * 64 * MI * 2 + 32 * 256 * 2);
     auto kern = gemm_tn_kernel<MI, GATHER>;
     static bool attr_done = false;
@@ -241,7 +266,9 @@ static int launch_tn(const tn_params& p, int tiles, int splits, hipStream_t st) 
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(tiles, 1, splits), dim3(512), LDS, st, p);
+    static const int rr = [] { const char* e = getenv("WHMR_TN_RR"); return e && e[0] == '1' ? 1 : 0; }();
+    p.tiles = tiles; p.splits = splits; p.round_robin = rr;
+    hipLaunchKernelGGL(kern, dim3(tiles * splits), dim3(512), LDS, st, p);
     WHMR_CHECK_LAUNCH();
     return 0;
 }
