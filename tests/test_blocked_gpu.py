@@ -84,6 +84,36 @@ def test_gemm_blk_matches_row_major_kernel_bitwise(dev):
     assert torch.equal(L.from_blocked(t, M), ref)
 
 
+def test_gemm_blk_mfma_shapes_agree(dev):
+    """the bf16 kernel on v_mfma_f32_16x16x32_bf16 (default) and the 32x32x16 kernel behind WHMR_BLK_MFMA=32 (whmr_gemm_blk_set_tile(5, 32)) read
+    the SAME packed operands and give the same results: every tile height, bf16 + GELU / fp32 residual epilogues, ragged M"""
+    from whmr_amd import _lib as L
+    g = torch.Generator().manual_seed(16)
+    M, N, K = 1000, 512, 768
+    a = torch.randn(M, K, generator=g).bfloat16().to(dev)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).bfloat16().to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    res = torch.randn(M, N, generator=g).to(dev)
+    ab, wb = L.to_blocked(a), L.to_blocked(w)
+    nb = ab.shape[0]
+    ref = a.float() @ w.float().t() + bias
+    try:
+        for tile in (0x44, 0x43, 0x33, 0x32, 0x22, 0x21, 0x55, 0x54):
+            outs = {}
+            for shape in (16, 32):
+                L.lib().whmr_gemm_blk_set_tile(5, shape)
+                o16 = torch.full((nb, N // 8, 32, 8), float('nan'), device=dev, dtype=torch.bfloat16)
+                L.gemm_blk(ab, wb, o16, M, bias=bias, epi=L.EPI_BF16_GELU, tile=tile)
+                t = L.to_blocked(res)
+                L.gemm_blk(ab, wb, t, M, bias=bias, epi=L.EPI_F32_RES, res=t, tile=tile)
+                outs[shape] = (L.from_blocked(o16, M).float(), L.from_blocked(t, M))
+            assert _rel(outs[16][1], ref + res) < 1e-5, hex(tile)
+            assert _rel(outs[16][1], outs[32][1]) < 1e-6, hex(tile)
+            assert _rel(outs[16][0], outs[32][0]) < 1e-2, hex(tile)
+    finally:
+        L.lib().whmr_gemm_blk_set_tile(5, 16)
+
+
 @pytest.mark.parametrize('C', [768, 1024, 256])
 def test_layernorm_blk(dev, C):
     from whmr_amd import _lib as L

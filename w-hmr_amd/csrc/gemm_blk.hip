@@ -4,9 +4,10 @@
 //
 // Layout ("blocked"): a [R, C] matrix is stored as [R/32][C/E][32][E] with E = 8 (bf16) or 4 (fp32), i.e. 512-byte units of
 // 32 rows x 16 bytes.  That unit is at once
-//   * what one half-wave of an MFMA 32x32x16 operand fetch reads (lane = row, 8 consecutive k),
-//   * what one half-wave of the (operand-swapped) MFMA result owns (lane = row, 4 fp32 / 8 bf16 consecutive columns),
+//   * what an MFMA operand fetch reads (lane = row, 8 consecutive k: 16 rows x 4 units for 16x16x32, 32 rows x 2 units for 32x32x16),
+//   * what the (operand-swapped) MFMA result owns (lane = row, 4 fp32 / 8 bf16 consecutive columns),
 //   * a contiguous 512 B of global memory AND of LDS.
+// The bf16 kernel (gemm_blk16_impl.h) computes on v_mfma_f32_16x16x32_bf16, the split-bf16 kernel (gemm_blk_impl.h) on 32x32x16.
 // Consequences: global_load_lds copies whole 1-KiB runs (no swizzle: the ds_read_b128 fragment reads of a linear image are
 // conflict-free), and the epilogue stores straight from the accumulators in 1-KiB wave stores -- no LDS transpose, no barrier.
 //
@@ -14,14 +15,16 @@
 // wave rows are two GROUPS (one wave of each per SIMD) that run one s_barrier apart.  Work unit = half a K tile (32 deep):
 //   MEM(h)  : ds_read this wave's fragments of half tile h (2 MI + 4 reads), issue its share of the LDS-DMA of half tile h + 3
 //             (ring of 4 half-tile slots, counted vmcnt: two younger groups stay in flight), wait
-//   MFMA(h) : 4 MI MFMAs straight from registers
+//   MFMA(h) : 8 MI MFMAs (16x16x32; 4 MI of 32x32x16 in the split-bf16 kernel) straight from registers
 // with ONE s_barrier per half tile and the two groups walking each slot in opposite order (group 0: MFMA then MEM, group 1: MEM then
 // MFMA): on every SIMD one wave feeds the matrix pipe while the other talks to LDS and the texture addresser.  In a lock-step loop all
 // 8 waves issue their DMA at the same time and the matrix pipes idle for the ~1000 clk the L1 needs to take 64 KiB (qkv main loop
 // 48 -> 36-38 us in the lab).
-#include "gemm_blk_impl.h"
+#include "gemm_blk16_impl.h"
+#include "gemm_blk_impl.h"      // the 32x32x16 kernel: split-bf16 operands (gemm_blk_x3.hip) and, behind WHMR_BLK_MFMA=32, the A/B partner of the bf16 kernel
 
 static int g_blk_sched = 1;
+static int g_blk_mfma32 = 0;      // A/B only: 1 = bf16 operands on the 32x32x16 kernel (tools/lab/mfma16_ab.sh); same packed operands, same results to rounding
 
 // The chooser minimises (rounds over 256 CUs) x (tile rows).
 static const int kBlkTiles[][2] = {{4, 4}, {5, 5}, {4, 3}, {3, 3}, {3, 2}, {2, 2}, {5, 4}, {2, 1}};
@@ -40,12 +43,14 @@ extern "C" int whmr_gemm_blk_tile(const whmr_gemm_blk_desc* pp, int tile, void* 
         if (!p.A_lo || !p.W_lo || (p.epi < 2 && !p.C_lo) || (p.xhat && !p.xhat_lo)) return (int)hipErrorInvalidValue;
         return blk_x3_launch_tile(pp, tile, stream, g_blk_sched);
     }
-    return blk_launch_tile<false>(p, tile, (hipStream_t)stream, g_blk_sched);
+    if (g_blk_mfma32) return blk_launch_tile<false>(p, tile, (hipStream_t)stream, g_blk_sched);
+    return blk16_launch_tile(p, tile, (hipStream_t)stream, g_blk_sched);
 }
 
 static int g_blk_force[4] = {0, 0, 0, 0};                   // whmr_set_option keys 110..113: tile for N = 2304 / (768, K <= 1024) / 3072 / (768, K > 1024)
 extern "C" int whmr_gemm_blk_set_tile(int slot, int tile) {
-    if (slot == 4) { g_blk_sched = tile; return 0; }                 // A/B: main-loop schedule (0 two barriers per half tile, 1 one barrier)
+    if (slot == 4) { g_blk_sched = tile; return 0; }
+    if (slot == 5) { g_blk_mfma32 = tile == 32; return 0; }          // A/B: MFMA shape of the bf16 kernel (16 = default, 32)                 // A/B: main-loop schedule (0 two barriers per half tile, 1 one barrier)
     if (slot < 0 || slot > 3) return (int)hipErrorInvalidValue;
     g_blk_force[slot] = tile;
     return 0;
