@@ -85,9 +85,10 @@ int whmr_orient_state(const float* cam_rotmat, const float* rotmat, long ld_rot,
 int whmr_orient_tail(const float* r, const float* pose_aa, const float* rotmat, float* g_pose, float* g_rotmat, int B, void* stream);
 
 /* ---- blocked-layout bf16 GEMM: the ViT's bf16 inference path (vit.py:61-140 qkv / proj / fc1 + GELU / fc2, vit.py:157 patch embed).
- * A [R, C] matrix is stored as [ceil(R/32)][C/E][32][E], E = 8 (bf16) / 4 (fp32): 512-byte units of 32 rows x 16 bytes -- the unit a
- * half-wave of an MFMA 32x32x16 operand fetch reads AND a half-wave of its (operand-swapped) result owns.  LDS-DMA staging copies whole
- * units (no swizzle), the epilogue stores straight from the accumulators; two wave groups run in ping-pong (gemm_blk.hip). */
+ * A [R, C] matrix is stored as [ceil(R/32)][C/E][32][E], E = 8 (bf16) / 4 (fp32): 512-byte units of 32 rows x 16 bytes -- the unit an
+ * MFMA operand fetch reads (lane = row, 8 consecutive k) AND the (operand-swapped) result owns (lane = row, 8 consecutive columns).  LDS-DMA
+ * staging copies whole units, the epilogue stores straight from the accumulators; two wave groups run in ping-pong (gemm_blk.hip).  bf16
+ * operands compute on v_mfma_f32_16x16x32_bf16, split-bf16 operand pairs (A_lo / W_lo set) on 32x32x16; the packed layouts are the same. */
 struct whmr_gemm_blk_desc {
     const void* A;        /* bf16 blocked [ceil(M/32)][K/8][32][8] */
     const void* W;        /* bf16 blocked [N/32][K/8][32][8] (nn.Linear weight [N, K], packed once) */
