@@ -738,7 +738,7 @@ def main(argv=None):
             res['roofline'] = {'bound': 'mfma', 'kernel': ('fp32 (exact-f32 MFMA) GEMM launches of one step (%d: gemm_f32_big_kernel for large M, the 64x64 / skinny kernels elsewhere)' % len(gemm)) if fp32_mode else
                                ('split-bf16 (bf16x3) GEMM launches of one step (%d: gemm_blk_kernel<X3>; achieved / frac count the ALGORITHMIC 2MNK flops -- the '
                                 'matrix pipes issue three bf16 MFMAs per product, see mfma_issue_frac)' % len(gemm)) if x3_mode else
-                               'bf16 MFMA GEMM launches of one step (%d: gemm_blk_kernel on the blocked ViT path, gemm_tn_kernel for the weight gradients, gemm_bf16_big_kernel elsewhere)' % len(gemm),
+                               'bf16 MFMA GEMM launches of one step (%d: gemm_blk16_kernel on the blocked ViT path, gemm_tn_kernel for the weight gradients, gemm_bf16_big_kernel elsewhere)' % len(gemm),
                                'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
                                'flops_per_launch': flops_per_launch, 'avg_launch_us': avg_s * 1e6,
                                'traffic': traffic['bytes_per_launch'] if traffic else None,

@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def per_kernel(db, counter):
     cur = sqlite3.connect(db).cursor()
     return cur.execute("select kernel_name, avg(value), count(*) from counters_collection where counter_name = ? and "
-                       "(kernel_name like '%gemm_blk_kernel%' or kernel_name like '%gemm_bf16_big_kernel%') group by kernel_name", (counter,)).fetchall()
+                       "(kernel_name like '%gemm_blk%_kernel%' or kernel_name like '%gemm_bf16_big_kernel%') group by kernel_name", (counter,)).fetchall()
 
 
 def main(fetch_db, write_db, out):
