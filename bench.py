@@ -332,7 +332,7 @@ def secondary_rows(args, dev, x, budget_s=40.0):
         at.workload, at.numerics = 'whmr_train', 'bf16'
         with torch.enable_grad():
             stept, _, _, _ = build_workload(at, dev)
-            ms = time_steps(stept, 4, 2)
+            ms = time_steps(stept, 8, 4)
         rows['whmr_train'] = {'ms_per_step': ms, 'images_per_sec': args.batch / ms * 1e3, 'workload': WORKLOAD['whmr_train']}
     else:
         rows['whmr_train'] = {'skipped': 'secondary budget spent'}
