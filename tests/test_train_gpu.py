@@ -949,6 +949,52 @@ def test_vit_node_publishes_gradients_to_the_reducer(dev):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize('bucket_bytes', [1 << 20, 64 << 20])
+def test_whmr_train_step_reducer_small_buckets_with_side_stream_gradients(dev, assets, state_dict, bucket_bytes):
+    """GradReducer on the full training step with the heavy chain on its side stream (whmr_train.OVERLAP_HEAVY, the default): head buckets
+    then mix gradients produced on two streams.  With 1-MiB buckets every bucket closes long before the streams are joined, so the pack must
+    wait on the events of EVERY producing stream (round-2 advisor finding); always_bucket runs the multi-GPU code path at world size 1
+    (pack, exchange stream, unpack).  The reduced gradients must equal the plain backward's bit for bit (the sampler's order-dependent
+    bf16 scatter aside: compared with a tolerance, like the determinism test)."""
+    from oracle import synth
+    from oracle import train as OT
+    from whmr_amd.parallel import GradReducer
+    from whmr_amd.train import whmr_train
+    assert whmr_train.OVERLAP_HEAVY
+    B = 4
+    inp = synth.make_inputs(B, 3)
+    d = {k: inp[k].to(dev) for k in ('x', 'center', 'scale', 'bbox_height', 'orig_shape', 'bbox_info')}
+    runs = []
+    for with_reducer in (False, True):
+        m = _train_model(assets, state_dict, 'bf16', dev)
+        m.feature_extractor.backbone.drop_path_rate = 0.0
+        named = [(n, p) for n, p in m.named_parameters() if p.requires_grad and not n.startswith('cam_model')]
+        red = None
+        if with_reducer:
+            red = GradReducer([p for _, p in named], groups=[n.startswith('feature_extractor') for n, _ in named], bucket_bytes=bucket_bytes,
+                              always_bucket=True)
+            red.attach(m.feature_extractor.backbone)
+        for _ in range(2):                                                     # twice: buckets re-arm after finish()
+            for _, p in named:
+                p.grad = None
+            out_list, _ = m(d['x'], None, d['center'], d['scale'], d['bbox_height'], d['orig_shape'], d['bbox_info'], is_train=True)
+            loss = OT.cotangent_loss(out_list['smpl_out'], dev=dev) + OT.dp_cotangent_loss(out_list['dp_out'][0], dev=dev)
+            loss.backward()
+            if red is not None:
+                red.finish()
+        torch.cuda.synchronize()
+        runs.append({n: p.grad.detach().clone() for n, p in named if p.grad is not None})
+    if bucket_bytes < (8 << 20):
+        assert len(red.buckets) > 20
+    assert runs[0].keys() == runs[1].keys() and len(runs[0]) > 200
+    exact = [k for k in runs[0] if k.startswith('regressor') or k.startswith('est_Tz') or k.startswith('dp_head')]
+    assert len(exact) > 30
+    for k in exact:
+        assert torch.equal(runs[0][k], runs[1][k]), k
+    for k, g in runs[0].items():
+        assert _rms(runs[1][k].cpu(), g.cpu()) < 2e-2, k
+
+
 @pytest.mark.parametrize('dt', [torch.bfloat16, torch.float32])
 def test_passthrough_nodes_accumulate_the_data_gradient_in_place(dev, dt):
     """ConvNHWCFn / DeconvBNReLUFn with ``passthrough``: the input map is handed on as a second output, and the gradient that comes back on it
