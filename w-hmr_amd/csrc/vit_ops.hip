@@ -228,13 +228,37 @@ __global__ __launch_bounds__(32 * PARTS) void layernorm_blk_kernel(const float* 
     const float rstd = 1.0f / sqrtf(var / (float)C + eps);
     const int m = rb * 32 + row;
     if constexpr (OUT_STD == 1) {
-        if (m >= rows) return;
-        float* yr = (float*)y + (size_t)m * C + n4_0 * 4;
+        // row-major fp32 output: a thread owns ONE row's columns, so direct stores would put the 32 lanes of a part on 32 different rows (16 B per
+        // 128-B line and store).  Each part transposes 32 rows x 32 columns at a time through its own 4.5-KB LDS patch (written and read by the same
+        // half wave: no workgroup barrier) and stores whole 128-B row pieces, 8 lanes per row.
+        if constexpr (NPER % 8 == 0) {
+            __shared__ float tp[PARTS][32][36];
 #pragma unroll
-        for (int q = 0; q < NPER; ++q) {
-            const float4 gg = *(const float4*)(g + (n4_0 + q) * 4), bb = *(const float4*)(b + (n4_0 + q) * 4);
-            *(float4*)(yr + q * 4) = make_float4((v[q].x - mean) * rstd * gg.x + bb.x, (v[q].y - mean) * rstd * gg.y + bb.y,
-                                                 (v[q].z - mean) * rstd * gg.z + bb.z, (v[q].w - mean) * rstd * gg.w + bb.w);
+            for (int q0 = 0; q0 < NPER; q0 += 8) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float4 gg = *(const float4*)(g + (n4_0 + q0 + q) * 4), bb = *(const float4*)(b + (n4_0 + q0 + q) * 4);
+                    *(float4*)&tp[part][row][q * 4] = make_float4((v[q0 + q].x - mean) * rstd * gg.x + bb.x, (v[q0 + q].y - mean) * rstd * gg.y + bb.y,
+                                                                  (v[q0 + q].z - mean) * rstd * gg.z + bb.z, (v[q0 + q].w - mean) * rstd * gg.w + bb.w);
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int t = row + 32 * k, r = t >> 3, c4 = t & 7;
+                    const float4 o = *(const float4*)&tp[part][r][c4 * 4];
+                    if (rb * 32 + r < rows) *(float4*)((float*)y + (size_t)(rb * 32 + r) * C + (n4_0 + q0 + c4) * 4) = o;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        } else {
+            if (m >= rows) return;
+            float* yr = (float*)y + (size_t)m * C + n4_0 * 4;
+#pragma unroll
+            for (int q = 0; q < NPER; ++q) {
+                const float4 gg = *(const float4*)(g + (n4_0 + q) * 4), bb = *(const float4*)(b + (n4_0 + q) * 4);
+                *(float4*)(yr + q * 4) = make_float4((v[q].x - mean) * rstd * gg.x + bb.x, (v[q].y - mean) * rstd * gg.y + bb.y,
+                                                     (v[q].z - mean) * rstd * gg.z + bb.z, (v[q].w - mean) * rstd * gg.w + bb.w);
+            }
         }
     } else if constexpr (OUT_STD == 2) {
         const size_t off = ((size_t)rb * (C >> 3) + (n4_0 >> 1)) * 256 + row * 8;
@@ -341,9 +365,16 @@ __global__ __launch_bounds__(256) void patch_im2col_blk_kernel(const float* __re
         const int iy = py * P - pad + ky, ix = px * P - pad + kx;
         if ((unsigned)iy < (unsigned)H) {
             const float* row = x + b * sb + ci * sc + (long)iy * sh;
+            if (sw == 1 && !((ix | W) & 1) && !((uintptr_t)(row + ix) & 7)) {
+                // unit pixel stride, even start and width: a pair of pixels is inside or outside together -- four 8-byte loads instead of eight dwords
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-                if ((unsigned)(ix + e) < (unsigned)W) v[e] = row[(long)(ix + e) * sw];
+                for (int e = 0; e < 8; e += 2)
+                    if ((unsigned)(ix + e) < (unsigned)W) { const float2 t = *(const float2*)(row + ix + e); v[e] = t.x; v[e + 1] = t.y; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if ((unsigned)(ix + e) < (unsigned)W) v[e] = row[(long)(ix + e) * sw];
+            }
         }
     }
     if (cols_lo) {                                      // split-bf16 pair (bf16x3 numerics): pixel = hi + lo
