@@ -613,3 +613,20 @@ def test_forward_glue_kernels_match_the_tensor_expressions(dev, Bf, B):
     assert torch.equal(g_rot[:, 1:], rot[:, 1:]) and torch.equal(g_pose[:, 3:], aa[:, 3:])
     assert (g_rot[:, :1] - gs).abs().max() < 1e-6
     assert (g_pose[:, :3] - G.rotation_matrix_to_angle_axis(gs.reshape(-1, 3, 3))).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize('IH,IW,dt', [(41, 30, torch.bfloat16), (41, 30, torch.float32), (21, 17, torch.float32), (9, 7, torch.bfloat16)])
+def test_tz_conv1_matches_conv2d(dev, IH, IW, dt):
+    """second convolution of the Tz head (whmr.py:420, Conv2d(64, 5, k7, s2), no bias) on the NHWC map, tokens [B, 5, OH*OW] like the reference's
+    reshape (whmr.py:571): four output pixels per wave; widths whose pixel count is not a multiple of four exercise the ragged last group"""
+    from whmr_amd import _lib as L
+    g = torch.Generator().manual_seed(IH * 100 + IW)
+    B = 3
+    x = torch.randn(B, IH, IW, 64, generator=g).to(dt)
+    w = torch.randn(5, 64, 7, 7, generator=g) * 0.05
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w, stride=2).reshape(B, 5, -1)
+    OH, OW = (IH - 7) // 2 + 1, (IW - 7) // 2 + 1
+    tok = torch.full((B, 5, OH * OW), float('nan'), device=dev)
+    L.tz_conv1(x.to(dev), w.permute(0, 2, 3, 1).reshape(5, 49, 64).contiguous().to(dev), tok)
+    assert ref.shape == tok.shape
+    assert _rel(tok.cpu(), ref) < 1e-5
