@@ -139,6 +139,7 @@ def build_workload(args, dev):
         red = None if use_graph else GradReducer(params, groups=[n.startswith('feature_extractor') for n, _ in named], always_bucket=args.always_bucket)
         if red is not None:
             red.attach(m.feature_extractor.backbone)          # the ViT node publishes its gradients block by block: buckets exchange under its backward
+        args.reducer = red
         rank = int(os.environ.get('RANK', '0'))
         inp = {k: v.to(dev) for k, v in synth.make_inputs(args.batch, 7 + rank).items()}
         a = (inp['x'], None, inp['center'], inp['scale'], inp['bbox_height'], inp['orig_shape'], inp['bbox_info'])
@@ -564,37 +565,144 @@ def launch_ranks(args, argv):
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
     import signal
     import threading
-    # own session = own process group: a hung rank (a collective that never completes, a wedged GPU) is ended by killing exactly that
-    # group after --rank-timeout, and the launcher exits non-zero instead of hanging the driver
+    # A hung rank (a collective that never completes, a wedged GPU) must not hang the driver: after
+    # --rank-timeout the launcher ends the whole tree and exits 124.  torch elastic starts every worker in its OWN session
+    # (SubprocessHandler: start_new_session=True), so killing the agent's process group reaches the agent only -- the ranks would survive as
+    # orphans that keep the GPUs and the inherited stdout pipe.  Hence: snapshot the agent's descendants, SIGTERM the agent (its handler tears
+    # its workers down), and after a grace period SIGKILL the agent and every descendant that is still alive.  The relay runs on a thread,
+    # so a pipe that a surviving process keeps open cannot block the launcher either.
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, start_new_session=True)
-    timed_out = []
+    found = []
 
-    def _kill():
-        timed_out.append(True)
+    def relay():                                # the child's stderr goes straight through, its stdout is filtered for THE line
         try:
-            os.killpg(proc.pid, signal.SIGKILL)
+            for out in proc.stdout:
+                if out.startswith('{') and '"metric"' in out:
+                    found.append(out.strip())
+                else:
+                    sys.stdout.write(out)
+        except ValueError:                      # pipe closed under the reader by the watchdog path
+            pass
+    reader = threading.Thread(target=relay, daemon=True)
+    reader.start()
+    deadline = time.monotonic() + args.rank_timeout
+    while proc.poll() is None and time.monotonic() < deadline:
+        time.sleep(0.1)
+    if proc.poll() is None:
+        tree = process_tree(proc.pid)
+        try:
+            proc.send_signal(signal.SIGTERM)
         except ProcessLookupError:
             pass
-    watchdog = threading.Timer(args.rank_timeout, _kill)
-    watchdog.daemon = True
-    watchdog.start()
-    line = None
-    for out in proc.stdout:                     # relay: the child's stderr goes straight through, its stdout is filtered for THE line
-        if out.startswith('{') and '"metric"' in out:
-            line = out.strip()
-        else:
-            sys.stdout.write(out)
-    rc = proc.wait()
-    watchdog.cancel()
-    if timed_out:
-        print('bench.py launcher: the %d ranks did not finish within %.0f s and were killed' % (args.gpus, args.rank_timeout), file=sys.stderr)
+        grace = time.monotonic() + min(10.0, max(2.0, 0.2 * args.rank_timeout))
+        while time.monotonic() < grace and (proc.poll() is None or any(alive(q) for q in tree)):
+            time.sleep(0.1)
+        for q in set(tree) | set(process_tree(proc.pid)) | {proc.pid}:
+            try:
+                os.kill(q, signal.SIGKILL)
+            except (ProcessLookupError, PermissionError):
+                pass
+        try:
+            proc.wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            pass
+        try:
+            proc.stdout.close()
+        except Exception:                       # noqa: BLE001
+            pass
+        reader.join(timeout=2)
+        print('bench.py launcher: the %d ranks did not finish within %.0f s and were killed (agent + %d descendants)'
+              % (args.gpus, args.rank_timeout, len(tree)), file=sys.stderr)
         return 124
+    rc = proc.wait()
+    reader.join(timeout=10)
+    line = found[-1] if found else None
     if line is not None:
         print(line, flush=True)
     elif rc == 0:
         rc = 1
         print('bench.py launcher: the %d ranks exited 0 without printing a result line' % args.gpus, file=sys.stderr)
     return rc
+
+
+def process_tree(pid):
+    """pids of every descendant of ``pid`` (children of children ...), whatever session / process group they moved to"""
+    try:
+        import psutil
+        return [c.pid for c in psutil.Process(pid).children(recursive=True)]
+    except Exception:                           # noqa: BLE001   (psutil missing or the process already gone: walk /proc)
+        kids = {}
+        for d in os.listdir('/proc'):
+            if d.isdigit():
+                try:
+                    with open('/proc/%s/stat' % d) as f:
+                        ppid = int(f.read().rsplit(')', 1)[1].split()[1])
+                    kids.setdefault(ppid, []).append(int(d))
+                except (OSError, ValueError, IndexError):
+                    pass
+        out, todo = [], [pid]
+        while todo:
+            for c in kids.get(todo.pop(), []):
+                out.append(c)
+                todo.append(c)
+        return out
+
+
+def alive(pid):
+    try:
+        with open('/proc/%d/stat' % pid) as f:
+            return f.read().rsplit(')', 1)[1].split()[0] != 'Z'
+    except OSError:
+        return False
+
+
+def device_record(rank, local, dev, dry):
+    """what this rank computes on -- `device_id` must be unique over the ranks of a run"""
+    rec = {'rank': rank, 'local_rank': local, 'pid': os.getpid(), 'visible_devices': os.environ.get('HIP_VISIBLE_DEVICES', os.environ.get('ROCR_VISIBLE_DEVICES'))}
+    if dry:
+        rec.update(device='cpu', device_id='cpu:%d' % (0 if os.environ.get('WHMR_BENCH_DRYRUN_SAME_DEVICE') else rank))     # (test hook: a clashing map)
+        return rec
+    pr = torch.cuda.get_device_properties(dev)
+    ident = None
+    for attr in ('uuid', 'pci_bus_id'):                   # whichever this torch build exposes; the index alone cannot see a remapped visibility list
+        v = getattr(pr, attr, None)
+        if v is not None and str(v) not in ('', '0'):
+            ident = '%s=%s' % (attr, v)
+            break
+    rec.update(device='cuda:%d' % dev.index, name=pr.name, arch=getattr(pr, 'gcnArchName', None), compute_units=pr.multi_processor_count,
+               device_id='%s/%s/idx%d' % (rec['visible_devices'], ident, dev.index))
+    return rec
+
+
+def multi_rank_report(args, dist, world, dt_own, rank_map, red, dry):
+    """What explains an N > 1 number: every rank's own step time (a slow rank vs a slow exchange), the communicator's library
+    version, the rank -> device map, and for the training step what the gradient exchange moved and how much of it finish() had to WAIT for."""
+    rows = [None] * world
+    own = {'ms_per_step': dt_own / args.steps * 1e3}
+    if red is not None:
+        waits = red.exposed_wait_ms()
+        own.update(exposed_exchange_wait_ms_mean=sum(waits) / max(len(waits), 1), exposed_exchange_wait_ms_max=max(waits) if waits else 0.0,
+                   collectives_per_step=red.stats['collectives'] / max(args.steps, 1), bytes_exchanged_per_step=red.stats['bytes_exchanged'] / max(args.steps, 1),
+                   buckets=len(red.buckets), bucket_bytes=[b['numel'] * 4 for b in red.buckets], unused_parameters=len(red.skipped))
+    dist.all_gather_object(rows, own)
+    ms = [r['ms_per_step'] for r in rows]
+    rep = {'per_rank_ms_per_step': {'min': min(ms), 'max': max(ms), 'all': ms},
+           'ranks': rank_map,
+           'backend': 'gloo (dryrun)' if dry else 'nccl = RCCL',
+           'note': 'per_rank_ms_per_step: each rank\'s own time over the timed steps BEFORE the closing barrier (the line\'s ms_per_step is the max over ranks '
+                   'incl. the barrier); launched with one process per GPU, fresh child of the launcher, rendezvous on 127.0.0.1'}
+    if not dry:
+        try:
+            rep['rccl_version'] = '.'.join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:                           # noqa: BLE001
+            rep['rccl_version'] = 'unavailable (%s)' % type(e).__name__
+    if red is not None:
+        rep['gradient_exchange'] = {
+            'per_rank': [{k: r[k] for k in r if k != 'ms_per_step'} for r in rows],
+            'note': 'exposed_exchange_wait_ms = time inside GradReducer.finish() per step (event pair on the compute stream around the waits for the '
+                    'exchange stream, straggler packs and the 1/world scaling): the part of the all-reduce the backward did not hide; bytes = fp32 '
+                    'gradient bytes handed to all_reduce per step and rank (a ring moves 2 (N-1)/N of that over each link)'}
+    return rep
 
 
 def count_ranks(dist, dev):
@@ -611,6 +719,10 @@ def dryrun_workload(args, dev):
     (incl. a parameter that never receives a gradient, as global_orient / cam_model in W-HMR) so the N > 1 bookkeeping of the entry point is
     covered by a gloo test.  Nothing here is the product path and its line is labelled "dryrun"."""
     torch.manual_seed(0)
+    if os.environ.get('WHMR_BENCH_DRYRUN_HANG'):         # launcher test: ranks that are up (rendezvous done) and then never finish a step
+        def hang():
+            time.sleep(3600)
+        return hang, None, torch.zeros(args.batch, 32), (1, 32)
     net = torch.nn.Sequential(torch.nn.Linear(32, 64), torch.nn.BatchNorm1d(64), torch.nn.GELU(), torch.nn.Linear(64, 8))
     unused = torch.nn.Linear(8, 8)               # registered with the reducer, never in the graph
     rank = int(os.environ.get('RANK', '0'))
@@ -632,6 +744,7 @@ def dryrun_workload(args, dev):
         opt.step()
         return loss
     args.dry_state = (net, unused, red)
+    args.reducer = red
     return step, None, x, (1, 32)
 
 
@@ -663,6 +776,16 @@ def main(argv=None):
         else:
             dist.init_process_group('nccl', device_id=dev, timeout=tmo)          # "nccl" IS RCCL on ROCm
 
+    # who runs where: one record per rank, gathered over the communicator; two ranks on ONE device is a launch error (a wrong LOCAL_RANK /
+    # HIP_VISIBLE_DEVICES map would "scale" by time-sharing a GPU), refused before anything is timed
+    rank_map = [device_record(rank, local, dev, dry)]
+    if dist is not None:
+        rank_map = [None] * world
+        dist.all_gather_object(rank_map, device_record(rank, local, dev, dry))
+        ids = [r['device_id'] for r in rank_map]
+        if len(set(ids)) != len(ids):
+            raise SystemExit('bench.py: two ranks share a device: %s' % json.dumps(rank_map))
+
     def sync():
         if not dry:
             torch.cuda.synchronize()
@@ -685,12 +808,20 @@ def main(argv=None):
     with (torch.enable_grad() if training else torch.no_grad()):
         for _ in range(args.warmup):
             step()
+        red = getattr(args, 'reducer', None)
         barrier()
+        if red is not None:
+            red.timing, red._wait_marks = True, []
+            red.stats = {k: 0 for k in red.stats}
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
+        sync()
+        dt_own = time.perf_counter() - t0                # this rank's own time, before it waits for the others
         barrier()
         dt = time.perf_counter() - t0
+        if red is not None:
+            red.timing = False
         if L is not None:
             # dominant-kernel timing: one instrumented step, HIP events around every GEMM launch on the launch stream
             L.PROFILE = []
@@ -699,6 +830,9 @@ def main(argv=None):
             prof, L.PROFILE = L.PROFILE, None
     dt = reduce_max_time(dt, dist, dev)
     n_ranks = count_ranks(dist, dev)
+    multi = None
+    if dist is not None:
+        multi = multi_rank_report(args, dist, world, dt_own, rank_map, getattr(args, 'reducer', None), dry)
 
     fp32_mode = args.numerics == 'fp32'                               # parity numerics: exact-f32 MFMA (v_mfma_f32_32x32x2_f32) GEMMs
     x3_mode = args.numerics == 'bf16x3'                               # parity-grade numerics on the bf16 pipes: three bf16 MFMAs per product
@@ -733,6 +867,8 @@ def main(argv=None):
         }
         if args.ref_1gpu:
             res['efficiency_vs_1gpu'] = value / (n_ranks * args.ref_1gpu)
+        if multi is not None:
+            res['multi_gpu'] = multi
         if not dry:
             res['model_tflops'] = VIT_FLOP_PER_IMG[args.workload] * n_ranks * args.batch * args.steps / dt / 1e12
             res['roofline'] = {'bound': 'mfma', 'kernel': ('fp32 (exact-f32 MFMA) GEMM launches of one step (%d: gemm_f32_big_kernel for large M, the 64x64 / skinny kernels elsewhere)' % len(gemm)) if fp32_mode else

@@ -364,6 +364,126 @@ def test_bench_launcher_kills_hung_ranks_and_exits_nonzero():
     assert time.time() - t0 < 60
 
 
+def test_bench_launcher_ends_ranks_that_really_hang():
+    """torch elastic starts every worker in its own session, so killing the agent's process group leaves the ranks alive as
+    orphans that hold the GPUs and the stdout pipe.  Here the two ranks are UP (rendezvous done, step running) and never finish: the launcher
+    must return 124 within timeout + grace, and no process of the tree may survive it."""
+    import subprocess
+    import sys
+    import time
+    import psutil
+    marker = 'whmr-hang-%d' % os.getpid()
+    env = dict(os.environ, WHMR_BENCH_DRYRUN_HANG=marker)
+    env.pop('WORLD_SIZE', None)
+    env.pop('RANK', None)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dryrun-cpu', '--rank-timeout', '25', '--steps', '1', '--warmup', '0'],
+                       capture_output=True, text=True, timeout=180, env=env)
+    took = time.time() - t0
+    assert r.returncode == 124, (r.returncode, r.stdout[-400:], r.stderr[-800:])
+    assert 'were killed' in r.stderr and '"metric"' not in r.stdout
+    assert 24 < took < 60, took                  # the ranks were running when the watchdog fired, and the launcher did not wait for them
+    time.sleep(0.5)
+    left = []
+    for q in psutil.process_iter(['pid', 'environ', 'cmdline', 'status']):
+        try:
+            if (q.info['environ'] or {}).get('WHMR_BENCH_DRYRUN_HANG') == marker and q.info['status'] != psutil.STATUS_ZOMBIE:
+                left.append((q.info['pid'], q.info['cmdline']))
+        except (psutil.NoSuchProcess, psutil.AccessDenied):
+            pass
+    assert not left, left
+
+
+def test_bench_multi_gpu_block_explains_the_run():
+    """at world > 1 the line carries what explains a scaling curve -- every rank's own step time, the rank -> device map (unique
+    devices), the backend, and for the training step the gradient exchange (bytes, collectives, buckets, exposed wait of finish())."""
+    out = _run_bench('--gpus', '4', '--steps', '2', '--warmup', '1', '--workload', 'whmr_train')
+    assert out['n_gpus'] == 4 and out['config']['global_batch'] == 64
+    mg = out['multi_gpu']
+    ms = mg['per_rank_ms_per_step']
+    assert len(ms['all']) == 4 and ms['min'] <= ms['max'] <= out['ms_per_step'] * 1.0001 + 1e-9
+    assert sorted(r['rank'] for r in mg['ranks']) == [0, 1, 2, 3] and len({r['device_id'] for r in mg['ranks']}) == 4
+    assert len({r['pid'] for r in mg['ranks']}) == 4
+    ge = mg['gradient_exchange']['per_rank']
+    assert len(ge) == 4
+    n_used = (32 * 64 + 64) + 2 * 64 + (64 * 8 + 8)                 # Linear, BatchNorm affine, Linear of the stand-in net; the unused Linear(8, 8) left the buckets
+    for r in ge:
+        assert r['unused_parameters'] == 2 and r['buckets'] >= 2
+        assert sum(r['bucket_bytes']) == 4 * n_used
+        # step 1 of the timed region still carries the two unused parameters' zeros (the census runs at the first finish() = the warm-up step)
+        assert abs(r['bytes_exchanged_per_step'] - 4 * n_used) < 1e-6
+        assert r['collectives_per_step'] == r['buckets']
+        assert r['exposed_exchange_wait_ms_max'] >= r['exposed_exchange_wait_ms_mean'] >= 0.0
+    # forward workloads: no exchange block, still the rank map; ViT-L at 32 crops per rank = BASELINE configs[4]'s per-GPU share (bookkeeping only here)
+    fw = _run_bench('--gpus', '2', '--steps', '2', '--warmup', '0', '--workload', 'vitl256x192', '--batch', '32')
+    assert fw['n_gpus'] == 2 and fw['config']['global_batch'] == 64 and 'gradient_exchange' not in fw['multi_gpu']
+    assert abs(fw['value'] - 2 * 32 * 2 / (fw['ms_per_step'] * 2e-3)) < 1e-6 * fw['value']
+
+
+def test_bench_refuses_two_ranks_on_one_device():
+    """two ranks that report the same device id (a wrong LOCAL_RANK -> device map) end the run before anything is timed"""
+    import subprocess
+    import sys
+    env = dict(os.environ, WHMR_BENCH_DRYRUN_SAME_DEVICE='1')
+    env.pop('WORLD_SIZE', None)
+    env.pop('RANK', None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dryrun-cpu', '--steps', '1', '--warmup', '0', '--rank-timeout', '120'],
+                       capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode != 0 and '"metric"' not in r.stdout
+    assert 'two ranks share a device' in r.stderr
+
+
+def test_grad_reducer_four_ranks_unequal_parameter_use(tmp_path):
+    """world 4 (gloo): the ranks use DIFFERENT parameters in some steps (a branch only even ranks take, as a loss term that is absent from part of
+    a batch).  The static-graph contract: the first step's census must agree -- so step 0 uses everything everywhere -- and later a locally missing
+    gradient travels as zeros; the result equals the mean over the four ranks of the per-rank gradients (zeros where unused)."""
+    import json
+    import subprocess
+    import sys
+    script = tmp_path / 'w4.py'
+    script.write_text("""
+import json, os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from whmr_amd.parallel import GradReducer
+dist.init_process_group('gloo')
+rank, world = dist.get_rank(), dist.get_world_size()
+torch.manual_seed(0)
+trunk, head_a, head_b = torch.nn.Linear(6, 6), torch.nn.Linear(6, 3), torch.nn.Linear(6, 2)
+params = list(trunk.parameters()) + list(head_a.parameters()) + list(head_b.parameters())
+red = GradReducer(params, bucket_bytes=96, groups=[0, 0, 1, 1, 2, 2])
+worst = 0.0
+for step in range(3):
+    for p in params:
+        p.grad = None
+    xs = [torch.randn(5, 6, generator=torch.Generator().manual_seed(100 * step + r)) for r in range(world)]
+    use_b = lambda r: step == 0 or r %% 2 == 0          # head_b: everywhere in step 0, on the even ranks afterwards
+    def loss_of(r):
+        h = trunk(xs[r])
+        l = head_a(h).pow(2).mean()
+        return l + head_b(h).pow(2).mean() if use_b(r) else l
+    # reference: mean over ranks of the single-process gradients (a parameter a rank did not use contributes zeros)
+    ref = [torch.zeros_like(p) for p in params]
+    for r in range(world):
+        gs = torch.autograd.grad(loss_of(r), params, allow_unused=True)
+        for acc, g in zip(ref, gs):
+            if g is not None:
+                acc += g / world
+    loss_of(rank).backward()
+    red.finish()
+    for p, g in zip(params, ref):
+        worst = max(worst, float((p.grad - g).abs().max()))
+if rank == 0:
+    print(json.dumps({'err': worst, 'buckets': len(red.buckets), 'collectives': red.stats['collectives'], 'skipped': len(red.skipped)}))
+dist.destroy_process_group()
+""" % ROOT)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1')
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=4', '--master-addr', '127.0.0.1',
+                          '--master-port', '29547', str(script)], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2500:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    assert res['err'] < 1e-6 and res['buckets'] == 4 and res['skipped'] == 0 and res['collectives'] == 12     # (96-byte buckets: the trunk's weight and bias travel apart)
+
+
 def test_split_bf16_operand_pairs_and_elementwise_metric():
     """host side of the bf16x3 numerics: a hi / lo pair carries >= 16 significand bits, the K-concatenated weight layout pairs up with the
     activation layout ([x_hi | x_lo | x_hi] . [W_hi | W_hi | W_lo] = x_hi W_hi + x_lo W_hi + x_hi W_lo), and the element-wise parity metric

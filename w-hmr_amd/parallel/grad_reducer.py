@@ -52,6 +52,11 @@ class GradReducer:
         self._fired = set()                      # id(param) of the gradients that arrived since the last finish()
         self._published = set()                  # ... of those, the ones delivered through publish() (their accumulate hook is ignored)
         self._stream = None
+        # bookkeeping for a self-explaining N > 1 benchmark line (bench.py): what was exchanged, and -- with `timing` on -- how long finish() kept
+        # the compute stream waiting for the exchange stream (the EXPOSED part of the all-reduce; the rest ran under the backward)
+        self.timing = False
+        self.stats = {'finishes': 0, 'collectives': 0, 'bytes_exchanged': 0}
+        self._wait_marks = []
         self._build(self.params, self.groups)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
 
@@ -71,6 +76,7 @@ class GradReducer:
             cur_g = g
         if cur:
             self._close(cur)
+        self._next = 0                           # index of the next bucket whose collective may start (_launch_ready)
         self._slot = {}                          # id(param) -> (bucket, index in bucket); tensors must not be compared with ==
         for b in self.buckets:
             for i, p in enumerate(b['params']):
@@ -109,7 +115,8 @@ class GradReducer:
             b['streams'].add(torch.cuda.current_stream(p.grad.device))
         b['pending'] -= 1
         if b['pending'] == 0:
-            self._pack_and_launch(b)
+            self._pack(b)
+            self._launch_ready()
 
     def publish(self, p, grad):
         """Early delivery from INSIDE an autograd node: the W-HMR backbone is one node (ViTFn), so the hooks above would see all of its ~150
@@ -131,9 +138,22 @@ class GradReducer:
         module.grad_sink = self.publish
         return self
 
-    def _pack_and_launch(self, b):
+    def _launch_ready(self):
+        """Collectives start in BUCKET ORDER on every rank: a packed bucket waits until all buckets before it have been launched.  With the same
+        parameters used on every rank the buckets also fill in this order and nothing waits; when a rank does NOT produce some gradient in a step
+        (its bucket is only completed, with zeros, by finish()) the other ranks' later buckets must not overtake it -- the ranks would issue
+        their all-reduces in different orders (gloo aborts on the size mismatch, RCCL would pair unrelated buffers or hang)."""
+        while self._next < len(self.buckets):
+            b = self.buckets[self._next]
+            if b['flat'] is None and not b.get('void'):
+                return
+            if not b.get('void'):
+                self._launch(b)
+            self._next += 1
+
+    def _pack(self, b):
         # the bucket's last gradient has arrived: ONE multi-tensor copy packs all of them (a copy per hook was ~225 small launches
-        # per step: 1.3 ms of the batch-64 W-HMR step), then the exchange starts.  Locally missing gradients travel as zeros.
+        # per step: 1.3 ms of the batch-64 W-HMR step), then the exchange may start.  Locally missing gradients travel as zeros.
         have = [(q, off) for q, off in zip(b['params'], b['offsets']) if q.grad is not None]
         dev = have[0][0].grad.device if have else b['params'][0].device
         full = len(have) == len(b['params'])
@@ -149,13 +169,14 @@ class GradReducer:
         if have:
             views = [flat[off:off + q.numel()].view_as(q) for q, off in have]
             torch._foreach_copy_(views, [q.grad for q, _ in have])
-        self._launch(b)
 
     def _launch(self, b):
         if self.world == 1 and not (self.always_bucket and dist.is_initialized()):
             return                               # (always_bucket on an initialised one-rank group still runs the collective: the hardware smoke of
                                                  #  the exchange-stream choreography on a 1-GPU box, bench.py --always-bucket)
         flat = b['flat']
+        self.stats['collectives'] += 1
+        self.stats['bytes_exchanged'] += flat.numel() * 4
         if flat.is_cuda:
             # the exchange runs on a side stream so that the rest of the backward keeps the compute stream busy
             if self._stream is None:
@@ -201,11 +222,17 @@ class GradReducer:
                 if not used[i]:
                     self.skipped.append(p)
                     self._skipped_ids.add(id(p))
+        self.stats['finishes'] += 1
+        mark = self._mark() if self.timing else None
         for b in self.buckets:
             if b['flat'] is None:
                 if all(id(p) in self._skipped_ids for p in b['params']):
-                    continue                                     # nothing but unused parameters: no exchange at all
-                self._pack_and_launch(b)                         # stragglers: missing gradients travel as zeros (same on every rank)
+                    b['void'] = True                             # nothing but unused parameters: no exchange at all
+                else:
+                    self._pack(b)                                # stragglers: missing gradients travel as zeros (same on every rank)
+            self._launch_ready()
+            if b.get('void'):
+                continue
             self._wait(b)
             if self.average and self.world > 1:
                 b['flat'].div_(self.world)
@@ -213,9 +240,13 @@ class GradReducer:
                 if id(p) not in self._skipped_ids:               # unused everywhere: .grad stays None, as under DDP
                     p.grad = b['flat'][off:off + p.numel()].view_as(p)
             b['pending'], b['work'] = len(b['params']), None
+        if mark is not None:
+            self._wait_marks.append((mark, self._mark()))
         # the flat buffers now back the gradients: allocate fresh ones on the next step's first hook
         for b in self.buckets:
             b['flat'] = None
+            b['void'] = False
+        self._next = 0
         self._fired.clear()
         self._published.clear()
         if used is not None and self.skipped:                    # from the next step on the buckets hold used parameters only
@@ -223,6 +254,28 @@ class GradReducer:
             self.groups = [self.groups[i] for i in keep] if self.groups is not None else None
             self.params = [self.params[i] for i in keep]
             self._build(self.params, self.groups)
+
+    def _mark(self):
+        dev = next((p.device for p in self.params), torch.device('cpu'))
+        if dev.type == 'cuda':
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream(dev))
+            return ev
+        import time
+        return time.perf_counter()
+
+    def exposed_wait_ms(self):
+        """Per finish() since `timing` was switched on: milliseconds the compute stream (CPU: the host) spent inside finish() -- straggler packs,
+        the waits for the exchange stream, the 1/world scaling -- i.e. the part of the exchange the backward did NOT hide.  Synchronises."""
+        out = []
+        for a, b in self._wait_marks:
+            if isinstance(a, float):
+                out.append((b - a) * 1e3)
+            else:
+                b.synchronize()
+                out.append(a.elapsed_time(b))
+        self._wait_marks = []
+        return out
 
     def remove(self):
         for h in self._hooks:
