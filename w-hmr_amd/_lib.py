@@ -169,8 +169,6 @@ def lib():
             l.whmr_gemm_blk_set_tile(4, int(os.environ['WHMR_BLK_SCHED']))
         if os.environ.get('WHMR_BLK_MFMA'):          # A/B switch: 32 = the bf16 blocked GEMM on v_mfma_f32_32x32x16_bf16 (default 16x16x32), tools/lab/mfma16_ab.sh
             l.whmr_gemm_blk_set_tile(5, int(os.environ['WHMR_BLK_MFMA']))
-        if os.environ.get('WHMR_BLK_RES_LEAD'):      # A/B: half K tiles between the residual ring's last in-loop request and the end of the main loop (tools/r4_ring_ab.sh)
-            l.whmr_gemm_blk_set_tile(6, int(os.environ['WHMR_BLK_RES_LEAD']))
     return _lib
 
 

@@ -50,7 +50,6 @@ extern "C" int whmr_gemm_blk_tile(const whmr_gemm_blk_desc* pp, int tile, void* 
 static int g_blk_force[4] = {0, 0, 0, 0};                   // whmr_set_option keys 110..113: tile for N = 2304 / (768, K <= 1024) / 3072 / (768, K > 1024)
 extern "C" int whmr_gemm_blk_set_tile(int slot, int tile) {
     if (slot == 4) { g_blk_sched = tile; return 0; }
-    if (slot == 6) { g_blk16_res_lead = tile < 0 ? 0 : tile; return 0; }   // A/B: lead (half K tiles) of the residual ring's in-loop fill
     if (slot == 5) { g_blk_mfma32 = tile == 32; return 0; }          // A/B: MFMA shape of the bf16 kernel (16 = default, 32)                 // A/B: main-loop schedule (0 two barriers per half tile, 1 one barrier)
     if (slot < 0 || slot > 3) return (int)hipErrorInvalidValue;
     g_blk_force[slot] = tile;

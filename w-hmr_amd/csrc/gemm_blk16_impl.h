@@ -33,32 +33,6 @@ template <int OFF> __device__ __forceinline__ bf16x8_t b16_lds_read128(uint32_t 
     return v;
 }
 
-// One chunk of the residual ring (fp32 epilogue, epi 2): 4 x 16 B per lane, hidden from hipcc's waitcnt bookkeeping and consumed behind hand-counted
-// vmcnt waits (vmcnt retires in order on gfx9, loads and stores alike).  Address = wave-uniform 64-bit base (SGPR pair) + per-lane 32-bit offset.
-// The destinations are "+v": a ring slot lives in ONE set of registers from the kernel's first instruction to its last use.  The in-loop request is
-// conditional on a wave-uniform selector, and that test sits INSIDE the asm statement: as a C++ `if` around the statement it becomes a phi of the
-// old and the new value, which hipcc reconciles with v_mov copies of registers whose data is still in flight.
-__device__ __forceinline__ void b16_res_chunk(f32x4_t (&r)[4], uint32_t loff, uint64_t base) {
-    asm volatile("global_load_dwordx4 %0, %4, %5\n\t"
-                 "global_load_dwordx4 %1, %4, %5 offset:512\n\t"
-                 "global_load_dwordx4 %2, %4, %5 offset:256\n\t"
-                 "global_load_dwordx4 %3, %4, %5 offset:768"
-                 : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "v"(loff), "s"(base) : "memory");
-}
-template <int WANT> __device__ __forceinline__ void b16_res_chunk_if(f32x4_t (&r)[4], uint32_t loff, uint64_t base, int sel) {
-    asm volatile("s_cmp_lg_u32 %6, %7\n\t"
-                 "s_cbranch_scc1 1f\n\t"
-                 "global_load_dwordx4 %0, %4, %5\n\t"
-                 "global_load_dwordx4 %1, %4, %5 offset:512\n\t"
-                 "global_load_dwordx4 %2, %4, %5 offset:256\n\t"
-                 "global_load_dwordx4 %3, %4, %5 offset:768\n"
-                 "1:"
-                 : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "v"(loff), "s"(base), "s"(sel), "n"(WANT) : "memory", "scc");
-}
-template <int I, int N, class F> __device__ __forceinline__ void b16_static_for(F&& f) {
-    if constexpr (I < N) { f(std::integral_constant<int, I>{}); b16_static_for<I + 1, N>(f); }
-}
-
 template <int MI0, int MI1>
 struct blk16_cfg {
     static constexpr int MB = MI0 + MI1;                 // A row blocks (32 rows) per tile
@@ -70,14 +44,11 @@ struct blk16_cfg {
     static constexpr int STAT_OFF = BIAS_OFF + 2048;     // LayerNorm folding: [BM][4][2] floats -- row statistics (consumer) / per-wave-column partial sums (producer)
     static constexpr int LDS = 4 * SLOT + 2048 + BM * 32;
     static constexpr int MIMAX = MI0 > MI1 ? MI0 : MI1;
-    // residual ring of the fp32 (epi 2) epilogue: chunks of 4 x 16 B per lane = one (row block, column block) pair; as many as the tile's
-    // register budget allows next to accumulators + fragments (kernel VGPRs without the ring: MI 2: 109, 3: 158, 4: 198, 5: 242)
-    static constexpr int RNB = MIMAX <= 2 ? 4 : MIMAX == 3 ? 3 : MIMAX == 4 ? 2 : 1;
 };
 
 // SCHED 1: one barrier per half tile, groups in opposite order within a slot;  SCHED 0: two barriers per half tile (MEM | MFMA rendezvous)
 template <int MI0, int MI1, int EPI, int SCHED>
-__global__ __launch_bounds__(512, 2) void gemm_blk16_kernel(const whmr_gemm_blk_desc p, const int res_lead) {
+__global__ __launch_bounds__(512, 2) void gemm_blk16_kernel(const whmr_gemm_blk_desc p) {
     using cfg = blk16_cfg<MI0, MI1>;
     constexpr int MB = cfg::MB, BM = cfg::BM, BN = cfg::BN, SLOT = cfg::SLOT, HU = cfg::HU, HUPW = cfg::HUPW, NJ = 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -136,43 +107,11 @@ __global__ __launch_bounds__(512, 2) void gemm_blk16_kernel(const whmr_gemm_blk_
                 __builtin_amdgcn_global_load_lds((gbl16_void_t*)(hsrc[i] + (size_t)h * 2048), (lds16_void_t*)(smem + slot * SLOT + (wave + 8 * i) * 1024), 16, 0, 0);
         }
     };
-    // own DMA groups still allowed in flight: `young` groups of (HUPW or HUPW - 1) loads; `extra`: one chunk (4 loads) of the residual ring is
-    // younger than the awaited group as well (epi 2, below)
-    auto wait_dma = [&](int young, bool extra = false) {
-        if (!extra) {
-            if (young >= 2) { if (dma_full) b16_wait_vmcnt<2 * HUPW>(); else b16_wait_vmcnt<2 * (HUPW - 1)>(); }
-            else if (young == 1) { if (dma_full) b16_wait_vmcnt<HUPW>(); else b16_wait_vmcnt<HUPW - 1>(); }
-            else b16_wait_vmcnt<0>();
-        } else {
-            if (young >= 2) { if (dma_full) b16_wait_vmcnt<2 * HUPW + 4>(); else b16_wait_vmcnt<2 * (HUPW - 1) + 4>(); }
-            else if (young == 1) { if (dma_full) b16_wait_vmcnt<HUPW + 4>(); else b16_wait_vmcnt<HUPW - 1 + 4>(); }
-            else b16_wait_vmcnt<4>();
-        }
-    };
-
-    // ---- residual ring (epi 2: fp32 out = acc + bias + blocked residual).  The epilogue used to load 2 x 16 B per lane, wait, add, store, 12-20
-    // times in a row: 16 KB in flight per CU, ~4 TB/s over the whole launch (proj / fc2 are HBM-side: 115 MB per launch).  Now the residual
-    // tile of a wave travels as CHUNKS (one row block x one 32-column block = 4 loads per lane) through a ring of RNB register chunks: the first
-    // ring-full is requested under the main loop -- one chunk every third half tile, so that every DMA wait of that window sees exactly one chunk
-    // younger than the group it awaits (vmcnt retires in order) -- and each later chunk as soon as its slot has been consumed.
-    constexpr int RNB = (EPI == 2) ? cfg::RNB : 1;
-    const bool ring_in_loop = H >= 3 * RNB;
-    f32x4_t rv[RNB][4];                                                // [slot][2 a + b]: rows 16 a + l15, fp32 unit 2 g + b of the column block
-    const int rb0 = (m0 >> 5) + (wm == 0 ? 0 : MI0);                   // first row block of this wave
-    const int NC4 = p.N >> 2;
-    uint32_t res_loff = 0;
-    if constexpr (EPI == 2) {
-#pragma unroll
-        for (int s = 0; s < RNB; ++s)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) rv[s][e] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        res_loff = 2 * g * 512 + l15 * 16;
-    }
-    // wave-uniform part of the address of chunk (row block i, column block j) of this wave; chunk c of a wave with MIW row blocks = (j = c / MIW, i = c % MIW)
-    auto res_base = [&](int i, int j) -> uint64_t {
-        int rb = rb0 + i;
-        if (rb > rb_last) rb = rb_last;                                // M tail: a valid address, the values are not used
-        return (uint64_t)(uintptr_t)p.res + ((uint64_t)rb * NC4 + ((n0 + wn * 64) >> 2)) * 512 + j * 4096;
+    // own DMA groups still allowed in flight: `young` groups of (HUPW or HUPW - 1) loads
+    auto wait_dma = [&](int young) {
+        if (young >= 2) { if (dma_full) b16_wait_vmcnt<2 * HUPW>(); else b16_wait_vmcnt<2 * (HUPW - 1)>(); }
+        else if (young == 1) { if (dma_full) b16_wait_vmcnt<HUPW>(); else b16_wait_vmcnt<HUPW - 1>(); }
+        else b16_wait_vmcnt<0>();
     };
 
     // acc[i][j][mh][nh]: rows 16 mh + l15 of row block i, columns 8 g + 4 nh + (0..3) of column block j
@@ -197,9 +136,6 @@ __global__ __launch_bounds__(512, 2) void gemm_blk16_kernel(const whmr_gemm_blk_
     // (hazards: gemm_blk_impl.h -- the ring and the order of its accesses are unchanged)
     auto main_loop = [&](auto miw_tag) {
         constexpr int MIW = decltype(miw_tag)::value;
-        // first MEM phase of the ring fill: the last chunk goes out `res_lead` half tiles before the end of the loop (clamped to the loop)
-        // (loops shorter than the fill window -- K < 96 RNB -- fill the ring in front of the epilogue instead: xr0 = H is never reached)
-        const int xr0 = [&] { constexpr int NBE = RNB < 2 * MIW ? RNB : 2 * MIW; const int v = H - 3 * (NBE - 1) - 1 - res_lead; return !ring_in_loop ? H : v > 0 ? v : 0; }();
         const uint32_t a_b = lds0 + (wm * MI0) * 2048 + g * 512 + l15 * 16;
         const uint32_t b_b = lds0 + (MB + wn * 2) * 2048 + g * 512 + l15 * 16;
         bf16x8_t fa[MIW][2], fb[NJ][2];                    // [.][mh] rows 16 mh.. of the A block;  [.][nh] LDS slots 16 nh.. of the W block
@@ -218,18 +154,7 @@ __global__ __launch_bounds__(512, 2) void gemm_blk16_kernel(const whmr_gemm_blk_
             if constexpr (MIW > 3) fa[3][1] = b16_lds_read128<6144 + 256>(sa);
             if constexpr (MIW > 4) fa[4][1] = b16_lds_read128<8192 + 256>(sa);
             if (x + 3 < H) hstage(x + 3);
-            bool extra = false;
-            if constexpr (EPI == 2) {
-                // ring fill: chunk k right behind the DMA group of MEM(xr0 + 3 k); it stays younger than the awaited group for three waits
-                constexpr int NBE = RNB < 2 * MIW ? RNB : 2 * MIW;
-                const int d = __builtin_amdgcn_readfirstlane(x - xr0);      // (an SGPR for the asm's s_cmp, whatever hipcc keeps x in)
-                extra = d >= 0 && d < 3 * NBE;
-                b16_static_for<0, NBE>([&](auto k) {
-                    constexpr int K_ = decltype(k)::value;
-                    b16_res_chunk_if<3 * K_>(rv[K_], res_loff, res_base(K_ % MIW, K_ / MIW), d);
-                });
-            }
-            wait_dma(H - 2 - x, extra);                                // own share of half tile x + 1 has landed (x + 2, x + 3 may fly)
+            wait_dma(H - 2 - x);                                       // own share of half tile x + 1 has landed (x + 2, x + 3 may fly)
             b16_wait_lgkmcnt<0>();
             __builtin_amdgcn_sched_barrier(0);
         };
@@ -281,6 +206,7 @@ __global__ __launch_bounds__(512, 2) void gemm_blk16_kernel(const whmr_gemm_blk_
     // ---- epilogue: straight from the accumulators.  Lane (g, l15) owns rows 16 mh + l15 of its row blocks and the 8 consecutive columns
     // 8 g .. 8 g + 7 of each column block (nh = 0: the first four, nh = 1: the last four) = 16 bytes of bf16 unit g / two fp32 units 2 g, 2 g + 1.
     const int miw = wm == 0 ? MI0 : MI1;
+    const int rb0 = (m0 >> 5) + (wm == 0 ? 0 : MI0);                   // first row block of this wave
     const int rw0 = wm == 0 ? 0 : MI0 * 32;                           // its first row inside the tile
     const int nb0 = n0 + wn * 64;
     const float* sBias = (const float*)(smem + cfg::BIAS_OFF) + wn * 64;
@@ -337,6 +263,7 @@ __global__ __launch_bounds__(512, 2) void gemm_blk16_kernel(const whmr_gemm_blk_
             }
         }
     } else {
+        const int NC4 = p.N >> 2;
         const bool emit = p.xhat != nullptr;                            // also write bf16(C) as the next GEMM's operand + row partial sums
         float sx[cfg::MIMAX][2], sxx[cfg::MIMAX][2], sh[cfg::MIMAX][2];
 #pragma unroll
@@ -367,87 +294,48 @@ __global__ __launch_bounds__(512, 2) void gemm_blk16_kernel(const whmr_gemm_blk_
                 }
             }
         }
-        // one (row block i, column block j) pair of this wave: out = acc + bias + residual -> fp32 stream (+ bf16 operand copy and row sums when emitting);
-        // rr[2 a + b] = residual of rows 16 a + l15, fp32 unit 2 g + b
-        auto epi_pair = [&](int i, int j, const float4* bq, const f32x4_t* rr) {
-            const size_t off = ((size_t)(rb0 + i) * NC4 + ((nb0 + j * 32) >> 2) + 2 * g) * 512 + l15 * 16;
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                uint32_t pk[4];
+        for (int j = 0; j < NJ; ++j) {
+            float4 bq[2];
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const f32x4_t c = acc[i][j][a][b];
-                    const f32x4_t r = rr[2 * a + b];
-                    float4 o;
-                    o.x = c[0] + bq[b].x + r[0]; o.y = c[1] + bq[b].y + r[1];
-                    o.z = c[2] + bq[b].z + r[2]; o.w = c[3] + bq[b].w + r[3];
-                    *(float4*)((char*)p.C + off + b * 512 + a * 256) = o;
-                    if (emit) {
-                        // explicit order / explicit fma: every tile instantiation must produce the same bits for a row (batch-independence tests)
-                        o.x -= sh[i][a]; o.y -= sh[i][a]; o.z -= sh[i][a]; o.w -= sh[i][a];
-                        sx[i][a] += o.x; sx[i][a] += o.y; sx[i][a] += o.z; sx[i][a] += o.w;
-                        sxx[i][a] = fmaf(o.x, o.x, sxx[i][a]); sxx[i][a] = fmaf(o.y, o.y, sxx[i][a]);
-                        sxx[i][a] = fmaf(o.z, o.z, sxx[i][a]); sxx[i][a] = fmaf(o.w, o.w, sxx[i][a]);
-                        pk[2 * b] = pack_bf16x2(o.x, o.y); pk[2 * b + 1] = pack_bf16x2(o.z, o.w);
-                    }
-                }
-                if (emit)
-                    *(uint4*)((char*)p.xhat + ((size_t)(rb0 + i) * (p.N >> 3) + ((nb0 + j * 32) >> 3) + g) * 512 + (16 * a + l15) * 16) =
-                        make_uint4(pk[0], pk[1], pk[2], pk[3]);
-            }
-        };
-        if constexpr (EPI == 2) {
-            // ---- ring epilogue.  VMEM order of this wave from here on: [L_0 .. L_(NBE-1)] P_0 L_NBE P_1 L_(NBE+1) ... (L_c = the 4 loads of chunk
-            // c, P_c = its 4 fp32 stores + 2 bf16 stores when emitting).  Younger than L_c when P_c starts: min(NBE - 1, T - 1 - c) chunks of loads and
-            // min(NBE - 1, c) chunks of stores -- a compile-time vmcnt, valid only while every store is really issued (`full`: no row block of this
-            // wave lies behind the M tail); the tail waves wait for everything.
-            auto ring = [&](auto miw_tag) {
-                constexpr int MIW = decltype(miw_tag)::value;
-                constexpr int T = 2 * MIW, NBE = RNB < T ? RNB : T;
-                const bool full = rb0 + MIW - 1 <= rb_last;
-                b16_static_for<0, NBE>([&](auto k) {                    // short loops: the ring-full is requested here
-                    constexpr int K_ = decltype(k)::value;
-                    b16_res_chunk_if<0>(rv[K_], res_loff, res_base(K_ % MIW, K_ / MIW), __builtin_amdgcn_readfirstlane((int)ring_in_loop));
-                });
-                b16_static_for<0, T>([&](auto ct) {
-                    constexpr int c = decltype(ct)::value, i = c % MIW, j = c / MIW, slot = c % NBE;
-                    constexpr int nl = (NBE - 1 < T - 1 - c) ? NBE - 1 : T - 1 - c, np = (NBE - 1 < c) ? NBE - 1 : c;
-                    float4 bq[2];
+            for (int b = 0; b < 2; ++b) bq[b] = *(const float4*)(sBias + j * 32 + 8 * g + 4 * b);
 #pragma unroll
-                    for (int b = 0; b < 2; ++b) bq[b] = *(const float4*)(sBias + j * 32 + 8 * g + 4 * b);
-                    if (!full) b16_wait_vmcnt<0>();
-                    else if (emit) b16_wait_vmcnt<4 * nl + 6 * np>();
-                    else b16_wait_vmcnt<4 * nl + 4 * np>();
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (rb0 + i <= rb_last) epi_pair(i, j, bq, rv[slot]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if constexpr (c + NBE < T) b16_res_chunk(rv[slot], res_loff, res_base((c + NBE) % MIW, (c + NBE) / MIW));
-                });
-            };
-            if constexpr (MI0 == MI1) {
-                ring(std::integral_constant<int, MI0>{});
-            } else {
-                if (wm == 0) ring(std::integral_constant<int, MI0>{});
-                else ring(std::integral_constant<int, MI1>{});
-            }
-        } else {
+            for (int i = 0; i < cfg::MIMAX; ++i) {
+                if (i >= miw || rb0 + i > rb_last) continue;
+                // fp32 units 2 g (nh = 0) and 2 g + 1 (nh = 1) of this column block; row 16 a + l15
+                const size_t off = ((size_t)(rb0 + i) * NC4 + ((nb0 + j * 32) >> 2) + 2 * g) * 512 + l15 * 16;
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                float4 bq[2];
+                for (int a = 0; a < 2; ++a) {
+                    float4 rv[2];
+                    if constexpr (EPI == 2) {
 #pragma unroll
-                for (int b = 0; b < 2; ++b) bq[b] = *(const float4*)(sBias + j * 32 + 8 * g + 4 * b);
-#pragma unroll
-                for (int i = 0; i < cfg::MIMAX; ++i) {
-                    if (i >= miw || rb0 + i > rb_last) continue;
-                    f32x4_t r3[4];
-#pragma unroll
-                    for (int a = 0; a < 2; ++a) {                       // EPI 3: row-major residual, row = m % res_rows (pos embed, vit.py:320)
+                        for (int b = 0; b < 2; ++b) rv[b] = *(const float4*)((const char*)p.res + off + b * 512 + a * 256);
+                    } else {                                            // EPI 3: row-major residual, row = m % res_rows (pos embed, vit.py:320)
                         const int m = (rb0 + i) * 32 + 16 * a + l15;
-                        const float* rp = p.res + (size_t)(m % p.res_rows) * p.N + nb0 + j * 32 + 8 * g;
+                        const float* rr = p.res + (size_t)(m % p.res_rows) * p.N + nb0 + j * 32 + 8 * g;
 #pragma unroll
-                        for (int b = 0; b < 2; ++b) { const float4 t = *(const float4*)(rp + 4 * b); r3[2 * a + b] = f32x4_t{t.x, t.y, t.z, t.w}; }
+                        for (int b = 0; b < 2; ++b) rv[b] = *(const float4*)(rr + 4 * b);
                     }
-                    epi_pair(i, j, bq, r3);
+                    uint32_t pk[4];
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        const f32x4_t c = acc[i][j][a][b];
+                        float4 o;
+                        o.x = c[0] + bq[b].x + rv[b].x; o.y = c[1] + bq[b].y + rv[b].y;
+                        o.z = c[2] + bq[b].z + rv[b].z; o.w = c[3] + bq[b].w + rv[b].w;
+                        *(float4*)((char*)p.C + off + b * 512 + a * 256) = o;
+                        if (emit) {
+                            // explicit order / explicit fma: every tile instantiation must produce the same bits for a row (batch-independence tests)
+                            o.x -= sh[i][a]; o.y -= sh[i][a]; o.z -= sh[i][a]; o.w -= sh[i][a];
+                            sx[i][a] += o.x; sx[i][a] += o.y; sx[i][a] += o.z; sx[i][a] += o.w;
+                            sxx[i][a] = fmaf(o.x, o.x, sxx[i][a]); sxx[i][a] = fmaf(o.y, o.y, sxx[i][a]);
+                            sxx[i][a] = fmaf(o.z, o.z, sxx[i][a]); sxx[i][a] = fmaf(o.w, o.w, sxx[i][a]);
+                            pk[2 * b] = pack_bf16x2(o.x, o.y); pk[2 * b + 1] = pack_bf16x2(o.z, o.w);
+                        }
+                    }
+                    if (emit)
+                        *(uint4*)((char*)p.xhat + ((size_t)(rb0 + i) * (p.N >> 3) + ((nb0 + j * 32) >> 3) + g) * 512 + (16 * a + l15) * 16) =
+                            make_uint4(pk[0], pk[1], pk[2], pk[3]);
                 }
             }
         }
@@ -477,9 +365,6 @@ __global__ __launch_bounds__(512, 2) void gemm_blk16_kernel(const whmr_gemm_blk_
     }
 }
 
-// half K tiles between the last in-loop chunk request of the residual ring (epi 2) and the end of the main loop (whmr_gemm_blk_set_tile slot 6)
-static int g_blk16_res_lead = 6;
-
 template <int MI0, int MI1, int EPI, int SCHED>
 static int launch_blk16_s(const whmr_gemm_blk_desc& p, hipStream_t st) {
     using cfg = blk16_cfg<MI0, MI1>;
@@ -491,7 +376,7 @@ static int launch_blk16_s(const whmr_gemm_blk_desc& p, hipStream_t st) {
         attr_done = true;
     }
     const int tiles = ((p.M + cfg::BM - 1) / cfg::BM) * (p.N / cfg::BN);
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), cfg::LDS, st, p, g_blk16_res_lead);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), cfg::LDS, st, p);
     WHMR_CHECK_LAUNCH();
     return 0;
 }

@@ -10,7 +10,8 @@ folded into the conv weights, every conv an (implicit-)GEMM on the same MFMA ker
                   projection skip = 1x1 (strided) gather GEMM
     head          whmr_avgpool_nhwc -> one [768,2048] fp32 GEMM for the three fc layers
 
-``numerics``: 'bf16' (bf16 operands/activations, fp32 accumulate) or 'fp32' (exact-f32 MFMA: the 1e-4 parity mode).
+``numerics``: 'fp32' (default; exact-f32 MFMA: the 1e-4 parity mode, also what 'bf16x3' selects here) or 'bf16' (bf16 operands/activations,
+fp32 accumulate: the throughput opt-in).
 The nn.Module tree (``Bottleneck`` / ``ResNet50``) only CONTAINS the parameters under torchvision's names; it has no forward of its
 own -- tests compare the HIP path with the CPU oracle (oracle/whmr.py::cam_model_forward).  The post-processing (softargmax over 256
 bins -> angles -> euler -> rotation matrix) is a handful of [B,256] tensor ops.
@@ -145,7 +146,7 @@ class CameraRegressorNetwork(nn.Module):
             nn.init.constant_(fc.bias, 0)
             setattr(self, n, fc)
 
-        self.numerics = 'bf16'
+        self.numerics = 'fp32'              # parity-grade by default (the reference runs it in fp32); WHMR sets its own mode here ('bf16' = throughput opt-in)
         self._prep = None
 
     # ------------------------------------------------------------------ HIP path

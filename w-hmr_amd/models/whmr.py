@@ -10,8 +10,11 @@ bbox_info, is_train=False, J_regressor=None, full_x=None, cam_rotmat=None)`` and
   * ``is_train=True`` (module in ``.train()``) returns the train view with an autograd graph whose every stage has a hand-written HIP
     backward (``whmr_amd.train``): Dropout and the ViT's stochastic depth draw fresh masks, BatchNorm uses batch statistics and updates
     its running statistics; in eval mode they are identities / running statistics;
-  * ``numerics``: 'bf16' (MFMA bf16 operands for ViT / deconv / Tz conv / cam_model; everything after the feature maps is fp32)
-    or 'fp32' (exact-f32 MFMA everywhere; the 1e-4 parity mode);
+  * ``numerics``: 'bf16x3' (DEFAULT: split-bf16 operand pairs on the bf16 matrix pipes for ViT / deconv / Tz conv, fp32 everything else -- the
+    reference computes in fp32 (whmr.py:503-678) and a module that is swapped in behind ``whmr_net`` must land within the 1e-4 contract: every
+    ``vis_dict`` tensor <= 1e-4 element-wise of the reference; trains in 'fp32'), 'fp32' (exact-f32 MFMA everywhere) or 'bf16' (the explicit
+    THROUGHPUT opt-in: bf16 MFMA operands for ViT / deconv / Tz conv / cam_model, 3x faster, pred_cam_t / focal_length ~2.6e-3 and cam_rotmat
+    up to 2e-2 off the reference; what ``bench.py``'s headline -- BASELINE configs[1], "bf16 inference" -- runs);
   * ``load_state_dict(ckpt['model'], strict=True)`` accepts a reference checkpoint unchanged (third-party smplx / pare keys without a
     counterpart are listed in ``ignored_checkpoint_keys``).
 Every tensor op on the hot path is a kernel of this repo, including the camera-calibration ResNet-50 (``cam_model.py``: NHWC implicit
@@ -288,7 +291,7 @@ class IUV_predict_layer(nn.Module):
 class WHMR(nn.Module):
     """whmr.py:308-678 (vitpose branch)."""
 
-    def __init__(self, smpl_mean_params=SMPL_MEAN_PARAMS, pretrained=True, assets=None, numerics='bf16',
+    def __init__(self, smpl_mean_params=SMPL_MEAN_PARAMS, pretrained=True, assets=None, numerics='bf16x3',
                  return_view='vis', cam_ckpt='data/pretrained_model/camcalib_sa_biased_l2.ckpt'):
         super().__init__()
         assert cfg.MODEL.PyMAF.BACKBONE == 'vitpose', 'only the vitpose branch is on the hot path (SURVEY 2.1)'
