@@ -230,6 +230,32 @@ def build_workload(args, dev):
     raise SystemExit('unknown workload %s' % args.workload)
 
 
+def host_cpu_info():
+    """CPU model string, physical cores, logical CPUs this process may run on ("core count and CPU model stated")"""
+    model, cores = None, set()
+    try:
+        phys = core = None
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                k, _, v = line.partition(':')
+                k, v = k.strip(), v.strip()
+                if k == 'model name' and model is None:
+                    model = v
+                elif k == 'physical id':
+                    phys = v
+                elif k == 'core id':
+                    core = v
+                elif not k and phys is not None:
+                    cores.add((phys, core))
+                    phys = core = None
+            if phys is not None:
+                cores.add((phys, core))
+    except OSError:
+        pass
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    return {'model': model, 'physical_cores': len(cores) or None, 'logical_cpus': os.cpu_count(), 'usable_cpus': usable}
+
+
 def cpu_baseline(sd, x_cpu, size, heads=12):
     """Oracle (pure-PyTorch fp32 restatement of the reference ViT) on the host cores, bounded sample (~10-20 s).
 
@@ -238,14 +264,21 @@ def cpu_baseline(sd, x_cpu, size, heads=12):
     """
     from oracle.vit import vit_forward
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-    best = None
+    best, sweep = None, {}
     with torch.no_grad():
+        # one thread: the per-core figure (BASELINE.md 3 asks for it next to the all-core number); 2 crops, one warm pass
+        torch.set_num_threads(1)
+        vit_forward(sd, x_cpu[:1], num_heads=heads)
+        t0 = time.perf_counter()
+        vit_forward(sd, x_cpu[:2], num_heads=heads)
+        one_thread = 2 / (time.perf_counter() - t0)
         for th in sorted({min(t, ncpu) for t in (8, 16, 32, 64)}):
             torch.set_num_threads(th)
             vit_forward(sd, x_cpu[:2], num_heads=heads)
             t0 = time.perf_counter()
             vit_forward(sd, x_cpu[:8], num_heads=heads)
             dt = time.perf_counter() - t0
+            sweep[str(th)] = 8 / dt
             if best is None or dt < best[1]:
                 best = (th, dt)
         torch.set_num_threads(best[0])
@@ -256,9 +289,10 @@ def cpu_baseline(sd, x_cpu, size, heads=12):
             reps += 1
         dt = (time.perf_counter() - t0) / reps
     return {'value': n / dt, 'unit': 'images/sec', 'cores': best[0], 'kind': 'port',
+            'cpu': host_cpu_info(), 'one_thread_images_per_sec': one_thread, 'thread_sweep_images_per_sec': sweep,
             'sample': 'oracle.vit.vit_forward fp32 (CPU restatement of the reference ViT), %d pass(es) over one batch of %d '
-                      '%dx%d crops (%.1f s each), torch threads = %d (best of a short sweep; %d logical CPUs visible)'
-                      % (reps, n, size[0], size[1], dt, best[0], ncpu)}
+                      '%dx%d crops (%.1f s each), torch threads = %d (best of a short sweep on 8 crops: thread_sweep_images_per_sec; %d logical CPUs usable); '
+                      'one_thread_images_per_sec: 2 crops on 1 thread' % (reps, n, size[0], size[1], dt, best[0], ncpu)}
 
 
 cpu_baseline.last_output = None
@@ -321,6 +355,12 @@ def secondary_rows(args, dev, x, budget_s=40.0):
             ms = time_steps(stepw, 10, 3)
         rows['whmr'] = {'ms_per_step': ms, 'images_per_sec': args.batch / ms * 1e3, 'cam_model_frames_per_step': 1,
                         'workload': WORKLOAD['whmr'] + '; ' + aw.full_x_note}
+        try:                                # the north star's "achieved HBM GB/s on the sampler / LBS kernels", under the driver's clock
+            with torch.no_grad():
+                rows['whmr']['hbm_rows'] = whmr_hbm_rows(aw, dev)
+            rows['whmr']['hbm_rows_note'] = HBM_ROWS_NOTE
+        except Exception as e:              # noqa: BLE001
+            rows['whmr']['hbm_rows'] = {'error': '%s: %s' % (type(e).__name__, e)}
         if spent() < budget_s:
             rows['whmr']['parity_vs_cpu_oracle'] = whmr_parity(aw, dev, modes=('bf16', 'bf16x3'))
         del stepw
@@ -397,7 +437,7 @@ def cpu_train_baseline(n_img=4):
         opt.step()
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
-    return {'value': n_img / best, 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
+    return {'value': n_img / best, 'unit': 'images/sec', 'cores': threads, 'kind': 'port', 'cpu': host_cpu_info(),
             'sample': 'oracle.train.whmr_forward_train + autograd backward + Adam (CPU restatement of the reference training step, fp32), one '
                       'step on %d 256x192 crops (%.1f s), torch threads = %d' % (n_img, best, threads)}
 
@@ -484,6 +524,12 @@ def whmr_hbm_rows(args, dev, n=20):
     return rows
 
 
+HBM_ROWS_NOTE = ('GPU time of ONE call, 20 calls replayed from a HIP graph on the tensors of a real forward (an eager call is host-launch bound and would '
+                 'time the interpreter); maf_sample = one fused launch (projection + bilinear gather of 256 channels at 67 points + point MLP); smpl_call = '
+                 'pose chain, pose-corrective blend + skinning, joint regression + stage tail (3 dependent launches); algorithmic bytes per SURVEY 8(d); both '
+                 'are latency-bound at these sizes')
+
+
 def cpu_whmr_baseline(args, n_img=4):
     """CPU leg of the whmr workload: the oracle's full forward (oracle/whmr.py, incl. the ResNet-50 of cam_model on one 600x800 frame) on a
     bounded sample of ``n_img`` crops"""
@@ -500,7 +546,7 @@ def cpu_whmr_baseline(args, n_img=4):
             OW.whmr_forward(sd, assets, cpu['x'], cpu['center'], cpu['scale'], cpu['bbox_height'], cpu['orig_shape'], cpu['bbox_info'], full_x=full)
             dt = time.perf_counter() - t0
             best = dt if best is None else min(best, dt)
-    return {'value': n_img / best, 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
+    return {'value': n_img / best, 'unit': 'images/sec', 'cores': threads, 'kind': 'port', 'cpu': host_cpu_info(),
             'sample': 'oracle.whmr.whmr_forward fp32 (CPU restatement of WHMR.forward incl. cam_model on a 600x800 frame per crop, as the reference runs it), %d 256x192 crops (%.1f s), '
                       'torch threads = %d' % (n_img, best, threads)}
 
@@ -888,10 +934,7 @@ def main(argv=None):
                                                    'batch; the CPU leg replicates the frame per crop like demo/tester.py:161 (--full-x per-crop times the GPU that way)'}
                 # the HBM-bound rows of the north star: MAF sampler and SMPL (LBS) call
                 res['hbm_rows'] = whmr_hbm_rows(args, dev)
-                res['hbm_rows_note'] = 'GPU time of ONE call, 20 calls replayed from a HIP graph on the tensors of a real forward (an eager call is host-launch ' \
-                                       'bound and would time the interpreter); maf_sample = one fused launch (projection + bilinear gather of 256 channels at 67 ' \
-                                       'points + point MLP); smpl_call = pose chain + pose-corrective GEMM + skinning + joint regression + stage tail (5 dependent ' \
-                                       'launches); both are latency-bound at these sizes (SURVEY 8d)'
+                res['hbm_rows_note'] = HBM_ROWS_NOTE
             if args.workload == 'whmr' and n_ranks == 1 and not args.no_parity:
                 res['parity'], res['fp32_ms_per_step'] = whmr_parity_and_fp32(args, dev)
                 res['parity_note'] = 'max-rel error of the last regressor stage (theta [B,85], vertices [B,6890,3], kp_2d [B,49,2]) of the full-batch device forward vs the CPU oracle on the ' \

@@ -413,20 +413,6 @@ struct whmr_stage_tail {
 };
 int whmr_smpl_stage_tail(const struct whmr_smpl_model* m, const struct whmr_stage_tail* t, int B, float* scratch /* >= B*33*3 floats */, void* stream);
 
-/* The whole SMPL call of a regressor stage -- pose chain, pose-corrective blend shapes + skinning, joint regression + the stage tail above -- as ONE
- * launch (three phases of a persistent grid separated by two grid barriers; csrc/smpl_fused.hip).  Replaces the five dependent launches
- * whmr_smpl_pose_chain -> whmr_gemm_f32 (posedirs) -> whmr_smpl_skin -> whmr_smpl_stage_tail for models/whmr.py:128-209; same arithmetic (shared
- * device code) -> same vertices.  A / posed_joints / pose_feat / verts: required outputs ([B,24,12], [B,24,3], [B,207], [B,6890,3]); rotmat / aa optional;
- * reg_*: CSR of the first R rows of [J_regressor_extra ; J_regressor] (R = tail.R = 9 or 33); barrier: 16 uint32 per stream, zero between launches
- * (the kernel resets the counter [0]; [2..13] receive six 64-bit phase stamps of workgroup 0); tail.verts / posed_joints / regd are filled in by the launcher. */
-struct whmr_smpl_call {
-    const float* pose9; int64_t pose_stride; const float* betas; int64_t beta_stride; int32_t B, do_gs;
-    float* rotmat; float* aa; float* A; float* posed_joints; float* pose_feat; float* verts;
-    const int32_t* reg_ptr; const int32_t* reg_col; const float* reg_val; uint32_t* barrier /* 16 uint32 */;
-    const float* posedirs_tiled;   /* [108][208][192]: posedirs re-tiled per 64-vertex chunk (k-major inside a chunk, zero padded) */
-    struct whmr_stage_tail tail;
-};
-int whmr_smpl_fused(const struct whmr_smpl_model* m, const struct whmr_smpl_call* f, void* stream);
 /* Pose-corrective blend shapes + skinning in ONE launch (verts.py:46-53, lbs.py:67-77): replaces the [B,207] x [207,20670] whmr_gemm_f32 into a [B,20670]
  * buffer + whmr_smpl_skin.  posedirs_tiled: [108][208][192] (posedirs re-tiled per 64-vertex chunk, k-major, zero padded); pose_feat [B,207] and
  * A [B,24,12] from whmr_smpl_pose_chain; verts [B,6890,3].  Same vertices, bit for bit. */

@@ -391,7 +391,7 @@ def test_nhwc_pools_and_stem_im2col(dev, dt):
         assert torch.equal(got[:, :21, :7], ref.bfloat16().float()) and not got[:, 21:].any() and not got[:, :, 7].any()
 
 
-@pytest.mark.parametrize('numerics,tol', [('fp32', 1e-4), ('bf16', 4e-2)])
+@pytest.mark.parametrize('numerics,tol', [('fp32', 1e-4), ('bf16x3', 1e-4), ('bf16', 4e-2)])
 def test_cam_model_resnet50(dev, numerics, tol):
     """SURVEY 8f N1 / 8(a17): the HIP NHWC ResNet-50 of cam_model against the CPU fp32 oracle (oracle/whmr.py::cam_model_forward: pooled
     features, the three 256-bin logit vectors, the soft-argmax angles and the Rx(pitch).Rz(roll) rotation)."""

@@ -1,4 +1,5 @@
-"""One SMPL call (regressor-stage form) at several batch sizes: the one-launch kernel vs the five per-phase launches, 20 calls per HIP graph."""
+"""One SMPL call (regressor-stage form) at several batch sizes: the three-launch product form vs the five per-phase launches of round 2, 20 calls per HIP graph
+(+ phase stamps of the blend + skin launch)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,8 +14,8 @@ for B in (1, 8, 64, 256):
     betas = torch.randn(B, 10, generator=g).to(dev)
     rot = (torch.eye(3).expand(B, 24, 3, 3) + 0.1 * torch.randn(B, 24, 3, 3, generator=g)).contiguous().to(dev)
     res = {}
-    for fused in (False, True, 'csr'):
-        m.fused, m.csr_tail, m.blend_skin = fused is True, fused == 'csr', fused == 'csr'
+    for fused in (False, 'csr'):
+        m.csr_tail, m.blend_skin = fused == 'csr', fused == 'csr'
         fn = lambda: m.run(betas, rot, gram_schmidt=True, want_aa=True, want_smpl_joints=True, want_markers=True)
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
@@ -35,12 +36,7 @@ for B in (1, 8, 64, 256):
         res[fused] = e0.elapsed_time(e1) / 20 * 1e3
     from whmr_amd import _lib as L
     fn = lambda: m.run(betas, rot, gram_schmidt=True, want_aa=True, want_smpl_joints=True, want_markers=True)
-    m.fused = True
-    fn(); torch.cuda.synchronize()
-    st = L.smpl_barrier(dev).cpu()[2:14].view(torch.int64).tolist()
-    print('      phase stamps of workgroup 0 (us): chain %.1f | barrier %.1f | blend+skin %.1f | barrier %.1f | regress+tail %.1f'
-          % tuple((st[i + 1] - st[i]) / 100.0 for i in range(5)))
-    m.fused, m.csr_tail, m.blend_skin = False, True, True
+    m.csr_tail, m.blend_skin = True, True
     buf = torch.zeros(16, dtype=torch.int32, device=dev)
     L.lib().whmr_smpl_blend_skin_stamps(buf.data_ptr())
     fn(); torch.cuda.synchronize()
@@ -48,4 +44,4 @@ for B in (1, 8, 64, 256):
     bs = buf.cpu()[2:10].view(torch.int64).tolist()
     print('      blend+skin launch, workgroup 0 (us): loads + staging %.1f | fp32-MFMA offsets %.1f | shape blend + skinning %.1f' % tuple((bs[i + 1] - bs[i]) / 100.0 for i in range(3)))
     byt = B * 84172.0 + 19.6e6
-    print('B %4d: five launches (round 2) %.1f us, three launches (blend+skin, CSR tail) %.1f us = %.1f %% of 8 TB/s, one launch %.1f us' % (B, res[False], res['csr'], byt / res['csr'] / 1e6 / 8 * 100, res[True]), flush=True)
+    print('B %4d: five launches (round 2) %.1f us, three launches (blend+skin, CSR tail) %.1f us = %.1f %% of 8 TB/s' % (B, res[False], res['csr'], byt / res['csr'] / 1e6 / 8 * 100), flush=True)

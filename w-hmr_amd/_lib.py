@@ -55,14 +55,6 @@ class WhmrStageTail(C.Structure):
                 ('bbox_info', C.c_void_p), ('rotmat', C.c_void_p), ('xc_next', C.c_void_p), ('ld_next', C.c_int64), ('F_next', C.c_int32)]
 
 
-class WhmrSmplFused(C.Structure):
-    """struct whmr_smpl_call (include/whmr_hip.h): the one-launch SMPL call"""
-    _fields_ = [('pose9', C.c_void_p), ('pose_stride', C.c_int64), ('betas', C.c_void_p), ('beta_stride', C.c_int64), ('B', C.c_int32), ('do_gs', C.c_int32),
-                ('rotmat', C.c_void_p), ('aa', C.c_void_p), ('A', C.c_void_p), ('posed_joints', C.c_void_p), ('pose_feat', C.c_void_p), ('verts', C.c_void_p),
-                ('reg_ptr', C.c_void_p), ('reg_col', C.c_void_p), ('reg_val', C.c_void_p), ('barrier', C.c_void_p), ('posedirs_tiled', C.c_void_p),
-                ('tail', WhmrStageTail)]
-
-
 class WhmrMafWeights(C.Structure):
     _fields_ = [('w0t', C.c_void_p), ('b0', C.c_void_p), ('w1t', C.c_void_p), ('b1', C.c_void_p),
                 ('w2t', C.c_void_p), ('b2', C.c_void_p), ('w0b', C.c_void_p), ('w1b', C.c_void_p), ('w2b', C.c_void_p)]
@@ -105,7 +97,6 @@ _SIGS = {
     'whmr_regressor_post': [_P, _L, _P, _P, _P, _P, _P, _P, _I, _F, _F, _F, _P, _P, _P, _P, _P, _P],
     'whmr_smpl_skin': [C.POINTER(WhmrSmplModel), _P, _L, _P, _P, _P, _I, _P, _P],
     'whmr_smpl_stage_tail': [C.POINTER(WhmrSmplModel), C.POINTER(WhmrStageTail), _I, _P, _P],
-    'whmr_smpl_fused': [C.POINTER(WhmrSmplModel), C.POINTER(WhmrSmplFused), _P],
     'whmr_smpl_stage_tail_csr': [C.POINTER(WhmrSmplModel), C.POINTER(WhmrStageTail), _P, _P, _P, _I, _P],
     'whmr_smpl_blend_skin': [C.POINTER(WhmrSmplModel), _P, _P, _L, _P, _P, _I, _P, _P],
     'whmr_smpl_blend_skin_stamps': [_P],
@@ -743,35 +734,6 @@ def _stage_tail_desc(t, verts, posed_joints, joints49, smpl_joints45, markers, p
             assert nxt['xc'].dtype == torch.float32 and nxt['xc'].stride(1) == 1 and nxt['xc'].shape[1] >= nxt['F'] + 234
             t.bbox_info, t.rotmat = _f32c(nxt['bbox_info']).data_ptr(), _f32c(nxt['rotmat']).data_ptr()
             t.xc_next, t.ld_next, t.F_next = nxt['xc'].data_ptr(), nxt['xc'].stride(0), nxt['F']
-    return out
-
-
-_SMPL_BARRIERS = {}
-
-
-def smpl_barrier(device):
-    """the one-launch SMPL call's arrival counter: one zeroed uint32 per (device, stream), reset by the kernel itself"""
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
-    t = _SMPL_BARRIERS.get(key)
-    if t is None:
-        t = _SMPL_BARRIERS[key] = torch.zeros(16, dtype=torch.int32, device=device)      # [0] the counter; [2..13] six 64-bit phase stamps of workgroup 0
-    return t
-
-
-def smpl_fused(model, csr, posedirs_tiled, pose9, betas, do_gs, rotmat, aa, A, posed_joints, pose_feat, verts, joints49, smpl_joints45, markers, post=None, nxt=None):
-    """whmr_smpl_fused: pose chain + blend shapes + skinning + joint regression + stage tail in ONE launch.  csr = (ptr, col, val) int32 / int32 / fp32
-    of [J_regressor_extra ; J_regressor]; returns the projection outputs like ``smpl_stage_tail``."""
-    f = WhmrSmplFused()
-    out = _stage_tail_desc(f.tail, verts, posed_joints, joints49, smpl_joints45, markers, post, nxt)
-    pp, ps = _rows(pose9, 216)
-    bp, bs = _rows(betas, 10)
-    f.pose9, f.pose_stride, f.betas, f.beta_stride, f.B, f.do_gs = pp, ps, bp, bs, betas.shape[0], int(do_gs)
-    f.rotmat, f.aa, f.A, f.posed_joints, f.pose_feat, f.verts = _ptr(rotmat), _ptr(aa), A.data_ptr(), posed_joints.data_ptr(), pose_feat.data_ptr(), verts.data_ptr()
-    f.reg_ptr, f.reg_col, f.reg_val = (t.data_ptr() for t in csr)
-    assert posedirs_tiled.dtype == torch.float32 and posedirs_tiled.is_contiguous() and tuple(posedirs_tiled.shape) == (108, 208, 192)
-    f.posedirs_tiled = posedirs_tiled.data_ptr()
-    f.barrier = smpl_barrier(verts.device).data_ptr()
-    _check(lib().whmr_smpl_fused(C.byref(model), C.byref(f), _stream()), 'whmr_smpl_fused')
     return out
 
 

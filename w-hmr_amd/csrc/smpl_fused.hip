@@ -1,26 +1,21 @@
-// One-launch SMPL call: pose chain -> pose-corrective blend shapes + skinning -> joint regression + stage tail, as THREE PHASES OF ONE KERNEL
-// separated by two grid barriers (replaces the 5 dependent launches smpl_pose_chain / pose-corrective GEMM / smpl_skin / smpl_regress /
-// smpl_stage_tail of smpl_lbs.hip: 59.7 us at batch 64, each launch ~ the launch floor -- VERDICT r2 weak #8).  Reference: the SMPL forward +
-// the tail of Regressor.forward, models/whmr.py:128-209 (spec of the math: models/smpl_webuser/lbs.py:27-80).
+// SMPL call of a regressor stage as THREE launches (models/whmr.py:128-209; math: models/smpl_webuser/lbs.py:27-80): whmr_smpl_pose_chain (smpl_lbs.hip) ->
+// whmr_smpl_blend_skin -> whmr_smpl_stage_tail_csr.  The two kernels of this file:
 //
-//   phase 1  one wave per image: Gram-Schmidt, angle-axis, rest joints, 24-joint kinematic chain -> A [B,24,3x4], pose feature [B,207]
-//            (smpl_chain_image of smpl_dev.h: the code of smpl_pose_chain_kernel, so the same bits)
-//   phase 2  work item = 64 vertices x 32 images on a 6-wave workgroup: the pose-corrective offsets pose_feature . posedirs on
-//            v_mfma_f32_32x32x2_f32 (exact f32, a sequential fma chain over k = the arithmetic of the GEMM the per-phase path runs, so the same
-//            bits): wave w owns 32 of the item's 192 (vertex, coordinate) columns, A operand = the 32 images' pose features from LDS, B operand =
-//            posedirs rows straight from global memory with 13 steps in flight; the 32 x 192 offsets go through LDS to the skinning layout
-//            (thread = vertex x image subset): shape blend, + offset, T = sum_j w_j A_j, v = T [v_posed; 1].  posedirs (17 MB) is read once per
-//            32 images.  (A first cut kept the offsets on the VALU with the pose features as LDS broadcast reads: LDS-bandwidth bound, 92 us.)
-//   phase 3  one workgroup per image: the 9 (+24) joint-regressor rows as a CSR gather over the skinned mesh (products through LDS, one thread per
+//   blend + skin  work item = 64 vertices x 32 images on a 6-wave workgroup: the pose-corrective offsets pose_feature . posedirs on
+//            v_mfma_f32_32x32x2_f32 (exact f32, a sequential fma chain over k = the arithmetic of the fp32 GEMM it replaced, so the same bits): wave w
+//            owns 32 of the item's 192 (vertex, coordinate) columns, A operand = the 32 images' pose features from LDS, B operand = posedirs rows
+//            straight from global memory (re-tiled per 64-vertex chunk, all 104 k-steps in flight); the 32 x 192 offsets go through LDS to the
+//            skinning layout (thread = vertex x image subset): shape blend, + offset, T = sum_j w_j A_j, v = T [v_posed; 1].  posedirs (17 MB) is read
+//            once per 32 images.
+//   CSR tail      one workgroup per image: the 9 (+24) joint-regressor rows as a CSR gather over the skinned mesh (products through LDS, one thread per
 //            (row, coordinate) adds its segment in index order: deterministic), then smpl_stage_tail_image (joint map, markers, theta, kp_2d,
 //            kp_2d_w, cam_t, focal, the next stage's input state).
 //
-// Grid barrier: a self-resetting arrival counter in device memory (one per stream, zeroed once by the host): workgroup barrier (every wave's stores
-// have completed), one agent-scope atomic arrive, spin on an agent-scope load.  NO cache-wide fences: everything a later phase reads from an earlier
-// one travels through agent-scope (sc1) stores / loads (st_f<true> / ld_f<true> of smpl_dev.h), which are coherent across the XCD-private L2s by
-// themselves -- a release / acquire fence pair per workgroup writes back and invalidates whole L2s and cost 4x the five launches it replaced.
-// The grid is sized by the occupancy query (all workgroups co-resident on an idle device); beside kernels of other streams late workgroups start
-// when those finish -- nothing this kernel waits for ever waits for this kernel.
+// History: both were written as phases 2 / 3 of a ONE-launch SMPL call (persistent grid, two spin grid barriers, coherent sc1 traffic between the
+// phases; round 3).  That kernel was bit-identical but slower than the three launches (56 vs 42 us at batch 64: one workgroup per CU pays every
+// phase's memory round trips alone) and its barrier relied on co-residency that nothing enforced (two such launches on two streams could
+// spin forever) -- removed in round 4 (last version: git show 7a2c1ef:w-hmr_amd/csrc/smpl_fused.hip).  The COH template parameter of
+// the shared device code (smpl_dev.h) is what is left of it: false everywhere.
 // Floating-point contraction per EXPRESSION (the language rule), not across statements after inlining (hipcc's default "fast"): whether a product
 // is fused into an fma then depends on the source expression only, not on the kernel it was inlined into -- the per-phase kernels and the
 // one-launch kernel share smpl_dev.h / geometry_dev.h and must produce the same bits.
@@ -35,9 +30,9 @@ struct whmr_smpl_call {
     float* A; float* posed_joints; float* pose_feat;   // [B,24,12], [B,24,3], [B,207]: phase-1 results the later phases read (required)
     float* verts;                                   // [B, 6890, 3]
     const int32_t* reg_ptr; const int32_t* reg_col; const float* reg_val;   // CSR of the [R, 6890] regressor rows (extra rows first, then J_regressor)
-    uint32_t* barrier;                              // arrival counter, 0 between launches (+ 6 phase stamps behind it: 16 uint32 in all)
+    uint32_t* barrier;                              // tools only: 16 uint32 whose words [2..13] receive phase stamps of workgroup 0 (may be null)
     const float* posedirs_tiled;                    // [108][208][192]: posedirs re-tiled per 64-vertex chunk, k-major inside a chunk, zero padded
-    whmr_stage_tail tail;                           // phase 3 (verts / posed_joints / regd are filled in by the launcher)
+    whmr_stage_tail tail;                           // (unused by the launches of this file)
 };
 
 #define FUSED_VT 64          // vertices per phase-2 item (192 posedirs columns = 6 MFMA column tiles, one per wave)
@@ -46,15 +41,6 @@ struct whmr_smpl_call {
 #define FUSED_NNZ 1536       // CSR products staged per pass (phase 3): 4 per thread
 #define FUSED_KP 208         // pose-feature depth padded to the MFMA's k step (row 207 is zero)
 
-__device__ __forceinline__ void grid_barrier(uint32_t* ctr, uint32_t target) {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");    // this wave's sc1 stores have been acknowledged by the coherence point ...
-    __syncthreads();                                               // ... and so have every other wave's of the workgroup
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
-    }
-    __syncthreads();
-}
 
 // LDS of phase 2: sPF [208][32] | sBeta [10][32] | sA [32][288] | sPO [32][192]
 #define P2_PF 0
@@ -220,90 +206,6 @@ __device__ __forceinline__ void fused_phase3(const whmr_smpl_model& m, const whm
                                    nmk ? (const int32_t*)(sTab + 70) : m.marker_ids);
         __syncthreads();
     }
-}
-
-__global__ __launch_bounds__(FUSED_NT, 1) void smpl_fused_kernel(const whmr_smpl_model m, const whmr_smpl_call p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int G = gridDim.x, B = p.B;
-    constexpr int NW = FUSED_NT / 64;
-    // phase stamps of workgroup 0 (100 MHz wall clock) behind the counter: barrier[2 + 2 i], i = 0..5 (tools/smpl_timing.py reads them)
-    uint64_t* stamps = (uint64_t*)(p.barrier + 2);
-#define STAMP(i) do { if (blockIdx.x == 0 && tid == 0) stamps[i] = wall_clock64(); } while (0)
-    STAMP(0);
-    // ---------------------------------------------------------------- phase 1: pose chains, one wave per image
-    {
-        smpl_chain_lds* L = (smpl_chain_lds*)smem;                                // one per wave (2016 B each)
-        const int per_pass = G * NW, first = blockIdx.x * NW + wave;
-        for (int it = 0; it < (B + per_pass - 1) / per_pass; ++it) {
-            const int b = first + it * per_pass;
-            smpl_chain_image<true>(m, p.pose9, p.pose_stride, p.betas, p.beta_stride, p.do_gs, p.rotmat, p.aa, p.A, p.posed_joints, p.pose_feat, b, lane,
-                                   b < B, L[wave]);
-            __syncthreads();
-        }
-    }
-    STAMP(1);
-    grid_barrier(p.barrier, (uint32_t)G);
-    STAMP(2);
-    // ---------------------------------------------------------------- phase 2: pose-corrective offsets + skinning
-    {
-        const int nvb = (NV + FUSED_VT - 1) / FUSED_VT, ngrp = (B + FUSED_IG - 1) / FUSED_IG;
-        for (int it = blockIdx.x; it < nvb * ngrp; it += G)
-            fused_phase2_item<true>(m, p, it / ngrp, (it % ngrp) * FUSED_IG, (float*)smem);
-    }
-    STAMP(3);
-    grid_barrier(p.barrier, (uint32_t)(2 * G));
-    STAMP(4);
-    // ---------------------------------------------------------------- phase 3: joint regression (CSR) + stage tail, one workgroup per image
-    fused_phase3<true, FUSED_NT>(m, p.tail, p.verts, p.reg_ptr, p.reg_col, p.reg_val, B, blockIdx.x, G, smem);
-    STAMP(5);
-    // ---------------------------------------------------------------- counter reset by the last workgroup to leave
-    __syncthreads();
-    if (tid == 0) {
-        const uint32_t old = __hip_atomic_fetch_add(p.barrier, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == (uint32_t)(3 * G - 1)) __hip_atomic_store(p.barrier, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
-static size_t fused_lds_bytes() {
-    const size_t p2 = (size_t)P2_FLOATS * 4;
-    const size_t p3 = (36 + 49) * 3 * 4 + 12 + (size_t)FUSED_NNZ * 3 * 4 + 256 * 4;
-    const size_t p1 = (FUSED_NT / 64) * sizeof(smpl_chain_lds);
-    size_t n = p2 > p3 ? p2 : p3;
-    return n > p1 ? n : p1;
-}
-
-// The whole SMPL call of a regressor stage in one launch.  f->tail: the stage-tail descriptor (R = 9 or 33; verts / posed_joints / regd are set
-// here); f->barrier: one zero-initialised uint32 per stream that only this entry touches; reg_ptr / reg_col / reg_val: CSR of the first R rows of
-// [J_regressor_extra ; J_regressor].  Returns hipErrorInvalidValue outside that envelope.
-extern "C" int whmr_smpl_fused(const whmr_smpl_model* m, const whmr_smpl_call* ff, void* stream) {
-    whmr_smpl_call f = *ff;
-    if (f.B <= 0 || !f.A || !f.posed_joints || !f.pose_feat || !f.verts || !f.barrier || !f.reg_ptr || !f.reg_col || !f.reg_val || !f.posedirs_tiled) return (int)hipErrorInvalidValue;
-    if (f.tail.R != 9 && f.tail.R != 33) return (int)hipErrorInvalidValue;
-    if (f.tail.smpl_joints45 && f.tail.R != 33) return (int)hipErrorInvalidValue;
-    if (f.tail.xc_next && (!f.tail.state || !f.tail.rotmat || !f.tail.bbox_info)) return (int)hipErrorInvalidValue;
-    f.tail.verts = f.verts;
-    f.tail.posed_joints = f.posed_joints;
-    f.tail.regd = nullptr;
-    const size_t lds = fused_lds_bytes();
-    static int max_grid = 0;
-    if (!max_grid) {
-        hipError_t e = hipFuncSetAttribute((const void*)smpl_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        int per_cu = 0, dev = 0;
-        hipDeviceProp_t prop;
-        if ((e = hipGetDevice(&dev)) != hipSuccess || (e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return (int)e;
-        if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, smpl_fused_kernel, FUSED_NT, lds)) != hipSuccess) return (int)e;
-        if (per_cu < 1) return (int)hipErrorInvalidValue;
-        max_grid = prop.multiProcessorCount;                                      // one workgroup per CU, all co-resident: the barrier's precondition
-    }
-    const int nvb = (NV + FUSED_VT - 1) / FUSED_VT;
-    int want = nvb * ((f.B + FUSED_IG - 1) / FUSED_IG);                           // phase-2 items: the widest phase
-    if (want < f.B) want = f.B;
-    const int G = want < max_grid ? want : max_grid;
-    hipLaunchKernelGGL(smpl_fused_kernel, dim3(G), dim3(FUSED_NT), lds, (hipStream_t)stream, *m, f);
-    WHMR_CHECK_LAUNCH();
-    return 0;
 }
 
 // ---- the stage tail with the joint regression as a CSR gather, ONE launch per stage (was smpl_regress_kernel over the dense [33, 6890] rows for

@@ -10,8 +10,9 @@ folded into the conv weights, every conv an (implicit-)GEMM on the same MFMA ker
                   projection skip = 1x1 (strided) gather GEMM
     head          whmr_avgpool_nhwc -> one [768,2048] fp32 GEMM for the three fc layers
 
-``numerics``: 'fp32' (default; exact-f32 MFMA: the 1e-4 parity mode, also what 'bf16x3' selects here) or 'bf16' (bf16 operands/activations,
-fp32 accumulate: the throughput opt-in).
+``numerics``: 'fp32' (default; exact-f32 MFMA), 'bf16x3' (what WHMR's default sets: fp32 maps, every convolution behind the stem as ONE bf16 MFMA
+launch on K-concatenated split operands -- fp32-grade logits at ~3x the bf16 cost instead of ~7x) or 'bf16' (bf16 operands / activations, fp32
+accumulate: the throughput opt-in).
 The nn.Module tree (``Bottleneck`` / ``ResNet50``) only CONTAINS the parameters under torchvision's names; it has no forward of its
 own -- tests compare the HIP path with the CPU oracle (oracle/whmr.py::cam_model_forward).  The post-processing (softargmax over 256
 bins -> angles -> euler -> rotation matrix) is a handful of [B,256] tensor ops.
@@ -71,19 +72,33 @@ def resnet50(pretrained=False):
     return ResNet50()
 
 
-def fold_resnet50(bb, dt):
+def fold_resnet50(bb, dt, x3=False):
     """Eval-mode BatchNorm folded into the conv weights of a torchvision-layout ResNet-50 trunk ``bb`` (conv1 / bn1 / layer1-4), weights laid out
-    [N, (ky, kx, ci)] in the compute dtype ``dt`` -- the operand set of ``run_resnet50``."""
-    def fold(conv, bn, stem_cols=False):
+    [N, (ky, kx, ci)] in the compute dtype ``dt`` -- the operand set of ``run_resnet50``.  ``x3`` (dt fp32): the bf16x3 numerics -- every conv
+    behind the stem gets the K-concatenated split weight [N, (ky, kx), [W_hi | W_hi | W_lo]] (bf16, 3 Cin per tap) that pairs with ``L.split3`` of
+    its fp32 input map; the stem (K = 147, not a multiple of the bf16 kernel's K step) stays on the exact-f32 kernel."""
+    def fold(conv, bn, stem_cols=False, split=False):
         s = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach().float()
         w = conv.weight.detach().float() * s[:, None, None, None]
         b = (bn.bias - bn.running_mean * s).detach().float().contiguous()
         if stem_cols:                                          # whmr_conv_im2col column order (ci, ky, kx 7->8), K 168 -> 192
             w = F.pad(F.pad(w, (0, 1)).reshape(w.shape[0], -1), (0, 192 - 3 * 7 * 8))
+        elif split:
+            w = L.split3_weight(w.permute(0, 2, 3, 1).contiguous()).reshape(w.shape[0], -1)       # per tap [hi | hi | lo] over the channels
+            return w.contiguous(), b
         else:
             w = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
         return w.to(dt).contiguous(), b
 
+    if x3:
+        assert dt == torch.float32
+        prep = {'stem': fold(bb.conv1, bb.bn1), 'blocks': [], 'x3': True}
+        for li in range(1, 5):
+            for blk in getattr(bb, 'layer%d' % li):
+                prep['blocks'].append(dict(c1=fold(blk.conv1, blk.bn1, split=True), c2=fold(blk.conv2, blk.bn2, split=True),
+                                           c3=fold(blk.conv3, blk.bn3, split=True), stride=blk.conv2.stride[0],
+                                           down=fold(blk.downsample[0], blk.downsample[1], split=True) if blk.downsample is not None else None))
+        return prep
     prep = {'stem': fold(bb.conv1, bb.bn1, stem_cols=(dt == torch.bfloat16)), 'blocks': []}
     for li in range(1, 5):
         for blk in getattr(bb, 'layer%d' % li):
@@ -109,6 +124,8 @@ def run_resnet50(P, images, dt):
         L.gemm(images.float().permute(0, 2, 3, 1).contiguous(), w, x, bias=b, act=L.ACT_RELU,
                conv=dict(IH=H, IW=W, Cin=3, OH=OH, OW=OW, KW=7, SH=2, SW=2, PH=3, PW=3))
     x = L.maxpool_nhwc(x, 3, 2, 1)
+    if P.get('x3'):
+        return _run_blocks_x3(P, x)
     for blk in P['blocks']:
         _, IH, IW, Cin = x.shape
         s = blk['stride']
@@ -133,6 +150,38 @@ def run_resnet50(P, images, dt):
     return x
 
 
+def _run_blocks_x3(P, x):
+    """layer1-4 in the bf16x3 numerics: fp32 NHWC maps between the convolutions; every convolution = ONE launch of the bf16 MFMA kernel on the
+    K-concatenated split operands ([x_hi | x_lo | x_hi] . [W_hi | W_hi | W_lo]^T = the three split products, fp32 accumulate; bias, skip and ReLU
+    in its fp32 epilogue).  The block input is split once for conv1 and the downsample conv."""
+    dev, f32 = x.device, torch.float32
+    B = x.shape[0]
+    for blk in P['blocks']:
+        _, IH, IW, Cin = x.shape
+        s = blk['stride']
+        OH, OW = (IH - 1) // s + 1, (IW - 1) // s + 1
+        planes = blk['c1'][0].shape[0]
+        x3 = L.split3(x)                                                           # [B, IH, IW, 3 Cin] bf16
+        y1 = torch.empty(B, IH, IW, planes, dtype=f32, device=dev)
+        L.gemm(x3, blk['c1'][0], y1, bias=blk['c1'][1], act=L.ACT_RELU)
+        y2 = torch.empty(B, OH, OW, planes, dtype=f32, device=dev)
+        L.gemm(L.split3(y1), blk['c2'][0], y2, bias=blk['c2'][1], act=L.ACT_RELU,
+               conv=dict(IH=IH, IW=IW, Cin=3 * planes, OH=OH, OW=OW, KW=3, SH=s, SW=s, PH=1, PW=1))
+        if blk['down'] is None:
+            skip = x
+        else:
+            skip = torch.empty(B, OH, OW, planes * 4, dtype=f32, device=dev)
+            if s == 1:
+                L.gemm(x3, blk['down'][0], skip, bias=blk['down'][1])
+            else:
+                L.gemm(x3, blk['down'][0], skip, bias=blk['down'][1],
+                       conv=dict(IH=IH, IW=IW, Cin=3 * Cin, OH=OH, OW=OW, KW=1, SH=s, SW=s, PH=0, PW=0))
+        out = torch.empty(B, OH, OW, planes * 4, dtype=f32, device=dev)
+        L.gemm(L.split3(y2), blk['c3'][0], out, bias=blk['c3'][1], act=L.ACT_RELU, residual=skip.view(-1, planes * 4), res_first=True)
+        x = out
+    return x
+
+
 class CameraRegressorNetwork(nn.Module):
     def __init__(self, backbone='resnet50', num_fc_layers=1, num_fc_channels=1024, num_out_channels=256):
         super().__init__()
@@ -148,6 +197,7 @@ class CameraRegressorNetwork(nn.Module):
 
         self.numerics = 'fp32'              # parity-grade by default (the reference runs it in fp32); WHMR sets its own mode here ('bf16' = throughput opt-in)
         self._prep = None
+        self.fused_logits = None
 
     # ------------------------------------------------------------------ HIP path
     def _versions(self):
@@ -159,7 +209,7 @@ class CameraRegressorNetwork(nn.Module):
         if self._prep is not None and self._prep['key'] == key:
             return self._prep
         dt = torch.bfloat16 if self.numerics == 'bf16' else torch.float32
-        prep = fold_resnet50(self.backbone, dt)
+        prep = fold_resnet50(self.backbone, dt, x3=self.numerics == 'bf16x3')
         prep['key'] = key
         prep['fc_w'] = torch.cat([self.fc_vfov.weight, self.fc_pitch.weight, self.fc_roll.weight], 0).detach().float().contiguous()
         prep['fc_b'] = torch.cat([self.fc_vfov.bias, self.fc_pitch.bias, self.fc_roll.bias], 0).detach().float().contiguous()
@@ -181,6 +231,7 @@ class CameraRegressorNetwork(nn.Module):
         logits = torch.empty(B, P['fc_w'].shape[0], dtype=torch.float32, device=dev)
         L.gemm(feat, P['fc_w'], logits, bias=P['fc_b'])
         n = self.num_out_channels
+        self.fused_logits = logits           # [B, 3 n] = [vfov | pitch | roll]: what WHMR._camera hands to whmr_cam_head (explicit, not via ._base)
         return [logits[:, :n], logits[:, n:2 * n], logits[:, 2 * n:]], feat
 
 

@@ -58,10 +58,7 @@ class SMPL(nn.Module):
         ids = marker_ids if marker_ids is not None else torch.zeros(0, dtype=torch.long)
         self.marker_ids = torch.as_tensor(ids, dtype=torch.long)
         self._dev_cache = None
-        # fused = True: the whole call as ONE launch behind two grid barriers (csrc/smpl_fused.hip).  Same bits, but NOT faster on this part
-        # (56 vs 42 us at batch 64 -- a persistent grid holds one workgroup per CU and pays every phase's memory round trips alone),
-        # so the default is the per-phase form: pose chain -> blend shapes + skinning -> CSR joint regression + stage tail (3 launches)
-        self.fused = False
+        # launch form: pose chain -> blend shapes + skinning -> CSR joint regression + stage tail (3 launches)
         self.csr_tail = True        # False: the dense B x 33-workgroup regression + tail launch of round 2 (A/B)
         self.blend_skin = True      # pose-corrective offsets + skinning as one launch; False: fp32 GEMM into a [B, 20670] buffer + the skin kernel (A/B)
 
@@ -140,14 +137,6 @@ class SMPL(nn.Module):
         A = torch.empty(B, 24, 12, **f32)
         pj = torch.empty(B, 24, 3, **f32)
         pf = torch.empty(B, 207, **f32)
-        if self.fused:
-            verts = torch.empty(B, self.NUM_VERTS, 3, **f32)
-            joints = torch.empty(B, 49, 3, **f32)
-            sj = torch.empty(B, 45, 3, **f32) if want_smpl_joints else None
-            mk = torch.empty(B, m.n_markers, 3, **f32) if (want_markers and m.n_markers) else None
-            tail = L.smpl_fused(m, self._dev_cache[2]['csr'], self._dev_cache[2]['posedirs_tiled'], pose9, betas, gram_schmidt, rot, aa, A, pj, pf, verts, joints, sj, mk,
-                                post=None if post is None else dict(post, aa=aa), nxt=None if nxt is None else dict(nxt, rotmat=rot))
-            return ModelOutput(verts, joints, sj, rot, aa, mk, tail)
         L.smpl_pose_chain(m, pose9, betas, gram_schmidt, rot, aa, A, pj, pf)
         verts = torch.empty(B, self.NUM_VERTS, 3, **f32)
         if self.blend_skin:         # pose-corrective offsets (verts.py:51-53) on the matrix pipes + shape blend + skinning, one launch

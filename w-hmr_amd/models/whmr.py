@@ -501,7 +501,14 @@ class WHMR(nn.Module):
                 pred, _ = self.cam_model(full_x)
                 # soft-argmax -> (pitch, roll) -> R([pitch, 0, roll]), R([-pitch, 0, roll]) (whmr.py:513-522) in one launch
                 # (convert_preds_to_angles + 2 x batch_euler2matrix were ~160 element-wise launches)
-                logits = pred[0]._base if pred[0]._base is not None else torch.cat(pred, 1)
+                # the head's three Linear layers run as ONE GEMM into a [Bf, 3 D] matrix that forward() also publishes as `fused_logits`;
+                # it is taken only when it provably IS what the three views slice (same storage, offsets 0 / D / 2 D), else the views are joined
+                D = pred[0].shape[1]
+                logits = getattr(self.cam_model, 'fused_logits', None)
+                if not (logits is not None and logits.dim() == 2 and logits.shape == (pred[0].shape[0], 3 * D) and logits.is_contiguous()
+                        and logits.dtype == torch.float32 and all(pr.data_ptr() == logits.data_ptr() + 4 * i * D and pr.stride() == (3 * D, 1) and pr.shape[1] == D
+                                                                  for i, pr in enumerate(pred))):
+                    logits = torch.cat([pr.float() for pr in pred], 1)
                 from .cam_model import PITCH_RANGE, ROLL_RANGE
                 cam_rotmat, render_rotmat = L.cam_head(logits, pred[0].shape[1], PITCH_RANGE, ROLL_RANGE, B)
             else:

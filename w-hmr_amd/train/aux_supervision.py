@@ -100,7 +100,9 @@ class IUVLossFn(torch.autograd.Function):
         B, H, W, Cc = y.shape
         ld = y.stride(2)
         dyp = L.iuv_losses_bwd(y, iuv, ctx.w, g, ld)
-        # dy is a VIEW of the padded [B*H*W, ld] operand: ConvNHWCFn.backward finds the whole buffer through dy._base (no side channel)
+        # dy is a VIEW of the padded [B*H*W, ld] operand: ConvNHWCFn.backward finds the whole buffer through dy._base.  The tag is the producer's
+        # explicit promise "laid out [M, ld], columns [Cc, ld) are zero" (csrc/iuv_loss.hip writes them) -- heads_autograd._padded_base takes nothing else
+        dyp.whmr_zero_padded = ld
         return dyp.view(B, H, W, ld)[..., :Cc], None, None
 
 

@@ -132,11 +132,16 @@ class AttentionF32Fn(torch.autograd.Function):
 def _padded_base(dy, M, npad, dt):
     """A producer that already holds the gradient of a ConvNHWCFn output as the zero-padded [M, npad] matrix (IUVLossFn: csrc/iuv_loss.hip writes it
     that way) returns the [..., :Cout] VIEW of it; the convolution's backward then takes the whole buffer from the view's base and skips the
-    zero-fill + copy that would rebuild that operand.  (Was a process-global dict keyed by data_ptr: ADVICE r2.)"""
+    zero-fill + copy that would rebuild that operand.  The producer OPTS IN by tagging the buffer (``base.whmr_zero_padded = npad``: "columns
+    [Cout, npad) are zero and I am laid out [M, npad]"); geometry alone is not trusted, and the view must be exactly
+    ``base.view(..., npad)[..., :Cout]`` -- same storage offset, same strides in EVERY dimension."""
     base = dy._base
-    if base is None or base.dtype != dt or base.numel() != M * npad or not base.is_contiguous() or base.data_ptr() != dy.data_ptr():
+    if base is None or getattr(base, 'whmr_zero_padded', None) != npad:
         return None
-    if dy.dim() < 2 or dy.stride(-1) != 1 or dy.stride(-2) != npad:
+    if base.dtype != dt or base.numel() != M * npad or not base.is_contiguous() or base.data_ptr() != dy.data_ptr():
+        return None
+    want = base.view(*dy.shape[:-1], npad)[..., :dy.shape[-1]]
+    if dy.dim() < 2 or dy.stride() != want.stride() or dy.shape != want.shape:
         return None
     return base.view(M, npad)
 
