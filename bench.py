@@ -720,18 +720,24 @@ def device_record(rank, local, dev, dry):
     return rec
 
 
-def multi_rank_report(args, dist, world, dt_own, rank_map, red, dry):
+def multi_rank_report(args, dist, world, dt_own, rank_map, red, dry, dev):
     """What explains an N > 1 number: every rank's own step time (a slow rank vs a slow exchange), the communicator's library
     version, the rank -> device map, and for the training step what the gradient exchange moved and how much of it finish() had to WAIT for."""
-    rows = [None] * world
     own = {'ms_per_step': dt_own / args.steps * 1e3}
+    # every rank's own step time as a plain float64 all_gather (the figure that must not get lost), the exchange details as objects
+    tms = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+    dist.all_gather(tms, torch.tensor([own['ms_per_step']], dtype=torch.float64, device=dev))
+    ms = [float(t.item()) for t in tms]
+    rows = [None] * world
     if red is not None:
         waits = red.exposed_wait_ms()
         own.update(exposed_exchange_wait_ms_mean=sum(waits) / max(len(waits), 1), exposed_exchange_wait_ms_max=max(waits) if waits else 0.0,
                    collectives_per_step=red.stats['collectives'] / max(args.steps, 1), bytes_exchanged_per_step=red.stats['bytes_exchanged'] / max(args.steps, 1),
                    buckets=len(red.buckets), bucket_bytes=[b['numel'] * 4 for b in red.buckets], unused_parameters=len(red.skipped))
-    dist.all_gather_object(rows, own)
-    ms = [r['ms_per_step'] for r in rows]
+    try:
+        dist.all_gather_object(rows, own)
+    except Exception as e:                       # noqa: BLE001
+        rows = [dict(own, note='other ranks unavailable: %s' % type(e).__name__)]
     rep = {'per_rank_ms_per_step': {'min': min(ms), 'max': max(ms), 'all': ms},
            'ranks': rank_map,
            'backend': 'gloo (dryrun)' if dry else 'nccl = RCCL',
@@ -826,9 +832,19 @@ def main(argv=None):
     # HIP_VISIBLE_DEVICES map would "scale" by time-sharing a GPU), refused before anything is timed
     rank_map = [device_record(rank, local, dev, dry)]
     if dist is not None:
-        rank_map = [None] * world
-        dist.all_gather_object(rank_map, device_record(rank, local, dev, dry))
-        ids = [r['device_id'] for r in rank_map]
+        # the clash test itself travels as one int64 per rank (a plain tensor all_gather: the collective every backend has); the readable records
+        # follow as objects and are allowed to fail without costing the run its line
+        import hashlib
+        mine = int.from_bytes(hashlib.sha256(rank_map[0]['device_id'].encode()).digest()[:7], 'big')
+        ids = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(ids, torch.tensor([mine], dtype=torch.int64, device=dev))
+        ids = [int(t.item()) for t in ids]
+        try:
+            recs = [None] * world
+            dist.all_gather_object(recs, rank_map[0])
+            rank_map = recs
+        except Exception as e:                   # noqa: BLE001
+            rank_map = [dict(rank_map[0], note='records of the other ranks unavailable: %s: %s' % (type(e).__name__, e))]
         if len(set(ids)) != len(ids):
             raise SystemExit('bench.py: two ranks share a device: %s' % json.dumps(rank_map))
 
@@ -878,7 +894,10 @@ def main(argv=None):
     n_ranks = count_ranks(dist, dev)
     multi = None
     if dist is not None:
-        multi = multi_rank_report(args, dist, world, dt_own, rank_map, getattr(args, 'reducer', None), dry)
+        try:
+            multi = multi_rank_report(args, dist, world, dt_own, rank_map, getattr(args, 'reducer', None), dry, dev)
+        except Exception as e:                   # noqa: BLE001   (explanatory block only: never costs the run its line)
+            multi = {'error': '%s: %s' % (type(e).__name__, e)}
 
     fp32_mode = args.numerics == 'fp32'                               # parity numerics: exact-f32 MFMA (v_mfma_f32_32x32x2_f32) GEMMs
     x3_mode = args.numerics == 'bf16x3'                               # parity-grade numerics on the bf16 pipes: three bf16 MFMAs per product

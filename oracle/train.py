@@ -75,17 +75,23 @@ def regressor_forward_train(sd, assets, i, x, bbox_info, Tz, orig_shape, center,
 
 
 def whmr_forward_train(sd, assets, x, center, scale, bbox_height, orig_shape, bbox_info, stage=2, stats=None, dp_out=None,
-                       drop_masks=None, drop_path_rate=0.0):
+                       drop_masks=None, drop_path_rate=0.0, relu_gates=None, fmaps_out=None):
     """-> list of the 4 ``smpl_out`` dicts (mean-pose mesh + 3 stages).  ``stats`` (dict, optional) receives the updated BN running stats,
-    ``dp_out`` (list, optional) the IUV head's output dict."""
+    ``dp_out`` (list, optional) the IUV head's output dict, ``fmaps_out`` (list, optional) the three deconv maps.
+    ``relu_gates`` (tests only; None = the reference's arithmetic): three boolean NCHW masks that REPLACE the ReLU decisions of the deconv stages
+    (whmr.py:488-498) -- a parity test injects the gates another evaluation took, so that pre-activations within rounding of zero stop showing up
+    as O(1/sqrt(map size)) differences of every gradient behind them (tests/test_train_gpu.py)."""
     B = x.shape[0]
     s_feat = vit_forward(sd, x, 'feature_extractor.backbone.', drop_masks=drop_masks, drop_path_rate=drop_path_rate)   # stochastic depth (vit.py:132-139)
     smpl_out = OW.regressor_forward_init(sd, assets, B)
     outs, fmaps = [smpl_out], []
     for i in range(3):
         w = sd['deconv_layers.%d.weight' % (3 * i)]
-        s_feat = F.relu(_bn_train(F.conv_transpose2d(s_feat, w, None, stride=2, padding=1), sd, 'deconv_layers.%d.' % (3 * i + 1), stats))
+        z = _bn_train(F.conv_transpose2d(s_feat, w, None, stride=2, padding=1), sd, 'deconv_layers.%d.' % (3 * i + 1), stats)
+        s_feat = F.relu(z) if relu_gates is None else z * relu_gates[i].to(z.dtype)
         fmaps.append(s_feat)
+        if fmaps_out is not None:
+            fmaps_out.append(s_feat)
     Tz = tz_head_train(sd, s_feat.detach() if stage == 1 else s_feat, stats)
     if dp_out is not None:
         dp_out.append(dp_head_forward(sd, s_feat))
@@ -112,7 +118,7 @@ def dp_cotangent_loss(dp, seed=1, dev=None):
     total = 0.0
     for k in ('predict_u', 'predict_v', 'predict_uv_index', 'predict_ann_index'):
         t = dp[k]
-        c = torch.randn(t.shape, generator=g) / float(t[0].numel()) ** 0.5
+        c = torch.randn(t.shape, generator=g, dtype=torch.float32).to(t.dtype if dev is None else torch.float32) / float(t[0].numel()) ** 0.5
         total = total + (t * (c.to(dev) if dev is not None else c)).sum()
     return total
 
@@ -126,7 +132,7 @@ def cotangent_loss(outs, seed=0, dev=None):
     for l in range(1, len(outs)):
         for k in TRAIN_LOSS_KEYS:
             t = outs[l][k]
-            c = torch.randn(t.shape, generator=g) / float(max(1, t[0].numel())) ** 0.5
+            c = torch.randn(t.shape, generator=g, dtype=torch.float32).to(t.dtype if dev is None else torch.float32) / float(max(1, t[0].numel())) ** 0.5
             if k in ('kp_2d', 'kp_2d_w'):
                 c = c * 0.05
             if k == 'focal_length':

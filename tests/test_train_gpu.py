@@ -432,6 +432,19 @@ def test_whmr_train_step_fp32_matches_oracle_autograd(dev, assets, state_dict, s
             assert e < 1e-4, (l, k, e)
     for k, v in stats.items():
         assert _rel(m.state_dict()[k].cpu(), v) < 1e-4, k
+    # second oracle pass with the ReLU gates of the three deconv stages replaced by the device's (its maps > 0): what is left of the deconv / backbone
+    # gradient differences once no gate is decided differently (the B = 64 test below does the same at the benchmark size)
+    gates = [(f.cpu() > 0) for f in vis[1:]]
+    p2 = {k: (v.clone().requires_grad_(True) if k in keys else v) for k, v in state_dict.items()}
+    dp2, fm_ref = [], []
+    with torch.no_grad():
+        OT.whmr_forward_train(state_dict, assets, inp['x'], inp['center'], inp['scale'], inp['bbox_height'], inp['orig_shape'], inp['bbox_info'], stage=stage,
+                              fmaps_out=fm_ref)
+    flips = [int((g_ != (f > 0)).sum()) for g_, f in zip(gates, fm_ref)]
+    outs_g = OT.whmr_forward_train(p2, assets, inp['x'], inp['center'], inp['scale'], inp['bbox_height'], inp['orig_shape'], inp['bbox_info'], stage=stage,
+                                   dp_out=dp2, relu_gates=gates)
+    (OT.cotangent_loss(outs_g) + OT.dp_cotangent_loss(dp2[0])).backward()
+    worst_gated = 0.0
     named = dict(m.named_parameters())
     bad = {}
     for k in keys:
@@ -456,15 +469,28 @@ def test_whmr_train_step_fp32_matches_oracle_autograd(dev, assets, state_dict, s
         e = _rms(g.cpu(), ref) if dense else _rel(g.cpu(), ref)
         if not e < (1e-2 if dense else 1e-3):
             bad[k] = e
+        if dense:                                  # the same gradient against the oracle pass that took the DEVICE's ReLU gates: fp32 resolution
+            eg = _rel(g.cpu(), p2[k].grad)
+            worst_gated = max(worst_gated, eg)
+            if not eg < GATED_MAXREL_B2:
+                bad[(k, 'same gates')] = eg
+    print('train view, TRAIN.STAGE %d: %s ReLU gates differ from the CPU oracle; worst deconv / backbone gradient with the device gates injected: max-rel %.2e'
+          % (stage, flips, worst_gated))
     assert not bad, 'gradient mismatch: %s' % sorted(bad.items(), key=lambda kv: str(kv[1]))[:8]
     assert named['global_orient.fc1.weight'].grad is None
+
+
+KP2DW_DELTA = 1e-5                        # kp_2d_w vs float64, relative to the projection's condition number (measured: see the printout)
+GATED_MAXREL_B2 = 3e-4                    # the same at B = 2 over ALL 150-odd deconv / backbone gradients (small gradients: measured in the printout)
+GATED_MAXREL = 1e-4                       # B = 64 deconv / backbone gradients against the oracle run with the device's ReLU gates (measured 1.4-1.8e-5)
 
 
 def test_whmr_train_step_batch64_vs_cpu_oracle(dev, assets, state_dict):
     """BASELINE configs[3] at its per-GPU batch of 64 (only B = 2 was tested): at this size other GEMM tiles, TN split-K
     slice counts and the heavy-chain side stream engage.  fp32 numerics, stochastic depth with the SAME injected keep masks on both sides:
     loss, every supervised per-stage output, the BatchNorm running statistics and ten watched gradients (heads exactly, the ReLU-gated
-    deconv / backbone ones by RMS) against torch autograd through the CPU oracle.  ~20-40 s of CPU oracle."""
+    deconv / backbone ones by RMS) against torch autograd through the CPU oracle -- and the same gradients against a second oracle pass that takes the
+    DEVICE's ReLU gates (max-rel 1e-3), plus a float64 forward that shows the kp_2d_w outliers are conditioning.  ~1-1.5 min of CPU oracle."""
     from oracle import synth
     from oracle import train as OT
     B = 64
@@ -478,26 +504,74 @@ def test_whmr_train_step_batch64_vs_cpu_oracle(dev, assets, state_dict):
     masks = torch.floor((1 - torch.linspace(0, 0.3, 12)).repeat_interleave(2).view(-1, 1) + torch.rand(24, B, generator=torch.Generator().manual_seed(5)))
     torch.set_num_threads(min(16, max(torch.get_num_threads(), 8)))
     stats, dp_ref = {}, []
+    fmaps_ref = []
     outs_ref = OT.whmr_forward_train(p, assets, inp['x'], inp['center'], inp['scale'], inp['bbox_height'], inp['orig_shape'], inp['bbox_info'],
-                                     stats=stats, dp_out=dp_ref, drop_masks=masks, drop_path_rate=0.3)
+                                     stats=stats, dp_out=dp_ref, drop_masks=masks, drop_path_rate=0.3, fmaps_out=fmaps_ref)
     loss_ref = OT.cotangent_loss(outs_ref) + OT.dp_cotangent_loss(dp_ref[0])
     loss_ref.backward()
     m = _train_model(assets, state_dict, 'fp32', dev)
     vit = m.feature_extractor.backbone
     vit.drop_path_rate, vit.dpr, vit.drop_masks = 0.3, [v.item() for v in torch.linspace(0, 0.3, 12)], masks
     d = {k: inp[k].to(dev) for k in ('x', 'center', 'scale', 'bbox_height', 'orig_shape', 'bbox_info')}
-    out_list, _ = m(d['x'], None, d['center'], d['scale'], d['bbox_height'], d['orig_shape'], d['bbox_info'], is_train=True)
+    out_list, vis_dev = m(d['x'], None, d['center'], d['scale'], d['bbox_height'], d['orig_shape'], d['bbox_info'], is_train=True)
     loss = OT.cotangent_loss(out_list['smpl_out'], dev=dev) + OT.dp_cotangent_loss(out_list['dp_out'][0], dev=dev)
     loss.backward()
     assert abs(loss.item() - loss_ref.item()) < 1e-4 * max(1.0, abs(loss_ref.item())), (loss.item(), loss_ref.item())
+    # ---- two more evaluations of the oracle that turn the two ARGUED gates of this test into shown ones:
+    # (i) float64 (forward only): kp_2d_w = (focal (x + tx) / (z + Tz) + c) / c - 1 with the TRAINING-mode Tz head (BatchNorm1d over the 64 crops ->
+    #     sigmoid x 10).  Among 64 synthetic crops some put a joint close to the camera plane (z + Tz small) and the division amplifies fp32 rounding.
+    #     If that is the whole story, the device is as close to float64 as the CPU fp32 oracle is -- asserted below, per stage.
+    # (ii) fp32 again with the ReLU gates of the three deconv stages REPLACED by the ones the device took (its maps > 0): the gradients behind a ReLU
+    #     that sees a dense gradient (deconvs, backbone) then agree to the arithmetic's own resolution instead of ~2-4e-3 RMS.
+    def dbl(t):
+        if torch.is_tensor(t):
+            return t.detach().double() if t.is_floating_point() else t
+        if isinstance(t, dict):
+            return {k_: dbl(v_) for k_, v_ in t.items()}
+        return type(t)(dbl(v_) for v_ in t) if isinstance(t, (list, tuple)) else t
+    torch.set_default_dtype(torch.float64)
+    try:
+        p64 = {k: (v.detach().double().requires_grad_(True) if k in watch else dbl(v)) for k, v in state_dict.items()}
+        dp64 = []
+        outs64 = OT.whmr_forward_train(p64, dbl(assets), *(dbl(inp[k]) for k in ('x', 'center', 'scale', 'bbox_height', 'orig_shape', 'bbox_info')),
+                                       dp_out=dp64, drop_masks=masks.double(), drop_path_rate=0.3)
+        (OT.cotangent_loss(outs64) + OT.dp_cotangent_loss(dp64[0])).backward()
+        outs64 = [{k_: (v_.detach() if torch.is_tensor(v_) else v_) for k_, v_ in o.items()} for o in outs64]
+    finally:
+        torch.set_default_dtype(torch.float32)
+    gates = [(f.cpu() > 0) for f in vis_dev[1:]]
+    p2 = {k: (v.clone().requires_grad_(True) if k in watch else v) for k, v in state_dict.items()}
+    dp2, fm2 = [], []
+    outs_g = OT.whmr_forward_train(p2, assets, inp['x'], inp['center'], inp['scale'], inp['bbox_height'], inp['orig_shape'], inp['bbox_info'],
+                                   dp_out=dp2, drop_masks=masks, drop_path_rate=0.3, relu_gates=gates)
+    (OT.cotangent_loss(outs_g) + OT.dp_cotangent_loss(dp2[0])).backward()
+    flips = [int((g_ != (f.detach() > 0)).sum()) for g_, f in zip(gates, fmaps_ref)]
+    print('B=64 train step: ReLU gates of the 3 deconv stages that differ between the device and the CPU fp32 oracle: %s of %s'
+          % (flips, [g_.numel() for g_ in gates]))
     bad = {}
     for l in range(1, 4):
         for k in OT.TRAIN_LOSS_KEYS + ('theta', 'pred_cam_t'):
-            e = _rel(out_list['smpl_out'][l][k].detach().cpu(), outs_ref[l][k].detach())
-            # kp_2d_w = (focal (x + tx) / (z + Tz) + c) / c - 1 with the TRAINING-mode Tz head (BatchNorm1d over the 64 crops -> sigmoid x 10): among 64
-            # synthetic crops some put a joint close to the camera plane (z + Tz small), where the division amplifies fp32 rounding of both sides
-            # alike (CPU fp32 vs float64 shows the same); those outliers also set max |b|.  Gated at 1e-3; everything else at 1e-4.
-            if not e < (1e-3 if k == 'kp_2d_w' else 1e-4):
+            got, ref32, ref64 = out_list['smpl_out'][l][k].detach().cpu(), outs_ref[l][k].detach(), outs64[l][k]
+            e = _rel(got, ref32)
+            if k == 'kp_2d_w':
+                # q = focal (X + t) / ((Z + Tz) c): both sums cancel when a joint sits near the camera plane / the optical axis.  An upstream relative
+                # error delta of the joints / translation shows up as |dq| <= delta (amp_depth |q| + focal (|X| + |t|) / (|Z + Tz| c)), amp_depth =
+                # (|Z| + |Tz|) / |Z + Tz| -- the projection's own condition number.  EVERY element of the device result (no joint excluded) sits
+                # inside that bound around the float64 value with delta = KP2DW_DELTA, and so does the CPU fp32 oracle.
+                o64 = outs64[l]
+                J, T = o64['kp_3d'], o64['pred_cam_t'].unsqueeze(1)
+                c = (inp['orig_shape'][:, [1, 0]].double() / 2.0).unsqueeze(1)
+                depth = (J[..., 2:3] + T[..., 2:3]).abs().clamp_min(1e-30)
+                amp = (J[..., 2:3].abs() + T[..., 2:3].abs()) / depth
+                bound = amp * ref64.abs() + o64['focal_length'].view(-1, 1, 1) * (J[..., :2].abs() + T[..., :2].abs()) / (depth * c)
+                r_dev = ((got.double() - ref64).abs() / bound).max().item()
+                r_cpu = ((ref32.double() - ref64).abs() / bound).max().item()
+                print('B=64 train step: stage %d kp_2d_w: max-rel device vs CPU fp32 %.2e; error / condition bound vs float64: device %.2e, CPU fp32 %.2e; '
+                      'worst amplification %.0f' % (l, e, r_dev, r_cpu, amp.max().item()))
+                if not r_dev < KP2DW_DELTA:
+                    bad[(l, k, 'vs float64 / condition number')] = (r_dev, r_cpu)
+                continue
+            if not e < 1e-4:
                 bad[(l, k)] = e
     for k, v in dp_ref[0].items():
         e = _rel(out_list['dp_out'][0][k].detach().cpu(), v.detach())
@@ -513,12 +587,27 @@ def test_whmr_train_step_batch64_vs_cpu_oracle(dev, assets, state_dict):
         assert g is not None and g.shape == ref.shape, k
         dense = k.startswith('deconv_layers') or k.startswith('feature_extractor')          # behind ReLU gates that see a dense gradient: see the B = 2 test
         e = _rms(g.cpu(), ref) if dense else _rel(g.cpu(), ref)
-        print('B=64 train step: %-55s %s error %.2e' % (k, 'rms' if dense else 'max-rel', e))
-        # heads: 1e-3 at B = 2; here the few crops whose synthetic Tz puts a joint near the camera plane (see kp_2d_w above) own the largest
-        # Jacobian entries of the perspective projection AND their worst conditioning, so the max-rel of the gradients they dominate (stage
-        # regressors, the stage-3 sampler MLP) is gated at 1e-2 with the RMS error at 2e-3
-        if not e < 1e-2 or (not dense and not _rms(g.cpu(), ref) < 2e-3):
-            bad[k] = e
+        eg_max, eg_rms = _rel(g.cpu(), p2[k].grad), _rms(g.cpu(), p2[k].grad)
+        e64_dev, e64_cpu = _rel(g.cpu(), p64[k].grad), _rel(ref, p64[k].grad)
+        print('B=64 train step: %-55s %s error %.2e | same ReLU gates on both sides: max-rel %.2e, rms %.2e | max-rel vs float64: device %.2e, CPU fp32 %.2e'
+              % (k, 'rms' if dense else 'max-rel', e, eg_max, eg_rms, e64_dev, e64_cpu))
+        if dense:
+            # behind ReLUs that see a dense gradient.  As is (the reference's own gates) by RMS: each of the ~190 gates (of 264 M) that two fp32
+            # evaluations decide differently moves these gradients by ~1/sqrt(map size); with the device's gates injected into the oracle they agree
+            # to fp32 resolution (measured 1.4-1.8e-5 max-rel)
+            if not e < 1e-2:
+                bad[k] = e
+            if not (eg_max < GATED_MAXREL and eg_rms < GATED_MAXREL):
+                bad[(k, 'same gates')] = (eg_max, eg_rms)
+        else:
+            # heads, max-rel: two fp32 evaluations of one exact gradient are held to 1e-3 of each other -- or, where fp32 itself is that far from the
+            # float64 value (the stage-3 sampler MLP: 1.4e-2 on BOTH sides; crops whose synthetic Tz puts a joint near the camera plane own the
+            # largest and worst-conditioned Jacobian entries), to no more than their own distance from it; and the device is never an order of
+            # magnitude further from float64 than the reference's fp32 arithmetic
+            if not (e < 1e-3 or e <= 1.05 * max(e64_dev, e64_cpu)):
+                bad[k] = (e, e64_dev, e64_cpu)
+            if not e64_dev <= 10 * e64_cpu + 2e-4:
+                bad[(k, 'vs float64')] = (e64_dev, e64_cpu)
     assert not bad, bad
 
 

@@ -43,7 +43,7 @@ def test_vit_224_fp32_and_bf16(dev):
     out16 = _build(sd, '', (224, 224), 'bf16', dev)(x.to(dev))
     err = _rel(out16.cpu(), ref)
     print('bf16 ViT max-rel error vs fp32 reference: %.3e' % err)
-    assert err < 5e-2
+    assert err < 1.1e-2                                               # 2 x the measured 5.3e-3 (round 4; was 5e-2)
 
 
 def test_vit_full_size_properties(dev):
@@ -67,12 +67,13 @@ def test_vit_large_256x192_matches_oracle(dev):
     sd = synth.make_vit_state(3, (256, 192), embed_dim=1024, depth=2)
     x = synth.make_inputs(3, 9, (256, 192))['x']
     ref = vit_forward(sd, x, num_heads=16)
-    for numerics, tol in (('fp32', 1e-4), ('bf16', 5e-2)):
+    for numerics, tol in (('fp32', 1e-4), ('bf16', 1e-2)):                # bf16: 2 x the measured 4.3e-3
         m = ViT(img_size=(256, 192), patch_size=16, embed_dim=1024, depth=2, num_heads=16, ratio=1, mlp_ratio=4,
                 qkv_bias=True, drop_path_rate=0.5, numerics=numerics)
         m.load_state_dict(sd, strict=True)
         out = m.to(dev).eval()(x.to(dev))
         assert out.shape == (3, 1024, 16, 12)
+        print('ViT-L depth 2 %s max-rel %.2e' % (numerics, _rel(out.cpu(), ref)))
         assert _rel(out.cpu(), ref) < tol, numerics
 
 
@@ -88,7 +89,7 @@ def test_vit_large_full_depth_matches_oracle(dev):
     x = synth.make_inputs(2, 13, (256, 192))['x']
     with torch.no_grad():
         ref = vit_forward(sd, x, num_heads=16)
-    for numerics, tol, min_tokens in (('fp32', 1e-4, None), ('bf16', 8e-2, None), ('bf16', 8e-2, 0)):
+    for numerics, tol, min_tokens in (('fp32', 1e-4, None), ('bf16', 1.3e-2, None), ('bf16', 1.3e-2, 0)):      # bf16: 2 x the measured 6.2e-3 / 6.1e-3
         m = ViT(img_size=(256, 192), patch_size=16, embed_dim=1024, depth=24, num_heads=16, ratio=1, mlp_ratio=4,
                 qkv_bias=True, drop_path_rate=0.5, numerics=numerics)
         m.load_state_dict(sd, strict=True)
@@ -119,4 +120,4 @@ def test_vit_large_blocked_32_crops_properties(dev):
         ref = vit_forward(sd, x[:2], num_heads=16)
     err = _rel(full[:2].cpu(), ref)
     print('ViT-L depth 24, 32 crops, blocked bf16: max-rel %.2e on the first two crops' % err)
-    assert err < 8e-2
+    assert err < 1.4e-2                                               # 2 x the measured 6.6e-3
