@@ -732,7 +732,8 @@ def multi_rank_report(args, dist, world, dt_own, rank_map, red, dry, dev):
     if red is not None:
         waits = red.exposed_wait_ms()
         own.update(exposed_exchange_wait_ms_mean=sum(waits) / max(len(waits), 1), exposed_exchange_wait_ms_max=max(waits) if waits else 0.0,
-                   collectives_per_step=red.stats['collectives'] / max(args.steps, 1), bytes_exchanged_per_step=red.stats['bytes_exchanged'] / max(args.steps, 1),
+                   collectives_per_step=getattr(args, 'reducer_stats', red.stats)['collectives'] / max(args.steps, 1),
+                   bytes_exchanged_per_step=getattr(args, 'reducer_stats', red.stats)['bytes_exchanged'] / max(args.steps, 1),
                    buckets=len(red.buckets), bucket_bytes=[b['numel'] * 4 for b in red.buckets], unused_parameters=len(red.skipped))
     try:
         dist.all_gather_object(rows, own)
@@ -884,6 +885,7 @@ def main(argv=None):
         dt = time.perf_counter() - t0
         if red is not None:
             red.timing = False
+            args.reducer_stats = dict(red.stats)     # snapshot: the instrumented step below also exchanges gradients
         if L is not None:
             # dominant-kernel timing: one instrumented step, HIP events around every GEMM launch on the launch stream
             L.PROFILE = []

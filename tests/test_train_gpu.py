@@ -481,7 +481,7 @@ def test_whmr_train_step_fp32_matches_oracle_autograd(dev, assets, state_dict, s
 
 
 KP2DW_DELTA = 1e-5                        # kp_2d_w vs float64, relative to the projection's condition number (measured: see the printout)
-GATED_MAXREL_B2 = 3e-4                    # the same at B = 2 over ALL 150-odd deconv / backbone gradients (small gradients: measured in the printout)
+GATED_MAXREL_B2 = 3e-5                    # the same at B = 2 over ALL 150-odd deconv / backbone gradients (measured 3.7-4.6e-6, both TRAIN.STAGE layouts)
 GATED_MAXREL = 1e-4                       # B = 64 deconv / backbone gradients against the oracle run with the device's ReLU gates (measured 1.4-1.8e-5)
 
 
