@@ -1,7 +1,7 @@
 #!/bin/bash
 # One gpurun call that refreshes the round's evidence under gpurun_out/<tag>_* and writes the judged summaries straight into profiles/<tag>_*
 # (each file starts with the command that produced it and the commit it ran on -- recorded HERE, at run time; nothing is stamped afterwards).
-#   usage (repo root, on the GPU box):  bash tools/gpu_round3.sh <tag> <commit> [tests]
+#   usage (repo root, on the GPU box):  bash tools/gpu_round.sh <tag> <commit> [tests]
 set -uo pipefail
 TAG=${1:?tag}
 COMMIT=${2:?commit}
@@ -11,8 +11,8 @@ PROF=$OUT/profiles_$TAG
 mkdir -p $OUT $PROF
 export TMPDIR=/tmp
 cd $R
-fail() { echo "gpu_round3: $*" >&2; exit 1; }
-hdr() { echo "# $1"; echo "# tree: commit $COMMIT; one MI355X gpurun box, $(date -u +%Y-%m-%d); produced by tools/gpu_round3.sh $TAG"; }
+fail() { echo "gpu_round: $*" >&2; exit 1; }
+hdr() { echo "# $1"; echo "# tree: commit $COMMIT; one MI355X gpurun box, $(date -u +%Y-%m-%d); produced by tools/gpu_round.sh $TAG"; }
 if [ "${3:-}" = "tests" ]; then
   timeout 2400 python -m pytest tests -m gpu -q > $OUT/${TAG}_gpu_tests.log 2>&1
   echo "gpu tests rc=$?"; tail -3 $OUT/${TAG}_gpu_tests.log
@@ -30,6 +30,7 @@ bench vit224_fp32 --numerics fp32 --steps 5 --warmup 2 --no-cpu
 bench whmr --workload whmr
 bench whmr_bf16x3 --workload whmr --numerics bf16x3 --no-cpu --steps 10 --warmup 3
 bench whmr_train --workload whmr_train --steps 10 --warmup 3
+bench whmr_bf16x3_b1 --workload whmr --numerics bf16x3 --batch 1 --no-cpu --no-parity --steps 50 --warmup 10
 bench vit256x192 --workload vit256x192 --no-cpu
 bench vitl256x192_b32 --workload vitl256x192 --batch 32 --no-cpu
 bench whmr_b1 --workload whmr --batch 1 --no-cpu --no-parity --steps 50 --warmup 10
