@@ -627,7 +627,7 @@ def launch_ranks(args, argv):
                     found.append(out.strip())
                 else:
                     sys.stdout.write(out)
-        except ValueError:                      # pipe closed under the reader by the watchdog path
+        except ValueError:
             pass
     reader = threading.Thread(target=relay, daemon=True)
     reader.start()
@@ -652,10 +652,8 @@ def launch_ranks(args, argv):
             proc.wait(timeout=10)
         except subprocess.TimeoutExpired:
             pass
-        try:
-            proc.stdout.close()
-        except Exception:                       # noqa: BLE001
-            pass
+        # (the pipe is NOT closed from here: closing a file another thread is blocked reading can block in turn; once the tree is dead the relay
+        #  thread sees EOF, and if some stranger still holds the write end the daemon thread simply dies with this process)
         reader.join(timeout=2)
         print('bench.py launcher: the %d ranks did not finish within %.0f s and were killed (agent + %d descendants)'
               % (args.gpus, args.rank_timeout, len(tree)), file=sys.stderr)
