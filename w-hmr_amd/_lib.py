@@ -205,7 +205,7 @@ PROFILE = None        # bench.py sets this to a list: (kernel, flops, start_even
 
 def gemm(a, w, out, bias=None, residual=None, res_row_mod=0, act=ACT_NONE, conv=None, scatter=None, M=None,
          lda=None, glds=True, tile=None, phases=None, res_first=False, splits=None, row_scale=None, accumulate=False,
-         trans_a=False, trans_w=False, pre_out=None, gelu_bwd_of=None):
+         trans_a=False, trans_w=False, pre_out=None, gelu_bwd_of=None, split3_out=None):
     """out = act(a . w^T + bias) + residual.  a/w dtype selects the kernel (bf16 MFMA or exact-fp32 MFMA).
 
     conv = dict(IH, IW, Cin, OH, OW, KW, SH, SW, PH, PW): a is an NHWC image [B, IH, IW, Cin], rows are output pixels.
@@ -276,6 +276,11 @@ def gemm(a, w, out, bias=None, residual=None, res_row_mod=0, act=ACT_NONE, conv=
     p.N, p.K = N, K
     p.epi_flags |= (16 if trans_a else 0) | (32 if trans_w else 0) | (128 if gelu_bwd_of is not None else 0)
     p.C2 = pre_out.data_ptr() if pre_out is not None else None
+    if split3_out is not None:              # bf16 kernel, fp32 out: also write the [hi | lo | hi] split-bf16 operand form of `out` (3 N channels per row / pixel)
+        _dev(split3_out)
+        assert a.dtype == torch.bfloat16 and out.dtype == torch.float32 and pre_out is None and split3_out.dtype == torch.bfloat16
+        assert split3_out.is_contiguous() and split3_out.numel() == 3 * out.numel() and out.is_contiguous() and N % 4 == 0
+        p.C2, p.epi_flags = split3_out.data_ptr(), p.epi_flags | 256
     if phases is not None:                  # dict(cy, cx): 4 stacked phase matrices w[4, N, K] (sub-pixel deconv)
         assert a.dtype == torch.bfloat16 and conv is not None and scatter is not None and w.shape[0] == 4
         p.n_phase, p.phase_w_stride, p.phase_cy, p.phase_cx = 4, N * K, phases['cy'], phases['cx']

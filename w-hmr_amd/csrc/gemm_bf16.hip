@@ -48,6 +48,15 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const whmr_gemm p,
     const size_t off = (size_t)m * p.ldc + n;
     if (p.out_bf16) *(uint2*)((bf16_t*)p.C + off) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
     else *(float4*)((float*)p.C + off) = make_float4(v[0], v[1], v[2], v[3]);
+    if (!p.out_bf16 && (p.epi_flags & 256)) {                       // split-bf16 copy [hi | lo | hi] of the fp32 row (gemm_params.h)
+        uint32_t h0, l0, h1, l1;
+        split_bf16x2(v[0], v[1], h0, l0);
+        split_bf16x2(v[2], v[3], h1, l1);
+        bf16_t* d = (bf16_t*)p.C2 + 3 * (size_t)m * p.ldc + n;
+        *(uint2*)d = make_uint2(h0, h1);
+        *(uint2*)(d + p.N) = make_uint2(l0, l1);
+        *(uint2*)(d + 2 * p.N) = make_uint2(h0, h1);
+    }
 }
 
 struct tile_cfg { int id, bm, bn, per_cu, eff_pct; };
@@ -69,7 +78,8 @@ extern "C" int whmr_set_option(int key, int value) {
 extern "C" int whmr_gemm_bf16_split(const whmr_gemm* pp, int tile, int splits_in, void* stream) {
     const whmr_gemm& p = *pp;
     if (!p.workspace || p.n_phase > 1 || p.c_mode != 0 || (p.N & 3) || (p.ldc & 3) || (p.ldr & 3) || (p.K % 64)) return (int)hipErrorInvalidValue;
-    if (p.C2 || (p.epi_flags & (4 | 128))) return (int)hipErrorInvalidValue;      // second output / gelu' product / C-addressed skip: packed epilogue of the unsplit kernel only
+    if ((p.C2 && !(p.epi_flags & 256)) || (p.epi_flags & (4 | 128))) return (int)hipErrorInvalidValue;      // second output / gelu' product / C-addressed skip: packed epilogue of the unsplit kernel only
+    if ((p.epi_flags & 256) && (p.out_bf16 || p.ldc != p.N)) return (int)hipErrorInvalidValue;
     long splits = splits_in;
     while (splits > 1 && splits * p.M * p.N * 4 > p.workspace_bytes) --splits;
     if (splits <= 1) return (int)hipErrorInvalidValue;
@@ -77,6 +87,7 @@ extern "C" int whmr_gemm_bf16_split(const whmr_gemm* pp, int tile, int splits_in
     splits = (p.K + kps - 1) / kps;
     whmr_gemm q = p;
     q.C = p.workspace; q.out_bf16 = 0; q.act = 0; q.bias = nullptr; q.residual = nullptr; q.row_scale = nullptr; q.epi_flags = p.epi_flags & 8; q.ldc = p.N;    // bit 3 (K order of the gather) belongs to the main loop
+    q.C2 = nullptr;
     q.split_k = kps;
     const int rc = whmr_gemm_bf16_big(&q, tile, stream);
     if (rc) return rc;

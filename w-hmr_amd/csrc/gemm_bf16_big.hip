@@ -587,6 +587,23 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
             *(float4*)((float*)Cout + off) = make_float4(v[0], v[1], v[2], v[3]);
     };
 
+    // fp32 output + epi_flags bit 8: C2 also receives the split-bf16 operand form of the stored values, [hi | lo | hi] along the channel axis (3 N
+    // columns per row / pixel) -- what whmr_split3_bf16 makes of C in a pass of its own; the NEXT convolution of the bf16x3 path multiplies it
+    // by [W_hi | W_hi | W_lo].  `off` = the element offset store_vec got (row stride ldc, or the scattered pixel offset): the copy sits at 3 off.
+    const bool s3 = !OUT_BF16 && (p.epi_flags & 256);
+    auto store_s3 = [&](size_t off, const float* v) {
+        if constexpr (!OUT_BF16) {
+            const size_t row = off - ncol;                                   // start of the row / pixel
+            uint32_t h0, l0, h1, l1;
+            split_bf16x2(v[0], v[1], h0, l0);
+            split_bf16x2(v[2], v[3], h1, l1);
+            bf16_t* d = (bf16_t*)p.C2 + 3 * row + ncol;
+            *(uint2*)d = make_uint2(h0, h1);
+            *(uint2*)(d + p.N) = make_uint2(l0, l1);
+            *(uint2*)(d + 2 * p.N) = make_uint2(h0, h1);
+        }
+    };
+
     if constexpr (!GATHER && MI <= 4) {
         if (res && n0 + BN <= p.N && (p.ldc % CPT) == 0 && (p.ldr % (res_bf16 ? CPT : 4)) == 0) {   // block-uniform: the two paths have different barrier sequences
             // ---- fast residual path (proj / fc2 / patch-embed; ResNet conv3 + bf16 skip): all residual rows of a pass are
@@ -636,7 +653,10 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
                         }
                     }
                     if (res_first) activate(v);
-                    if (m < m_end && (p.res_row_mod != -2003 || v[0] == 12345.678f)) store_vec((size_t)m * p.ldc + ncol, v);
+                    if (m < m_end && (p.res_row_mod != -2003 || v[0] == 12345.678f)) {
+                        store_vec((size_t)m * p.ldc + ncol, v);
+                        if (s3) store_s3((size_t)m * p.ldc + ncol, v);
+                    }
                 }
                 lds_barrier();                                   // slab consumed: the next pass may overwrite it
                 if (i + 1 < MI) prefetch_res(i + 1);
@@ -699,6 +719,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
                 if (v[0] == 12345.678f) store_vec(crow + ncol, v);
             } else if (vec_ok) {
                 store_vec(crow + ncol, v);
+                if (s3) store_s3(crow + ncol, v);
             } else {
 #pragma unroll 1
                 for (int e = 0; e < CPT; ++e) {
@@ -760,6 +781,11 @@ extern "C" int whmr_gemm_bf16_big(const whmr_gemm* pp, int tile, void* stream) {
     if (p.a_mode == 1 && (p.Cin % 64 || !p.zeros)) return (int)hipErrorInvalidValue;
     if (p.a_mode == 0 && (p.lda % 8)) return (int)hipErrorInvalidValue;
     // the second output / the gelu' product exist on the packed bf16 epilogue only: bf16 output, row-major C with 16-B rows, no split-K, no row factors
+    if (p.epi_flags & 256) {
+        // split-bf16 copy of an fp32 output: fp32 C with dense rows (ldc == N when not scattered), N a multiple of 4 (8-byte pieces); the split-K route
+        // hands the copy to splitk_epilogue_kernel (whmr_gemm_bf16_split clears the flag on the slice launches)
+        if (!p.C2 || p.out_bf16 || (p.N & 3) || (p.c_mode == 0 && p.ldc != p.N) || p.split_k) return (int)hipErrorInvalidValue;
+    } else
     if (p.C2 && !(p.act == 1 && p.out_bf16 && !p.residual && p.c_mode == 0 && !(p.N & 7) && !(p.ldc & 7) && !p.row_scale && !p.split_k && p.res_row_mod == 0))
         return (int)hipErrorInvalidValue;
     if ((p.epi_flags & 128) && !(p.residual && (p.epi_flags & 1) && !(p.epi_flags & 6) && p.act == 0 && p.out_bf16 && p.c_mode == 0 && !(p.N & 7) && !(p.ldc & 7) &&

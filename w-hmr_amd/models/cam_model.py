@@ -154,18 +154,20 @@ def _run_blocks_x3(P, x):
     """layer1-4 in the bf16x3 numerics: fp32 NHWC maps between the convolutions; every convolution = ONE launch of the bf16 MFMA kernel on the
     K-concatenated split operands ([x_hi | x_lo | x_hi] . [W_hi | W_hi | W_lo]^T = the three split products, fp32 accumulate; bias, skip and ReLU
     in its fp32 epilogue).  The block input is split once for conv1 and the downsample conv."""
-    dev, f32 = x.device, torch.float32
+    dev, f32, bf = x.device, torch.float32, torch.bfloat16
     B = x.shape[0]
-    for blk in P['blocks']:
+    x3 = L.split3(x)                                                               # [B, IH, IW, 3 Cin] bf16 (the max-pool output: the only separate split pass)
+    nblk = len(P['blocks'])
+    for bi, blk in enumerate(P['blocks']):
         _, IH, IW, Cin = x.shape
         s = blk['stride']
         OH, OW = (IH - 1) // s + 1, (IW - 1) // s + 1
         planes = blk['c1'][0].shape[0]
-        x3 = L.split3(x)                                                           # [B, IH, IW, 3 Cin] bf16
-        y1 = torch.empty(B, IH, IW, planes, dtype=f32, device=dev)
-        L.gemm(x3, blk['c1'][0], y1, bias=blk['c1'][1], act=L.ACT_RELU)
-        y2 = torch.empty(B, OH, OW, planes, dtype=f32, device=dev)
-        L.gemm(L.split3(y1), blk['c2'][0], y2, bias=blk['c2'][1], act=L.ACT_RELU,
+        # every convolution writes the split-bf16 operand form of its fp32 output next to it (epi_flags bit 8): no split pass between the layers
+        y1, y1s = torch.empty(B, IH, IW, planes, dtype=f32, device=dev), torch.empty(B, IH, IW, 3 * planes, dtype=bf, device=dev)
+        L.gemm(x3, blk['c1'][0], y1, bias=blk['c1'][1], act=L.ACT_RELU, split3_out=y1s)
+        y2, y2s = torch.empty(B, OH, OW, planes, dtype=f32, device=dev), torch.empty(B, OH, OW, 3 * planes, dtype=bf, device=dev)
+        L.gemm(y1s, blk['c2'][0], y2, bias=blk['c2'][1], act=L.ACT_RELU, split3_out=y2s,
                conv=dict(IH=IH, IW=IW, Cin=3 * planes, OH=OH, OW=OW, KW=3, SH=s, SW=s, PH=1, PW=1))
         if blk['down'] is None:
             skip = x
@@ -177,8 +179,9 @@ def _run_blocks_x3(P, x):
                 L.gemm(x3, blk['down'][0], skip, bias=blk['down'][1],
                        conv=dict(IH=IH, IW=IW, Cin=3 * Cin, OH=OH, OW=OW, KW=1, SH=s, SW=s, PH=0, PW=0))
         out = torch.empty(B, OH, OW, planes * 4, dtype=f32, device=dev)
-        L.gemm(L.split3(y2), blk['c3'][0], out, bias=blk['c3'][1], act=L.ACT_RELU, residual=skip.view(-1, planes * 4), res_first=True)
-        x = out
+        outs = torch.empty(B, OH, OW, 12 * planes, dtype=bf, device=dev) if bi + 1 < nblk else None
+        L.gemm(y2s, blk['c3'][0], out, bias=blk['c3'][1], act=L.ACT_RELU, residual=skip.view(-1, planes * 4), res_first=True, split3_out=outs)
+        x, x3 = out, outs
     return x
 
 

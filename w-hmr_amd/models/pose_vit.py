@@ -100,6 +100,7 @@ class ViT(nn.Module):
         self._ws = {}
         self.blocked = True                 # bf16 inference on the blocked-layout kernels when the shapes allow it
         self.blocked_min_tokens = 2048      # ... and the batch has at least this many tokens (set 0 to force the blocked path)
+        self.x3_min_tokens = 320            # bf16x3: below this many tokens (one 224^2 / 256x192 crop) the exact-f32 path is the faster parity-grade one
         self.ln_fold = True                 # ... with norm1 / norm2 folded into the qkv / fc1 GEMMs (no LayerNorm pass inside the blocks)
         import os
         self.ln_fold_x3 = os.environ.get('WHMR_X3_FOLD', '1') != '0'      # the same fold in the bf16x3 pipeline (A/B: tools/r3_x3ab.sh)
@@ -169,10 +170,12 @@ class ViT(nn.Module):
         hid_dim = self.blocks[0].mlp.fc1.weight.shape[0] if self.depth else D
         self._eff = 'fp32' if self.numerics == 'fp32' else 'bf16'
         if self.numerics == 'bf16x3':
-            if D % 256 == 0 and hid_dim % 256 == 0 and D // self.num_heads == 64 and 64 < N <= 256 and P % 8 == 0 and (Cin * P * P) % 32 == 0:
+            if (M >= self.x3_min_tokens and D % 256 == 0 and hid_dim % 256 == 0 and D // self.num_heads == 64 and 64 < N <= 256 and P % 8 == 0
+                    and (Cin * P * P) % 32 == 0):
                 return self._forward_tokens_x3(x, B, Hp, Wp), (B, Hp, Wp)
             # the split-bf16 kernels are built for the ViTPose shapes (dim % 256 == 0, head dim 64, 64 < tokens <= 256 per image); any other
-            # shape keeps the parity-grade contract on the exact-f32 MFMA path below
+            # shape keeps the parity-grade contract on the exact-f32 MFMA path below -- and so does ONE crop: a few blocked tiles walk K alone
+            # (ViT-B 256x192 at batch 1 under a graph: 2.03 ms split-bf16 vs 1.40 ms exact-f32; from two crops up the split kernels win: 2.1 vs 8.5 ms at 8)
             self._eff = 'fp32'
         dt = torch.float32 if self._eff == 'fp32' else torch.bfloat16
         # below ~2k tokens (batch <= 10 at 192 tokens) the launches are latency-bound and the row-major kernels' smaller tiles + split-K win
