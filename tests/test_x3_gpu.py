@@ -136,6 +136,61 @@ def test_attention_blk_x3(dev, N):
     assert err < 2e-5
 
 
+def test_gemm_epilogue_writes_the_split3_operand_form(dev):
+    """epi_flags bit 8 of whmr_gemm_bf16 (round 4): an fp32 output also leaves its split-bf16 operand form [hi | lo | hi] -- bit for bit what
+    whmr_split3_bf16 makes of that output in a pass of its own -- on every epilogue route the bf16x3 path uses: plain rows with bias + ReLU, the
+    residual-before-ReLU route of a ResNet block, the split-K route (few tiles, deep K), a strided 3x3 convolution gather, and the four
+    scattered sub-pixel phases of a deconvolution."""
+    from whmr_amd import _lib as L
+    g = torch.Generator().manual_seed(3)
+
+    def check(out, s3):
+        ref = L.split3(out.contiguous())
+        assert torch.equal(s3.view(ref.shape), ref)
+    # plain rows, M tail inside a tile, bias + ReLU
+    M, N, K = 1000, 256, 192
+    a = torch.randn(M, K, generator=g).bfloat16().to(dev)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).bfloat16().to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    out, s3 = torch.empty(M, N, device=dev), torch.full((M, 3 * N), float('nan'), device=dev, dtype=torch.bfloat16)
+    L.gemm(a, w, out, bias=bias, act=L.ACT_RELU, split3_out=s3)
+    assert _rel(out.cpu(), F.relu(a.float().cpu() @ w.float().cpu().t() + bias.cpu())) < 1e-5
+    check(out, s3)
+    # fp32 skip added before the ReLU (conv3 of a bottleneck block)
+    skip = torch.randn(M, N, generator=g).to(dev)
+    L.gemm(a, w, out, bias=bias, act=L.ACT_RELU, residual=skip, res_first=True, split3_out=s3)
+    assert _rel(out.cpu(), F.relu(a.float().cpu() @ w.float().cpu().t() + bias.cpu() + skip.cpu())) < 1e-5
+    check(out, s3)
+    # split-K route: 475 x 512 x 4608 (the chooser slices K: tests/test_kernels_gpu.py::test_gemm_bf16_split_k)
+    M2, N2, K2 = 475, 512, 4608
+    a2 = torch.randn(M2, K2, generator=g).bfloat16().to(dev)
+    w2 = (torch.randn(N2, K2, generator=g) / math.sqrt(K2)).bfloat16().to(dev)
+    out2, s32 = torch.empty(M2, N2, device=dev), torch.full((M2, 3 * N2), float('nan'), device=dev, dtype=torch.bfloat16)
+    L.gemm(a2, w2, out2, act=L.ACT_RELU, split3_out=s32)
+    assert _rel(out2.cpu(), F.relu(a2.float().cpu() @ w2.float().cpu().t())) < 2e-5
+    check(out2, s32)
+    # strided 3x3 convolution gather (NHWC, 64 channels)
+    B, H, W, Ci, Co = 2, 11, 9, 64, 128
+    x = torch.randn(B, H, W, Ci, generator=g).bfloat16().to(dev)
+    wc = (torch.randn(Co, 3, 3, Ci, generator=g) / 24).bfloat16().to(dev)
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y, ys = torch.empty(B, OH, OW, Co, device=dev), torch.full((B, OH, OW, 3 * Co), float('nan'), device=dev, dtype=torch.bfloat16)
+    L.gemm(x, wc.view(Co, -1), y, split3_out=ys, conv=dict(IH=H, IW=W, Cin=Ci, OH=OH, OW=OW, KW=3, SH=2, SW=2, PH=1, PW=1))
+    refc = F.conv2d(x.float().cpu().permute(0, 3, 1, 2), wc.float().cpu().permute(0, 3, 1, 2), stride=2, padding=1).permute(0, 2, 3, 1)
+    assert _rel(y.cpu(), refc) < 1e-5
+    check(y, ys)
+    # deconvolution as four scattered sub-pixel phases in one launch (whmr.py:488-498; the product's own call, models/whmr.py::_deconv)
+    Hd, Wd, Cd = 5, 4, 64
+    xd = torch.randn(B, Hd, Wd, Cd, generator=g).bfloat16().to(dev)
+    ph = (torch.randn(4, 256, 4 * Cd, generator=g) / 16).bfloat16().to(dev)
+    od = torch.full((B, 2 * Hd, 2 * Wd, 256), float('nan'), device=dev)
+    ods = torch.full((B, 2 * Hd, 2 * Wd, 768), float('nan'), device=dev, dtype=torch.bfloat16)
+    L.gemm(xd, ph, od, act=L.ACT_RELU, split3_out=ods, conv=dict(IH=Hd, IW=Wd, Cin=Cd, OH=Hd, OW=Wd, KW=2, SH=1, SW=1, PH=1, PW=1),
+           scatter=dict(c_off=0, osb=4 * Hd * Wd * 256, osy=4 * Wd * 256, osx=2 * 256), phases=dict(cy=2 * Wd * 256, cx=256))
+    assert torch.isfinite(od).all()                                     # every output pixel of every phase was written ...
+    check(od, ods)                                                      # ... and so was its split form
+
+
 def _vit(sd, size, dev, numerics, dim=768, depth=12, heads=12):
     from whmr_amd.models.pose_vit import ViT
     m = ViT(img_size=size, patch_size=16, embed_dim=dim, depth=depth, num_heads=heads, ratio=1, mlp_ratio=4, qkv_bias=True, numerics=numerics)
