@@ -23,6 +23,10 @@
 #include <cstdlib>
 #include "common.h"
 
+#ifndef TN_NS4
+#define TN_NS4 3          // ring slots of the 256-row ping-pong tile; 4 (three steps ahead, 128 KB) measured 0.3 ms SLOWER per training step (22.05 vs 21.73 ms, one box)
+#endif
+
 typedef __attribute__((address_space(3))) void tn_lds_void_t;
 typedef const __attribute__((address_space(1))) void tn_gbl_void_t;
 
@@ -68,11 +72,17 @@ struct tn_params {
     const bf16_t* zeros;      // >= 512 B of zeros
 };
 
-template <int MI, bool GATHER>   // wave rows own MI 32-row blocks: BM = 64 MI
+// PP (round 4): the two wave rows are two GROUPS half a step apart (the blocked forward kernel's schedule, gemm_blk16_impl.h SCHED 1): per 32-row step a
+// group runs MEM (all fragment reads of the step + its share of the DMA two steps ahead + the counted wait) and MFMA (16 MFMAs from registers), with
+// ONE barrier per step; group 0 walks a step as [MFMA | MEM], group 1 as [MEM | MFMA], so on every SIMD one wave feeds the matrix pipe while its
+// partner waits for LDS.  In the lock-step loop (PP = false) both waves of a SIMD issue their fragment reads at the same time and the pipe idles
+// for the LDS round trip, twice per step.
+template <int MI, bool GATHER, bool PP>   // wave rows own MI 32-row blocks: BM = 64 MI
 __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const tn_params p) {
     constexpr int BM = 64 * MI, BN = 256, BK = 32;
     constexpr int CHA = BM / 8, CHB = BN / 8;                 // 16-B chunks per tile row
     constexpr int A_BYTES = BK * BM * 2, B_BYTES = BK * BN * 2, SLOT = A_BYTES + B_BYTES;
+    constexpr int NS = (PP && MI == 4) ? TN_NS4 : 3;          // ring slots: the ping-pong loop of the 256-row tile may run 3 steps ahead (4 x 32 KB)
     constexpr int UNITS = SLOT / 1024, UPW = (UNITS + 7) / 8; // 1-KiB DMA units per step; per wave 4 (BM 256), 3 (BM 128), 3 or 2 (BM 64: 20 units)
     constexpr int REM = UNITS % 8;                            // waves < REM issue UPW units, the others UPW - 1 (REM == 0: all UPW)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -128,7 +138,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const tn_params p) {
         }
     }
     auto stage = [&](int kt) {
-        const int slot = kt % 3;
+        const int slot = kt % NS;
 #pragma unroll
         for (int i = 0; i < UPW; ++i) {
             if (i == UPW - 1 && !dma_full) continue;
@@ -167,6 +177,75 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const tn_params p) {
 
     if (nkt > 0) stage(0);
     if (nkt > 1) stage(1);
+    if constexpr (NS == 4) { if (nkt > 2) stage(2); }
+    if constexpr (PP) {
+        tn_raw qa[2][MI], qb[2][2];                                             // the fragments of one step (both 16-row halves)
+        auto MEM = [&](int x) {
+            const uint32_t ta = lds0 + (x % NS) * SLOT, tb = ta + A_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) tn_frag_issue<CHB>(qb[ks][j], tb, ks * 16, wn * 64 + j * 32, lane);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) tn_frag_issue<CHA>(qa[ks][i], ta, ks * 16, wm * (32 * MI) + i * 32, lane);
+            }
+            // slot (x + NS - 1) % NS held step x - 1: both groups read it in MEM(x - 1), one barrier ago at the latest
+            if (x + NS - 1 < nkt) stage(x + NS - 1);
+            // own share of step x + 1 has landed; the younger steps (x + 2 .. x + NS - 1, as far as they exist) may fly
+            const int young = (nkt - 2 - x) < (NS - 2) ? (nkt - 2 - x) : (NS - 2);
+            if (young >= 2) { if (dma_full) tn_wait_vmcnt<2 * UPW>(); else tn_wait_vmcnt<2 * (UPW - 1)>(); }
+            else if (young == 1) { if (dma_full) tn_wait_vmcnt<UPW>(); else tn_wait_vmcnt<UPW - 1>(); }
+            else tn_wait_vmcnt<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto MFMA = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8_t fb[2], fa[MI];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fb[j] = tn_frag_value(qb[ks][j]);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) fa[i] = tn_frag_value(qa[ks][i]);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                if (do_db) {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) {
+                        const uint32_t w[4] = {qa[ks][i].x.x, qa[ks][i].x.y, qa[ks][i].y.x, qa[ks][i].y.y};
+                        float t = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) t += __uint_as_float(w[e] << 16) + __uint_as_float(w[e] & 0xffff0000u);
+                        dbs[i] += t;
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if (nkt > 0) {
+            {                                                                   // own share of step 0 (steps 1 .. NS - 2 may fly)
+                const int young = (nkt - 1) < (NS - 2) ? (nkt - 1) : (NS - 2);
+                if (young >= 2) { if (dma_full) tn_wait_vmcnt<2 * UPW>(); else tn_wait_vmcnt<2 * (UPW - 1)>(); }
+                else if (young == 1) { if (dma_full) tn_wait_vmcnt<UPW>(); else tn_wait_vmcnt<UPW - 1>(); }
+                else tn_wait_vmcnt<0>();
+            }
+            __builtin_amdgcn_s_barrier();
+            MEM(0);
+            if (wm == 1) MFMA();                                                // group 1 is half a step ahead
+            for (int k = 0; k < nkt; ++k) {
+                __builtin_amdgcn_s_barrier();
+                if (wm == 0) MFMA();                                            // MFMA(k)
+                if (k + 1 < nkt) {
+                    MEM(k + 1);
+                    if (wm == 1) MFMA();                                        // MFMA(k + 1)
+                }
+            }
+        }
+    } else
     for (int kt = 0; kt < nkt; ++kt) {
         if (kt + 1 < nkt) { if (dma_full) tn_wait_vmcnt<UPW>(); else tn_wait_vmcnt<UPW - 1>(); }      // own share of step kt has landed (step kt + 1 may fly)
         else tn_wait_vmcnt<0>();
@@ -256,10 +335,10 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
     *(float4*)(C + (size_t)m * ldc + n) = a;
 }
 
-template <int MI, bool GATHER>
-static int launch_tn(tn_params p, int tiles, int splits, hipStream_t st) {
-    constexpr int LDS = 3 * (32 * 64 * MI * 2 + 32 * 256 * 2);
-    auto kern = gemm_tn_kernel<MI, GATHER>;
+template <int MI, bool GATHER, bool PP>
+static int launch_tn_pp(tn_params p, int tiles, int splits, hipStream_t st) {
+    constexpr int LDS = ((PP && MI == 4) ? TN_NS4 : 3) * (32 * 64 * MI * 2 + 32 * 256 * 2);
+    auto kern = gemm_tn_kernel<MI, GATHER, PP>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -271,6 +350,12 @@ static int launch_tn(tn_params p, int tiles, int splits, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(tiles * splits), dim3(512), LDS, st, p);
     WHMR_CHECK_LAUNCH();
     return 0;
+}
+
+static int g_tn_pp = [] { const char* e = getenv("WHMR_TN_PP"); return e ? (e[0] == '1' ? 1 : 0) : 1; }();     // A/B: 0 = the lock-step loop of round 2-3
+template <int MI, bool GATHER>
+static int launch_tn(tn_params p, int tiles, int splits, hipStream_t st) {
+    return g_tn_pp ? launch_tn_pp<MI, GATHER, true>(p, tiles, splits, st) : launch_tn_pp<MI, GATHER, false>(p, tiles, splits, st);
 }
 
 static int tn_run(tn_params p, int splits, void* workspace, long workspace_bytes, hipStream_t st) {
