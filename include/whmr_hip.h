@@ -51,7 +51,9 @@ struct whmr_gemm {
                              * 64-channel slice are walked before the next slice, so the window overlap of a large-kernel conv on a map that
                              * exceeds the Infinity Cache is re-read from cache instead of HBM (Tz-head 7x7 s3 conv);
                              * bit 8 (fp32 C): C2 also receives the split-bf16 operand form of C, [hi | lo | hi] along the channel axis (3 N per row / pixel):
-                             * the K-concatenated activation operand of the next convolution of the bf16x3 numerics, without a whmr_split3_bf16 pass */
+                             * the K-concatenated activation operand of the next convolution of the bf16x3 numerics, without a whmr_split3_bf16 pass;
+                             * bit 9 (with bit 8): only [hi | lo] (2 N per row / pixel) -- the operand of a narrow convolution that takes the W_lo product
+                             * as extra OUTPUT columns instead of a third K slice (the Tz head's 7x7 s3 convolution, N = 64: bound by its A bytes) */
     int64_t phase_w_stride, phase_cy, phase_cx;
     int64_t split_k;        /* internal (set by the bf16 launcher, pass 0): K elements per split-K slice, blockIdx.z = slice */
     const float* row_scale; /* optional [M]: act(acc + bias) is multiplied by row_scale[m] BEFORE the (post-activation) residual is added --
@@ -321,7 +323,8 @@ int whmr_attention_bwd(const void* qkv, const void* o, const float* dout, const 
                        float scale, void* stream);
 
 /* Second convolution of the Tz head (whmr.py:420 + the reshape at :571): Conv2d(64,5,k7,s2) on the NHWC map x [B,IH,IW,64]
- * (bf16 or fp32), weights w [5][7*7][64] fp32 -> tokens [B,5,OH*OW] fp32. */
+ * (x_bf16 = 1: bf16, 0: fp32; 2: fp32 [B,IH,IW,128] whose channel halves c and 64 + c are added as they are read -- the bf16x3 form of the first
+ * convolution leaves its W_lo product in columns 64..127), weights w [5][7*7][64] fp32 -> tokens [B,5,OH*OW] fp32. */
 int whmr_tz_conv1(const void* x, int x_bf16, const float* w, float* tok, int B, int IH, int IW, void* stream);
 
 /* estimate_translation (utils/geometry.py:344-408; trainer host stall): S [B,J,3], joints_2d [B,J,3] = (x, y, conf);

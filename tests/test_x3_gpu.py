@@ -156,6 +156,10 @@ def test_gemm_epilogue_writes_the_split3_operand_form(dev):
     L.gemm(a, w, out, bias=bias, act=L.ACT_RELU, split3_out=s3)
     assert _rel(out.cpu(), F.relu(a.float().cpu() @ w.float().cpu().t() + bias.cpu())) < 1e-5
     check(out, s3)
+    # two-part form [hi | lo] (epi_flags bit 9: the operand of the Tz head's N-concatenated first convolution)
+    s2 = torch.full((M, 2 * N), float('nan'), device=dev, dtype=torch.bfloat16)
+    L.gemm(a, w, out, bias=bias, act=L.ACT_RELU, split3_out=s2, split_parts=2)
+    assert torch.equal(s2, s3[:, :2 * N])
     # fp32 skip added before the ReLU (conv3 of a bottleneck block)
     skip = torch.randn(M, N, generator=g).to(dev)
     L.gemm(a, w, out, bias=bias, act=L.ACT_RELU, residual=skip, res_first=True, split3_out=s3)

@@ -205,7 +205,7 @@ PROFILE = None        # bench.py sets this to a list: (kernel, flops, start_even
 
 def gemm(a, w, out, bias=None, residual=None, res_row_mod=0, act=ACT_NONE, conv=None, scatter=None, M=None,
          lda=None, glds=True, tile=None, phases=None, res_first=False, splits=None, row_scale=None, accumulate=False,
-         trans_a=False, trans_w=False, pre_out=None, gelu_bwd_of=None, split3_out=None):
+         trans_a=False, trans_w=False, pre_out=None, gelu_bwd_of=None, split3_out=None, split_parts=3):
     """out = act(a . w^T + bias) + residual.  a/w dtype selects the kernel (bf16 MFMA or exact-fp32 MFMA).
 
     conv = dict(IH, IW, Cin, OH, OW, KW, SH, SW, PH, PW): a is an NHWC image [B, IH, IW, Cin], rows are output pixels.
@@ -279,8 +279,8 @@ def gemm(a, w, out, bias=None, residual=None, res_row_mod=0, act=ACT_NONE, conv=
     if split3_out is not None:              # bf16 kernel, fp32 out: also write the [hi | lo | hi] split-bf16 operand form of `out` (3 N channels per row / pixel)
         _dev(split3_out)
         assert a.dtype == torch.bfloat16 and out.dtype == torch.float32 and pre_out is None and split3_out.dtype == torch.bfloat16
-        assert split3_out.is_contiguous() and split3_out.numel() == 3 * out.numel() and out.is_contiguous() and N % 4 == 0
-        p.C2, p.epi_flags = split3_out.data_ptr(), p.epi_flags | 256
+        assert split_parts in (2, 3) and split3_out.is_contiguous() and split3_out.numel() == split_parts * out.numel() and out.is_contiguous() and N % 4 == 0
+        p.C2, p.epi_flags = split3_out.data_ptr(), p.epi_flags | 256 | (512 if split_parts == 2 else 0)       # 2 parts: [hi | lo] only
     if phases is not None:                  # dict(cy, cx): 4 stacked phase matrices w[4, N, K] (sub-pixel deconv)
         assert a.dtype == torch.bfloat16 and conv is not None and scatter is not None and w.shape[0] == 4
         p.n_phase, p.phase_w_stride, p.phase_cy, p.phase_cx = 4, N * K, phases['cy'], phases['cx']
@@ -1075,11 +1075,14 @@ def attention_bwd_f32(qkv, dout, B, N, H, d, scale):
 
 
 def tz_conv1(x_nhwc, w, tok):
-    """x [B,IH,IW,64] (bf16 / fp32) , w [5,49,64] fp32 -> tok [B,5,OH*OW] fp32 (whmr.py:420 + the reshape at :571)."""
+    """x [B,IH,IW,64] (bf16 / fp32) -- or fp32 [B,IH,IW,128] whose channel halves are ADDED as they are read (the bf16x3 conv0 leaves the W_lo product
+    in columns 64..127) -- , w [5,49,64] fp32 -> tok [B,5,OH*OW] fp32 (whmr.py:420 + the reshape at :571)."""
     _dev(x_nhwc, w, tok)
     B, IH, IW, Cc = x_nhwc.shape
-    assert Cc == 64 and x_nhwc.is_contiguous() and w.dtype == torch.float32 and w.is_contiguous() and tok.is_contiguous()
-    _check(lib().whmr_tz_conv1(x_nhwc.data_ptr(), int(x_nhwc.dtype == torch.bfloat16), w.data_ptr(), tok.data_ptr(), B, IH, IW, _stream()),
+    assert Cc in (64, 128) and x_nhwc.is_contiguous() and w.dtype == torch.float32 and w.is_contiguous() and tok.is_contiguous()
+    assert Cc == 64 or x_nhwc.dtype == torch.float32
+    mode = 2 if Cc == 128 else int(x_nhwc.dtype == torch.bfloat16)
+    _check(lib().whmr_tz_conv1(x_nhwc.data_ptr(), mode, w.data_ptr(), tok.data_ptr(), B, IH, IW, _stream()),
            'whmr_tz_conv1')
     return tok
 

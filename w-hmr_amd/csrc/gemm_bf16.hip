@@ -52,10 +52,11 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const whmr_gemm p,
         uint32_t h0, l0, h1, l1;
         split_bf16x2(v[0], v[1], h0, l0);
         split_bf16x2(v[2], v[3], h1, l1);
-        bf16_t* d = (bf16_t*)p.C2 + 3 * (size_t)m * p.ldc + n;
+        const int parts = (p.epi_flags & 512) ? 2 : 3;
+        bf16_t* d = (bf16_t*)p.C2 + parts * (size_t)m * p.ldc + n;
         *(uint2*)d = make_uint2(h0, h1);
         *(uint2*)(d + p.N) = make_uint2(l0, l1);
-        *(uint2*)(d + 2 * p.N) = make_uint2(h0, h1);
+        if (parts == 3) *(uint2*)(d + 2 * p.N) = make_uint2(h0, h1);
     }
 }
 

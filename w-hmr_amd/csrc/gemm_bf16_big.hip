@@ -597,10 +597,16 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_bf16_big_kernel(const
             uint32_t h0, l0, h1, l1;
             split_bf16x2(v[0], v[1], h0, l0);
             split_bf16x2(v[2], v[3], h1, l1);
-            bf16_t* d = (bf16_t*)p.C2 + 3 * row + ncol;
-            *(uint2*)d = make_uint2(h0, h1);
-            *(uint2*)(d + p.N) = make_uint2(l0, l1);
-            *(uint2*)(d + 2 * p.N) = make_uint2(h0, h1);
+            if (p.epi_flags & 512) {                                         // two parts only: [hi | lo] (2 N per row / pixel)
+                bf16_t* d = (bf16_t*)p.C2 + 2 * row + ncol;
+                *(uint2*)d = make_uint2(h0, h1);
+                *(uint2*)(d + p.N) = make_uint2(l0, l1);
+            } else {
+                bf16_t* d = (bf16_t*)p.C2 + 3 * row + ncol;
+                *(uint2*)d = make_uint2(h0, h1);
+                *(uint2*)(d + p.N) = make_uint2(l0, l1);
+                *(uint2*)(d + 2 * p.N) = make_uint2(h0, h1);
+            }
         }
     };
 

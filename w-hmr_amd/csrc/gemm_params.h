@@ -29,7 +29,9 @@ struct whmr_gemm {
                              * 64-channel slice are walked before the next slice, so the window overlap of a large-kernel conv on a map that
                              * exceeds the Infinity Cache is re-read from cache instead of HBM (Tz-head 7x7 s3 conv);
                              * bit 8 (fp32 C): C2 also receives the split-bf16 operand form of C, [hi | lo | hi] along the channel axis (3 N per row / pixel):
-                             * the K-concatenated activation operand of the next convolution of the bf16x3 numerics, without a whmr_split3_bf16 pass */
+                             * the K-concatenated activation operand of the next convolution of the bf16x3 numerics, without a whmr_split3_bf16 pass;
+                             * bit 9 (with bit 8): only [hi | lo] (2 N per row / pixel) -- the operand of a narrow convolution that takes the W_lo product
+                             * as extra OUTPUT columns instead of a third K slice (the Tz head's 7x7 s3 convolution, N = 64: bound by its A bytes) */
     int64_t phase_w_stride, phase_cy, phase_cx;
     int64_t split_k;        /* internal (set by the bf16 launcher, pass 0): K elements per split-K slice, blockIdx.z = slice */
     const float* row_scale; /* optional [M]: act(acc + bias) is multiplied by row_scale[m] BEFORE the (post-activation) residual is added --

@@ -5,21 +5,26 @@
 // launches on the pipelined skinny GEMM -- 5 tokens per image give every weight load only 5 FMAs; dropped.)
 #include "common.h"
 
-template <typename T>
+// PAIR (fp32 only): the map has 128 channels per pixel and channel c of the convolution's input is x[c] + x[64 + c] -- the bf16x3 form of conv0 leaves the
+// hi.hi + lo.hi products in columns 0..63 and the hi.lo product in columns 64..127 (models/whmr.py::_tz_operands); they are added as they are read.
+template <typename T, bool PAIR = false>
 __global__ __launch_bounds__(256) void tz_conv1_kernel(const T* __restrict__ x, const float* __restrict__ w /*[5][49][64]*/,
                                                        float* __restrict__ tok, int B, int IH, int IW, int OH, int OW) {
+    constexpr int CS = PAIR ? 128 : 64;                     // channels per pixel in memory
     const int lane = threadIdx.x & 63;
     const int pix = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int npix = OH * OW;
     if (pix >= B * npix) return;
     const int b = pix / npix, p = pix - b * npix;
     const int oy = p / OW, ox = p - oy * OW;
-    const T* xb = x + ((size_t)b * IH * IW) * 64 + lane;
+    const T* xb = x + ((size_t)b * IH * IW) * CS + lane;
     float a[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     for (int ky = 0; ky < 7; ++ky)
 #pragma unroll
         for (int kx = 0; kx < 7; ++kx) {
-            const float v = io<T>::ld(xb + ((size_t)(oy * 2 + ky) * IW + (ox * 2 + kx)) * 64);
+            const T* xp = xb + ((size_t)(oy * 2 + ky) * IW + (ox * 2 + kx)) * CS;
+            float v = io<T>::ld(xp);
+            if constexpr (PAIR) v += io<T>::ld(xp + 64);
             const float* wt = w + (ky * 7 + kx) * 64 + lane;
 #pragma unroll
             for (int n = 0; n < 5; ++n) a[n] = fmaf(v, wt[n * 49 * 64], a[n]);
@@ -36,7 +41,8 @@ extern "C" int whmr_tz_conv1(const void* x, int x_bf16, const float* w, float* t
     if (B <= 0 || OH <= 0 || OW <= 0) return (int)hipErrorInvalidValue;
     const int waves = B * OH * OW;
     hipStream_t st = (hipStream_t)stream;
-    if (x_bf16) hipLaunchKernelGGL(tz_conv1_kernel<bf16_t>, dim3((waves + 3) / 4), dim3(256), 0, st, (const bf16_t*)x, w, tok, B, IH, IW, OH, OW);
+    if (x_bf16 == 2) hipLaunchKernelGGL((tz_conv1_kernel<float, true>), dim3((waves + 3) / 4), dim3(256), 0, st, (const float*)x, w, tok, B, IH, IW, OH, OW);
+    else if (x_bf16) hipLaunchKernelGGL(tz_conv1_kernel<bf16_t>, dim3((waves + 3) / 4), dim3(256), 0, st, (const bf16_t*)x, w, tok, B, IH, IW, OH, OW);
     else hipLaunchKernelGGL(tz_conv1_kernel<float>, dim3((waves + 3) / 4), dim3(256), 0, st, (const float*)x, w, tok, B, IH, IW, OH, OW);
     WHMR_CHECK_LAUNCH();
     return 0;

@@ -390,10 +390,14 @@ class WHMR(nn.Module):
 
         def build():
             w0 = c0.detach().permute(0, 2, 3, 1)                                             # [64, ky, kx, ci]
-            if self.numerics == 'bf16x3':            # [W_hi | W_hi | W_lo] per tap, then the chunk-major K order of the bf16 kernel
-                w3 = L.split3_weight(w0.float().contiguous())
-                n, kh, kw, ci = w3.shape
-                w0 = w3.reshape(n, kh * kw, ci // 64, 64).permute(0, 2, 1, 3).reshape(n, -1).contiguous()
+            if self.numerics == 'bf16x3':
+                # N = 64 makes this convolution A-traffic bound, so the W_lo product goes into 64 extra OUTPUT columns instead of a third K slice:
+                # activation [x_hi | x_lo] (2 C per pixel) against rows n < 64: [W_hi | W_hi] (hi.hi + lo.hi), rows 64 + n: [W_lo | 0] (hi.lo);
+                # tz_conv1 adds the column halves as it reads them.  Then the chunk-major K order of the bf16 kernel.
+                hi, lo = L.split_bf16(w0.float().contiguous())
+                w2 = torch.cat([torch.cat([hi, hi], -1), torch.cat([lo, torch.zeros_like(lo)], -1)], 0)        # [128, ky, kx, 2 ci]
+                n, kh, kw, ci = w2.shape
+                w0 = w2.reshape(n, kh * kw, ci // 64, 64).permute(0, 2, 1, 3).reshape(n, -1).contiguous()
             elif self._dt == torch.float32:
                 w0 = w0.reshape(c0.shape[0], -1).contiguous()                              # [64, (ky,kx,ci)]
             else:   # chunk-major K order (epi_flags bit 3): (ci chunk of 64, ky, kx, ci in chunk) -- window overlap re-read from cache
@@ -418,12 +422,16 @@ class WHMR(nn.Module):
             xs = getattr(x_nhwc, 'whmr_split3', None)
             if xs is None:
                 xs = L.split3(x_nhwc)
-            out_s3 = torch.empty(B, 2 * H, 2 * W, 3 * Cout, dtype=torch.bfloat16, device=x_nhwc.device)
-            L.gemm(xs, phases, out, bias=shift, act=L.ACT_RELU, split3_out=out_s3,
+            parts = 2 if i == len(self.deconv_layers) // 3 - 1 else 3      # the last map feeds the Tz convolution only: [hi | lo]
+            out_s3 = torch.empty(B, 2 * H, 2 * W, parts * Cout, dtype=torch.bfloat16, device=x_nhwc.device)
+            L.gemm(xs, phases, out, bias=shift, act=L.ACT_RELU, split3_out=out_s3, split_parts=parts,
                    conv=dict(IH=H, IW=W, Cin=3 * Cin, OH=H, OW=W, KW=2, SH=1, SW=1, PH=1, PW=1),
                    scatter=dict(c_off=0, osb=4 * H * W * Cout, osy=4 * W * Cout, osx=2 * Cout),
                    phases=dict(cy=2 * W * Cout, cx=Cout))
-            out.whmr_split3 = out_s3
+            if parts == 3:
+                out.whmr_split3 = out_s3
+            else:
+                out.whmr_split2 = out_s3
             return out
         if self._dt != torch.float32:          # all 4 sub-pixel phases in one launch (4x the tiles to fill the CUs)
             L.gemm(x_nhwc, phases, out, bias=shift, act=L.ACT_RELU,
@@ -445,12 +453,12 @@ class WHMR(nn.Module):
         w0, w1, bn4 = self._tz_operands()
         assert (C, self.conv[1].weight.shape[0], self.conv[0].weight.shape[0]) == (256, 5, 64)
         H1, W1 = (H - 7) // 3 + 1, (W - 7) // 3 + 1
-        y0 = torch.empty(B, H1, W1, 64, dtype=self._dt, device=dev)                  # NHWC, mode dtype (feeds the 2nd conv)
+        y0 = torch.empty(B, H1, W1, 128 if self.numerics == 'bf16x3' else 64, dtype=self._dt, device=dev)     # NHWC, mode dtype (feeds the 2nd conv)
         if self.numerics == 'bf16x3':
-            fs = getattr(f_nhwc, 'whmr_split3', None)                          # left by the last deconv stage's epilogue
+            fs = getattr(f_nhwc, 'whmr_split2', None)                          # [hi | lo], left by the last deconv stage's epilogue
             if fs is None:
-                fs = L.split3(f_nhwc)
-            L.gemm(fs, w0, y0.view(-1, 64), conv=dict(IH=H, IW=W, Cin=3 * C, OH=H1, OW=W1, KW=7, SH=3, SW=3, PH=0, PW=0, chunk_major=True))
+                fs = torch.cat(L.split_bf16(f_nhwc), -1).contiguous()
+            L.gemm(fs, w0, y0.view(-1, 128), conv=dict(IH=H, IW=W, Cin=2 * C, OH=H1, OW=W1, KW=7, SH=3, SW=3, PH=0, PW=0, chunk_major=True))
         else:
             L.gemm(f_nhwc, w0, y0.view(-1, 64), conv=dict(IH=H, IW=W, Cin=C, OH=H1, OW=W1, KW=7, SH=3, SW=3, PH=0, PW=0,
                                                           chunk_major=self._dt != torch.float32))
