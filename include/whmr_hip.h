@@ -164,6 +164,21 @@ int whmr_gemm_f32_set_big(int on);
 int whmr_gemm_tn_bf16(const void* A, long lda, const void* B, long ldb, float* C, long ldc, float* db, int Mo, int No, int K, int splits,
                       void* workspace, long workspace_bytes, void* stream);
 
+/* The same product for up to 4 Linears that share the reduction length K (= tokens) in ONE launch: the weight gradients of one transformer layer
+ * (qkv, proj, fc1, fc2 of vit.py:61-165 under loss.backward()).  One by one each of them slices K 7-28 ways to own the chip and moves ~65 MB of
+ * fp32 partial tiles through the workspace twice; together their 108 tiles fill it with two slices.  Every item: Mo % 256 == 0, No % 256 == 0,
+ * otherwise the envelope above; db nullable.  Deterministic (fixed slice order); with another slice count than the single launch the last bits
+ * differ.  workspace (fp32 partials): >= sum over items of splits * Mo * (No + 1) * 4 bytes with splits = 256 / (total 256 x 256 tiles), else
+ * the launch runs unsliced.  hipErrorInvalidValue outside the envelope (the caller then issues the single launches). */
+struct whmr_tn_item {
+    const void* A; long lda;      /* [K, lda >= Mo] bf16: dY */
+    const void* B; long ldb;      /* [K, ldb >= No] bf16: X  */
+    float* C; long ldc;           /* [Mo, ldc >= No] fp32: dW */
+    float* db;                    /* [Mo] fp32 column sums of A, or null */
+    int Mo, No;
+};
+int whmr_gemm_tn_bf16_group(const struct whmr_tn_item* items, int n_items, int K, void* workspace, long workspace_bytes, void* stream);
+
 /* Convolution weight gradient without a column matrix (same kernel, the B operand gathered): C [Mo, KH*KW*GC] (fp32) = A^T . col(img) with
  * A [K = nB*OH*OW, lda] bf16 (one row per position of the OH x OW grid) and img [nB, IH, IW, ldp >= GC] bf16 NHWC; column (tap = ky*KW + kx, c) of
  * reduction row (b, oy, ox) is img[b, oy*S + ky - P, ox*S + kx - P, c], zero outside the image.  Autograd of Conv2d (A = dY over the output

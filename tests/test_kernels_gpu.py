@@ -170,6 +170,39 @@ def test_gemm_tn(dev, K, Mo, No, splits):
     assert not L.gemm_tn_ok(ad[:, :40], bd) and not L.gemm_tn_ok(ad[:-1], bd[:-1])
 
 
+@pytest.mark.parametrize('K,shapes', [(12288, [(768, 3072), (3072, 768), (768, 768), (2304, 768)]), (4096, [(1024, 1024), (3072, 1024)]),
+                                      (96, [(256, 256), (512, 256), (256, 512)]), (2048, [(4096, 1024), (1024, 4096), (1024, 1024), (3072, 1024)])])
+def test_gemm_tn_group(dev, K, shapes):
+    """the weight gradients of one transformer layer in ONE launch (whmr_gemm_tn_bf16_group): every product against float64 and against the single
+    launch (same kernel body, another slice count: last bits only), bias sums included, bitwise repeatable; ViT-B (two slices), a 2-item group,
+    a K too short to slice, ViT-L (208 tiles: unsliced, direct stores)"""
+    from whmr_amd import _lib as L
+    g = torch.Generator().manual_seed(K + len(shapes))
+    jobs, refs = [], []
+    for i, (Mo, No) in enumerate(shapes):
+        a = (torch.randn(K, Mo + 64, generator=g) * 0.5).bfloat16()
+        b = (torch.randn(K, No, generator=g) * 0.5).bfloat16()
+        ad, bd = a.to(dev)[:, 32:32 + Mo], b.to(dev)
+        out = torch.full((Mo, No), float('nan'), device=dev)
+        db = torch.full((Mo,), float('nan'), device=dev) if i != 1 else None
+        jobs.append((ad, bd, out, db))
+        refs.append(((a[:, 32:32 + Mo].double().t() @ b.double()).float(), a[:, 32:32 + Mo].double().sum(0).float()))
+    assert L.gemm_tn_group_ok(jobs)
+    L.gemm_tn_group(jobs)
+    first = [(o.clone(), None if d is None else d.clone()) for _, _, o, d in jobs]
+    for (ad, bd, out, db), (ref, dref) in zip(jobs, refs):
+        assert _rel(out.cpu(), ref) < 2e-5
+        assert db is None or _rel(db.cpu(), dref) < 2e-5
+        single = torch.empty_like(out)
+        L.gemm_tn(ad, bd, single)
+        assert _rel(out.cpu(), single.cpu()) < 2e-6
+    for _, _, o, d in jobs:
+        o.fill_(float('nan'))
+    L.gemm_tn_group(jobs)
+    assert all(torch.equal(o, f[0]) and (d is None or torch.equal(d, f[1])) for (_, _, o, d), f in zip(jobs, first))
+    assert not L.gemm_tn_group_ok(jobs + jobs + jobs) and not L.gemm_tn_group_ok([(jobs[0][0][:, :128], jobs[0][1], None, None)])
+
+
 def test_conv_dw_tn(dev):
     """convolution weight gradients from the gathering TN kernel (no column matrix) against torch autograd on the CPU: 3x3 s1 p1 (IUV head),
     7x7 s3 p0 (Tz head) and ConvTranspose2d k4 s2 p1 (deconv stages), incl. forced split-K"""

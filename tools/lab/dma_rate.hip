@@ -1,0 +1,84 @@
+// Per-CU load-rate probe: how many bytes per second does ONE CU pull from L2 through each path when its 8 waves issue nothing else?
+//   mode 0  global_load_lds_dwordx4 (LDS-DMA, 1 KiB per wave instruction) into a ring of LDS slots
+//   mode 1  global_load_dwordx4 into registers (no LDS write)
+//   mode 2  global_load_dwordx4 into registers + ds_write_b128 of the previous batch (register-staged copy to LDS)
+// Every workgroup streams over the same `span` bytes (L2 / MALL resident after the first pass), 16 B per lane, `depth` loads in flight per wave.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/lab/dma_rate.hip -o tools/lab/dma_rate && tools/lab/dma_rate [blocks]
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+
+template <int MODE, int DEPTH>
+__global__ __launch_bounds__(512) void probe(const char* __restrict__ src, long span, int iters, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // wave w of block b walks pieces of 1 KiB: piece index p -> byte (p * 8 + w) * 1024 (the 8 waves of a block read 8 KiB rows), offset by the block
+    const char* base = src + wave * 1024 + lane * 16;
+    long off = (((long)blockIdx.x * 37) % (span / 8192)) * 8192;
+    uint32_t acc = 0;
+    uint4 r[DEPTH];
+#pragma unroll
+    for (int j = 0; j < DEPTH; ++j) r[j] = make_uint4(0, 0, 0, 0);
+    for (int it = 0; it < iters; ++it) {
+        if (MODE == 2) {                                                        // previous batch -> LDS
+#pragma unroll
+            for (int j = 0; j < DEPTH; ++j) *(uint4*)(smem + ((j * 8 + wave) * 1024 + lane * 16)) = r[j];
+        }
+#pragma unroll
+        for (int j = 0; j < DEPTH; ++j) {
+            const char* p = base + off;
+            off += 8192;
+            if (off + 8192 > span) off = 0;
+            if (MODE == 0) __builtin_amdgcn_global_load_lds((gbl_void_t*)p, (lds_void_t*)(smem + (j * 8 + wave) * 1024), 16, 0, 0);
+            else r[j] = *(const uint4*)p;
+        }
+        if (MODE == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else {
+#pragma unroll
+            for (int j = 0; j < DEPTH; ++j) acc ^= r[j].x ^ r[j].w;
+        }
+    }
+    if (MODE == 0) { __syncthreads(); acc = ((uint32_t*)smem)[tid]; }
+    if (acc == 0x12345678u) out[0] = (float)acc;
+}
+
+template <int MODE, int DEPTH>
+static void run(const char* name, const char* src, long span, int blocks, float* out) {
+    auto k = probe<MODE, DEPTH>;
+    CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    const int iters = 4000 / DEPTH;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(512), 96 * 1024, 0, src, span, 50, out);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(512), 96 * 1024, 0, src, span, iters, out);
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    const double bytes = (double)iters * DEPTH * 8192;                        // per block
+    printf("%-44s depth %2d  blocks %3d  span %4ld MB: %7.1f us  %6.1f GB/s per CU  %6.2f TB/s chip\n", name, DEPTH, blocks, span >> 20, ms * 1e3,
+           bytes / (ms * 1e-3) / 1e9, bytes * blocks / (ms * 1e-3) / 1e12);
+}
+
+int main(int argc, char** argv) {
+    const int blocks = argc > 1 ? atoi(argv[1]) : 256;
+    const long span = (argc > 2 ? atol(argv[2]) : 8) << 20;
+    char* src; float* out;
+    CK(hipMalloc(&src, span + 65536)); CK(hipMalloc(&out, 64));
+    CK(hipMemset(src, 1, span + 65536));
+    for (int rep = 0; rep < 2; ++rep) {
+        run<0, 4>("global_load_lds_dwordx4 (LDS-DMA)", src, span, blocks, out);
+        run<0, 8>("global_load_lds_dwordx4 (LDS-DMA)", src, span, blocks, out);
+        run<1, 4>("global_load_dwordx4 -> registers", src, span, blocks, out);
+        run<1, 8>("global_load_dwordx4 -> registers", src, span, blocks, out);
+        run<2, 4>("global_load_dwordx4 -> registers -> ds_write", src, span, blocks, out);
+        run<2, 8>("global_load_dwordx4 -> registers -> ds_write", src, span, blocks, out);
+    }
+    return 0;
+}

@@ -60,12 +60,19 @@ class WhmrMafWeights(C.Structure):
                 ('w2t', C.c_void_p), ('b2', C.c_void_p), ('w0b', C.c_void_p), ('w1b', C.c_void_p), ('w2b', C.c_void_p)]
 
 
+class WhmrTnItem(C.Structure):
+    """struct whmr_tn_item (include/whmr_hip.h): one product of a grouped weight-gradient launch"""
+    _fields_ = [('A', C.c_void_p), ('lda', C.c_long), ('B', C.c_void_p), ('ldb', C.c_long), ('C', C.c_void_p), ('ldc', C.c_long),
+                ('db', C.c_void_p), ('Mo', C.c_int32), ('No', C.c_int32)]
+
+
 _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_long
 _SIGS = {
     'whmr_gemm_bf16': [C.POINTER(WhmrGemm), _I, _P],
     'whmr_gemm_f32': [C.POINTER(WhmrGemm), _I, _P],
     'whmr_gemm_f32_set_big': [_I],
     'whmr_gemm_tn_bf16': [_P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _I, _P, _L, _P],
+    'whmr_gemm_tn_bf16_group': [C.POINTER(WhmrTnItem), _I, _I, _P, _L, _P],
     'whmr_conv_dw_tn_bf16': [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _L, _P, _P],
     'whmr_gemm_bf16_big': [C.POINTER(WhmrGemm), _I, _P],
     'whmr_gemm_bf16_split': [C.POINTER(WhmrGemm), _I, _I, _P],
@@ -859,6 +866,30 @@ def gemm_tn(a, b, out, splits=0, db=None):
                                    a.shape[0], int(splits), ws.data_ptr(), ws.numel(), _stream()), 'whmr_gemm_tn_bf16')
     _profile_end(ev, 'gemm_bf16', 2.0 * a.shape[0] * a.shape[1] * b.shape[1])
     return out
+
+
+def gemm_tn_group_ok(jobs):
+    """envelope of whmr_gemm_tn_bf16_group for jobs = [(a [K, Mo], b [K, No], out, db | None), ...]"""
+    return (0 < len(jobs) <= 4 and all(gemm_tn_ok(a, b) and a.shape[1] % 256 == 0 and a.shape[0] == jobs[0][0].shape[0] for a, b, _, _ in jobs))
+
+
+def gemm_tn_group(jobs):
+    """out_i [Mo_i, No_i] fp32 = a_i^T . b_i (+ db_i = column sums of a_i) for up to 4 products over the same K in ONE launch (the weight gradients
+    of a transformer layer: two K slices instead of 7-28 per product)"""
+    assert gemm_tn_group_ok(jobs)
+    items = (WhmrTnItem * len(jobs))()
+    flops = 0.0
+    for it, (a, b, out, db) in zip(items, jobs):
+        _dev(a, b, out)
+        assert out.dtype == torch.float32 and out.shape == (a.shape[1], b.shape[1]) and out.stride(1) == 1
+        assert db is None or (db.dtype == torch.float32 and db.is_contiguous() and db.numel() == a.shape[1])
+        it.A, it.lda, it.B, it.ldb, it.C, it.ldc = a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0)
+        it.db, it.Mo, it.No = _ptr(db), a.shape[1], b.shape[1]
+        flops += 2.0 * a.shape[0] * a.shape[1] * b.shape[1]
+    ws = splitk_workspace(jobs[0][0].device)
+    ev = _profile_begin()
+    _check(lib().whmr_gemm_tn_bf16_group(items, len(jobs), jobs[0][0].shape[0], ws.data_ptr(), ws.numel(), _stream()), 'whmr_gemm_tn_bf16_group')
+    _profile_end(ev, 'gemm_bf16', flops)
 
 
 def conv_dw_tn_ok(a, img):

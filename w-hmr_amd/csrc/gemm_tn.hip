@@ -20,9 +20,13 @@
 // weight gradient read the same pixels one shift apart), and the 32 CUs of an XCD walking ~1-4 slices side by side find them in their own
 // L2 -- dispatched round-robin, the tiles of a slice sat on 8 different XCDs and every one of them fetched the rows again (4.5x the unique
 // bytes for the 768 x 2304 gradient, 9x for the IUV head's).
+#include <algorithm>
 #include <cstdlib>
 #include "common.h"
 
+#ifndef TN_LAB
+#define TN_LAB 0          // tools/lab/tn_lab.hip only (timing ablations, wrong results): 1 no MFMAs, 2 no fragment reads, 4 no LDS-DMA
+#endif
 #ifndef TN_NS4
 #define TN_NS4 3          // ring slots of the 256-row ping-pong tile; 4 (three steps ahead, 128 KB) measured 0.3 ms SLOWER per training step (22.05 vs 21.73 ms, one box)
 #endif
@@ -77,26 +81,24 @@ struct tn_params {
 // ONE barrier per step; group 0 walks a step as [MFMA | MEM], group 1 as [MEM | MFMA], so on every SIMD one wave feeds the matrix pipe while its
 // partner waits for LDS.  In the lock-step loop (PP = false) both waves of a SIMD issue their fragment reads at the same time and the pipe idles
 // for the LDS round trip, twice per step.
+// One (tile, K range) of a product: the body of both kernels below.  `out` (row stride ldo) receives the tile -- the result itself or a split-K partial --
+// and `dbo` (when the product carries a bias gradient) the column sums of A over the same K range.
 template <int MI, bool GATHER, bool PP>   // wave rows own MI 32-row blocks: BM = 64 MI
-__global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const tn_params p) {
+__device__ __forceinline__ void tn_body(const tn_params& p, char* smem, int tile, int k_begin, int k_end, float* __restrict__ out, long ldo,
+                                        float* __restrict__ dbo) {
     constexpr int BM = 64 * MI, BN = 256, BK = 32;
     constexpr int CHA = BM / 8, CHB = BN / 8;                 // 16-B chunks per tile row
     constexpr int A_BYTES = BK * BM * 2, B_BYTES = BK * BN * 2, SLOT = A_BYTES + B_BYTES;
     constexpr int NS = (PP && MI == 4) ? TN_NS4 : 3;          // ring slots: the ping-pong loop of the 256-row tile may run 3 steps ahead (4 x 32 KB)
     constexpr int UNITS = SLOT / 1024, UPW = (UNITS + 7) / 8; // 1-KiB DMA units per step; per wave 4 (BM 256), 3 (BM 128), 3 or 2 (BM 64: 20 units)
     constexpr int REM = UNITS % 8;                            // waves < REM issue UPW units, the others UPW - 1 (REM == 0: all UPW)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int l31 = lane & 31, hi = lane >> 5;
     const int tiles_n = p.No / BN;
-    const int lid = p.round_robin ? (int)blockIdx.x : xcd_remap(blockIdx.x, p.tiles * p.splits);
-    const int slice = lid / p.tiles, tile = lid - slice * p.tiles;
     const int tm = tile / tiles_n, tn = tile % tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
-    const int k_begin = slice * p.k_per_split;
-    const int k_end = min(p.K, k_begin + p.k_per_split);
     const int nkt = (k_end - k_begin) / BK;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(tn_lds_void_t*)smem;
     const bool dma_full = (REM == 0) || (wave < REM);
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const tn_params p) {
             } else {
                 src = usrc[i] + (size_t)kt * (isA ? stepA : stepB);
             }
-            __builtin_amdgcn_global_load_lds((tn_gbl_void_t*)src, (tn_lds_void_t*)(smem + slot * SLOT + u * 1024), 16, 0, 0);
+            if (!(TN_LAB & 4)) __builtin_amdgcn_global_load_lds((tn_gbl_void_t*)src, (tn_lds_void_t*)(smem + slot * SLOT + u * 1024), 16, 0, 0);
         }
     };
     f32x16_t acc[MI][2];
@@ -180,23 +182,31 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const tn_params p) {
     if constexpr (NS == 4) { if (nkt > 2) stage(2); }
     if constexpr (PP) {
         tn_raw qa[2][MI], qb[2][2];                                             // the fragments of one step (both 16-row halves)
+        unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};                    // TN_LAB & 8: s_memtime stamps of step 60
+        bool rec = false;
+#define TN_STAMP(i) do { if ((TN_LAB & 8) && rec) st[i] = __builtin_amdgcn_s_memtime(); } while (0)
         auto MEM = [&](int x) {
             const uint32_t ta = lds0 + (x % NS) * SLOT, tb = ta + A_BYTES;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
+                if (TN_LAB & 2) continue;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) tn_frag_issue<CHB>(qb[ks][j], tb, ks * 16, wn * 64 + j * 32, lane);
 #pragma unroll
                 for (int i = 0; i < MI; ++i) tn_frag_issue<CHA>(qa[ks][i], ta, ks * 16, wm * (32 * MI) + i * 32, lane);
             }
+            TN_STAMP(2);
             // slot (x + NS - 1) % NS held step x - 1: both groups read it in MEM(x - 1), one barrier ago at the latest
             if (x + NS - 1 < nkt) stage(x + NS - 1);
+            TN_STAMP(3);
             // own share of step x + 1 has landed; the younger steps (x + 2 .. x + NS - 1, as far as they exist) may fly
             const int young = (nkt - 2 - x) < (NS - 2) ? (nkt - 2 - x) : (NS - 2);
             if (young >= 2) { if (dma_full) tn_wait_vmcnt<2 * UPW>(); else tn_wait_vmcnt<2 * (UPW - 1)>(); }
             else if (young == 1) { if (dma_full) tn_wait_vmcnt<UPW>(); else tn_wait_vmcnt<UPW - 1>(); }
             else tn_wait_vmcnt<0>();
+            TN_STAMP(4);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            TN_STAMP(5);
             __builtin_amdgcn_sched_barrier(0);
         };
         auto MFMA = [&]() {
@@ -212,7 +222,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const tn_params p) {
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                        if (!(TN_LAB & 1)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
                 if (do_db) {
 #pragma unroll
                     for (int i = 0; i < MI; ++i) {
@@ -238,13 +248,19 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const tn_params p) {
             if (wm == 1) MFMA();                                                // group 1 is half a step ahead
             for (int k = 0; k < nkt; ++k) {
                 __builtin_amdgcn_s_barrier();
+                if (TN_LAB & 8) { if (k == 61) { rec = true; TN_STAMP(7); } rec = k == 60; TN_STAMP(0); }
                 if (wm == 0) MFMA();                                            // MFMA(k)
+                if (wm == 0) TN_STAMP(1);
                 if (k + 1 < nkt) {
                     MEM(k + 1);
                     if (wm == 1) MFMA();                                        // MFMA(k + 1)
+                    if (wm == 1) TN_STAMP(6);
                 }
             }
+            if ((TN_LAB & 8) && lane == 0 && blockIdx.x == 8 && p.ws)           // lab: the stamps of one block, per wave, 96 MB into the workspace
+                for (int i = 0; i < 8; ++i) ((unsigned long long*)(p.ws + (24u << 20)))[wave * 8 + i] = st[i];
         }
+#undef TN_STAMP
     } else
     for (int kt = 0; kt < nkt; ++kt) {
         if (kt + 1 < nkt) { if (dma_full) tn_wait_vmcnt<UPW>(); else tn_wait_vmcnt<UPW - 1>(); }      // own share of step kt has landed (step kt + 1 may fly)
@@ -284,7 +300,6 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const tn_params p) {
         }
     }
     if (do_db) {
-        float* dbo = p.ws ? p.ws + (size_t)p.splits * p.Mo * p.No + (size_t)slice * p.Mo : p.db;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const float v = dbs[i] + __shfl_xor(dbs[i], 32, 64);
@@ -292,8 +307,6 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const tn_params p) {
         }
     }
     // D[row = (r & 3) + 8 (r >> 2) + 4 hi][col = l31]: for a fixed r the 32 lanes of a half-wave write 128 contiguous bytes
-    float* out = p.ws ? p.ws + (size_t)slice * p.Mo * p.No : p.C;
-    const long ldo = p.ws ? p.No : p.ldc;
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -305,6 +318,76 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const tn_params p) {
                 out[(size_t)m * ldo + n] = acc[i][j][r];
             }
         }
+}
+
+template <int MI, bool GATHER, bool PP>
+__global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const tn_params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lid = p.round_robin ? (int)blockIdx.x : xcd_remap(blockIdx.x, p.tiles * p.splits);
+    const int slice = lid / p.tiles, tile = lid - slice * p.tiles;
+    const int k_begin = slice * p.k_per_split;
+    const int k_end = min(p.K, k_begin + p.k_per_split);
+    tn_body<MI, GATHER, PP>(p, smem, tile, k_begin, k_end, p.ws ? p.ws + (size_t)slice * p.Mo * p.No : p.C, p.ws ? (long)p.No : p.ldc,
+                            p.ws ? p.ws + (size_t)p.splits * p.Mo * p.No + (size_t)slice * p.Mo : p.db);
+}
+
+// Grouped launch (round 4): the weight gradients of ONE transformer layer (qkv, proj, fc1, fc2: 27 + 9 + 36 + 36 tiles of 256 x 256 at D = 768, all over
+// the same K = tokens) in one grid.  Launched one by one each product slices K 7-28 ways to own the chip (~250 blocks), i.e. every launch writes and
+// re-reads ~65 MB of fp32 partial tiles (a third of its time: 12 us of stores behind a 47 us main loop + a 13 us reduce); together 108 tiles fill the
+// chip with TWO slices -- a quarter of the partial traffic, one prologue / epilogue per 192 steps instead of four per 162.  Block order = (product,
+// slice, tile) with the XCD remap of the single launch: the tiles of one slice of one product sit on one XCD (qkv: 27 = 216 / 8) and share its L2.
+#define TN_GROUP_MAX 4
+struct whmr_tn_item {             // include/whmr_hip.h
+    const void* A; long lda;
+    const void* B; long ldb;
+    float* C; long ldc;
+    float* db;
+    int Mo, No;
+};
+struct tn_group {
+    tn_params it[TN_GROUP_MAX];
+    int first[TN_GROUP_MAX];      // first logical block of every product
+    int n, total;
+};
+
+template <typename F> __device__ __forceinline__ auto tn_pick(const tn_group& g, int i, F f) {
+    auto v = f(g.it[0]);
+#pragma unroll
+    for (int j = 1; j < TN_GROUP_MAX; ++j)
+        if (i == j) v = f(g.it[j]);
+    return v;
+}
+
+template <bool PP>
+__global__ __launch_bounds__(512, 2) void gemm_tn_group_kernel(const tn_group g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lid = xcd_remap(blockIdx.x, g.total);
+    int i = 0;
+#pragma unroll
+    for (int j = 1; j < TN_GROUP_MAX; ++j)
+        if (j < g.n && lid >= g.first[j]) i = j;
+    tn_params p{};                                                              // uniform: every field lives in SGPRs
+    p.A = tn_pick(g, i, [](const tn_params& t) { return t.A; });
+    p.B = tn_pick(g, i, [](const tn_params& t) { return t.B; });
+    p.C = tn_pick(g, i, [](const tn_params& t) { return t.C; });
+    p.ws = tn_pick(g, i, [](const tn_params& t) { return t.ws; });
+    p.db = tn_pick(g, i, [](const tn_params& t) { return t.db; });
+    p.lda = tn_pick(g, i, [](const tn_params& t) { return t.lda; });
+    p.ldb = tn_pick(g, i, [](const tn_params& t) { return t.ldb; });
+    p.ldc = tn_pick(g, i, [](const tn_params& t) { return t.ldc; });
+    p.Mo = tn_pick(g, i, [](const tn_params& t) { return t.Mo; });
+    p.No = tn_pick(g, i, [](const tn_params& t) { return t.No; });
+    p.tiles = tn_pick(g, i, [](const tn_params& t) { return t.tiles; });
+    p.K = g.it[0].K; p.k_per_split = g.it[0].k_per_split; p.splits = g.it[0].splits;
+    int l = lid;
+#pragma unroll
+    for (int j = 1; j < TN_GROUP_MAX; ++j)
+        if (i == j) l = lid - g.first[j];
+    const int slice = l / p.tiles, tile = l - slice * p.tiles;
+    const int k_begin = slice * p.k_per_split;
+    const int k_end = min(p.K, k_begin + p.k_per_split);
+    tn_body<4, false, PP>(p, smem, tile, k_begin, k_end, p.ws ? p.ws + (size_t)slice * p.Mo * p.No : p.C, p.ws ? (long)p.No : p.ldc,
+                          p.ws ? p.ws + (size_t)p.splits * p.Mo * p.No + (size_t)slice * p.Mo : p.db);
 }
 
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ ws, int splits, int Mo, int No, float* __restrict__ C, long ldc,
@@ -396,6 +479,93 @@ extern "C" int whmr_gemm_tn_bf16(const void* A, long lda, const void* B, long ld
     tn_params p{};
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.Mo = Mo; p.No = No; p.K = K; p.db = db;
     return tn_run(p, splits, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// reduce of a grouped launch: blockIdx.y = product
+__global__ __launch_bounds__(256) void tn_reduce_group_kernel(const tn_group g) {
+    const int i = blockIdx.y;
+    const float* ws = tn_pick(g, i, [](const tn_params& t) { return t.ws; });
+    float* C = tn_pick(g, i, [](const tn_params& t) { return t.C; });
+    float* db = tn_pick(g, i, [](const tn_params& t) { return t.db; });
+    const long ldc = tn_pick(g, i, [](const tn_params& t) { return t.ldc; });
+    const int Mo = tn_pick(g, i, [](const tn_params& t) { return t.Mo; }), No = tn_pick(g, i, [](const tn_params& t) { return t.No; });
+    const int splits = g.it[0].splits;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int n4 = No >> 2;
+    if (db && idx < Mo) {
+        const float* wd = ws + (size_t)splits * Mo * No + idx;
+        float a = wd[0];
+        for (int s = 1; s < splits; ++s) a += wd[(size_t)s * Mo];
+        db[idx] = a;
+    }
+    if (idx >= (long)Mo * n4) return;
+    const int m = (int)(idx / n4), n = (int)(idx - (long)m * n4) * 4;
+    const size_t stride = (size_t)Mo * No;
+    const float* w = ws + (size_t)m * No + n;
+    float4 a = *(const float4*)w;
+    for (int s = 1; s < splits; ++s) {                                          // slice order, like tn_reduce_kernel (a grouped launch has 2-3 slices)
+        const float4 b = *(const float4*)(w + (size_t)s * stride);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    *(float4*)(C + (size_t)m * ldc + n) = a;
+}
+
+// n_items (<= 4) products over the SAME reduction length K in one launch: the weight gradients of one transformer layer.  Mo % 256 == 0 here
+// (the 256-row tile); otherwise the envelope of whmr_gemm_tn_bf16.  Results are deterministic (fixed slice order) but, with another slice count,
+// not bit-identical to the single launches.
+extern "C" int whmr_gemm_tn_bf16_group(const whmr_tn_item* items, int n_items, int K, void* workspace, long workspace_bytes, void* stream) {
+    if (!items || n_items <= 0 || n_items > TN_GROUP_MAX || K <= 0 || (K % 32)) return (int)hipErrorInvalidValue;
+    tn_group g{};
+    int tiles = 0;
+    for (int i = 0; i < n_items; ++i) {
+        const whmr_tn_item& q = items[i];
+        if (q.Mo <= 0 || q.No <= 0 || (q.Mo % 256) || (q.No % 256) || (q.lda % 8) || (q.ldb % 8) || (q.ldc % 4) || ((uintptr_t)q.A & 15) ||
+            ((uintptr_t)q.B & 15) || ((uintptr_t)q.C & 15) || q.lda < q.Mo || q.ldb < q.No || q.ldc < q.No || !q.A || !q.B || !q.C)
+            return (int)hipErrorInvalidValue;
+        tn_params& p = g.it[i];
+        p.A = (const bf16_t*)q.A; p.B = (const bf16_t*)q.B; p.C = q.C; p.lda = q.lda; p.ldb = q.ldb; p.ldc = q.ldc; p.Mo = q.Mo; p.No = q.No; p.K = K;
+        p.db = q.db;
+        p.tiles = (q.Mo / 256) * (q.No / 256);
+        tiles += p.tiles;
+    }
+    const int steps = K / 32;
+    int splits = tiles >= 192 ? 1 : 256 / tiles;                          // one round of blocks: never more blocks than CUs
+    if (splits > steps / 8) splits = steps / 8 > 0 ? steps / 8 : 1;
+    if (TN_LAB) { const char* e = getenv("TN_LAB_SPLITS"); if (e) splits = atoi(e); }
+    long need = 0;
+    for (int i = 0; i < n_items; ++i) need += (long)splits * g.it[i].Mo * (g.it[i].No + 1) * 4;
+    if (splits > 1 && (!workspace || need > workspace_bytes)) splits = 1;
+    const int sps = (steps + splits - 1) / splits;
+    splits = (steps + sps - 1) / sps;
+    float* w = (float*)workspace;
+    int first = 0;
+    for (int i = 0; i < n_items; ++i) {
+        tn_params& p = g.it[i];
+        p.k_per_split = sps * 32; p.splits = splits;
+        p.ws = splits > 1 ? w : nullptr;
+        w += (size_t)splits * p.Mo * (p.No + 1);
+        g.first[i] = first;
+        first += p.tiles * splits;
+    }
+    for (int i = n_items; i < TN_GROUP_MAX; ++i) { g.it[i] = g.it[0]; g.first[i] = first; }
+    g.n = n_items; g.total = first;
+    hipStream_t st = (hipStream_t)stream;
+    constexpr int LDS = TN_NS4 * (32 * 256 * 2 + 32 * 256 * 2);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_group_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(gemm_tn_group_kernel<true>, dim3(g.total), dim3(512), LDS, st, g);
+    WHMR_CHECK_LAUNCH();
+    if (splits > 1) {
+        long most = 0;
+        for (int i = 0; i < n_items; ++i) most = std::max(most, (long)g.it[i].Mo * (g.it[i].No >> 2));
+        hipLaunchKernelGGL(tn_reduce_group_kernel, dim3((unsigned)((most + 255) / 256), n_items), dim3(256), 0, st, g);
+        WHMR_CHECK_LAUNCH();
+    }
+    return 0;
 }
 
 // Convolution weight gradient without a column matrix: C [Mo, KH*KW*GC] = A^T . col(img), A [K = B*OH*OW, lda] bf16 (dY or X, one row per

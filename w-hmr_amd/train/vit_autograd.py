@@ -149,6 +149,9 @@ OVERLAP_DW = os.environ.get('WHMR_OVERLAP_DW', '0') != '0'
 FUSE_GELU = os.environ.get('WHMR_FUSE_GELU', '1') != '0'      # bf16 mode: GELU inside fc1's epilogue (pre-activation kept as a second output) and its
                                                                # backward inside fc2's data-gradient epilogue (A/B switch)
 USE_TN = os.environ.get('WHMR_TN_GEMM', '1') != '0'          # weight gradients on whmr_gemm_tn_bf16 (A/B switch; fp32 mode and odd shapes keep the transposed-copy path)
+# the four weight gradients of a layer in ONE launch of the TN kernel (whmr_gemm_tn_bf16_group: two K slices instead of 7-28 per product, a quarter of
+# the fp32 partial-tile traffic); A/B switch
+GROUP_DW = os.environ.get('WHMR_TN_GROUP', '1') != '0'
 _side_streams = {}
 
 
@@ -186,6 +189,18 @@ def vit_backward(m, s, dout):
     if side is not None:
         side.wait_stream(main)
 
+    pending = []                                                                       # weight-gradient products of the current layer (GROUP_DW)
+
+    def run_pending():
+        if not pending:
+            return
+        if len(pending) > 1 and L.gemm_tn_group_ok(pending):
+            L.gemm_tn_group(pending)
+        else:
+            for a_, b_, dw_, db_ in pending:
+                L.gemm_tn(a_, b_, dw_, db=db_)
+        pending.clear()
+
     def dw_branch(dy_op, x_saved, lin):
         w = lin.weight
         n_out, k_in = dy_op.shape[1], x_saved.shape[1]
@@ -197,7 +212,10 @@ def vit_backward(m, s, dout):
                 grads[lin.bias] = db
                 side_made.append(db)
             dw = torch.empty(n_out, k_in, **f32)
-            L.gemm_tn(dy_op, x_saved, dw, db=db)
+            if GROUP_DW and side is None and n_out % 256 == 0:
+                pending.append((dy_op, x_saved, dw, db))                               # launched with the layer's other three (run_pending)
+            else:
+                L.gemm_tn(dy_op, x_saved, dw, db=db)
             grads[w] = dw.view_as(w)
             side_made.append(dw)
             return
@@ -302,10 +320,12 @@ def vit_backward(m, s, dout):
         L.layernorm_bwd(a.t_in, d_h1, blk.norm1.weight, dt_grad, dt_grad, dg, db, 1e-6, cast_out=dy_next,
                         row_scale=rev[bi + 1][1].rs_mlp if (fuse_cast and bi + 1 < len(rev)) else None)   # dt_grad now = d t_in
         grads[blk.norm1.weight], grads[blk.norm1.bias] = dg, db
+        run_pending()
         flush()                                                                            # this block's gradients may start their exchange
     # t_0 = cols . Wp^T + b + (pos_embed[1:] + pos_embed[:1])
     pe = m.patch_embed.proj
     linear_bwd(dy_next if fuse_cast else _op(dt_grad, dt), s.cols, pe, need_dx=False)
+    run_pending()
     dpos = torch.empty(N * D, **f32)
     L.colsum(dt_grad.view(B, N * D), dpos)                                            # sum over the batch
     dpos = dpos.view(N, D)
