@@ -46,6 +46,54 @@ __global__ __launch_bounds__(512) void probe(const char* __restrict__ src, long 
     if (acc == 0x12345678u) out[0] = (float)acc;
 }
 
+// TN pattern: a block streams K rows of a [K, ld] bf16 matrix, 512 B (256 columns at its tile offset) per row, 32 rows per step, as 1-KiB pieces of two
+// rows each (lanes 0-31 row r, lanes 32-63 row r + 1), optionally with gemm_tn.hip's chunk swizzle; `tiles` blocks share the same rows (column tiles).
+//   SWZ 0/1; rows_wrap: K rows before wrapping (small = L2 resident, large = streaming)
+template <int SWZ, int DEPTH>
+__global__ __launch_bounds__(512) void probe_tn(const char* __restrict__ src, int ld_bytes, int rows_wrap, int tiles, int iters, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = blockIdx.x % tiles, grp = blockIdx.x / tiles;
+    const char* base = src + (size_t)grp * rows_wrap * ld_bytes + tile * 512;
+    int k = 0;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < DEPTH; ++j) {
+            // piece (wave, j): rows k + 2 (wave + 8 j) + {0, 1}
+            const int row = k + 2 * (wave + 8 * j) + (lane >> 5);
+            const int pos = lane & 31;
+            const int chunk = SWZ ? (pos ^ (4 * (row & 3))) : pos;
+            const char* p = base + (size_t)row * ld_bytes + chunk * 16;
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)p, (lds_void_t*)(smem + (j * 8 + wave) * 1024), 16, 0, 0);
+        }
+        k += 16 * DEPTH;
+        if (k + 16 * DEPTH > rows_wrap) k = 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (((uint32_t*)smem)[tid] == 0x12345678u) out[0] = 1.f;
+}
+
+template <int SWZ, int DEPTH>
+static void run_tn(const char* name, const char* src, int ld_bytes, int rows_wrap, int tiles, int blocks, float* out) {
+    auto k = probe_tn<SWZ, DEPTH>;
+    CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    const int iters = 4000 / DEPTH;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(512), 96 * 1024, 0, src, ld_bytes, rows_wrap, tiles, 50, out);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(512), 96 * 1024, 0, src, ld_bytes, rows_wrap, tiles, iters, out);
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    const double bytes = (double)iters * DEPTH * 8192;
+    printf("%-30s swz %d depth %2d ld %5d B rows %6d tiles %2d blocks %3d: %7.1f us  %6.1f GB/s per CU\n", name, SWZ, DEPTH, ld_bytes, rows_wrap, tiles, blocks, ms * 1e3,
+           bytes / (ms * 1e-3) / 1e9);
+}
+
 template <int MODE, int DEPTH>
 static void run(const char* name, const char* src, long span, int blocks, float* out) {
     auto k = probe<MODE, DEPTH>;
@@ -72,6 +120,20 @@ int main(int argc, char** argv) {
     char* src; float* out;
     CK(hipMalloc(&src, span + 65536)); CK(hipMalloc(&out, 64));
     CK(hipMemset(src, 1, span + 65536));
+    if (argc > 3) {                                              // TN pattern sweep
+        for (int rep = 0; rep < 2; ++rep)
+            for (int ld : {1536, 4608, 6144, 2048}) {
+                const int tiles = ld / 512;
+                const int groups = blocks / tiles;                   // row groups: each streams its own rows
+                for (int rows : {256, 8192}) {
+                    if ((long)groups * rows * ld > span) continue;
+                    run_tn<1, 4>("LDS-DMA, TN pattern", src, ld, rows, tiles, groups * tiles, out);
+                    run_tn<0, 4>("LDS-DMA, TN pattern", src, ld, rows, tiles, groups * tiles, out);
+                    run_tn<1, 8>("LDS-DMA, TN pattern", src, ld, rows, tiles, groups * tiles, out);
+                }
+            }
+        return 0;
+    }
     for (int rep = 0; rep < 2; ++rep) {
         run<0, 4>("global_load_lds_dwordx4 (LDS-DMA)", src, span, blocks, out);
         run<0, 8>("global_load_lds_dwordx4 (LDS-DMA)", src, span, blocks, out);

@@ -25,7 +25,10 @@
 #include "common.h"
 
 #ifndef TN_LAB
-#define TN_LAB 0          // tools/lab/tn_lab.hip only (timing ablations, wrong results): 1 no MFMAs, 2 no fragment reads, 4 no LDS-DMA
+#define TN_LAB 0          // tools/lab/tn_lab.hip only (timing ablations, wrong results): 1 no MFMAs, 2 no fragment reads, 4 no LDS-DMA, 8 stamps, 16 L2-hot operands (four-wave body)
+#endif
+#ifndef TN4_NS
+#define TN4_NS 4          // ring slots of the four-wave body (32 KB each)
 #endif
 #ifndef TN_NS4
 #define TN_NS4 3          // ring slots of the 256-row ping-pong tile; 4 (three steps ahead, 128 KB) measured 0.3 ms SLOWER per training step (22.05 vs 21.73 ms, one box)
@@ -35,6 +38,7 @@ typedef __attribute__((address_space(3))) void tn_lds_void_t;
 typedef const __attribute__((address_space(1))) void tn_gbl_void_t;
 
 template <int N> __device__ __forceinline__ void tn_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void tn_wait_lgkmcnt() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
 
 // 8 reduction rows (R0 + 4 hi + {0..3, 8..11}) of column c0 + (lane & 31) of a swizzled [32][CH * 8] bf16 tile (CH 16-B chunks per row): two
 // transposing reads, ISSUED here and hidden from hipcc's waitcnt bookkeeping -- the caller waits once (lgkmcnt(0) + sched_barrier) for all
@@ -320,6 +324,176 @@ __device__ __forceinline__ void tn_body(const tn_params& p, char* smem, int tile
         }
 }
 
+// ---- W4 (round 4): the 256 x 256 tile on FOUR waves, one per SIMD (512 registers each: 256 accumulators + two fragment sets) -------------------
+// Stamps of the 8-wave ping-pong loop (tools/lab/tn_lab.hip): per 32-row step a wave spends 560 cycles in its 16 MFMAs and 1300 in MEM -- 24 transposing
+// reads issue at ~19 cycles each per wave (460-580), the 4 LDS-DMA pieces at 42 cycles each beside the partner's reads but 130 beside the partner's
+// MFMAs -- so a step lasts 560 + 1300 = 1860 cycles for 1024 cycles of matrix work per SIMD: the two waves of a SIMD do not hide each other's memory
+// phase, they queue behind each other's issue.  One wave per SIMD has nobody to queue behind: its MFMA stream (32 per step, 32 cycles each) runs
+// back to back and the step's 32 reads + 8 DMA pieces sit in the gaps between MFMAs (1.3 per gap; ~5 fit).  Wave (wm, wn) of 2 x 2 owns 128 x 128
+// outputs: 8 fragments per 16-row half step (A 4, B 4) for 16 MFMAs -- 0.5 fragment per MFMA instead of 0.75.  Ring of 4 slots (128 KB), the
+// DMA three steps ahead, ONE barrier per step (between the two half steps: the next step's first fragments are read under the second half's MFMAs).
+template <int OFF> __device__ __forceinline__ void tn4_read_at(uint2& d, uint32_t addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void tn4_read(uint2& d, uint32_t addr, const int off) {     // off: a constant after unrolling (0, 4, 8 or 12 KiB)
+    switch (off) {
+        case 0: tn4_read_at<0>(d, addr); break;
+        case 4096: tn4_read_at<4096>(d, addr); break;
+        case 8192: tn4_read_at<8192>(d, addr); break;
+        default: tn4_read_at<12288>(d, addr); break;
+    }
+}
+
+template <int NS>
+__device__ __forceinline__ void tn4_body(const tn_params& p, char* smem, int tile, int k_begin, int k_end, float* __restrict__ out, long ldo,
+                                         float* __restrict__ dbo) {
+    constexpr int BN = 256, BK = 32, A_BYTES = BK * 256 * 2, SLOT = 2 * A_BYTES, UPW = 8;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int tiles_n = p.No / BN;
+    const int tm = tile / tiles_n, tn = tile % tiles_n;
+    const int m0 = tm * 256, n0 = tn * BN;
+    const int nkt = (k_end - k_begin) / BK;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(tn_lds_void_t*)smem;
+
+    // DMA unit u = wave + 4 i (i < 8): i < 4 -> A units (two 512-B rows each), else B units.  Lane L -> byte L * 16 of the unit -> (row, chunk
+    // position); source chunk = position ^ 4 (row & 3) (the swizzle sits on the source side).  Per-lane 32-bit byte offsets from uniform bases.
+    uint32_t voff[UPW];
+#pragma unroll
+    for (int i = 0; i < UPW; ++i) {
+        const int u = (wave + 4 * i) & 15;
+        const int off = u * 1024 + lane * 16;
+        const int row = off >> 9, pos = (off & 511) >> 4;
+        voff[i] = (uint32_t)(row * (i < 4 ? p.lda : p.ldb) * 2 + ((pos ^ (4 * (row & 3))) << 4));
+    }
+    const char* baseA = (const char*)(p.A + (size_t)k_begin * p.lda + m0);
+    const char* baseB = (const char*)(p.B + (size_t)k_begin * p.ldb + n0);
+    const size_t stepA = (size_t)BK * p.lda * 2, stepB = (size_t)BK * p.ldb * 2;
+    auto dma = [&](int kt, int i) {                                            // piece i of step kt; past the end: the last step again (nobody reads it)
+        const int ks_ = (TN_LAB & 16) ? (kt & 3) : kt < nkt ? kt : nkt - 1;      // lab 16: every step re-reads the first four steps' rows (L2-hot operands)
+        const char* src = (i < 4 ? baseA + (size_t)ks_ * stepA : baseB + (size_t)ks_ * stepB) + voff[i];
+        if (!(TN_LAB & 4)) __builtin_amdgcn_global_load_lds((tn_gbl_void_t*)src, (tn_lds_void_t*)(smem + (kt % NS) * SLOT + (wave + 4 * i) * 1024), 16, 0, 0);
+    };
+    // fragment read addresses inside slot 0: lane -> (row, column) of tn_frag_issue with R0 = 0; a half step adds 16 rows (8 KiB), the second read 8 rows
+    uint32_t fa_off[4], fb_off[4];
+    {
+        const int g = lane >> 4, i16 = lane & 15;
+        const int row = 4 * (g >> 1) + (i16 >> 2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ca = wm * 128 + i * 32 + 16 * (g & 1) + 4 * (i16 & 3), cb = wn * 128 + i * 32 + 16 * (g & 1) + 4 * (i16 & 3);
+            fa_off[i] = lds0 + row * 512 + ((((ca >> 3) ^ (4 * (row & 3)))) << 4) + (ca & 7) * 2;
+            fb_off[i] = lds0 + A_BYTES + row * 512 + ((((cb >> 3) ^ (4 * (row & 3)))) << 4) + (cb & 7) * 2;
+        }
+    }
+    f32x16_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // bias gradient: column sums of A.  The tiles_n column tiles of a row tile and both wave columns read the same A fragments: fragment block
+    // b = 4 wm + i (0..7) of the row tile is summed by the one (column tile, wave column) with b % (2 tiles_n) == 2 tn + wn -- at most one block
+    // per wave at tiles_n >= 2 -- as four v_dot2c against bf16 ones, behind a scalar branch (inline asm: the compiler would turn the branch into
+    // sixteen unconditional dot products and a select per half step on every wave: +27 % on the bare MFMA stream)
+    bool db_on[4];
+    float dbs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { dbs[i] = 0.f; db_on[i] = p.db != nullptr && ((wm * 4 + i) % (2 * tiles_n)) == 2 * tn + wn; }
+    const bool want_db = db_on[0] | db_on[1] | db_on[2] | db_on[3];
+    auto db_add = [&](float& s, const tn_raw& f) {
+        asm volatile("v_dot2c_f32_bf16 %0, %1, %5\n\tv_dot2c_f32_bf16 %0, %2, %5\n\tv_dot2c_f32_bf16 %0, %3, %5\n\tv_dot2c_f32_bf16 %0, %4, %5"
+                     : "+v"(s) : "v"(f.x.x), "v"(f.x.y), "v"(f.y.x), "v"(f.y.y), "v"(0x3f803f80u));
+    };
+
+    tn_raw qa[2][4], qb[2][4];                                                 // two fragment sets: the half step in the MFMAs, the next one in flight
+    // reads of half step (slot base sb, rows 16 ks ..) into set `dst`, fragment f (0..3 A, 4..7 B), read r (0, 1)
+#define TN4_READ(dst, sb, ks, f, r)                                                                                          \
+    do {                                                                                                                     \
+        if (!(TN_LAB & 2)) {                                                                                                 \
+            if ((f) < 4) tn4_read((r) ? qa[dst][(f) & 3].y : qa[dst][(f) & 3].x, fa_off[(f) & 3] + (sb), (ks) * 8192 + (r) * 4096);            \
+            else tn4_read((r) ? qb[dst][(f) & 3].y : qb[dst][(f) & 3].x, fb_off[(f) & 3] + (sb), (ks) * 8192 + (r) * 4096);                    \
+        }                                                                                                                    \
+    } while (0)
+    // The 16 reads of a half step are issued in the order its MFMAs (i-major) need them -- B0 A0 B1 B2 B3 A1 A2 A3 -- and waited for by COUNT in front
+    // of the MFMA that first uses them (lgkmcnt 12 / 11 / 10 / 9 / 8 for MFMAs 0-4, 10 for MFMA 8, 12 for MFMA 12: what is still allowed in flight
+    // = the later reads of that half step + the reads the new half step has issued so far), so no half step ends on an LDS round trip.  Nothing
+    // else in the loop touches lgkmcnt (no scalar loads: checked in the ISA).
+    // one half step: the 16 MFMAs of fragment set `cur`, and in their gaps the 16 reads of the next half step (set cur ^ 1; slot base nsb, half nks)
+    // + 4 of the 8 DMA pieces of step dkt (pieces dp0 .. dp0 + 3) + the bias sums of set `cur`.  Reads and pieces are unconditional: past the last
+    // step they fetch data nobody uses -- no branch in the stream, one vmcnt count for every step.
+#define TN4_HALF(cur, nsb, nks, dkt, dp0)                                                                                    \
+    do {                                                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                      \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                  \
+                const int g_ = i * 4 + j;                                                                                    \
+                if (g_ == 0) tn_wait_lgkmcnt<12>(); else if (g_ == 1) tn_wait_lgkmcnt<11>(); else if (g_ == 2) tn_wait_lgkmcnt<10>();           \
+                else if (g_ == 3) tn_wait_lgkmcnt<9>(); else if (g_ == 4) tn_wait_lgkmcnt<8>(); else if (g_ == 8) tn_wait_lgkmcnt<10>();          \
+                else if (g_ == 12) tn_wait_lgkmcnt<12>();                                                                    \
+                __builtin_amdgcn_sched_barrier(0);                                                                           \
+                if (!(TN_LAB & 1)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tn_frag_value(qa[cur][i]), tn_frag_value(qb[cur][j]), acc[i][j], 0, 0, 0); \
+                __builtin_amdgcn_sched_barrier(0);                                                                           \
+                TN4_READ((cur) ^ 1, nsb, nks, ((0x32107654 >> (4 * (7 - (g_ >> 1)))) & 15), g_ & 1);                         \
+                if ((g_ & 3) == 1) dma(dkt, (dp0) + (g_ >> 2));                                                              \
+                if (j == 3 && db_on[i]) db_add(dbs[i], qa[cur][i]);                                                          \
+                __builtin_amdgcn_sched_barrier(0);                                                                           \
+            }                                                                                                                \
+        }                                                                                                                    \
+    } while (0)
+
+    // prologue: steps 0 .. NS - 2 in flight, step 0 landed, its first half step in registers
+    if (nkt > 0) {
+#pragma unroll
+        for (int s0 = 0; s0 < NS - 1; ++s0)
+#pragma unroll
+            for (int i = 0; i < UPW; ++i) dma(s0, i);
+        tn_wait_vmcnt<(NS - 2) * UPW>();
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int f = 0; f < 8; ++f) { TN4_READ(0, 0u, 0, f, 0); TN4_READ(0, 0u, 0, f, 1); }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        for (int x = 0; x < nkt; ++x) {
+            const uint32_t sb = (uint32_t)((x % NS) * SLOT), sb1 = (uint32_t)(((x + 1) % NS) * SLOT);
+            // first half step; reads of the second half (same slot); pieces 0-3 of step x + NS - 1 (its slot held step x - 1: everybody passed the
+            // barrier of step x - 1 after their last read of it)
+            TN4_HALF(0, sb, 1, x + NS - 1, 0);
+            // own pieces of step x + 1 have landed: younger = steps x + 2 .. x + NS - 2 (8 each) + the 4 pieces just issued
+            tn_wait_vmcnt<(NS - 3) * UPW + 4>();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // second half step; reads of step x + 1's first half; pieces 4-7
+            TN4_HALF(1, sb1, 0, x + NS - 1, 4);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        tn_wait_vmcnt<0>();                                                      // the surplus pieces land in this workgroup's LDS: not after it has gone
+    }
+#undef TN4_HALF
+#undef TN4_READ
+    if (want_db) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float v = dbs[i] + __shfl_xor(dbs[i], 32, 64);
+            if (db_on[i] && hi == 0) dbo[m0 + wm * 128 + i * 32 + l31] = v;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 128 + j * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                out[(size_t)m * ldo + n] = acc[i][j][r];
+            }
+        }
+}
+
 template <int MI, bool GATHER, bool PP>
 __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const tn_params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -481,6 +655,38 @@ extern "C" int whmr_gemm_tn_bf16(const void* A, long lda, const void* B, long ld
     return tn_run(p, splits, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
+// the grouped launch on the four-wave body
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_tn4_group_kernel(const tn_group g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lid = xcd_remap(blockIdx.x, g.total);
+    int i = 0;
+#pragma unroll
+    for (int j = 1; j < TN_GROUP_MAX; ++j)
+        if (j < g.n && lid >= g.first[j]) i = j;
+    tn_params p{};
+    p.A = tn_pick(g, i, [](const tn_params& t) { return t.A; });
+    p.B = tn_pick(g, i, [](const tn_params& t) { return t.B; });
+    p.C = tn_pick(g, i, [](const tn_params& t) { return t.C; });
+    p.ws = tn_pick(g, i, [](const tn_params& t) { return t.ws; });
+    p.db = tn_pick(g, i, [](const tn_params& t) { return t.db; });
+    p.lda = tn_pick(g, i, [](const tn_params& t) { return t.lda; });
+    p.ldb = tn_pick(g, i, [](const tn_params& t) { return t.ldb; });
+    p.ldc = tn_pick(g, i, [](const tn_params& t) { return t.ldc; });
+    p.Mo = tn_pick(g, i, [](const tn_params& t) { return t.Mo; });
+    p.No = tn_pick(g, i, [](const tn_params& t) { return t.No; });
+    p.tiles = tn_pick(g, i, [](const tn_params& t) { return t.tiles; });
+    p.K = g.it[0].K; p.k_per_split = g.it[0].k_per_split; p.splits = g.it[0].splits;
+    int l = lid;
+#pragma unroll
+    for (int j = 1; j < TN_GROUP_MAX; ++j)
+        if (i == j) l = lid - g.first[j];
+    const int slice = l / p.tiles, tile = l - slice * p.tiles;
+    const int k_begin = slice * p.k_per_split;
+    const int k_end = min(p.K, k_begin + p.k_per_split);
+    tn4_body<TN4_NS>(p, smem, tile, k_begin, k_end, p.ws ? p.ws + (size_t)slice * p.Mo * p.No : p.C, p.ws ? (long)p.No : p.ldc,
+                p.ws ? p.ws + (size_t)p.splits * p.Mo * p.No + (size_t)slice * p.Mo : p.db);
+}
+
 // reduce of a grouped launch: blockIdx.y = product
 __global__ __launch_bounds__(256) void tn_reduce_group_kernel(const tn_group g) {
     const int i = blockIdx.y;
@@ -550,14 +756,17 @@ extern "C" int whmr_gemm_tn_bf16_group(const whmr_tn_item* items, int n_items, i
     for (int i = n_items; i < TN_GROUP_MAX; ++i) { g.it[i] = g.it[0]; g.first[i] = first; }
     g.n = n_items; g.total = first;
     hipStream_t st = (hipStream_t)stream;
-    constexpr int LDS = TN_NS4 * (32 * 256 * 2 + 32 * 256 * 2);
+    constexpr int LDS = TN_NS4 * (32 * 256 * 2 + 32 * 256 * 2), LDS4 = TN4_NS * (32 * 256 * 2 + 32 * 256 * 2);
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_group_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_tn4_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    hipLaunchKernelGGL(gemm_tn_group_kernel<true>, dim3(g.total), dim3(512), LDS, st, g);
+    static const int w4 = [] { const char* e = getenv("WHMR_TN_W4"); return e ? (e[0] == '1' ? 1 : 0) : 1; }();     // A/B: 0 = the eight-wave ping-pong body
+    if (w4) hipLaunchKernelGGL(gemm_tn4_group_kernel, dim3(g.total), dim3(256), LDS4, st, g);
+    else hipLaunchKernelGGL(gemm_tn_group_kernel<true>, dim3(g.total), dim3(512), LDS, st, g);
     WHMR_CHECK_LAUNCH();
     if (splits > 1) {
         long most = 0;
