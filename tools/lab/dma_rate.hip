@@ -46,6 +46,43 @@ __global__ __launch_bounds__(512) void probe(const char* __restrict__ src, long 
     if (acc == 0x12345678u) out[0] = (float)acc;
 }
 
+// Streaming probe: continuous issue (one piece out, vmcnt(DEPTH - 1)), contiguous 1-KiB pieces, every block its own region (`share` = 1) or `share`
+// blocks per region (the column tiles of a GEMM row panel: first toucher misses, the others hit the line in flight), fresh data (span >> caches).
+template <int DEPTH>
+__global__ __launch_bounds__(512) void probe_stream(const char* __restrict__ src, long region, int share, int iters, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const char* base = src + (size_t)(blockIdx.x / share) * region + wave * 1024 + lane * 16;
+    long off = 0;
+    for (int it = 0; it < iters; ++it) {
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(base + off), (lds_void_t*)(smem + ((it % DEPTH) * 8 + wave) * 1024), 16, 0, 0);
+        off += 8192;
+        if (off + 8192 > region) off = 0;
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DEPTH - 1) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (((uint32_t*)smem)[tid] == 0x12345678u) out[0] = 1.f;
+}
+
+template <int DEPTH>
+static void run_stream(const char* src, long region, int share, int blocks, float* out) {
+    auto k = probe_stream<DEPTH>;
+    CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    const int iters = (int)(region / 8192);                                  // one pass over the region: every byte fresh
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(512), 128 * 1024, 0, src, region, share, iters, out);
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    const double bytes = (double)iters * 8192;
+    printf("stream LDS-DMA depth %2d (%3d KB in flight per CU) blocks %3d share %2d region %3ld MB: %7.1f us  %6.1f GB/s per CU  %5.2f TB/s unique\n", DEPTH, DEPTH * 8,
+           blocks, share, region >> 20, ms * 1e3, bytes / (ms * 1e-3) / 1e9, bytes * (blocks / share) / (ms * 1e-3) / 1e12);
+}
+
 // TN pattern: a block streams K rows of a [K, ld] bf16 matrix, 512 B (256 columns at its tile offset) per row, 32 rows per step, as 1-KiB pieces of two
 // rows each (lanes 0-31 row r, lanes 32-63 row r + 1), optionally with gemm_tn.hip's chunk swizzle; `tiles` blocks share the same rows (column tiles).
 //   SWZ 0/1; rows_wrap: K rows before wrapping (small = L2 resident, large = streaming)
@@ -120,6 +157,19 @@ int main(int argc, char** argv) {
     char* src; float* out;
     CK(hipMalloc(&src, span + 65536)); CK(hipMalloc(&out, 64));
     CK(hipMemset(src, 1, span + 65536));
+    if (argc > 3 && argv[3][0] == 's') {                         // streaming sweep: per-CU rate on fresh data against depth, active CUs and sharing
+        for (int rep = 0; rep < 2; ++rep)
+            for (int share : {1, 3, 12})
+                for (int nb : {24, 96, 252}) {
+                    const long region = ((span / (nb / share)) >> 13) << 13;
+                    const long r = region > (48l << 20) ? (48l << 20) : region;
+                    run_stream<4>(src, r, share, nb, out);
+                    run_stream<8>(src, r, share, nb, out);
+                    run_stream<16>(src, r, share, nb, out);
+                    CK(hipMemset((void*)src, rep + 2, span));                // evict: the next pass reads fresh lines again
+                }
+        return 0;
+    }
     if (argc > 3) {                                              // TN pattern sweep
         for (int rep = 0; rep < 2; ++rep)
             for (int ld : {1536, 4608, 6144, 2048}) {

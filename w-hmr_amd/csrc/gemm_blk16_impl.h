@@ -33,6 +33,28 @@ template <int OFF> __device__ __forceinline__ bf16x8_t b16_lds_read128(uint32_t 
     return v;
 }
 
+// read q (0..15, a constant after unrolling) of a half tile's 16 fragment reads of the four-wave body: W blocks j = q >> 1, halves nh = q & 1, then A blocks
+__device__ __forceinline__ void blk16_read_sel(bf16x8_t (&fa)[4][2], bf16x8_t (&fb)[4][2], uint32_t sa, uint32_t sb, const int q) {
+    switch (q) {
+        case 0: fb[0][0] = b16_lds_read128<0>(sb); break;
+        case 1: fb[0][1] = b16_lds_read128<256>(sb); break;
+        case 2: fb[1][0] = b16_lds_read128<2048>(sb); break;
+        case 3: fb[1][1] = b16_lds_read128<2048 + 256>(sb); break;
+        case 4: fb[2][0] = b16_lds_read128<4096>(sb); break;
+        case 5: fb[2][1] = b16_lds_read128<4096 + 256>(sb); break;
+        case 6: fb[3][0] = b16_lds_read128<6144>(sb); break;
+        case 7: fb[3][1] = b16_lds_read128<6144 + 256>(sb); break;
+        case 8: fa[0][0] = b16_lds_read128<0>(sa); break;
+        case 9: fa[0][1] = b16_lds_read128<256>(sa); break;
+        case 10: fa[1][0] = b16_lds_read128<2048>(sa); break;
+        case 11: fa[1][1] = b16_lds_read128<2048 + 256>(sa); break;
+        case 12: fa[2][0] = b16_lds_read128<4096>(sa); break;
+        case 13: fa[2][1] = b16_lds_read128<4096 + 256>(sa); break;
+        case 14: fa[3][0] = b16_lds_read128<6144>(sa); break;
+        default: fa[3][1] = b16_lds_read128<6144 + 256>(sa); break;
+    }
+}
+
 template <int MI0, int MI1>
 struct blk16_cfg {
     static constexpr int MB = MI0 + MI1;                 // A row blocks (32 rows) per tile
@@ -47,14 +69,22 @@ struct blk16_cfg {
 };
 
 // SCHED 1: one barrier per half tile, groups in opposite order within a slot;  SCHED 0: two barriers per half tile (MEM | MFMA rendezvous)
-template <int MI0, int MI1, int EPI, int SCHED>
-__global__ __launch_bounds__(512, 2) void gemm_blk16_kernel(const whmr_gemm_blk_desc p) {
+//
+// NW = 4 (round 4, tile id 0x144): the same 256 x 256 tile on FOUR waves, one per SIMD, 512 registers each (256 accumulators in AGPRs + two
+// fragment sets) -- the structure of gemm_tn.hip's four-wave body.  Stamps of the eight-wave loops (tools/lab/tn_lab.hip) show that the two waves
+// of a SIMD do not hide each other's memory phase, they queue behind each other's issue (LDS-DMA pieces issue at 42 cycles beside reads, 130 beside
+// the partner's MFMAs); alone on its SIMD a wave runs its 64 MFMAs per half tile back to back with the half tile's 16 fragment reads and 8
+// LDS-DMA pieces in the gaps.  Wave (wm, wn) of 2 x 2 owns 128 x 128 outputs: 16 fragment reads per 64 MFMAs instead of 12 per 32.  Same ring, same
+// MFMA instruction and k order per accumulator, same epilogue arithmetic (the row statistics keep the eight-wave kernel's partial sums): same bits.
+template <int MI0, int MI1, int EPI, int SCHED, int NW>
+__device__ __forceinline__ void gemm_blk16_body(const whmr_gemm_blk_desc& p, char* smem) {
     using cfg = blk16_cfg<MI0, MI1>;
-    constexpr int MB = cfg::MB, BM = cfg::BM, BN = cfg::BN, SLOT = cfg::SLOT, HU = cfg::HU, HUPW = cfg::HUPW, NJ = 2;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MB = cfg::MB, BM = cfg::BM, BN = cfg::BN, SLOT = cfg::SLOT, HU = cfg::HU, NJ = NW == 8 ? 2 : 4, NT = NW * 64;
+    constexpr int HUPW = (HU + NW - 1) / NW;             // DMA units per wave (waves >= HU % NW issue one less when HU % NW != 0)
+    static_assert(NW == 8 || (MI0 == 4 && MI1 == 4), "the four-wave body is the 256-row tile");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;              // wm = group
+    const int wm = NW == 8 ? wave >> 2 : wave >> 1, wn = NW == 8 ? wave & 3 : wave & 1;     // NW 8: wm = group
     const int l15 = lane & 15, g = lane >> 4;             // row inside a 16-row half / K chunk of the operand fragments = column group of the results
     const int tiles_n = p.N / BN, tiles_m = (p.M + BM - 1) / BM;
     const int lid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
@@ -66,13 +96,15 @@ __global__ __launch_bounds__(512, 2) void gemm_blk16_kernel(const whmr_gemm_blk_
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds16_void_t*)smem;
 
     // this tile's bias slice -> LDS (one float per thread, in flight under the whole main loop)
-    if (tid < BN) ((float*)(smem + cfg::BIAS_OFF))[tid] = p.bias ? p.bias[n0 + tid] : 0.f;
-    else if (tid < 2 * BN && p.stats_in) ((float*)(smem + cfg::BIAS_OFF))[tid] = p.colsum[n0 + tid - BN];
+    for (int t = tid; t < 2 * BN; t += NT) {
+        if (t < BN) ((float*)(smem + cfg::BIAS_OFF))[t] = p.bias ? p.bias[n0 + t] : 0.f;
+        else if (p.stats_in) ((float*)(smem + cfg::BIAS_OFF))[t] = p.colsum[n0 + t - BN];
+    }
     if (p.stats_in) {
         // consumer of a folded LayerNorm: this tile's row statistics (K/256 partial (sum, sum of squares) pairs per row, written by the producer
         // GEMM's column tiles) -> LDS now, so that the epilogue finds them without a global round trip
         const int S3 = p.K >> 8;
-        for (int r = tid; r < BM; r += 512) {
+        for (int r = tid; r < BM; r += NT) {
             int m = m0 + r;
             if (m > rb_last * 32 + 31) m = rb_last * 32 + 31;
             for (int t = 0; t < S3; ++t)
@@ -82,13 +114,13 @@ __global__ __launch_bounds__(512, 2) void gemm_blk16_kernel(const whmr_gemm_blk_
 
     // ---- DMA units of this wave: u = wave + 8 i -> row block u >> 1 (A blocks first, then the 8 W blocks), 1-KiB half u & 1 (two 8-deep chunks).
     // A units are copied as they are; inside a W chunk LDS slot s (= lane & 31) receives column 8 ((s & 15) >> 2) + 4 (s >> 4) + (s & 3).
-    const bool dma_full = (HU % 8 == 0) || (wave < HU % 8);          // this wave issues HUPW units (else HUPW - 1)
+    const bool dma_full = (HU % NW == 0) || (wave < HU % NW);        // this wave issues HUPW units (else HUPW - 1)
     const int wslot = lane & 31;
     const int wsrc = (lane & 32) * 16 + (8 * ((wslot & 15) >> 2) + 4 * (wslot >> 4) + (wslot & 3)) * 16;
     const char* hsrc[HUPW];
 #pragma unroll
     for (int i = 0; i < HUPW; ++i) {
-        int u = wave + 8 * i;
+        int u = wave + NW * i;
         if (u >= HU) u = HU - 1;                          // never issued (dma_full is false); keeps the address valid
         const int b = u >> 1, half = u & 1;
         if (b < MB) {
@@ -99,12 +131,13 @@ __global__ __launch_bounds__(512, 2) void gemm_blk16_kernel(const whmr_gemm_blk_
             hsrc[i] = (const char*)p.W + ((size_t)((n0 >> 5) + b - MB) * KC) * 512 + half * 1024 + wsrc;
         }
     }
+    auto hpiece = [&](int h, int i) {                     // piece i of half tile h
+        __builtin_amdgcn_global_load_lds((gbl16_void_t*)(hsrc[i] + (size_t)h * 2048), (lds16_void_t*)(smem + (h & 3) * SLOT + (wave + NW * i) * 1024), 16, 0, 0);
+    };
     auto hstage = [&](int h) {
-        const int slot = h & 3;
 #pragma unroll
         for (int i = 0; i < HUPW; ++i) {
-            if (i < HUPW - 1 || dma_full)
-                __builtin_amdgcn_global_load_lds((gbl16_void_t*)(hsrc[i] + (size_t)h * 2048), (lds16_void_t*)(smem + slot * SLOT + (wave + 8 * i) * 1024), 16, 0, 0);
+            if (i < HUPW - 1 || dma_full) hpiece(h, i);
         }
     };
     // own DMA groups still allowed in flight: `young` groups of (HUPW or HUPW - 1) loads
@@ -137,7 +170,7 @@ __global__ __launch_bounds__(512, 2) void gemm_blk16_kernel(const whmr_gemm_blk_
     auto main_loop = [&](auto miw_tag) {
         constexpr int MIW = decltype(miw_tag)::value;
         const uint32_t a_b = lds0 + (wm * MI0) * 2048 + g * 512 + l15 * 16;
-        const uint32_t b_b = lds0 + (MB + wn * 2) * 2048 + g * 512 + l15 * 16;
+        const uint32_t b_b = lds0 + (MB + wn * NJ) * 2048 + g * 512 + l15 * 16;
         bf16x8_t fa[MIW][2], fb[NJ][2];                    // [.][mh] rows 16 mh.. of the A block;  [.][nh] LDS slots 16 nh.. of the W block
         auto MEM = [&](int x) {
             const uint32_t sa = a_b + (x & 3) * SLOT, sb = b_b + (x & 3) * SLOT;
@@ -196,7 +229,53 @@ __global__ __launch_bounds__(512, 2) void gemm_blk16_kernel(const whmr_gemm_blk_
             if (wm == 0) __builtin_amdgcn_s_barrier();
         }
     };
-    if constexpr (MI0 == MI1) {
+    if constexpr (NW == 4) {
+        // ---- four waves: 64 MFMAs per half tile from fragment set `cur`; in their gaps the 16 reads of half tile h + 1 (set cur ^ 1) and the 8
+        // LDS-DMA pieces of half tile h + 3 (its slot held h - 1: everybody is past the barrier that opens h).  Pieces past the last half tile
+        // fetch the last one again (nobody reads it): no branch in the stream, one vmcnt count for every half tile.
+        static_assert(HU % 4 == 0 && HUPW == 8, "");
+        const uint32_t a_b = lds0 + (wm * 4) * 2048 + g * 512 + l15 * 16;
+        const uint32_t b_b = lds0 + (MB + wn * 4) * 2048 + g * 512 + l15 * 16;
+        bf16x8_t fa[2][4][2], fb[2][4][2];                       // [set][block][mh / nh]
+#define B16_PHASE(cur, h)                                                                                                    \
+    do {                                                                                                                     \
+        const int hn_ = (h) + 3 < H ? (h) + 3 : H - 1, sl_ = ((h) + 1) & 3;                                                  \
+        _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                                                      \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                  \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                              \
+                    _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                                          \
+                        const int g_ = ((a * 4 + i) * 4 + j) * 2 + b;                                                        \
+                        acc[i][j][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[cur][j][b], fa[cur][i][a], acc[i][j][a][b], 0, 0, 0); \
+                        __builtin_amdgcn_sched_barrier(0);                                                                   \
+                        if (g_ < 16) blk16_read_sel(fa[(cur) ^ 1], fb[(cur) ^ 1], a_b + sl_ * SLOT, b_b + sl_ * SLOT, g_);   \
+                        if (g_ >= 16 && g_ < 48 && (g_ & 3) == 0) {                                                          \
+                            __builtin_amdgcn_global_load_lds((gbl16_void_t*)(hsrc[(g_ - 16) >> 2] + (size_t)hn_ * 2048),     \
+                                                             (lds16_void_t*)(smem + (((h) + 3) & 3) * SLOT + (wave + 4 * ((g_ - 16) >> 2)) * 1024), 16, 0, 0); \
+                        }                                                                                                    \
+                        __builtin_amdgcn_sched_barrier(0);                                                                   \
+                    }                                                                                                        \
+                }                                                                                                            \
+            }                                                                                                                \
+        }                                                                                                                    \
+    } while (0)
+        // prologue (half tiles 0-2 are in flight, 0 has landed for everybody): the first fragment set
+#pragma unroll
+        for (int q = 0; q < 16; ++q) blk16_read_sel(fa[0], fb[0], a_b, b_b, q);
+        b16_wait_lgkmcnt<0>();
+        __builtin_amdgcn_sched_barrier(0);
+        auto open = [&]() {                                            // own pieces of the next half tile have landed (the 8 of the one after may fly)
+            b16_wait_vmcnt<8>();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto close = [&]() { b16_wait_lgkmcnt<0>(); __builtin_amdgcn_sched_barrier(0); };
+        for (int h = 0; h < H; h += 2) {                               // H is even here (K % 64 == 0: the launcher checks)
+            open(); B16_PHASE(0, h); close();
+            open(); B16_PHASE(1, h + 1); close();
+        }
+        b16_wait_vmcnt<0>();                                           // the surplus pieces land in this workgroup's LDS: not after it has gone
+#undef B16_PHASE
+    } else if constexpr (MI0 == MI1) {
         main_loop(std::integral_constant<int, MI0>{});
     } else {
         if (wm == 0) main_loop(std::integral_constant<int, MI0>{});
@@ -208,8 +287,8 @@ __global__ __launch_bounds__(512, 2) void gemm_blk16_kernel(const whmr_gemm_blk_
     const int miw = wm == 0 ? MI0 : MI1;
     const int rb0 = (m0 >> 5) + (wm == 0 ? 0 : MI0);                   // first row block of this wave
     const int rw0 = wm == 0 ? 0 : MI0 * 32;                           // its first row inside the tile
-    const int nb0 = n0 + wn * 64;
-    const float* sBias = (const float*)(smem + cfg::BIAS_OFF) + wn * 64;
+    const int nb0 = n0 + wn * (NJ * 32);
+    const float* sBias = (const float*)(smem + cfg::BIAS_OFF) + wn * (NJ * 32);
     if constexpr (EPI == 0 || EPI == 1) {
         const int NC8 = p.N >> 3;
         const bool fold = p.stats_in != nullptr;                        // LayerNorm folded into this GEMM: per-row (rstd, rstd * mean)
@@ -265,11 +344,17 @@ __global__ __launch_bounds__(512, 2) void gemm_blk16_kernel(const whmr_gemm_blk_
     } else {
         const int NC4 = p.N >> 2;
         const bool emit = p.xhat != nullptr;                            // also write bf16(C) as the next GEMM's operand + row partial sums
-        float sx[cfg::MIMAX][2], sxx[cfg::MIMAX][2], sh[cfg::MIMAX][2];
+        // row partial sums per PAIR of column blocks (64 columns: one wave column of the eight-wave kernel) -- the four-wave body keeps two of
+        // them per row so that the sums are taken in the same order whatever kernel ran the tile
+        float sx[cfg::MIMAX][2][NJ / 2], sxx[cfg::MIMAX][2][NJ / 2], sh[cfg::MIMAX][2];
 #pragma unroll
         for (int i = 0; i < cfg::MIMAX; ++i)
 #pragma unroll
-            for (int a = 0; a < 2; ++a) { sx[i][a] = 0.f; sxx[i][a] = 0.f; sh[i][a] = 0.f; }
+            for (int a = 0; a < 2; ++a) {
+                sh[i][a] = 0.f;
+#pragma unroll
+                for (int q = 0; q < NJ / 2; ++q) { sx[i][a][q] = 0.f; sxx[i][a][q] = 0.f; }
+            }
         if (emit && (p.shift || p.shift_stats || p.shift_out)) {
             // Per-row SHIFT of the folded LayerNorm: the bf16 operand copy and the partial sums are taken of (x - s_m), s_m = the row's mean one
             // residual step earlier (its previous shift + the mean of its previous shifted statistics).  LN(x) = ((x - s) - mean(x - s)) * rstd is
@@ -327,9 +412,11 @@ __global__ __launch_bounds__(512, 2) void gemm_blk16_kernel(const whmr_gemm_blk_
                         if (emit) {
                             // explicit order / explicit fma: every tile instantiation must produce the same bits for a row (batch-independence tests)
                             o.x -= sh[i][a]; o.y -= sh[i][a]; o.z -= sh[i][a]; o.w -= sh[i][a];
-                            sx[i][a] += o.x; sx[i][a] += o.y; sx[i][a] += o.z; sx[i][a] += o.w;
-                            sxx[i][a] = fmaf(o.x, o.x, sxx[i][a]); sxx[i][a] = fmaf(o.y, o.y, sxx[i][a]);
-                            sxx[i][a] = fmaf(o.z, o.z, sxx[i][a]); sxx[i][a] = fmaf(o.w, o.w, sxx[i][a]);
+                            float& ax = sx[i][a][j >> 1];
+                            float& axx = sxx[i][a][j >> 1];
+                            ax += o.x; ax += o.y; ax += o.z; ax += o.w;
+                            axx = fmaf(o.x, o.x, axx); axx = fmaf(o.y, o.y, axx);
+                            axx = fmaf(o.z, o.z, axx); axx = fmaf(o.w, o.w, axx);
                             pk[2 * b] = pack_bf16x2(o.x, o.y); pk[2 * b + 1] = pack_bf16x2(o.z, o.w);
                         }
                     }
@@ -348,21 +435,35 @@ __global__ __launch_bounds__(512, 2) void gemm_blk16_kernel(const whmr_gemm_blk_
             for (int i = 0; i < cfg::MIMAX; ++i) {
                 if (i >= miw) continue;
 #pragma unroll
-                for (int a = 0; a < 2; ++a) {
-                    float u = sx[i][a] + __shfl_xor(sx[i][a], 16, 64), v = sxx[i][a] + __shfl_xor(sxx[i][a], 16, 64);
-                    u += __shfl_xor(u, 32, 64); v += __shfl_xor(v, 32, 64);
-                    if (g == 0) sRed[(rw0 + i * 32 + 16 * a + l15) * 4 + wn] = make_float2(u, v);
-                }
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int q = 0; q < NJ / 2; ++q) {
+                        float u = sx[i][a][q] + __shfl_xor(sx[i][a][q], 16, 64), v = sxx[i][a][q] + __shfl_xor(sxx[i][a][q], 16, 64);
+                        u += __shfl_xor(u, 32, 64); v += __shfl_xor(v, 32, 64);
+                        if (g == 0) sRed[(rw0 + i * 32 + 16 * a + l15) * 4 + wn * (NJ / 2) + q] = make_float2(u, v);
+                    }
             }
             __syncthreads();
             const int S3 = p.N >> 8;
-            for (int r = tid; r < BM; r += 512) {
+            for (int r = tid; r < BM; r += NT) {
                 if ((m0 >> 5) + (r >> 5) > rb_last) continue;
                 const float2 v0 = sRed[r * 4], v1 = sRed[r * 4 + 1], v2 = sRed[r * 4 + 2], v3 = sRed[r * 4 + 3];
                 *(float2*)(p.stats_out + ((size_t)(m0 + r) * S3 + tn) * 2) = make_float2((v0.x + v1.x) + (v2.x + v3.x), (v0.y + v1.y) + (v2.y + v3.y));
             }
         }
     }
+}
+
+template <int MI0, int MI1, int EPI, int SCHED>
+__global__ __launch_bounds__(512, 2) void gemm_blk16_kernel(const whmr_gemm_blk_desc p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemm_blk16_body<MI0, MI1, EPI, SCHED, 8>(p, smem);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_blk16w4_kernel(const whmr_gemm_blk_desc p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemm_blk16_body<4, 4, EPI, 1, 4>(p, smem);
 }
 
 template <int MI0, int MI1, int EPI, int SCHED>
@@ -381,6 +482,32 @@ static int launch_blk16_s(const whmr_gemm_blk_desc& p, hipStream_t st) {
     return 0;
 }
 
+template <int EPI>
+static int launch_blk16w4_s(const whmr_gemm_blk_desc& p, hipStream_t st) {
+    using cfg = blk16_cfg<4, 4>;
+    auto kern = gemm_blk16w4_kernel<EPI>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, cfg::LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    const int tiles = ((p.M + cfg::BM - 1) / cfg::BM) * (p.N / cfg::BN);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), cfg::LDS, st, p);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+static int launch_blk16w4_epi(const whmr_gemm_blk_desc& p, hipStream_t st) {
+    switch (p.epi) {
+        case 0: return launch_blk16w4_s<0>(p, st);
+        case 1: return launch_blk16w4_s<1>(p, st);
+        case 2: return launch_blk16w4_s<2>(p, st);
+        case 3: return launch_blk16w4_s<3>(p, st);
+    }
+    return (int)hipErrorInvalidValue;
+}
+
 template <int MI0, int MI1>
 static int launch_blk16_epi(const whmr_gemm_blk_desc& p, hipStream_t st, int sched) {
     // sched: 0 two barriers per half tile, anything else one barrier
@@ -396,6 +523,7 @@ static int launch_blk16_epi(const whmr_gemm_blk_desc& p, hipStream_t st, int sch
 // Tile heights (x 256 columns): the wave rows own MI0 and MI1 row blocks.
 static int blk16_launch_tile(const whmr_gemm_blk_desc& p, int tile, hipStream_t st, int sched) {
     switch (tile) {
+        case 0x144: return (p.K % 64) ? launch_blk16_epi<4, 4>(p, st, sched) : launch_blk16w4_epi(p, st);     // 256 x 256 on four waves (one per SIMD)
         case 0x44: return launch_blk16_epi<4, 4>(p, st, sched);      // 256 x 256
         case 0x55: return launch_blk16_epi<5, 5>(p, st, sched);      // 320 x 256
         case 0x43: return launch_blk16_epi<4, 3>(p, st, sched);      // 224 x 256

@@ -592,6 +592,37 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
     *(float4*)(C + (size_t)m * ldc + n) = a;
 }
 
+// single product on the four-wave body (256-row tiles, no gather)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_tn4_kernel(const tn_params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lid = p.round_robin ? (int)blockIdx.x : xcd_remap(blockIdx.x, p.tiles * p.splits);
+    const int slice = lid / p.tiles, tile = lid - slice * p.tiles;
+    const int k_begin = slice * p.k_per_split;
+    const int k_end = min(p.K, k_begin + p.k_per_split);
+    tn4_body<TN4_NS>(p, smem, tile, k_begin, k_end, p.ws ? p.ws + (size_t)slice * p.Mo * p.No : p.C, p.ws ? (long)p.No : p.ldc,
+                     p.ws ? p.ws + (size_t)p.splits * p.Mo * p.No + (size_t)slice * p.Mo : p.db);
+}
+
+static int tn_w4() {
+    static const int w4 = [] { const char* e = getenv("WHMR_TN_W4"); return e ? (e[0] == '1' ? 1 : 0) : 1; }();     // A/B: 0 = the eight-wave ping-pong body
+    return w4;
+}
+
+static int launch_tn4(tn_params p, int tiles, int splits, hipStream_t st) {
+    constexpr int LDS = TN4_NS * (32 * 256 * 2 + 32 * 256 * 2);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_tn4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    static const int rr = [] { const char* e = getenv("WHMR_TN_RR"); return e && e[0] == '1' ? 1 : 0; }();
+    p.tiles = tiles; p.splits = splits; p.round_robin = rr;
+    hipLaunchKernelGGL(gemm_tn4_kernel, dim3(tiles * splits), dim3(256), LDS, st, p);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}
+
 template <int MI, bool GATHER, bool PP>
 static int launch_tn_pp(tn_params p, int tiles, int splits, hipStream_t st) {
     constexpr int LDS = ((PP && MI == 4) ? TN_NS4 : 3) * (32 * 64 * MI * 2 + 32 * 256 * 2);
@@ -631,7 +662,7 @@ static int tn_run(tn_params p, int splits, void* workspace, long workspace_bytes
     p.ws = splits > 1 ? (float*)workspace : nullptr;
     int rc;
     if (p.gather) rc = MI == 4 ? launch_tn<4, true>(p, tiles, splits, st) : MI == 2 ? launch_tn<2, true>(p, tiles, splits, st) : launch_tn<1, true>(p, tiles, splits, st);
-    else rc = MI == 4 ? launch_tn<4, false>(p, tiles, splits, st) : MI == 2 ? launch_tn<2, false>(p, tiles, splits, st) : launch_tn<1, false>(p, tiles, splits, st);
+    else rc = MI == 4 ? (tn_w4() ? launch_tn4(p, tiles, splits, st) : launch_tn<4, false>(p, tiles, splits, st)) : MI == 2 ? launch_tn<2, false>(p, tiles, splits, st) : launch_tn<1, false>(p, tiles, splits, st);
     if (rc) return rc;
     if (splits > 1) {
         hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)(((long)p.Mo * (p.No >> 2) + 255) / 256)), dim3(256), 0, st, (const float*)workspace, splits,
@@ -764,8 +795,7 @@ extern "C" int whmr_gemm_tn_bf16_group(const whmr_tn_item* items, int n_items, i
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    static const int w4 = [] { const char* e = getenv("WHMR_TN_W4"); return e ? (e[0] == '1' ? 1 : 0) : 1; }();     // A/B: 0 = the eight-wave ping-pong body
-    if (w4) hipLaunchKernelGGL(gemm_tn4_group_kernel, dim3(g.total), dim3(256), LDS4, st, g);
+    if (tn_w4()) hipLaunchKernelGGL(gemm_tn4_group_kernel, dim3(g.total), dim3(256), LDS4, st, g);
     else hipLaunchKernelGGL(gemm_tn_group_kernel<true>, dim3(g.total), dim3(512), LDS, st, g);
     WHMR_CHECK_LAUNCH();
     if (splits > 1) {
