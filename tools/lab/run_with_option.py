@@ -1,5 +1,5 @@
 """Run bench.py with whmr_set_option(key, value) applied first (A/B of tuning switches that have no environment variable):
-    python tools/lab/run_with_option.py <key> <value> [bench.py arguments ...]"""
+    python tools/lab/run_with_option.py <key>[,<key>...] <value>[,<value>...] [bench.py arguments ...]"""
 import os
 import sys
 
@@ -8,5 +8,6 @@ sys.path.insert(0, root)
 import bench                      # noqa: E402
 from whmr_amd import _lib         # noqa: E402
 
-_lib.lib().whmr_set_option(int(sys.argv[1]), int(sys.argv[2]))
+for k, v in zip(sys.argv[1].split(','), sys.argv[2].split(',')):
+    _lib.lib().whmr_set_option(int(k), int(v))
 raise SystemExit(bench.main(sys.argv[3:]))

@@ -332,113 +332,165 @@ __device__ __forceinline__ void tn_body(const tn_params& p, char* smem, int tile
 // back to back and the step's 32 reads + 8 DMA pieces sit in the gaps between MFMAs (1.3 per gap; ~5 fit).  Wave (wm, wn) of 2 x 2 owns 128 x 128
 // outputs: 8 fragments per 16-row half step (A 4, B 4) for 16 MFMAs -- 0.5 fragment per MFMA instead of 0.75.  Ring of 4 slots (128 KB), the
 // DMA three steps ahead, ONE barrier per step (between the two half steps: the next step's first fragments are read under the second half's MFMAs).
+// Tiles of 64 MI x 256 (MI = 4, 2, 1: wave (wm, wn) of 2 x 2 owns 32 MI x 128 outputs) and the gathering B operand of the convolution weight gradients
+// run the same body; MI < 4 has fewer MFMAs per fragment (the B fragments are shared by fewer row blocks) and is bound by its reads / its LDS-DMA.
 template <int OFF> __device__ __forceinline__ void tn4_read_at(uint2& d, uint32_t addr) {
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
 }
-__device__ __forceinline__ void tn4_read(uint2& d, uint32_t addr, const int off) {     // off: a constant after unrolling (0, 4, 8 or 12 KiB)
-    switch (off) {
+// read q = 2 ks + r (half step ks, rows + 8 r) of a fragment in a tile of ROWB-byte rows: byte offset 8 q ROWB (a constant after unrolling)
+template <int ROWB> __device__ __forceinline__ void tn4_read(uint2& d, uint32_t addr, const int q) {
+    switch (q) {
         case 0: tn4_read_at<0>(d, addr); break;
-        case 4096: tn4_read_at<4096>(d, addr); break;
-        case 8192: tn4_read_at<8192>(d, addr); break;
-        default: tn4_read_at<12288>(d, addr); break;
+        case 1: tn4_read_at<8 * ROWB>(d, addr); break;
+        case 2: tn4_read_at<16 * ROWB>(d, addr); break;
+        default: tn4_read_at<24 * ROWB>(d, addr); break;
+    }
+}
+__device__ __forceinline__ void tn_wait_lgkmcnt_n(const int n) {                        // n: a constant after unrolling
+    switch (n) {
+        case 0: tn_wait_lgkmcnt<0>(); break;   case 1: tn_wait_lgkmcnt<1>(); break;   case 2: tn_wait_lgkmcnt<2>(); break;   case 3: tn_wait_lgkmcnt<3>(); break;
+        case 4: tn_wait_lgkmcnt<4>(); break;   case 5: tn_wait_lgkmcnt<5>(); break;   case 6: tn_wait_lgkmcnt<6>(); break;   case 7: tn_wait_lgkmcnt<7>(); break;
+        case 8: tn_wait_lgkmcnt<8>(); break;   case 9: tn_wait_lgkmcnt<9>(); break;   case 10: tn_wait_lgkmcnt<10>(); break; case 11: tn_wait_lgkmcnt<11>(); break;
+        case 12: tn_wait_lgkmcnt<12>(); break; case 13: tn_wait_lgkmcnt<13>(); break; case 14: tn_wait_lgkmcnt<14>(); break; default: tn_wait_lgkmcnt<15>(); break;
     }
 }
 
-template <int NS>
+template <int NS, int MI, bool GATHER>
 __device__ __forceinline__ void tn4_body(const tn_params& p, char* smem, int tile, int k_begin, int k_end, float* __restrict__ out, long ldo,
                                          float* __restrict__ dbo) {
-    constexpr int BN = 256, BK = 32, A_BYTES = BK * 256 * 2, SLOT = 2 * A_BYTES, UPW = 8;
+    constexpr int BM = 64 * MI, BN = 256, BK = 32, CHA = BM / 8, ROWA = BM * 2;
+    constexpr int A_BYTES = BK * BM * 2, B_BYTES = BK * BN * 2, SLOT = A_BYTES + B_BYTES;
+    constexpr int NA = A_BYTES / 1024, UPW = (NA + 16) / 4;                   // 1-KiB DMA units per step: NA = 4 MI of A, 16 of B; per wave MI + 4
+    constexpr int PH0 = (UPW + 1) / 2, PH1 = UPW - PH0;                        // pieces issued under the first / second half step
+    constexpr int NM = 4 * MI, NR = 2 * (MI + 4);                              // MFMAs and reads per half step
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, hi = lane >> 5;
     const int tiles_n = p.No / BN;
     const int tm = tile / tiles_n, tn = tile % tiles_n;
-    const int m0 = tm * 256, n0 = tn * BN;
+    const int m0 = tm * BM, n0 = tn * BN;
     const int nkt = (k_end - k_begin) / BK;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(tn_lds_void_t*)smem;
 
-    // DMA unit u = wave + 4 i (i < 8): i < 4 -> A units (two 512-B rows each), else B units.  Lane L -> byte L * 16 of the unit -> (row, chunk
-    // position); source chunk = position ^ 4 (row & 3) (the swizzle sits on the source side).  Per-lane 32-bit byte offsets from uniform bases.
+    // DMA unit u = wave + 4 i (i < UPW): i < MI -> A units (1 KiB = 1024 / ROWA rows), else B units (two 512-B rows).  Lane L -> byte L * 16 of the
+    // unit -> (row, chunk position); source chunk = position ^ swizzle(row) (the swizzle sits on the source side).  Per-lane 32-bit byte offsets
+    // from uniform bases; the gathering B operand carries (image, oy, ox) of its row from step to step instead (pieces are issued in step order).
     uint32_t voff[UPW];
+    int gb[UPW], goy[UPW], gox[UPW];
 #pragma unroll
     for (int i = 0; i < UPW; ++i) {
-        const int u = (wave + 4 * i) & 15;
+        const bool isA = i < MI;
+        const int u = wave + 4 * i - (isA ? 0 : NA);
         const int off = u * 1024 + lane * 16;
-        const int row = off >> 9, pos = (off & 511) >> 4;
-        voff[i] = (uint32_t)(row * (i < 4 ? p.lda : p.ldb) * 2 + ((pos ^ (4 * (row & 3))) << 4));
+        const int rowb = isA ? ROWA : 512;
+        const int row = off / rowb, pos = (off % rowb) >> 4;
+        const int chunk = pos ^ (isA ? tn_swz<CHA>(row) : tn_swz<32>(row));
+        if (GATHER && !isA) {
+            voff[i] = (uint32_t)(chunk << 4);
+            const int k = k_begin + row, ohw = p.OH * p.OW;
+            gb[i] = k / ohw;
+            const int rem = k - gb[i] * ohw;
+            goy[i] = rem / p.OW;
+            gox[i] = rem - goy[i] * p.OW;
+        } else {
+            voff[i] = (uint32_t)(row * (isA ? p.lda : p.ldb) * 2 + (chunk << 4));
+            gb[i] = goy[i] = gox[i] = 0;
+        }
     }
     const char* baseA = (const char*)(p.A + (size_t)k_begin * p.lda + m0);
-    const char* baseB = (const char*)(p.B + (size_t)k_begin * p.ldb + n0);
+    const char* baseB = GATHER ? (const char*)p.B : (const char*)(p.B + (size_t)k_begin * p.ldb + n0);
     const size_t stepA = (size_t)BK * p.lda * 2, stepB = (size_t)BK * p.ldb * 2;
-    auto dma = [&](int kt, int i) {                                            // piece i of step kt; past the end: the last step again (nobody reads it)
+    const int g_tap = GATHER ? n0 / p.GC : 0, g_c0 = GATHER ? n0 - g_tap * p.GC : 0;
+    const int g_ky = GATHER ? g_tap / p.KW : 0, g_kx = GATHER ? g_tap - g_ky * p.KW : 0;
+    auto dma = [&](int kt, int i) {                                            // piece i of step kt; past the end: data nobody reads (the last step again / zeros)
         const int ks_ = (TN_LAB & 16) ? (kt & 3) : kt < nkt ? kt : nkt - 1;      // lab 16: every step re-reads the first four steps' rows (L2-hot operands)
-        const char* src = (i < 4 ? baseA + (size_t)ks_ * stepA : baseB + (size_t)ks_ * stepB) + voff[i];
+        const char* src;
+        if (GATHER && i >= MI) {
+            const int iy = goy[i] * p.S + g_ky - p.P, ix = gox[i] * p.S + g_kx - p.P;
+            const bool in = kt < nkt && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+            src = in ? baseB + (((size_t)(gb[i] * p.IH + iy) * p.IW + ix) * p.ldb + g_c0) * 2 + voff[i] : (const char*)p.zeros + voff[i];
+            gox[i] += BK;
+            while (gox[i] >= p.OW) {
+                gox[i] -= p.OW;
+                if (++goy[i] == p.OH) { goy[i] = 0; ++gb[i]; }
+            }
+        } else {
+            src = (i < MI ? baseA + (size_t)ks_ * stepA : baseB + (size_t)ks_ * stepB) + voff[i];
+        }
         if (!(TN_LAB & 4)) __builtin_amdgcn_global_load_lds((tn_gbl_void_t*)src, (tn_lds_void_t*)(smem + (kt % NS) * SLOT + (wave + 4 * i) * 1024), 16, 0, 0);
     };
-    // fragment read addresses inside slot 0: lane -> (row, column) of tn_frag_issue with R0 = 0; a half step adds 16 rows (8 KiB), the second read 8 rows
-    uint32_t fa_off[4], fb_off[4];
+    // fragment read addresses inside slot 0: lane -> (row, column) of tn_frag_issue with R0 = 0; a half step adds 16 rows, the second read 8 rows
+    uint32_t fa_off[MI], fb_off[4];
     {
         const int g = lane >> 4, i16 = lane & 15;
         const int row = 4 * (g >> 1) + (i16 >> 2);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ca = wm * 128 + i * 32 + 16 * (g & 1) + 4 * (i16 & 3), cb = wn * 128 + i * 32 + 16 * (g & 1) + 4 * (i16 & 3);
-            fa_off[i] = lds0 + row * 512 + ((((ca >> 3) ^ (4 * (row & 3)))) << 4) + (ca & 7) * 2;
-            fb_off[i] = lds0 + A_BYTES + row * 512 + ((((cb >> 3) ^ (4 * (row & 3)))) << 4) + (cb & 7) * 2;
+        for (int i = 0; i < MI; ++i) {
+            const int ca = wm * (32 * MI) + i * 32 + 16 * (g & 1) + 4 * (i16 & 3);
+            fa_off[i] = lds0 + row * ROWA + ((((ca >> 3) ^ tn_swz<CHA>(row))) << 4) + (ca & 7) * 2;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int cb = wn * 128 + j * 32 + 16 * (g & 1) + 4 * (i16 & 3);
+            fb_off[j] = lds0 + A_BYTES + row * 512 + ((((cb >> 3) ^ tn_swz<32>(row))) << 4) + (cb & 7) * 2;
         }
     }
-    f32x16_t acc[4][4];
+    f32x16_t acc[MI][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // bias gradient: column sums of A.  The tiles_n column tiles of a row tile and both wave columns read the same A fragments: fragment block
-    // b = 4 wm + i (0..7) of the row tile is summed by the one (column tile, wave column) with b % (2 tiles_n) == 2 tn + wn -- at most one block
-    // per wave at tiles_n >= 2 -- as four v_dot2c against bf16 ones, behind a scalar branch (inline asm: the compiler would turn the branch into
-    // sixteen unconditional dot products and a select per half step on every wave: +27 % on the bare MFMA stream)
-    bool db_on[4];
-    float dbs[4];
+    // b = MI wm + i (0 .. 2 MI - 1) of the row tile is summed by the one (column tile, wave column) with b % (2 tiles_n) == 2 tn + wn -- at most one
+    // block per wave at tiles_n >= MI / 2 -- as four v_dot2c against bf16 ones, behind a scalar branch (inline asm: the compiler would turn the
+    // branch into sixteen unconditional dot products and a select per half step on every wave: +27 % on the bare MFMA stream)
+    bool db_on[MI];
+    float dbs[MI];
+    bool want_db = false;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { dbs[i] = 0.f; db_on[i] = p.db != nullptr && ((wm * 4 + i) % (2 * tiles_n)) == 2 * tn + wn; }
-    const bool want_db = db_on[0] | db_on[1] | db_on[2] | db_on[3];
+    for (int i = 0; i < MI; ++i) { dbs[i] = 0.f; db_on[i] = p.db != nullptr && ((wm * MI + i) % (2 * tiles_n)) == 2 * tn + wn; want_db |= db_on[i]; }
     auto db_add = [&](float& s, const tn_raw& f) {
         asm volatile("v_dot2c_f32_bf16 %0, %1, %5\n\tv_dot2c_f32_bf16 %0, %2, %5\n\tv_dot2c_f32_bf16 %0, %3, %5\n\tv_dot2c_f32_bf16 %0, %4, %5"
                      : "+v"(s) : "v"(f.x.x), "v"(f.x.y), "v"(f.y.x), "v"(f.y.y), "v"(0x3f803f80u));
     };
 
-    tn_raw qa[2][4], qb[2][4];                                                 // two fragment sets: the half step in the MFMAs, the next one in flight
-    // reads of half step (slot base sb, rows 16 ks ..) into set `dst`, fragment f (0..3 A, 4..7 B), read r (0, 1)
-#define TN4_READ(dst, sb, ks, f, r)                                                                                          \
+    tn_raw qa[2][MI], qb[2][4];                                                // two fragment sets: the half step in the MFMAs, the next one in flight
+    // The NR = 2 (MI + 4) reads of a half step are issued in the order its MFMAs (i-major) need them -- B0 A0 B1 B2 B3 A1 .. -- i.e. read position
+    // q -> fragment q >> 1 of that order, read q & 1 -- and waited for by COUNT in front of the MFMA that first uses them: what may still be in
+    // flight there = the later reads of that half step + the reads the new half step has issued so far (MI = 4: lgkmcnt 12 / 11 / 10 / 9 / 8 for
+    // MFMAs 0-4, 10 for MFMA 8, 12 for MFMA 12), so no half step ends on an LDS round trip.  Nothing else in the loop touches lgkmcnt (no scalar
+    // loads: checked in the ISA).
+#define TN4_READ(dst, sb, ks, q)                                                                                             \
     do {                                                                                                                     \
         if (!(TN_LAB & 2)) {                                                                                                 \
-            if ((f) < 4) tn4_read((r) ? qa[dst][(f) & 3].y : qa[dst][(f) & 3].x, fa_off[(f) & 3] + (sb), (ks) * 8192 + (r) * 4096);            \
-            else tn4_read((r) ? qb[dst][(f) & 3].y : qb[dst][(f) & 3].x, fb_off[(f) & 3] + (sb), (ks) * 8192 + (r) * 4096);                    \
+            const int fo_ = (q) >> 1, r_ = (q) & 1;                      /* order: B0 A0 B1 B2 B3 A1 A2 A3 */                \
+            if (fo_ == 1) tn4_read<ROWA>(r_ ? qa[dst][0].y : qa[dst][0].x, fa_off[0] + (sb), 2 * (ks) + r_);                 \
+            else if (fo_ >= 5) tn4_read<ROWA>(r_ ? qa[dst][(fo_ - 4) % MI].y : qa[dst][(fo_ - 4) % MI].x, fa_off[(fo_ - 4) % MI] + (sb), 2 * (ks) + r_); \
+            else { const int j_ = fo_ == 0 ? 0 : fo_ - 1;                                                                    \
+                   tn4_read<512>(r_ ? qb[dst][j_].y : qb[dst][j_].x, fb_off[j_] + (sb), 2 * (ks) + r_); }                    \
         }                                                                                                                    \
     } while (0)
-    // The 16 reads of a half step are issued in the order its MFMAs (i-major) need them -- B0 A0 B1 B2 B3 A1 A2 A3 -- and waited for by COUNT in front
-    // of the MFMA that first uses them (lgkmcnt 12 / 11 / 10 / 9 / 8 for MFMAs 0-4, 10 for MFMA 8, 12 for MFMA 12: what is still allowed in flight
-    // = the later reads of that half step + the reads the new half step has issued so far), so no half step ends on an LDS round trip.  Nothing
-    // else in the loop touches lgkmcnt (no scalar loads: checked in the ISA).
-    // one half step: the 16 MFMAs of fragment set `cur`, and in their gaps the 16 reads of the next half step (set cur ^ 1; slot base nsb, half nks)
-    // + 4 of the 8 DMA pieces of step dkt (pieces dp0 .. dp0 + 3) + the bias sums of set `cur`.  Reads and pieces are unconditional: past the last
+    // one half step: the NM = 4 MI MFMAs of fragment set `cur`, and in their gaps the NR reads of the next half step (set cur ^ 1; slot base nsb, half
+    // nks) + `np` of the DMA pieces of step dkt (pieces dp0 ..) + the bias sums of set `cur`.  Reads and pieces are unconditional: past the last
     // step they fetch data nobody uses -- no branch in the stream, one vmcnt count for every step.
-#define TN4_HALF(cur, nsb, nks, dkt, dp0)                                                                                    \
+#define TN4_HALF(cur, nsb, nks, dkt, dp0, np)                                                                                \
     do {                                                                                                                     \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                      \
+        _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                                                     \
             _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                  \
                 const int g_ = i * 4 + j;                                                                                    \
-                if (g_ == 0) tn_wait_lgkmcnt<12>(); else if (g_ == 1) tn_wait_lgkmcnt<11>(); else if (g_ == 2) tn_wait_lgkmcnt<10>();           \
-                else if (g_ == 3) tn_wait_lgkmcnt<9>(); else if (g_ == 4) tn_wait_lgkmcnt<8>(); else if (g_ == 8) tn_wait_lgkmcnt<10>();          \
-                else if (g_ == 12) tn_wait_lgkmcnt<12>();                                                                    \
+                /* last read position this MFMA needs (fragment order above), if it is the first user of that fragment */   \
+                const int need_ = i == 0 ? (j == 0 ? 3 : 2 * (j + 1) + 1) : (j == 0 ? 2 * (4 + i) + 1 : -1);                  \
+                if (need_ >= 0) tn_wait_lgkmcnt_n((NR - 1 - need_) + (g_ * NR) / NM);                                        \
                 __builtin_amdgcn_sched_barrier(0);                                                                           \
                 if (!(TN_LAB & 1)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tn_frag_value(qa[cur][i]), tn_frag_value(qb[cur][j]), acc[i][j], 0, 0, 0); \
                 __builtin_amdgcn_sched_barrier(0);                                                                           \
-                TN4_READ((cur) ^ 1, nsb, nks, ((0x32107654 >> (4 * (7 - (g_ >> 1)))) & 15), g_ & 1);                         \
-                if ((g_ & 3) == 1) dma(dkt, (dp0) + (g_ >> 2));                                                              \
+                _Pragma("unroll") for (int q_ = (g_ * NR) / NM; q_ < ((g_ + 1) * NR) / NM; ++q_) TN4_READ((cur) ^ 1, nsb, nks, q_);            \
+                _Pragma("unroll") for (int t_ = 0; t_ < (np); ++t_)                                                          \
+                    if ((t_ * NM + NM / 2) / (np) == g_) dma(dkt, (dp0) + t_);                                               \
                 if (j == 3 && db_on[i]) db_add(dbs[i], qa[cur][i]);                                                          \
                 __builtin_amdgcn_sched_barrier(0);                                                                           \
             }                                                                                                                \
@@ -454,20 +506,20 @@ __device__ __forceinline__ void tn4_body(const tn_params& p, char* smem, int til
         tn_wait_vmcnt<(NS - 2) * UPW>();
         __builtin_amdgcn_s_barrier();
 #pragma unroll
-        for (int f = 0; f < 8; ++f) { TN4_READ(0, 0u, 0, f, 0); TN4_READ(0, 0u, 0, f, 1); }
+        for (int q = 0; q < NR; ++q) TN4_READ(0, 0u, 0, q);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         for (int x = 0; x < nkt; ++x) {
             const uint32_t sb = (uint32_t)((x % NS) * SLOT), sb1 = (uint32_t)(((x + 1) % NS) * SLOT);
-            // first half step; reads of the second half (same slot); pieces 0-3 of step x + NS - 1 (its slot held step x - 1: everybody passed the
-            // barrier of step x - 1 after their last read of it)
-            TN4_HALF(0, sb, 1, x + NS - 1, 0);
-            // own pieces of step x + 1 have landed: younger = steps x + 2 .. x + NS - 2 (8 each) + the 4 pieces just issued
-            tn_wait_vmcnt<(NS - 3) * UPW + 4>();
+            // first half step; reads of the second half (same slot); the first PH0 pieces of step x + NS - 1 (its slot held step x - 1: everybody passed
+            // the barrier of step x - 1 after their last read of it)
+            TN4_HALF(0, sb, 1, x + NS - 1, 0, PH0);
+            // own pieces of step x + 1 have landed: younger = steps x + 2 .. x + NS - 2 (UPW each) + the PH0 pieces just issued
+            tn_wait_vmcnt<(NS - 3) * UPW + PH0>();
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            // second half step; reads of step x + 1's first half; pieces 4-7
-            TN4_HALF(1, sb1, 0, x + NS - 1, 4);
+            // second half step; reads of step x + 1's first half; the other pieces
+            TN4_HALF(1, sb1, 0, x + NS - 1, PH0, PH1);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         tn_wait_vmcnt<0>();                                                      // the surplus pieces land in this workgroup's LDS: not after it has gone
@@ -476,19 +528,19 @@ __device__ __forceinline__ void tn4_body(const tn_params& p, char* smem, int til
 #undef TN4_READ
     if (want_db) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < MI; ++i) {
             const float v = dbs[i] + __shfl_xor(dbs[i], 32, 64);
-            if (db_on[i] && hi == 0) dbo[m0 + wm * 128 + i * 32 + l31] = v;
+            if (db_on[i] && hi == 0) dbo[m0 + wm * (32 * MI) + i * 32 + l31] = v;
         }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + wn * 128 + j * 32 + l31;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const int m = m0 + wm * (32 * MI) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                 out[(size_t)m * ldo + n] = acc[i][j][r];
             }
         }
@@ -592,33 +644,36 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
     *(float4*)(C + (size_t)m * ldc + n) = a;
 }
 
-// single product on the four-wave body (256-row tiles, no gather)
+// single product on the four-wave body
+template <int MI, bool GATHER>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_tn4_kernel(const tn_params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lid = p.round_robin ? (int)blockIdx.x : xcd_remap(blockIdx.x, p.tiles * p.splits);
     const int slice = lid / p.tiles, tile = lid - slice * p.tiles;
     const int k_begin = slice * p.k_per_split;
     const int k_end = min(p.K, k_begin + p.k_per_split);
-    tn4_body<TN4_NS>(p, smem, tile, k_begin, k_end, p.ws ? p.ws + (size_t)slice * p.Mo * p.No : p.C, p.ws ? (long)p.No : p.ldc,
-                     p.ws ? p.ws + (size_t)p.splits * p.Mo * p.No + (size_t)slice * p.Mo : p.db);
+    tn4_body<TN4_NS, MI, GATHER>(p, smem, tile, k_begin, k_end, p.ws ? p.ws + (size_t)slice * p.Mo * p.No : p.C, p.ws ? (long)p.No : p.ldc,
+                                 p.ws ? p.ws + (size_t)p.splits * p.Mo * p.No + (size_t)slice * p.Mo : p.db);
 }
 
 static int tn_w4() {
-    static const int w4 = [] { const char* e = getenv("WHMR_TN_W4"); return e ? (e[0] == '1' ? 1 : 0) : 1; }();     // A/B: 0 = the eight-wave ping-pong body
+    static const int w4 = [] { const char* e = getenv("WHMR_TN_W4"); return e ? atoi(e) : 3; }();     // A/B: 0 = the eight-wave ping-pong body; bit 0 plain, bit 1 gathering products
     return w4;
 }
 
+template <int MI, bool GATHER>
 static int launch_tn4(tn_params p, int tiles, int splits, hipStream_t st) {
-    constexpr int LDS = TN4_NS * (32 * 256 * 2 + 32 * 256 * 2);
+    constexpr int LDS = TN4_NS * (32 * 64 * MI * 2 + 32 * 256 * 2);
+    auto kern = gemm_tn4_kernel<MI, GATHER>;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_tn4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
     static const int rr = [] { const char* e = getenv("WHMR_TN_RR"); return e && e[0] == '1' ? 1 : 0; }();
     p.tiles = tiles; p.splits = splits; p.round_robin = rr;
-    hipLaunchKernelGGL(gemm_tn4_kernel, dim3(tiles * splits), dim3(256), LDS, st, p);
+    hipLaunchKernelGGL(kern, dim3(tiles * splits), dim3(256), LDS, st, p);
     WHMR_CHECK_LAUNCH();
     return 0;
 }
@@ -661,8 +716,14 @@ static int tn_run(tn_params p, int splits, void* workspace, long workspace_bytes
     p.k_per_split = sps * 32;
     p.ws = splits > 1 ? (float*)workspace : nullptr;
     int rc;
-    if (p.gather) rc = MI == 4 ? launch_tn<4, true>(p, tiles, splits, st) : MI == 2 ? launch_tn<2, true>(p, tiles, splits, st) : launch_tn<1, true>(p, tiles, splits, st);
-    else rc = MI == 4 ? (tn_w4() ? launch_tn4(p, tiles, splits, st) : launch_tn<4, false>(p, tiles, splits, st)) : MI == 2 ? launch_tn<2, false>(p, tiles, splits, st) : launch_tn<1, false>(p, tiles, splits, st);
+    const int w4 = tn_w4() & (p.gather ? 2 : 1);             // WHMR_TN_W4: bit 0 plain products, bit 1 gathering (convolution) products
+    if (p.gather) {
+        if (w4) rc = MI == 4 ? launch_tn4<4, true>(p, tiles, splits, st) : MI == 2 ? launch_tn4<2, true>(p, tiles, splits, st) : launch_tn4<1, true>(p, tiles, splits, st);
+        else rc = MI == 4 ? launch_tn<4, true>(p, tiles, splits, st) : MI == 2 ? launch_tn<2, true>(p, tiles, splits, st) : launch_tn<1, true>(p, tiles, splits, st);
+    } else {
+        if (w4) rc = MI == 4 ? launch_tn4<4, false>(p, tiles, splits, st) : MI == 2 ? launch_tn4<2, false>(p, tiles, splits, st) : launch_tn4<1, false>(p, tiles, splits, st);
+        else rc = MI == 4 ? launch_tn<4, false>(p, tiles, splits, st) : MI == 2 ? launch_tn<2, false>(p, tiles, splits, st) : launch_tn<1, false>(p, tiles, splits, st);
+    }
     if (rc) return rc;
     if (splits > 1) {
         hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)(((long)p.Mo * (p.No >> 2) + 255) / 256)), dim3(256), 0, st, (const float*)workspace, splits,
@@ -714,7 +775,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int slice = l / p.tiles, tile = l - slice * p.tiles;
     const int k_begin = slice * p.k_per_split;
     const int k_end = min(p.K, k_begin + p.k_per_split);
-    tn4_body<TN4_NS>(p, smem, tile, k_begin, k_end, p.ws ? p.ws + (size_t)slice * p.Mo * p.No : p.C, p.ws ? (long)p.No : p.ldc,
+    tn4_body<TN4_NS, 4, false>(p, smem, tile, k_begin, k_end, p.ws ? p.ws + (size_t)slice * p.Mo * p.No : p.C, p.ws ? (long)p.No : p.ldc,
                 p.ws ? p.ws + (size_t)p.splits * p.Mo * p.No + (size_t)slice * p.Mo : p.db);
 }
 
@@ -795,7 +856,7 @@ extern "C" int whmr_gemm_tn_bf16_group(const whmr_tn_item* items, int n_items, i
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    if (tn_w4()) hipLaunchKernelGGL(gemm_tn4_group_kernel, dim3(g.total), dim3(256), LDS4, st, g);
+    if (tn_w4() & 1) hipLaunchKernelGGL(gemm_tn4_group_kernel, dim3(g.total), dim3(256), LDS4, st, g);
     else hipLaunchKernelGGL(gemm_tn_group_kernel<true>, dim3(g.total), dim3(512), LDS, st, g);
     WHMR_CHECK_LAUNCH();
     if (splits > 1) {
