@@ -657,7 +657,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 }
 
 static int tn_w4() {
-    static const int w4 = [] { const char* e = getenv("WHMR_TN_W4"); return e ? atoi(e) : 3; }();     // A/B: 0 = the eight-wave ping-pong body; bit 0 plain, bit 1 gathering products
+    static const int w4 = [] { const char* e = getenv("WHMR_TN_W4"); return e ? atoi(e) : 1; }();     // 0 = the eight-wave ping-pong body; bit 0: plain products on four waves (default), bit 1: gathering products too
+                                                                                                         // (rocprof, training step: deconv dW 247 vs 222 us, Tz conv dW 390 vs 333, IUV head 728 vs 734: the per-lane pixel bookkeeping of the gather sits in the MFMA stream -- stays off)
     return w4;
 }
 
