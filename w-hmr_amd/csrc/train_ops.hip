@@ -258,16 +258,23 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
         const float* xr = x + (size_t)row * C;
         const float* dyr = dy + (size_t)row * C;
-        float4 v[MAXV], d[MAXV];
+        float4 v[MAXV], d[MAXV], rres[MAXV];
         float s = 0.f;
+        const float rs = (cast_out && row_scale) ? row_scale[row] : 1.0f;
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
             const int c4 = lane + 64 * i;
             if (c4 < nv) {
                 v[i] = *(const float4*)(xr + c4 * 4);
                 d[i] = *(const float4*)(dyr + c4 * 4);
-                s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+                // the residual gradient is requested with the row (it was a dependent round trip behind the three reductions)
+                rres[i] = dres ? *(const float4*)(dres + (size_t)row * C + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
+        }
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c4 = lane + 64 * i;
+            if (c4 < nv) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
         }
         const float mean = wave_sum(s) / (float)C;
         float q = 0.f;
@@ -301,13 +308,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             if (c4 < nv) {
                 float4 o = make_float4(rstd * (d[i].x - mg - v[i].x * mgx), rstd * (d[i].y - mg - v[i].y * mgx),
                                        rstd * (d[i].z - mg - v[i].z * mgx), rstd * (d[i].w - mg - v[i].w * mgx));
-                if (dres) {
-                    const float4 r = *(const float4*)(dres + (size_t)row * C + c4 * 4);
-                    o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
-                }
+                if (dres) { o.x += rres[i].x; o.y += rres[i].y; o.z += rres[i].z; o.w += rres[i].w; }
                 *(float4*)(dxr + c4 * 4) = o;
                 if (cast_out) {                        // the bf16 GEMM operand of the next branch's backward, stochastic-depth row factor applied
-                    const float rs = row_scale ? row_scale[row] : 1.0f;
                     *(uint2*)(cast_out + (size_t)row * C + c4 * 4) = make_uint2(pack_bf16x2(o.x * rs, o.y * rs), pack_bf16x2(o.z * rs, o.w * rs));
                 }
             }
