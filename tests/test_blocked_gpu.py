@@ -84,6 +84,50 @@ def test_gemm_blk_matches_row_major_kernel_bitwise(dev):
     assert torch.equal(L.from_blocked(t, M), ref)
 
 
+@pytest.mark.parametrize('M,N,K', [(1000, 512, 768), (12544, 768, 768), (777, 256, 64), (3000, 2304, 3072)])
+def test_gemm_blk_four_wave_tile_is_bit_identical(dev, M, N, K):
+    """tile id 0x144 (the 256 x 256 tile on four waves, one per SIMD: gemm_blk16_body<.., NW = 4>) against 0x44: same MFMA instruction and k order per
+    accumulator, same epilogue arithmetic, the LayerNorm-fold row statistics taken in the eight-wave kernel's order -- every epilogue, the producer
+    side of the fold (bf16 operand copy + partial sums, with a row shift) and the consumer side, ragged M, 2 half tiles to the ViT's K"""
+    from whmr_amd import _lib as L
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).bfloat16().to(dev)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).bfloat16().to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    res = torch.randn(M, N, generator=g).to(dev)
+    pos = torch.randn(196, N, generator=g).to(dev)
+    ab, wb = L.to_blocked(a), L.to_blocked(w)
+    nb = ab.shape[0]
+    got = {}
+    for tile in (0x44, 0x144):
+        o = []
+        out = torch.full((nb, N // 8, 32, 8), float('nan'), device=dev, dtype=torch.bfloat16)
+        L.gemm_blk(ab, wb, out, M, bias=bias, epi=L.EPI_BF16, tile=tile); o.append(L.from_blocked(out, M).clone())
+        L.gemm_blk(ab, wb, out, M, bias=bias, epi=L.EPI_BF16_GELU, tile=tile); o.append(L.from_blocked(out, M).clone())
+        t = L.to_blocked(res)
+        xhat = torch.full((nb, N // 8, 32, 8), float('nan'), device=dev, dtype=torch.bfloat16)
+        stats = torch.full((nb * 32, N // 256, 2), float('nan'), device=dev)
+        shift = torch.linspace(-1, 1, nb * 32, device=dev)
+        sout = torch.full((nb * 32,), float('nan'), device=dev)
+        if N <= 1024:
+            L.gemm_blk(ab, wb, t, M, bias=bias, epi=L.EPI_F32_RES, res=t, tile=tile, xhat=xhat, stats_out=stats, shift=shift, shift_out=sout)
+            o += [L.from_blocked(xhat, M).clone(), stats[:M].clone(), sout[:M].clone()]
+        else:
+            L.gemm_blk(ab, wb, t, M, bias=bias, epi=L.EPI_F32_RES, res=t, tile=tile)
+        o.append(L.from_blocked(t, M).clone())
+        t2 = torch.full((nb, N // 4, 32, 4), float('nan'), device=dev)
+        L.gemm_blk(ab, wb, t2, M, bias=bias, epi=L.EPI_F32_POS, res=pos, res_rows=196, tile=tile); o.append(L.from_blocked(t2, M).clone())
+        if K % 256 == 0 and K <= 1024:                                   # consumer of a folded LayerNorm (statistics of some raw stream of width K)
+            st_in = torch.rand(nb * 32, K // 256, 2, device=dev) * 3 + 1
+            st_in[..., 1] = st_in[..., 0] ** 2 / 256 * 1.5 + 1
+            cs = torch.randn(N, generator=g).to(dev)
+            L.gemm_blk(ab, wb, out, M, bias=bias, epi=L.EPI_BF16, tile=tile, stats_in=st_in, colsum=cs, ln_eps=1e-6); o.append(L.from_blocked(out, M).clone())
+        got[tile] = o
+    assert len(got[0x44]) == len(got[0x144])
+    for x8, x4 in zip(got[0x44], got[0x144]):
+        assert torch.isfinite(x8.float()).all() and torch.equal(x8, x4)
+
+
 def test_gemm_blk_mfma_shapes_agree(dev):
     """the bf16 kernel on v_mfma_f32_16x16x32_bf16 (default) and the 32x32x16 kernel behind WHMR_BLK_MFMA=32 (whmr_gemm_blk_set_tile(5, 32)) read
     the SAME packed operands and give the same results: every tile height, bf16 + GELU / fp32 residual epilogues, ragged M"""
