@@ -98,6 +98,9 @@ def test_gemm_blk_four_wave_tile_is_bit_identical(dev, M, N, K):
     pos = torch.randn(196, N, generator=g).to(dev)
     ab, wb = L.to_blocked(a), L.to_blocked(w)
     nb = ab.shape[0]
+    st_in = (torch.rand(nb * 32, max(1, K // 256), 2, generator=g) * 3 + 1).to(dev)
+    st_in[..., 1] = st_in[..., 0] ** 2 / 256 * 1.5 + 1
+    cs = torch.randn(N, generator=g).to(dev)
     got = {}
     for tile in (0x44, 0x144):
         o = []
@@ -118,9 +121,6 @@ def test_gemm_blk_four_wave_tile_is_bit_identical(dev, M, N, K):
         t2 = torch.full((nb, N // 4, 32, 4), float('nan'), device=dev)
         L.gemm_blk(ab, wb, t2, M, bias=bias, epi=L.EPI_F32_POS, res=pos, res_rows=196, tile=tile); o.append(L.from_blocked(t2, M).clone())
         if K % 256 == 0 and K <= 1024:                                   # consumer of a folded LayerNorm (statistics of some raw stream of width K)
-            st_in = torch.rand(nb * 32, K // 256, 2, device=dev) * 3 + 1
-            st_in[..., 1] = st_in[..., 0] ** 2 / 256 * 1.5 + 1
-            cs = torch.randn(N, generator=g).to(dev)
             L.gemm_blk(ab, wb, out, M, bias=bias, epi=L.EPI_BF16, tile=tile, stats_in=st_in, colsum=cs, ln_eps=1e-6); o.append(L.from_blocked(out, M).clone())
         got[tile] = o
     assert len(got[0x44]) == len(got[0x144])

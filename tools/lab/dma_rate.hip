@@ -83,6 +83,54 @@ static void run_stream(const char* src, long region, int share, int blocks, floa
            blocks, share, region >> 20, ms * 1e3, bytes / (ms * 1e-3) / 1e9, bytes * (blocks / share) / (ms * 1e-3) / 1e12);
 }
 
+// Scalar-prefetch probe: does pulling the lines of a piece into the XCD's L2 through the SCALAR cache path (8 s_load_dword, one per 128-B line, PF pieces
+// ahead) lift the per-CU rate of the LDS-DMA that follows on fresh data?  (the 57 GB/s per-CU ceiling sits in front of L2 on the vector path)
+template <int DEPTH, int PF>
+__global__ __launch_bounds__(512) void probe_spf(const char* __restrict__ src, long region, int iters, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const char* wbase = src + (size_t)blockIdx.x * region + wave * 1024;          // wave-uniform
+    long off = 0;
+    for (int it = 0; it < iters; ++it) {
+        if (PF > 0) {
+            long po = off + (long)PF * 8192;
+            while (po + 8192 > region) po -= (region / 8192) * 8192;
+            if (po < 0) po = 0;
+            const char* pp = wbase + po;
+            // results are never read; they land asynchronously, so they go to fixed high SGPRs nothing else in this kernel uses
+            asm volatile("s_load_dword s88, %0, 0x0\n\ts_load_dword s89, %0, 0x80\n\ts_load_dword s90, %0, 0x100\n\ts_load_dword s91, %0, 0x180\n\t"
+                         "s_load_dword s92, %0, 0x200\n\ts_load_dword s93, %0, 0x280\n\ts_load_dword s94, %0, 0x300\n\ts_load_dword s95, %0, 0x380"
+                         :: "s"(pp) : "memory", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95");
+        }
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(wbase + off + lane * 16), (lds_void_t*)(smem + ((it % DEPTH) * 8 + wave) * 1024), 16, 0, 0);
+        off += 8192;
+        if (off + 8192 > region) off = 0;
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DEPTH - 1) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (((uint32_t*)smem)[tid] == 0x12345678u) out[0] = 1.f;
+}
+
+template <int DEPTH, int PF>
+static void run_spf(const char* src, long region, int blocks, float* out) {
+    auto k = probe_spf<DEPTH, PF>;
+    CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    const int iters = (int)(region / 8192);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(512), 128 * 1024, 0, src, region, iters, out);
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    const double bytes = (double)iters * 8192;
+    printf("fresh stream, LDS-DMA depth %2d, scalar prefetch %2d pieces ahead, blocks %3d region %3ld MB: %7.1f us  %6.1f GB/s per CU  %5.2f TB/s chip\n", DEPTH, PF, blocks,
+           region >> 20, ms * 1e3, bytes / (ms * 1e-3) / 1e9, bytes * blocks / (ms * 1e-3) / 1e12);
+}
+
 // TN pattern: a block streams K rows of a [K, ld] bf16 matrix, 512 B (256 columns at its tile offset) per row, 32 rows per step, as 1-KiB pieces of two
 // rows each (lanes 0-31 row r, lanes 32-63 row r + 1), optionally with gemm_tn.hip's chunk swizzle; `tiles` blocks share the same rows (column tiles).
 //   SWZ 0/1; rows_wrap: K rows before wrapping (small = L2 resident, large = streaming)
@@ -157,6 +205,18 @@ int main(int argc, char** argv) {
     char* src; float* out;
     CK(hipMalloc(&src, span + 65536)); CK(hipMalloc(&out, 64));
     CK(hipMemset(src, 1, span + 65536));
+    if (argc > 3 && argv[3][0] == 'p') {                         // scalar prefetch in front of the LDS-DMA, fresh data
+        for (int rep = 0; rep < 2; ++rep)
+            for (int nb : {24, 96, 252}) {
+                const long region = ((span / nb) >> 13) << 13;
+                const long r = region > (32l << 20) ? (32l << 20) : region;
+                run_spf<8, 0>(src, r, nb, out);  CK(hipMemset((void*)src, rep + 2, span));
+                run_spf<8, 8>(src, r, nb, out);  CK(hipMemset((void*)src, rep + 3, span));
+                run_spf<8, 24>(src, r, nb, out); CK(hipMemset((void*)src, rep + 4, span));
+                run_spf<8, 64>(src, r, nb, out); CK(hipMemset((void*)src, rep + 5, span));
+            }
+        return 0;
+    }
     if (argc > 3 && argv[3][0] == 's') {                         // streaming sweep: per-CU rate on fresh data against depth, active CUs and sharing
         for (int rep = 0; rep < 2; ++rep)
             for (int share : {1, 3, 12})
