@@ -399,6 +399,24 @@ __device__ __forceinline__ bf16x8_t tr_frag(uint32_t lds_base, int R0, int c0, i
     return f.v;
 }
 
+// the same fragment, ISSUED only (round 4): the caller waits once for a whole group (tr_wait ties the registers to the wait, so that no consumer
+// can be scheduled above it).  Every tr_frag above pays its own LDS round trip: 12 per (key tile, query tile) step of the backward kernel.
+struct tr_raw { uint2 a, b; };
+__device__ __forceinline__ void tr_issue(tr_raw& f, uint32_t lds_base, int R0, int c0, int lane) {
+    const int g = lane >> 4, i = lane & 15;
+    const int col = c0 + 16 * (g & 1) + 4 * (i & 3);
+    const int row = R0 + 4 * (g >> 1) + (i >> 2);
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3" : "=&v"(f.a), "=&v"(f.b) : "v"(lds_base + swz_addr(row, col)), "v"(lds_base + swz_addr(row + 8, col)) : "memory");
+}
+__device__ __forceinline__ void tr_wait(tr_raw& f0, tr_raw& f1, tr_raw& f2, tr_raw& f3) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f0.a), "+v"(f0.b), "+v"(f1.a), "+v"(f1.b), "+v"(f2.a), "+v"(f2.b), "+v"(f3.a), "+v"(f3.b) :: "memory");
+}
+__device__ __forceinline__ bf16x8_t tr_value(const tr_raw& f) {
+    union { bf16x8_t v; uint32_t u[4]; } o;
+    o.u[0] = f.a.x; o.u[1] = f.a.y; o.u[2] = f.b.x; o.u[3] = f.b.y;
+    return o.v;
+}
+
 template <int NKT>
 __global__ __launch_bounds__(NKT * 64) void attention_bwd_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                                        const float* __restrict__ dout, const float* __restrict__ lse,
@@ -420,35 +438,34 @@ __global__ __launch_bounds__(NKT * 64) void attention_bwd_bf16_kernel(const bf16
     const float* dob = dout + (size_t)b * N * C + h * 64;
     const bf16_t* ob = o + (size_t)b * N * C + h * 64;
     // ---- stage Q, K (bf16 rows), dO (fp32 -> bf16), zero the dQ accumulator, per-query lse and D = sum_d dO * O
+    // (round 4) D rides along: the 8 lanes of a row hold its 8 chunks of dO (fp32, before the rounding) and fetch the matching chunks of O -- one
+    // coalesced pass instead of a second, row-per-THREAD walk over dO and O (64 cache lines per wave instruction)
     for (int c = tid; c < NPAD * 8; c += NKT * 64) {
         const int row = c >> 3, ch = c & 7;
         uint4 q = make_uint4(0, 0, 0, 0), k = q, d = q;
+        float dsum = 0.f, ls = INFINITY;                     // padded queries: P = exp2(-inf) = 0
         if (row < N) {
             q = *(const uint4*)(base + (size_t)row * ld + ch * 8);
             k = *(const uint4*)(base + (size_t)row * ld + C + ch * 8);
             const float4 a = *(const float4*)(dob + (size_t)row * C + ch * 8), bb = *(const float4*)(dob + (size_t)row * C + ch * 8 + 4);
+            const uint4 ov = *(const uint4*)(ob + (size_t)row * C + ch * 8);
+            if (ch == 0) ls = lse[((size_t)b * H + h) * N + row];
             d = make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(bb.x, bb.y), pack_bf16x2(bb.z, bb.w));
+            dsum = a.x * __uint_as_float(ov.x << 16) + a.y * __uint_as_float(ov.x & 0xffff0000u) +
+                   a.z * __uint_as_float(ov.y << 16) + a.w * __uint_as_float(ov.y & 0xffff0000u);
+            dsum += bb.x * __uint_as_float(ov.z << 16) + bb.y * __uint_as_float(ov.z & 0xffff0000u) +
+                    bb.z * __uint_as_float(ov.w << 16) + bb.w * __uint_as_float(ov.w & 0xffff0000u);
         }
+        dsum += __shfl_xor(dsum, 1, 64);
+        dsum += __shfl_xor(dsum, 2, 64);
+        dsum += __shfl_xor(dsum, 4, 64);
         const int off = row * 128 + ((ch ^ ((row >> 1) & 7)) << 4);
         *(uint4*)(Qs + off) = q;
         *(uint4*)(Ks + off) = k;
         *(uint4*)(dOs + off) = d;
+        if (ch == 0) { lseS[row] = ls; Ds[row] = dsum; }
     }
     for (int c = tid; c < NPAD * DQS / 4; c += NKT * 64) ((float4*)dQa)[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int row = tid; row < NPAD; row += NKT * 64) {
-        float dsum = 0.f, ls = INFINITY;                     // padded queries: P = exp2(-inf) = 0
-        if (row < N) {
-            ls = lse[((size_t)b * H + h) * N + row];
-            for (int dd = 0; dd < 64; dd += 4) {
-                const float4 a = *(const float4*)(dob + (size_t)row * C + dd);
-                const uint2 ov = *(const uint2*)(ob + (size_t)row * C + dd);
-                dsum += a.x * __uint_as_float(ov.x << 16) + a.y * __uint_as_float(ov.x & 0xffff0000u) +
-                        a.z * __uint_as_float(ov.y << 16) + a.w * __uint_as_float(ov.y & 0xffff0000u);
-            }
-        }
-        lseS[row] = ls;
-        Ds[row] = dsum;
-    }
     // this wave's key tile: K_j / V_j row fragments (lane = key, k = d) straight from global memory
     const int k0 = wave * 32;
     int krow = k0 + l31;
@@ -471,6 +488,20 @@ __global__ __launch_bounds__(NKT * 64) void attention_bwd_bf16_kernel(const bf16
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dvt[dh][r] = 0.f; dkt[dh][r] = 0.f; }
 
+    // K_j^T fragments of the dQ product: the wave's own key tile, the same in every step -- read once (they were re-read, one LDS round trip each,
+    // in all NKT steps)
+    tr_raw ktr[2][2];
+#pragma unroll
+    for (int j2 = 0; j2 < 2; ++j2)
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh) tr_issue(ktr[j2][dh], ks_l, k0 + 16 * j2, dh * 32, lane);
+    tr_wait(ktr[0][0], ktr[0][1], ktr[1][0], ktr[1][1]);
+    bf16x8_t ktf[2][2];
+#pragma unroll
+    for (int j2 = 0; j2 < 2; ++j2)
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh) ktf[j2][dh] = tr_value(ktr[j2][dh]);
+
 #pragma unroll 1
     for (int step = 0; step < NKT; ++step) {
         const int it = (wave + step) % NKT, q0 = it * 32;
@@ -482,6 +513,7 @@ __global__ __launch_bounds__(NKT * 64) void attention_bwd_bf16_kernel(const bf16
             qf[kk] = *(const bf16x8_t*)(Qs + off);
             dof[kk] = *(const bf16x8_t*)(dOs + off);
         }
+
         // ---- lane = query orientation: dS^T -> dQ_i^T partial
         {
             f32x16_t st, dpt;
@@ -511,7 +543,7 @@ __global__ __launch_bounds__(NKT * 64) void attention_bwd_bf16_kernel(const bf16
                 for (int e = 0; e < 4; ++e) sf.u[e] = pack_bf16x2(st[8 * j2 + 2 * e], st[8 * j2 + 2 * e + 1]);
 #pragma unroll
                 for (int dh = 0; dh < 2; ++dh)
-                    dq[dh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(ks_l, k0 + 16 * j2, dh * 32, lane), sf.v, dq[dh], 0, 0, 0);
+                    dq[dh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[j2][dh], sf.v, dq[dh], 0, 0, 0);
             }
             float* arow = dQa + (q0 + l31) * DQS;
 #pragma unroll
@@ -526,6 +558,17 @@ __global__ __launch_bounds__(NKT * 64) void attention_bwd_bf16_kernel(const bf16
         }
         // ---- lane = key orientation: P, dS -> dV_j^T, dK_j^T
         {
+            // the transposed dO_i / Q_i fragments of the dV / dK products depend on nothing this step computes: requested here, in front of the S / dP
+            // MFMAs and the exponentials (LDS returns in order: the compiler's own counted waits stay valid, merely stricter), awaited once in
+            // front of their MFMAs
+            tr_raw dotr[2][2], qtr[2][2];
+#pragma unroll
+            for (int j2 = 0; j2 < 2; ++j2)
+#pragma unroll
+                for (int dh = 0; dh < 2; ++dh) {
+                    tr_issue(dotr[j2][dh], dos_l, q0 + 16 * j2, dh * 32, lane);
+                    tr_issue(qtr[j2][dh], qs_l, q0 + 16 * j2, dh * 32, lane);
+                }
             f32x16_t s, dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -541,6 +584,8 @@ __global__ __launch_bounds__(NKT * 64) void attention_bwd_bf16_kernel(const bf16
                 s[r] = p;                                                            // P
                 dp[r] = scale * p * (dp[r] - Ds[q]);                                 // dS
             }
+            tr_wait(dotr[0][0], dotr[0][1], dotr[1][0], dotr[1][1]);
+            tr_wait(qtr[0][0], qtr[0][1], qtr[1][0], qtr[1][1]);
 #pragma unroll
             for (int j2 = 0; j2 < 2; ++j2) {
                 union { bf16x8_t v; uint32_t u[4]; } pf, sf;
@@ -551,8 +596,8 @@ __global__ __launch_bounds__(NKT * 64) void attention_bwd_bf16_kernel(const bf16
                 }
 #pragma unroll
                 for (int dh = 0; dh < 2; ++dh) {
-                    dvt[dh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(dos_l, q0 + 16 * j2, dh * 32, lane), pf.v, dvt[dh], 0, 0, 0);
-                    dkt[dh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(qs_l, q0 + 16 * j2, dh * 32, lane), sf.v, dkt[dh], 0, 0, 0);
+                    dvt[dh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_value(dotr[j2][dh]), pf.v, dvt[dh], 0, 0, 0);
+                    dkt[dh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_value(qtr[j2][dh]), sf.v, dkt[dh], 0, 0, 0);
                 }
             }
         }
