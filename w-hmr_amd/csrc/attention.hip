@@ -577,12 +577,22 @@ __global__ __launch_bounds__(NKT * 64) void attention_bwd_bf16_kernel(const bf16
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[kk], kf[kk], s, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof[kk], vf[kk], dp, 0, 0, 0);
             }
+            // per-query lse / D of the 16 queries a lane's registers hold: four aligned float4 reads each (as per-register conditionals they were 32
+            // scalar LDS reads inside 16 exec-masked blocks)
+            float4 ls4[4], d4[4];
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+                ls4[k4] = *(const float4*)(lseS + q0 + 8 * k4 + 4 * hi);
+                d4[k4] = *(const float4*)(Ds + q0 + 8 * k4 + 4 * hi);
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int q = q0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const float p = key_ok_lane ? __builtin_amdgcn_exp2f(fmaf(s[r], sc, -lseS[q])) : 0.f;
+                const float lsq = (r & 3) == 0 ? ls4[r >> 2].x : (r & 3) == 1 ? ls4[r >> 2].y : (r & 3) == 2 ? ls4[r >> 2].z : ls4[r >> 2].w;
+                const float dq_ = (r & 3) == 0 ? d4[r >> 2].x : (r & 3) == 1 ? d4[r >> 2].y : (r & 3) == 2 ? d4[r >> 2].z : d4[r >> 2].w;
+                float p = __builtin_amdgcn_exp2f(fmaf(s[r], sc, -lsq));
+                p = key_ok_lane ? p : 0.f;
                 s[r] = p;                                                            // P
-                dp[r] = scale * p * (dp[r] - Ds[q]);                                 // dS
+                dp[r] = scale * p * (dp[r] - dq_);                                   // dS
             }
             tr_wait(dotr[0][0], dotr[0][1], dotr[1][0], dotr[1][1]);
             tr_wait(qtr[0][0], qtr[0][1], qtr[1][0], qtr[1][1]);
