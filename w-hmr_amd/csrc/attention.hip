@@ -382,25 +382,9 @@ __global__ __launch_bounds__(NKT * 64, 4) void attention_bf16_chunk_kernel(const
 __device__ __forceinline__ uint32_t swz_addr(int row, int col) {      // byte offset of element (row, col) in a [rows][64] bf16 tile
     return row * 128 + ((((col >> 3) ^ ((row >> 1) & 7))) << 4) + (col & 7) * 2;
 }
-// both halves of a fragment are issued before the one wait
-__device__ __forceinline__ void lds_tr_read64x2(uint32_t addr_a, uint32_t addr_b, uint2& a, uint2& b) {
-    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(a), "=&v"(b) : "v"(addr_a), "v"(addr_b) : "memory");
-}
-// A operand "X^T": lane -> m = c0 + (lane & 31) (a column of X), k-slots hi*8 + e <-> X rows R0 + 4*hi + (e & 3) + 8*(e >> 2)
-__device__ __forceinline__ bf16x8_t tr_frag(uint32_t lds_base, int R0, int c0, int lane) {
-    const int g = lane >> 4, i = lane & 15;
-    const int col = c0 + 16 * (g & 1) + 4 * (i & 3);
-    const int row = R0 + 4 * (g >> 1) + (i >> 2);
-    uint2 a, b;
-    lds_tr_read64x2(lds_base + swz_addr(row, col), lds_base + swz_addr(row + 8, col), a, b);
-    union { bf16x8_t v; uint32_t u[4]; } f;
-    f.u[0] = a.x; f.u[1] = a.y; f.u[2] = b.x; f.u[3] = b.y;
-    return f.v;
-}
-
-// the same fragment, ISSUED only (round 4): the caller waits once for a whole group (tr_wait ties the registers to the wait, so that no consumer
-// can be scheduled above it).  Every tr_frag above pays its own LDS round trip: 12 per (key tile, query tile) step of the backward kernel.
+// A operand "X^T": lane -> m = c0 + (lane & 31) (a column of X), k-slots hi*8 + e <-> X rows R0 + 4*hi + (e & 3) + 8*(e >> 2).  The reads are ISSUED only
+// (round 4): the caller waits once for a whole group (tr_wait ties the registers to the wait, so that no consumer can be scheduled above it) -- as
+// a read + wait per fragment the backward kernel paid 12 LDS round trips per (key tile, query tile) step.
 struct tr_raw { uint2 a, b; };
 __device__ __forceinline__ void tr_issue(tr_raw& f, uint32_t lds_base, int R0, int c0, int lane) {
     const int g = lane >> 4, i = lane & 15;
