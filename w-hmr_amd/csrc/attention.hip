@@ -401,6 +401,16 @@ __device__ __forceinline__ bf16x8_t tr_value(const tr_raw& f) {
     return o.v;
 }
 
+#ifndef ATT_LAB
+#define ATT_LAB 0          // tools/lab/attn_bwd_lab.hip only: s_memtime stamps of workgroup 300 (per wave: staging, the six phases of step 2, loop end, kernel end)
+#endif
+#if ATT_LAB
+__device__ unsigned long long att_lab_stamps[8 * 16];
+#define ATT_STAMP(i) do { if (blockIdx.x == 300 && lane == 0) att_lab_stamps[wave * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ATT_STAMP(i) do { } while (0)
+#endif
+
 template <int NKT>
 __global__ __launch_bounds__(NKT * 64) void attention_bwd_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                                        const float* __restrict__ dout, const float* __restrict__ lse,
@@ -421,9 +431,12 @@ __global__ __launch_bounds__(NKT * 64) void attention_bwd_bf16_kernel(const bf16
     const bf16_t* base = qkv + (size_t)b * N * ld + h * 64;
     const float* dob = dout + (size_t)b * N * C + h * 64;
     const bf16_t* ob = o + (size_t)b * N * C + h * 64;
+    ATT_STAMP(0);
     // ---- stage Q, K (bf16 rows), dO (fp32 -> bf16), zero the dQ accumulator, per-query lse and D = sum_d dO * O
     // (round 4) D rides along: the 8 lanes of a row hold its 8 chunks of dO (fp32, before the rounding) and fetch the matching chunks of O -- one
-    // coalesced pass instead of a second, row-per-THREAD walk over dO and O (64 cache lines per wave instruction)
+    // coalesced pass instead of a second, row-per-THREAD walk over dO and O (64 cache lines per wave instruction).  (Requesting all 20 loads of a
+    // thread's four chunks before the first use changes nothing: the pass is bound by the CU's fetch rate for 128-B rows scattered over 4.6 KB
+    // strides, 15 000-17 000 of a workgroup's 49 000 cycles: tools/lab/attn_bwd_lab.hip.)
     for (int c = tid; c < NPAD * 8; c += NKT * 64) {
         const int row = c >> 3, ch = c & 7;
         uint4 q = make_uint4(0, 0, 0, 0), k = q, d = q;
@@ -486,9 +499,11 @@ __global__ __launch_bounds__(NKT * 64) void attention_bwd_bf16_kernel(const bf16
 #pragma unroll
         for (int dh = 0; dh < 2; ++dh) ktf[j2][dh] = tr_value(ktr[j2][dh]);
 
+    ATT_STAMP(1);
 #pragma unroll 1
     for (int step = 0; step < NKT; ++step) {
         const int it = (wave + step) % NKT, q0 = it * 32;
+        if (step == 2) ATT_STAMP(2);
         bf16x8_t qf[4], dof[4];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
@@ -515,6 +530,7 @@ __global__ __launch_bounds__(NKT * 64) void attention_bwd_bf16_kernel(const bf16
                 const float p = key < N ? __builtin_amdgcn_exp2f(fmaf(st[r], sc, -ls)) : 0.f;
                 st[r] = scale * p * (dpt[r] - dq_);                                  // dS^T
             }
+            if (step == 2) ATT_STAMP(3);                                             // S^T / dP^T MFMAs + exponentials done
             f32x16_t dq[2];
 #pragma unroll
             for (int dh = 0; dh < 2; ++dh)
@@ -529,6 +545,7 @@ __global__ __launch_bounds__(NKT * 64) void attention_bwd_bf16_kernel(const bf16
                 for (int dh = 0; dh < 2; ++dh)
                     dq[dh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[j2][dh], sf.v, dq[dh], 0, 0, 0);
             }
+            if (step == 2) ATT_STAMP(4);                                             // dQ MFMAs issued
             float* arow = dQa + (q0 + l31) * DQS;
 #pragma unroll
             for (int dh = 0; dh < 2; ++dh)
@@ -540,6 +557,7 @@ __global__ __launch_bounds__(NKT * 64) void attention_bwd_bf16_kernel(const bf16
                     *ap = a;
                 }
         }
+        if (step == 2) ATT_STAMP(5);                                                 // dQ accumulated in LDS
         // ---- lane = key orientation: P, dS -> dV_j^T, dK_j^T
         {
             // the transposed dO_i / Q_i fragments of the dV / dK products depend on nothing this step computes: requested here, in front of the S / dP
@@ -578,6 +596,7 @@ __global__ __launch_bounds__(NKT * 64) void attention_bwd_bf16_kernel(const bf16
                 s[r] = p;                                                            // P
                 dp[r] = scale * p * (dp[r] - dq_);                                   // dS
             }
+            if (step == 2) ATT_STAMP(6);                                             // S / dP MFMAs + exponentials done
             tr_wait(dotr[0][0], dotr[0][1], dotr[1][0], dotr[1][1]);
             tr_wait(qtr[0][0], qtr[0][1], qtr[1][0], qtr[1][1]);
 #pragma unroll
@@ -595,8 +614,11 @@ __global__ __launch_bounds__(NKT * 64) void attention_bwd_bf16_kernel(const bf16
                 }
             }
         }
+        if (step == 2) ATT_STAMP(7);                                                 // dV / dK MFMAs issued
         __syncthreads();                                     // the next step's owner of this query tile sees the update
+        if (step == 2) ATT_STAMP(8);
     }
+    ATT_STAMP(9);
     // ---- dQ rows of query tile `wave` (fp32 accumulator -> bf16), 16 lanes per row
     bf16_t* dqb = dqkv + (size_t)b * N * ld + h * 64;
 #pragma unroll
@@ -631,6 +653,7 @@ __global__ __launch_bounds__(NKT * 64) void attention_bwd_bf16_kernel(const bf16
             const uint4 v = *(const uint4*)(tile + which * 32 * TS + row * TS + ch * 16);
             if (key < N) *(uint4*)(dqb + (size_t)key * ld + (1 + which) * C + ch * 8) = v;
         }
+    ATT_STAMP(10);
 }
 
 // ---- fp32 attention on the matrix pipes (parity mode, d = 64, N <= 256): v_mfma_f32_32x32x2_f32 is exact f32 arithmetic, so this is the VALU
