@@ -510,3 +510,28 @@ def test_split_bf16_operand_pairs_and_elementwise_metric():
     a = b.clone()
     a[1] += 1e-3
     assert ((a - b).abs().max() / b.abs().max()) < 1e-5 and ew_err(a, b) > 1e-6 and ew_err(b, b) == 0.0
+
+
+def test_ctypes_structures_match_the_c_header_layout(tmp_path):
+    """the drop-in boundary is a C ABI: every ctypes mirror in whmr_amd/_lib.py has the size and the field offsets gcc gives the struct of
+    include/whmr_hip.h (a field added on one side only, or a wrong width, would shift every pointer behind it)"""
+    import ctypes
+    import subprocess
+    from whmr_amd import _lib as L
+    pairs = {'whmr_gemm': L.WhmrGemm, 'whmr_gemm_blk_desc': L.WhmrGemmBlk, 'whmr_tn_item': L.WhmrTnItem, 'whmr_smpl_model': L.WhmrSmplModel,
+             'whmr_maf_weights': L.WhmrMafWeights, 'whmr_stage_tail': L.WhmrStageTail}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "whmr_hip.h"', 'int main(void) {']
+    for cname, cls in pairs.items():
+        lines.append('  printf("%s %%zu\\n", sizeof(struct %s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            lines.append('  printf("%s.%s %%zu\\n", offsetof(struct %s, %s));' % (cname, fname, cname, fname))
+    lines += ['  return 0;', '}']
+    src = tmp_path / 'layout.c'
+    src.write_text('\n'.join(lines))
+    exe = tmp_path / 'layout'
+    subprocess.run(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)], check=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in pairs.items():
+        assert int(got[cname]) == ctypes.sizeof(cls), (cname, got[cname], ctypes.sizeof(cls))
+        for fname, _ in cls._fields_:
+            assert int(got['%s.%s' % (cname, fname)]) == getattr(cls, fname).offset, (cname, fname)
