@@ -138,6 +138,39 @@ def test_vit_backward_224_hip_attention(dev):
     assert not bad, 'gradient mismatch: %s' % sorted(bad.items(), key=lambda kv: -kv[1])[:6]
 
 
+def test_vit_backward_grouped_weight_gradients_match_single_launches(dev):
+    """the four weight gradients of a layer in ONE grouped launch (whmr_gemm_tn_bf16_group, two K slices, four-wave body) against the four single
+    launches (vit_autograd.GROUP_DW off): the same products with another slice count -- equal to fp32 rounding, biases included, and every
+    other gradient of the backbone bit-identical (nothing else may change); 256x192 crops at batch 64 = the training step's token count"""
+    from oracle import synth
+    from whmr_amd.models.pose_vit import ViT
+    from whmr_amd.train import vit_autograd as VA
+    size = (256, 192)
+    sd = synth.make_vit_state(7, size, depth=2)
+    x = synth.make_inputs(64, 12, size)['x'].to(dev)
+    G = torch.randn(64, 768, 16, 12, generator=torch.Generator().manual_seed(8)).to(dev)
+    grads = {}
+    old = VA.GROUP_DW
+    try:
+        for grouped in (False, True):
+            VA.GROUP_DW = grouped
+            m = ViT(img_size=size, depth=2, qkv_bias=True, numerics='bf16', drop_path_rate=0.0)
+            m.load_state_dict(sd, strict=True)
+            m = m.to(dev).train()
+            (m(x) * G).sum().backward()
+            grads[grouped] = {n: p.grad.clone() for n, p in m.named_parameters()}
+    finally:
+        VA.GROUP_DW = old
+    lin = ('attn.qkv.', 'attn.proj.', 'mlp.fc1.', 'mlp.fc2.')
+    for n, g1 in grads[True].items():
+        g0 = grads[False][n]
+        assert torch.isfinite(g1).all()
+        if 'blocks.' in n and any(t in n for t in lin):
+            assert _rel(g1, g0) < 2e-6, (n, _rel(g1, g0))
+        else:
+            assert torch.equal(g1, g0), n
+
+
 def test_vit_large_backward_256x192(dev):
     """ViT-L/16 geometry (dim 1024, 16 heads, 192 tokens), depth 1: gradients of the HIP backward vs the CPU oracle's autograd."""
     from oracle import synth
