@@ -48,14 +48,14 @@ __global__ __launch_bounds__(512) void probe(const char* __restrict__ src, long 
 
 // Streaming probe: continuous issue (one piece out, vmcnt(DEPTH - 1)), contiguous 1-KiB pieces, every block its own region (`share` = 1) or `share`
 // blocks per region (the column tiles of a GEMM row panel: first toucher misses, the others hit the line in flight), fresh data (span >> caches).
-template <int DEPTH>
+template <int DEPTH, int AUX = 0>
 __global__ __launch_bounds__(512) void probe_stream(const char* __restrict__ src, long region, int share, int iters, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const char* base = src + (size_t)(blockIdx.x / share) * region + wave * 1024 + lane * 16;
     long off = 0;
     for (int it = 0; it < iters; ++it) {
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)(base + off), (lds_void_t*)(smem + ((it % DEPTH) * 8 + wave) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(base + off), (lds_void_t*)(smem + ((it % DEPTH) * 8 + wave) * 1024), 16, 0, AUX);
         off += 8192;
         if (off + 8192 > region) off = 0;
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DEPTH - 1) : "memory");
@@ -65,9 +65,9 @@ __global__ __launch_bounds__(512) void probe_stream(const char* __restrict__ src
     if (((uint32_t*)smem)[tid] == 0x12345678u) out[0] = 1.f;
 }
 
-template <int DEPTH>
+template <int DEPTH, int AUX = 0>
 static void run_stream(const char* src, long region, int share, int blocks, float* out) {
-    auto k = probe_stream<DEPTH>;
+    auto k = probe_stream<DEPTH, AUX>;
     CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     const int iters = (int)(region / 8192);                                  // one pass over the region: every byte fresh
     hipEvent_t e0, e1;
@@ -79,7 +79,7 @@ static void run_stream(const char* src, long region, int share, int blocks, floa
     float ms;
     CK(hipEventElapsedTime(&ms, e0, e1));
     const double bytes = (double)iters * 8192;
-    printf("stream LDS-DMA depth %2d (%3d KB in flight per CU) blocks %3d share %2d region %3ld MB: %7.1f us  %6.1f GB/s per CU  %5.2f TB/s unique\n", DEPTH, DEPTH * 8,
+    printf("stream LDS-DMA aux %2d depth %2d (%3d KB in flight per CU) blocks %3d share %2d region %3ld MB: %7.1f us  %6.1f GB/s per CU  %5.2f TB/s unique\n", AUX, DEPTH, DEPTH * 8,
            blocks, share, region >> 20, ms * 1e3, bytes / (ms * 1e-3) / 1e9, bytes * (blocks / share) / (ms * 1e-3) / 1e12);
 }
 
@@ -205,6 +205,22 @@ int main(int argc, char** argv) {
     char* src; float* out;
     CK(hipMalloc(&src, span + 65536)); CK(hipMalloc(&out, 64));
     CK(hipMemset(src, 1, span + 65536));
+    if (argc > 3 && argv[3][0] == 'a') {                         // cache-policy bits of the LDS-DMA (aux operand) on fresh data, one CU group and the whole chip
+        for (int rep = 0; rep < 2; ++rep)
+            for (int nb : {24, 252}) {
+                const long region = ((span / nb) >> 13) << 13;
+                const long r = region > (32l << 20) ? (32l << 20) : region;
+                run_stream<8, 0>(src, r, 1, nb, out);  CK(hipMemset((void*)src, rep + 2, span));
+                run_stream<8, 1>(src, r, 1, nb, out);  CK(hipMemset((void*)src, rep + 3, span));
+                run_stream<8, 2>(src, r, 1, nb, out);  CK(hipMemset((void*)src, rep + 4, span));
+                run_stream<8, 3>(src, r, 1, nb, out);  CK(hipMemset((void*)src, rep + 5, span));
+                run_stream<8, 16>(src, r, 1, nb, out); CK(hipMemset((void*)src, rep + 6, span));
+                run_stream<8, 17>(src, r, 1, nb, out); CK(hipMemset((void*)src, rep + 7, span));
+                run_stream<8, 18>(src, r, 1, nb, out); CK(hipMemset((void*)src, rep + 8, span));
+                run_stream<8, 19>(src, r, 1, nb, out); CK(hipMemset((void*)src, rep + 9, span));
+            }
+        return 0;
+    }
     if (argc > 3 && argv[3][0] == 'p') {                         // scalar prefetch in front of the LDS-DMA, fresh data
         for (int rep = 0; rep < 2; ++rep)
             for (int nb : {24, 96, 252}) {
