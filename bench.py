@@ -946,6 +946,14 @@ def main(argv=None):
                                'traffic_note': traffic['note'] if traffic else 'no PMC pass of the current GEMM sources committed'}
             if x3_mode:
                 res['roofline']['mfma_issue_frac'] = 3.0 * achieved / peak          # share of the dense bf16 MFMA peak the pipes actually issue
+            if not fp32_mode and not x3_mode:
+                # what caps `frac` short of the MFMA roof on this part (measured; profiles/r04_dma_rate.txt, r04_fw4_ab.txt)
+                res['roofline']['operand_read_ceiling'] = {
+                    'per_cu_GBps_fresh': 57.0, 'per_cu_GBps_l2_hot': 131.0, 'bytes_per_half_tile': 32768, 'us_per_half_tile_read': 0.575,
+                    'us_per_half_tile_mfma': 0.465, 'us_per_half_tile_measured': 0.60,
+                    'note': 'a CU fetches operand data that is not hot in its XCD L2 at 57 GB/s whatever it keeps in flight (one CU or 256); a 256 x 256 '
+                            'tile needs 32 KB per 32-deep half tile, so the blocked GEMM main loop (0.60 us per half tile, eight- and four-wave forms alike) '
+                            'sits on the read path, not on MFMA issue: frac is capped near 0.465 / 0.60 x (tile rounds, prologue + epilogue)'}
             if args.workload == 'whmr':
                 res['cam_model_frames'] = {'gpu_per_step': {'hoisted': 1, 'per-crop': args.batch, 'none': 0}[args.full_x],
                                            'cpu_baseline_per_crop': 1,
