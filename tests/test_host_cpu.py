@@ -337,6 +337,34 @@ def test_grad_reducer_unused_and_misuse():
     red.remove()
 
 
+def test_grad_reducer_deferred_launch_keeps_bucket_order():
+    """bucket k + 1 completes (and is packed) BEFORE bucket k -- its collective is held back by _launch_ready and started later, from
+    another delivery; collectives still start in bucket order and each one sees a fully packed buffer."""
+    from whmr_amd.parallel import GradReducer
+    torch.manual_seed(0)
+    a, b = torch.nn.Linear(4, 4), torch.nn.Linear(4, 4)
+    params = list(a.parameters()) + list(b.parameters())
+    red = GradReducer(params, bucket_bytes=1 << 20, always_bucket=True, groups=[0, 0, 1, 1])
+    assert len(red.buckets) == 2 and red.buckets[0]['params'][0] is b.bias      # bucket 0 = the LAST parameters (backward order)
+    launched = []
+    real = red._launch
+    red._launch = lambda bk: (launched.append(([i for i, q in enumerate(red.buckets) if q is bk][0], bk['flat'].clone())), real(bk))[1]
+    grads = [torch.randn_like(p) for p in params]
+    # deliver bucket 1 (a.*) first: it packs, but may not launch before bucket 0
+    for p, g in zip(params[:2], grads[:2]):
+        assert red.publish(p, g)
+    assert red.buckets[1]['flat'] is not None and launched == []
+    for p, g in zip(params[2:], grads[2:]):
+        assert red.publish(p, g)
+    assert [i for i, _ in launched] == [0, 1]
+    want1 = torch.cat([grads[1].reshape(-1), grads[0].reshape(-1)])                # bucket 1 in backward order: a.bias, a.weight
+    assert torch.equal(launched[1][1], want1)
+    red.finish()
+    for p, g in zip(params, grads):
+        assert torch.equal(p.grad, g)
+    red.remove()
+
+
 def test_integration_doc_lists_every_entry_point():
     """INTEGRATION.md's entry-point table names every symbol include/whmr_hip.h declares (and nothing the header lacks)"""
     import re

@@ -89,6 +89,35 @@ def test_vit_backward_matches_oracle_autograd(dev, numerics, tol):
         assert _rel(m(x.to(dev)), out.detach()) < (1e-5 if numerics == 'fp32' else 2e-2)
 
 
+def test_default_numerics_model_trains_in_fp32(dev):
+    """a DEFAULT-constructed ViT / WHMR is numerics='bf16x3', an inference mode that trains in fp32.  Its training step must
+    not depend on what the last eval forward left in the module (``_eff`` used to pick a bf16 weight copy against fp32 activations): run an eval
+    forward on the split-bf16 path first (>= 320 tokens), then a training step, and compare every gradient with the numerics='fp32' model --
+    same kernels, same operands: bit-identical."""
+    from oracle import synth
+    from whmr_amd.models.pose_vit import ViT
+    size = (256, 192)
+    sd = synth.make_vit_state(3, size, depth=2)
+    x = synth.make_inputs(2, 9, size)['x'].to(dev)
+    G = torch.randn(2, 768, 16, 12, generator=torch.Generator().manual_seed(4)).to(dev)
+    grads = {}
+    for numerics in ('bf16x3', 'fp32'):
+        m = ViT(img_size=size, depth=2, qkv_bias=True) if numerics == 'bf16x3' else ViT(img_size=size, depth=2, qkv_bias=True, numerics='fp32')
+        assert m.numerics == numerics
+        m.load_state_dict(sd, strict=True)
+        m = m.to(dev).eval()
+        with torch.no_grad():
+            m(x)                                   # 384 tokens: the bf16x3 model takes its split-bf16 kernels here
+        m.train()
+        out = m(x)
+        assert out.requires_grad
+        (out * G).sum().backward()
+        grads[numerics] = {k: p.grad.clone() for k, p in m.named_parameters()}
+        assert all(torch.isfinite(g).all() for g in grads[numerics].values())
+    for k, g in grads['fp32'].items():
+        assert torch.equal(grads['bf16x3'][k], g), k
+
+
 @pytest.mark.parametrize('N', [196, 192, 100])
 def test_attention_backward_kernel(dev, N):
     """MFMA attention backward vs autograd of the fp32 attention on the same bf16 inputs."""
@@ -1178,3 +1207,45 @@ def test_weight_operands_one_launch_matches_the_per_weight_casts(dev):
     assert not wo.stale()
     ps[1].data = ps[1].data.clone()
     assert wo.stale()
+
+
+def test_grad_reducer_exchange_waits_for_the_pack_on_its_own_stream(dev, monkeypatch):
+    """a bucket packed on stream A may be launched later from stream B (it waited for the bucket before it).  The exchange
+    stream must order itself behind the PACK (an event at the tail of stream A), not behind stream B.  Fake collective = flat *= 2 on the
+    exchange stream; stream A is held back by a long sleep kernel, so an exchange that only waits for stream B would double garbage and be
+    overwritten by the late copy (gradients x 1 instead of x 2)."""
+    import torch.distributed as dist
+    from whmr_amd.parallel import GradReducer
+
+    class _Work:
+        def wait(self):
+            return True
+
+    def fake_all_reduce(t, op=None, group=None, async_op=False):
+        t.mul_(2.0)
+        return _Work()
+    monkeypatch.setattr(dist, 'is_initialized', lambda: True)
+    monkeypatch.setattr(dist, 'get_world_size', lambda group=None: 1)
+    monkeypatch.setattr(dist, 'all_reduce', fake_all_reduce)
+    a, b = torch.nn.Linear(256, 256).to(dev), torch.nn.Linear(256, 256).to(dev)
+    params = list(a.parameters()) + list(b.parameters())
+    red = GradReducer(params, bucket_bytes=1 << 30, always_bucket=True, groups=[0, 0, 1, 1])
+    assert len(red.buckets) == 2
+    sa, sb = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    grads = [torch.randn_like(p) for p in params]
+    torch.cuda.synchronize(dev)
+    with torch.cuda.stream(sa):
+        torch.cuda._sleep(200_000_000)                     # ~0.1 s: stream A is far behind the host
+        ga = [g.clone() for g in grads[:2]]                # the gradients of bucket 1 are PRODUCED on stream A, behind the sleep
+        for p, g in zip(params[:2], ga):
+            red.publish(p, g)                              # packs bucket 1 on stream A; its launch waits for bucket 0
+    assert red.buckets[1]['flat'] is not None and red.buckets[1]['work'] is None
+    with torch.cuda.stream(sb):
+        for p, g in zip(params[2:], grads[2:]):
+            red.publish(p, g)                              # bucket 0 packs and launches; bucket 1 launches from HERE (stream B)
+    assert red.buckets[1]['work'] is not None
+    red.finish()
+    torch.cuda.synchronize(dev)
+    for p, g in zip(params, grads):
+        assert torch.equal(p.grad, 2.0 * g)
+    red.remove()

@@ -179,6 +179,67 @@ static void run_tn(const char* name, const char* src, int ld_bytes, int rows_wra
            bytes / (ms * 1e-3) / 1e9);
 }
 
+
+// GEMM-pattern probe (round 5): every workgroup streams TWO operands like a 256 x 256 tile of the blocked GEMM -- per half K tile
+// 16 KiB of an "A" panel and 16 KiB of a "W" panel, 4 pieces per wave, three half tiles (96 KiB) in flight, one s_barrier per half tile, every
+// workgroup at the same K offset -- and the panels are SHARED the way the GEMM's tile map shares them:
+//   MAP 0  same-XCD sharing = the kernel's xcd_remap: block b sits on XCD b % 8 with local index li = b / 8; A panel = (xcd, li / tiles_n) is read by
+//          the tiles_n column tiles of a row panel (share 9 for qkv, 12 for fc1), W panel = li % tiles_n by the 32 / tiles_n row panels of the XCD
+//          (share 3.5 / 2.7) -- and by the other seven XCDs through their own L2s;
+//   MAP 1  the same sharing factors with the sharers on DIFFERENT XCDs (logical tile id = b: dispatch order);
+//   MAP 2  no sharing: every workgroup its own A and W panels.
+// `klen` = bytes of one panel (256 rows x K x 2 B); the GEMM's own K = 768 gives 393 KB, longer panels show the steady state.
+template <int MAP>
+__global__ __launch_bounds__(512) void probe_gemm(const char* __restrict__ a_src, const char* __restrict__ w_src, long klen, int tiles_n, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x, xcd = b & 7, li = b >> 3;
+    long a_panel, w_panel;
+    if (MAP == 0) { a_panel = (long)xcd * 8 + li / tiles_n; w_panel = li % tiles_n; }
+    else if (MAP == 1) { a_panel = b / tiles_n; w_panel = b % tiles_n; }
+    else { a_panel = b; w_panel = b; }
+    const char* ab = a_src + a_panel * klen + wave * 1024 + lane * 16;      // a half tile of a panel = 16 contiguous KiB (the blocked layout)
+    const char* wb = w_src + w_panel * klen + wave * 1024 + lane * 16;
+    const int H = (int)(klen / 16384);
+    auto stage = [&](int h) {
+        char* slot = smem + (h & 3) * 32768;
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(ab + (long)h * 16384), (lds_void_t*)(slot + wave * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(ab + (long)h * 16384 + 8192), (lds_void_t*)(slot + 8192 + wave * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(wb + (long)h * 16384), (lds_void_t*)(slot + 16384 + wave * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(wb + (long)h * 16384 + 8192), (lds_void_t*)(slot + 24576 + wave * 1024), 16, 0, 0);
+    };
+    stage(0); stage(1); stage(2);
+    for (int h = 0; h < H; ++h) {
+        if (h + 3 < H) { stage(h + 3); asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
+        else if (h + 2 < H) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (h + 1 < H) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    __syncthreads();
+    if (((uint32_t*)smem)[tid] == 0x12345678u) out[0] = 1.f;
+}
+
+template <int MAP>
+static double run_gemm(const char* a_src, const char* w_src, long klen, int tiles_n, int blocks, float* out, const char* what) {
+    auto k = probe_gemm<MAP>;
+    CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(512), 128 * 1024, 0, a_src, w_src, klen, tiles_n, out);
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    const double bytes = 2.0 * klen;                                         // per workgroup
+    const char* maps[3] = {"same-XCD sharers (xcd_remap)", "cross-XCD sharers (dispatch order)", "no sharing"};
+    printf("GEMM pattern %-36s tiles_n %2d panel %5ld KB blocks %3d %-22s: %7.1f us  %6.1f GB/s per CU  %5.3f us per 32-KB half tile\n", maps[MAP], tiles_n, klen >> 10, blocks, what,
+           ms * 1e3, bytes / (ms * 1e-3) / 1e9, ms * 1e3 / (klen / 16384));
+    return ms;
+}
+
 template <int MODE, int DEPTH>
 static void run(const char* name, const char* src, long span, int blocks, float* out) {
     auto k = probe<MODE, DEPTH>;
@@ -218,6 +279,30 @@ int main(int argc, char** argv) {
                 run_stream<8, 17>(src, r, 1, nb, out); CK(hipMemset((void*)src, rep + 7, span));
                 run_stream<8, 18>(src, r, 1, nb, out); CK(hipMemset((void*)src, rep + 8, span));
                 run_stream<8, 19>(src, r, 1, nb, out); CK(hipMemset((void*)src, rep + 9, span));
+            }
+        return 0;
+    }
+    if (argc > 3 && argv[3][0] == 'x') {                         // GEMM-pattern sharing probe: same-XCD vs cross-XCD vs unshared, short (K = 768) and long panels
+        char* flush;
+        const long fl = 768l << 20;
+        CK(hipMalloc(&flush, fl));
+        for (int rep = 0; rep < 2; ++rep)
+            for (long klen : {393216l, 6291456l}) {                 // 256 rows x 768 x 2 B (the GEMM's own panels) and 16 x that (steady state)
+                if (256 * klen * 2 > span) { printf("span too small for panel %ld\n", klen); continue; }
+                const char* a = src; const char* w = src + 256 * klen;
+                for (int tn : {9, 12}) {
+                    CK(hipMemset(flush, rep + 1, fl));               // push the operands out of L2 and the Infinity Cache: "fresh"
+                    run_gemm<0>(a, w, klen, tn, 256, out, "fresh");
+                    run_gemm<0>(a, w, klen, tn, 256, out, "again (MALL / L2 warm)");
+                    CK(hipMemset(flush, rep + 2, fl));
+                    run_gemm<1>(a, w, klen, tn, 256, out, "fresh");
+                    run_gemm<1>(a, w, klen, tn, 256, out, "again (MALL / L2 warm)");
+                }
+                CK(hipMemset(flush, rep + 3, fl));
+                run_gemm<2>(a, w, klen, 1, 256, out, "fresh");
+                run_gemm<2>(a, w, klen, 1, 256, out, "again (MALL / L2 warm)");
+                run_gemm<0>(a, w, klen, 9, 32, out, "32 blocks, warm");   // 4 CUs per XCD: is the shared rate a per-CU or a per-XCD limit?
+                run_gemm<0>(a, w, klen, 9, 128, out, "128 blocks, warm");
             }
         return 0;
     }

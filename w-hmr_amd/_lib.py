@@ -870,12 +870,20 @@ def gemm_tn(a, b, out, splits=0, db=None):
 
 def gemm_tn_group_ok(jobs):
     """envelope of whmr_gemm_tn_bf16_group for jobs = [(a [K, Mo], b [K, No], out, db | None), ...]"""
-    return (0 < len(jobs) <= 4 and all(gemm_tn_ok(a, b) and a.shape[1] % 256 == 0 and a.shape[0] == jobs[0][0].shape[0] for a, b, _, _ in jobs))
+    # mirrors EVERY check of the C entry (gemm_tn.hip), the output side included -- the caller falls back to single launches on False instead of
+    # learning it from a rejected launch (ADVICE r4: the two envelopes could disagree on out.stride(0) % 4 / the 16-byte alignment of C)
+    return (0 < len(jobs) <= 4 and all(
+        gemm_tn_ok(a, b) and a.shape[1] % 256 == 0 and a.shape[0] == jobs[0][0].shape[0]
+        and out.dtype == torch.float32 and out.dim() == 2 and tuple(out.shape) == (a.shape[1], b.shape[1]) and out.stride(1) == 1
+        and out.stride(0) % 4 == 0 and out.stride(0) >= b.shape[1] and out.data_ptr() % 16 == 0
+        and (db is None or (db.dtype == torch.float32 and db.is_contiguous() and db.numel() == a.shape[1]))
+        for a, b, out, db in jobs))
 
 
 def gemm_tn_group(jobs):
     """out_i [Mo_i, No_i] fp32 = a_i^T . b_i (+ db_i = column sums of a_i) for up to 4 products over the same K in ONE launch (the weight gradients
-    of a transformer layer: two K slices instead of 7-28 per product)"""
+    of a transformer layer: two K slices instead of 7-28 per product).  -> False when the C entry rejects the envelope (include/whmr_hip.h: "the caller
+    then issues the single launches"); ``gemm_tn_group_ok`` mirrors its checks, so that is not expected to happen."""
     assert gemm_tn_group_ok(jobs)
     items = (WhmrTnItem * len(jobs))()
     flops = 0.0
@@ -888,8 +896,12 @@ def gemm_tn_group(jobs):
         flops += 2.0 * a.shape[0] * a.shape[1] * b.shape[1]
     ws = splitk_workspace(jobs[0][0].device)
     ev = _profile_begin()
-    _check(lib().whmr_gemm_tn_bf16_group(items, len(jobs), jobs[0][0].shape[0], ws.data_ptr(), ws.numel(), _stream()), 'whmr_gemm_tn_bf16_group')
+    rc = lib().whmr_gemm_tn_bf16_group(items, len(jobs), jobs[0][0].shape[0], ws.data_ptr(), ws.numel(), _stream())
+    if rc == 1:                                  # hipErrorInvalidValue = outside the C envelope: nothing was launched, the caller issues the single launches
+        return False
+    _check(rc, 'whmr_gemm_tn_bf16_group')
     _profile_end(ev, 'gemm_bf16', flops)
+    return True
 
 
 def conv_dw_tn_ok(a, img):

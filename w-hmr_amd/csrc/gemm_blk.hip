@@ -23,6 +23,22 @@
 #include "gemm_blk16_impl.h"
 #include "gemm_blk_impl.h"      // the 32x32x16 kernel: split-bf16 operands (gemm_blk_x3.hip) and, behind WHMR_BLK_MFMA=32, the A/B partner of the bf16 kernel
 
+#ifdef WHMR_BLK_STAMPS
+// lab build only (tools/gemm_stamps.py): every bf16 blocked launch takes the next [tiles][2][8] u64 record of a caller-provided device buffer
+static unsigned long long* g_stamp_buf = nullptr;
+static long g_stamp_cap = 0, g_stamp_used = 0;
+static int g_stamp_launches = 0;
+unsigned long long* blk_stamp_next(int tiles) {
+    if (!g_stamp_buf || g_stamp_used + 1 + (long)tiles * 16 > g_stamp_cap) return nullptr;
+    unsigned long long* q = g_stamp_buf + g_stamp_used;
+    g_stamp_used += (long)tiles * 16;
+    ++g_stamp_launches;
+    return q;
+}
+extern "C" int whmr_debug_blk_stamps(void* buf, long capacity_u64) { g_stamp_buf = (unsigned long long*)buf; g_stamp_cap = capacity_u64; g_stamp_used = 0; g_stamp_launches = 0; return 0; }
+extern "C" long whmr_debug_blk_stamps_used(void) { return g_stamp_used; }
+#endif
+
 static int g_blk_sched = 1;
 static int g_blk_mfma32 = 0;      // A/B only: 1 = bf16 operands on the 32x32x16 kernel (tools/lab/mfma16_ab.sh); same packed operands, same results to rounding
 

@@ -21,6 +21,31 @@
 #include "common.h"
 #include "gemm_blk.h"
 
+// ---- lab instrumentation (tools/gemm_stamps.py; NEVER defined in the product build): per tile and wave group, s_memrealtime (100 MHz, one clock for
+// the whole chip) at kernel entry / first half tile landed / main loop done / epilogue stores issued / stores drained, the CU it ran on and the
+// shader-clock count of the tile.  The kernels gain a trailing pointer parameter; the C ABI is unchanged (whmr_debug_blk_stamps sets the buffer).
+#ifdef WHMR_BLK_STAMPS
+#define BLK16_STAMP_PARAM , unsigned long long* stamps
+#define BLK16_STAMP_PASS , stamps
+#define BLK16_STAMP(slot)                                                                                                    \
+    do {                                                                                                                     \
+        if (stamps && lane == 0 && (wave & 3) == 0)                                                                          \
+            stamps[((size_t)lid * 2 + (wave >> 2)) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime();                         \
+    } while (0)
+#define BLK16_STAMP_RAW(slot, v)                                                                                             \
+    do {                                                                                                                     \
+        if (stamps && lane == 0 && (wave & 3) == 0) stamps[((size_t)lid * 2 + (wave >> 2)) * 8 + (slot)] = (v);              \
+    } while (0)
+unsigned long long* blk_stamp_next(int tiles);
+#define BLK16_STAMP_ARG(tiles) , blk_stamp_next(tiles)
+#else
+#define BLK16_STAMP_PARAM
+#define BLK16_STAMP_PASS
+#define BLK16_STAMP(slot) do { } while (0)
+#define BLK16_STAMP_RAW(slot, v) do { } while (0)
+#define BLK16_STAMP_ARG(tiles)
+#endif
+
 typedef __attribute__((address_space(3))) void lds16_void_t;
 typedef const __attribute__((address_space(1))) void gbl16_void_t;
 
@@ -77,7 +102,7 @@ struct blk16_cfg {
 // LDS-DMA pieces in the gaps.  Wave (wm, wn) of 2 x 2 owns 128 x 128 outputs: 16 fragment reads per 64 MFMAs instead of 12 per 32.  Same ring, same
 // MFMA instruction and k order per accumulator, same epilogue arithmetic (the row statistics keep the eight-wave kernel's partial sums): same bits.
 template <int MI0, int MI1, int EPI, int SCHED, int NW>
-__device__ __forceinline__ void gemm_blk16_body(const whmr_gemm_blk_desc& p, char* smem) {
+__device__ __forceinline__ void gemm_blk16_body(const whmr_gemm_blk_desc& p, char* smem BLK16_STAMP_PARAM) {
     using cfg = blk16_cfg<MI0, MI1>;
     constexpr int MB = cfg::MB, BM = cfg::BM, BN = cfg::BN, SLOT = cfg::SLOT, HU = cfg::HU, NJ = NW == 8 ? 2 : 4, NT = NW * 64;
     constexpr int HUPW = (HU + NW - 1) / NW;             // DMA units per wave (waves >= HU % NW issue one less when HU % NW != 0)
@@ -90,6 +115,9 @@ __device__ __forceinline__ void gemm_blk16_body(const whmr_gemm_blk_desc& p, cha
     const int lid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
     const int tm = lid / tiles_n, tn = lid % tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
+    BLK16_STAMP(0);
+    BLK16_STAMP_RAW(5, ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492));    // XCC_ID | HW_ID
+    BLK16_STAMP_RAW(6, __builtin_amdgcn_s_memtime());
     const int KC = p.K >> 3;                              // 16-B chunks per row
     const int H = p.K >> 5;                               // half K tiles (32 deep) = ring slots to walk
     const int rb_last = ((p.M + 31) >> 5) - 1;            // last valid row block
@@ -163,6 +191,7 @@ __device__ __forceinline__ void gemm_blk16_body(const whmr_gemm_blk_desc& p, cha
     if (H > 2) hstage(2);
     wait_dma(H > 2 ? 2 : H - 1);
     __builtin_amdgcn_s_barrier();
+    BLK16_STAMP(1);
 
     // ONE barrier per half K tile; the two groups walk a slot in opposite order:
     //   slot k:   group 0: MFMA(k), MEM(k+1)      group 1: MEM(k+1), MFMA(k+1)
@@ -282,6 +311,7 @@ __device__ __forceinline__ void gemm_blk16_body(const whmr_gemm_blk_desc& p, cha
         else main_loop(std::integral_constant<int, MI1>{});
     }
 
+    BLK16_STAMP(2);
     // ---- epilogue: straight from the accumulators.  Lane (g, l15) owns rows 16 mh + l15 of its row blocks and the 8 consecutive columns
     // 8 g .. 8 g + 7 of each column block (nh = 0: the first four, nh = 1: the last four) = 16 bytes of bf16 unit g / two fp32 units 2 g, 2 g + 1.
     const int miw = wm == 0 ? MI0 : MI1;
@@ -452,18 +482,24 @@ __device__ __forceinline__ void gemm_blk16_body(const whmr_gemm_blk_desc& p, cha
             }
         }
     }
+#ifdef WHMR_BLK_STAMPS
+    BLK16_STAMP(3);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    BLK16_STAMP(4);
+    BLK16_STAMP_RAW(7, __builtin_amdgcn_s_memtime());
+#endif
 }
 
 template <int MI0, int MI1, int EPI, int SCHED>
-__global__ __launch_bounds__(512, 2) void gemm_blk16_kernel(const whmr_gemm_blk_desc p) {
+__global__ __launch_bounds__(512, 2) void gemm_blk16_kernel(const whmr_gemm_blk_desc p BLK16_STAMP_PARAM) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    gemm_blk16_body<MI0, MI1, EPI, SCHED, 8>(p, smem);
+    gemm_blk16_body<MI0, MI1, EPI, SCHED, 8>(p, smem BLK16_STAMP_PASS);
 }
 
 template <int EPI>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_blk16w4_kernel(const whmr_gemm_blk_desc p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_blk16w4_kernel(const whmr_gemm_blk_desc p BLK16_STAMP_PARAM) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    gemm_blk16_body<4, 4, EPI, 1, 4>(p, smem);
+    gemm_blk16_body<4, 4, EPI, 1, 4>(p, smem BLK16_STAMP_PASS);
 }
 
 template <int MI0, int MI1, int EPI, int SCHED>
@@ -477,7 +513,7 @@ static int launch_blk16_s(const whmr_gemm_blk_desc& p, hipStream_t st) {
         attr_done = true;
     }
     const int tiles = ((p.M + cfg::BM - 1) / cfg::BM) * (p.N / cfg::BN);
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), cfg::LDS, st, p);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), cfg::LDS, st, p BLK16_STAMP_ARG(tiles));
     WHMR_CHECK_LAUNCH();
     return 0;
 }
@@ -493,7 +529,7 @@ static int launch_blk16w4_s(const whmr_gemm_blk_desc& p, hipStream_t st) {
         attr_done = true;
     }
     const int tiles = ((p.M + cfg::BM - 1) / cfg::BM) * (p.N / cfg::BN);
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), cfg::LDS, st, p);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), cfg::LDS, st, p BLK16_STAMP_ARG(tiles));
     WHMR_CHECK_LAUNCH();
     return 0;
 }

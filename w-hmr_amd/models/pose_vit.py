@@ -106,9 +106,11 @@ class ViT(nn.Module):
         self.ln_fold_x3 = os.environ.get('WHMR_X3_FOLD', '1') != '0'      # the same fold in the bf16x3 pipeline (A/B: tools/r3_x3ab.sh)
 
     # ------------------------------------------------------------------ weight / workspace caches
-    def _w(self, p, shape=None):
-        """Operand copy of a weight in the compute dtype (bf16 copies are re-made when the parameter changes)."""
-        if self._eff == 'fp32':
+    def _w(self, p, shape=None, eff=None):
+        """Operand copy of a weight in the compute dtype (bf16 copies are re-made when the parameter changes).  ``eff`` ('fp32' | 'bf16'):
+        the operand dtype of the CALLER's path; the default is the row-major path of the current eval forward (``self._eff``, set per call) --
+        the training forward passes its own (a 'bf16x3' model trains in fp32 whatever the last eval call left in ``_eff``)."""
+        if (eff or self._eff) == 'fp32':
             w = p.detach()
             return w.reshape(shape) if shape is not None else w
         key = id(p)

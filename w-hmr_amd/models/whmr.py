@@ -411,7 +411,10 @@ class WHMR(nn.Module):
         return self._cache.get(('tz', self.numerics), [c0, c1, bn.weight, bn.bias, bn.running_mean, bn.running_var], build)
 
     # ------------------------------------------------------------------ stages
-    def _deconv(self, i, x_nhwc):
+    def _deconv(self, i, x_nhwc, x_split=None):
+        """-> (map [B, 2H, 2W, Cout], its split-bf16 operand form or None).  ``x_split``: the [hi | lo | hi] operand form of ``x_nhwc`` that the
+        producing stage's epilogue left (bf16x3 only); handed over EXPLICITLY by the caller -- it used to ride as an attribute on the map tensor,
+        which nothing tied to the map's contents."""
         B, H, W, Cin = x_nhwc.shape
         phases, shift = self._deconv_operands(i)
         Cout = phases[0].shape[0]
@@ -419,35 +422,29 @@ class WHMR(nn.Module):
         if self.numerics == 'bf16x3':          # fp32 map in, fp32 map out; the bf16 kernel on the K-concatenated split operands (Cin' = 3 Cin)
             # the split-bf16 operand form of the OUTPUT ([hi | lo | hi], what the next deconv stage / the Tz convolution multiplies) leaves the
             # epilogue next to the fp32 map (epi_flags bit 8): the split pass over each map (0.45 ms per forward at batch 64) is gone
-            xs = getattr(x_nhwc, 'whmr_split3', None)
-            if xs is None:
-                xs = L.split3(x_nhwc)
+            xs = x_split if x_split is not None else L.split3(x_nhwc)
             parts = 2 if i == len(self.deconv_layers) // 3 - 1 else 3      # the last map feeds the Tz convolution only: [hi | lo]
             out_s3 = torch.empty(B, 2 * H, 2 * W, parts * Cout, dtype=torch.bfloat16, device=x_nhwc.device)
             L.gemm(xs, phases, out, bias=shift, act=L.ACT_RELU, split3_out=out_s3, split_parts=parts,
                    conv=dict(IH=H, IW=W, Cin=3 * Cin, OH=H, OW=W, KW=2, SH=1, SW=1, PH=1, PW=1),
                    scatter=dict(c_off=0, osb=4 * H * W * Cout, osy=4 * W * Cout, osx=2 * Cout),
                    phases=dict(cy=2 * W * Cout, cx=Cout))
-            if parts == 3:
-                out.whmr_split3 = out_s3
-            else:
-                out.whmr_split2 = out_s3
-            return out
+            return out, out_s3                 # parts == 3: [hi | lo | hi] for the next deconv stage; 2: [hi | lo] for the Tz convolution
         if self._dt != torch.float32:          # all 4 sub-pixel phases in one launch (4x the tiles to fill the CUs)
             L.gemm(x_nhwc, phases, out, bias=shift, act=L.ACT_RELU,
                    conv=dict(IH=H, IW=W, Cin=Cin, OH=H, OW=W, KW=2, SH=1, SW=1, PH=1, PW=1),
                    scatter=dict(c_off=0, osb=4 * H * W * Cout, osy=4 * W * Cout, osx=2 * Cout),
                    phases=dict(cy=2 * W * Cout, cx=Cout))
-            return out
+            return out, None
         for py in range(2):
             for px in range(2):
                 L.gemm(x_nhwc, phases[py * 2 + px], out, bias=shift, act=L.ACT_RELU,
                        conv=dict(IH=H, IW=W, Cin=Cin, OH=H, OW=W, KW=2, SH=1, SW=1, PH=1 - py, PW=1 - px),
                        scatter=dict(c_off=(py * 2 * W + px) * Cout, osb=4 * H * W * Cout, osy=4 * W * Cout, osx=2 * Cout))
-        return out
+        return out, None
 
-    def _tz_head(self, f_nhwc):
-        """whmr.py:567-577."""
+    def _tz_head(self, f_nhwc, f_split=None):
+        """whmr.py:567-577.  ``f_split`` (bf16x3): the [hi | lo] operand form of the map, as the last deconv stage's epilogue wrote it."""
         B, H, W, C = f_nhwc.shape
         dev = f_nhwc.device
         w0, w1, bn4 = self._tz_operands()
@@ -455,9 +452,7 @@ class WHMR(nn.Module):
         H1, W1 = (H - 7) // 3 + 1, (W - 7) // 3 + 1
         y0 = torch.empty(B, H1, W1, 128 if self.numerics == 'bf16x3' else 64, dtype=self._dt, device=dev)     # NHWC, mode dtype (feeds the 2nd conv)
         if self.numerics == 'bf16x3':
-            fs = getattr(f_nhwc, 'whmr_split2', None)                          # [hi | lo], left by the last deconv stage's epilogue
-            if fs is None:
-                fs = torch.cat(L.split_bf16(f_nhwc), -1).contiguous()
+            fs = f_split if f_split is not None else torch.cat(L.split_bf16(f_nhwc), -1).contiguous()
             L.gemm(fs, w0, y0.view(-1, 128), conv=dict(IH=H, IW=W, Cin=2 * C, OH=H1, OW=W1, KW=7, SH=3, SW=3, PH=0, PW=0, chunk_major=True))
         else:
             L.gemm(f_nhwc, w0, y0.view(-1, 64), conv=dict(IH=H, IW=W, Cin=C, OH=H1, OW=W1, KW=7, SH=3, SW=3, PH=0, PW=0,
@@ -577,24 +572,25 @@ class WHMR(nn.Module):
         # placeholder Tz and the Tz-dependent outputs of the stages a view returns are (re)computed by one small launch each after the join.
         tz_side, map_ready = None, [None, None, None]
         if self.overlap_tz and B >= 4:          # (one or two crops: every launch is latency-bound, the extra finalize launch costs more than it hides)
-            f = self._deconv(0, f)
+            f, fsplit = self._deconv(0, f)
             fmaps.append(f)
             main_tz = torch.cuda.current_stream(dev)
             tz_side = self._camera_stream(dev, 'tz')
             tz_side.wait_stream(main_tz)
             with torch.cuda.stream(tz_side):
                 for i in (1, 2):
-                    f = self._deconv(i, f)
+                    f, fsplit = self._deconv(i, f, fsplit)
                     fmaps.append(f)
                     map_ready[i] = torch.cuda.Event()
                     map_ready[i].record(tz_side)
-                Tz_true = self._tz_head(fmaps[-1])
+                Tz_true = self._tz_head(fmaps[-1], fsplit)
             Tz = self._tz_placeholder(B, dev)
         else:
+            fsplit = None
             for i in range(3):
-                f = self._deconv(i, f)
+                f, fsplit = self._deconv(i, f, fsplit)
                 fmaps.append(f)
-            Tz = Tz_true = self._tz_head(fmaps[-1])
+            Tz = Tz_true = self._tz_head(fmaps[-1], fsplit)
         for i in range(3):
             self.maf_extractor[i].im_feat = fmaps[i].permute(0, 3, 1, 2)              # logical NCHW view (whmr.py:564)
         stage_state = []

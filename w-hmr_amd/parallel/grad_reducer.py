@@ -169,6 +169,13 @@ class GradReducer:
         if have:
             views = [flat[off:off + q.numel()].view_as(q) for q, off in have]
             torch._foreach_copy_(views, [q.grad for q, _ in have])
+        # The launch may happen LATER and from ANOTHER stream (a packed bucket waits in _launch_ready for the buckets before it; finish() launches
+        # stragglers): the exchange stream orders itself behind THIS event -- the tail of the packing stream -- not behind whatever stream is
+        # current at launch time (it could otherwise read a half-packed buffer).
+        b['packed'] = None
+        if dev.type == 'cuda':
+            b['packed'] = torch.cuda.Event()
+            b['packed'].record(torch.cuda.current_stream(dev))
 
     def _launch(self, b):
         if self.world == 1 and not (self.always_bucket and dist.is_initialized()):
@@ -181,7 +188,11 @@ class GradReducer:
             # the exchange runs on a side stream so that the rest of the backward keeps the compute stream busy
             if self._stream is None:
                 self._stream = torch.cuda.Stream(device=flat.device)
-            self._stream.wait_stream(torch.cuda.current_stream(flat.device))
+            if b.get('packed') is not None:
+                self._stream.wait_event(b['packed'])             # the pack (fill + multi-tensor copy), on whichever stream it ran
+            else:
+                self._stream.wait_stream(torch.cuda.current_stream(flat.device))
+            flat.record_stream(self._stream)                     # allocated on the packing stream, read / written by the exchange stream
             with torch.cuda.stream(self._stream):
                 b['work'] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:

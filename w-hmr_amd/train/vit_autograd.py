@@ -63,7 +63,7 @@ def vit_forward_train(m, x):
     s.ops = ops = _weight_operands(m) if dt == torch.bfloat16 else None
 
     def wop(p, shape=None):                      # W in the compute dtype: the weight operand of y = x . W^T
-        return ops[id(p)][0] if ops is not None else m._w(p, shape)
+        return ops[id(p)][0] if ops is not None else m._w(p, shape, eff='fp32')      # ops is None <=> dt is fp32 ('fp32' and 'bf16x3' models)
 
     L.gemm(s.cols, wop(m.patch_embed.proj.weight, (D, Cin * P * P)), t, bias=m.patch_embed.proj.bias, residual=pos, res_row_mod=N)
     s.layers = []
@@ -194,8 +194,8 @@ def vit_backward(m, s, dout):
     def run_pending():
         if not pending:
             return
-        if len(pending) > 1 and L.gemm_tn_group_ok(pending):
-            L.gemm_tn_group(pending)
+        if len(pending) > 1 and L.gemm_tn_group_ok(pending) and L.gemm_tn_group(pending):
+            pass
         else:
             for a_, b_, dw_, db_ in pending:
                 L.gemm_tn(a_, b_, dw_, db=db_)
