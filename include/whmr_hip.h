@@ -215,6 +215,10 @@ int whmr_attention_set_variant(int chunked);
 int whmr_rot_to_mat(const float* in, float* out, int n, int mode, void* stream);
 /* rotation_matrix_to_angle_axis (geometry.py:54-83 via :160-240 and :86-136): [n,9] -> [n,3], NaN -> 0. */
 int whmr_mat_to_aa(const float* in, float* out, int n, void* stream);
+/* backward of the above: d_in [n,9] = (d aa / d R)^T d_out [n,3] -- what torch autograd computes through geometry.py:54-83 in the reference's training
+ * graph (whmr.py:174: theta's pose; whmr.py:632-633: global_pose).  Same branch as the forward; a NaN component passes no gradient (the forward's masked
+ * write); at sin^2 == 0 exactly the selected branch k = 2 is differentiated (torch yields NaN there). */
+int whmr_mat_to_aa_bwd(const float* in, const float* d_out, float* d_in, int n, void* stream);
 /* perspective_projection (geometry.py:310-341).  rot may be null (identity) or batch-1 (rot_bstride 0, else 9);
  * focal per image (focal_bstride 1) or one scalar (0); center / post_div may be null.
  * out = K (R p + t) / z  [ / post_div[b] + post_shift ]  (the latter = whmr.py:173). */
@@ -365,6 +369,22 @@ int whmr_bn_apply_relu(const void* z, int z_bf16, const float* stats, void* y, i
 /* backward of relu(bn(z)) for the upstream gradient dy: dz, dgamma, dbeta ((+)= when accumulate).  scratch >= 2050*C floats. */
 int whmr_bn_relu_bwd(const void* z, int z_bf16, const void* dy, int dy_bf16, const float* stats, void* dz, int dz_bf16, float* dgamma,
                      float* dbeta, int accumulate, long M, int C, float* scratch, void* stream);
+/* ---- SyncBatchNorm (core/trainer.py:83: nn.SyncBatchNorm.convert_sync_batchnorm before DDP; trained layers: 3 x BatchNorm2d(256) at whmr.py:497 and
+ * BatchNorm1d(1) at whmr.py:428): whmr_bn_stats / whmr_bn_relu_bwd cut at the point where the ranks' sums meet -- the host all-reduces ONE packed
+ * fp64 vector per layer and direction (torch.distributed, RCCL / gloo) between the two halves.
+ *   whmr_bn_sums             sums64 [2C + 1] = sum z | sum z^2 | rows of THIS rank (un-shifted, double)
+ *   whmr_bn_stats_from_sums  stats [4C] + running statistics (unbiased variance of the GLOBAL batch) from the summed vector
+ *   whmr_bn_bwd_sums         sums64 [2C] = sum g | sum g xhat over this rank's rows (g = dy where relu(bn(z)) > 0, xhat from the global stats),
+ *                            and the LOCAL dgamma / dbeta ((+)= when accumulate) -- torch's SyncBatchNorm keeps the parameter gradients per rank
+ *   whmr_bn_bwd_apply        dz = a (g - sum_g / N - xhat sum_gx / N), sums64 summed over the ranks, N = *count (device: element 2C of the forward vector)
+ * scratch >= 2050*C floats.  With one rank the pair of calls equals the unsplit entry up to the last bit of the double -> float roundings. */
+int whmr_bn_sums(const void* z, int z_bf16, long M, int C, double* sums64, float* scratch, void* stream);
+int whmr_bn_stats_from_sums(const double* sums64, int C, const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                            float* running_var, float* stats, void* stream);
+int whmr_bn_bwd_sums(const void* z, int z_bf16, const void* dy, int dy_bf16, const float* stats, float* dgamma, float* dbeta, int accumulate, long M,
+                     int C, double* sums64, float* scratch, void* stream);
+int whmr_bn_bwd_apply(const void* z, int z_bf16, const void* dy, int dy_bf16, const float* stats, const double* sums64, const double* count, void* dz,
+                      int dz_bf16, long M, int C, float* scratch, void* stream);
 /* dst[(ky*KW+kx)*C + c][m] = src[b, oy*S+ky-P, ox*S+kx-P, c] (NHWC src, zero outside), m = (b, oy, ox) < B*OH*OW, row length Mpad. */
 int whmr_im2col_t(const void* src, void* dst, int is_bf16, int B, int IH, int IW, int C, int OH, int OW, int KH, int KW, int S, int P,
                   long Mpad, void* stream);

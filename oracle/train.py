@@ -74,10 +74,47 @@ def regressor_forward_train(sd, assets, i, x, bbox_info, Tz, orig_shape, center,
     return out, x
 
 
+def global_orient_forward_train(sd, x, cam_rotmat, local_orient):
+    """whmr.py:289-305 with is_train=True (Dropout p = 0 in the parity runs): no Gram-Schmidt (:303-304); the three loop passes are identical."""
+    B = x.shape[0]
+    lo = local_orient.reshape(B, -1)
+    xc = torch.cat([x, G.rotmat_to_rot6d(cam_rotmat), lo], dim=1)
+    xc = F.linear(xc, sd['global_orient.fc1.weight'], sd['global_orient.fc1.bias'])
+    xc = F.linear(xc, sd['global_orient.fc2.weight'], sd['global_orient.fc2.bias'])
+    return (F.linear(xc, sd['global_orient.decrot.weight'], sd['global_orient.decrot.bias']) + lo).reshape(-1, 1, 3, 3)
+
+
+def global_output_train(sd, assets, smpl_out, body_feat, cam_rotmat):
+    """whmr.py:630-654 in training mode, with its graph: the global-orientation head on the last stage's body_feat / root rotation (cam_rotmat is
+    detached in the reference: it comes out of torch.no_grad(), whmr.py:509-524), angle-axis, SMPL of [global root | the other 23 rotations]."""
+    g_rot = global_orient_forward_train(sd, body_feat, cam_rotmat.detach(), smpl_out['rotmat'][:, 0])
+    g_aa = G.rotation_matrix_to_angle_axis(g_rot.reshape(-1, 3, 3)).reshape(-1, 3)
+    g_rotmat = torch.cat([g_rot, smpl_out['rotmat'][:, 1:]], dim=1)
+    g_verts, g_joints = S.smpl_forward(smpl_out['pred_shape'], g_rotmat, assets['smpl'])
+    return {'global_pose': torch.cat([g_aa, smpl_out['pose'][:, 3:]], dim=1), 'global_shape': smpl_out['pred_shape'], 'global_rotmat': g_rotmat,
+            'global_kp_3d': g_joints, 'global_verts': g_verts}
+
+
+GLOBAL_LOSS_KEYS = ('global_verts', 'global_pose', 'global_kp_3d')
+
+
+def global_cotangent_loss(g_out, seed=2, dev=None):
+    """Fixed random linear functional of ``global_output`` (same role as cotangent_loss): reaches global_orient.*, and through global_pose the
+    angle-axis conversion of the stage-3 rotations."""
+    g = torch.Generator().manual_seed(seed)
+    total = 0.0
+    for k in GLOBAL_LOSS_KEYS:
+        t = g_out[k]
+        c = torch.randn(t.shape, generator=g, dtype=torch.float32) / float(max(1, t[0].numel())) ** 0.5
+        total = total + (t * (c.to(dev) if dev is not None else c)).sum()
+    return total
+
+
 def whmr_forward_train(sd, assets, x, center, scale, bbox_height, orig_shape, bbox_info, stage=2, stats=None, dp_out=None,
-                       drop_masks=None, drop_path_rate=0.0, relu_gates=None, fmaps_out=None):
+                       drop_masks=None, drop_path_rate=0.0, relu_gates=None, fmaps_out=None, global_out=None, cam_rotmat=None):
     """-> list of the 4 ``smpl_out`` dicts (mean-pose mesh + 3 stages).  ``stats`` (dict, optional) receives the updated BN running stats,
-    ``dp_out`` (list, optional) the IUV head's output dict, ``fmaps_out`` (list, optional) the three deconv maps.
+    ``dp_out`` (list, optional) the IUV head's output dict, ``fmaps_out`` (list, optional) the three deconv maps, ``global_out`` (list, optional)
+    the ``global_output`` dict of whmr.py:630-654 with its graph, computed with ``cam_rotmat`` [B, 3, 3] (identity when None).
     ``relu_gates`` (tests only; None = the reference's arithmetic): three boolean NCHW masks that REPLACE the ReLU decisions of the deconv stages
     (whmr.py:488-498) -- a parity test injects the gates another evaluation took, so that pre-activations within rounding of zero stop showing up
     as O(1/sqrt(map size)) differences of every gradient behind them (tests/test_train_gpu.py)."""
@@ -100,8 +137,11 @@ def whmr_forward_train(sd, assets, x, center, scale, bbox_height, orig_shape, bb
         pose, markers = smpl_out['rotmat'].detach(), smpl_out['markers'].detach()
         pts = sd['points_grid'].expand(B, -1, -1).transpose(1, 2) if i == 0 else G.projection(markers, cam)
         ref, _ = OW.maf_sampling(sd, pts, fmaps[i], 'maf_extractor.%d.' % i)
-        smpl_out, _ = regressor_forward_train(sd, assets, i, ref, bbox_info, Tz, orig_shape, center, scale, bbox_height, pose, shape, cam, stage)
+        smpl_out, body_feat = regressor_forward_train(sd, assets, i, ref, bbox_info, Tz, orig_shape, center, scale, bbox_height, pose, shape, cam, stage)
         outs.append(smpl_out)
+    if global_out is not None:
+        cr = cam_rotmat if cam_rotmat is not None else torch.eye(3).unsqueeze(0).expand(B, -1, -1)
+        global_out.append(global_output_train(sd, assets, smpl_out, body_feat, cr))
     return outs
 
 

@@ -5,8 +5,9 @@ models/whmr.py is imported unmodified, put in ``.train()`` with the Dropout prob
 run on the seeded B=2 inputs with ``is_train=True`` for both ``cfg.TRAIN.STAGE`` layouts; forward hooks on the three Regressor
 modules hand out the per-stage output dicts WITH their autograd graph (the released forward only returns ``vis_dict``).  The scalar
 ``oracle.train.cotangent_loss`` of those outputs is back-propagated through the reference, and
-  * every per-stage output, the BatchNorm running statistics after the step and every parameter gradient are asserted equal to the
-    oracle's (functional restatement + torch autograd);
+  * every per-stage output, ``global_output`` (whmr.py:630-654: hooks on the global-orientation head and the last SMPL call), the BatchNorm running
+    statistics after the step and every parameter gradient -- ``global_orient.*`` included, through the third cotangent
+    ``oracle.train.global_cotangent_loss`` -- are asserted equal to the oracle's (functional restatement + torch autograd);
   * the fixture stores the loss, per-parameter gradient (L2 norm, sum) pairs for all trained parameters, a few small gradients in full
     and the updated running statistics -- plain arrays only.
 Usage:  python tests/golden/make_golden_train.py
@@ -32,8 +33,9 @@ from oracle import train as OT               # noqa: E402
 
 FULL_KEYS = ('dp_head.predict_ann_index.bias', 'regressor.2.deccam.weight', 'regressor.0.decshape.bias', 'est_Tz.0.weight', 'deconv_layers.7.weight', 'deconv_layers.1.bias',
              'maf_extractor.2.conv2.bias', 'maf_extractor.0.conv2.weight', 'transformer_decoder.norm1.weight', 'conv.1.weight',
-             'feature_extractor.backbone.last_norm.weight', 'feature_extractor.backbone.blocks.0.attn.qkv.bias')
-SKIP = ('running', 'cam_model', 'smpl', 'Dmap', 'points_grid', 'init_', 'num_batches', 'global_orient')
+             'feature_extractor.backbone.last_norm.weight', 'feature_extractor.backbone.blocks.0.attn.qkv.bias', 'global_orient.decrot.weight',
+             'global_orient.fc2.bias')
+SKIP = ('running', 'cam_model', 'smpl', 'Dmap', 'points_grid', 'init_', 'num_batches')
 
 
 def grad_keys(sd):
@@ -67,6 +69,13 @@ def main():
         reg.register_forward_hook(lambda m, i, o: cap.append(o[0]))
     dp_cap = []
     net.dp_head.register_forward_hook(lambda m, i, o: dp_cap.append(o))
+    # global_output (whmr.py:630-654) is built inside forward and not returned in training: the global-orientation head's output (with graph), its
+    # cam_rotmat input and the LAST call of regressor[0].smpl (the global mesh) come from hooks; global_pose is re-assembled below with the
+    # reference's own rotation_matrix_to_angle_axis, exactly as whmr.py:632-633 does
+    go_cap, smpl_cap = [], []
+    net.global_orient.register_forward_hook(lambda m, i, o: go_cap.append((i[1], o)))
+    net.regressor[0].smpl.register_forward_hook(lambda m, i, o: smpl_cap.append(o))
+    from utils.geometry import rotation_matrix_to_angle_axis as ref_mat_to_aa
     fixture = {'grad_keys': np.array(keys)}
 
     def rel(a, b):
@@ -96,25 +105,41 @@ def main():
         net.zero_grad()
         del cap[:]
         del dp_cap[:]
+        del go_cap[:]
+        del smpl_cap[:]
         net(inp['x'], None, inp['center'], inp['scale'], inp['bbox_height'], inp['orig_shape'], inp['bbox_info'], is_train=True,
             J_regressor=None, full_x=inp['full_x'])
         assert len(cap) == 3
         loss_ref = OT.cotangent_loss([None] + cap)
         assert len(dp_cap) == 1                      # AUX_SUPV_ON: the IUV head ran on the last feature map (whmr.py:656-658)
         loss_dp_ref = OT.dp_cotangent_loss(dp_cap[0])
-        (loss_ref + loss_dp_ref).backward()
+        assert len(go_cap) == 1 and go_cap[0][1].requires_grad and not go_cap[0][0].requires_grad       # cam_rotmat comes out of torch.no_grad()
+        cam_rotmat_ref, g_rot_ref = go_cap[0]
+        g_ref = {'global_pose': torch.cat([ref_mat_to_aa(g_rot_ref.reshape(-1, 3, 3)).reshape(-1, 3), cap[2]['pose'][:, 3:]], dim=1),
+                 'global_kp_3d': smpl_cap[-1].joints, 'global_verts': smpl_cap[-1].vertices}
+        loss_g_ref = OT.global_cotangent_loss(g_ref)
+        (loss_ref + loss_dp_ref + loss_g_ref).backward()
         ref_named = dict(net.named_parameters())
         ref_state = net.state_dict()
 
         p = {k: (v.clone().requires_grad_(True) if k in keys else v) for k, v in sd.items()}
-        stats, dp = {}, []
+        stats, dp, gout = {}, [], []
         assert not MG.DROP_QUEUE                     # the reference consumed every mask: 2 per block with dpr > 0
+        from oracle import whmr as OW
+        with torch.no_grad():
+            cam_rotmat, _ = OW.cam_model_forward(sd, inp['full_x'])          # the oracle's own camera head (pinned by make_golden.py); whmr.py:509-524
+        assert rel(cam_rotmat, cam_rotmat_ref) < 2e-5
         outs = OT.whmr_forward_train(p, MG.ASSETS, inp['x'], inp['center'], inp['scale'], inp['bbox_height'], inp['orig_shape'],
                                      inp['bbox_info'], stage=stage, stats=stats, dp_out=dp,
-                                     drop_masks=drop_masks if with_dp else None, drop_path_rate=rate if with_dp else 0.0)
+                                     drop_masks=drop_masks if with_dp else None, drop_path_rate=rate if with_dp else 0.0,
+                                     global_out=gout, cam_rotmat=cam_rotmat_ref)
         loss = OT.cotangent_loss(outs)
         loss_dp = OT.dp_cotangent_loss(dp[0])
-        (loss + loss_dp).backward()
+        loss_g = OT.global_cotangent_loss(gout[0])
+        (loss + loss_dp + loss_g).backward()
+        for k in OT.GLOBAL_LOSS_KEYS:
+            assert rel(gout[0][k].detach(), g_ref[k].detach()) < 2e-5, k
+        assert abs(loss_g.item() - loss_g_ref.item()) < 1e-5 * max(1.0, abs(loss_g_ref.item()))
         for k in dp[0]:
             assert rel(dp[0][k].detach(), dp_cap[0][k].detach()) < 2e-5, k
         assert abs(loss_dp.item() - loss_dp_ref.item()) < 1e-5 * max(1.0, abs(loss_dp_ref.item()))
@@ -143,6 +168,8 @@ def main():
               % (len(keys), worst, sorted(set(k.split('.')[0] for k in untouched))))
         fixture['loss_%s' % tag] = np.array(loss_ref.item())
         fixture['loss_dp_%s' % tag] = np.array(loss_dp_ref.item())
+        fixture['loss_global_%s' % tag] = np.array(loss_g_ref.item())
+        fixture['cam_rotmat'] = cam_rotmat_ref.numpy().copy()
         fixture['grad_norm_sum_%s' % tag] = np.array([[ref_named[k].grad.double().norm().item(), ref_named[k].grad.double().sum().item()]
                                                              for k in keys])
         for k in FULL_KEYS:

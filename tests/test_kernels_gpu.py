@@ -663,3 +663,30 @@ def test_tz_conv1_matches_conv2d(dev, IH, IW, dt):
     L.tz_conv1(x.to(dev), w.permute(0, 2, 3, 1).reshape(5, 49, 64).contiguous().to(dev), tok)
     assert ref.shape == tok.shape
     assert _rel(tok.cpu(), ref) < 1e-5
+
+
+def test_mat_to_aa_backward_matches_autograd(dev):
+    """whmr_mat_to_aa_bwd against torch autograd through the oracle's rotation_matrix_to_angle_axis (bit-identical to the reference's
+    utils/geometry.py:54-83 on the fixture): rotations that take each of the four quaternion branches (angles up to pi), and the NON-orthonormal
+    matrices the training graph feeds it (no Gram-Schmidt in training, whmr.py:129,174)."""
+    from oracle import geometry as G
+    from whmr_amd import _lib as L
+    g = torch.Generator().manual_seed(2)
+    axis = torch.nn.functional.normalize(torch.randn(600, 3, generator=g), dim=1)
+    ang = torch.cat([torch.rand(300, generator=g) * 3.1, 3.0 + torch.rand(300, generator=g) * 0.14])          # well inside (0, pi)
+    R = G.batch_rodrigues(axis * ang[:, None])
+    R = torch.cat([R, R[:200] + 0.05 * torch.randn(200, 3, 3, generator=g)])                                    # + perturbed (not rotations)
+    d2, d0, d1 = R[:, 2, 2], R[:, 0, 0], R[:, 1, 1]
+    branch = torch.where(d2 < 1e-6, torch.where(d0 > d1, 0, 1), torch.where(d0 < -d1, 2, 3))
+    assert all(int((branch == b).sum()) >= 10 for b in range(4)), branch.bincount()
+    cot = torch.randn(R.shape[0], 3, generator=g)
+    Rr = R.clone().requires_grad_(True)
+    aa = G.rotation_matrix_to_angle_axis(Rr)
+    (aa * cot).sum().backward()
+    got = L.mat_to_aa_bwd(R.to(dev), cot.to(dev)).cpu().view(-1, 3, 3)
+    fwd = L.mat_to_aa(R.reshape(-1, 9).to(dev)).cpu()
+    assert _rel(fwd, aa.detach()) < 1e-5
+    ref = Rr.grad
+    scale = ref.abs().amax(dim=(1, 2), keepdim=True).clamp_min(1e-6)
+    worst = ((got - ref).abs() / scale).max().item()
+    assert worst < 2e-4, worst          # per matrix, relative to its largest gradient entry (near pi the map is ill-conditioned: fp32 both sides)

@@ -243,14 +243,18 @@ def test_train_oracle_matches_reference_fixture(assets, state_dict, droppath):
     keys = [str(k) for k in fx['grad_keys']]
     inp = synth.make_inputs(2, 0)
     p = {k: (v.clone().requires_grad_(True) if k in keys else v) for k, v in state_dict.items()}
-    stats, dp = {}, []
+    stats, dp, gout = {}, [], []
     tag = 'stage2_droppath' if droppath else 'stage2'
     masks = torch.from_numpy(fx['drop_masks']) if droppath else None
+    # global_output (whmr.py:630-654) with the camera rotation the reference's cam_model produced for the fixture's full image
     outs = OT.whmr_forward_train(p, assets, inp['x'], inp['center'], inp['scale'], inp['bbox_height'], inp['orig_shape'], inp['bbox_info'],
-                                 stage=2, stats=stats, dp_out=dp, drop_masks=masks, drop_path_rate=0.3 if droppath else 0.0)
-    loss, loss_dp = OT.cotangent_loss(outs), OT.dp_cotangent_loss(dp[0])
-    (loss + loss_dp).backward()
+                                 stage=2, stats=stats, dp_out=dp, drop_masks=masks, drop_path_rate=0.3 if droppath else 0.0,
+                                 global_out=gout, cam_rotmat=torch.from_numpy(fx['cam_rotmat']))
+    loss, loss_dp, loss_g = OT.cotangent_loss(outs), OT.dp_cotangent_loss(dp[0]), OT.global_cotangent_loss(gout[0])
+    (loss + loss_dp + loss_g).backward()
     assert abs(loss.item() - float(fx['loss_' + tag])) < 1e-5 and abs(loss_dp.item() - float(fx['loss_dp_' + tag])) < 1e-5
+    assert abs(loss_g.item() - float(fx['loss_global_' + tag])) < 1e-5
+    assert any(k.startswith('global_orient.') for k in keys)                         # the head's gradients are part of the pinned set (round 5)
     if droppath:
         assert abs(float(fx['loss_stage2_droppath']) - float(fx['loss_stage2'])) > 1e-4       # the masks really change the function
     ns = fx['grad_norm_sum_' + tag]

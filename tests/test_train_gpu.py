@@ -1,5 +1,6 @@
 """Backward pass of the ViT backbone (HIP GEMM / LayerNorm / GELU kernels) against the CPU oracle's autograd."""
 import math
+import os
 
 import pytest
 import torch
@@ -456,8 +457,9 @@ def _train_model(assets, state_dict, numerics, dev):
 ZERO_GRAD_KEYS = ('est_Tz.0.bias', 'est_Tz.1.bias', 'transformer_decoder.mlp.fc2.bias')
 
 
-def _grad_keys(sd):
-    skip = ('running', 'cam_model', 'smpl', 'Dmap', 'points_grid', 'init_', 'num_batches', 'global_orient')
+def _grad_keys(sd, with_global=False):
+    # global_orient.* receives a gradient when the loss covers global_output (round 5: test_whmr_train_step_fp32_matches_oracle_autograd)
+    skip = ('running', 'cam_model', 'smpl', 'Dmap', 'points_grid', 'init_', 'num_batches') + (() if with_global else ('global_orient',))
     return [k for k, v in sd.items() if v.is_floating_point() and not any(s in k for s in skip)]
 
 
@@ -470,22 +472,31 @@ def test_whmr_train_step_fp32_matches_oracle_autograd(dev, assets, state_dict, s
     from oracle import train as OT
     from whmr_amd.core.cfgs import cfg
     inp = synth.make_inputs(2, 0)
-    keys = _grad_keys(state_dict)
+    keys = _grad_keys(state_dict, with_global=True)
     p = {k: (v.clone().requires_grad_(True) if k in keys else v) for k, v in state_dict.items()}
-    stats, dp_ref = {}, []
+    stats, dp_ref, g_ref = {}, [], []
+    # global_output (whmr.py:630-654) with a non-trivial camera rotation: the one the reference's cam_model gave the fixture's frame
+    import numpy as np
+    from conftest import GOLDEN
+    cam_rotmat = torch.from_numpy(np.load(os.path.join(GOLDEN, 'whmr_train_b2.npz'))['cam_rotmat'])
     outs_ref = OT.whmr_forward_train(p, assets, inp['x'], inp['center'], inp['scale'], inp['bbox_height'], inp['orig_shape'],
-                                     inp['bbox_info'], stage=stage, stats=stats, dp_out=dp_ref)
-    (OT.cotangent_loss(outs_ref) + OT.dp_cotangent_loss(dp_ref[0])).backward()
+                                     inp['bbox_info'], stage=stage, stats=stats, dp_out=dp_ref, global_out=g_ref, cam_rotmat=cam_rotmat)
+    (OT.cotangent_loss(outs_ref) + OT.dp_cotangent_loss(dp_ref[0]) + OT.global_cotangent_loss(g_ref[0])).backward()
     m = _train_model(assets, state_dict, 'fp32', dev)
     old = cfg.TRAIN.STAGE
     cfg.TRAIN.STAGE = stage
     try:
         d = {k: inp[k].to(dev) for k in ('x', 'center', 'scale', 'bbox_height', 'orig_shape', 'bbox_info')}
-        out_list, vis = m(d['x'], None, d['center'], d['scale'], d['bbox_height'], d['orig_shape'], d['bbox_info'], is_train=True)
-        (OT.cotangent_loss(out_list['smpl_out'], dev=dev) + OT.dp_cotangent_loss(out_list['dp_out'][0], dev=dev)).backward()
+        out_list, vis = m(d['x'], None, d['center'], d['scale'], d['bbox_height'], d['orig_shape'], d['bbox_info'], is_train=True,
+                          cam_rotmat=cam_rotmat.to(dev))
+        (OT.cotangent_loss(out_list['smpl_out'], dev=dev) + OT.dp_cotangent_loss(out_list['dp_out'][0], dev=dev)
+         + OT.global_cotangent_loss(out_list['global_output'], dev=dev)).backward()
     finally:
         cfg.TRAIN.STAGE = old
     assert len(out_list['smpl_out']) == 4 and len(vis) == 4 and len(out_list['dp_out']) == 1
+    for k in ('global_pose', 'global_rotmat', 'global_kp_3d', 'global_verts', 'global_shape'):
+        e = _rel(out_list['global_output'][k].detach().cpu(), g_ref[0][k].detach())
+        assert out_list['global_output'][k].requires_grad and e < 1e-4, (k, e)
     for k, v in dp_ref[0].items():                                                     # IUV head outputs (NCHW), iuv_predictor.py:71-91
         assert out_list['dp_out'][0][k].shape == v.shape and _rel(out_list['dp_out'][0][k].detach().cpu(), v.detach()) < 1e-4, k
     for l in range(1, 4):
@@ -503,9 +514,10 @@ def test_whmr_train_step_fp32_matches_oracle_autograd(dev, assets, state_dict, s
         OT.whmr_forward_train(state_dict, assets, inp['x'], inp['center'], inp['scale'], inp['bbox_height'], inp['orig_shape'], inp['bbox_info'], stage=stage,
                               fmaps_out=fm_ref)
     flips = [int((g_ != (f > 0)).sum()) for g_, f in zip(gates, fm_ref)]
+    g2 = []
     outs_g = OT.whmr_forward_train(p2, assets, inp['x'], inp['center'], inp['scale'], inp['bbox_height'], inp['orig_shape'], inp['bbox_info'], stage=stage,
-                                   dp_out=dp2, relu_gates=gates)
-    (OT.cotangent_loss(outs_g) + OT.dp_cotangent_loss(dp2[0])).backward()
+                                   dp_out=dp2, relu_gates=gates, global_out=g2, cam_rotmat=cam_rotmat)
+    (OT.cotangent_loss(outs_g) + OT.dp_cotangent_loss(dp2[0]) + OT.global_cotangent_loss(g2[0])).backward()
     worst_gated = 0.0
     named = dict(m.named_parameters())
     bad = {}
@@ -539,7 +551,8 @@ def test_whmr_train_step_fp32_matches_oracle_autograd(dev, assets, state_dict, s
     print('train view, TRAIN.STAGE %d: %s ReLU gates differ from the CPU oracle; worst deconv / backbone gradient with the device gates injected: max-rel %.2e'
           % (stage, flips, worst_gated))
     assert not bad, 'gradient mismatch: %s' % sorted(bad.items(), key=lambda kv: str(kv[1]))[:8]
-    assert named['global_orient.fc1.weight'].grad is None
+    # the global-orientation head is part of the graph (whmr.py:289-305,631): its six parameters were compared above like every other head
+    assert sum(k.startswith('global_orient.') for k in keys) == 6 and all(named[k].grad is not None for k in keys if k.startswith('global_orient.'))
 
 
 KP2DW_DELTA = 1e-5                        # kp_2d_w vs float64, relative to the projection's condition number (measured: see the printout)
@@ -1249,3 +1262,99 @@ def test_grad_reducer_exchange_waits_for_the_pack_on_its_own_stream(dev, monkeyp
     for p, g in zip(params, grads):
         assert torch.equal(p.grad, 2.0 * g)
     red.remove()
+
+
+@pytest.mark.parametrize('dtname', ['fp32', 'bf16'])
+def test_sync_batchnorm_split_kernels(dev, dtname):
+    """The SyncBatchNorm halves of the BatchNorm kernels (include/whmr_hip.h: whmr_bn_sums / _stats_from_sums / _bwd_sums / _bwd_apply):
+    (a) run back to back with nothing exchanged they equal the unsplit entries (whmr_bn_stats / whmr_bn_relu_bwd) to fp32 rounding;
+    (b) the sums of two HALF batches, added like the all-reduce adds them, give the statistics, running statistics and data gradients of the
+        whole batch, and the halves' local dgamma / dbeta add up to the whole batch's (two ranks of B == one process of 2B)."""
+    from whmr_amd import _lib as L
+    dt = torch.float32 if dtname == 'fp32' else torch.bfloat16
+    g = torch.Generator().manual_seed(5)
+    M, Cc = 2 * 37 * 24, 256
+    z = (torch.randn(M, Cc, generator=g) * 1.7 + torch.linspace(-4, 4, Cc)).to(dt).to(dev)
+    dy = torch.randn(M, Cc, generator=g).to(dt).to(dev)
+    gamma, beta = (torch.rand(Cc, generator=g) + 0.5).to(dev), torch.randn(Cc, generator=g).to(dev)
+    rm0, rv0 = torch.randn(Cc, generator=g).to(dev), (torch.rand(Cc, generator=g) + 0.5).to(dev)
+    rel = lambda a, b: ((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30)).item()
+    # unsplit
+    rm_u, rv_u = rm0.clone(), rv0.clone()
+    st_u = L.bn_stats(z, gamma, beta, 1e-5, 0.1, rm_u, rv_u)
+    dz_u, dg_u, db_u = torch.empty_like(z), torch.empty(Cc, device=dev), torch.empty(Cc, device=dev)
+    L.bn_relu_bwd(z, dy, st_u, dz_u, dg_u, db_u)
+    # (a) split, one "rank"
+    rm_s, rv_s = rm0.clone(), rv0.clone()
+    sums = L.bn_sums(z)
+    assert sums.dtype == torch.float64 and sums[-1].item() == M
+    zd = z.double()
+    assert rel(sums[:Cc], zd.sum(0)) < 1e-6 and rel(sums[Cc:2 * Cc], (zd * zd).sum(0)) < 1e-6          # fp32 row-chunk partials, double from there
+    st_s = L.bn_stats_from_sums(sums, gamma, beta, 1e-5, 0.1, rm_s, rv_s)
+    assert rel(st_s, st_u) < 2e-6 and rel(rm_s, rm_u) < 1e-6 and rel(rv_s, rv_u) < 2e-6
+    dz_s, dg_s, db_s = torch.empty_like(z), torch.empty(Cc, device=dev), torch.empty(Cc, device=dev)
+    bs = L.bn_bwd_sums(z, dy, st_u, dg_s, db_s)
+    L.bn_bwd_apply(z, dy, st_u, bs, sums[-1:], dz_s)
+    assert torch.equal(dg_s, dg_u) and torch.equal(db_s, db_u)
+    assert rel(dz_s.float(), dz_u.float()) < (1e-6 if dt == torch.float32 else 1e-2)
+    # (b) two half batches
+    h = M // 2
+    parts = [(z[:h].contiguous(), dy[:h].contiguous()), (z[h:].contiguous(), dy[h:].contiguous())]
+    tot = sum(L.bn_sums(zp) for zp, _ in parts)                    # the all-reduce
+    assert tot[-1].item() == M and rel(tot, sums) < 1e-6
+    rm_h, rv_h = rm0.clone(), rv0.clone()
+    st_h = L.bn_stats_from_sums(tot, gamma, beta, 1e-5, 0.1, rm_h, rv_h)
+    assert rel(st_h, st_u) < 2e-6 and rel(rm_h, rm_u) < 1e-6 and rel(rv_h, rv_u) < 2e-6
+    loc = []
+    for zp, dyp in parts:
+        dgp, dbp = torch.empty(Cc, device=dev), torch.empty(Cc, device=dev)
+        loc.append((L.bn_bwd_sums(zp, dyp, st_h, dgp, dbp), dgp, dbp))
+    btot = loc[0][0] + loc[1][0]                                   # the all-reduce
+    assert rel(loc[0][1] + loc[1][1], dg_u) < 1e-5 and rel(loc[0][2] + loc[1][2], db_u) < 1e-5
+    dz_h = torch.cat([L.bn_bwd_apply(zp, dyp, st_h, btot, tot[-1:], torch.empty_like(zp)) for zp, dyp in parts])
+    assert rel(dz_h.float(), dz_u.float()) < (2e-5 if dt == torch.float32 else 1e-2)
+    # and the whole thing against float64 BatchNorm autograd on the CPU (fp32 maps only: the bf16 maps round z itself)
+    if dt == torch.float32:
+        zr = z.cpu().double().requires_grad_(True)
+        y = torch.relu(torch.nn.functional.batch_norm(zr, None, None, gamma.cpu().double(), beta.cpu().double(), True, 0.1, 1e-5))
+        y.backward(dy.cpu().double())
+        assert rel(dz_h.cpu(), zr.grad) < 1e-4
+
+
+def test_whmr_train_step_with_converted_sync_batchnorm_world1(dev, assets, state_dict):
+    """convert_sync_batchnorm on the W-HMR model (core/trainer.py:83) at world size 1 with the split kernels FORCED (always=True: the exchange is
+    a no-op): the training step -- per-stage outputs, BatchNorm running statistics, loss and every gradient -- equals the local-BatchNorm step
+    (the four trained BatchNorm layers take the SyncBatchNorm path: 3 x BatchNorm2d of the deconv pyramid, BatchNorm1d of the Tz head)."""
+    from oracle import synth
+    from oracle import train as OT
+    from whmr_amd.parallel import convert_sync_batchnorm, revert_sync_batchnorm
+    inp = synth.make_inputs(2, 0)
+    d = {k: inp[k].to(dev) for k in ('x', 'center', 'scale', 'bbox_height', 'orig_shape', 'bbox_info')}
+    res = {}
+    for mode in ('local', 'sync'):
+        m = _train_model(assets, state_dict, 'fp32', dev)
+        if mode == 'sync':
+            convert_sync_batchnorm(m, always=True)
+            assert m.whmr_sync_layers >= 4
+        out_list, _ = m(d['x'], None, d['center'], d['scale'], d['bbox_height'], d['orig_shape'], d['bbox_info'], is_train=True)
+        loss = OT.cotangent_loss(out_list['smpl_out'], dev=dev) + OT.dp_cotangent_loss(out_list['dp_out'][0], dev=dev)
+        loss.backward()
+        res[mode] = (loss.item(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None},
+                     {k: v.clone() for k, v in m.state_dict().items() if 'running_' in k and 'cam_model' not in k},
+                     out_list['smpl_out'][3]['verts'].detach().clone())
+        if mode == 'sync':
+            revert_sync_batchnorm(m)
+            assert not any(hasattr(q, 'whmr_sync') for q in m.modules())
+    assert abs(res['local'][0] - res['sync'][0]) < 1e-5 * max(1.0, abs(res['local'][0]))
+    assert _rel(res['sync'][3], res['local'][3]) < 1e-5
+    for k, v in res['local'][2].items():
+        assert _rel(res['sync'][2][k], v) < 1e-5, k
+    assert res['local'][1].keys() == res['sync'][1].keys()
+    bad = {}
+    for k, gl in res['local'][1].items():
+        if gl.abs().max() < 1e-7 or k in ZERO_GRAD_KEYS:
+            continue
+        e = _rel(res['sync'][1][k], gl)
+        if not e < 2e-4:
+            bad[k] = e
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:6]

@@ -98,6 +98,7 @@ _SIGS = {
     'whmr_attention': [_P, _P, _I, _I, _I, _I, _F, _I, _P],
     'whmr_rot_to_mat': [_P, _P, _I, _I, _P],
     'whmr_mat_to_aa': [_P, _P, _I, _P],
+    'whmr_mat_to_aa_bwd': [_P, _P, _P, _I, _P],
     'whmr_perspective': [_P, _P, _I, _P, _P, _I, _P, _P, _F, _P, _I, _I, _P],
     'whmr_weak_projection': [_P, _P, _P, _I, _I, _F, _F, _F, _P],
     'whmr_smpl_pose_chain': [C.POINTER(WhmrSmplModel), _P, _L, _P, _L, _I, _I, _P, _P, _P, _P, _P, _P],
@@ -126,6 +127,10 @@ _SIGS = {
     'whmr_bn_stats': [_P, _I, _L, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P],
     'whmr_bn_apply_relu': [_P, _I, _P, _P, _I, _L, _I, _P],
     'whmr_bn_relu_bwd': [_P, _I, _P, _I, _P, _P, _I, _P, _P, _I, _L, _I, _P, _P],
+    'whmr_bn_sums': [_P, _I, _L, _I, _P, _P, _P],
+    'whmr_bn_stats_from_sums': [_P, _I, _P, _P, _F, _F, _P, _P, _P, _P],
+    'whmr_bn_bwd_sums': [_P, _I, _P, _I, _P, _P, _P, _I, _L, _I, _P, _P, _P],
+    'whmr_bn_bwd_apply': [_P, _I, _P, _I, _P, _P, _P, _P, _I, _L, _I, _P, _P],
     'whmr_im2col_t': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _P],
     'whmr_smpl_joints_bwd': [C.POINTER(WhmrSmplModel), _P, _P, _P, _I, _P, _P, _P, _P],
     'whmr_smpl_skin_bwd': [C.POINTER(WhmrSmplModel), _P, _L, _P, _P, _P, _P, _I, _I, _P, _P, _P],
@@ -635,6 +640,17 @@ def rot_to_mat(x, mode):
     n = x.numel() // (6, 9, 3)[mode]
     out = torch.empty(n, 3, 3, dtype=torch.float32, device=x.device)
     _check(lib().whmr_rot_to_mat(x.data_ptr(), out.data_ptr(), n, mode, _stream()), 'whmr_rot_to_mat')
+    return out
+
+
+def mat_to_aa_bwd(R, d_aa):
+    """d_R [n, 9] = (d aa / d R)^T d_aa [n, 3]: backward of ``mat_to_aa`` (include/whmr_hip.h)"""
+    _dev(R, d_aa)
+    R, d_aa = R.reshape(-1, 9).float().contiguous(), d_aa.reshape(-1, 3).float().contiguous()
+    n = R.shape[0]
+    assert d_aa.shape[0] == n
+    out = torch.empty(n, 9, dtype=torch.float32, device=R.device)
+    _check(lib().whmr_mat_to_aa_bwd(R.data_ptr(), d_aa.data_ptr(), out.data_ptr(), n, _stream()), 'whmr_mat_to_aa_bwd')
     return out
 
 
@@ -1155,6 +1171,53 @@ def bn_stats(z, gamma, beta, eps, momentum=0.0, running_mean=None, running_var=N
     _check(lib().whmr_bn_stats(z.data_ptr(), _bf(z), M, Cc, _ptr(gamma), _ptr(beta), eps, momentum, _ptr(running_mean), _ptr(running_var),
                                stats.data_ptr(), sc.data_ptr(), _stream()), 'whmr_bn_stats')
     return stats
+
+
+def bn_sums(z):
+    """SyncBatchNorm forward, first half: z [M, C] channels-last -> sums64 [2C + 1] fp64 = sum z | sum z^2 | M of THIS rank (include/whmr_hip.h);
+    the caller all-reduces it over the ranks and hands it to ``bn_stats_from_sums``."""
+    _dev(z)
+    assert z.dim() == 2 and z.is_contiguous() and z.dtype in (torch.float32, torch.bfloat16)
+    M, Cc = z.shape
+    sums = torch.empty(2 * Cc + 1, dtype=torch.float64, device=z.device)
+    sc = train_scratch(z.device, 2050 * Cc)
+    _check(lib().whmr_bn_sums(z.data_ptr(), _bf(z), M, Cc, sums.data_ptr(), sc.data_ptr(), _stream()), 'whmr_bn_sums')
+    return sums
+
+
+def bn_stats_from_sums(sums, gamma, beta, eps, momentum=0.0, running_mean=None, running_var=None):
+    """sums64 [2C + 1] (summed over the ranks) -> stats [4, C] = mean | invstd | a | b; running stats updated in place when given."""
+    _dev(sums, gamma, beta, running_mean, running_var)
+    assert sums.dtype == torch.float64 and sums.is_contiguous() and sums.numel() % 2 == 1
+    Cc = (sums.numel() - 1) // 2
+    stats = torch.empty(4, Cc, dtype=torch.float32, device=sums.device)
+    _check(lib().whmr_bn_stats_from_sums(sums.data_ptr(), Cc, _ptr(gamma), _ptr(beta), eps, momentum, _ptr(running_mean), _ptr(running_var),
+                                         stats.data_ptr(), _stream()), 'whmr_bn_stats_from_sums')
+    return stats
+
+
+def bn_bwd_sums(z, dy, stats, dgamma, dbeta, accumulate=False):
+    """SyncBatchNorm backward, first half: -> sums64 [2C] fp64 = sum g | sum g xhat of THIS rank's rows; dgamma / dbeta get the LOCAL sums."""
+    _dev(z, dy, stats, dgamma, dbeta)
+    assert z.is_contiguous() and dy.is_contiguous() and z.shape == dy.shape
+    M, Cc = z.shape
+    sums = torch.empty(2 * Cc, dtype=torch.float64, device=z.device)
+    sc = train_scratch(z.device, 2050 * Cc)
+    _check(lib().whmr_bn_bwd_sums(z.data_ptr(), _bf(z), dy.data_ptr(), _bf(dy), stats.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), int(accumulate),
+                                  M, Cc, sums.data_ptr(), sc.data_ptr(), _stream()), 'whmr_bn_bwd_sums')
+    return sums
+
+
+def bn_bwd_apply(z, dy, stats, sums, count, dz):
+    """second half: dz from the globally summed ``sums`` [2C] and the global row count ``count`` (a 1-element fp64 device tensor)."""
+    _dev(z, dy, stats, sums, count, dz)
+    assert z.is_contiguous() and dy.is_contiguous() and dz.is_contiguous() and z.shape == dy.shape == dz.shape
+    assert sums.dtype == torch.float64 and count.dtype == torch.float64 and count.numel() == 1
+    M, Cc = z.shape
+    sc = train_scratch(z.device, 2050 * Cc)
+    _check(lib().whmr_bn_bwd_apply(z.data_ptr(), _bf(z), dy.data_ptr(), _bf(dy), stats.data_ptr(), sums.data_ptr(), count.data_ptr(), dz.data_ptr(),
+                                   _bf(dz), M, Cc, sc.data_ptr(), _stream()), 'whmr_bn_bwd_apply')
+    return dz
 
 
 def bn_apply_relu(z, stats, y):

@@ -83,13 +83,18 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const TZ* __restrict__ 
 // block = 16 channels x 16 part lanes; fixed-order double sums.
 // MODE 0: stats = [mean | invstd | a | b], running stats updated (momentum; unbiased variance) when given.
 // MODE 1: dbeta, dgamma (+= when accumulate), coef = [dbeta/M | dgamma/M].
+// MODE 2 (SyncBatchNorm forward): sums64 = [sum z | sum z^2 | M] in double, un-shifted -- what the ranks add up (one all-reduce) before
+//         bn_stats_from_sums_kernel.  The shifted partials keep the fp32 accumulation of a row chunk well conditioned; the un-shift
+//         (s1 + M shift, s2 + 2 shift s1 + M shift^2) happens here in double, so E[z^2] - mean^2 of the GLOBAL batch has 53-bit operands.
+// MODE 3 (SyncBatchNorm backward): sums64 = [sum g | sum g xhat] of THIS rank's rows in double (xhat from the global statistics) and the
+//         LOCAL dbeta / dgamma (torch's SyncBatchNorm semantics: the parameter gradients stay per rank, the data-parallel reducer averages them).
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int nparts, long M, int C, const float* __restrict__ z0_f32,
                                                           const bf16_t* __restrict__ z0_bf16, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float eps, float momentum, float* __restrict__ stats,
                                                           float* __restrict__ running_mean, float* __restrict__ running_var,
                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
-                                                          float* __restrict__ coef) {
+                                                          float* __restrict__ coef, double* __restrict__ sums64 = nullptr) {
     __shared__ double red[2][16][17];
     const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
     double a = 0.0, b = 0.0;
@@ -117,12 +122,45 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
             stats[c] = (float)mean; stats[C + c] = invstd; stats[2 * C + c] = aa; stats[3 * C + c] = bt - (float)mean * aa;
             if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
             if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * (double)M / (double)(M > 1 ? M - 1 : 1));
+        } else if (MODE == 2) {
+            const double shift = z0_f32 ? (double)z0_f32[c] : (double)bf16_to_f32(z0_bf16[c]);
+            sums64[c] = s1 + (double)M * shift;
+            sums64[C + c] = s2 + 2.0 * shift * s1 + (double)M * shift * shift;
+            if (c == 0) sums64[2 * C] = (double)M;
         } else {
             dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
             dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
-            coef[c] = (float)(s1 / (double)M); coef[C + c] = (float)(s2 / (double)M);
+            if (MODE == 1) { coef[c] = (float)(s1 / (double)M); coef[C + c] = (float)(s2 / (double)M); }
+            else { sums64[c] = s1; sums64[C + c] = s2; }
         }
     }
+}
+
+// SyncBatchNorm: stats = [mean | invstd | a | b] from the moments of the GLOBAL batch (sums64 = [sum z | sum z^2 | rows], already summed over
+// the ranks), running statistics updated with the global batch's unbiased variance -- the tail of bn_finalize_kernel<0> on other inputs.
+__global__ __launch_bounds__(256) void bn_stats_from_sums_kernel(const double* __restrict__ sums64, int C, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, float eps, float momentum, float* __restrict__ stats,
+                                                                 float* __restrict__ running_mean, float* __restrict__ running_var) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const double n = sums64[2 * C];
+    const double mean = sums64[c] / n;
+    double var = sums64[C + c] / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+    const float aa = g * invstd;
+    stats[c] = (float)mean; stats[C + c] = invstd; stats[2 * C + c] = aa; stats[3 * C + c] = bt - (float)mean * aa;
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * n / (n > 1.0 ? n - 1.0 : 1.0));
+}
+
+// SyncBatchNorm backward: coef = [sum g / N | sum g xhat / N] from the globally summed sums and the global row count
+__global__ __launch_bounds__(256) void bn_coef_from_sums_kernel(const double* __restrict__ sums64, const double* __restrict__ count, int C, float* __restrict__ coef) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const double n = *count;
+    coef[c] = (float)(sums64[c] / n); coef[C + c] = (float)(sums64[C + c] / n);
 }
 
 template <typename TZ, typename TY>
@@ -187,6 +225,35 @@ extern "C" int whmr_bn_stats(const void* z, int z_bf16, long M, int C, const flo
     return 0;
 }
 
+// ---- SyncBatchNorm (core/trainer.py:83: convert_sync_batchnorm before DDP): whmr_bn_stats cut where the ranks' sums meet.
+//   whmr_bn_sums             sums64 [2C + 1] = sum z | sum z^2 | rows of THIS rank        -> all-reduce(SUM) over the ranks (host)
+//   whmr_bn_stats_from_sums  stats [4C] (+ running statistics) from the summed vector
+// scratch: >= BN_PARTS * 2 * C floats.
+extern "C" int whmr_bn_sums(const void* z, int z_bf16, long M, int C, double* sums64, float* scratch, void* stream) {
+    if (!bn_shape_ok(M, C) || !sums64) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    const int rpb = 256 / (C >> 3);
+    const int parts = (int)min((long)BN_PARTS, (M + rpb - 1) / rpb);
+    const size_t lds = (size_t)2 * rpb * C * sizeof(float);
+    if (z_bf16) hipLaunchKernelGGL((bn_partial_kernel<bf16_t, bf16_t, 0>), dim3(parts), dim3(256), lds, st, (const bf16_t*)z, (const bf16_t*)nullptr, (const float*)nullptr, M, C, scratch);
+    else hipLaunchKernelGGL((bn_partial_kernel<float, float, 0>), dim3(parts), dim3(256), lds, st, (const float*)z, (const float*)nullptr, (const float*)nullptr, M, C, scratch);
+    WHMR_CHECK_LAUNCH();
+    hipLaunchKernelGGL((bn_finalize_kernel<2>), dim3((C + 15) / 16), dim3(256), 0, st, scratch, parts, M, C, z_bf16 ? nullptr : (const float*)z,
+                       z_bf16 ? (const bf16_t*)z : nullptr, (const float*)nullptr, (const float*)nullptr, 0.f, 0.f, (float*)nullptr, (float*)nullptr,
+                       (float*)nullptr, (float*)nullptr, (float*)nullptr, 0, (float*)nullptr, sums64);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int whmr_bn_stats_from_sums(const double* sums64, int C, const float* gamma, const float* beta, float eps, float momentum,
+                                       float* running_mean, float* running_var, float* stats, void* stream) {
+    if (C <= 0 || !sums64 || !stats) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(bn_stats_from_sums_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums64, C, gamma, beta, eps, momentum, stats,
+                       running_mean, running_var);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int whmr_bn_apply_relu(const void* z, int z_bf16, const float* stats, void* y, int y_bf16, long M, int C, void* stream) {
     if (!bn_shape_ok(M, C)) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
@@ -228,6 +295,53 @@ extern "C" int whmr_bn_relu_bwd(const void* z, int z_bf16, const void* dy, int d
     if (z_bf16 && !dy_bf16 && dz_bf16) return bn_bwd_launch<bf16_t, float, bf16_t>(z, dy, stats, dz, dgamma, dbeta, accumulate, M, C, scratch, st);
     if (!z_bf16 && !dy_bf16 && !dz_bf16) return bn_bwd_launch<float, float, float>(z, dy, stats, dz, dgamma, dbeta, accumulate, M, C, scratch, st);
     return (int)hipErrorInvalidValue;
+}
+
+// ---- SyncBatchNorm backward: whmr_bn_relu_bwd cut at its reduction.
+//   whmr_bn_bwd_sums   sums64 [2C] = sum g | sum g xhat over THIS rank's rows (g = dy where relu(bn(z)) > 0; stats = the GLOBAL statistics) and the
+//                      LOCAL dgamma / dbeta ((+)= when accumulate)                        -> all-reduce(SUM) of sums64 over the ranks (host)
+//   whmr_bn_bwd_apply  dz = a (g - sum_g / N - xhat sum_gx / N) with the summed vector and N = *count (the forward's summed row count, on the device)
+// scratch: >= (BN_PARTS * 2 + 2) * C floats.
+template <typename TZ, typename TDY>
+static int bn_bwd_sums_launch(const void* z, const void* dy, const float* stats, float* dgamma, float* dbeta, int accumulate, long M, int C,
+                              double* sums64, float* scratch, hipStream_t st) {
+    const int rpb = 256 / (C >> 3);
+    const int parts = (int)min((long)BN_PARTS, (M + rpb - 1) / rpb);
+    const size_t lds = (size_t)2 * rpb * C * sizeof(float);
+    hipLaunchKernelGGL((bn_partial_kernel<TZ, TDY, 1>), dim3(parts), dim3(256), lds, st, (const TZ*)z, (const TDY*)dy, stats, M, C, scratch);
+    WHMR_CHECK_LAUNCH();
+    hipLaunchKernelGGL((bn_finalize_kernel<3>), dim3((C + 15) / 16), dim3(256), 0, st, scratch, parts, M, C, (const float*)nullptr, (const bf16_t*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, 0.f, 0.f, (float*)nullptr, (float*)nullptr, (float*)nullptr, dgamma, dbeta,
+                       accumulate, (float*)nullptr, sums64);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int whmr_bn_bwd_sums(const void* z, int z_bf16, const void* dy, int dy_bf16, const float* stats, float* dgamma, float* dbeta, int accumulate,
+                                long M, int C, double* sums64, float* scratch, void* stream) {
+    if (!bn_shape_ok(M, C) || !sums64 || !dgamma || !dbeta) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    if (z_bf16 && dy_bf16) return bn_bwd_sums_launch<bf16_t, bf16_t>(z, dy, stats, dgamma, dbeta, accumulate, M, C, sums64, scratch, st);
+    if (z_bf16 && !dy_bf16) return bn_bwd_sums_launch<bf16_t, float>(z, dy, stats, dgamma, dbeta, accumulate, M, C, sums64, scratch, st);
+    if (!z_bf16 && !dy_bf16) return bn_bwd_sums_launch<float, float>(z, dy, stats, dgamma, dbeta, accumulate, M, C, sums64, scratch, st);
+    return (int)hipErrorInvalidValue;
+}
+
+extern "C" int whmr_bn_bwd_apply(const void* z, int z_bf16, const void* dy, int dy_bf16, const float* stats, const double* sums64, const double* count,
+                                 void* dz, int dz_bf16, long M, int C, float* scratch, void* stream) {
+    if (!bn_shape_ok(M, C) || !sums64 || !count) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    float* coef = scratch + (size_t)BN_PARTS * 2 * C;
+    hipLaunchKernelGGL(bn_coef_from_sums_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums64, count, C, coef);
+    WHMR_CHECK_LAUNCH();
+    const int rpb = 256 / (C >> 3);
+    const int blocks = (int)min((long)4096, (M + rpb - 1) / rpb);
+    if (z_bf16 && dy_bf16 && dz_bf16) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, bf16_t, bf16_t>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)z, (const bf16_t*)dy, stats, coef, (bf16_t*)dz, M, C);
+    else if (z_bf16 && !dy_bf16 && dz_bf16) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, float, bf16_t>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)z, (const float*)dy, stats, coef, (bf16_t*)dz, M, C);
+    else if (!z_bf16 && !dy_bf16 && !dz_bf16) hipLaunchKernelGGL((bn_bwd_apply_kernel<float, float, float>), dim3(blocks), dim3(256), 0, st, (const float*)z, (const float*)dy, stats, coef, (float*)dz, M, C);
+    else return (int)hipErrorInvalidValue;
+    WHMR_CHECK_LAUNCH();
+    return 0;
 }
 
 // T[(ky*KW + kx)*C + c][m] = src[b, oy*S + ky - P, ox*S + kx - P, c] (0 outside), m = (b*OH + oy)*OW + ox, columns M..Mpad-1 zero.

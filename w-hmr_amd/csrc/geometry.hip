@@ -79,6 +79,27 @@ extern "C" int whmr_mat_to_aa(const float* in, float* out, int n, void* stream) 
     return 0;
 }
 
+// backward of whmr_mat_to_aa: d_in [n, 9] = (d aa / d R)^T d_out [n, 3] (geometry_dev.h rotmat_to_aa3_bwd)
+__global__ void mat_to_aa_bwd_kernel(const float* __restrict__ in, const float* __restrict__ d_out, float* __restrict__ d_in, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float R[9], g[3], dR[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[k] = in[9 * i + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) g[k] = d_out[3 * i + k];
+    rotmat_to_aa3_bwd(R, g, dR);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) d_in[9 * i + k] = dR[k];
+}
+
+extern "C" int whmr_mat_to_aa_bwd(const float* in, const float* d_out, float* d_in, int n, void* stream) {
+    if (n <= 0) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(mat_to_aa_bwd_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, in, d_out, d_in, n);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int whmr_perspective(const float* pts, const float* rot, int rot_bstride, const float* trans, const float* focal,
                                 int focal_bstride, const float* center, const float* post_div, float post_shift, float* out,
                                 int B, int P, void* stream) {

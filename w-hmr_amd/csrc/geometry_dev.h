@@ -92,3 +92,68 @@ __device__ __forceinline__ void rotmat_to_aa3(const float* R, float* o) {
     o[1] = (a1 != a1) ? 0.f : a1;
     o[2] = (a2 != a2) ? 0.f : a2;
 }
+
+// Reverse mode of rotmat_to_aa3 (what torch autograd computes through utils/geometry.py:54-83,86-136,160-240 in the reference's training graph:
+// global_pose / theta carry rotation_matrix_to_angle_axis of rotmats that have a graph, whmr.py:174,632-633): dR [9] = (d aa / d R)^T d_aa.
+// Same branch selection as the forward (the reference multiplies the four candidate quaternions by 0 / 1 masks: only the selected one has a
+// gradient); the forward's `aa[isnan(aa)] = 0` is an in-place masked write, so a NaN component passes no gradient.  One deliberate difference:
+// at sin^2(theta) == 0 exactly (R = I bit for bit) torch's where(sin2 > 0, two_theta / sin, 2) still back-propagates through the unselected
+// branch's sqrt(0) and yields NaN; here the selected branch k = 2 is differentiated (d q_i = 2 d aa_i), a finite value.
+__device__ __forceinline__ void rotmat_to_aa3_bwd(const float* R, const float* d_o, float* dR) {
+#define RT(a, b) R[3 * (b) + (a)]
+#define DRT(a, b) dR[3 * (b) + (a)]
+    const float d0 = RT(0, 0), d1 = RT(1, 1), d2 = RT(2, 2);
+    const bool m2 = d2 < 1e-6f, m01 = d0 > d1, m0n1 = d0 < -d1;
+    const int br = (m2 && m01) ? 0 : (m2 && !m01) ? 1 : (!m2 && m0n1) ? 2 : 3;
+    float n0, n1, n2, n3, t;
+    if (br == 0) { t = 1 + d0 - d1 - d2; n0 = RT(1, 2) - RT(2, 1); n1 = t; n2 = RT(0, 1) + RT(1, 0); n3 = RT(2, 0) + RT(0, 2); }
+    else if (br == 1) { t = 1 - d0 + d1 - d2; n0 = RT(2, 0) - RT(0, 2); n1 = RT(0, 1) + RT(1, 0); n2 = t; n3 = RT(1, 2) + RT(2, 1); }
+    else if (br == 2) { t = 1 - d0 - d1 + d2; n0 = RT(0, 1) - RT(1, 0); n1 = RT(2, 0) + RT(0, 2); n2 = RT(1, 2) + RT(2, 1); n3 = t; }
+    else { t = 1 + d0 + d1 + d2; n0 = t; n1 = RT(1, 2) - RT(2, 1); n2 = RT(2, 0) - RT(0, 2); n3 = RT(0, 1) - RT(1, 0); }
+    const float st = sqrtf(t);
+    const float q0 = n0 / st * 0.5f, q1 = n1 / st * 0.5f, q2 = n2 / st * 0.5f, q3 = n3 / st * 0.5f;
+    const float s2 = q1 * q1 + q2 * q2 + q3 * q3;
+    const float sn = sqrtf(s2);
+    const float two_theta = 2.0f * (q0 < 0.0f ? atan2f(-sn, -q0) : atan2f(sn, q0));
+    const float k = s2 > 0.0f ? two_theta / sn : 2.0f;
+    // aa_i = q_i k, NaN components masked
+    const float a0 = q1 * k, a1 = q2 * k, a2 = q3 * k;
+    const float g0 = (a0 != a0) ? 0.f : d_o[0], g1 = (a1 != a1) ? 0.f : d_o[1], g2 = (a2 != a2) ? 0.f : d_o[2];
+    float dq0 = 0.f, dq1 = g0 * k, dq2 = g1 * k, dq3 = g2 * k;
+    if (s2 > 0.0f) {
+        const float dk = g0 * q1 + g1 * q2 + g2 * q3;
+        const float dtt = dk / sn;                                   // d two_theta
+        float dsn = -dk * two_theta / s2;
+        // two_theta = 2 atan2(+-sn, +-q0): d atan2(y, x) = (x dy - y dx) / (x^2 + y^2), the same expression for both sign choices
+        const float den = s2 + q0 * q0;
+        dsn += 2.0f * dtt * q0 / den;
+        dq0 = -2.0f * dtt * sn / den;
+        const float ds2 = dsn / (2.0f * sn);
+        dq1 += 2.0f * q1 * ds2; dq2 += 2.0f * q2 * ds2; dq3 += 2.0f * q3 * ds2;
+    }
+    // q_i = 0.5 n_i / sqrt(t)
+    const float dn0 = 0.5f * dq0 / st, dn1 = 0.5f * dq1 / st, dn2 = 0.5f * dq2 / st, dn3 = 0.5f * dq3 / st;
+    const float dst = -(dq0 * q0 + dq1 * q1 + dq2 * q2 + dq3 * q3) / st;
+    float dt = dst / (2.0f * st);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) dR[i] = 0.f;
+    if (br == 0) {
+        dt += dn1;
+        DRT(1, 2) += dn0; DRT(2, 1) -= dn0; DRT(0, 1) += dn2; DRT(1, 0) += dn2; DRT(2, 0) += dn3; DRT(0, 2) += dn3;
+        DRT(0, 0) += dt; DRT(1, 1) -= dt; DRT(2, 2) -= dt;
+    } else if (br == 1) {
+        dt += dn2;
+        DRT(2, 0) += dn0; DRT(0, 2) -= dn0; DRT(0, 1) += dn1; DRT(1, 0) += dn1; DRT(1, 2) += dn3; DRT(2, 1) += dn3;
+        DRT(0, 0) -= dt; DRT(1, 1) += dt; DRT(2, 2) -= dt;
+    } else if (br == 2) {
+        dt += dn3;
+        DRT(0, 1) += dn0; DRT(1, 0) -= dn0; DRT(2, 0) += dn1; DRT(0, 2) += dn1; DRT(1, 2) += dn2; DRT(2, 1) += dn2;
+        DRT(0, 0) -= dt; DRT(1, 1) -= dt; DRT(2, 2) += dt;
+    } else {
+        dt += dn0;
+        DRT(1, 2) += dn1; DRT(2, 1) -= dn1; DRT(2, 0) += dn2; DRT(0, 2) -= dn2; DRT(0, 1) += dn3; DRT(1, 0) -= dn3;
+        DRT(0, 0) += dt; DRT(1, 1) += dt; DRT(2, 2) += dt;
+    }
+#undef RT
+#undef DRT
+}

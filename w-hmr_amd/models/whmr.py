@@ -253,13 +253,30 @@ class Global_Orient_Regressor(nn.Module):
             return (wd @ (w2 @ w1)).float().contiguous(), (wd @ (w2 @ b1 + b2) + bd).float().contiguous()
         return self._cache.get('collapsed', ws, build)
 
-    @torch.no_grad()
     def forward(self, x, cam_rotmat, local_orient, is_train=False, xc=None, raw=False):
         """xc (optional): a buffer with >= 2164 columns whose first 2149 already hold x (the last regressor stage's input buffer);
         columns 2149..2163 are overwritten in place instead of copying x.  local_orient: [B, 3, 3] or the stage's whole rotmat [B, 24, 3, 3]
-        (its root block is read in place).  raw: return the head's output before the Gram-Schmidt step."""
+        (its root block is read in place).  raw: return the head's output before the Gram-Schmidt step.
+        is_train=True (whmr.py:289-305 as called at :631 in training): the three Linear layers as autograd nodes with HIP forward / backward
+        (train.heads_autograd.LinearFn), Dropout active in ``.train()``, no Gram-Schmidt -> pred_rot [B, 1, 3, 3] with a graph into fc1 / fc2 /
+        decrot, ``x`` (the last stage's body_feat) and ``local_orient``.  The reference runs the stack three times on the SAME input and keeps
+        the last result (local_orient is never fed back, :293-301): one pass, one dropout draw."""
         if is_train:
-            raise NotImplementedError('inference-only this round')
+            return self._forward_train(x, cam_rotmat, local_orient)
+        with torch.no_grad():
+            return self._forward_eval(x, cam_rotmat, local_orient, xc, raw)
+
+    def _forward_train(self, x, cam_rotmat, local_orient):
+        from ..train.heads_autograd import LinearFn
+        B = x.shape[0]
+        rot6 = cam_rotmat.detach()[:, :, :2].reshape(B, 6)                             # rotmat_to_rot6d (geometry.py:275-286); cam_rotmat is detached (whmr.py:509-524)
+        lo = local_orient.reshape(B, -1)
+        xc = torch.cat([x, rot6.to(x.dtype), lo], dim=1)
+        h = self.drop1(LinearFn.apply(xc, self.fc1.weight, self.fc1.bias))
+        h = self.drop2(LinearFn.apply(h, self.fc2.weight, self.fc2.bias))
+        return (LinearFn.apply(h, self.decrot.weight, self.decrot.bias) + lo).reshape(-1, 1, 3, 3)
+
+    def _forward_eval(self, x, cam_rotmat, local_orient, xc=None, raw=False):
         B, dev = cam_rotmat.shape[0], cam_rotmat.device
         if xc is None:
             xc = torch.empty(B, 2149 + 6 + 9, dtype=torch.float32, device=dev)

@@ -17,6 +17,7 @@ import torch
 import os
 
 from .. import _lib as L
+from ..parallel import sync_bn
 
 USE_TN = os.environ.get('WHMR_TN_GEMM', '1') != '0'      # weight gradients on the gathering TN kernel (A/B switch)
 
@@ -63,20 +64,27 @@ def deconv_forward_train(x_nhwc, weight, gamma, beta, bn, dt, update_running=Tru
     z2 = z.view(-1, Cout)
     track = update_running and bn.track_running_stats and bn.running_mean is not None
     assert not track or bn.momentum is not None, 'cumulative-average BatchNorm (momentum=None) is not used by W-HMR (BN_MOMENTUM = 0.1)'
+    sg = sync_bn.sync_of(bn)
+    if sg is not None:
+        # SyncBatchNorm (core/trainer.py:83): the statistics of ALL ranks' rows -- one packed fp64 all-reduce between the two halves of bn_stats
+        y2, stats, count = sync_bn.bn_relu_forward(z2, gamma.detach(), beta.detach(), bn, track, sg)
+        if track and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked += 1
+        return y2.view_as(z), (x_nhwc, z, stats, sg, count)
     stats = L.bn_stats(z2, gamma.detach(), beta.detach(), bn.eps, bn.momentum if track else 0.0,
                        bn.running_mean if track else None, bn.running_var if track else None)
     if track and bn.num_batches_tracked is not None:
         bn.num_batches_tracked += 1
     y = torch.empty_like(z)
     L.bn_apply_relu(z2, stats, y.view(-1, Cout))
-    return y, (x_nhwc, z, stats)
+    return y, (x_nhwc, z, stats, None, None)
 
 
 @torch.no_grad()
 def deconv_backward(saved, weight, dy, dt, need_dx=True, dx_dtype=None, dx_into=None):
     """dy [B,2H,2W,Cout] (dt or fp32) -> (dx [B,H,W,Cin] or None, dW [Cin,Cout,4,4] fp32, dgamma [Cout], dbeta [Cout]).
     ``dx_into`` [B,H,W,Cin] (contiguous, the dx dtype): the data gradient is ADDED to it in the GEMM epilogue and it is returned as dx."""
-    x, z, stats = saved
+    x, z, stats, sg, count = saved
     B, H, W, Cin = x.shape
     Cout = z.shape[-1]
     dev = x.device
@@ -85,7 +93,10 @@ def deconv_backward(saved, weight, dy, dt, need_dx=True, dx_dtype=None, dx_into=
         dy = dy.to(dt)
     dz = torch.empty_like(z)
     dg, db = torch.empty(Cout, dtype=torch.float32, device=dev), torch.empty(Cout, dtype=torch.float32, device=dev)
-    L.bn_relu_bwd(z.view(-1, Cout), dy.view(-1, Cout), stats, dz.view(-1, Cout), dg, db)
+    if sg is not None:
+        sync_bn.bn_relu_backward(z.view(-1, Cout), dy.view(-1, Cout), stats, count, dz.view(-1, Cout), dg, db, sg)
+    else:
+        L.bn_relu_bwd(z.view(-1, Cout), dy.view(-1, Cout), stats, dz.view(-1, Cout), dg, db)
     M = B * H * W
     # dW[ci, (ky,kx,co)] = sum_m x[m, ci] * dz[b, 2iy-1+ky, 2ix-1+kx, co]
     pad = 64 if dt == torch.bfloat16 else 8          # the bf16 GEMM needs K % 64 == 0; rows are zero-padded up to it

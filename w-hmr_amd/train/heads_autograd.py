@@ -129,6 +129,25 @@ class AttentionF32Fn(torch.autograd.Function):
         return L.attention_bwd_f32(qkv, _f32(dout), B, N, H, d, scale), None, None, None, None, None
 
 
+class MatToAAFn(torch.autograd.Function):
+    """aa [n, 3] = MatToAAFn.apply(R [n, 9] | [n, 3, 3]): rotation_matrix_to_angle_axis (utils/geometry.py:54-83) with its backward
+    (whmr_mat_to_aa / whmr_mat_to_aa_bwd) -- where the reference's training graph carries it: theta's pose (whmr.py:174), global_pose (:632-633)."""
+
+    @staticmethod
+    def forward(ctx, R):
+        if not R.is_cuda:
+            raise RuntimeError('whmr_amd runs on a HIP device only (no CPU fallback)')
+        Rm = _f32(R.detach().reshape(-1, 9))
+        ctx.saved, ctx.shape = Rm, R.shape
+        return L.mat_to_aa(Rm)
+
+    @staticmethod
+    def backward(ctx, d_aa):
+        Rm = ctx.saved
+        ctx.saved = None
+        return L.mat_to_aa_bwd(Rm, _f32(d_aa)).view(ctx.shape)
+
+
 def _padded_base(dy, M, npad, dt):
     """A producer that already holds the gradient of a ConvNHWCFn output as the zero-padded [M, npad] matrix (IUVLossFn: csrc/iuv_loss.hip writes it
     that way) returns the [..., :Cout] VIEW of it; the convolution's backward then takes the whole buffer from the view's base and skips the
