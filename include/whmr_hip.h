@@ -206,7 +206,8 @@ int whmr_cast_f32_bf16(const float* src, void* dst, long n, void* stream);
  * in the parity mode), VALU kernel for any other d / N <= 256 (the 5-token timm Block of the Tz head). */
 int whmr_attention(const void* qkv, void* out, int B, int N, int H, int d, float scale, int is_bf16, void* stream);
 /* A/B switches: bit 0: 1 = chunked online-softmax bf16 variant (2 workgroups / CU, default), 0 = single pass; bits 1-2: timing ablations of the
- * blocked kernel (wrong results); bit 3 set: fp32 attention always on the VALU kernel. */
+ * round-2 blocked kernel (wrong results); bit 3 set: fp32 attention always on the VALU kernel; bit 4 set: whmr_attention_blk on the round-2 kernel
+ * (one workgroup per (image, head), 32-row tiles) instead of the persistent 16-row-tile kernel. */
 int whmr_attention_set_variant(int chunked);
 
 /* ---- rotation / projection helpers: utils/geometry.py ------------------------------------------------------------ */

@@ -22,7 +22,12 @@ for N in (196, 192):
         print('N=%d row-major %s: %.1f us' % (N, 'chunked' if var else 'single-pass', timeit(lambda: L.attention(qkv, att, B, N, 12, 64, 0.125))))
     qb = L.to_blocked(qkv.view(B * N, 2304))
     ob = torch.empty((B * N + 31) // 32, 96, 32, 8, device=dev, dtype=torch.bfloat16)
-    for var, name in ((1, 'full'), (1 | 4, 'staging only (no key loop)'), (1 | 2, 'key loop only (no staging)'), (1 | 2 | 4, 'neither (launch + Q load + store)')):
+    L.attention_set_variant(1)
+    print('N=%d blocked, persistent 16-row-tile kernel (round 5): %.1f us' % (N, timeit(lambda: L.attention_blk(qb, ob, B, N, 12, 0.125))))
+    for var, name in ((1 | 2, 'no operand traffic after the first item'), (1 | 4, 'no arithmetic after the first item'), (1 | 2 | 4, 'neither')):
+        L.attention_set_variant(var)
+        print('N=%d blocked, persistent kernel, %s: %.1f us' % (N, name, timeit(lambda: L.attention_blk(qb, ob, B, N, 12, 0.125))))
+    for var, name in ((1 | 16, 'round-2 kernel, full'), (1 | 16 | 4, 'round-2 kernel, staging only (no key loop)'), (1 | 16 | 2, 'round-2 kernel, key loop only (no staging)'), (1 | 16 | 2 | 4, 'round-2 kernel, neither (launch + Q load + store)')):
         L.attention_set_variant(var)
         print('N=%d blocked %s: %.1f us' % (N, name, timeit(lambda: L.attention_blk(qb, ob, B, N, 12, 0.125))))
 L.attention_set_variant(1)

@@ -838,7 +838,10 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
 static int g_attn_chunked = 1;      // whmr_attention_set_variant: bit 0: 1 = chunked online-softmax kernel (default), 0 = single pass
 static int g_attn_abl = 0;          // bits 1-2 (timing probes only, wrong results): 2 = skip the K / V staging, 4 = skip the key loop
 static int g_attn_f32_mfma = 1;     // bit 3 SET switches the fp32 attention back to the VALU kernel (A/B, tests)
-extern "C" int whmr_attention_set_variant(int v) { g_attn_chunked = v & 1; g_attn_abl = v & 6; g_attn_f32_mfma = !(v & 8); return 0; }
+static int g_attn_blk_old = 0;      // bit 4 SET: the blocked bf16 attention on the round-2 kernel (one workgroup per (image, head), 32-row tiles) instead of
+                                    // the persistent 16-row-tile kernel of attention_blk16.hip (A/B, tests)
+extern "C" int whmr_attention_set_variant(int v) { g_attn_chunked = v & 1; g_attn_abl = v & 6; g_attn_f32_mfma = !(v & 8); g_attn_blk_old = (v >> 4) & 1; return 0; }
+int whmr_attention_blk16_launch(const void* qkv, void* out, int B, int N, int H, float scale, hipStream_t st, int abl);      // attention_blk16.hip
 
 template <int NKT>
 static int launch_bf16(const void* qkv, void* out, int B, int N, int H, float scale, hipStream_t st, float* lse = nullptr) {
@@ -868,6 +871,7 @@ static int launch_bf16_blk(const void* qkv, void* out, int B, int N, int H, floa
 extern "C" int whmr_attention_blk(const void* qkv, void* out, int B, int N, int H, float scale, void* stream) {
     if (B <= 0 || N <= 64 || N > 256 || H <= 0 || scale <= 0.f) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
+    if (!g_attn_blk_old && N <= 240) return whmr_attention_blk16_launch(qkv, out, B, N, H, scale, st, g_attn_abl);
     switch ((N + 31) / 32) {
         case 3: return launch_bf16_blk<3>(qkv, out, B, N, H, scale, st);
         case 4: return launch_bf16_blk<4>(qkv, out, B, N, H, scale, st);
