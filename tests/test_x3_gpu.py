@@ -118,11 +118,14 @@ def test_patch_im2col_blk_x3(dev):
     assert not L.from_blocked(lo, 64)[M:].any() and not L.from_blocked(hi, 64)[M:].any()
 
 
-@pytest.mark.parametrize('N', [196, 192, 100, 256])
-def test_attention_blk_x3(dev, N):
+@pytest.mark.parametrize('N,B', [(196, 3), (192, 3), (100, 3), (256, 3), (65, 2), (208, 2), (196, 64), (192, 27)])
+def test_attention_blk_x3(dev, N, B):
+    """split-bf16 attention (round 5: the persistent 16-row-tile kernel for N <= 208, csrc/attention_blk16.hip; the round-3 kernel above that)
+    against float64 on the same fp32 inputs -- fp32-grade -- and against the round-3 kernel; B = 64 / 27: three / one-or-two items per workgroup
+    (the staged prefetch of the next item's K / Q and V)."""
     from whmr_amd import _lib as L
     g = torch.Generator().manual_seed(N)
-    B, H, d = 3, 12, 64
+    H, d = 12, 64
     qkv = torch.randn(B, N, 3, H, d, generator=g) * 1.5
     q, k, v = qkv.double().permute(2, 0, 3, 1, 4)
     ref = ((q * d ** -0.5) @ k.transpose(-2, -1)).softmax(-1) @ v
@@ -131,9 +134,20 @@ def test_attention_blk_x3(dev, N):
     oh = torch.full((qh.shape[0], H * d // 8, 32, 8), float('nan'), device=dev, dtype=torch.bfloat16)
     ol = torch.full_like(oh, float('nan'))
     L.attention_blk(qh, oh, B, N, H, d ** -0.5, qkv_lo=ql, out_lo=ol)
-    err = _rel(_join(L, oh, ol, B * N), ref)
-    print('x3 attention N=%d max-rel %.2e' % (N, err))
+    got = _join(L, oh, ol, B * N)
+    err = _rel(got, ref)
+    print('x3 attention N=%d B=%d max-rel %.2e' % (N, B, err))
     assert err < 2e-5
+    oh2, ol2 = torch.full_like(oh, float('nan')), torch.full_like(oh, float('nan'))
+    L.attention_x3_set_variant(1)
+    try:
+        L.attention_blk(qh, oh2, B, N, H, d ** -0.5, qkv_lo=ql, out_lo=ol2)
+    finally:
+        L.attention_x3_set_variant(0)
+    assert _rel(got, _join(L, oh2, ol2, B * N)) < 2e-5
+    oh3, ol3 = torch.full_like(oh, float('nan')), torch.full_like(oh, float('nan'))
+    L.attention_blk(qh, oh3, B, N, H, d ** -0.5, qkv_lo=ql, out_lo=ol3)
+    assert torch.equal(L.from_blocked(oh3, B * N), L.from_blocked(oh, B * N)) and torch.equal(L.from_blocked(ol3, B * N), L.from_blocked(ol, B * N))     # deterministic
 
 
 def test_gemm_epilogue_writes_the_split3_operand_form(dev):

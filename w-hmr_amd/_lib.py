@@ -91,6 +91,7 @@ _SIGS = {
     'whmr_layernorm_blk_mean': [_P, _P, _P, _P, _P, _I, _I, _F, _P],
     'whmr_patch_im2col_blk_x3': [_P, _P, _P, _I, _I, _I, _I, _I, _I, _L, _L, _L, _L, _P],
     'whmr_attention_blk_x3': [_P, _P, _P, _P, _I, _I, _I, _F, _P],
+    'whmr_attention_x3_set_variant': [_I],
     'whmr_attention_set_variant': [_I],
     'whmr_layernorm': [_P, _P, _P, _P, _I, _I, _F, _I, _P],
     'whmr_patch_im2col': [_P, _P, _I, _I, _I, _I, _I, _I, _L, _L, _L, _L, _I, _P],
@@ -973,9 +974,15 @@ def crop_normalize(frame, inv_affine, patch_w, patch_h, x0, x1, out, raw, mean, 
     return out
 
 
+def attention_x3_set_variant(old_kernel):
+    """1 = the round-3 split-bf16 attention kernel for every N (A/B, tests); 0 = the persistent 16-row-tile kernel where it applies (N <= 208)"""
+    _check(lib().whmr_attention_x3_set_variant(int(old_kernel)), 'whmr_attention_x3_set_variant')
+
+
 def attention_set_variant(chunked):
-    """bit 0: 1 = chunked online-softmax bf16 attention kernel (default), 0 = single-pass kernel; bits 1-2: timing ablations of the blocked kernel
-    (wrong results); bit 3 set: fp32 attention on the VALU kernel instead of the matrix-pipe one (A/B measurements, tests)."""
+    """bit 0: 1 = chunked online-softmax bf16 attention kernel (default), 0 = single-pass kernel; bits 1-2: timing ablations of the blocked kernels
+    (wrong results); bit 3 set: fp32 attention on the VALU kernel instead of the matrix-pipe one; bit 4 set: the blocked bf16 attention on the
+    round-2 kernel instead of the persistent 16-row-tile one (A/B measurements, tests)."""
     _check(lib().whmr_attention_set_variant(int(chunked)), 'whmr_attention_set_variant')
 
 

@@ -25,6 +25,7 @@
 //   * O^T accumulators: lane = query, 4 consecutive d per d tile; pairs of lane groups exchange halves (v_permlane16_swap) and every lane
 //     stores one whole 16-B piece of the blocked output.  Rows past N of the last query tile recompute row N - 1 (clamped loads) and store the
 //     same bytes to the same place: no exec-masked store, so the count of stores a wave has in flight at the item boundary is a constant.
+#include <type_traits>
 #include "common.h"
 
 #define LOG2E 1.4426950408889634f
@@ -67,6 +68,16 @@ template <int CNT> __device__ __forceinline__ void att_wait_lds(bf16x8_t (&f)[4]
 template <int CNT> __device__ __forceinline__ void att_wait_tr(uint2 (&f)[8]) {
     asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]) : "n"(CNT));
 }
+// compile-time loop: the body receives std::integral_constant<int, I>, so tile indices can be folded into the LDS instructions' immediate offsets
+// (ONE address register per image instead of one per tile: as run-time offsets they cost ~30 VGPRs and, in the split-bf16 kernel, spills)
+template <int I, int N, class F> __device__ __forceinline__ void att_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        att_static_for<I + 1, N>(f);
+    }
+}
+#define ATT_IC(name, ic) constexpr int name = decltype(ic)::value
+
 // lab instrumentation (tools/attn_stamps.py; never defined in the product build): s_memtime per wave and item of workgroup ATT16_STAMP_WG at the phase
 // boundaries -> a device buffer set by whmr_debug_att16_stamps
 #ifdef ATT16_STAMPS
@@ -137,31 +148,30 @@ __global__ __launch_bounds__((NQT + att16_cfg<NQT>::NL) * 64) void attention_blk
         const uint32_t ka = kb + (g * KP + c) * 16;
         constexpr int NP = (NQT + 1) / 2;                                // key-tile pairs
         bf16x8_t kf[3][4];                                               // [set][tile 0 half 0 | tile 0 half 1 | tile 1 half 0 | tile 1 half 1]
-        auto kread = [&](bf16x8_t (&f)[4], int kt) {                     // kt is a constant after unrolling
-            f[0] = att_read128<0>(ka + kt * 256);
-            f[1] = att_read128<4 * KP * 16>(ka + kt * 256);
-            if (kt + 1 < NQT) {
-                f[2] = att_read128<256>(ka + kt * 256);
-                f[3] = att_read128<4 * KP * 16 + 256>(ka + kt * 256);
+        auto kread = [&](bf16x8_t (&f)[4], auto kt_) {
+            ATT_IC(kt, kt_);
+            f[0] = att_read128<kt * 256>(ka);
+            f[1] = att_read128<4 * KP * 16 + kt * 256>(ka);
+            if constexpr (kt + 1 < NQT) {
+                f[2] = att_read128<kt * 256 + 256>(ka);
+                f[3] = att_read128<4 * KP * 16 + kt * 256 + 256>(ka);
             } else {
                 f[2] = f[0]; f[3] = f[1];
             }
         };
-        auto kcount = [](int pr) { return pr < NP ? (2 * pr + 1 < NQT ? 4 : 2) : 0; };      // reads of pair pr
-        kread(kf[0], 0);
-        if (NP > 1) kread(kf[1], 2);
-#pragma unroll
-        for (int pr = 0; pr < NP; ++pr) {
-            const int kt = 2 * pr, cur = pr % 3;
-            if (pr + 2 < NP) kread(kf[(pr + 2) % 3], kt + 4);
-            const int young = kcount(pr + 1) + kcount(pr + 2);           // reads issued after this pair's
-            if (young == 8) att_wait_lds<8>(kf[cur]); else if (young == 6) att_wait_lds<6>(kf[cur]); else if (young == 4) att_wait_lds<4>(kf[cur]);
-            else if (young == 2) att_wait_lds<2>(kf[cur]); else att_wait_lds<0>(kf[cur]);
+        kread(kf[0], std::integral_constant<int, 0>{});
+        if constexpr (NP > 1) kread(kf[1], std::integral_constant<int, 2>{});
+        att_static_for<0, NP>([&](auto pr_) {
+            ATT_IC(pr, pr_);
+            constexpr int kt = 2 * pr, cur = pr % 3;
+            if constexpr (pr + 2 < NP) kread(kf[(pr + 2) % 3], std::integral_constant<int, kt + 4>{});
+            constexpr int c1 = pr + 1 < NP ? (2 * (pr + 1) + 1 < NQT ? 4 : 2) : 0, c2 = pr + 2 < NP ? (2 * (pr + 2) + 1 < NQT ? 4 : 2) : 0;
+            att_wait_lds<c1 + c2>(kf[cur]);                              // reads issued after this pair's
             s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[cur][0], q[0], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-            if (kt + 1 < NQT) s[kt + 1 < NQT ? kt + 1 : kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[cur][2], q[0], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            if constexpr (kt + 1 < NQT) s[kt + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[cur][2], q[0], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
             s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[cur][1], q[1], s[kt], 0, 0, 0);
-            if (kt + 1 < NQT) s[kt + 1 < NQT ? kt + 1 : kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[cur][3], q[1], s[kt + 1 < NQT ? kt + 1 : kt], 0, 0, 0);
-        }
+            if constexpr (kt + 1 < NQT) s[kt + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[cur][3], q[1], s[kt + 1], 0, 0, 0);
+        });
         ATT_STAMP(it, 2);
         // softmax over the keys of query c.  Four independent chains (the register index r) for the maximum and the sum instead of one chain of 4 NQT
         // dependent operations; the exchanges across the four lane groups are v_permlane16_swap / v_permlane32_swap of two copies (VALU, no LDS
@@ -212,23 +222,24 @@ __global__ __launch_bounds__((NQT + att16_cfg<NQT>::NL) * 64) void attention_blk
         const uint32_t va = vb + ((((c & 3) >> 1) * VP + 4 * g + (c >> 2)) * 16 + 8 * (c & 1));
         uint2 vr[2][8];                                                   // two sets: [set][2 dt + (keys 32 j + 4 g .. | + 16)].  (A ring of three = 24 reads
         // in flight is past what the 4-bit lgkmcnt field can express -- lgkmcnt(15) with 16 younger reads measured WRONG results, non-deterministically.)
-        auto vread = [&](uint2 (&f)[8], int j) {
-            f[0] = att_read_tr<0>(va + j * 512);               f[1] = att_read_tr<256>(va + j * 512);
-            f[2] = att_read_tr<2 * VP * 16>(va + j * 512);     f[3] = att_read_tr<2 * VP * 16 + 256>(va + j * 512);
-            f[4] = att_read_tr<4 * VP * 16>(va + j * 512);     f[5] = att_read_tr<4 * VP * 16 + 256>(va + j * 512);
-            f[6] = att_read_tr<6 * VP * 16>(va + j * 512);     f[7] = att_read_tr<6 * VP * 16 + 256>(va + j * 512);
+        auto vread = [&](uint2 (&f)[8], auto j_) {
+            ATT_IC(j, j_);
+            f[0] = att_read_tr<j * 512>(va);                    f[1] = att_read_tr<j * 512 + 256>(va);
+            f[2] = att_read_tr<2 * VP * 16 + j * 512>(va);      f[3] = att_read_tr<2 * VP * 16 + j * 512 + 256>(va);
+            f[4] = att_read_tr<4 * VP * 16 + j * 512>(va);      f[5] = att_read_tr<4 * VP * 16 + j * 512 + 256>(va);
+            f[6] = att_read_tr<6 * VP * 16 + j * 512>(va);      f[7] = att_read_tr<6 * VP * 16 + j * 512 + 256>(va);
         };
-        vread(vr[0], 0);
-#pragma unroll
-        for (int j = 0; j < NK2; ++j) {
-            const int cur = j & 1;
+        vread(vr[0], std::integral_constant<int, 0>{});
+        att_static_for<0, NK2>([&](auto j_) {
+            ATT_IC(j, j_);
+            constexpr int cur = j & 1;
             union { bf16x8_t v; uint32_t u[4]; } pf;
             pf.u[0] = pk[2 * j][0];
             pf.u[1] = pk[2 * j][1];
-            pf.u[2] = (2 * j + 1 < NQT) ? pk[2 * j + 1 < NQT ? 2 * j + 1 : 0][0] : 0u;
-            pf.u[3] = (2 * j + 1 < NQT) ? pk[2 * j + 1 < NQT ? 2 * j + 1 : 0][1] : 0u;
-            if (j + 1 < NK2) {
-                vread(vr[cur ^ 1], j + 1);
+            if constexpr (2 * j + 1 < NQT) { pf.u[2] = pk[2 * j + 1][0]; pf.u[3] = pk[2 * j + 1][1]; }
+            else { pf.u[2] = pf.u[3] = 0u; }
+            if constexpr (j + 1 < NK2) {
+                vread(vr[cur ^ 1], std::integral_constant<int, j + 1>{});
                 att_wait_tr<8>(vr[cur]);
             } else {
                 att_wait_tr<0>(vr[cur]);
@@ -240,7 +251,7 @@ __global__ __launch_bounds__((NQT + att16_cfg<NQT>::NL) * 64) void attention_blk
                 vf.h[1] = vr[cur][2 * dt + 1];
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf.v, o[dt], 0, 0, 0);
             }
-        }
+        });
         ATT_STAMP(it, 4);
         // store: lane (g, c) holds d = 16 dt + 4 g + (0..3) = half of the 16-B piece 2 dt + (g >> 1).  Even groups complete the piece of dt = 2 t
         // with their odd neighbour's half, odd groups the piece of dt = 2 t + 1 with their even neighbour's (v_permlane16_swap exchanges the odd
@@ -308,6 +319,260 @@ __global__ __launch_bounds__((NQT + att16_cfg<NQT>::NL) * 64) void attention_blk
     }
 }
 
+// =====================================================================================================================================
+// The same kernel for the "bf16x3" (split-bf16) numerics: every operand a hi / lo bf16 pair, every product three MFMAs (hi.hi + hi.lo + lo.hi,
+// fp32 accumulate) -- replaces attention_x3_blk_kernel (attention_x3.hip: one workgroup per (image, head) and CU, load -> stage -> compute ->
+// store in series, 3 rounds of 768 workgroups: 62 us at N = 196, batch 64) for N <= 208.
+// LDS holds ONE set of images (K, V, Q as hi + lo pairs = 158 KiB at N = 196), so the prefetch is staged by operand instead of by item:
+//   A  K(i), Q(i) in LDS          -> Q fragments to registers, S^T = K Q^T (18 -> 6 MFMAs per key tile)
+//   B  everybody done with K, Q   -> the loaders request K(i + 1), Q(i + 1); softmax, P split into hi / lo
+//   C  V(i) in LDS                -> O^T = V^T P^T
+//   D  everybody done with V      -> the loaders request V(i + 1); store O as a hi / lo pair
+// so K / Q of the next item stream in under the softmax and P V, V under S^T and the softmax.  Every loader issues the SAME number of pieces per
+// stage (the surplus re-requests the stage's last piece): its counted vmcnt waits are then compile-time constants.
+// V image: VP = KP + 8 rows per chunk (= 8 mod 16, see the header); for an odd number of key tiles the last P V step's second half (zero
+// probabilities) re-reads the first half's rows instead of rows the image does not have.
+template <int NQT>
+struct att16x3_cfg {
+    static constexpr int NK2 = (NQT + 1) / 2, KP = NQT * 16, VP = KP + 8;
+    static constexpr int KB = 8 * KP * 16, VB = 8 * VP * 16;
+    static constexpr int K_OFF = 0, V_OFF = 2 * KB, Q_OFF = 2 * KB + 2 * VB, LDS = 4 * KB + 2 * VB;
+    static constexpr int KI = 8 * KP / 64, VI = 8 * VP / 64;                 // wave instructions per image
+    static constexpr int NL = (16 - NQT) < 3 ? (16 - NQT) : 3;
+    static constexpr int TOT_KQ = 4 * KI, TOT_V = 2 * VI;
+    static constexpr int CNT_KQ = (TOT_KQ + NL - 1) / NL, CNT_V = (TOT_V + NL - 1) / NL;      // pieces per loader and stage
+    static_assert(NL >= 1 && LDS <= 160 * 1024 && CNT_KQ <= 63 && CNT_V <= 63, "");
+};
+
+template <int CNT> __device__ __forceinline__ void att_wait_tr4(uint2 (&f)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : "n"(CNT));
+}
+
+template <int NQT>
+__global__ __launch_bounds__((NQT + att16x3_cfg<NQT>::NL) * 64) void attention_blk16_x3_kernel(const bf16_t* __restrict__ qkv_hi, const bf16_t* __restrict__ qkv_lo,
+                                                                                            bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo,
+                                                                                            int items, int N, int H, float scale) {
+    using cfg = att16x3_cfg<NQT>;
+    constexpr int NK2 = cfg::NK2, KP = cfg::KP, VP = cfg::VP;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, c = lane & 15;
+    const int C = H * 64, ld8 = (3 * C) >> 3, oc8 = C >> 3;
+    int item = blockIdx.x;
+    if (item >= items) return;
+
+    if (wave >= NQT) {
+        // ---- loaders
+        const int l = wave - NQT;
+        // stage K + Q: instruction index x in [0, TOT_KQ): image x / KI = K hi | K lo | Q hi | Q lo, instruction x % KI of it
+        auto issue_kq = [&](int it) {
+            const int b = it / H, h = it - b * H, m_img = b * N;
+#pragma unroll 1
+            for (int i = 0; i < cfg::CNT_KQ; ++i) {
+                int x = l + i * cfg::NL;
+                x = x < cfg::TOT_KQ ? x : cfg::TOT_KQ - 1;
+                const int img = x / cfg::KI, ii = x - img * cfg::KI;
+                const int p = ii * 64 + lane;
+                const int chunk = p / KP;
+                int row = p - chunk * KP;
+                row = row < N ? row : N - 1;
+                const char* base = (const char*)((img & 1) ? qkv_lo : qkv_hi);
+                const char* src = base + att_piece(m_img + row, ((img < 2 ? C : 0) >> 3) + h * 8 + chunk, ld8);
+                char* dst = smem + (img < 2 ? cfg::K_OFF + img * cfg::KB : cfg::Q_OFF + (img - 2) * cfg::KB) + ii * 1024;
+                __builtin_amdgcn_global_load_lds((att_gbl_void_t*)src, (att_lds_void_t*)dst, 16, 0, 0);
+            }
+        };
+        auto issue_v = [&](int it) {
+            const int b = it / H, h = it - b * H, m_img = b * N;
+#pragma unroll 1
+            for (int i = 0; i < cfg::CNT_V; ++i) {
+                int x = l + i * cfg::NL;
+                x = x < cfg::TOT_V ? x : cfg::TOT_V - 1;
+                const int img = x / cfg::VI, ii = x - img * cfg::VI;
+                const int p = ii * 64 + lane;
+                const int chunk = p / VP;
+                int row = p - chunk * VP;
+                row = row < N ? row : N - 1;
+                const char* base = (const char*)(img ? qkv_lo : qkv_hi);
+                const char* src = base + att_piece(m_img + row, ((2 * C) >> 3) + h * 8 + chunk, ld8);
+                char* dst = smem + cfg::V_OFF + img * cfg::VB + ii * 1024;
+                __builtin_amdgcn_global_load_lds((att_gbl_void_t*)src, (att_lds_void_t*)dst, 16, 0, 0);
+            }
+        };
+        issue_kq(item);
+        issue_v(item);
+        for (;;) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(cfg::CNT_V) : "memory");       // K, Q of `item` have landed (its V may still fly)
+            __builtin_amdgcn_s_barrier();                                            // A
+            __builtin_amdgcn_s_barrier();                                            // B
+            const int next = item + gridDim.x;
+            const bool more = next < items;
+            if (more) {
+                issue_kq(next);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(cfg::CNT_KQ) : "memory");  // V of `item` has landed (K, Q of the next item may fly)
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();                                            // C
+            __builtin_amdgcn_s_barrier();                                            // D
+            if (!more) break;
+            issue_v(next);
+            item = next;
+        }
+        return;
+    }
+
+    // ---- compute waves: wave = query tile
+    const float sc = scale * LOG2E;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(att_lds_void_t*)smem;
+    const uint32_t ka = lds0 + cfg::K_OFF + (g * KP + c) * 16;
+    const uint32_t qa = lds0 + cfg::Q_OFF + (g * KP + 16 * wave + c) * 16;
+    const uint32_t va = lds0 + cfg::V_OFF + ((((c & 3) >> 1) * VP + 4 * g + (c >> 2)) * 16 + 8 * (c & 1));
+    for (;;) {
+        __builtin_amdgcn_s_barrier();                                                // A
+        bf16x8_t q[4];                                                               // hi half 0 | hi half 1 | lo half 0 | lo half 1
+        q[0] = att_read128<0>(qa);
+        q[1] = att_read128<4 * KP * 16>(qa);
+        q[2] = att_read128<cfg::KB>(qa);
+        q[3] = att_read128<cfg::KB + 4 * KP * 16>(qa);
+        att_wait_lds<0>(q);
+        // S^T = K Q^T with split operands: per key tile and d half k_lo q_hi + k_hi q_lo + k_hi q_hi.  Ring of three sets, one key tile each
+        // (4 reads: hi / lo x two halves): two tiles' reads in flight under the 6 MFMAs of this one.
+        f32x4_t s[NQT];
+        bf16x8_t kf[3][4];                                                           // [set][hi half 0 | hi half 1 | lo half 0 | lo half 1]
+        auto kread = [&](bf16x8_t (&f)[4], auto kt_) {
+            ATT_IC(kt, kt_);
+            f[0] = att_read128<kt * 256>(ka);
+            f[1] = att_read128<4 * KP * 16 + kt * 256>(ka);
+            f[2] = att_read128<cfg::KB + kt * 256>(ka);
+            f[3] = att_read128<cfg::KB + 4 * KP * 16 + kt * 256>(ka);
+        };
+        // ring depth: three sets (two key tiles of reads in flight) where the registers allow it, two at 13 query tiles (128-register budget of 16 waves)
+        constexpr int KR = NQT >= 13 ? 2 : 3;
+        kread(kf[0], std::integral_constant<int, 0>{});
+        if constexpr (KR == 3 && NQT > 1) kread(kf[1], std::integral_constant<int, 1>{});
+        att_static_for<0, NQT>([&](auto kt_) {
+            ATT_IC(kt, kt_);
+            constexpr int cur = kt % KR, ahead = KR - 1;
+            if constexpr (kt + ahead < NQT) kread(kf[(kt + ahead) % KR], std::integral_constant<int, kt + ahead>{});
+            constexpr int young = (kt + ahead < NQT ? ahead : (NQT - 1 - kt)) * 4;
+            att_wait_lds<young>(kf[cur]);
+            f32x4_t a = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[cur][2], q[0], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[cur][3], q[1], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[cur][0], q[2], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[cur][1], q[3], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[cur][0], q[0], a, 0, 0, 0);
+            s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[cur][1], q[1], a, 0, 0, 0);
+        });
+        __builtin_amdgcn_s_barrier();                                                // B: K and Q may be overwritten
+        // softmax (as in the bf16 kernel), probabilities split into hi / lo
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if ((NQT - 1) * 16 + 4 * g + r >= N) s[NQT - 1][r] = -INFINITY;
+        f32x4_t m4 = s[0];
+#pragma unroll
+        for (int kt = 1; kt < NQT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m4[r] = fmaxf(m4[r], s[kt][r]);
+        float mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+        {
+            const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            mx = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+            const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            mx = fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+        }
+        const float mxs = mx * sc;
+        f32x4_t sum4 = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        uint32_t ph[NQT][2], pl[NQT][2];
+#pragma unroll
+        for (int kt = 0; kt < NQT; ++kt) {
+            const f32x4_t t = s[kt] * sc - mxs;
+            f32x4_t e;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(t[r]);
+            sum4 += e;
+            split_bf16x2(e[0], e[1], ph[kt][0], pl[kt][0]);
+            split_bf16x2(e[2], e[3], ph[kt][1], pl[kt][1]);
+        }
+        float sum = (sum4[0] + sum4[1]) + (sum4[2] + sum4[3]);
+        {
+            const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(sum), __float_as_uint(sum), false, false);
+            sum = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+            const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(sum), __float_as_uint(sum), false, false);
+            sum = __uint_as_float(b[0]) + __uint_as_float(b[1]);
+        }
+        const float inv = 1.0f / sum;
+        __builtin_amdgcn_s_barrier();                                                // C: V is in LDS
+        // O^T = V^T P^T with split operands: per (key pair j, d tile) v_lo p_hi + v_hi p_lo + v_hi p_hi.  Ring of three sets, one d tile each
+        // (4 transposing reads: hi / lo x the two 4-key groups)
+        f32x4_t o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        uint2 vr[3][4];                                                              // [set][hi keys .. | hi keys + 16 | lo keys .. | lo keys + 16]
+        auto vread = [&](uint2 (&f)[4], auto u_) {                                   // unit u = 4 j + dt
+            ATT_IC(u, u_);
+            constexpr int j = u >> 2, dt = u & 3;
+            constexpr bool wrap = 2 * j + 1 >= NQT;                                  // the second 16 keys of the last step do not exist: zero probabilities
+            constexpr int off = j * 512 + dt * (2 * VP * 16);
+            f[0] = att_read_tr<off>(va);
+            f[2] = att_read_tr<cfg::VB + off>(va);
+            f[1] = att_read_tr<off + (wrap ? 0 : 256)>(va);
+            f[3] = att_read_tr<cfg::VB + off + (wrap ? 0 : 256)>(va);
+        };
+        constexpr int NU = 4 * NK2;
+        vread(vr[0], std::integral_constant<int, 0>{});
+        vread(vr[1], std::integral_constant<int, 1>{});
+        att_static_for<0, NU>([&](auto u_) {
+            ATT_IC(u, u_);
+            constexpr int j = u >> 2, dt = u & 3, cur = u % 3;
+            if constexpr (u + 2 < NU) vread(vr[(u + 2) % 3], std::integral_constant<int, u + 2>{});
+            att_wait_tr4<(u + 2 < NU) ? 8 : (u + 1 < NU) ? 4 : 0>(vr[cur]);
+            union { bf16x8_t v; uint32_t w[4]; } fh, fl;
+            fh.w[0] = ph[2 * j][0]; fh.w[1] = ph[2 * j][1];
+            fl.w[0] = pl[2 * j][0]; fl.w[1] = pl[2 * j][1];
+            if constexpr (2 * j + 1 < NQT) {
+                fh.w[2] = ph[2 * j + 1][0]; fh.w[3] = ph[2 * j + 1][1];
+                fl.w[2] = pl[2 * j + 1][0]; fl.w[3] = pl[2 * j + 1][1];
+            } else {
+                fh.w[2] = fh.w[3] = fl.w[2] = fl.w[3] = 0u;
+            }
+            union { bf16x8_t v; uint2 h[2]; } vh, vl;
+            vh.h[0] = vr[cur][0]; vh.h[1] = vr[cur][1];
+            vl.h[0] = vr[cur][2]; vl.h[1] = vr[cur][3];
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl.v, fh.v, o[dt], 0, 0, 0);
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh.v, fl.v, o[dt], 0, 0, 0);
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh.v, fh.v, o[dt], 0, 0, 0);
+        });
+        __builtin_amdgcn_s_barrier();                                                // D: V may be overwritten
+        // store O as a hi / lo pair (the bf16 kernel's piece assembly, once per part)
+        const int b = item / H, h = item - b * H;
+        int qr = 16 * wave + c;
+        qr = qr < N ? qr : N - 1;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const f32x4_t oa = o[2 * t] * inv, ob = o[2 * t + 1] * inv;
+            uint32_t xa0, xa1, yb0, yb1, la0, la1, lb0, lb1;
+            split_bf16x2(oa[0], oa[1], xa0, la0);
+            split_bf16x2(oa[2], oa[3], xa1, la1);
+            split_bf16x2(ob[0], ob[1], yb0, lb0);
+            split_bf16x2(ob[2], ob[3], yb1, lb1);
+            const int dt = 2 * t + (g & 1);
+            const size_t off = att_piece(b * N + qr, h * 8 + 2 * dt + (g >> 1), oc8);
+            const auto r0 = __builtin_amdgcn_permlane16_swap(xa0, yb0, false, false);
+            const auto r1 = __builtin_amdgcn_permlane16_swap(xa1, yb1, false, false);
+            *(uint4*)((char*)out_hi + off) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+            const auto s0 = __builtin_amdgcn_permlane16_swap(la0, lb0, false, false);
+            const auto s1 = __builtin_amdgcn_permlane16_swap(la1, lb1, false, false);
+            *(uint4*)((char*)out_lo + off) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+        }
+        const int next = item + gridDim.x;
+        if (next >= items) break;
+        item = next;
+    }
+}
+
 static int att16_cus() {
     static int cus = 0;
     if (!cus) {
@@ -352,4 +617,38 @@ int whmr_attention_blk16_launch(const void* qkv, void* out, int B, int N, int H,
         case 15: return att16_launch<15>(qkv, out, B, N, H, scale, st, abl);
     }
     return -1;                  // N > 240: 16 query tiles + the loader wave exceed 1024 threads -- the caller keeps the round-2 kernel
+}
+
+template <int NQT>
+static int att16x3_launch(const void* qh, const void* ql, void* oh, void* ol, int B, int N, int H, float scale, hipStream_t st) {
+    using cfg = att16x3_cfg<NQT>;
+    auto kern = attention_blk16_x3_kernel<NQT>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, cfg::LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    const int items = B * H;
+    const int cus = att16_cus();
+    const int grid = items < cus ? items : cus;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3((NQT + cfg::NL) * 64), cfg::LDS, st, (const bf16_t*)qh, (const bf16_t*)ql, (bf16_t*)oh, (bf16_t*)ol, items, N, H, scale);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+// called by whmr_attention_blk_x3 (attention_x3.hip) for 64 < N <= 208; -1 = not covered (the caller keeps its own kernel)
+int whmr_attention_blk16_x3_launch(const void* qh, const void* ql, void* oh, void* ol, int B, int N, int H, float scale, hipStream_t st) {
+    switch ((N + 15) / 16) {
+        case 5: return att16x3_launch<5>(qh, ql, oh, ol, B, N, H, scale, st);
+        case 6: return att16x3_launch<6>(qh, ql, oh, ol, B, N, H, scale, st);
+        case 7: return att16x3_launch<7>(qh, ql, oh, ol, B, N, H, scale, st);
+        case 8: return att16x3_launch<8>(qh, ql, oh, ol, B, N, H, scale, st);
+        case 9: return att16x3_launch<9>(qh, ql, oh, ol, B, N, H, scale, st);
+        case 10: return att16x3_launch<10>(qh, ql, oh, ol, B, N, H, scale, st);
+        case 11: return att16x3_launch<11>(qh, ql, oh, ol, B, N, H, scale, st);
+        case 12: return att16x3_launch<12>(qh, ql, oh, ol, B, N, H, scale, st);
+        case 13: return att16x3_launch<13>(qh, ql, oh, ol, B, N, H, scale, st);
+    }
+    return -1;
 }
