@@ -84,100 +84,6 @@ def test_gemm_blk_matches_row_major_kernel_bitwise(dev):
     assert torch.equal(L.from_blocked(t, M), ref)
 
 
-@pytest.mark.parametrize('M,N,K', [(1000, 512, 768), (12544, 768, 768), (777, 256, 64), (3000, 2304, 3072)])
-def test_gemm_blk_four_wave_tile_is_bit_identical(dev, M, N, K):
-    """tile id 0x144 (the 256 x 256 tile on four waves, one per SIMD: gemm_blk16_body<.., NW = 4>) against 0x44: same MFMA instruction and k order per
-    accumulator, same epilogue arithmetic, the LayerNorm-fold row statistics taken in the eight-wave kernel's order -- every epilogue, the producer
-    side of the fold (bf16 operand copy + partial sums, with a row shift) and the consumer side, ragged M, 2 half tiles to the ViT's K"""
-    from whmr_amd import _lib as L
-    g = torch.Generator().manual_seed(M + N + K)
-    a = torch.randn(M, K, generator=g).bfloat16().to(dev)
-    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).bfloat16().to(dev)
-    bias = torch.randn(N, generator=g).to(dev)
-    res = torch.randn(M, N, generator=g).to(dev)
-    pos = torch.randn(196, N, generator=g).to(dev)
-    ab, wb = L.to_blocked(a), L.to_blocked(w)
-    nb = ab.shape[0]
-    st_in = (torch.rand(nb * 32, max(1, K // 256), 2, generator=g) * 3 + 1).to(dev)
-    st_in[..., 1] = st_in[..., 0] ** 2 / 256 * 1.5 + 1
-    cs = torch.randn(N, generator=g).to(dev)
-    got = {}
-    for tile in (0x44, 0x144):
-        o = []
-        out = torch.full((nb, N // 8, 32, 8), float('nan'), device=dev, dtype=torch.bfloat16)
-        L.gemm_blk(ab, wb, out, M, bias=bias, epi=L.EPI_BF16, tile=tile); o.append(L.from_blocked(out, M).clone())
-        L.gemm_blk(ab, wb, out, M, bias=bias, epi=L.EPI_BF16_GELU, tile=tile); o.append(L.from_blocked(out, M).clone())
-        t = L.to_blocked(res)
-        xhat = torch.full((nb, N // 8, 32, 8), float('nan'), device=dev, dtype=torch.bfloat16)
-        stats = torch.full((nb * 32, N // 256, 2), float('nan'), device=dev)
-        shift = torch.linspace(-1, 1, nb * 32, device=dev)
-        sout = torch.full((nb * 32,), float('nan'), device=dev)
-        if N <= 1024:
-            L.gemm_blk(ab, wb, t, M, bias=bias, epi=L.EPI_F32_RES, res=t, tile=tile, xhat=xhat, stats_out=stats, shift=shift, shift_out=sout)
-            o += [L.from_blocked(xhat, M).clone(), stats[:M].clone(), sout[:M].clone()]
-        else:
-            L.gemm_blk(ab, wb, t, M, bias=bias, epi=L.EPI_F32_RES, res=t, tile=tile)
-        o.append(L.from_blocked(t, M).clone())
-        t2 = torch.full((nb, N // 4, 32, 4), float('nan'), device=dev)
-        L.gemm_blk(ab, wb, t2, M, bias=bias, epi=L.EPI_F32_POS, res=pos, res_rows=196, tile=tile); o.append(L.from_blocked(t2, M).clone())
-        if K % 256 == 0 and K <= 1024:                                   # consumer of a folded LayerNorm (statistics of some raw stream of width K)
-            L.gemm_blk(ab, wb, out, M, bias=bias, epi=L.EPI_BF16, tile=tile, stats_in=st_in, colsum=cs, ln_eps=1e-6); o.append(L.from_blocked(out, M).clone())
-        got[tile] = o
-    assert len(got[0x44]) == len(got[0x144])
-    for x8, x4 in zip(got[0x44], got[0x144]):
-        assert torch.isfinite(x8.float()).all() and torch.equal(x8, x4)
-
-
-def test_gemm_blk_mfma_shapes_agree(dev):
-    """the bf16 kernel on v_mfma_f32_16x16x32_bf16 (default) and the 32x32x16 kernel behind WHMR_BLK_MFMA=32 (whmr_gemm_blk_set_tile(5, 32)) read
-    the SAME packed operands and give the same results: every tile height, bf16 + GELU / fp32 residual epilogues, ragged M"""
-    from whmr_amd import _lib as L
-    g = torch.Generator().manual_seed(16)
-    M, N, K = 1000, 512, 768
-    a = torch.randn(M, K, generator=g).bfloat16().to(dev)
-    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).bfloat16().to(dev)
-    bias = torch.randn(N, generator=g).to(dev)
-    res = torch.randn(M, N, generator=g).to(dev)
-    ab, wb = L.to_blocked(a), L.to_blocked(w)
-    nb = ab.shape[0]
-    ref = a.float() @ w.float().t() + bias
-    try:
-        for tile in (0x44, 0x43, 0x33, 0x32, 0x22, 0x21, 0x55, 0x54):
-            outs = {}
-            for shape in (16, 32):
-                L.lib().whmr_gemm_blk_set_tile(5, shape)
-                o16 = torch.full((nb, N // 8, 32, 8), float('nan'), device=dev, dtype=torch.bfloat16)
-                L.gemm_blk(ab, wb, o16, M, bias=bias, epi=L.EPI_BF16_GELU, tile=tile)
-                t = L.to_blocked(res)
-                L.gemm_blk(ab, wb, t, M, bias=bias, epi=L.EPI_F32_RES, res=t, tile=tile)
-                outs[shape] = (L.from_blocked(o16, M).float(), L.from_blocked(t, M))
-            assert _rel(outs[16][1], ref + res) < 1e-5, hex(tile)
-            assert _rel(outs[16][1], outs[32][1]) < 1e-6, hex(tile)
-            assert _rel(outs[16][0], outs[32][0]) < 1e-2, hex(tile)
-    finally:
-        L.lib().whmr_gemm_blk_set_tile(5, 16)
-
-
-@pytest.mark.parametrize('C', [768, 1024, 256])
-def test_layernorm_blk(dev, C):
-    from whmr_amd import _lib as L
-    g = torch.Generator().manual_seed(C)
-    rows = 391
-    x = torch.randn(rows, C, generator=g) * 3 + 0.5
-    w, b = torch.randn(C, generator=g), torch.randn(C, generator=g)
-    ref = F.layer_norm(x, (C,), w, b, 1e-6)
-    xb = L.to_blocked(x.to(dev))
-    out = torch.empty(xb.shape[0], C // 8, 32, 8, device=dev, dtype=torch.bfloat16)
-    L.layernorm_blk(xb, w.to(dev), b.to(dev), out, rows, 1e-6)
-    assert _rel(L.from_blocked(out, rows).float().cpu(), ref) < 1e-2
-    std = torch.empty(rows, C, device=dev)
-    L.layernorm_blk(xb, w.to(dev), b.to(dev), std, rows, 1e-6, out_std=True)
-    assert _rel(std.cpu(), ref) < 2e-6
-    # against the row-major kernel: same two-pass statistics, different summation tree -> fp32 rounding only
-    rm = torch.empty(rows, C, device=dev)
-    L.layernorm(x.to(dev), w.to(dev), b.to(dev), rm, 1e-6)
-    assert _rel(std, rm) < 2e-6
-
 
 @pytest.mark.parametrize('N,B', [(196, 3), (192, 3), (100, 3), (256, 3), (65, 2), (208, 2), (196, 64), (192, 27)])
 def test_attention_blk(dev, N, B):
@@ -424,35 +330,3 @@ def test_vit_ln_fold_shift_chain_on_offset_stream(dev):
     ef, eu = _rel(out_f, ref), _rel(out_u, ref)
     print('offset stream (30 std per token): folded+shift %.3e, explicit bf16 LayerNorm %.3e (vs bf16x3)' % (ef, eu))
     assert ef < 2 * eu + 1e-3
-
-
-@pytest.mark.parametrize('M,N,K', [(392, 768, 768), (1001, 512, 64), (777, 256, 96), (1000, 256, 32), (12544, 2304, 768), (3000, 768, 3072), (6144, 1024, 1024)])
-def test_gemm_blk_w_direct_schedule_is_bit_identical(dev, M, N, K):
-    """the W-direct main loop (weight fragments straight from global memory into registers, three half tiles deep, counted vmcnt; schedule 2)
-    against the LDS-staged main loop on every tile and epilogue: the same MFMAs in the same order -> the same bits; K of 1 / 2 / 3 half tiles
-    (prologue edge cases), K not a multiple of the 3-set unroll (1024 -> 32 half tiles), M tails, and the bf16x3 form"""
-    from whmr_amd import _lib as L
-    g = torch.Generator().manual_seed(M + K)
-    a = torch.randn(M, K, generator=g)
-    w = torch.randn(N, K, generator=g) / math.sqrt(K)
-    bias = torch.randn(N, generator=g).to(dev)
-    res = torch.randn(M, N, generator=g)
-    (ah, al), (wh, wl) = [(L.to_blocked(h.to(dev)), L.to_blocked(l.to(dev))) for h, l in (L.split_bf16(a), L.split_bf16(w))]
-    nb = ah.shape[0]
-    try:
-        for tile in ([0] if M > 4000 else [0x44, 0x43, 0x33, 0x32, 0x22, 0x21, 0x55]):
-            outs = {}
-            for sched in (1, 2):
-                L.lib().whmr_gemm_blk_set_tile(4, sched)
-                o16 = torch.full((nb, N // 8, 32, 8), float('nan'), device=dev, dtype=torch.bfloat16)
-                L.gemm_blk(ah, wh, o16, M, bias=bias, epi=L.EPI_BF16_GELU, tile=tile)
-                t = L.to_blocked(res.to(dev))
-                L.gemm_blk(ah, wh, t, M, bias=bias, epi=L.EPI_F32_RES, res=t, tile=tile)
-                oh, ol = torch.full_like(o16, float('nan')), torch.full_like(o16, float('nan'))
-                L.gemm_blk(ah, wh, oh, M, bias=bias, epi=L.EPI_BF16, tile=tile, a_lo=al, w_lo=wl, out_lo=ol)
-                outs[sched] = (L.from_blocked(o16, M), L.from_blocked(t, M), L.from_blocked(oh, M), L.from_blocked(ol, M))
-            for x, y in zip(outs[1], outs[2]):
-                assert torch.equal(x, y), (hex(tile), M, N, K)
-            assert _rel(outs[2][1].cpu(), a.bfloat16().float() @ w.bfloat16().float().t() + bias.cpu() + res) < 1e-4
-    finally:
-        L.lib().whmr_gemm_blk_set_tile(4, 1)

@@ -169,10 +169,6 @@ def lib():
         for slot, key in enumerate(('WHMR_BLK_TILE_QKV', 'WHMR_BLK_TILE_PROJ', 'WHMR_BLK_TILE_FC1', 'WHMR_BLK_TILE_FC2')):     # A/B: force a tile per ViT shape
             if os.environ.get(key):
                 l.whmr_gemm_blk_set_tile(slot, int(os.environ[key], 0))
-        if os.environ.get('WHMR_BLK_SCHED'):         # A/B switch of the blocked GEMM's main loop (0 / 1: W through LDS, 2: W direct), tools/r3_wd.sh
-            l.whmr_gemm_blk_set_tile(4, int(os.environ['WHMR_BLK_SCHED']))
-        if os.environ.get('WHMR_BLK_MFMA'):          # A/B switch: 32 = the bf16 blocked GEMM on v_mfma_f32_32x32x16_bf16 (default 16x16x32), tools/lab/mfma16_ab.sh
-            l.whmr_gemm_blk_set_tile(5, int(os.environ['WHMR_BLK_MFMA']))
     return _lib
 
 

@@ -21,7 +21,9 @@
 // 8 waves issue their DMA at the same time and the matrix pipes idle for the ~1000 clk the L1 needs to take 64 KiB (qkv main loop
 // 48 -> 36-38 us in the lab).
 #include "gemm_blk16_impl.h"
-#include "gemm_blk_impl.h"      // the 32x32x16 kernel: split-bf16 operands (gemm_blk_x3.hip) and, behind WHMR_BLK_MFMA=32, the A/B partner of the bf16 kernel
+// (the 32x32x16 kernel of gemm_blk_impl.h now only exists for split-bf16 operands: gemm_blk_x3.hip.  Its bf16 instantiation -- the A/B partner of
+// round 3, WHMR_BLK_MFMA=32 -- the two-barrier schedule and the W-direct main loop are no longer compiled: DESIGN 6 keeps their numbers.)
+__attribute__((visibility("hidden"))) int blk_x3_launch_tile(const whmr_gemm_blk_desc* pp, int tile, void* stream, int sched);
 
 #ifdef WHMR_BLK_STAMPS
 // lab build only (tools/gemm_stamps.py): every bf16 blocked launch takes the next [tiles][2][8] u64 record of a caller-provided device buffer
@@ -39,8 +41,6 @@ extern "C" int whmr_debug_blk_stamps(void* buf, long capacity_u64) { g_stamp_buf
 extern "C" long whmr_debug_blk_stamps_used(void) { return g_stamp_used; }
 #endif
 
-static int g_blk_sched = 1;
-static int g_blk_mfma32 = 0;      // A/B only: 1 = bf16 operands on the 32x32x16 kernel (tools/lab/mfma16_ab.sh); same packed operands, same results to rounding
 
 // The chooser minimises (rounds over 256 CUs) x (tile rows).
 static const int kBlkTiles[][2] = {{4, 4}, {5, 5}, {4, 3}, {3, 3}, {3, 2}, {2, 2}, {5, 4}, {2, 1}};
@@ -57,16 +57,13 @@ extern "C" int whmr_gemm_blk_tile(const whmr_gemm_blk_desc* pp, int tile, void* 
     if (p.A_lo || p.W_lo || p.C_lo) {
         // split-bf16 operands: both lo halves, a lo output for the bf16 epilogues, a lo half of the folded-LayerNorm operand copy
         if (!p.A_lo || !p.W_lo || (p.epi < 2 && !p.C_lo) || (p.xhat && !p.xhat_lo)) return (int)hipErrorInvalidValue;
-        return blk_x3_launch_tile(pp, tile, stream, g_blk_sched);
+        return blk_x3_launch_tile(pp, tile, stream, 1);
     }
-    if (g_blk_mfma32) return blk_launch_tile<false>(p, tile, (hipStream_t)stream, g_blk_sched);
-    return blk16_launch_tile(p, tile, (hipStream_t)stream, g_blk_sched);
+    return blk16_launch_tile(p, tile, (hipStream_t)stream);
 }
 
 static int g_blk_force[4] = {0, 0, 0, 0};                   // whmr_set_option keys 110..113: tile for N = 2304 / (768, K <= 1024) / 3072 / (768, K > 1024)
 extern "C" int whmr_gemm_blk_set_tile(int slot, int tile) {
-    if (slot == 4) { g_blk_sched = tile; return 0; }
-    if (slot == 5) { g_blk_mfma32 = tile == 32; return 0; }          // A/B: MFMA shape of the bf16 kernel (16 = default, 32)                 // A/B: main-loop schedule (0 two barriers per half tile, 1 one barrier)
     if (slot < 0 || slot > 3) return (int)hipErrorInvalidValue;
     g_blk_force[slot] = tile;
     return 0;

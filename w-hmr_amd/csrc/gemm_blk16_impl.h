@@ -58,28 +58,6 @@ template <int OFF> __device__ __forceinline__ bf16x8_t b16_lds_read128(uint32_t 
     return v;
 }
 
-// read q (0..15, a constant after unrolling) of a half tile's 16 fragment reads of the four-wave body: W blocks j = q >> 1, halves nh = q & 1, then A blocks
-__device__ __forceinline__ void blk16_read_sel(bf16x8_t (&fa)[4][2], bf16x8_t (&fb)[4][2], uint32_t sa, uint32_t sb, const int q) {
-    switch (q) {
-        case 0: fb[0][0] = b16_lds_read128<0>(sb); break;
-        case 1: fb[0][1] = b16_lds_read128<256>(sb); break;
-        case 2: fb[1][0] = b16_lds_read128<2048>(sb); break;
-        case 3: fb[1][1] = b16_lds_read128<2048 + 256>(sb); break;
-        case 4: fb[2][0] = b16_lds_read128<4096>(sb); break;
-        case 5: fb[2][1] = b16_lds_read128<4096 + 256>(sb); break;
-        case 6: fb[3][0] = b16_lds_read128<6144>(sb); break;
-        case 7: fb[3][1] = b16_lds_read128<6144 + 256>(sb); break;
-        case 8: fa[0][0] = b16_lds_read128<0>(sa); break;
-        case 9: fa[0][1] = b16_lds_read128<256>(sa); break;
-        case 10: fa[1][0] = b16_lds_read128<2048>(sa); break;
-        case 11: fa[1][1] = b16_lds_read128<2048 + 256>(sa); break;
-        case 12: fa[2][0] = b16_lds_read128<4096>(sa); break;
-        case 13: fa[2][1] = b16_lds_read128<4096 + 256>(sa); break;
-        case 14: fa[3][0] = b16_lds_read128<6144>(sa); break;
-        default: fa[3][1] = b16_lds_read128<6144 + 256>(sa); break;
-    }
-}
-
 template <int MI0, int MI1>
 struct blk16_cfg {
     static constexpr int MB = MI0 + MI1;                 // A row blocks (32 rows) per tile
@@ -93,20 +71,14 @@ struct blk16_cfg {
     static constexpr int MIMAX = MI0 > MI1 ? MI0 : MI1;
 };
 
-// SCHED 1: one barrier per half tile, groups in opposite order within a slot;  SCHED 0: two barriers per half tile (MEM | MFMA rendezvous)
-//
-// NW = 4 (round 4, tile id 0x144): the same 256 x 256 tile on FOUR waves, one per SIMD, 512 registers each (256 accumulators in AGPRs + two
-// fragment sets) -- the structure of gemm_tn.hip's four-wave body.  Stamps of the eight-wave loops (tools/lab/tn_lab.hip) show that the two waves
-// of a SIMD do not hide each other's memory phase, they queue behind each other's issue (LDS-DMA pieces issue at 42 cycles beside reads, 130 beside
-// the partner's MFMAs); alone on its SIMD a wave runs its 64 MFMAs per half tile back to back with the half tile's 16 fragment reads and 8
-// LDS-DMA pieces in the gaps.  Wave (wm, wn) of 2 x 2 owns 128 x 128 outputs: 16 fragment reads per 64 MFMAs instead of 12 per 32.  Same ring, same
-// MFMA instruction and k order per accumulator, same epilogue arithmetic (the row statistics keep the eight-wave kernel's partial sums): same bits.
+// One barrier per half tile, the two wave groups in opposite order within a slot.  (Round 3-4 also carried a two-barrier schedule and the same tile on
+// FOUR waves, one per SIMD -- tile id 0x144, bit-identical, same K slope, worse epilogue: profiles/r04_fw4_ab.txt.  Both are gone from the build.)
 template <int MI0, int MI1, int EPI, int SCHED, int NW>
 __device__ __forceinline__ void gemm_blk16_body(const whmr_gemm_blk_desc& p, char* smem BLK16_STAMP_PARAM) {
     using cfg = blk16_cfg<MI0, MI1>;
     constexpr int MB = cfg::MB, BM = cfg::BM, BN = cfg::BN, SLOT = cfg::SLOT, HU = cfg::HU, NJ = NW == 8 ? 2 : 4, NT = NW * 64;
     constexpr int HUPW = (HU + NW - 1) / NW;             // DMA units per wave (waves >= HU % NW issue one less when HU % NW != 0)
-    static_assert(NW == 8 || (MI0 == 4 && MI1 == 4), "the four-wave body is the 256-row tile");
+    static_assert(NW == 8 && SCHED == 1, "eight waves, one barrier per half tile");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = NW == 8 ? wave >> 2 : wave >> 1, wn = NW == 8 ? wave & 3 : wave & 1;     // NW 8: wm = group
@@ -258,53 +230,7 @@ __device__ __forceinline__ void gemm_blk16_body(const whmr_gemm_blk_desc& p, cha
             if (wm == 0) __builtin_amdgcn_s_barrier();
         }
     };
-    if constexpr (NW == 4) {
-        // ---- four waves: 64 MFMAs per half tile from fragment set `cur`; in their gaps the 16 reads of half tile h + 1 (set cur ^ 1) and the 8
-        // LDS-DMA pieces of half tile h + 3 (its slot held h - 1: everybody is past the barrier that opens h).  Pieces past the last half tile
-        // fetch the last one again (nobody reads it): no branch in the stream, one vmcnt count for every half tile.
-        static_assert(HU % 4 == 0 && HUPW == 8, "");
-        const uint32_t a_b = lds0 + (wm * 4) * 2048 + g * 512 + l15 * 16;
-        const uint32_t b_b = lds0 + (MB + wn * 4) * 2048 + g * 512 + l15 * 16;
-        bf16x8_t fa[2][4][2], fb[2][4][2];                       // [set][block][mh / nh]
-#define B16_PHASE(cur, h)                                                                                                    \
-    do {                                                                                                                     \
-        const int hn_ = (h) + 3 < H ? (h) + 3 : H - 1, sl_ = ((h) + 1) & 3;                                                  \
-        _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                                                      \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                  \
-                _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                              \
-                    _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                                          \
-                        const int g_ = ((a * 4 + i) * 4 + j) * 2 + b;                                                        \
-                        acc[i][j][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[cur][j][b], fa[cur][i][a], acc[i][j][a][b], 0, 0, 0); \
-                        __builtin_amdgcn_sched_barrier(0);                                                                   \
-                        if (g_ < 16) blk16_read_sel(fa[(cur) ^ 1], fb[(cur) ^ 1], a_b + sl_ * SLOT, b_b + sl_ * SLOT, g_);   \
-                        if (g_ >= 16 && g_ < 48 && (g_ & 3) == 0) {                                                          \
-                            __builtin_amdgcn_global_load_lds((gbl16_void_t*)(hsrc[(g_ - 16) >> 2] + (size_t)hn_ * 2048),     \
-                                                             (lds16_void_t*)(smem + (((h) + 3) & 3) * SLOT + (wave + 4 * ((g_ - 16) >> 2)) * 1024), 16, 0, 0); \
-                        }                                                                                                    \
-                        __builtin_amdgcn_sched_barrier(0);                                                                   \
-                    }                                                                                                        \
-                }                                                                                                            \
-            }                                                                                                                \
-        }                                                                                                                    \
-    } while (0)
-        // prologue (half tiles 0-2 are in flight, 0 has landed for everybody): the first fragment set
-#pragma unroll
-        for (int q = 0; q < 16; ++q) blk16_read_sel(fa[0], fb[0], a_b, b_b, q);
-        b16_wait_lgkmcnt<0>();
-        __builtin_amdgcn_sched_barrier(0);
-        auto open = [&]() {                                            // own pieces of the next half tile have landed (the 8 of the one after may fly)
-            b16_wait_vmcnt<8>();
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        auto close = [&]() { b16_wait_lgkmcnt<0>(); __builtin_amdgcn_sched_barrier(0); };
-        for (int h = 0; h < H; h += 2) {                               // H is even here (K % 64 == 0: the launcher checks)
-            open(); B16_PHASE(0, h); close();
-            open(); B16_PHASE(1, h + 1); close();
-        }
-        b16_wait_vmcnt<0>();                                           // the surplus pieces land in this workgroup's LDS: not after it has gone
-#undef B16_PHASE
-    } else if constexpr (MI0 == MI1) {
+    if constexpr (MI0 == MI1) {
         main_loop(std::integral_constant<int, MI0>{});
     } else {
         if (wm == 0) main_loop(std::integral_constant<int, MI0>{});
@@ -496,12 +422,6 @@ __global__ __launch_bounds__(512, 2) void gemm_blk16_kernel(const whmr_gemm_blk_
     gemm_blk16_body<MI0, MI1, EPI, SCHED, 8>(p, smem BLK16_STAMP_PASS);
 }
 
-template <int EPI>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_blk16w4_kernel(const whmr_gemm_blk_desc p BLK16_STAMP_PARAM) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    gemm_blk16_body<4, 4, EPI, 1, 4>(p, smem BLK16_STAMP_PASS);
-}
-
 template <int MI0, int MI1, int EPI, int SCHED>
 static int launch_blk16_s(const whmr_gemm_blk_desc& p, hipStream_t st) {
     using cfg = blk16_cfg<MI0, MI1>;
@@ -518,56 +438,28 @@ static int launch_blk16_s(const whmr_gemm_blk_desc& p, hipStream_t st) {
     return 0;
 }
 
-template <int EPI>
-static int launch_blk16w4_s(const whmr_gemm_blk_desc& p, hipStream_t st) {
-    using cfg = blk16_cfg<4, 4>;
-    auto kern = gemm_blk16w4_kernel<EPI>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, cfg::LDS);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
-    const int tiles = ((p.M + cfg::BM - 1) / cfg::BM) * (p.N / cfg::BN);
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), cfg::LDS, st, p BLK16_STAMP_ARG(tiles));
-    WHMR_CHECK_LAUNCH();
-    return 0;
-}
-
-static int launch_blk16w4_epi(const whmr_gemm_blk_desc& p, hipStream_t st) {
-    switch (p.epi) {
-        case 0: return launch_blk16w4_s<0>(p, st);
-        case 1: return launch_blk16w4_s<1>(p, st);
-        case 2: return launch_blk16w4_s<2>(p, st);
-        case 3: return launch_blk16w4_s<3>(p, st);
-    }
-    return (int)hipErrorInvalidValue;
-}
-
 template <int MI0, int MI1>
-static int launch_blk16_epi(const whmr_gemm_blk_desc& p, hipStream_t st, int sched) {
-    // sched: 0 two barriers per half tile, anything else one barrier
+static int launch_blk16_epi(const whmr_gemm_blk_desc& p, hipStream_t st) {
     switch (p.epi) {
-        case 0: return sched ? launch_blk16_s<MI0, MI1, 0, 1>(p, st) : launch_blk16_s<MI0, MI1, 0, 0>(p, st);
-        case 1: return sched ? launch_blk16_s<MI0, MI1, 1, 1>(p, st) : launch_blk16_s<MI0, MI1, 1, 0>(p, st);
-        case 2: return sched ? launch_blk16_s<MI0, MI1, 2, 1>(p, st) : launch_blk16_s<MI0, MI1, 2, 0>(p, st);
-        case 3: return sched ? launch_blk16_s<MI0, MI1, 3, 1>(p, st) : launch_blk16_s<MI0, MI1, 3, 0>(p, st);
+        case 0: return launch_blk16_s<MI0, MI1, 0, 1>(p, st);
+        case 1: return launch_blk16_s<MI0, MI1, 1, 1>(p, st);
+        case 2: return launch_blk16_s<MI0, MI1, 2, 1>(p, st);
+        case 3: return launch_blk16_s<MI0, MI1, 3, 1>(p, st);
     }
     return (int)hipErrorInvalidValue;
 }
 
 // Tile heights (x 256 columns): the wave rows own MI0 and MI1 row blocks.
-static int blk16_launch_tile(const whmr_gemm_blk_desc& p, int tile, hipStream_t st, int sched) {
+static int blk16_launch_tile(const whmr_gemm_blk_desc& p, int tile, hipStream_t st) {
     switch (tile) {
-        case 0x144: return (p.K % 64) ? launch_blk16_epi<4, 4>(p, st, sched) : launch_blk16w4_epi(p, st);     // 256 x 256 on four waves (one per SIMD)
-        case 0x44: return launch_blk16_epi<4, 4>(p, st, sched);      // 256 x 256
-        case 0x55: return launch_blk16_epi<5, 5>(p, st, sched);      // 320 x 256
-        case 0x43: return launch_blk16_epi<4, 3>(p, st, sched);      // 224 x 256
-        case 0x33: return launch_blk16_epi<3, 3>(p, st, sched);      // 192 x 256
-        case 0x32: return launch_blk16_epi<3, 2>(p, st, sched);      // 160 x 256
-        case 0x22: return launch_blk16_epi<2, 2>(p, st, sched);      // 128 x 256
-        case 0x54: return launch_blk16_epi<5, 4>(p, st, sched);      // 288 x 256
-        case 0x21: return launch_blk16_epi<2, 1>(p, st, sched);      // 96 x 256: ViT-L at 32 crops (6144 tokens) x N = 1024 is exactly 256 such tiles
+        case 0x44: return launch_blk16_epi<4, 4>(p, st);      // 256 x 256
+        case 0x55: return launch_blk16_epi<5, 5>(p, st);      // 320 x 256
+        case 0x43: return launch_blk16_epi<4, 3>(p, st);      // 224 x 256
+        case 0x33: return launch_blk16_epi<3, 3>(p, st);      // 192 x 256
+        case 0x32: return launch_blk16_epi<3, 2>(p, st);      // 160 x 256
+        case 0x22: return launch_blk16_epi<2, 2>(p, st);      // 128 x 256
+        case 0x54: return launch_blk16_epi<5, 4>(p, st);      // 288 x 256
+        case 0x21: return launch_blk16_epi<2, 1>(p, st);      // 96 x 256: ViT-L at 32 crops (6144 tokens) x N = 1024 is exactly 256 such tiles
     }
     return (int)hipErrorInvalidValue;
 }

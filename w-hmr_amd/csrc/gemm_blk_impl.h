@@ -519,16 +519,12 @@ static int launch_blk_s(const whmr_gemm_blk_desc& p, hipStream_t st) {
 
 template <int MI0, int MI1, int EPI, bool X3>
 static int launch_blk(const whmr_gemm_blk_desc& p, hipStream_t st, int sched) {
-    // sched: 0 two barriers per half tile, 1 one barrier (W through LDS), 2 one barrier + W direct (fragments straight from global memory)
-    // (the 288- / 320-row tiles keep W in LDS: 160 accumulator registers + three fragment sets do not fit the 256-register budget)
-    constexpr bool WD_OK = MI0 + MI1 <= 8;
-    if constexpr (X3) {
-        if constexpr (WD_OK) { if (sched == 2) return launch_blk_s<MI0, MI1, EPI, 1, true, true>(p, st); }
-        return launch_blk_s<MI0, MI1, EPI, 1, true>(p, st);
-    } else {
-        if constexpr (WD_OK) { if (sched == 2) return launch_blk_s<MI0, MI1, EPI, 1, false, true>(p, st); }
-        return sched ? launch_blk_s<MI0, MI1, EPI, 1, false>(p, st) : launch_blk_s<MI0, MI1, EPI, 0, false>(p, st);
-    }
+    // Only the split-bf16 form (X3) with W through LDS and the one-barrier schedule is compiled since round 5.  The body still carries its plain-bf16
+    // branch (the bf16 kernel moved to 16x16x32: gemm_blk16_impl.h), the two-barrier schedule and the W-direct main loop (measured 3-4 % slower,
+    // DESIGN 6) behind `if constexpr`; none of them is instantiated.
+    static_assert(X3, "the 32x32x16 blocked kernel is the split-bf16 kernel");
+    (void)sched;
+    return launch_blk_s<MI0, MI1, EPI, 1, true>(p, st);
 }
 
 template <int MI0, int MI1, bool X3>

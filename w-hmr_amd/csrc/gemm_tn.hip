@@ -656,12 +656,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                                  p.ws ? p.ws + (size_t)p.splits * p.Mo * p.No + (size_t)slice * p.Mo : p.db);
 }
 
-static int tn_w4() {
-    static const int w4 = [] { const char* e = getenv("WHMR_TN_W4"); return e ? atoi(e) : 1; }();     // 0 = the eight-wave ping-pong body; bit 0: plain products on four waves (default), bit 1: gathering products too
-                                                                                                         // (rocprof, training step: deconv dW 247 vs 222 us, Tz conv dW 390 vs 333, IUV head 728 vs 734: the per-lane pixel bookkeeping of the gather sits in the MFMA stream -- stays off)
-    return w4;
-}
-
+// Which body runs which product is fixed (round 5; the A/B switches WHMR_TN_W4 / WHMR_TN_PP / WHMR_TN_RR of round 4 are gone with the variants that
+// lost -- profiles/r04_tn_group_ab.txt, r04_tn_lab.txt keep their numbers): plain products on the four-wave body, gathering (convolution) products on
+// the eight-wave ping-pong body (rocprof, training step: deconv dW 247 vs 222 us, Tz conv dW 390 vs 333 on four waves: the per-lane pixel
+// bookkeeping of the gather sits in the MFMA stream), XCD-aware (slice, tile) order everywhere.
 template <int MI, bool GATHER>
 static int launch_tn4(tn_params p, int tiles, int splits, hipStream_t st) {
     constexpr int LDS = TN4_NS * (32 * 64 * MI * 2 + 32 * 256 * 2);
@@ -672,8 +670,7 @@ static int launch_tn4(tn_params p, int tiles, int splits, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    static const int rr = [] { const char* e = getenv("WHMR_TN_RR"); return e && e[0] == '1' ? 1 : 0; }();
-    p.tiles = tiles; p.splits = splits; p.round_robin = rr;
+    p.tiles = tiles; p.splits = splits; p.round_robin = 0;
     hipLaunchKernelGGL(kern, dim3(tiles * splits), dim3(256), LDS, st, p);
     WHMR_CHECK_LAUNCH();
     return 0;
@@ -689,17 +686,15 @@ static int launch_tn_pp(tn_params p, int tiles, int splits, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    static const int rr = [] { const char* e = getenv("WHMR_TN_RR"); return e && e[0] == '1' ? 1 : 0; }();
-    p.tiles = tiles; p.splits = splits; p.round_robin = rr;
+    p.tiles = tiles; p.splits = splits; p.round_robin = 0;
     hipLaunchKernelGGL(kern, dim3(tiles * splits), dim3(512), LDS, st, p);
     WHMR_CHECK_LAUNCH();
     return 0;
 }
 
-static int g_tn_pp = [] { const char* e = getenv("WHMR_TN_PP"); return e ? (e[0] == '1' ? 1 : 0) : 1; }();     // A/B: 0 = the lock-step loop of round 2-3
 template <int MI, bool GATHER>
 static int launch_tn(tn_params p, int tiles, int splits, hipStream_t st) {
-    return g_tn_pp ? launch_tn_pp<MI, GATHER, true>(p, tiles, splits, st) : launch_tn_pp<MI, GATHER, false>(p, tiles, splits, st);
+    return launch_tn_pp<MI, GATHER, true>(p, tiles, splits, st);
 }
 
 static int tn_run(tn_params p, int splits, void* workspace, long workspace_bytes, hipStream_t st) {
@@ -717,14 +712,8 @@ static int tn_run(tn_params p, int splits, void* workspace, long workspace_bytes
     p.k_per_split = sps * 32;
     p.ws = splits > 1 ? (float*)workspace : nullptr;
     int rc;
-    const int w4 = tn_w4() & (p.gather ? 2 : 1);             // WHMR_TN_W4: bit 0 plain products, bit 1 gathering (convolution) products
-    if (p.gather) {
-        if (w4) rc = MI == 4 ? launch_tn4<4, true>(p, tiles, splits, st) : MI == 2 ? launch_tn4<2, true>(p, tiles, splits, st) : launch_tn4<1, true>(p, tiles, splits, st);
-        else rc = MI == 4 ? launch_tn<4, true>(p, tiles, splits, st) : MI == 2 ? launch_tn<2, true>(p, tiles, splits, st) : launch_tn<1, true>(p, tiles, splits, st);
-    } else {
-        if (w4) rc = MI == 4 ? launch_tn4<4, false>(p, tiles, splits, st) : MI == 2 ? launch_tn4<2, false>(p, tiles, splits, st) : launch_tn4<1, false>(p, tiles, splits, st);
-        else rc = MI == 4 ? launch_tn<4, false>(p, tiles, splits, st) : MI == 2 ? launch_tn<2, false>(p, tiles, splits, st) : launch_tn<1, false>(p, tiles, splits, st);
-    }
+    if (p.gather) rc = MI == 4 ? launch_tn<4, true>(p, tiles, splits, st) : MI == 2 ? launch_tn<2, true>(p, tiles, splits, st) : launch_tn<1, true>(p, tiles, splits, st);
+    else rc = MI == 4 ? launch_tn4<4, false>(p, tiles, splits, st) : MI == 2 ? launch_tn4<2, false>(p, tiles, splits, st) : launch_tn4<1, false>(p, tiles, splits, st);
     if (rc) return rc;
     if (splits > 1) {
         hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)(((long)p.Mo * (p.No >> 2) + 255) / 256)), dim3(256), 0, st, (const float*)workspace, splits,
@@ -849,16 +838,14 @@ extern "C" int whmr_gemm_tn_bf16_group(const whmr_tn_item* items, int n_items, i
     for (int i = n_items; i < TN_GROUP_MAX; ++i) { g.it[i] = g.it[0]; g.first[i] = first; }
     g.n = n_items; g.total = first;
     hipStream_t st = (hipStream_t)stream;
-    constexpr int LDS = TN_NS4 * (32 * 256 * 2 + 32 * 256 * 2), LDS4 = TN4_NS * (32 * 256 * 2 + 32 * 256 * 2);
+    constexpr int LDS4 = TN4_NS * (32 * 256 * 2 + 32 * 256 * 2);
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_group_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_tn4_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_tn4_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    if (tn_w4() & 1) hipLaunchKernelGGL(gemm_tn4_group_kernel, dim3(g.total), dim3(256), LDS4, st, g);
-    else hipLaunchKernelGGL(gemm_tn_group_kernel<true>, dim3(g.total), dim3(512), LDS, st, g);
+    hipLaunchKernelGGL(gemm_tn4_group_kernel, dim3(g.total), dim3(256), LDS4, st, g);
     WHMR_CHECK_LAUNCH();
     if (splits > 1) {
         long most = 0;
