@@ -57,6 +57,9 @@ def parse(argv=None):
     ap.add_argument('--ref-1gpu', type=float, default=None, help='images/sec of the same workload on 1 GPU: adds efficiency_vs_1gpu to the line')
     ap.add_argument('--master-port', type=int, default=None, help='rendezvous port of the self-launched ranks (default: a free port)')
     ap.add_argument('--dryrun-cpu', action='store_true', help='tests only: gloo/CPU stand-in step (launcher + rank bookkeeping), not a measurement')
+    ap.add_argument('--batchnorm', default='auto', choices=('auto', 'sync', 'local'),
+                    help='whmr_train: BatchNorm statistics of the four trained layers -- sync = over all ranks (the reference, core/trainer.py:83), local = per GPU; '
+                         'auto = sync at world size > 1, local on one GPU (sync on one GPU runs the split kernels with a no-op exchange)')
     ap.add_argument('--always-bucket', action='store_true',
                     help='whmr_train: pack and exchange the gradient buckets even at world size 1 (one-rank RCCL smoke of the reducer on a 1-GPU box)')
     ap.add_argument('--no-secondary', action='store_true',
@@ -136,6 +139,14 @@ def build_workload(args, dev):
         # global_orient.* (and dp_head.* without AUX supervision) never receive a gradient -- the reference asks DDP for find_unused_parameters
         # (core/trainer.py:84-91); GradReducer drops them at its first finish().  The backbone is one autograd node, so its parameters get
         # their own buckets: the head buckets are exchanged while the ViT backward still runs.
+        # BatchNorm: the reference converts every BatchNorm to SyncBatchNorm before DDP (core/trainer.py:83) -- at world size > 1 the four trained layers
+        # take their statistics and gradients over ALL ranks (one packed fp64 all-reduce per layer and direction, whmr_amd.parallel.sync_bn)
+        sync_bn = args.batchnorm == 'sync' or (args.batchnorm == 'auto' and world > 1)
+        if sync_bn:
+            from whmr_amd.parallel import convert_sync_batchnorm
+            convert_sync_batchnorm(m, always=(world == 1))
+        args.sync_bn = sync_bn
+        args.sync_group = getattr(m, 'whmr_sync_group', None)
         red = None if use_graph else GradReducer(params, groups=[n.startswith('feature_extractor') for n, _ in named], always_bucket=args.always_bucket)
         if red is not None:
             red.attach(m.feature_extractor.backbone)          # the ViT node publishes its gradients block by block: buckets exchange under its backward
@@ -201,7 +212,8 @@ def build_workload(args, dev):
             loss.backward()
             if red is not None:
                 red.finish()
-                broadcast_buffers(m)                            # DDP broadcast_buffers: BatchNorm running statistics follow rank 0
+                if not sync_bn:
+                    broadcast_buffers(m)                        # DDP broadcast_buffers: local BatchNorm running statistics follow rank 0 (identical on every rank under sync)
             return loss
 
         def train_step():
@@ -744,6 +756,9 @@ def multi_rank_report(args, dist, world, dt_own, rank_map, red, dry, dev):
                    collectives_per_step=getattr(args, 'reducer_stats', red.stats)['collectives'] / max(args.steps, 1),
                    bytes_exchanged_per_step=getattr(args, 'reducer_stats', red.stats)['bytes_exchanged'] / max(args.steps, 1),
                    buckets=len(red.buckets), bucket_bytes=[b['numel'] * 4 for b in red.buckets], unused_parameters=len(red.skipped))
+        sg = getattr(args, 'sync_group', None)
+        if sg is not None:
+            own.update(sync_bn_collectives_total=sg.collectives, sync_bn_bytes_total=sg.bytes)
     try:
         dist.all_gather_object(rows, own)
     except Exception as e:                       # noqa: BLE001
@@ -792,17 +807,25 @@ def dryrun_workload(args, dev):
     if args.workload != 'whmr_train':
         net.eval()
         return (lambda: net(x)), None, x, (1, 32)
-    from whmr_amd.parallel import GradReducer, broadcast_buffers
+    from whmr_amd.parallel import GradReducer, broadcast_buffers, convert_sync_batchnorm
+    from whmr_amd.parallel.sync_bn import batch_norm_1d
     params = list(net.parameters()) + list(unused.parameters())
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    sync_bn = args.batchnorm == 'sync' or (args.batchnorm == 'auto' and world > 1)
+    if sync_bn:                                  # the REAL cross-rank BatchNorm protocol (whmr_amd.parallel.sync_bn) on the stand-in's BatchNorm1d
+        convert_sync_batchnorm(net)
+    args.sync_bn, args.sync_group = sync_bn, getattr(net, 'whmr_sync_group', None)
     red = GradReducer(params, bucket_bytes=4096)
     opt = torch.optim.Adam(params, lr=1e-3)
 
     def step():
         opt.zero_grad(set_to_none=True)
-        loss = net(x).pow(2).mean()
+        h = batch_norm_1d(net[0](x), net[1])
+        loss = net[3](net[2](h)).pow(2).mean()
         loss.backward()
         red.finish()
-        broadcast_buffers(net)
+        if not sync_bn:
+            broadcast_buffers(net)
         opt.step()
         return loss
     args.dry_state = (net, unused, red)
@@ -923,8 +946,11 @@ def main(argv=None):
     if rank == 0:
         value = aggregate_value(n_ranks, args.batch, args.steps, dt)
         if training:
-            par = 'dp%d (RCCL all-reduce of the gradients in 128 MiB buckets; BatchNorm: local batch statistics + running-stat broadcast from rank 0 ' \
-                  'instead of the reference\'s SyncBatchNorm, core/trainer.py:83)' % n_ranks
+            if getattr(args, 'sync_bn', False):
+                bn = 'BatchNorm: SyncBatchNorm as in the reference (core/trainer.py:83) -- statistics / gradients of the 4 trained layers over all ranks, one packed fp64 all-reduce per layer and direction'
+            else:
+                bn = 'BatchNorm: local batch statistics + running-stat broadcast from rank 0 (--batchnorm local; the reference uses SyncBatchNorm, core/trainer.py:83)'
+            par = 'dp%d (RCCL all-reduce of the gradients in 128 MiB buckets; %s)' % (n_ranks, bn)
         else:
             par = 'replicas x%d (no data-path collective)' % n_ranks
         res = {

@@ -289,8 +289,8 @@ def test_bench_train_entry_two_ranks_gloo():
     """`bench.py --workload whmr_train --gpus 2` drives GradReducer (with a never-used parameter, as global_orient.* in W-HMR: the reference
     needs DDP's find_unused_parameters, core/trainer.py:84-91) and broadcast_buffers through the real entry point; the averaged gradient
     equals the mean of the two ranks' single-process gradients."""
-    out = _run_bench('--gpus', '2', '--steps', '1', '--warmup', '0', '--workload', 'whmr_train')
-    assert out['n_gpus'] == 2 and 'dp2' in out['config']['parallelism']
+    out = _run_bench('--gpus', '2', '--steps', '1', '--warmup', '0', '--workload', 'whmr_train', '--batchnorm', 'local')
+    assert out['n_gpus'] == 2 and 'dp2' in out['config']['parallelism'] and 'local batch statistics' in out['config']['parallelism']
     d = out['dry']
     assert d['unused_grad_is_none'] and d['skipped_params'] == 2 and d['buckets'] >= 2
     grads, means = [], []
@@ -305,6 +305,23 @@ def test_bench_train_entry_two_ranks_gloo():
     ref = float(sum(g.pow(2).sum() for g in avg).sqrt())
     assert abs(d['grad_norm'] - ref) < 1e-5 * ref
     assert abs(d['running_mean_sum'] - means[0]) < 1e-6              # every rank holds rank 0's running statistics
+
+
+def test_bench_train_entry_two_ranks_sync_batchnorm_gloo():
+    """the DEFAULT of `bench.py --workload whmr_train --gpus 2`: SyncBatchNorm as in the reference (core/trainer.py:83) -- the line says so, and the
+    reduced gradient / the running statistics equal those of ONE process on the 32 samples of both ranks (global batch statistics)."""
+    out = _run_bench('--gpus', '2', '--steps', '1', '--warmup', '0', '--workload', 'whmr_train')
+    assert out['n_gpus'] == 2 and 'SyncBatchNorm as in the reference' in out['config']['parallelism']
+    per_rank = out['multi_gpu']['gradient_exchange']['per_rank']
+    assert len(per_rank) == 2 and all(r['sync_bn_collectives_total'] == 2 for r in per_rank)          # one forward + one backward exchange per step
+    d = out['dry']
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(32, 64), torch.nn.BatchNorm1d(64), torch.nn.GELU(), torch.nn.Linear(64, 8))
+    x = torch.cat([torch.randn(16, 32, generator=torch.Generator().manual_seed(7 + rank)) for rank in range(2)])
+    net(x).pow(2).mean().backward()
+    ref = float(sum(p.grad.pow(2).sum() for p in net.parameters()).sqrt())
+    assert abs(d['grad_norm'] - ref) < 1e-5 * ref
+    assert abs(d['running_mean_sum'] - net[1].running_mean.sum().item()) < 1e-6
 
 
 def test_grad_reducer_unused_and_misuse():
