@@ -70,19 +70,44 @@ __device__ __forceinline__ void smpl_chain_image(const whmr_smpl_model& m, const
     const int row = lane / 4, col = lane % 4;
     if (valid && lane < 12) sG[0][lane] = (col < 3) ? sR[0][row * 3 + col] : sJ[0][row];
     __syncthreads();
-    // parents: ONE load per lane up front, then a lane read per step -- a (scalar) global load of m.parents[i] inside the loop put a memory round
-    // trip on each of the 23 dependent steps (7 of the kernel's 10 us)
+    // By TREE LEVEL (round 5): the joints of one depth only depend on the level above, so a level is ONE step -- lanes = (slot q = lane / 12 of
+    // up to five joints, transform entry lane % 12) -- and the SMPL tree (depths 0..8, at most five joints per level) takes 8 dependent LDS round
+    // trips instead of 23.  The depths come from the parents table in registers (lane reads, no memory), a level's joints from a ballot mask; any
+    // tree works (a level with more than five joints is walked in several steps).  Per joint the arithmetic is the expression of the serial loop:
+    // the same bits.
     const int par = m.parents[lane < NJ ? lane : 0];
+    int depth = 0;
+#pragma unroll
     for (int i = 1; i < NJ; ++i) {
-        const int p = __builtin_amdgcn_readlane(par, i);
-        if (valid && lane < 12) {
-            const float g0 = sG[p][row * 4 + 0], g1 = sG[p][row * 4 + 1], g2 = sG[p][row * 4 + 2], g3 = sG[p][row * 4 + 3];
-            float v;
-            if (col < 3) v = g0 * sR[i][col] + g1 * sR[i][3 + col] + g2 * sR[i][6 + col];
-            else v = g0 * (sJ[i][0] - sJ[p][0]) + g1 * (sJ[i][1] - sJ[p][1]) + g2 * (sJ[i][2] - sJ[p][2]) + g3;
-            sG[i][lane] = v;
+        const int pi = __builtin_amdgcn_readlane(par, i);
+        const int dp = __builtin_amdgcn_readlane(depth, pi < 0 ? 0 : pi);       // parents precede their children (smplx kinematic tree order)
+        if (lane == i) depth = dp + 1;
+    }
+    int maxd = 0;
+#pragma unroll
+    for (int i = 1; i < NJ; ++i) { const int di = __builtin_amdgcn_readlane(depth, i); maxd = di > maxd ? di : maxd; }
+    const int q = lane / 12, e12 = lane - q * 12;
+    for (int lev = 1; lev <= maxd; ++lev) {
+        unsigned long long mask = __ballot(valid && lane >= 1 && lane < NJ && depth == lev);
+        while (mask) {                                                             // (wave-uniform: at most ceil(joints of the level / 5) rounds)
+            int i = -1, p = 0;
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {                                          // the level's next five joints and their parents: scalar work (mask is wave-uniform)
+                const int it = mask ? (int)__builtin_ctzll(mask) : -1;
+                const int pt = __builtin_amdgcn_readlane(par, it < 0 ? 0 : it);
+                if (q == t) { i = it; p = pt; }
+                mask &= mask - 1;
+            }
+            if (valid && i >= 0) {
+                const int row2 = e12 / 4, col2 = e12 % 4;
+                const float g0 = sG[p][row2 * 4 + 0], g1 = sG[p][row2 * 4 + 1], g2 = sG[p][row2 * 4 + 2], g3 = sG[p][row2 * 4 + 3];
+                float v;
+                if (col2 < 3) v = g0 * sR[i][col2] + g1 * sR[i][3 + col2] + g2 * sR[i][6 + col2];
+                else v = g0 * (sJ[i][0] - sJ[p][0]) + g1 * (sJ[i][1] - sJ[p][1]) + g2 * (sJ[i][2] - sJ[p][2]) + g3;
+                sG[i][e12] = v;
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
     // A_i = G_i with translation  t_i - G_i[:, :3] . J_i   (lbs.py:51-55)
     for (int e = lane; valid && e < NJ * 12; e += 64) {
@@ -110,6 +135,21 @@ __device__ __forceinline__ void smpl_skin_vertex(const float (&w)[NJ], const flo
         T[4] = fmaf(w[j], r1.x, T[4]); T[5] = fmaf(w[j], r1.y, T[5]); T[6] = fmaf(w[j], r1.z, T[6]); T[7] = fmaf(w[j], r1.w, T[7]);
         T[8] = fmaf(w[j], r2.x, T[8]); T[9] = fmaf(w[j], r2.y, T[9]); T[10] = fmaf(w[j], r2.z, T[10]); T[11] = fmaf(w[j], r2.w, T[11]);
     }
+    st_f<COH>(o, fmaf(T[2], z, fmaf(T[1], y, T[0] * x)) + T[3]);
+    st_f<COH>(o + 1, fmaf(T[6], z, fmaf(T[5], y, T[4] * x)) + T[7]);
+    st_f<COH>(o + 2, fmaf(T[10], z, fmaf(T[9], y, T[8] * x)) + T[11]);
+}
+
+// the same with the image's transforms in an unaligned array (row-major [24][12])
+template <bool COH = false>
+__device__ __forceinline__ void smpl_skin_vertex_regs(const float (&w)[NJ], const float* __restrict__ A, float x, float y, float z, float* __restrict__ o) {
+    float T[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) T[e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 12; ++e) T[e] = fmaf(w[j], A[j * 12 + e], T[e]);
     st_f<COH>(o, fmaf(T[2], z, fmaf(T[1], y, T[0] * x)) + T[3]);
     st_f<COH>(o + 1, fmaf(T[6], z, fmaf(T[5], y, T[4] * x)) + T[7]);
     st_f<COH>(o + 2, fmaf(T[10], z, fmaf(T[9], y, T[8] * x)) + T[11]);

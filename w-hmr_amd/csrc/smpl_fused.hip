@@ -4,9 +4,10 @@
 //   blend + skin  work item = 64 vertices x 32 images on a 6-wave workgroup: the pose-corrective offsets pose_feature . posedirs on
 //            v_mfma_f32_32x32x2_f32 (exact f32, a sequential fma chain over k = the arithmetic of the fp32 GEMM it replaced, so the same bits): wave w
 //            owns 32 of the item's 192 (vertex, coordinate) columns, A operand = the 32 images' pose features from LDS, B operand = posedirs rows
-//            straight from global memory (re-tiled per 64-vertex chunk, all 104 k-steps in flight); the 32 x 192 offsets go through LDS to the
-//            skinning layout (thread = vertex x image subset): shape blend, + offset, T = sum_j w_j A_j, v = T [v_posed; 1].  posedirs (17 MB) is read
-//            once per 32 images.
+//            straight from global memory (re-tiled per 64-vertex chunk, all 104 k-steps in flight); the 32 x 192 offsets go through LDS to a
+//            (vertex x image subset) pass that adds the shape blend -> v_posed, in place; then the skinning T = sum_j w_j A_j ALSO runs on the f32 MFMA
+//            (round 5: [32 images, 24 joints] . [24 joints, 32 vertices] per transform entry, wave = (vertex tile, output coordinate)) and
+//            v = T [v_posed; 1] is applied in the accumulator layout.  posedirs (17 MB) is read once per 32 images.
 //   CSR tail      one workgroup per image: the 9 (+24) joint-regressor rows as a CSR gather over the skinned mesh (products through LDS, one thread per
 //            (row, coordinate) adds its segment in index order: deterministic), then smpl_stage_tail_image (joint map, markers, theta, kp_2d,
 //            kp_2d_w, cam_t, focal, the next stage's input state).
@@ -42,11 +43,13 @@ struct whmr_smpl_call {
 #define FUSED_KP 208         // pose-feature depth padded to the MFMA's k step (row 207 is zero)
 
 
-// LDS of phase 2: sPF [208][32] | sBeta [10][32] | sA [32][288] | sPO [32][192]
+// LDS of phase 2: sPF [208][32] | sBeta [10][32] | sA [32][289] | sPO [32][192].  An image's 24 x 12 skinning transforms sit 289 floats apart
+// (288 + 1): the skinning MFMAs read entry (j, e) of 32 IMAGES at once -- with a stride of 288 = 9 x 32 all of them on one LDS bank.
+#define P2_AS (NJ * 12 + 1)
 #define P2_PF 0
 #define P2_BETA (FUSED_KP * FUSED_IG)
 #define P2_A (P2_BETA + 10 * FUSED_IG)
-#define P2_PO (P2_A + FUSED_IG * NJ * 12)
+#define P2_PO (P2_A + FUSED_IG * P2_AS)
 #define P2_FLOATS (P2_PO + FUSED_IG * 3 * FUSED_VT)
 
 // COH: pose_feat / A were written by an earlier phase of the SAME kernel and the vertices are read by a later one (coherent sc1 accesses);
@@ -94,7 +97,7 @@ __device__ __forceinline__ void fused_phase2_item(const whmr_smpl_model& m, cons
 #pragma unroll
         for (int i = 0; i < NPFL; ++i) { const int e = tid + i * FUSED_NT; if (e < FUSED_KP * FUSED_IG) sPF[e] = tpf[i]; }
 #pragma unroll
-        for (int i = 0; i < NAL; ++i) { const int e = tid + i * FUSED_NT; if (e < FUSED_IG * NJ * 12) sA[e] = ta[i]; }
+        for (int i = 0; i < NAL; ++i) { const int e = tid + i * FUSED_NT; if (e < FUSED_IG * NJ * 12) sA[(e / (NJ * 12)) * P2_AS + e % (NJ * 12)] = ta[i]; }
     }
     __syncthreads();
     if (stamps) stamps[1] = wall_clock64();
@@ -123,24 +126,91 @@ __device__ __forceinline__ void fused_phase2_item(const whmr_smpl_model& m, cons
     }
     __syncthreads();
     if (stamps) stamps[2] = wall_clock64();
-    // ---- blend + skin: thread = (vertex lv = tid & 63, image subset sub = tid >> 6): images bb = sub, sub + 6, ...
+    // ---- few images in this group (B = 1 .. 6: the demo, one image per thread subset): the round-3 form -- thread = (vertex, image), shape blend + offset +
+    // skinning as a VALU fma chain straight to memory.  The matrix form below always computes a 32-image tile (4.2 us whatever B; this: ~2 us at B = 1).
+    // Both are the arithmetic of smpl_skin_vertex: the same bits (tests: three-launch vs five-launch form at B = 1 .. 130).
+    if (B - b0 <= FUSED_NT / 64) {
+        const int lv = tid & (FUSED_VT - 1), bb = tid >> 6;
+        const int v = v0 + lv;
+        if (v < NV && b0 + bb < B) {
+            const float t0 = m.v_template[3 * v], t1 = m.v_template[3 * v + 1], t2 = m.v_template[3 * v + 2];
+            float sd[30], w[NJ];
+#pragma unroll
+            for (int k = 0; k < 30; ++k) sd[k] = m.shapedirs[(size_t)k * NV + v];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) w[j] = m.lbs_weights[(size_t)j * NV + v];
+            float acc[3];
+            smpl_shape_vertex(t0, t1, t2, sd, sBeta + bb, FUSED_IG, acc);
+            const float* po = sPO + bb * (3 * FUSED_VT) + 3 * lv;
+            acc[0] += po[0]; acc[1] += po[1]; acc[2] += po[2];
+            float A1[NJ * 12];                                                         // (sA rows are not 16-B aligned any more: gather the image's transforms by value)
+#pragma unroll
+            for (int e = 0; e < NJ * 12; ++e) A1[e] = sA[bb * P2_AS + e];
+            smpl_skin_vertex_regs<COH>(w, A1, acc[0], acc[1], acc[2], p.verts + ((size_t)(b0 + bb) * NV + v) * 3);
+        }
+        __syncthreads();
+        if (stamps) stamps[3] = wall_clock64();
+        return;
+    }
+    // ---- shape blend + offset -> v_posed, IN PLACE in sPO: thread = (vertex lv = tid & 63, image subset sub = tid >> 6): images bb = sub, sub + 6, ...
+    // The skinning weights of the wave's 32 vertices (the B operand of the skinning MFMAs below) are requested first: they land under this pass.
+    const int vt = wave & 1, cc = wave >> 1;                                      // skinning: this wave's vertex tile (32 vertices) and output coordinate
+    const int vsk = v0 + vt * 32 + l31;
+    float wq[NJ / 2];
+    {
+        const int vc = vsk < NV ? vsk : NV - 1;
+#pragma unroll
+        for (int sidx = 0; sidx < NJ / 2; ++sidx) wq[sidx] = m.lbs_weights[(size_t)(2 * sidx + hi) * NV + vc];
+    }
     {
         const int lv = tid & (FUSED_VT - 1), sub = tid >> 6;
         const int v = v0 + lv;
         if (v < NV && b0 + sub < B) {
             const float t0 = m.v_template[3 * v], t1 = m.v_template[3 * v + 1], t2 = m.v_template[3 * v + 2];
-            float s[30], w[NJ];
+            float sd[30];
 #pragma unroll
-            for (int k = 0; k < 30; ++k) s[k] = m.shapedirs[(size_t)k * NV + v];
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) w[j] = m.lbs_weights[(size_t)j * NV + v];
+            for (int k = 0; k < 30; ++k) sd[k] = m.shapedirs[(size_t)k * NV + v];
             for (int bb = sub; bb < FUSED_IG; bb += FUSED_NT / 64) {
                 if (b0 + bb >= B) break;
                 float acc[3];
-                smpl_shape_vertex(t0, t1, t2, s, sBeta + bb, FUSED_IG, acc);
-                const float* po = sPO + bb * (3 * FUSED_VT) + 3 * lv;
+                smpl_shape_vertex(t0, t1, t2, sd, sBeta + bb, FUSED_IG, acc);
+                float* po = sPO + bb * (3 * FUSED_VT) + 3 * lv;
                 acc[0] += po[0]; acc[1] += po[1]; acc[2] += po[2];
-                smpl_skin_vertex<COH>(w, sA + bb * NJ * 12, acc[0], acc[1], acc[2], p.verts + ((size_t)(b0 + bb) * NV + v) * 3);
+                po[0] = acc[0]; po[1] = acc[1]; po[2] = acc[2];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- skinning on the matrix pipes (lbs.py:67-77): T = sum_j w_j A_j as [32 images, 24 joints] . [24 joints, 32 vertices] per transform entry,
+    // v_mfma_f32_32x32x2_f32 -- exact f32, a sequential fma chain over j starting from 0: the arithmetic of smpl_skin_vertex (smpl_dev.h), so the same
+    // bits.  Wave (vt, cc) owns output coordinate cc of 32 vertices x 32 images: the four entries 4 cc .. 4 cc + 3 of T (four accumulator tiles, 12
+    // MFMAs each), then v_cc = T[4cc+2] z + T[4cc+1] y + T[4cc] x + T[4cc+3] in the accumulator layout (lane = vertex, register = image).
+    // As a VALU loop (thread = vertex x image subset, 288 FMAs per pair fed by 72 broadcast ds_read_b128) this was 10 of the launch's 22 us.
+    {
+        f32x16_t T4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T4[q][r] = 0.f;
+        const float* ap = sA + l31 * P2_AS + hi * 12 + 4 * cc;                        // A operand: image l31, joint 2 s + hi, entry 4 cc + q
+#pragma unroll
+        for (int sidx = 0; sidx < NJ / 2; ++sidx) {
+            float a4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a4[q] = ap[sidx * 24 + q];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) T4[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q], wq[sidx], T4[q], 0, 0, 0);
+        }
+        // C layout: register r of lane (l31, hi) = image (r & 3) + 8 (r >> 2) + 4 hi, vertex l31 of the tile
+        if (vsk < NV) {
+            const float* vp = sPO + 3 * (vt * 32 + l31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int bb = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (b0 + bb < B) {
+                    const float x = vp[bb * (3 * FUSED_VT)], y = vp[bb * (3 * FUSED_VT) + 1], z = vp[bb * (3 * FUSED_VT) + 2];
+                    st_f<COH>(p.verts + ((size_t)(b0 + bb) * NV + vsk) * 3 + cc, fmaf(T4[2][r], z, fmaf(T4[1][r], y, T4[0][r] * x)) + T4[3][r]);
+                }
             }
         }
     }
