@@ -169,6 +169,9 @@ def lib():
         for slot, key in enumerate(('WHMR_BLK_TILE_QKV', 'WHMR_BLK_TILE_PROJ', 'WHMR_BLK_TILE_FC1', 'WHMR_BLK_TILE_FC2')):     # A/B: force a tile per ViT shape
             if os.environ.get(key):
                 l.whmr_gemm_blk_set_tile(slot, int(os.environ[key], 0))
+        if os.environ.get('WHMR_ATTN_OLD', '0') != '0':         # A/B: the blocked attention (bf16 and bf16x3) on the round-2 / round-3 kernels
+            l.whmr_attention_set_variant(1 | 16)
+            l.whmr_attention_x3_set_variant(1)
     return _lib
 
 

@@ -193,26 +193,25 @@ __global__ __launch_bounds__((NQT + att16_cfg<NQT>::NL) * 64) void attention_blk
             mx = fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
         }
         const float mxs = mx * sc;
+        // The exponentials are taken LAZILY, two key tiles (one P V step) at a time behind the MFMAs of the previous step: an MFMA executes for 16 cycles
+        // after it has issued, the wave's VALU work (4 v_exp + scale / sum / pack per tile) issues meanwhile -- as a phase of its own the softmax kept
+        // the matrix pipe idle for ~1 900 cycles per wave and item (stamps), and all waves of a SIMD sit in the same phase behind each barrier.
         f32x4_t sum4 = f32x4_t{0.f, 0.f, 0.f, 0.f};
         uint32_t pk[NQT][2];                                             // P as packed bf16: [kt][keys 4 g + (0, 1) | 4 g + (2, 3)]
+        auto expo = [&](auto kt_) {
+            ATT_IC(kt, kt_);
+            if constexpr (kt < NQT) {
+                const f32x4_t t = s[kt] * sc - mxs;
+                f32x4_t e;
 #pragma unroll
-        for (int kt = 0; kt < NQT; ++kt) {
-            const f32x4_t t = s[kt] * sc - mxs;                           // two v_pk_fma_f32
-            f32x4_t e;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(t[r]);
-            sum4 += e;
-            pk[kt][0] = pack_bf16x2(e[0], e[1]);
-            pk[kt][1] = pack_bf16x2(e[2], e[3]);
-        }
-        float sum = (sum4[0] + sum4[1]) + (sum4[2] + sum4[3]);
-        {
-            const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(sum), __float_as_uint(sum), false, false);
-            sum = __uint_as_float(a[0]) + __uint_as_float(a[1]);
-            const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(sum), __float_as_uint(sum), false, false);
-            sum = __uint_as_float(b[0]) + __uint_as_float(b[1]);
-        }
-        const float inv = __builtin_amdgcn_rcpf(sum);                    // 1 ulp; the result is rounded to bf16
+                for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(t[r]);
+                sum4 += e;
+                pk[kt][0] = pack_bf16x2(e[0], e[1]);
+                pk[kt][1] = pack_bf16x2(e[2], e[3]);
+            }
+        };
+        expo(std::integral_constant<int, 0>{});
+        expo(std::integral_constant<int, 1>{});
         ATT_STAMP(it, 3);
         // O^T = V^T P^T: o[dt][r] = O[query c][d = 16 dt + 4 g + r]
         f32x4_t o[4];
@@ -251,7 +250,19 @@ __global__ __launch_bounds__((NQT + att16_cfg<NQT>::NL) * 64) void attention_blk
                 vf.h[1] = vr[cur][2 * dt + 1];
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf.v, o[dt], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);                           // the next step's probabilities: VALU work under the MFMAs just issued
+            expo(std::integral_constant<int, 2 * j + 2>{});
+            expo(std::integral_constant<int, 2 * j + 3>{});
+            __builtin_amdgcn_sched_barrier(0);
         });
+        float sum = (sum4[0] + sum4[1]) + (sum4[2] + sum4[3]);
+        {
+            const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(sum), __float_as_uint(sum), false, false);
+            sum = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+            const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(sum), __float_as_uint(sum), false, false);
+            sum = __uint_as_float(b[0]) + __uint_as_float(b[1]);
+        }
+        const float inv = __builtin_amdgcn_rcpf(sum);                    // 1 ulp; the result is rounded to bf16
         ATT_STAMP(it, 4);
         // store: lane (g, c) holds d = 16 dt + 4 g + (0..3) = half of the 16-B piece 2 dt + (g >> 1).  Even groups complete the piece of dt = 2 t
         // with their odd neighbour's half, odd groups the piece of dt = 2 t + 1 with their even neighbour's (v_permlane16_swap exchanges the odd
@@ -484,26 +495,23 @@ __global__ __launch_bounds__((NQT + att16x3_cfg<NQT>::NL) * 64) void attention_b
             mx = fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
         }
         const float mxs = mx * sc;
+        // lazy exponentials + hi / lo split, one P V step ahead of its MFMAs (see the bf16 kernel)
         f32x4_t sum4 = f32x4_t{0.f, 0.f, 0.f, 0.f};
         uint32_t ph[NQT][2], pl[NQT][2];
+        auto expo = [&](auto kt_) {
+            ATT_IC(kt, kt_);
+            if constexpr (kt < NQT) {
+                const f32x4_t t = s[kt] * sc - mxs;
+                f32x4_t e;
 #pragma unroll
-        for (int kt = 0; kt < NQT; ++kt) {
-            const f32x4_t t = s[kt] * sc - mxs;
-            f32x4_t e;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(t[r]);
-            sum4 += e;
-            split_bf16x2(e[0], e[1], ph[kt][0], pl[kt][0]);
-            split_bf16x2(e[2], e[3], ph[kt][1], pl[kt][1]);
-        }
-        float sum = (sum4[0] + sum4[1]) + (sum4[2] + sum4[3]);
-        {
-            const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(sum), __float_as_uint(sum), false, false);
-            sum = __uint_as_float(a[0]) + __uint_as_float(a[1]);
-            const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(sum), __float_as_uint(sum), false, false);
-            sum = __uint_as_float(b[0]) + __uint_as_float(b[1]);
-        }
-        const float inv = 1.0f / sum;
+                for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(t[r]);
+                sum4 += e;
+                split_bf16x2(e[0], e[1], ph[kt][0], pl[kt][0]);
+                split_bf16x2(e[2], e[3], ph[kt][1], pl[kt][1]);
+            }
+        };
+        expo(std::integral_constant<int, 0>{});
+        expo(std::integral_constant<int, 1>{});
         __builtin_amdgcn_s_barrier();                                                // C: V is in LDS
         // O^T = V^T P^T with split operands: per (key pair j, d tile) v_lo p_hi + v_hi p_lo + v_hi p_hi.  Ring of three sets, one d tile each
         // (4 transposing reads: hi / lo x the two 4-key groups)
@@ -544,7 +552,19 @@ __global__ __launch_bounds__((NQT + att16x3_cfg<NQT>::NL) * 64) void attention_b
             o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl.v, fh.v, o[dt], 0, 0, 0);
             o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh.v, fl.v, o[dt], 0, 0, 0);
             o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh.v, fh.v, o[dt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (dt == 1) expo(std::integral_constant<int, 2 * j + 2>{});             // the next step's probabilities under this step's MFMAs
+            if constexpr (dt == 3) expo(std::integral_constant<int, 2 * j + 3>{});
+            __builtin_amdgcn_sched_barrier(0);
         });
+        float sum = (sum4[0] + sum4[1]) + (sum4[2] + sum4[3]);
+        {
+            const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(sum), __float_as_uint(sum), false, false);
+            sum = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+            const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(sum), __float_as_uint(sum), false, false);
+            sum = __uint_as_float(b[0]) + __uint_as_float(b[1]);
+        }
+        const float inv = 1.0f / sum;
         __builtin_amdgcn_s_barrier();                                                // D: V may be overwritten
         // store O as a hi / lo pair (the bf16 kernel's piece assembly, once per part)
         const int b = item / H, h = item - b * H;
