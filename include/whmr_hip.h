@@ -146,9 +146,10 @@ int whmr_layernorm_blk_x3(const float* x, const float* gamma, const float* beta,
 int whmr_patch_im2col_blk_x3(const float* x, void* cols_hi, void* cols_lo, int B, int Cin, int H, int W, int P, int pad, long sb, long sc, long sh,
                              long sw, void* stream);
 int whmr_attention_blk_x3(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, int B, int N, int H, float scale, void* stream);
-/* A/B switch: 1 = the round-3 kernel (one workgroup per (image, head), 32-row tiles) for every N instead of the persistent 16-row-tile kernel
- * (csrc/attention_blk16.hip, N <= 208); 0 = default. */
-int whmr_attention_x3_set_variant(int old_kernel);
+/* A/B switch.  bit 0: the round-3 kernel (one workgroup per (image, head), 32-row tiles) for every N instead of the persistent 16-row-tile kernel
+ * (csrc/attention_blk16.hip, N <= 208).  bits 4-7: k + 1 forces k half-microseconds between the start of the CU quarters of the persistent kernel
+ * (0 = by shape: 1 us at 13 query tiles, none below).  0 = default. */
+int whmr_attention_x3_set_variant(int variant);
 
 /* exact-fp32 MFMA GEMM (v_mfma_f32_32x32x2_f32), any M/N/K.  Parity mode of the calls above, plus always:
  * Regressor fc1/fc2/decpose/decshape/deccam (whmr.py:118-126), Global_Orient_Regressor (whmr.py:295-301),

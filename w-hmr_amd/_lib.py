@@ -172,6 +172,8 @@ def lib():
         if os.environ.get('WHMR_ATTN_OLD', '0') != '0':         # A/B: the blocked attention (bf16 and bf16x3) on the round-2 / round-3 kernels
             l.whmr_attention_set_variant(1 | 16)
             l.whmr_attention_x3_set_variant(1)
+        if os.environ.get('WHMR_ATTN_X3_STAGGER'):               # A/B: k half-microseconds between the CU quarters of the split-bf16 attention (default: by shape)
+            l.whmr_attention_x3_set_variant((int(os.environ['WHMR_ATTN_X3_STAGGER']) + 1) << 4)
     return _lib
 
 

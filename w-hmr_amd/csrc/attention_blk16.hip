@@ -362,7 +362,7 @@ template <int CNT> __device__ __forceinline__ void att_wait_tr4(uint2 (&f)[4]) {
 template <int NQT>
 __global__ __launch_bounds__((NQT + att16x3_cfg<NQT>::NL) * 64) void attention_blk16_x3_kernel(const bf16_t* __restrict__ qkv_hi, const bf16_t* __restrict__ qkv_lo,
                                                                                             bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo,
-                                                                                            int items, int N, int H, float scale) {
+                                                                                            int items, int N, int H, float scale, int stagger) {
     using cfg = att16x3_cfg<NQT>;
     constexpr int NK2 = cfg::NK2, KP = cfg::KP, VP = cfg::VP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -372,6 +372,11 @@ __global__ __launch_bounds__((NQT + att16x3_cfg<NQT>::NL) * 64) void attention_b
     const int C = H * 64, ld8 = (3 * C) >> 3, oc8 = C >> 3;
     int item = blockIdx.x;
     if (item >= items) return;
+    // The workgroups of a persistent launch run their items in step: all 256 CUs enter the MFMA phases together.  At 13 query tiles (16 waves)
+    // that pattern makes the package drop its clock for the WHOLE forward (2126 -> 2046 MHz, profiles/r05_power_clock_attention_stagger.txt),
+    // which costs the GEMMs more than this kernel saves.  Starting the four quarters of every XCD's CUs 1 us apart keeps the clock; `stagger`
+    // = half-microseconds between quarters (0 where the clock does not react: <= 12 query tiles).
+    for (int i = ((blockIdx.x >> 3) & 3) * stagger; i > 0; --i) __builtin_amdgcn_s_sleep(16);
 
     if (wave >= NQT) {
         // ---- loaders
@@ -640,8 +645,9 @@ int whmr_attention_blk16_launch(const void* qkv, void* out, int B, int N, int H,
 }
 
 template <int NQT>
-static int att16x3_launch(const void* qh, const void* ql, void* oh, void* ol, int B, int N, int H, float scale, hipStream_t st) {
+static int att16x3_launch(const void* qh, const void* ql, void* oh, void* ol, int B, int N, int H, float scale, hipStream_t st, int lab) {
     using cfg = att16x3_cfg<NQT>;
+    const int stagger = lab ? lab - 1 : (NQT >= 13 ? 2 : 0);          // lab = k + 1 forces k (A/B)
     auto kern = attention_blk16_x3_kernel<NQT>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -652,23 +658,23 @@ static int att16x3_launch(const void* qh, const void* ql, void* oh, void* ol, in
     const int items = B * H;
     const int cus = att16_cus();
     const int grid = items < cus ? items : cus;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3((NQT + cfg::NL) * 64), cfg::LDS, st, (const bf16_t*)qh, (const bf16_t*)ql, (bf16_t*)oh, (bf16_t*)ol, items, N, H, scale);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3((NQT + cfg::NL) * 64), cfg::LDS, st, (const bf16_t*)qh, (const bf16_t*)ql, (bf16_t*)oh, (bf16_t*)ol, items, N, H, scale, stagger);
     WHMR_CHECK_LAUNCH();
     return 0;
 }
 
 // called by whmr_attention_blk_x3 (attention_x3.hip) for 64 < N <= 208; -1 = not covered (the caller keeps its own kernel)
-int whmr_attention_blk16_x3_launch(const void* qh, const void* ql, void* oh, void* ol, int B, int N, int H, float scale, hipStream_t st) {
+int whmr_attention_blk16_x3_launch(const void* qh, const void* ql, void* oh, void* ol, int B, int N, int H, float scale, hipStream_t st, int lab) {
     switch ((N + 15) / 16) {
-        case 5: return att16x3_launch<5>(qh, ql, oh, ol, B, N, H, scale, st);
-        case 6: return att16x3_launch<6>(qh, ql, oh, ol, B, N, H, scale, st);
-        case 7: return att16x3_launch<7>(qh, ql, oh, ol, B, N, H, scale, st);
-        case 8: return att16x3_launch<8>(qh, ql, oh, ol, B, N, H, scale, st);
-        case 9: return att16x3_launch<9>(qh, ql, oh, ol, B, N, H, scale, st);
-        case 10: return att16x3_launch<10>(qh, ql, oh, ol, B, N, H, scale, st);
-        case 11: return att16x3_launch<11>(qh, ql, oh, ol, B, N, H, scale, st);
-        case 12: return att16x3_launch<12>(qh, ql, oh, ol, B, N, H, scale, st);
-        case 13: return att16x3_launch<13>(qh, ql, oh, ol, B, N, H, scale, st);
+        case 5: return att16x3_launch<5>(qh, ql, oh, ol, B, N, H, scale, st, lab);
+        case 6: return att16x3_launch<6>(qh, ql, oh, ol, B, N, H, scale, st, lab);
+        case 7: return att16x3_launch<7>(qh, ql, oh, ol, B, N, H, scale, st, lab);
+        case 8: return att16x3_launch<8>(qh, ql, oh, ol, B, N, H, scale, st, lab);
+        case 9: return att16x3_launch<9>(qh, ql, oh, ol, B, N, H, scale, st, lab);
+        case 10: return att16x3_launch<10>(qh, ql, oh, ol, B, N, H, scale, st, lab);
+        case 11: return att16x3_launch<11>(qh, ql, oh, ol, B, N, H, scale, st, lab);
+        case 12: return att16x3_launch<12>(qh, ql, oh, ol, B, N, H, scale, st, lab);
+        case 13: return att16x3_launch<13>(qh, ql, oh, ol, B, N, H, scale, st, lab);
     }
     return -1;
 }

@@ -201,14 +201,14 @@ static int launch_x3(const void* qh, const void* ql, void* oh, void* ol, int B, 
     return 0;
 }
 
-int whmr_attention_blk16_x3_launch(const void* qh, const void* ql, void* oh, void* ol, int B, int N, int H, float scale, hipStream_t st);      // attention_blk16.hip
+int whmr_attention_blk16_x3_launch(const void* qh, const void* ql, void* oh, void* ol, int B, int N, int H, float scale, hipStream_t st, int lab);      // attention_blk16.hip
 static int g_x3_old = 0;       // whmr_set_option(120, 1): the round-3 kernel above instead of the persistent 16-row-tile one (A/B, tests)
-extern "C" int whmr_attention_x3_set_variant(int old_kernel) { g_x3_old = old_kernel; return 0; }
+extern "C" int whmr_attention_x3_set_variant(int variant) { g_x3_old = variant; return 0; }
 
 extern "C" int whmr_attention_blk_x3(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, int B, int N, int H, float scale, void* stream) {
     if (B <= 0 || N <= 64 || N > 256 || H <= 0 || scale <= 0.f || !qkv_lo || !out_lo) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
-    if (!g_x3_old && N <= 208) return whmr_attention_blk16_x3_launch(qkv_hi, qkv_lo, out_hi, out_lo, B, N, H, scale, st);
+    if (!(g_x3_old & 1) && N <= 208) return whmr_attention_blk16_x3_launch(qkv_hi, qkv_lo, out_hi, out_lo, B, N, H, scale, st, g_x3_old >> 4);
     switch ((N + 31) / 32) {
         case 3: return launch_x3<3>(qkv_hi, qkv_lo, out_hi, out_lo, B, N, H, scale, st);
         case 4: return launch_x3<4>(qkv_hi, qkv_lo, out_hi, out_lo, B, N, H, scale, st);
