@@ -29,7 +29,7 @@ bench vit224_bf16x3 --numerics bf16x3 --steps 20 --warmup 5
 bench vit224_fp32 --numerics fp32 --steps 5 --warmup 2 --no-cpu
 bench whmr --workload whmr
 bench whmr_bf16x3 --workload whmr --numerics bf16x3 --no-cpu --steps 10 --warmup 3
-bench whmr_train --workload whmr_train --steps 10 --warmup 3
+bench whmr_train --workload whmr_train --steps 30 --warmup 30
 bench whmr_bf16x3_b1 --workload whmr --numerics bf16x3 --batch 1 --no-cpu --no-parity --steps 50 --warmup 10
 bench vit256x192 --workload vit256x192 --no-cpu
 bench vitl256x192_b32 --workload vitl256x192 --batch 32 --no-cpu
