@@ -372,8 +372,8 @@ __global__ __launch_bounds__((NQT + att16x3_cfg<NQT>::NL) * 64) void attention_b
     const int C = H * 64, ld8 = (3 * C) >> 3, oc8 = C >> 3;
     int item = blockIdx.x;
     if (item >= items) return;
-    // The workgroups of a persistent launch run their items in step: all 256 CUs enter the MFMA phases together.  At 13 query tiles (16 waves)
-    // that pattern makes the package drop its clock for the WHOLE forward (2126 -> 2046 MHz, profiles/r05_power_clock_attention_stagger.txt),
+    // The workgroups of a persistent launch run their items in step: all 256 CUs enter the same phase together.  At 13 query tiles (16 waves)
+    // the package then drops its clock for the WHOLE forward (measured; why exactly is a hypothesis) (2126 -> 2046 MHz, profiles/r05_power_clock_attention_stagger.txt),
     // which costs the GEMMs more than this kernel saves.  Starting the four quarters of every XCD's CUs 1 us apart keeps the clock; `stagger`
     // = half-microseconds between quarters (0 where the clock does not react: <= 12 query tiles).
     for (int i = ((blockIdx.x >> 3) & 3) * stagger; i > 0; --i) __builtin_amdgcn_s_sleep(16);
