@@ -48,7 +48,7 @@ class SyncGroup:
 
     def all_reduce(self, t):
         """sum ``t`` (fp64 vector) over the ranks in place; one collective"""
-        if dist.is_initialized() and dist.get_world_size(self.group) > 1:
+        if dist.is_initialized() and (dist.get_world_size(self.group) > 1 or self.always):      # always: also with ONE rank (the hardware run of the RCCL call on a 1-GPU box)
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
             self.collectives += 1
             self.bytes += t.numel() * t.element_size()
