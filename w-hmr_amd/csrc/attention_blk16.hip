@@ -647,7 +647,7 @@ int whmr_attention_blk16_launch(const void* qkv, void* out, int B, int N, int H,
 template <int NQT>
 static int att16x3_launch(const void* qh, const void* ql, void* oh, void* ol, int B, int N, int H, float scale, hipStream_t st, int lab) {
     using cfg = att16x3_cfg<NQT>;
-    const int stagger = lab ? lab - 1 : (NQT >= 13 ? 2 : 0);          // lab = k + 1 forces k (A/B)
+
     auto kern = attention_blk16_x3_kernel<NQT>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -658,6 +658,8 @@ static int att16x3_launch(const void* qh, const void* ql, void* oh, void* ol, in
     const int items = B * H;
     const int cus = att16_cus();
     const int grid = items < cus ? items : cus;
+    // lab = k + 1 forces k (A/B); by default only a launch that fills the chip is staggered (a few workgroups neither move the clock nor should wait)
+    const int stagger = lab ? lab - 1 : ((NQT >= 13 && items >= cus) ? 2 : 0);
     hipLaunchKernelGGL(kern, dim3(grid), dim3((NQT + cfg::NL) * 64), cfg::LDS, st, (const bf16_t*)qh, (const bf16_t*)ql, (bf16_t*)oh, (bf16_t*)ol, items, N, H, scale, stagger);
     WHMR_CHECK_LAUNCH();
     return 0;
