@@ -75,6 +75,9 @@ int whmr_gemm_bf16_big(const struct whmr_gemm* p, int tile, void* stream);
 int whmr_set_option(int key, int value);
 /* Same, K sliced over `splits` blocks per tile (fp32 partial sums in p->workspace, deterministic epilogue pass). */
 int whmr_gemm_bf16_split(const struct whmr_gemm* p, int tile, int splits, void* stream);
+/* Split-K without the finishing pass: raw fp32 partial sums of `splits` equal K slices as [splits][M][N] planes at p->C (no bias / activation /
+ * residual; K % (64 * splits) == 0) -- for a consumer that adds the planes itself (whmr_tz_fold). */
+int whmr_gemm_bf16_split_raw(const struct whmr_gemm* p, int tile, int splits, void* stream);
 
 /* ---- forward glue: the O(batch) arithmetic between the kernels of WHMR.forward, one launch each (geometry.hip) ----
  * whmr_cam_head: camera-calibration head post-processing (whmr.py:513-522; utils/cam_utils.py:121-145; pare softargmax1d / batch_euler2matrix):
@@ -351,6 +354,14 @@ int whmr_attention_bwd(const void* qkv, const void* o, const float* dout, const 
  * convolution leaves its W_lo product in columns 64..127), weights w [5][7*7][64] fp32 -> tokens [B,5,OH*OW] fp32. */
 int whmr_tz_conv1(const void* x, int x_bf16, const float* w, float* tok, int B, int IH, int IW, void* stream);
 
+/* Tail of the COMPOSED Tz-head convolutions (whmr.py:418-421 as applied at :567-571; inference views): conv1(conv0(x)) == Conv2d(256,5,k25,s6), evaluated as
+ * the implicit GEMM P[(b,Y,m),(jA,jB,o)] = sum_{q,p,ci} x[b,6Y+q,6m+p,ci] * Wc[o,ci,q+6jA,p+6jB] (whmr_gemm_bf16 / whmr_gemm_f32 in conv-gather mode over the
+ * [B,IH,IW/6,6C] view of the map: kernel 6x1, stride 6x1; every map byte is read once).  This entry sums the 25 shifted partials:
+ * tok[b,o,r*OW+s] = sum_{jA,jB} P[(b,r+jA,s+jB),(jA*5+jB)*5+o].  P: fp32 rows of ldp floats, [B,OHp,OWp] pixel rows; halves = 2 adds column 128+n
+ * (bf16x3: the W_lo product as extra output columns); nsplit partial planes split_stride floats apart are added (1 = a finished GEMM output). */
+int whmr_tz_fold(const float* P, int ldp, int halves, int nsplit, long split_stride, float* tok, int B, int OHp, int OWp, int OH, int OW,
+                 void* stream);
+
 /* estimate_translation (utils/geometry.py:344-408; trainer host stall): S [B,J,3], joints_2d [B,J,3] = (x, y, conf);
  * joints j0..j0+nj-1 enter the weighted least squares; out [B,3]. */
 int whmr_estimate_translation(const float* S, const float* joints_2d, int B, int J, int j0, int nj, float focal, float img_w,
@@ -490,6 +501,18 @@ int whmr_iuv_losses(const void* y, int y_bf16, long ld, const float* iuv, long s
  * d(g[0] loss_U + g[1] loss_V + g[2] loss_IndexUV + g[3] loss_segAnn) / dy, g [4] on the device. */
 int whmr_iuv_losses_bwd(const void* y, int y_bf16, long ld, const float* iuv, long sb, long sc, long sh, long sw, int B, int H, int W,
                         float point_weight, const float* g, void* dy, long ldg, void* stream);
+
+/* ---- attainable ceilings of the box the benchmark runs on (csrc/ceilings.hip; SURVEY 8(d) "datasheet numbers AND measure on the box"); replaces no
+ * reference code -- bench.py calls them after its timed region and reports them as roofline.attainable / sclk_mhz_observed.
+ * whmr_mfma_ceiling: `blocks` workgroups x 4 waves, each `iters` x 8 register-fed v_mfma_f32_16x16x32_bf16 on random operands
+ *   (flop = blocks * 4 * iters * 8 * 16384); stats[0] / stats[1] = s_memrealtime (100 MHz) / s_memtime (shader clock) ticks of one wave over its loop.
+ * whmr_hbm_copy: streaming copy of `bytes` (multiple of 16) -- moves 2 * bytes through HBM.
+ * whmr_clock_probe_begin (side stream) / _end (observed stream): one wave samples both counters at its start and when _end raises the flag;
+ *   state = 6 x uint64, zeroed by the caller: [0] flag, [1..2] realtime / shader clock at start, [3..4] at end, [5] 1 = left through limit_seconds. */
+int whmr_mfma_ceiling(int blocks, int iters, float* sink, unsigned long long* stats, void* stream);
+int whmr_hbm_copy(const void* src, void* dst, long bytes, void* stream);
+int whmr_clock_probe_begin(unsigned long long* state, double limit_seconds, void* stream);
+int whmr_clock_probe_end(unsigned long long* state, void* stream);
 
 #ifdef __cplusplus
 }

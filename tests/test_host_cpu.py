@@ -704,3 +704,26 @@ def test_ctypes_structures_match_the_c_header_layout(tmp_path):
         assert int(got[cname]) == ctypes.sizeof(cls), (cname, got[cname], ctypes.sizeof(cls))
         for fname, _ in cls._fields_:
             assert int(got['%s.%s' % (cname, fname)]) == getattr(cls, fname).offset, (cname, fname)
+
+
+def test_composed_tz_weights_equal_the_two_convolutions():
+    """whmr.py:418-421: conv1(conv0(x)) == Conv2d(256 -> 5, k25, s6) with the composed weights, in the space-to-depth GEMM + 25-term fold form the
+    HIP path evaluates (models/whmr.py::compose_tz_weights / _tz_tokens_composed; csrc/tz_head.hip::tz_fold_kernel) -- host algebra, torch fp64."""
+    import torch.nn.functional as F
+    from whmr_amd.models.whmr import compose_tz_weights
+    g = torch.Generator().manual_seed(0)
+    B, H, W, C = 1, 128, 96, 16
+    x = torch.randn(B, H, W, C, generator=g, dtype=torch.float64)
+    w0 = torch.randn(64, C, 7, 7, generator=g, dtype=torch.float64) * 0.05
+    w1 = torch.randn(5, 64, 7, 7, generator=g, dtype=torch.float64) * 0.05
+    ref = F.conv2d(F.conv2d(x.permute(0, 3, 1, 2), w0, stride=3), w1, stride=2)
+    G = compose_tz_weights(w0, w1)
+    assert G.shape == (128, 36 * C) and G.dtype == torch.float32 and not G[125:].any()
+    xp = torch.cat([x, x.new_zeros(B, 22 * 6 - H, W, C)], 1).view(B, 22, 6, 16, 6 * C).permute(0, 1, 3, 2, 4).reshape(B * 22 * 16, 36 * C)
+    P = (xp @ G.double().t()).view(B, 22, 16, 128)
+    tok = torch.zeros_like(ref)
+    for jA in range(5):
+        for jB in range(5):
+            for o in range(5):
+                tok[:, o] += P[:, jA:jA + 18, jB:jB + 12, (jA * 5 + jB) * 5 + o]
+    assert ((tok - ref).abs().max() / ref.abs().max()).item() < 1e-6

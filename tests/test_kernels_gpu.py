@@ -665,6 +665,63 @@ def test_tz_conv1_matches_conv2d(dev, IH, IW, dt):
     assert _rel(tok.cpu(), ref) < 1e-5
 
 
+@pytest.mark.parametrize('mode', ['fp32', 'bf16x3', 'bf16'])
+def test_tz_composed_convolution_matches_the_two_convolutions(dev, mode):
+    """whmr.py:418-421 / :567-571: Conv2d(256, 64, k7, s3) -> Conv2d(64, 5, k7, s2) (no bias, nothing in between) as ONE Conv2d(256, 5, k25, s6),
+    evaluated as the space-to-depth implicit GEMM + ``whmr_tz_fold`` (models/whmr.py::_tz_tokens_composed) against torch's two conv2d calls in fp64.
+    B = 3 (ragged last row tile); the bottom rows Y = 21 read past the map (zero source)."""
+    from whmr_amd import _lib as L
+    from whmr_amd.models.whmr import compose_tz_weights
+    g = torch.Generator().manual_seed(11)
+    B, H, W, C = 3, 128, 96, 256
+    x = torch.relu(torch.randn(B, H, W, C, generator=g))
+    w0 = torch.randn(64, C, 7, 7, generator=g) / math.sqrt(49 * C)
+    w1 = torch.randn(5, 64, 7, 7, generator=g) / math.sqrt(49 * 64)
+    ref = F.conv2d(F.conv2d(x.double().permute(0, 3, 1, 2), w0.double(), stride=3), w1.double(), stride=2).reshape(B, 5, -1)
+    G = compose_tz_weights(w0, w1).to(dev)
+    xd = x.to(dev)
+    if mode == 'bf16':
+        a, gw, Cp, halves, tol = xd.bfloat16(), G.bfloat16(), C, 1, 1e-2
+    elif mode == 'bf16x3':
+        a = torch.cat(L.split_bf16(xd), -1).contiguous()
+        hi, lo = L.split_bf16(G)
+        hi, lo = hi.view(128, 36, C), lo.view(128, 36, C)
+        gw = torch.cat([torch.cat([hi, hi], -1), torch.cat([lo, torch.zeros_like(lo)], -1)], 0).reshape(256, -1).contiguous()
+        Cp, halves, tol = 2 * C, 2, 2e-5
+    else:
+        a, gw, Cp, halves, tol = xd, G, C, 1, 1e-5
+    P = torch.full((B * 22 * 16, gw.shape[0]), float('nan'), device=dev)
+    L.gemm(a.view(B, H, 16, 6 * Cp), gw, P, conv=dict(IH=H, IW=16, Cin=6 * Cp, OH=22, OW=16, KW=1, SH=6, SW=1, PH=0, PW=0))
+    tok = torch.full((B * 5, 216), float('nan'), device=dev)
+    L.tz_fold(P, tok, B, 22, 16, 18, 12, halves=halves)
+    assert _rel(tok.view(B, 5, -1).cpu(), ref) < tol
+    if mode != 'fp32':          # two raw split-K planes (whmr_gemm_bf16_split_raw) added by the fold: what the model launches at batch 64
+        P2 = torch.full((2, B * 22 * 16, gw.shape[0]), float('nan'), device=dev)
+        L.gemm(a.view(B, H, 16, 6 * Cp), gw, P2, conv=dict(IH=H, IW=16, Cin=6 * Cp, OH=22, OW=16, KW=1, SH=6, SW=1, PH=0, PW=0),
+               tile=192 if mode == 'bf16x3' else 64, raw_splits=2)
+        tok2 = torch.full((B * 5, 216), float('nan'), device=dev)
+        L.tz_fold(P2, tok2, B, 22, 16, 18, 12, halves=halves, nsplit=2, split_stride=P2[0].numel())
+        assert _rel(tok2.view(B, 5, -1).cpu(), ref) < tol
+        assert _rel(tok2.cpu(), tok.cpu()) < 1e-5
+
+
+def test_tz_fold_split_planes(dev):
+    """whmr_tz_fold over nsplit partial planes and two column halves == the same sums done by torch"""
+    from whmr_amd import _lib as L
+    g = torch.Generator().manual_seed(5)
+    B, ns = 2, 3
+    P = torch.randn(ns, B * 22 * 16, 256, generator=g)
+    full = (P[:, :, :128] + P[:, :, 128:]).sum(0).view(B, 22, 16, 128)
+    ref = torch.zeros(B, 5, 18, 12)
+    for jA in range(5):
+        for jB in range(5):
+            for o in range(5):
+                ref[:, o] += full[:, jA:jA + 18, jB:jB + 12, (jA * 5 + jB) * 5 + o]
+    tok = torch.empty(B * 5, 216, device=dev)
+    L.tz_fold(P.to(dev), tok, B, 22, 16, 18, 12, halves=2, nsplit=ns, split_stride=B * 22 * 16 * 256)
+    assert _rel(tok.view(B, 5, 18, 12).cpu(), ref) < 1e-5
+
+
 def test_mat_to_aa_backward_matches_autograd(dev):
     """whmr_mat_to_aa_bwd against torch autograd through the oracle's rotation_matrix_to_angle_axis (bit-identical to the reference's
     utils/geometry.py:54-83 on the fixture): rotations that take each of the four quaternion branches (angles up to pi), and the NON-orthonormal

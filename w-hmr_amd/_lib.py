@@ -76,6 +76,7 @@ _SIGS = {
     'whmr_conv_dw_tn_bf16': [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _L, _P, _P],
     'whmr_gemm_bf16_big': [C.POINTER(WhmrGemm), _I, _P],
     'whmr_gemm_bf16_split': [C.POINTER(WhmrGemm), _I, _I, _P],
+    'whmr_gemm_bf16_split_raw': [C.POINTER(WhmrGemm), _I, _I, _P],
     'whmr_set_option': [_I, _I],
     'whmr_gemm_blk': [C.POINTER(WhmrGemmBlk), _P],
     'whmr_gemm_blk_tile': [C.POINTER(WhmrGemmBlk), _I, _P],
@@ -115,6 +116,11 @@ _SIGS = {
     'whmr_attention_fwd_train': [_P, _P, _P, _I, _I, _I, _I, _F, _P],
     'whmr_attention_bwd': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
     'whmr_tz_conv1': [_P, _I, _P, _P, _I, _I, _I, _P],
+    'whmr_tz_fold': [_P, _I, _I, _I, _L, _P, _I, _I, _I, _I, _I, _P],
+    'whmr_mfma_ceiling': [_I, _I, _P, _P, _P],
+    'whmr_hbm_copy': [_P, _P, _L, _P],
+    'whmr_clock_probe_begin': [_P, C.c_double, _P],
+    'whmr_clock_probe_end': [_P, _P],
     'whmr_estimate_translation': [_P, _P, _I, _I, _I, _I, _F, _F, _F, _P, _P],
     'whmr_transpose_cast': [_P, _I, _L, _P, _I, _L, _I, _I, _I, _P],
     'whmr_colsum': [_P, _I, _L, _I, _I, _P, _I, _P, _P],
@@ -219,7 +225,7 @@ PROFILE = None        # bench.py sets this to a list: (kernel, flops, start_even
 
 def gemm(a, w, out, bias=None, residual=None, res_row_mod=0, act=ACT_NONE, conv=None, scatter=None, M=None,
          lda=None, glds=True, tile=None, phases=None, res_first=False, splits=None, row_scale=None, accumulate=False,
-         trans_a=False, trans_w=False, pre_out=None, gelu_bwd_of=None, split3_out=None, split_parts=3):
+         trans_a=False, trans_w=False, pre_out=None, gelu_bwd_of=None, split3_out=None, split_parts=3, raw_splits=None):
     """out = act(a . w^T + bias) + residual.  a/w dtype selects the kernel (bf16 MFMA or exact-fp32 MFMA).
 
     conv = dict(IH, IW, Cin, OH, OW, KW, SH, SW, PH, PW): a is an NHWC image [B, IH, IW, Cin], rows are output pixels.
@@ -308,6 +314,10 @@ def gemm(a, w, out, bias=None, residual=None, res_row_mod=0, act=ACT_NONE, conv=
     if scatter is None and phases is None and (a.dtype == torch.bfloat16 or conv is None):
         ws = splitk_workspace(a.device)
         p.workspace, p.workspace_bytes = ws.data_ptr(), ws.numel()
+    if raw_splits:                          # bf16 kernel: `out` = [raw_splits, M, N] fp32 planes of raw split-K partial sums (no finishing pass)
+        assert a.dtype == torch.bfloat16 and tile is not None and out.dtype == torch.float32 and out.is_contiguous() and out.numel() == raw_splits * p.M * N
+        _check(lib().whmr_gemm_bf16_split_raw(C.byref(p), int(tile), int(raw_splits), _stream()), 'whmr_gemm_bf16_split_raw')
+        return out
     if tile is not None:                    # explicit tile id (A/B tests), see gemm_bf16_big.hip
         assert a.dtype == torch.bfloat16
         if splits and splits > 1:
@@ -1154,6 +1164,17 @@ def tz_conv1(x_nhwc, w, tok):
     return tok
 
 
+def tz_fold(P, tok, B, OHp, OWp, OH, OW, halves=1, nsplit=1, split_stride=0):
+    """tok[b, o, r*OW + s] = sum_{jA, jB} P[(b, r + jA, s + jB), (jA*5 + jB)*5 + o] (+ column 128 + n when halves == 2): the 25-term tail of the composed
+    Tz-head convolution Conv2d(256, 5, k25, s6) == conv1(conv0(.)) (whmr.py:418-421,567-571) evaluated as a space-to-depth implicit GEMM."""
+    _dev(P, tok)
+    assert P.dtype == torch.float32 and P.is_contiguous() and tok.dtype == torch.float32 and tok.is_contiguous()
+    ldp = P.shape[-1]
+    assert P.numel() >= (nsplit - 1) * split_stride + B * OHp * OWp * ldp and tok.numel() == B * 5 * OH * OW
+    _check(lib().whmr_tz_fold(P.data_ptr(), ldp, halves, nsplit, split_stride, tok.data_ptr(), B, OHp, OWp, OH, OW, _stream()), 'whmr_tz_fold')
+    return tok
+
+
 def estimate_translation(S, joints_2d, j0, nj, focal, img_w, img_h):
     _dev(S, joints_2d)
     S, joints_2d = _f32c(S), _f32c(joints_2d)
@@ -1330,3 +1351,71 @@ def csr_apply3(csr, x, n_out, out=None, accumulate=False):
     _check(lib().whmr_csr_apply3(ptr.data_ptr(), col.data_ptr(), val.data_ptr(), x.data_ptr(), n_in, out.data_ptr(), n_out, B, int(accumulate),
                                  _stream()), 'whmr_csr_apply3')
     return out
+
+
+# ---- attainable ceilings of this box (csrc/ceilings.hip): measurement aids of bench.py, not on the data path ---------------------------------
+def mfma_ceiling(device, seconds=0.15):
+    """-> dict(tflops, sclk_mhz): register-fed bf16 MFMA stream on every SIMD (two waves each, random operands), sized from a short calibration launch
+    to run ~``seconds``; the shader clock is read inside the kernel (s_memtime per s_memrealtime tick)."""
+    sink = torch.zeros(64, dtype=torch.float32, device=device)
+    stats = torch.zeros(2, dtype=torch.int64, device=device)
+    blocks = 2 * torch.cuda.get_device_properties(device).multi_processor_count
+
+    def run(iters):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _check(lib().whmr_mfma_ceiling(blocks, iters, sink.data_ptr(), stats.data_ptr(), _stream()), 'whmr_mfma_ceiling')
+        e1.record()
+        torch.cuda.synchronize(device)
+        return e0.elapsed_time(e1) * 1e-3
+    t = run(20000)
+    iters = int(min(max(20000 * seconds / max(t, 1e-6), 20000), 50e6))
+    run(iters)                                  # warm: the package clock settles under the load
+    t = run(iters)
+    st = stats.tolist()
+    return {'tflops': blocks * 4 * iters * 8 * 16384.0 / t / 1e12, 'sclk_mhz': st[1] / max(st[0], 1) * 100.0, 'seconds': t}
+
+
+def hbm_copy_ceiling(device, mbytes=1024, reps=5):
+    """-> GB/s moved (read + write) by a streaming copy of ``mbytes`` MiB"""
+    n = mbytes * (1 << 20)
+    src = torch.empty(n, dtype=torch.uint8, device=device).random_(0, 255)
+    dst = torch.empty_like(src)
+    _check(lib().whmr_hbm_copy(src.data_ptr(), dst.data_ptr(), n, _stream()), 'whmr_hbm_copy')
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        _check(lib().whmr_hbm_copy(src.data_ptr(), dst.data_ptr(), n, _stream()), 'whmr_hbm_copy')
+    e1.record()
+    torch.cuda.synchronize(device)
+    assert torch.equal(src[:4096], dst[:4096]) and torch.equal(src[-4096:], dst[-4096:])
+    return 2.0 * n * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
+class ClockProbe:
+    """Average shader clock while other streams work: ``with ClockProbe(dev) as p: <launch work on the current stream>``; ``p.mhz`` afterwards.
+    One wave on a side stream samples s_memtime / s_memrealtime at its start and when the observed stream reaches the end marker (bounded wait)."""
+
+    def __init__(self, device, limit_seconds=2.0):
+        self.dev, self.limit = device, limit_seconds
+        self.state = torch.zeros(6, dtype=torch.int64, device=device)
+        self.side = torch.cuda.Stream(device=device)
+        self.mhz = self.seconds = None
+        self.timed_out = False
+
+    def __enter__(self):
+        self.side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(self.side):
+            _check(lib().whmr_clock_probe_begin(self.state.data_ptr(), float(self.limit), self.side.cuda_stream), 'whmr_clock_probe_begin')
+        return self
+
+    def __exit__(self, *exc):
+        _check(lib().whmr_clock_probe_end(self.state.data_ptr(), _stream()), 'whmr_clock_probe_end')
+        torch.cuda.current_stream(self.dev).wait_stream(self.side)
+        torch.cuda.synchronize(self.dev)
+        st = self.state.tolist()
+        ticks = st[3] - st[1]
+        self.seconds = ticks / 1e8
+        self.mhz = (st[4] - st[2]) / max(ticks, 1) * 100.0
+        self.timed_out = bool(st[5])
+        return False

@@ -1,0 +1,100 @@
+// Attainable ceilings of THIS box, measured next to the benchmark ("take gfx950 datasheet numbers and also measure on the box").
+// bench.py runs them after its timed region and reports them beside the nominal peaks:
+//   whmr_mfma_ceiling   register-fed v_mfma_f32_16x16x32_bf16 stream on random operands on every SIMD (no LDS, no memory): the dense bf16 matrix
+//                       rate the package sustains at the clock its governor grants under that load (nominal 2.5 PF assumes 2.4 GHz);
+//   whmr_hbm_copy       16-byte-per-lane streaming copy (read + write): the HBM rate a memory-bound kernel can reach;
+//   whmr_clock_probe_*  one wave that samples s_memtime (shader clock) and s_memrealtime (100 MHz) when it starts and when a flag is raised on
+//                       another stream -- the average shader clock of the XCD it sits on while the benchmark's steps run beside it.
+// Not on the data path: nothing here computes a result the model uses.
+#include "common.h"
+
+// stats[0] = s_memrealtime ticks (100 MHz) of wave 0 of block 0 over its loop, stats[1] = s_memtime (shader clocks) over the same span
+__global__ __launch_bounds__(256) void mfma_ceiling_kernel(int iters, unsigned seed, float* sink, unsigned long long* stats) {
+    const int lane = threadIdx.x & 63;
+    // random bf16 operands in [-2, 2): exponent field 0x3f80..0x3fff, random sign and mantissa (switching activity like real data, no inf / nan)
+    unsigned s = seed ^ (blockIdx.x * 2654435761u) ^ (threadIdx.x * 40503u);
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (short)(((s >> 16) & 0x807f) | 0x3f80); };
+    bf16x8_t a[2], b[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { a[i][e] = rnd(); b[i][e] = rnd(); }
+    f32x4_t acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const bool rec = blockIdx.x == 0 && threadIdx.x == 0;
+    unsigned long long r0 = 0, c0 = 0;
+    if (rec) { r0 = __builtin_amdgcn_s_memrealtime(); c0 = __builtin_amdgcn_s_memtime(); }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i & 1], b[(i >> 1) & 1], acc[i], 0, 0, 0);
+    }
+    if (rec) {
+        const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        stats[0] = r1 - r0; stats[1] = c1 - c0;
+    }
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (t == 12345.678f) sink[lane] = t;                  // keeps the accumulators live
+}
+
+// One launch: `blocks` workgroups of 4 waves (one per SIMD), 8 independent MFMAs per wave and iteration.  flop = blocks * 4 * iters * 8 * 16384.
+extern "C" int whmr_mfma_ceiling(int blocks, int iters, float* sink, unsigned long long* stats, void* stream) {
+    if (blocks <= 0 || iters <= 0 || !sink || !stats) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(mfma_ceiling_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, 0x9e3779b9u, sink, stats);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void hbm_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, long n16) {
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+}
+
+extern "C" int whmr_hbm_copy(const void* src, void* dst, long bytes, void* stream) {
+    if (!src || !dst || bytes <= 0 || (bytes & 15)) return (int)hipErrorInvalidValue;
+    const long n16 = bytes >> 4;
+    long blocks = (n16 + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(hbm_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)src, (uint4*)dst, n16);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+// state[0] = flag (raised by whmr_clock_probe_end), state[1..2] = realtime / shader clock at the start, state[3..4] = at the end, state[5] = 1 when the
+// probe left through its time limit instead of the flag.  The wait is BOUNDED (limit_ticks of the 100 MHz counter): a probe that is never released
+// ends by itself.
+__global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long* state, unsigned long long limit_ticks) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
+    state[1] = r0; state[2] = c0;
+    unsigned long long r = r0;
+    bool timed_out = false;
+    while (__hip_atomic_load(&state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ull) {
+        __builtin_amdgcn_s_sleep(64);
+        r = __builtin_amdgcn_s_memrealtime();
+        if (r - r0 > limit_ticks) { timed_out = true; break; }
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    state[3] = r1; state[4] = c1; state[5] = timed_out ? 1ull : 0ull;
+}
+
+__global__ void clock_probe_raise_kernel(unsigned long long* state) {
+    if (threadIdx.x == 0) __hip_atomic_store(&state[0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// state: 6 x uint64 in device memory, zeroed by the caller.  begin goes on a SIDE stream, end on the stream whose work is being observed.
+extern "C" int whmr_clock_probe_begin(unsigned long long* state, double limit_seconds, void* stream) {
+    if (!state || !(limit_seconds > 0.0) || limit_seconds > 5.0) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, (unsigned long long)(limit_seconds * 1e8));
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int whmr_clock_probe_end(unsigned long long* state, void* stream) {
+    if (!state) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(clock_probe_raise_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}

@@ -98,6 +98,21 @@ extern "C" int whmr_gemm_bf16_split(const whmr_gemm* pp, int tile, int splits_in
     return 0;
 }
 
+// Split-K WITHOUT the finishing pass: the raw fp32 partial sums of `splits` equal K slices go to C as [splits][M][N] planes (ldc = N) for a consumer that
+// adds them itself (whmr_tz_fold: the composed Tz-head convolution, M = 22528, N = 128, K = 9216 -- 176 tiles of 128 x 128 leave a third of the CUs idle
+// and each walks 144 K steps alone; two slices fill the chip).  No bias / activation / residual / second output; K must divide into `splits` slices of
+// whole 64-element steps.
+extern "C" int whmr_gemm_bf16_split_raw(const whmr_gemm* pp, int tile, int splits, void* stream) {
+    const whmr_gemm& p = *pp;
+    if (splits < 2 || p.K % (64 * splits) || p.n_phase > 1 || p.c_mode != 0 || p.out_bf16 || p.bias || p.residual || p.row_scale || p.C2 || p.act ||
+        (p.epi_flags & ~8) || (p.N & 3))
+        return (int)hipErrorInvalidValue;
+    whmr_gemm q = p;
+    q.ldc = p.N;
+    q.split_k = p.K / splits;
+    return whmr_gemm_bf16_big(&q, tile, stream);
+}
+
 extern "C" int whmr_gemm_bf16(const whmr_gemm* pp, int flags, void* stream) {
     const whmr_gemm& p = *pp;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % 64)) return (int)hipErrorInvalidValue;

@@ -47,3 +47,47 @@ extern "C" int whmr_tz_conv1(const void* x, int x_bf16, const float* w, float* t
     WHMR_CHECK_LAUNCH();
     return 0;
 }
+
+// ---- Composed form of the two Tz-head convolutions (whmr.py:418-421 applied at :567-571), inference views only.
+// conv1(conv0(x)) has no bias and no activation in between, so it IS one Conv2d(256, 5, k25, s6):
+//     Wc[o, ci, A, B] = sum_{c1, 3u + a = A, 3v + b = B} w1[o, c1, u, v] * w0[c1, ci, a, b]            (built once on the host side in fp64).
+// With y = 6 Y + q, x = 6 m + p the NHWC map [B, 128, 96, C] is the dense matrix [(b, y, m), (p, ci)] and
+//     P[(b, Y, m), (jA, jB, o)] = sum_{q, p, ci} x[b, 6 Y + q, 6 m + p, ci] * Wc[o, ci, q + 6 jA, p + 6 jB]
+// is an implicit GEMM (kernel 6 x 1, stride 6 x 1 over the [128, 16, 6 C] view) that reads every map byte exactly ONCE -- the 7 x 7 / stride-3 form
+// gathered each pixel ~5 times through the LDS-DMA path for N = 64 columns of MFMA work.  This kernel is the 25-term tail
+//     tok[b, o, r, s] = sum_{jA, jB} P[(b, r + jA, s + jB), (jA, jB, o)]        (output pixel (r, s) reads input rows 6 r + A, A = q + 6 jA)
+// over `nsplit` split-K partial planes and `halves` column halves (bf16x3: the W_lo product sits in columns 128 + n).  One wave per (b, r):
+// lane = (s, o), 25 loads of 5 contiguous floats per pixel row.
+__global__ __launch_bounds__(256) void tz_fold_kernel(const float* __restrict__ P, int ldp, int halves, int nsplit, long split_stride,
+                                                      float* __restrict__ tok, int B, int OHp, int OWp, int OH, int OW) {
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= B * OH) return;
+    const int b = w / OH, r = w - b * OH;
+    for (int e = lane; e < OW * 5; e += 64) {
+        const int s = e / 5, o = e - s * 5;
+        float acc = 0.f;
+        for (int sp = 0; sp < nsplit; ++sp) {
+            const float* Ps = P + sp * split_stride;
+#pragma unroll
+            for (int jA = 0; jA < 5; ++jA)
+#pragma unroll
+                for (int jB = 0; jB < 5; ++jB) {
+                    const float* row = Ps + ((size_t)(b * OHp + r + jA) * OWp + s + jB) * ldp + (jA * 5 + jB) * 5 + o;
+                    acc += row[0];
+                    if (halves == 2) acc += row[128];
+                }
+        }
+        tok[((size_t)b * 5 + o) * (OH * OW) + r * OW + s] = acc;
+    }
+}
+
+extern "C" int whmr_tz_fold(const float* P, int ldp, int halves, int nsplit, long split_stride, float* tok, int B, int OHp, int OWp, int OH,
+                            int OW, void* stream) {
+    if (B <= 0 || OH <= 0 || OW <= 0 || OH + 4 > OHp || OW + 4 > OWp || (halves != 1 && halves != 2) || nsplit < 1 || ldp < 128 * halves)
+        return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(tz_fold_kernel, dim3((B * OH + 3) / 4), dim3(256), 0, (hipStream_t)stream, P, ldp, halves, nsplit, split_stride, tok, B, OHp,
+                       OWp, OH, OW);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}

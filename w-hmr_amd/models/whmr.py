@@ -95,6 +95,21 @@ class _Cache:
 _CAM_STREAMS = {}
 
 
+def compose_tz_weights(w0, w1):
+    """whmr.py:418-421: Conv2d(256, 64, k7, s3, bias=False) followed by Conv2d(64, 5, k7, s2, bias=False) is the single convolution
+    Conv2d(256, 5, k25, s6) with Wc[o, ci, A, B] = sum_{c1, 3u + a = A, 3v + b = B} w1[o, c1, u, v] * w0[c1, ci, a, b] (fp64 here).  Returned as the weight
+    matrix of the space-to-depth implicit GEMM (``WHMR._tz_tokens_composed``): [128, 36 Ci] fp32, row n = (jA * 5 + jB) * 5 + o (125 used), column
+    k = (q * 6 + p) * Ci + ci, entry Wc[o, ci, q + 6 jA, p + 6 jB] (zero where a tap index exceeds 24)."""
+    w0, w1 = w0.double(), w1.double()                                                   # [64, Ci, 7, 7], [5, 64, 7, 7]
+    Ci = w0.shape[1]
+    wc = torch.zeros(5, Ci, 30, 30, dtype=torch.float64, device=w0.device)              # taps 25..29 stay zero (A = q + 6 jA <= 29)
+    for u in range(7):
+        for v in range(7):
+            wc[:, :, 3 * u:3 * u + 7, 3 * v:3 * v + 7] += torch.einsum('oc,cikl->oikl', w1[:, :, u, v], w0)
+    g = wc.view(5, Ci, 5, 6, 5, 6).permute(2, 4, 0, 3, 5, 1).reshape(125, 36 * Ci)      # [(jA, jB, o), (q, p, ci)]
+    return torch.cat([g, g.new_zeros(3, g.shape[1])], 0).float().contiguous()           # 128 rows
+
+
 class Regressor(nn.Module):
     """whmr.py:42-269.  fc1 -> fc2 (no nonlinearity) -> decpose/decshape/deccam residual heads -> SMPL -> projections."""
 
@@ -357,6 +372,8 @@ class WHMR(nn.Module):
         self._init_cache = None
         self.overlap_camera = True          # cam_model on a side stream beside the backbone (joined before the global-orientation head)
         self.overlap_tz = True              # Tz head on a side stream beside the regressor loop (its outputs finalized after the join)
+        self.compose_tz = os.environ.get('WHMR_COMPOSE_TZ', '1') != '0'   # inference: the two Tz-head convolutions as ONE composed k25 / s6 convolution (False: the two-convolution form)
+        self._tz_gemm_kw = {}               # explicit tile / split-K of the composed convolution's GEMM (A/B probes)
         self._tz_ones = {}
         self.eval()
 
@@ -427,6 +444,29 @@ class WHMR(nn.Module):
         bn = self.est_Tz[2]
         return self._cache.get(('tz', self.numerics), [c0, c1, bn.weight, bn.bias, bn.running_mean, bn.running_var], build)
 
+    def _tz_composed_operands(self):
+        """The two Tz-head convolutions (whmr.py:418-421: Conv2d(256, 64, k7, s3) -> Conv2d(64, 5, k7, s2), no bias, nothing in between) composed into
+        ONE Conv2d(256, 5, k25, s6): Wc[o, ci, A, B] = sum_{c1, 3u + a = A, 3v + b = B} w1[o, c1, u, v] w0[c1, ci, a, b], built in fp64.  Stored as the weight
+        of the space-to-depth implicit GEMM of ``_tz_head``: rows n = (jA, jB, o) (125, padded to 128), columns k = (q, p, ci) with A = q + 6 jA,
+        B = p + 6 jB (zero where A or B > 24).  Inference views only -- the training graph keeps the two convolutions (their weights get gradients)."""
+        c0, c1 = self.conv[0].weight, self.conv[1].weight
+
+        def build():
+            Ci = c0.shape[1]
+            g = compose_tz_weights(c0.detach(), c1.detach())                             # [128, 36 Ci] fp32
+            if self.numerics == 'bf16x3':
+                # map operand [x_hi | x_lo] per pixel (2 C channels); rows n < 128: [W_hi | W_hi] (hi.hi + lo.hi), rows 128 + n: [W_lo | 0] (hi.lo)
+                hi, lo = L.split_bf16(g)
+                hi, lo = hi.view(128, 36, Ci), lo.view(128, 36, Ci)
+                g = torch.cat([torch.cat([hi, hi], -1), torch.cat([lo, torch.zeros_like(lo)], -1)], 0).reshape(256, -1).contiguous()
+            elif self._dt != torch.float32:
+                g = L.cast_bf16(g)
+            bn = self.est_Tz[2]
+            bn4 = torch.stack([bn.weight.detach()[0], bn.bias.detach()[0], bn.running_mean[0], bn.running_var[0]]).float().contiguous()
+            return g, bn4
+        bn = self.est_Tz[2]
+        return self._cache.get(('tzc', self.numerics), [c0, c1, bn.weight, bn.bias, bn.running_mean, bn.running_var], build)
+
     # ------------------------------------------------------------------ stages
     def _deconv(self, i, x_nhwc, x_split=None):
         """-> (map [B, 2H, 2W, Cout], its split-bf16 operand form or None).  ``x_split``: the [hi | lo | hi] operand form of ``x_nhwc`` that the
@@ -464,9 +504,11 @@ class WHMR(nn.Module):
         """whmr.py:567-577.  ``f_split`` (bf16x3): the [hi | lo] operand form of the map, as the last deconv stage's epilogue wrote it."""
         B, H, W, C = f_nhwc.shape
         dev = f_nhwc.device
-        w0, w1, bn4 = self._tz_operands()
         assert (C, self.conv[1].weight.shape[0], self.conv[0].weight.shape[0]) == (256, 5, 64)
         H1, W1 = (H - 7) // 3 + 1, (W - 7) // 3 + 1
+        if self.compose_tz and W % 6 == 0:
+            return self._tz_tokens_tail(self._tz_tokens_composed(f_nhwc, f_split), B, dev, self._tz_composed_operands()[1])
+        w0, w1, bn4 = self._tz_operands()
         y0 = torch.empty(B, H1, W1, 128 if self.numerics == 'bf16x3' else 64, dtype=self._dt, device=dev)     # NHWC, mode dtype (feeds the 2nd conv)
         if self.numerics == 'bf16x3':
             fs = f_split if f_split is not None else torch.cat(L.split_bf16(f_nhwc), -1).contiguous()
@@ -478,6 +520,40 @@ class WHMR(nn.Module):
         D = H2 * W2
         t = torch.empty(B * 5, D, dtype=torch.float32, device=dev)                  # == conv1(...).reshape(B, 5, -1), whmr.py:571
         L.tz_conv1(y0, w1, t.view(B, 5, D))                                           # N = 5 output channels: one wave per pixel
+        return self._tz_tokens_tail(t, B, dev, bn4)
+
+    def _tz_tokens_composed(self, f_nhwc, f_split):
+        """whmr.py:567-571 as ONE convolution: tokens [B * 5, 18 * 12] = Conv2d(256, 5, k25, s6)(map), see ``_tz_composed_operands``.  The map
+        [B, H, W, C] is read as [B, H, W / 6, 6 C]: an implicit GEMM with a 6 x 1 kernel at stride 6 x 1 (rows (b, Y, m), K = (q, p, ci)) that touches
+        every map byte once, then ``L.tz_fold`` adds the 25 shifted partial sums of each output pixel."""
+        B, H, W, C = f_nhwc.shape
+        g, _ = self._tz_composed_operands()
+        H1, W1 = (H - 7) // 3 + 1, (W - 7) // 3 + 1
+        H2, W2 = (H1 - 7) // 2 + 1, (W1 - 7) // 2 + 1
+        OHp, OWp = (H + 5) // 6, W // 6
+        assert OHp >= H2 + 4 and OWp >= W2 + 4
+        x3 = self.numerics == 'bf16x3'
+        if x3:
+            fs = f_split if f_split is not None else torch.cat(L.split_bf16(f_nhwc), -1).contiguous()
+            a, Cp = fs, 2 * C
+        else:
+            a, Cp = f_nhwc, C
+        # N = 128 (256) columns only: the chooser's 176 (88) tiles leave CUs idle while each walks 144 (288) K steps alone.  Two raw split-K planes
+        # that tz_fold adds (tools/r6_tz_probe.py, batch 64: bf16 174 -> 124 us on the 128 x 128 tile, bf16x3 444 -> 270 us on the 192 x 256 tile);
+        # small batches keep the chooser (it slices K itself when the grid is small)
+        kw = dict(self._tz_gemm_kw)
+        M = B * OHp * OWp
+        if not kw and self._dt != torch.float32 and M >= 8192:
+            kw = dict(tile=192 if x3 else 64, raw_splits=2)
+        ns = kw.get('raw_splits') or 1
+        P = torch.empty(ns, M, g.shape[0], dtype=torch.float32, device=f_nhwc.device)
+        L.gemm(a.view(B, H, OWp, 6 * Cp), g, P if ns > 1 else P[0], conv=dict(IH=H, IW=OWp, Cin=6 * Cp, OH=OHp, OW=OWp, KW=1, SH=6, SW=1, PH=0, PW=0), **kw)
+        t = torch.empty(B * 5, H2 * W2, dtype=torch.float32, device=f_nhwc.device)
+        return L.tz_fold(P, t, B, OHp, OWp, H2, W2, halves=2 if x3 else 1, nsplit=ns, split_stride=M * g.shape[0])
+
+    def _tz_tokens_tail(self, t, B, dev, bn4):
+        """whmr.py:572-577: the timm Block over the 5 tokens, mean over tokens, est_Tz."""
+        D = t.shape[1]
         td = self.transformer_decoder
         h = torch.empty_like(t)
         qkv = torch.empty(B * 5, 3 * D, dtype=torch.float32, device=dev)
