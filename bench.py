@@ -60,6 +60,10 @@ def parse(argv=None):
     ap.add_argument('--batchnorm', default='auto', choices=('auto', 'sync', 'local'),
                     help='whmr_train: BatchNorm statistics of the four trained layers -- sync = over all ranks (the reference, core/trainer.py:83), local = per GPU; '
                          'auto = sync at world size > 1, local on one GPU (sync on one GPU runs the split kernels with a no-op exchange)')
+    ap.add_argument('--wrap', default='reducer', choices=('reducer', 'ddp'),
+                    help='whmr_train: how the data-parallel exchange is driven -- reducer = whmr_amd.parallel (GradReducer + convert_sync_batchnorm, default), '
+                         'ddp = the reference\'s own two lines (core/trainer.py:83-86): nn.SyncBatchNorm.convert_sync_batchnorm(model) then '
+                         'DistributedDataParallel(model, device_ids=[gpu], find_unused_parameters=True); needs a process group (torch.distributed.run)')
     ap.add_argument('--always-bucket', action='store_true',
                     help='whmr_train: pack and exchange the gradient buckets even at world size 1 (one-rank RCCL smoke of the reducer on a 1-GPU box)')
     ap.add_argument('--no-secondary', action='store_true',
@@ -142,14 +146,26 @@ def build_workload(args, dev):
         # BatchNorm: the reference converts every BatchNorm to SyncBatchNorm before DDP (core/trainer.py:83) -- at world size > 1 the four trained layers
         # take their statistics and gradients over ALL ranks (one packed fp64 all-reduce per layer and direction, whmr_amd.parallel.sync_bn)
         sync_bn = args.batchnorm == 'sync' or (args.batchnorm == 'auto' and world > 1)
-        if sync_bn:
-            from whmr_amd.parallel import convert_sync_batchnorm
-            convert_sync_batchnorm(m, always=(world == 1))
+        call = m
+        if args.wrap == 'ddp':
+            # the reference's own wrap, verbatim (core/trainer.py:83-86): torch swaps the BatchNorm modules for nn.SyncBatchNorm (whmr_amd honours them:
+            # parallel/sync_bn.py::sync_of) and DDP's reducer exchanges the gradients the HIP autograd nodes hand to autograd; no GradReducer
+            import torch.distributed as tdist
+            from torch.nn.parallel import DistributedDataParallel
+            if not tdist.is_initialized():
+                raise SystemExit('bench.py --wrap ddp needs a process group: run under torch.distributed.run (one rank is enough)')
+            m = torch.nn.SyncBatchNorm.convert_sync_batchnorm(m)
+            call = DistributedDataParallel(m, device_ids=[dev.index], find_unused_parameters=True)
+            sync_bn, use_graph, red = True, False, None
+        else:
+            if sync_bn:
+                from whmr_amd.parallel import convert_sync_batchnorm
+                convert_sync_batchnorm(m, always=(world == 1))          # (world > 1: on its own communicator, beside the gradient buckets' -- ADVICE r5)
+            red = None if use_graph else GradReducer(params, groups=[n.startswith('feature_extractor') for n, _ in named], always_bucket=args.always_bucket)
+            if red is not None:
+                red.attach(m.feature_extractor.backbone)          # the ViT node publishes its gradients block by block: buckets exchange under its backward
         args.sync_bn = sync_bn
         args.sync_group = getattr(m, 'whmr_sync_group', None)
-        red = None if use_graph else GradReducer(params, groups=[n.startswith('feature_extractor') for n, _ in named], always_bucket=args.always_bucket)
-        if red is not None:
-            red.attach(m.feature_extractor.backbone)          # the ViT node publishes its gradients block by block: buckets exchange under its backward
         args.reducer = red
         rank = int(os.environ.get('RANK', '0'))
         inp = {k: v.to(dev) for k, v in synth.make_inputs(args.batch, 7 + rank).items()}
@@ -197,7 +213,7 @@ def build_workload(args, dev):
         def fwd_bwd():
             for p in params:
                 p.grad = None
-            out, _ = m(*a, is_train=True)
+            out, _ = call(*a, is_train=True)
             sup = [out['smpl_out'][l][k] for l in range(1, 4) for k in keys]
             if args.loss == 'multi-tensor':
                 loss = MeanSquares.apply(*sup)
@@ -792,9 +808,12 @@ def multi_rank_report(args, dist, world, dt_own, rank_map, red, dry, dev):
                    collectives_per_step=getattr(args, 'reducer_stats', red.stats)['collectives'] / max(args.steps, 1),
                    bytes_exchanged_per_step=getattr(args, 'reducer_stats', red.stats)['bytes_exchanged'] / max(args.steps, 1),
                    buckets=len(red.buckets), bucket_bytes=[b['numel'] * 4 for b in red.buckets], unused_parameters=len(red.skipped))
-        sg = getattr(args, 'sync_group', None)
-        if sg is not None:
-            own.update(sync_bn_collectives_total=sg.collectives, sync_bn_bytes_total=sg.bytes)
+    sg = getattr(args, 'sync_group', None)
+    if sg is None and getattr(args, 'wrap', 'reducer') == 'ddp':
+        from whmr_amd.parallel.sync_bn import auto_sync_groups      # torch nn.SyncBatchNorm modules: the group sync_of made for them
+        sg = (auto_sync_groups() or [None])[0]
+    if sg is not None:
+        own.update(sync_bn_collectives_total=sg.collectives, sync_bn_bytes_total=sg.bytes)
     try:
         dist.all_gather_object(rows, own)
     except Exception as e:                       # noqa: BLE001
@@ -809,6 +828,10 @@ def multi_rank_report(args, dist, world, dt_own, rank_map, red, dry, dev):
             rep['rccl_version'] = '.'.join(str(v) for v in torch.cuda.nccl.version())
         except Exception as e:                           # noqa: BLE001
             rep['rccl_version'] = 'unavailable (%s)' % type(e).__name__
+    if red is None and any('sync_bn_collectives_total' in r for r in rows if r):
+        rep['sync_batchnorm'] = {'per_rank': [{k: r[k] for k in r if k.startswith('sync_bn_')} for r in rows if r],
+                                 'note': 'wrap = ddp: torch DistributedDataParallel exchanges the gradients (its reducer keeps no counters here); the BatchNorm '
+                                         'statistics of the nn.SyncBatchNorm modules travel as packed fp64 all-reduces of whmr_amd.parallel.sync_bn'}
     if red is not None:
         rep['gradient_exchange'] = {
             'per_rank': [{k: r[k] for k in r if k != 'ms_per_step'} for r in rows],
@@ -847,6 +870,37 @@ def dryrun_workload(args, dev):
     from whmr_amd.parallel.sync_bn import batch_norm_1d
     params = list(net.parameters()) + list(unused.parameters())
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.wrap == 'ddp':
+        # the reference's wrap (core/trainer.py:83-86) around the stand-in: cross-rank BatchNorm statistics (this package's exchanges: batch_norm_1d ->
+        # sync_of) under torch's OWN DistributedDataParallel reducer with find_unused_parameters -- pins the order of the BatchNorm all-reduces
+        # relative to DDP's bucket all-reduces on ONE communicator across two gloo ranks
+        from torch.nn.parallel import DistributedDataParallel
+
+        class StandIn(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.net, self.unused = net, unused
+
+            def forward(self, inp):
+                h = batch_norm_1d(self.net[0](inp), self.net[1])
+                return self.net[3](self.net[2](h))
+        # (torch's DDP refuses a CPU module that holds nn.SyncBatchNorm layers -- "SyncBatchNorm layers only work with GPU modules" -- so the CPU stand-in
+        # carries this package's mark on a plain BatchNorm1d, on the DEFAULT group: the same exchanges, sharing DDP's communicator; the two torch lines
+        # verbatim run in tests/test_train_gpu.py::test_reference_syncbn_ddp_wrap_world1_rccl)
+        mod = convert_sync_batchnorm(StandIn(), dedicated=False)
+        ddp = DistributedDataParallel(mod, find_unused_parameters=True)
+        opt = torch.optim.Adam(params, lr=1e-3)
+        args.sync_bn, args.sync_group = True, mod.whmr_sync_group
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            loss = ddp(x).pow(2).mean()
+            loss.backward()
+            opt.step()
+            return loss
+        args.dry_state = (net, unused, None)
+        args.reducer = None
+        return step, None, x, (1, 32)
     sync_bn = args.batchnorm == 'sync' or (args.batchnorm == 'auto' and world > 1)
     if sync_bn:                                  # the REAL cross-rank BatchNorm protocol (whmr_amd.parallel.sync_bn) on the stand-in's BatchNorm1d
         convert_sync_batchnorm(net)
@@ -888,7 +942,7 @@ def main(argv=None):
         torch.cuda.set_device(local)
         dev = torch.device('cuda', local)
     dist = None
-    if world > 1 or (args.always_bucket and 'MASTER_ADDR' in os.environ and 'RANK' in os.environ):    # (one-rank RCCL smoke under torch.distributed.run)
+    if world > 1 or ((args.always_bucket or args.wrap == 'ddp') and 'MASTER_ADDR' in os.environ and 'RANK' in os.environ):    # (one-rank RCCL smoke under torch.distributed.run)
         import torch.distributed as dist
         import datetime
         tmo = datetime.timedelta(seconds=max(60.0, min(args.rank_timeout, 1800.0)))      # a rank that never arrives fails the collective instead of hanging it
@@ -989,6 +1043,8 @@ def main(argv=None):
             else:
                 bn = 'BatchNorm: local batch statistics + running-stat broadcast from rank 0 (--batchnorm local; the reference uses SyncBatchNorm, core/trainer.py:83)'
             par = 'dp%d (RCCL all-reduce of the gradients in 128 MiB buckets; %s)' % (n_ranks, bn)
+            if args.wrap == 'ddp':
+                par = 'dp%d (torch DistributedDataParallel(find_unused_parameters=True) over nn.SyncBatchNorm.convert_sync_batchnorm(model): the reference\'s own wrap, core/trainer.py:83-86)' % n_ranks
         else:
             par = 'replicas x%d (no data-path collective)' % n_ranks
         res = {
@@ -1084,8 +1140,9 @@ def main(argv=None):
                 net, unused, red = st
                 res['dry'] = {'unused_grad_is_none': all(p.grad is None for p in unused.parameters()),
                               'grad_norm': float(sum(p.grad.pow(2).sum() for p in net.parameters()).sqrt()),
-                              'running_mean_sum': float(net[1].running_mean.sum()), 'buckets': len(red.buckets),
-                              'skipped_params': len(red.skipped)}
+                              'running_mean_sum': float(net[1].running_mean.sum()), 'buckets': len(red.buckets) if red is not None else None,
+                              'skipped_params': len(red.skipped) if red is not None else None, 'wrap': args.wrap,
+                              'batchnorm_class': type(net[1]).__name__}
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.destroy_process_group()

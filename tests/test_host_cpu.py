@@ -324,6 +324,30 @@ def test_bench_train_entry_two_ranks_sync_batchnorm_gloo():
     assert abs(d['running_mean_sum'] - net[1].running_mean.sum().item()) < 1e-6
 
 
+def test_bench_train_entry_two_ranks_torch_ddp_wrap_gloo():
+    """`bench.py --workload whmr_train --gpus 2 --wrap ddp`: torch's OWN `DistributedDataParallel(find_unused_parameters=True)` (core/trainer.py:84-86)
+    around the stand-in, with the cross-rank BatchNorm statistics exchanged by this package on the SAME communicator as DDP's buckets (torch refuses
+    nn.SyncBatchNorm inside a CPU module, so the stand-in carries this package's mark; the torch class itself runs in the GPU twin,
+    tests/test_train_gpu.py::test_reference_syncbn_ddp_wrap_world1_rccl): two gloo ranks, gradient / running statistics of ONE process on the 32
+    samples of both ranks; then four steps (DDP rebuilds its buckets after the first)."""
+    out = _run_bench('--gpus', '2', '--steps', '1', '--warmup', '0', '--workload', 'whmr_train', '--wrap', 'ddp')
+    assert out['n_gpus'] == 2 and 'torch DistributedDataParallel' in out['config']['parallelism']
+    d = out['dry']
+    assert d['wrap'] == 'ddp' and d['unused_grad_is_none']
+    # the timed step, the instrumented step is absent in a dry run, the clock-probe loop is GPU-only: one forward + one backward exchange per executed step
+    per_rank = out['multi_gpu']['sync_batchnorm']['per_rank']
+    assert len(per_rank) == 2 and per_rank[0] == per_rank[1] and per_rank[0]['sync_bn_collectives_total'] == 2
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(32, 64), torch.nn.BatchNorm1d(64), torch.nn.GELU(), torch.nn.Linear(64, 8))
+    x = torch.cat([torch.randn(16, 32, generator=torch.Generator().manual_seed(7 + rank)) for rank in range(2)])
+    net(x).pow(2).mean().backward()
+    ref = float(sum(p.grad.pow(2).sum() for p in net.parameters()).sqrt())
+    assert abs(d['grad_norm'] - ref) < 1e-5 * ref
+    assert abs(d['running_mean_sum'] - net[1].running_mean.sum().item()) < 1e-6
+    out3 = _run_bench('--gpus', '2', '--steps', '3', '--warmup', '1', '--workload', 'whmr_train', '--wrap', 'ddp')
+    assert out3['multi_gpu']['sync_batchnorm']['per_rank'][0]['sync_bn_collectives_total'] == 8
+
+
 def test_grad_reducer_unused_and_misuse():
     """single process, always_bucket: unused parameters are skipped (grad None), a second backward before finish() raises, and a
     skipped parameter that later gets a gradient raises"""

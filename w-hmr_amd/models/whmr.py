@@ -371,6 +371,7 @@ class WHMR(nn.Module):
         self._cache = _Cache()
         self._init_cache = None
         self.overlap_camera = True          # cam_model on a side stream beside the backbone (joined before the global-orientation head)
+        self.camera_launch = os.environ.get('WHMR_CAM_LAUNCH', 'vit')      # where the camera branch's launches are issued: 'vit' | 'loop' | 'early' (see _forward_eval)
         self.overlap_tz = True              # Tz head on a side stream beside the regressor loop (its outputs finalized after the join)
         self.compose_tz = os.environ.get('WHMR_COMPOSE_TZ', '1') != '0'   # inference: the two Tz-head convolutions as ONE composed k25 / s6 convolution (False: the two-convolution form)
         self._tz_gemm_kw = {}               # explicit tile / split-K of the composed convolution's GEMM (A/B probes)
@@ -642,19 +643,36 @@ class WHMR(nn.Module):
         # The camera-calibration ResNet-50 (whmr.py:509-522) only feeds the global-orientation head at the very end (whmr.py:630): it runs on a
         # SIDE stream beside the backbone / deconvs / regressor loop and is joined just before that head.  Its few-tile launches slot into the CUs
         # the big GEMM grids leave idle (tile-grid tails); under GraphedForward the fork / join become two branches of the captured graph.
-        side = None
+        # WHERE its launches are issued matters under a HIP-graph replay (round 6, tools/whmr_timeline.py on a rocprofv3 trace of the replayed step):
+        # a graph launch submits its nodes in capture order, and with the ~74 small dependent camera launches captured FIRST the backbone's first
+        # kernel only reached the device when that chain had nearly finished -- the "side" branch ran IN FRONT of the backbone (0.7-0.85 ms),
+        # not beside it.  ``camera_launch`` = 'vit' issues the branch right behind the backbone's launches ('loop': just before the join,
+        # 'early': the old order); its only dependency stays the start of the forward (an event), so it still overlaps everything.
+        side, cam_pending = None, None
         if full_x is not None and cam_rotmat is None and self.overlap_camera:
             main = torch.cuda.current_stream(dev)
             side = self._camera_stream(dev)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                cam_rotmat, render_rotmat = self._camera(full_x, None, B, dev)
+            if self.camera_launch == 'early':
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    cam_rotmat, render_rotmat = self._camera(full_x, None, B, dev)
+            else:
+                cam_pending = torch.cuda.Event()
+                cam_pending.record(main)
         else:
             cam_rotmat, render_rotmat = self._camera(full_x, cam_rotmat, B, dev)
+
+        def launch_camera():
+            side.wait_event(cam_pending)
+            with torch.cuda.stream(side):
+                return self._camera(full_x, None, B, dev)
 
         # backbone (tokens are NHWC already) -> deconv pyramid in NHWC
         vit = self.feature_extractor.backbone
         tok, (_, Hp, Wp) = vit.forward_tokens(x)
+        if cam_pending is not None and self.camera_launch == 'vit':
+            cam_rotmat, render_rotmat = launch_camera()
+            cam_pending = None
         s_feat = tok.view(B, Hp, Wp, vit.embed_dim)
         f = s_feat if self._dt == torch.float32 else L.cast_bf16(s_feat)
         fmaps = []
@@ -714,6 +732,8 @@ class WHMR(nn.Module):
             outs.append(smpl_output)
             stage_state.append(reg._last_stage)
 
+        if cam_pending is not None:                                                   # camera_launch == 'loop': issued behind every other launch
+            cam_rotmat, render_rotmat = launch_camera()
         if side is not None:                                                          # join: the camera rotation is needed from here on
             main.wait_stream(side)
             if not torch.cuda.is_current_stream_capturing():                          # (a capture's private pool never recycles)

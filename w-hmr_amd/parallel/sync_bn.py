@@ -20,9 +20,14 @@ Protocol (the same as torch's SyncBatchNorm, with ONE packed collective per laye
 With one rank (no process group) the marked layers take the unsplit kernels -- unless ``always=True``, which runs the split pair with a no-op
 exchange (the hardware test of the split kernels on a 1-GPU box).
 
-The collectives are issued from the autograd thread in program order, so every rank issues them in the same order relative to the gradient
-buckets of ``GradReducer`` (whose launches are in bucket order); pass a dedicated ``process_group`` (``dist.new_group()``) to keep the two kinds of
-traffic on separate communicators.
+Communicators: the BatchNorm all-reduces are issued synchronously from the autograd thread, the gradient buckets of ``GradReducer``
+when a bucket fills -- or, on a rank that lacks one of a bucket's gradients that step, only at ``finish()``.  On ONE communicator two ranks could
+then issue the two kinds of collectives in different orders (gloo aborts on the size mismatch, RCCL pairs unrelated buffers or hangs).  So
+``convert_sync_batchnorm`` gives the BatchNorm traffic its OWN group by default (``dist.new_group()`` over the ranks of ``process_group``; every
+rank must make the call, like any group creation).  Under torch's own ``DistributedDataParallel`` + ``nn.SyncBatchNorm`` (the reference's two
+lines, core/trainer.py:83-86, supported as they are: ``sync_of`` honours an ``nn.SyncBatchNorm`` module) both kinds of traffic share the
+module's ``process_group`` exactly as they do in torch itself: DDP launches its buckets in bucket order from the same autograd thread and
+requires the same graph on every rank, so the program order is the same everywhere.
 """
 import torch
 import torch.distributed as dist
@@ -55,10 +60,14 @@ class SyncGroup:
         return t
 
 
-def convert_sync_batchnorm(module, process_group=None, always=False):
+def convert_sync_batchnorm(module, process_group=None, always=False, dedicated=True):
     """``nn.SyncBatchNorm.convert_sync_batchnorm`` (core/trainer.py:83) for this package's modules: every BatchNorm under ``module`` shares one
     ``SyncGroup`` mark; its training-mode statistics are then taken over all ranks of ``process_group`` (None = the default group).  Returns the
-    module (same object: the parameters / buffers / state_dict keys do not change, unlike torch's conversion which swaps the module class)."""
+    module (same object: the parameters / buffers / state_dict keys do not change, unlike torch's conversion which swaps the module class).
+    ``dedicated`` (default): at world size > 1 the exchanges run on a NEW group over the same ranks, so that they can never interleave with the
+    gradient buckets of ``GradReducer`` on one communicator (module docstring) -- a collective call: every rank converts its model."""
+    if dedicated and dist.is_initialized() and dist.get_world_size(process_group) > 1:
+        process_group = dist.new_group(ranks=dist.get_process_group_ranks(process_group) if process_group is not None else None)
     sg = SyncGroup(process_group, always)
     n = 0
     for m in module.modules():
@@ -80,14 +89,24 @@ def revert_sync_batchnorm(module):
     return module
 
 
+ALWAYS_SPLIT = False          # tests on a 1-GPU box: SyncGroups made for torch's own nn.SyncBatchNorm modules run the split kernels / the collective at world 1
+_AUTO_GROUPS = {}             # process group (or None) -> the SyncGroup shared by every torch nn.SyncBatchNorm module on it
+
+
+def auto_sync_groups():
+    """the SyncGroups ``sync_of`` created for torch ``nn.SyncBatchNorm`` modules (bookkeeping: collectives / bytes per group)"""
+    return list(_AUTO_GROUPS.values())
+
+
 def sync_of(bn):
     """the active SyncGroup of a BatchNorm module, else None.  A module that torch's own ``nn.SyncBatchNorm.convert_sync_batchnorm`` swapped in
-    (the reference's line, core/trainer.py:83, applied to this package's model) counts as marked with its ``process_group``."""
+    (the reference's line, core/trainer.py:83, applied to this package's model) counts as marked with its ``process_group``; all such modules on
+    one group share one SyncGroup (tests/test_train_gpu.py::test_reference_syncbn_ddp_wrap_world1_rccl runs exactly those two lines)."""
     sg = getattr(bn, 'whmr_sync', None)
     if sg is None and isinstance(bn, nn.SyncBatchNorm):
-        sg = bn.__dict__.get('_whmr_sync_auto')
-        if sg is None or sg.group is not bn.process_group:
-            sg = bn.__dict__['_whmr_sync_auto'] = SyncGroup(bn.process_group)
+        sg = _AUTO_GROUPS.get(bn.process_group)
+        if sg is None:
+            sg = _AUTO_GROUPS[bn.process_group] = SyncGroup(bn.process_group, always=ALWAYS_SPLIT)
     return sg if (sg is not None and sg.active()) else None
 
 

@@ -56,6 +56,23 @@ def _projection(joints, cam):
 CHAIN_GRADS = os.environ.get('WHMR_CHAIN_GRADS', '1') != '0'      # feature maps handed from consumer to consumer (A/B switch), see whmr_forward_train
 CHAIN_SAMPLER3 = os.environ.get('WHMR_CHAIN_SAMPLER3', '0') != '0'   # the stage-3 sampler behind the two heads in the last map's chain (A/B switch)
 OVERLAP_HEAVY = os.environ.get('WHMR_TRAIN_OVERLAP', '1') != '0'      # deconv 2 / 3 + Tz head + IUV head on a side stream beside the regressor loop
+_STREAM_WARNING_OFF = False
+
+
+def _accept_side_stream_gradients():
+    """The heavy chain's parameters get their gradients on the side stream its forward ran on (autograd runs a node's backward on the stream of its
+    forward).  A gradient accumulator that torch keeps alive from an EARLIER iteration -- DistributedDataParallel stashes every parameter's at
+    construction (core/trainer.py:84-86), a retained graph does too -- is bound to the stream of that time, and torch >= 2.8 then warns once per
+    process ("AccumulateGrad node's stream does not match ...": the engine synchronises the two streams, the result is correct).  The mismatch is this
+    module's design, so the warning is switched off through torch's own knob the first time the side stream engages ("Side streams")."""
+    global _STREAM_WARNING_OFF
+    if not _STREAM_WARNING_OFF:
+        _STREAM_WARNING_OFF = True
+        fn = getattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch', None)
+        if fn is not None and os.environ.get('WHMR_KEEP_STREAM_WARNING', '0') == '0':
+            fn(False)
+
+
 _heavy_streams = {}
 
 
@@ -219,6 +236,7 @@ def whmr_forward_train(model, x, center, scale, bbox_height, orig_shape, bbox_in
         main = torch.cuda.current_stream(dev)
         heavy = _heavy_stream(dev)
         heavy.wait_stream(main)
+        _accept_side_stream_gradients()
     with torch.cuda.stream(heavy if heavy is not None else torch.cuda.current_stream(dev)):
         for i in (1, 2):
             y, fmaps[-1] = deconv(i, fmaps[-1])
