@@ -85,6 +85,29 @@ def test_gemm_blk_matches_row_major_kernel_bitwise(dev):
 
 
 
+@pytest.mark.parametrize('C', [768, 1024, 256])
+def test_layernorm_blk(dev, C):
+    """whmr_layernorm_blk (vit.py:125,133,242 on the blocked stream; models/pose_vit.py uses it for the unfolded LayerNorms and the final norm):
+    blocked bf16 operand form and row-major fp32 form against F.layer_norm and the row-major kernel; ragged last row block (391 rows)"""
+    from whmr_amd import _lib as L
+    g = torch.Generator().manual_seed(C)
+    rows = 391
+    x = torch.randn(rows, C, generator=g) * 3 + 0.5
+    w, b = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    ref = F.layer_norm(x, (C,), w, b, 1e-6)
+    xb = L.to_blocked(x.to(dev))
+    out = torch.empty(xb.shape[0], C // 8, 32, 8, device=dev, dtype=torch.bfloat16)
+    L.layernorm_blk(xb, w.to(dev), b.to(dev), out, rows, 1e-6)
+    assert _rel(L.from_blocked(out, rows).float().cpu(), ref) < 1e-2
+    std = torch.empty(rows, C, device=dev)
+    L.layernorm_blk(xb, w.to(dev), b.to(dev), std, rows, 1e-6, out_std=True)
+    assert _rel(std.cpu(), ref) < 2e-6
+    # against the row-major kernel: same two-pass statistics, different summation tree -> fp32 rounding only
+    rm = torch.empty(rows, C, device=dev)
+    L.layernorm(x.to(dev), w.to(dev), b.to(dev), rm, 1e-6)
+    assert _rel(std, rm) < 2e-6
+
+
 @pytest.mark.parametrize('N,B', [(196, 3), (192, 3), (100, 3), (256, 3), (65, 2), (208, 2), (196, 64), (192, 27)])
 def test_attention_blk(dev, N, B):
     """whmr_attention_blk (round 5: the persistent 16-row-tile kernel, csrc/attention_blk16.hip) against fp32 torch on the same bf16 inputs, and

@@ -20,7 +20,6 @@ x = torch.randn(B, 3, *(res if isinstance(res, tuple) else (res, res)), device=d
 def fwd_ms(): return min(timeit(lambda: m(x)) for _ in range(3))
 def setcfg(cfg):
     for s in range(4): L.lib().whmr_gemm_blk_set_tile(s, 0)
-    L.lib().whmr_gemm_blk_set_tile(4, 1)
     for s, t in cfg: L.lib().whmr_gemm_blk_set_tile(s, t)
 cfgs = [[(int(kv.split(':')[0]), int(kv.split(':')[1], 16)) for kv in a.split(',')] for a in sys.argv[1:]]
 for rnd in range(3):

@@ -175,11 +175,16 @@ def lib():
         for slot, key in enumerate(('WHMR_BLK_TILE_QKV', 'WHMR_BLK_TILE_PROJ', 'WHMR_BLK_TILE_FC1', 'WHMR_BLK_TILE_FC2')):     # A/B: force a tile per ViT shape
             if os.environ.get(key):
                 l.whmr_gemm_blk_set_tile(slot, int(os.environ[key], 0))
+        # the split-bf16 attention's variant is ONE word (bit 0: old kernel, bits 4-7: stagger + 1): compose both switches before the single call, so
+        # that WHMR_ATTN_X3_STAGGER does not silently clear WHMR_ATTN_OLD for the bf16x3 kernel only
+        x3_variant = 0
         if os.environ.get('WHMR_ATTN_OLD', '0') != '0':         # A/B: the blocked attention (bf16 and bf16x3) on the round-2 / round-3 kernels
             l.whmr_attention_set_variant(1 | 16)
-            l.whmr_attention_x3_set_variant(1)
+            x3_variant |= 1
         if os.environ.get('WHMR_ATTN_X3_STAGGER'):               # A/B: k half-microseconds between the CU quarters of the split-bf16 attention (default: by shape)
-            l.whmr_attention_x3_set_variant((int(os.environ['WHMR_ATTN_X3_STAGGER']) + 1) << 4)
+            x3_variant |= (int(os.environ['WHMR_ATTN_X3_STAGGER']) + 1) << 4
+        if x3_variant:
+            l.whmr_attention_x3_set_variant(x3_variant)
     return _lib
 
 

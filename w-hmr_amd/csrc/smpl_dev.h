@@ -88,7 +88,9 @@ __device__ __forceinline__ void smpl_chain_image(const whmr_smpl_model& m, const
     for (int i = 1; i < NJ; ++i) { const int di = __builtin_amdgcn_readlane(depth, i); maxd = di > maxd ? di : maxd; }
     const int q = lane / 12, e12 = lane - q * 12;
     for (int lev = 1; lev <= maxd; ++lev) {
-        unsigned long long mask = __ballot(valid && lane >= 1 && lane < NJ && depth == lev);
+        // (the mask is built from the tree alone -- NOT from `valid` -- so that a wave without an image runs the SAME number of barriers as one with:
+        //  `valid` only gates the LDS writes below)
+        unsigned long long mask = __ballot(lane >= 1 && lane < NJ && depth == lev);
         while (mask) {                                                             // (wave-uniform: at most ceil(joints of the level / 5) rounds)
             int i = -1, p = 0;
 #pragma unroll

@@ -371,7 +371,7 @@ class WHMR(nn.Module):
         self._cache = _Cache()
         self._init_cache = None
         self.overlap_camera = True          # cam_model on a side stream beside the backbone (joined before the global-orientation head)
-        self.camera_launch = os.environ.get('WHMR_CAM_LAUNCH', 'vit')      # where the camera branch's launches are issued: 'vit' | 'loop' | 'early' (see _forward_eval)
+        self.camera_launch = os.environ.get('WHMR_CAM_LAUNCH', 'early')    # where the camera branch's launches are issued: 'early' | 'vit' | 'loop' (A/B, see _forward_eval)
         self.overlap_tz = True              # Tz head on a side stream beside the regressor loop (its outputs finalized after the join)
         self.compose_tz = os.environ.get('WHMR_COMPOSE_TZ', '1') != '0'   # inference: the two Tz-head convolutions as ONE composed k25 / s6 convolution (False: the two-convolution form)
         self._tz_gemm_kw = {}               # explicit tile / split-K of the composed convolution's GEMM (A/B probes)
@@ -643,11 +643,11 @@ class WHMR(nn.Module):
         # The camera-calibration ResNet-50 (whmr.py:509-522) only feeds the global-orientation head at the very end (whmr.py:630): it runs on a
         # SIDE stream beside the backbone / deconvs / regressor loop and is joined just before that head.  Its few-tile launches slot into the CUs
         # the big GEMM grids leave idle (tile-grid tails); under GraphedForward the fork / join become two branches of the captured graph.
-        # WHERE its launches are issued matters under a HIP-graph replay (round 6, tools/whmr_timeline.py on a rocprofv3 trace of the replayed step):
-        # a graph launch submits its nodes in capture order, and with the ~74 small dependent camera launches captured FIRST the backbone's first
-        # kernel only reached the device when that chain had nearly finished -- the "side" branch ran IN FRONT of the backbone (0.7-0.85 ms),
-        # not beside it.  ``camera_launch`` = 'vit' issues the branch right behind the backbone's launches ('loop': just before the join,
-        # 'early': the old order); its only dependency stays the start of the forward (an event), so it still overlaps everything.
+        # ``camera_launch`` (A/B switch, round 6): 'early' issues the branch first (default), 'vit' right behind the backbone's launches, 'loop' just
+        # before the join -- its only dependency is the start of the forward either way.  Measured under the HIP-graph replay at batch 64
+        # (profiles/r06_experiments_that_did_not_pay.txt): early 4.30 ms, vit 4.87, loop 4.89 (the graph then folds the branch onto the regressor
+        # loop's queue); without any camera work 3.97, the camera chain alone 0.79 -- i.e. 'early' already hides 0.46 of its 0.79 ms, and so does a
+        # SEPARATE camera graph replayed on a side stream (4.34): what remains is the chain's own CU time and power beside the backbone.
         side, cam_pending = None, None
         if full_x is not None and cam_rotmat is None and self.overlap_camera:
             main = torch.cuda.current_stream(dev)
