@@ -427,7 +427,8 @@ def secondary_rows(args, dev, x, budget_s=40.0):
             stepw, _, _, _ = build_workload(aw, dev)
             ms = time_steps(stepw, 20, 10)
             clkw = observed_clock(stepw, dev, 10)
-        rows['whmr'] = {'ms_per_step': ms, 'images_per_sec': args.batch / ms * 1e3, 'sclk_mhz_observed': clkw.get('mhz'), 'cam_model_frames_per_step': 1,
+        tfw = VIT_FLOP_PER_IMG['whmr'] * args.batch / ms / 1e9
+        rows['whmr'] = {'ms_per_step': ms, 'images_per_sec': args.batch / ms * 1e3, 'sclk_mhz_observed': clkw.get('mhz'), 'model_tflops': tfw, 'frac': tfw / 2500.0, 'cam_model_frames_per_step': 1,
                         'workload': WORKLOAD['whmr'] + '; ' + aw.full_x_note}
         try:                                # the north star's "achieved HBM GB/s on the sampler / LBS kernels", under the driver's clock
             with torch.no_grad():
@@ -449,7 +450,13 @@ def secondary_rows(args, dev, x, budget_s=40.0):
             stept, _, _, _ = build_workload(at, dev)
             ms = time_steps(stept, 20, 20)        # 0.4 s of warm-up: the package clock needs a few 100 ms to settle after the idle parity legs above
             clkt = observed_clock(stept, dev, 5)
-        rows['whmr_train'] = {'ms_per_step': ms, 'images_per_sec': args.batch / ms * 1e3, 'sclk_mhz_observed': clkt.get('mhz'), 'workload': WORKLOAD['whmr_train']}
+        tf = VIT_FLOP_PER_IMG['whmr_train'] * args.batch / ms / 1e9
+        rows['whmr_train'] = {'ms_per_step': ms, 'images_per_sec': args.batch / ms * 1e3, 'sclk_mhz_observed': clkt.get('mhz'),
+                              'model_tflops': tf, 'frac': tf / 2500.0,
+                              'roofline_note': 'whole-step figure: algorithmic forward + backward flops of ViT-B, the deconv pyramid, the Tz convolution and the IUV head '
+                                               '(3 x forward, %.1f GF per image) / step time / the 2.5 PF dense bf16 peak -- everything else in the step (attention, '
+                                               'LayerNorm / BatchNorm / GELU passes, the regressor loop, rasteriser, Adam) counts as time only' % (VIT_FLOP_PER_IMG['whmr_train'] / 1e9),
+                              'workload': WORKLOAD['whmr_train']}
     else:
         rows['whmr_train'] = {'skipped': 'secondary budget spent'}
     rows['seconds'] = spent()
