@@ -1082,6 +1082,24 @@ def main(argv=None):
                                'flops_per_launch': flops_per_launch, 'avg_launch_us': avg_s * 1e6,
                                'traffic': traffic['bytes_per_launch'] if traffic else None,
                                'traffic_note': traffic['note'] if traffic else 'no PMC pass of the current GEMM sources committed'}
+            # the launches of the step that are NOT GEMMs: attention on the matrix pipes + softmax VALU, the memory-bound passes;
+            # `step_coverage` = instrumented launch time of one eager step / the timed step (the rest: launch gaps and un-instrumented small launches)
+            other = {}
+            for name, work, e0, e1 in prof:
+                if name not in ('gemm_bf16', 'gemm_f32', 'gemm_bf16x3'):
+                    o = other.setdefault(name, [0, 0.0, 0.0])
+                    o[0] += 1; o[1] += work; o[2] += e0.elapsed_time(e1) * 1e-3
+            rows = {}
+            for name, (n, work, sec) in other.items():
+                if name.endswith('_bytes'):
+                    rows[name[:-6]] = {'bound': 'hbm', 'launches': n, 'avg_launch_us': sec / n * 1e6, 'algorithmic_bytes_per_launch': work / n,
+                                       'achieved': work / sec / 1e9, 'peak': 8000.0, 'unit': 'GB/s', 'frac': work / sec / 8e12}
+                else:
+                    rows[name] = {'bound': 'mfma', 'launches': n, 'avg_launch_us': sec / n * 1e6, 'flops_per_launch': work / n,
+                                  'achieved': work / sec / 1e12, 'peak': peak, 'unit': 'TFLOP/s', 'frac': work / sec / 1e12 / peak}
+            if rows:
+                res['roofline']['other_launches'] = rows
+                res['roofline']['step_coverage'] = (sum(t for _, t in gemm) + sum(v[2] for v in other.values())) / (dt / args.steps)
             if x3_mode:
                 res['roofline']['mfma_issue_frac'] = 3.0 * achieved / peak          # share of the dense bf16 MFMA peak the pipes actually issue
             # the box's own ceilings and clock, measured in THIS process after the timed region (datasheet numbers AND a measurement on the box):

@@ -52,6 +52,27 @@ def test_no_cpu_fallback(assets, state_dict):
                              torch.float32)
 
 
+def test_ddp_buffer_ignore_list_keeps_the_trained_batchnorm_statistics(assets):
+    """the module tells torch's DistributedDataParallel (core/trainer.py:84-86) which buffers NOT to re-broadcast before every forward: the constant
+    tables (SMPL arrays, dense down-sampling matrices, mean parameters, point grid) and the frozen camera network's statistics; the statistics of the
+    four BatchNorm layers that train stay in the broadcast.  The list survives torch's SyncBatchNorm conversion (the other reference line, :83)."""
+    from whmr_amd.models import whmr_net
+    m = whmr_net(None, assets=assets)
+    ignore = set(m._ddp_params_and_buffers_to_ignore)
+    names = {n for n, _ in m.named_buffers()}
+    assert ignore <= names and not any(n in ignore for n, _ in m.named_parameters())
+    kept = sorted(names - ignore)
+    assert kept and all(('running_' in n or 'num_batches_tracked' in n) and not n.startswith('cam_model.') for n in kept), kept
+    assert {n.split('.running_')[0] for n in kept if '.running_mean' in n} == {'deconv_layers.1', 'deconv_layers.4', 'deconv_layers.7', 'est_Tz.2'}
+    for n in ('points_grid', 'regressor.0.Dmap0', 'regressor.2.init_pose', 'global_orient.init_pose'):
+        assert n in ignore, n
+    big = sum(b.numel() * b.element_size() for n, b in m.named_buffers() if n in ignore)
+    assert big > 50e6, big                                           # what a DDP forward would otherwise copy twice per step
+    m2 = torch.nn.SyncBatchNorm.convert_sync_batchnorm(m)
+    assert m2 is m and set(m2._ddp_params_and_buffers_to_ignore) == ignore
+    assert {n for n, _ in m2.named_buffers()} == names               # the conversion keeps the buffer names
+
+
 def test_state_dict_contract(assets, state_dict):
     """every own-code key of the reference state_dict exists with the right shape, strict on our side"""
     from whmr_amd.models import whmr_net

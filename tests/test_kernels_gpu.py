@@ -747,3 +747,29 @@ def test_mat_to_aa_backward_matches_autograd(dev):
     scale = ref.abs().amax(dim=(1, 2), keepdim=True).clamp_min(1e-6)
     worst = ((got - ref).abs() / scale).max().item()
     assert worst < 2e-4, worst          # per matrix, relative to its largest gradient entry (near pi the map is ill-conditioned: fp32 both sides)
+
+
+def test_measurement_aids_ceilings_and_clock_probe(dev):
+    """csrc/ceilings.hip (bench.py's roofline.attainable / hbm_attainable_GBps / sclk_mhz_observed): the copy kernel copies, the MFMA stream and the
+    clock probe return physically plausible figures, and a probe that is never released ends by itself (bounded wait)."""
+    from whmr_amd import _lib as L
+    g = torch.Generator().manual_seed(1)
+    src = torch.randint(0, 255, (1 << 20,), generator=g, dtype=torch.uint8).to(dev)
+    dst = torch.zeros_like(src)
+    L._check(L.lib().whmr_hbm_copy(src.data_ptr(), dst.data_ptr(), src.numel(), L._stream()), 'whmr_hbm_copy')
+    assert torch.equal(src, dst)
+    assert L.lib().whmr_hbm_copy(src.data_ptr(), dst.data_ptr(), 100, L._stream()) != 0          # not a multiple of 16 bytes: rejected
+    gbps = L.hbm_copy_ceiling(dev, mbytes=256, reps=3)
+    assert 500.0 < gbps < 16000.0, gbps                       # read + write bytes per second; the datasheet peak is 8 TB/s each way
+    mf = L.mfma_ceiling(dev, seconds=0.03)
+    assert 300.0 < mf['tflops'] < 2600.0 and 500.0 < mf['sclk_mhz'] < 3000.0, mf      # never above the 2.5 PF dense bf16 peak
+    with L.ClockProbe(dev) as cp:
+        a = torch.randn(2048, 2048, device=dev)
+        for _ in range(5):
+            a = a @ a * 1e-3
+    assert not cp.timed_out and 500.0 < cp.mhz < 3000.0 and cp.seconds > 0, (cp.mhz, cp.seconds)
+    state = torch.zeros(6, dtype=torch.int64, device=dev)      # never released: leaves through its time limit and says so
+    L._check(L.lib().whmr_clock_probe_begin(state.data_ptr(), 0.01, L._stream()), 'whmr_clock_probe_begin')
+    torch.cuda.synchronize()
+    st = state.tolist()
+    assert st[5] == 1 and 0.009 < (st[3] - st[1]) / 1e8 < 0.2, st

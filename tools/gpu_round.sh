@@ -34,6 +34,10 @@ bench whmr_bf16x3_b1 --workload whmr --numerics bf16x3 --batch 1 --no-cpu --no-p
 bench vit256x192 --workload vit256x192 --no-cpu
 bench vitl256x192_b32 --workload vitl256x192 --batch 32 --no-cpu
 bench whmr_b1 --workload whmr --batch 1 --no-cpu --no-parity --steps 50 --warmup 10
+# one-rank RCCL group in THIS process (env:// rendezvous, no torchrun): the reference's own SyncBatchNorm + DDP wrap, and GradReducer + convert_sync_batchnorm
+( export MASTER_ADDR=127.0.0.1 MASTER_PORT=29561 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 HSA_ENABLE_IPC_MODE_LEGACY=0
+  bench whmr_train_ddp_rccl1 --workload whmr_train --wrap ddp --no-cpu --steps 20 --warmup 10
+  bench whmr_train_rccl1_syncbn --workload whmr_train --batchnorm sync --always-bucket --no-cpu --steps 20 --warmup 10 ) || fail "one-rank RCCL benches failed"
 cd /tmp
 prof() {  # name, description, bench args...
   local n=$1 d=$2; shift 2
@@ -47,6 +51,12 @@ prof vit224_b64 "ViT-B/16 224^2 batch 64 bf16: timed steps + warm-ups + 1 instru
 prof vit224_b64_bf16x3 "the same workload in the bf16x3 numerics" --no-cpu --no-secondary --numerics bf16x3 --steps 10 --warmup 3
 prof whmr_b64 "full W-HMR forward, batch 64 + one 600x800 frame, bf16, HIP-graph replays + one eager instrumented step" --workload whmr --no-cpu --no-parity --steps 10 --warmup 3
 prof whmr_train_b64 "W-HMR training step, batch 64, bf16, Adam inside the step" --workload whmr_train --no-cpu --steps 4 --warmup 2
+# timeline of one replayed full forward (every launch with start offset / duration / HSA queue)
+rocprofv3 --kernel-trace -d $OUT/${TAG}_prof_tl -o tl -- python3 $R/bench.py --workload whmr --no-cpu --no-parity --steps 10 --warmup 3 > $OUT/${TAG}_prof_tl.log 2>&1
+TDB=$(find $OUT/${TAG}_prof_tl -name '*.db' | head -1)
+[ -n "$TDB" ] || fail "no rocprof database for the timeline"
+{ hdr "rocprofv3 --kernel-trace -- python3 bench.py --workload whmr --no-cpu --no-parity --steps 10 --warmup 3 ; python3 tools/whmr_timeline.py <db>   (the profiler serialises queues and stretches small launches)"; python3 $R/tools/whmr_timeline.py $TDB 0; } > $PROF/${TAG}_whmr_timeline.txt
+rm -rf $OUT/${TAG}_prof_tl
 pmc() {  # name, counters (quoted), bench args...
   local n=$1 c=$2; shift 2
   rocprofv3 --kernel-trace --pmc $c -d $OUT/${TAG}_pmc_$n -o pmc -- python3 $R/bench.py "$@" > $OUT/${TAG}_pmc_$n.log 2>&1

@@ -442,8 +442,10 @@ def layernorm_blk(x, weight, bias, out, rows, eps, out_std=False, mean_out=None)
         _check(lib().whmr_layernorm_blk_mean(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), out.data_ptr(), mean_out.data_ptr(), rows, Cdim, eps,
                                              _stream()), 'whmr_layernorm_blk_mean')
         return out
+    ev = _profile_begin()
     _check(lib().whmr_layernorm_blk(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), out.data_ptr(), rows, Cdim, eps, int(out_std), _stream()),
            'whmr_layernorm_blk')
+    _profile_end(ev, 'layernorm_bytes', float(rows) * Cdim * (4 + out.element_size()))          # fp32 stream read once, operand / output written once
     return out
 
 
@@ -458,7 +460,9 @@ def patch_im2col_blk(x, out, patch, pad, out_lo=None):
         _check(lib().whmr_patch_im2col_blk_x3(x.data_ptr(), out.data_ptr(), out_lo.data_ptr(), B, Cin, H, W, patch, pad, sb, sc, sh, sw, _stream()),
                'whmr_patch_im2col_blk_x3')
         return out
+    ev = _profile_begin()
     _check(lib().whmr_patch_im2col_blk(x.data_ptr(), out.data_ptr(), B, Cin, H, W, patch, pad, sb, sc, sh, sw, _stream()), 'whmr_patch_im2col_blk')
+    _profile_end(ev, 'patch_gather_bytes', float(x.numel()) * 4 + float(out.numel()) * 2)             # image read once (fp32), tokens written once (bf16)
     return out
 
 
@@ -469,10 +473,14 @@ def attention_blk(qkv, out, B, N, H, scale, qkv_lo=None, out_lo=None):
         _dev(qkv_lo, out_lo)
         assert qkv_lo.shape == qkv.shape and qkv_lo.dtype == torch.bfloat16 and qkv_lo.is_contiguous()
         assert out_lo.shape == out.shape and out_lo.dtype == torch.bfloat16 and out_lo.is_contiguous()
+        ev = _profile_begin()
         _check(lib().whmr_attention_blk_x3(qkv.data_ptr(), qkv_lo.data_ptr(), out.data_ptr(), out_lo.data_ptr(), B, N, H, scale, _stream()),
                'whmr_attention_blk_x3')
+        _profile_end(ev, 'attention', 4.0 * B * H * N * N * 64)              # QK^T + PV, head dim 64 (algorithmic flops; three MFMAs per product issued)
         return out
+    ev = _profile_begin()
     _check(lib().whmr_attention_blk(qkv.data_ptr(), out.data_ptr(), B, N, H, scale, _stream()), 'whmr_attention_blk')
+    _profile_end(ev, 'attention', 4.0 * B * H * N * N * 64)
     return out
 
 
