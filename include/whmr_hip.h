@@ -474,6 +474,13 @@ int whmr_smpl_stage_tail(const struct whmr_smpl_model* m, const struct whmr_stag
  * A [B,24,12] from whmr_smpl_pose_chain; verts [B,6890,3].  Same vertices, bit for bit. */
 int whmr_smpl_blend_skin(const struct whmr_smpl_model* m, const float* posedirs_tiled, const float* betas, long beta_stride, const float* pose_feat,
                          const float* A, int B, float* verts, void* stream);
+/* The same launch with the pose-corrective offsets (verts.py:51-53) on split-bf16 operands: hi.hi + lo.hi + hi.lo on v_mfma_f32_32x32x16_bf16, fp32
+ * accumulate (39 MFMAs of 32 cycles instead of 104 exact-f32 MFMAs of 64: the offsets phase was bound by the f32 matrix rate); shape blend and
+ * skinning unchanged (exact f32).  posedirs_x3: [108][13][2][2][192][8] bf16 = per 64-vertex chunk, K step of 16, half (8 k), plane (hi, lo), column:
+ * 8 consecutive k.  Vertices within ~3e-7 of whmr_smpl_blend_skin (the offsets are cm corrections of metre-scale coordinates); the module uses it in
+ * the bf16 / bf16x3 numerics, the exact form in fp32 and in training. */
+int whmr_smpl_blend_skin_x3(const struct whmr_smpl_model* m, const void* posedirs_x3, const float* betas, long beta_stride, const float* pose_feat,
+                            const float* A, int B, float* verts, void* stream);
 /* tools: route four 64-bit 100 MHz phase stamps of workgroup 0 of whmr_smpl_blend_skin into buf[2..9] (16 uint32 device words; null = off). */
 int whmr_smpl_blend_skin_stamps(uint32_t* buf);
 /* whmr_smpl_stage_tail with the joint regression as a CSR gather (reg_*: CSR of the first t->R rows of [J_regressor_extra ; J_regressor]): ONE launch,

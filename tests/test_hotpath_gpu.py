@@ -438,3 +438,33 @@ def test_smpl_three_launch_call_matches_the_five_launch_form(dev, assets, B):
     # the second call of the three-launch form: the same bits as the first (nothing carries state between calls)
     assert torch.equal(c.vertices, b.vertices) and torch.equal(c.joints, b.joints) and torch.equal(c.smpl_joints, b.smpl_joints) and torch.equal(xc3, xb)
     assert torch.equal(c2.vertices, b2.vertices)
+
+
+@pytest.mark.parametrize('B', [1, 3, 33, 64])
+def test_smpl_offsets_on_split_bf16_operands_stay_within_fp32_resolution_of_the_exact_form(dev, assets, B):
+    """whmr_smpl_blend_skin_x3 (the blend launch of the bf16 / bf16x3 numerics: pose-corrective offsets of models/smpl_webuser/verts.py:51-53 as
+    hi.hi + lo.hi + hi.lo on the bf16 matrix pipes, shape blend and skinning exact) against whmr_smpl_blend_skin (exact f32 everywhere) and the CPU
+    oracle: the offsets are centimetre corrections of metre-scale coordinates, so their ~1e-5 relative error is a few 1e-7 of a vertex.  Batch sizes
+    in the few-image VALU branch (1, 3), across an image-group boundary (33) and at the benchmark's 64; poses up to ~1 rad so the offsets are large."""
+    from oracle import geometry as OG
+    from oracle import smpl as OS
+    from whmr_amd.models.smpl import SMPL
+    g = torch.Generator().manual_seed(100 + B)
+    m = SMPL(arrays=assets['smpl'], marker_ids=assets['ssm']).to(dev)
+    betas = torch.randn(B, 10, generator=g)
+    rot = OG.batch_rodrigues(torch.randn(B * 24, 3, generator=g) * 0.7).view(B, 24, 3, 3)
+    outs = {}
+    for x3 in (False, True, True):
+        m.offsets_x3 = x3
+        o = m.run(betas.to(dev), rot.to(dev))
+        torch.cuda.synchronize()
+        outs.setdefault(x3, []).append(o.vertices.clone())
+    exact, fast, again = outs[False][0], outs[True][0], outs[True][1]
+    assert torch.equal(fast, again)                                        # deterministic
+    scale = exact.abs().max().item()
+    err = (fast - exact).abs().max().item() / scale
+    off = (exact - m.run(betas.to(dev), torch.eye(3, device=dev).expand(B, 24, 3, 3).contiguous()).vertices).abs().max().item()
+    print('B = %d: x3 offsets vs exact f32: max |dv| / max |v| = %.2e (largest pose-induced displacement %.3f of %.3f)' % (B, err, off, scale))
+    assert 0.0 < err < 1e-6, err
+    ref, _ = OS.smpl_forward(betas, rot, assets['smpl'])
+    assert ((fast.cpu() - ref).abs().max() / ref.abs().max()).item() < 3e-6

@@ -23,6 +23,8 @@ bench() {  # name, args...
   local n=$1; shift
   python bench.py "$@" > $PROF/${TAG}_bench_$n.json 2> $OUT/${TAG}_bench_$n.err || fail "bench $n failed: $(tail -2 $OUT/${TAG}_bench_$n.err)"
   [ -s $PROF/${TAG}_bench_$n.json ] || fail "bench $n wrote nothing"
+  grep '^{' $PROF/${TAG}_bench_$n.json | tail -1 > $PROF/${TAG}_bench_$n.json.tmp && mv $PROF/${TAG}_bench_$n.json.tmp $PROF/${TAG}_bench_$n.json    # (RCCL prints a banner to stdout)
+  [ -s $PROF/${TAG}_bench_$n.json ] || fail "bench $n printed no JSON line"
 }
 bench vit224
 bench vit224_bf16x3 --numerics bf16x3 --steps 20 --warmup 5

@@ -109,6 +109,7 @@ _SIGS = {
     'whmr_smpl_stage_tail': [C.POINTER(WhmrSmplModel), C.POINTER(WhmrStageTail), _I, _P, _P],
     'whmr_smpl_stage_tail_csr': [C.POINTER(WhmrSmplModel), C.POINTER(WhmrStageTail), _P, _P, _P, _I, _P],
     'whmr_smpl_blend_skin': [C.POINTER(WhmrSmplModel), _P, _P, _L, _P, _P, _I, _P, _P],
+    'whmr_smpl_blend_skin_x3': [C.POINTER(WhmrSmplModel), _P, _P, _L, _P, _P, _I, _P, _P],
     'whmr_smpl_blend_skin_stamps': [_P],
     'whmr_smpl_joints': [C.POINTER(WhmrSmplModel), _P, _P, _I, _P, _P, _P, _P, _P],
     'whmr_maf_sample': [_P, _I, _L, _L, _L, _L, _I, _I, _P, _P, _P, _L, _F, _F, _F, C.POINTER(WhmrMafWeights), _I, _I, _P, _L, _P, _P],
@@ -742,6 +743,14 @@ def smpl_blend_skin(model, posedirs_tiled, betas, pose_feat, A, verts):
     assert posedirs_tiled.dtype == torch.float32 and posedirs_tiled.is_contiguous() and tuple(posedirs_tiled.shape) == (108, 208, 192)
     _check(lib().whmr_smpl_blend_skin(C.byref(model), posedirs_tiled.data_ptr(), bp, bs, pose_feat.data_ptr(), A.data_ptr(), betas.shape[0],
                                       verts.data_ptr(), _stream()), 'whmr_smpl_blend_skin')
+
+
+def smpl_blend_skin_x3(model, posedirs_x3, betas, pose_feat, A, verts):
+    """the same launch with the pose-corrective offsets on split-bf16 operands (include/whmr_hip.h: whmr_smpl_blend_skin_x3)"""
+    bp, bs = _rows(betas, 10)
+    assert posedirs_x3.dtype == torch.bfloat16 and posedirs_x3.is_contiguous() and tuple(posedirs_x3.shape) == (108, 13, 2, 2, 192, 8)
+    _check(lib().whmr_smpl_blend_skin_x3(C.byref(model), posedirs_x3.data_ptr(), bp, bs, pose_feat.data_ptr(), A.data_ptr(), betas.shape[0],
+                                         verts.data_ptr(), _stream()), 'whmr_smpl_blend_skin_x3')
 
 
 def smpl_skin(model, betas, pose_feat, A, verts, pose_off=None):

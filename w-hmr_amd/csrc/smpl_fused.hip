@@ -33,6 +33,7 @@ struct whmr_smpl_call {
     const int32_t* reg_ptr; const int32_t* reg_col; const float* reg_val;   // CSR of the [R, 6890] regressor rows (extra rows first, then J_regressor)
     uint32_t* barrier;                              // tools only: 16 uint32 whose words [2..13] receive phase stamps of workgroup 0 (may be null)
     const float* posedirs_tiled;                    // [108][208][192]: posedirs re-tiled per 64-vertex chunk, k-major inside a chunk, zero padded
+    const bf16_t* posedirs_x3;                      // [108][13][2][2][192][8] bf16: the same tile as split-bf16 hi / lo planes in MFMA operand order (X3 kernels)
     whmr_stage_tail tail;                           // (unused by the launches of this file)
 };
 
@@ -54,7 +55,12 @@ struct whmr_smpl_call {
 
 // COH: pose_feat / A were written by an earlier phase of the SAME kernel and the vertices are read by a later one (coherent sc1 accesses);
 // false: a separate launch (whmr_smpl_blend_skin) -- plain cached accesses.
-template <bool COH>
+// X3 (round 6; inference numerics bf16 / bf16x3): the pose-corrective offsets on v_mfma_f32_32x32x16_bf16 with split-bf16 operands (hi.hi + lo.hi + hi.lo,
+// fp32 accumulate) instead of 104 exact-f32 MFMAs of 64 cycles each -- the offsets phase was bound by the f32 matrix rate (6.5 us of the launch's
+// 18 us: two SIMDs carry two waves).  The offsets are centimetre corrections of metre-scale coordinates: their 1e-5 relative error is ~3e-7 of a vertex.
+// posedirs comes pre-split (hi / lo planes, 8 consecutive k per 16-byte piece), the pose features are split as they are staged.  X3 = false keeps the
+// exact-f32 chain (fp32 numerics, training, the bit-identity tests against the five-launch form).
+template <bool COH, bool X3 = false>
 __device__ __forceinline__ void fused_phase2_item(const whmr_smpl_model& m, const whmr_smpl_call& p, int vb, int b0, float* smem) {
     float* sPF = smem + P2_PF;
     float* sBeta = smem + P2_BETA;
@@ -69,8 +75,16 @@ __device__ __forceinline__ void fused_phase2_item(const whmr_smpl_model& m, cons
     // (separate-launch form only: four 100 MHz stamps of workgroup 0 behind p.barrier, when given -- tools/smpl_timing.py)
     uint64_t* stamps = (!COH && p.barrier && blockIdx.x == 0 && tid == 0) ? (uint64_t*)(p.barrier + 2) : nullptr;
     if (stamps) stamps[0] = wall_clock64();
-    float pv[FUSED_KP / 2];
-    {
+    constexpr int KS = FUSED_KP / 16;                                             // K steps of the bf16 MFMA (13)
+    float pv[X3 ? 1 : FUSED_KP / 2];
+    bf16x8_t bx[X3 ? KS : 1][2];                                                  // X3: [k step][hi / lo plane], 8 consecutive k of this lane's column
+    if constexpr (X3) {
+        const bf16x8_t* pt = (const bf16x8_t*)p.posedirs_x3 + ((size_t)vb * KS * 2 + hi) * 2 * (3 * FUSED_VT) + 32 * wave + l31;
+#pragma unroll
+        for (int st = 0; st < KS; ++st)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) bx[st][pl] = pt[((size_t)st * 2 * 2 + pl) * (3 * FUSED_VT)];
+    } else {
         const float* pt = p.posedirs_tiled + (size_t)vb * (FUSED_KP * 3 * FUSED_VT) + hi * (3 * FUSED_VT) + 32 * wave + l31;
 #pragma unroll
         for (int u = 0; u < FUSED_KP / 2; ++u) pv[u] = pt[(size_t)u * (2 * 3 * FUSED_VT)];
@@ -94,8 +108,25 @@ __device__ __forceinline__ void fused_phase2_item(const whmr_smpl_model& m, cons
             const int k = e / FUSED_IG, bb = e % FUSED_IG;
             sBeta[e] = (b0 + bb < B) ? p.betas[(size_t)(b0 + bb) * p.beta_stride + k] : 0.f;
         }
+        if constexpr (X3) {
+            // split-bf16 planes in MFMA operand order: element (k = 16 s + 8 h + j, image) -> sPFx[((s * 2 + h) * 2 + plane) * 32 + image][j]
+            bf16_t* sx = (bf16_t*)sPF;
+#pragma unroll
+            for (int i = 0; i < NPFL; ++i) {
+                const int e = tid + i * FUSED_NT;
+                if (e < FUSED_KP * FUSED_IG) {
+                    const int k = e / FUSED_IG, bb = e % FUSED_IG;
+                    uint32_t h2, l2;
+                    split_bf16x2(tpf[i], 0.f, h2, l2);
+                    const int base = ((((k >> 4) * 2 + ((k >> 3) & 1)) * 2) * FUSED_IG + bb) * 8 + (k & 7);
+                    sx[base] = (bf16_t)(h2 & 0xffffu);
+                    sx[base + FUSED_IG * 8] = (bf16_t)(l2 & 0xffffu);
+                }
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < NPFL; ++i) { const int e = tid + i * FUSED_NT; if (e < FUSED_KP * FUSED_IG) sPF[e] = tpf[i]; }
+        }
 #pragma unroll
         for (int i = 0; i < NAL; ++i) { const int e = tid + i * FUSED_NT; if (e < FUSED_IG * NJ * 12) sA[(e / (NJ * 12)) * P2_AS + e % (NJ * 12)] = ta[i]; }
     }
@@ -109,6 +140,21 @@ __device__ __forceinline__ void fused_phase2_item(const whmr_smpl_model& m, cons
         f32x16_t acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        if constexpr (X3) {
+            // 13 K steps x (hi.hi + lo.hi + hi.lo): 39 bf16 MFMAs of 32 cycles instead of 104 f32 MFMAs of 64; all 26 operand reads first
+            const bf16x8_t* sx = (const bf16x8_t*)sPF + hi * 2 * FUSED_IG + l31;
+            bf16x8_t ax[KS][2];
+#pragma unroll
+            for (int st = 0; st < KS; ++st)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) ax[st][pl] = sx[(st * 2 * 2 + pl) * FUSED_IG];
+#pragma unroll
+            for (int st = 0; st < KS; ++st) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ax[st][0], bx[st][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ax[st][1], bx[st][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ax[st][0], bx[st][1], acc, 0, 0, 0);
+            }
+        } else {
         constexpr int S = FUSED_KP / 2;
         // the pose-feature operands are read ahead in two halves (52 registers each): fetched one step at a time each ds_read's latency sat on
         // the dependent MFMA chain (130 cycles per step measured, 64 for the instruction itself)
@@ -119,6 +165,7 @@ __device__ __forceinline__ void fused_phase2_item(const whmr_smpl_model& m, cons
             for (int u = 0; u < S / 2; ++u) av[u] = sPF[(2 * (half * (S / 2) + u) + hi) * FUSED_IG + l31];
 #pragma unroll
             for (int u = 0; u < S / 2; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], pv[half * (S / 2) + u], acc, 0, 0, 0);
+        }
         }
         // C layout: register r of lane (l31, hi) = image (r & 3) + 8 (r >> 2) + 4 hi, column l31
 #pragma unroll
@@ -303,6 +350,7 @@ extern "C" int whmr_smpl_stage_tail_csr(const whmr_smpl_model* m, const whmr_sta
 // buffer + smpl_skin_kernel<1>: 16.5 + 17.5 us at batch 64): one workgroup per (64-vertex chunk, 32-image group) runs phase 2 of the one-launch
 // kernel above with plain cached accesses -- the offsets on v_mfma_f32_32x32x2_f32 from the re-tiled posedirs copy (same bits as the GEMM), through
 // LDS to the skinning layout.  The pose-offset buffer (5.3 MB written + read at batch 64) is gone.
+template <bool X3>
 __global__ __launch_bounds__(FUSED_NT, 1) void smpl_blend_skin_kernel(const whmr_smpl_model m, const whmr_smpl_call p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // workgroup id -> (vertex chunk, image group) so that the image groups of ONE chunk are neighbours on the SAME XCD (ids with equal id % 8
@@ -312,11 +360,26 @@ __global__ __launch_bounds__(FUSED_NT, 1) void smpl_blend_skin_kernel(const whmr
     const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
     const int vb = (k / ngrp) * 8 + xcd;
     if (vb >= nvb) return;
-    fused_phase2_item<false>(m, p, vb, (k % ngrp) * FUSED_IG, (float*)smem);
+    fused_phase2_item<false, X3>(m, p, vb, (k % ngrp) * FUSED_IG, (float*)smem);
 }
 
 static uint32_t* g_blend_stamps = nullptr;          // tools only: whmr_set_option(200, 1) routes workgroup 0's phase stamps into a 64-byte device buffer
 extern "C" int whmr_smpl_blend_skin_stamps(uint32_t* buf) { g_blend_stamps = buf; return 0; }
+
+template <bool X3>
+static int launch_blend_skin(const whmr_smpl_model* m, const whmr_smpl_call& f, void* stream) {
+    const size_t lds = (size_t)P2_FLOATS * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)smpl_blend_skin_kernel<X3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    const int nvb = (NV + FUSED_VT - 1) / FUSED_VT, ngrp = (f.B + FUSED_IG - 1) / FUSED_IG;
+    hipLaunchKernelGGL(smpl_blend_skin_kernel<X3>, dim3(8 * ((nvb + 7) / 8) * ngrp), dim3(FUSED_NT), lds, (hipStream_t)stream, *m, f);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int whmr_smpl_blend_skin(const whmr_smpl_model* m, const float* posedirs_tiled, const float* betas, long beta_stride, const float* pose_feat,
                                     const float* A, int B, float* verts, void* stream) {
@@ -325,15 +388,16 @@ extern "C" int whmr_smpl_blend_skin(const whmr_smpl_model* m, const float* posed
     f.betas = betas; f.beta_stride = beta_stride; f.B = B;
     f.A = const_cast<float*>(A); f.pose_feat = const_cast<float*>(pose_feat); f.verts = verts; f.posedirs_tiled = posedirs_tiled;
     f.barrier = g_blend_stamps;
-    const size_t lds = (size_t)P2_FLOATS * 4;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)smpl_blend_skin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
-    const int nvb = (NV + FUSED_VT - 1) / FUSED_VT, ngrp = (B + FUSED_IG - 1) / FUSED_IG;
-    hipLaunchKernelGGL(smpl_blend_skin_kernel, dim3(8 * ((nvb + 7) / 8) * ngrp), dim3(FUSED_NT), lds, (hipStream_t)stream, *m, f);
-    WHMR_CHECK_LAUNCH();
-    return 0;
+    return launch_blend_skin<false>(m, f, stream);
+}
+
+// the same launch with the pose-corrective offsets on split-bf16 operands (fused_phase2_item<., X3 = true>); posedirs_x3: [108][13][2][2][192][8] bf16
+extern "C" int whmr_smpl_blend_skin_x3(const whmr_smpl_model* m, const void* posedirs_x3, const float* betas, long beta_stride, const float* pose_feat,
+                                       const float* A, int B, float* verts, void* stream) {
+    if (B <= 0 || !posedirs_x3 || !betas || !pose_feat || !A || !verts) return (int)hipErrorInvalidValue;
+    whmr_smpl_call f = {};
+    f.betas = betas; f.beta_stride = beta_stride; f.B = B;
+    f.A = const_cast<float*>(A); f.pose_feat = const_cast<float*>(pose_feat); f.verts = verts; f.posedirs_x3 = (const bf16_t*)posedirs_x3;
+    f.barrier = g_blend_stamps;
+    return launch_blend_skin<true>(m, f, stream);
 }

@@ -61,6 +61,7 @@ class SMPL(nn.Module):
         # launch form: pose chain -> blend shapes + skinning -> CSR joint regression + stage tail (3 launches)
         self.csr_tail = True        # False: the dense B x 33-workgroup regression + tail launch of round 2 (A/B)
         self.blend_skin = True      # pose-corrective offsets + skinning as one launch; False: fp32 GEMM into a [B, 20670] buffer + the skin kernel (A/B)
+        self.offsets_x3 = False     # blend launch: pose-corrective offsets on split-bf16 MFMA operands (~3e-7 of a vertex; WHMR sets it in the bf16 / bf16x3 numerics); False: exact f32
 
     @property
     def faces(self):
@@ -93,6 +94,9 @@ class SMPL(nn.Module):
             pt = torch.zeros(208, 108 * 192, dtype=torch.float32, device=dev)
             pt[:207, :self.NUM_VERTS * 3] = self.posedirs
             keep['posedirs_tiled'] = pt.view(208, 108, 192).permute(1, 0, 2).contiguous()
+            # the same tile as split-bf16 planes in MFMA operand order (whmr_smpl_blend_skin_x3): k = 16 s + 8 h + j -> [chunk][s][h][plane][column][j]
+            hi_, lo_ = L.split_bf16(pt.view(13, 2, 8, 108, 192))
+            keep['posedirs_x3'] = torch.stack([hi_, lo_], 0).permute(4, 1, 2, 0, 5, 3).contiguous()
             m = L.WhmrSmplModel()
             m.v_template, m.shapedirs = self.v_template.data_ptr(), keep['shapedirs_t'].data_ptr()
             m.posedirs, m.lbs_weights = self.posedirs.data_ptr(), keep['lbs_weights_t'].data_ptr()
@@ -140,7 +144,10 @@ class SMPL(nn.Module):
         L.smpl_pose_chain(m, pose9, betas, gram_schmidt, rot, aa, A, pj, pf)
         verts = torch.empty(B, self.NUM_VERTS, 3, **f32)
         if self.blend_skin:         # pose-corrective offsets (verts.py:51-53) on the matrix pipes + shape blend + skinning, one launch
-            L.smpl_blend_skin(m, self._dev_cache[2]['posedirs_tiled'], betas, pf, A, verts)
+            if self.offsets_x3:
+                L.smpl_blend_skin_x3(m, self._dev_cache[2]['posedirs_x3'], betas, pf, A, verts)
+            else:
+                L.smpl_blend_skin(m, self._dev_cache[2]['posedirs_tiled'], betas, pf, A, verts)
         else:                       # one fp32 MFMA GEMM [B,207] x [207,20670], then blend + skin
             pose_off = torch.empty(B, self.NUM_VERTS * 3, **f32)
             L.gemm(pf, self._dev_cache[2]['posedirs_t'], pose_off)

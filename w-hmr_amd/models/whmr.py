@@ -373,6 +373,7 @@ class WHMR(nn.Module):
         self.overlap_camera = True          # cam_model on a side stream beside the backbone (joined before the global-orientation head)
         self.camera_launch = os.environ.get('WHMR_CAM_LAUNCH', 'early')    # where the camera branch's launches are issued: 'early' | 'vit' | 'loop' (A/B, see _forward_eval)
         self.overlap_tz = True              # Tz head on a side stream beside the regressor loop (its outputs finalized after the join)
+        self.smpl_offsets_x3 = os.environ.get('WHMR_SMPL_X3', '1') != '0'   # A/B: 0 keeps the exact-f32 offsets in every numerics mode
         self.compose_tz = os.environ.get('WHMR_COMPOSE_TZ', '1') != '0'   # inference: the two Tz-head convolutions as ONE composed k25 / s6 convolution (False: the two-convolution form)
         self._tz_gemm_kw = {}               # explicit tile / split-K of the composed convolution's GEMM (A/B probes)
         self._tz_ones = {}
@@ -648,6 +649,8 @@ class WHMR(nn.Module):
         view = view or self.return_view
         with_aux = view == 'train'
         B, dev = x.shape[0], x.device
+        # SMPL's pose-corrective offsets: split-bf16 MFMA operands in the bf16 / bf16x3 numerics (~3e-7 of a vertex), the exact f32 chain in fp32
+        self.regressor[0].smpl.offsets_x3 = self.numerics != 'fp32' and self.smpl_offsets_x3
         # The camera-calibration ResNet-50 (whmr.py:509-522) only feeds the global-orientation head at the very end (whmr.py:630): it runs on a
         # SIDE stream beside the backbone / deconvs / regressor loop and is joined just before that head.  Its few-tile launches slot into the CUs
         # the big GEMM grids leave idle (tile-grid tails); under GraphedForward the fork / join become two branches of the captured graph.
