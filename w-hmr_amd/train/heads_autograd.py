@@ -308,6 +308,7 @@ class DownsampleFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, verts, d0, d1, cache):
+        ctx.set_materialize_grads(False)
         c = downsample_csr(d0, d1, cache)
         sub = L.csr_apply3(c['d0'], verts.detach(), d0.shape[0])
         tmp = L.csr_apply3(c['d1'], sub, d1.shape[0])
@@ -336,6 +337,7 @@ class RegressorPostFn(torch.autograd.Function):
     def forward(ctx, joints, cam, Tz, bbox_h, center, orig_shape, stage, consts):
         if not joints.is_cuda:
             raise RuntimeError('whmr_amd runs on a HIP device only (no CPU fallback)')
+        ctx.set_materialize_grads(False)            # cam_t / focal (and kp_2d_w at TRAIN.STAGE 1) usually carry no loss: the kernel takes null cotangents
         j, c, t = _f32(joints.detach()), _f32(cam.detach()), _f32(Tz.detach())
         bh, ce, os_ = _f32(bbox_h), _f32(center), _f32(orig_shape)
         B, J = j.shape[0], j.shape[1]

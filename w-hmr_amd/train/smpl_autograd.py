@@ -79,6 +79,7 @@ class SMPLFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, betas, rotmats, smpl):
+        ctx.set_materialize_grads(False)            # outputs no loss reaches arrive as None (smpl_backward takes each cotangent as optional), not as zero-filled tensors
         verts, joints, sj, mk, saved = smpl_forward_train(smpl, betas, rotmats, want_smpl_joints=True, want_markers=True)
         ctx.smpl, ctx.saved = smpl, saved
         if mk is None:
