@@ -43,7 +43,7 @@ bench whmr_b1 --workload whmr --batch 1 --no-cpu --no-parity --steps 50 --warmup
 cd /tmp
 prof() {  # name, description, bench args...
   local n=$1 d=$2; shift 2
-  rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof_$n -o $n -- python3 $R/bench.py "$@" > $OUT/${TAG}_prof_$n.log 2>&1
+  rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof_$n -o $n -- python3 $R/bench.py --no-ceilings "$@" > $OUT/${TAG}_prof_$n.log 2>&1
   local db=$(find $OUT/${TAG}_prof_$n -name '*.db' | head -1)
   [ -n "$db" ] || fail "no rocprof database for $n"
   { hdr "rocprofv3 --kernel-trace --stats -- python3 bench.py $*   ($d)"; python3 $R/tools/rocprof_summary.py $db | tail -n +2; } > $PROF/${TAG}_${n}_kernel_stats.txt
@@ -54,14 +54,14 @@ prof vit224_b64_bf16x3 "the same workload in the bf16x3 numerics" --no-cpu --no-
 prof whmr_b64 "full W-HMR forward, batch 64 + one 600x800 frame, bf16, HIP-graph replays + one eager instrumented step" --workload whmr --no-cpu --no-parity --steps 10 --warmup 3
 prof whmr_train_b64 "W-HMR training step, batch 64, bf16, Adam inside the step" --workload whmr_train --no-cpu --steps 4 --warmup 2
 # timeline of one replayed full forward (every launch with start offset / duration / HSA queue)
-rocprofv3 --kernel-trace -d $OUT/${TAG}_prof_tl -o tl -- python3 $R/bench.py --workload whmr --no-cpu --no-parity --steps 10 --warmup 3 > $OUT/${TAG}_prof_tl.log 2>&1
+rocprofv3 --kernel-trace -d $OUT/${TAG}_prof_tl -o tl -- python3 $R/bench.py --no-ceilings --workload whmr --no-cpu --no-parity --steps 10 --warmup 3 > $OUT/${TAG}_prof_tl.log 2>&1
 TDB=$(find $OUT/${TAG}_prof_tl -name '*.db' | head -1)
 [ -n "$TDB" ] || fail "no rocprof database for the timeline"
 { hdr "rocprofv3 --kernel-trace -- python3 bench.py --workload whmr --no-cpu --no-parity --steps 10 --warmup 3 ; python3 tools/whmr_timeline.py <db>   (the profiler serialises queues and stretches small launches)"; python3 $R/tools/whmr_timeline.py $TDB 0; } > $PROF/${TAG}_whmr_timeline.txt
 rm -rf $OUT/${TAG}_prof_tl
 pmc() {  # name, counters (quoted), bench args...
   local n=$1 c=$2; shift 2
-  rocprofv3 --kernel-trace --pmc $c -d $OUT/${TAG}_pmc_$n -o pmc -- python3 $R/bench.py "$@" > $OUT/${TAG}_pmc_$n.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c -d $OUT/${TAG}_pmc_$n -o pmc -- python3 $R/bench.py --no-ceilings "$@" > $OUT/${TAG}_pmc_$n.log 2>&1
   local db=$(find $OUT/${TAG}_pmc_$n -name '*.db' | head -1)
   [ -n "$db" ] || fail "no PMC database for $n"
   echo $db
