@@ -127,6 +127,12 @@ int whmr_gemm_blk(const struct whmr_gemm_blk_desc* p, void* stream);
 int whmr_gemm_blk_tile(const struct whmr_gemm_blk_desc* p, int tile, void* stream);
 /* A/B switch: force a tile for the ViT-B shapes (slot 0 qkv N = 2304, 1 proj, 2 fc1 N = 3072, 3 fc2); 0 = chooser. */
 int whmr_gemm_blk_set_tile(int slot, int tile);
+/* PILOT (round 6; off by default): fc1 (epi 1) -> fc2 (epi 2) of one transformer layer (vit.py:61-76 inside vit.py:117-140) as ONE persistent launch: grid = CU
+ * count, every workgroup walks a static list [fc1 tiles | fc2 tiles], an fc2 tile waits on the arrive counters of the fc1 row panels it reads (bounded
+ * spin: *err is raised after 20 ms, never a hang).  Same tile bodies as the two whmr_gemm_blk launches: bit-identical results.  Takes exactly the pair of
+ * the ViT-B inference path (fc2->A == fc1->C, same M, plain bf16 operands; tiles 320 x 256 / 160 x 256); anything else returns hipErrorInvalidValue and
+ * nothing is launched.  counters: >= ceil(M / 320) uint32 (zeroed by the call); err: one int32 (caller zeroes it once). */
+int whmr_gemm_blk_chain(const struct whmr_gemm_blk_desc* fc1, const struct whmr_gemm_blk_desc* fc2, void* counters, void* err, void* stream);
 /* LayerNorm on the blocked fp32 residual stream -> blocked bf16 GEMM operand (out_std 0) or row-major fp32 [rows, C] (out_std 1: last_norm). */
 int whmr_layernorm_blk(const float* x, const float* gamma, const float* beta, void* y, int rows, int C, float eps, int out_std, void* stream);
 /* The same (out_std 0) + the row means mean_out [ceil(rows/32)*32]: the first LayerNorm of the folded chain (vit.py:125 of block 0) runs explicitly and

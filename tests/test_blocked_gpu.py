@@ -353,3 +353,41 @@ def test_vit_ln_fold_shift_chain_on_offset_stream(dev):
     ef, eu = _rel(out_f, ref), _rel(out_u, ref)
     print('offset stream (30 std per token): folded+shift %.3e, explicit bf16 LayerNorm %.3e (vs bf16x3)' % (ef, eu))
     assert ef < 2 * eu + 1e-3
+
+
+@pytest.mark.parametrize('M', [12544, 1000, 352])
+def test_gemm_blk_chain_matches_two_launches(dev, M):
+    """whmr_gemm_blk_chain (round-6 pilot: fc1 -> fc2 of vit.py:61-76 as ONE persistent launch with arrive counters per 320-row panel) against the two
+    whmr_gemm_blk launches on the same tiles: hidden activations, residual stream, the next LayerNorm's operand copy and its statistics bit for bit;
+    fc2 overwrites fc1's A operand (as in the model); the device error flag stays clear.  M = 12544: the ViT-B batch-64 shape (717 list items on
+    256 workgroups); 1000 / 352: ragged last panel, fewer items than workgroups."""
+    from whmr_amd import _lib as L
+    g = torch.Generator().manual_seed(M)
+    C_, Hd = 768, 3072
+    x = torch.randn(M, C_, generator=g).bfloat16().to(dev)
+    w1 = L.to_blocked((torch.randn(Hd, C_, generator=g) / C_ ** 0.5).bfloat16().to(dev))
+    w2 = L.to_blocked((torch.randn(C_, Hd, generator=g) / Hd ** 0.5).bfloat16().to(dev))
+    b1, b2 = torch.randn(Hd, generator=g).to(dev), torch.randn(C_, generator=g).to(dev)
+    t0 = L.to_blocked(torch.randn(M, C_, generator=g).to(dev))
+    nb = t0.shape[0]
+    outs = []
+    for chained in (False, True, True):
+        h = L.to_blocked(x).clone()                                   # fc1's A operand; fc2 writes the next operand copy over it
+        hid = torch.full((nb, Hd // 8, 32, 8), float('nan'), dtype=torch.bfloat16, device=dev)
+        t = t0.clone()
+        stats = torch.full((nb * 32 * (C_ // 256) * 2,), float('nan'), device=dev)
+        fc1 = dict(a=h, w=w1, out=hid, M=M, bias=b1, epi=L.EPI_BF16_GELU)
+        fc2 = dict(a=hid, w=w2, out=t, M=M, bias=b2, epi=L.EPI_F32_RES, res=t, xhat=h, stats_out=stats)
+        if chained:
+            assert L.gemm_blk_chain(fc1, fc2), 'the C entry did not take the pair'
+        else:
+            L.gemm_blk(tile=0x55, **fc1)
+            L.gemm_blk(tile=0x32, **fc2)
+        torch.cuda.synchronize()
+        outs.append((L.from_blocked(hid, M), L.from_blocked(t, M), L.from_blocked(h, M), stats.view(-1, C_ // 256, 2)[:M].clone()))
+    assert L.chain_error(dev) == 0
+    for k, name in enumerate(('hidden', 'stream', 'operand copy', 'statistics')):
+        assert torch.equal(outs[0][k], outs[1][k]), name
+        assert torch.equal(outs[1][k], outs[2][k]), name + ' (second chained call)'
+    ref = torch.nn.functional.gelu(x.float().cpu() @ L.from_blocked(w1, Hd).float().cpu().t() + b1.cpu())
+    assert _rel(outs[1][0].float().cpu(), ref) < 2e-2

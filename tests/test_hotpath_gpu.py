@@ -259,6 +259,20 @@ def test_camera_side_stream_is_bit_identical(dev, assets, state_dict, gold):
             for k in ref:
                 assert torch.equal(out[k], ref[k]), k
     assert not torch.equal(ref['cam_rotmat'][0], torch.eye(3, device=dev))   # the frame did reach the camera head
+    # round 6: WHERE the camera branch is issued (right behind the backbone's launches / behind every other launch / first) and the two-convolution
+    # form of the Tz head's launch order do not change a bit either, eager and replayed from a HIP graph
+    from whmr_amd.graph import GraphedForward
+    full = kw['full_x'][:1].contiguous()
+    for pos in ('vit', 'loop', 'early'):
+        m.camera_launch = pos
+        out = m(*args, full_x=full)
+        for k in ref:
+            assert torch.equal(out[k], ref[k]), (pos, k)
+        g = GraphedForward(m, *args, full_x=full)
+        out = g(*args, full_x=full)
+        torch.cuda.synchronize()
+        for k in ref:
+            assert torch.equal(out[k], ref[k]), (pos, 'graph', k)
 
 
 def test_whmr_eval_view_with_h36m_regressor_and_sliced_input(dev, assets, state_dict):

@@ -81,6 +81,7 @@ _SIGS = {
     'whmr_gemm_blk': [C.POINTER(WhmrGemmBlk), _P],
     'whmr_gemm_blk_tile': [C.POINTER(WhmrGemmBlk), _I, _P],
     'whmr_gemm_blk_set_tile': [_I, _I],
+    'whmr_gemm_blk_chain': [C.POINTER(WhmrGemmBlk), C.POINTER(WhmrGemmBlk), _P, _P, _P],
     'whmr_layernorm_blk': [_P, _P, _P, _P, _I, _I, _F, _I, _P],
     'whmr_patch_im2col_blk': [_P, _P, _I, _I, _I, _I, _I, _I, _L, _L, _L, _L, _P],
     'whmr_attention_blk': [_P, _P, _I, _I, _I, _F, _P],
@@ -372,11 +373,62 @@ def split_bf16(t):
     return hi, (t - hi.float()).bfloat16()
 
 
-def gemm_blk(a, w, out, M, bias=None, epi=EPI_BF16, res=None, res_rows=0, tile=0, xhat=None, stats_out=None, stats_in=None, colsum=None,
-             ln_eps=1e-6, a_lo=None, w_lo=None, out_lo=None, shift=None, shift_stats=None, shift_out=None, xhat_lo=None):
+def gemm_blk(a, w, out, M, **kw):
     """out = epi(a . w^T + bias [+ res]) on blocked operands: a [M/32][K/8][32][8] bf16, w [N/32][K/8][32][8] bf16,
     out bf16 [M/32][N/8][32][8] (epi 0/1) or fp32 [M/32][N/4][32][4] (epi 2: + blocked res, may be `out`; epi 3: + res[m % res_rows] row-major).
-    a_lo / w_lo (/ out_lo for epi 0/1): the lo halves of split-bf16 operands -> the bf16x3 kernel (three MFMAs per product, fp32-grade result)."""
+    a_lo / w_lo (/ out_lo for epi 0/1): the lo halves of split-bf16 operands -> the bf16x3 kernel (three MFMAs per product, fp32-grade result).
+    Keyword arguments: see ``_blk_desc``."""
+    p, x3, N, K = _blk_desc(a, w, out, M, **kw)
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _check(lib().whmr_gemm_blk(C.byref(p), _stream()), 'whmr_gemm_blk')
+        e1.record()
+        PROFILE.append(('gemm_bf16x3' if x3 else 'gemm_bf16', 2.0 * M * N * K, e0, e1))
+        return out
+    _check(lib().whmr_gemm_blk(C.byref(p), _stream()), 'whmr_gemm_blk')
+    return out
+
+
+_CHAIN_SCRATCH = {}
+
+
+def gemm_blk_chain(fc1, fc2):
+    """PILOT (round 6): the fc1 -> fc2 pair of a transformer layer as ONE persistent launch (whmr_gemm_blk_chain).  fc1 / fc2: dicts of gemm_blk's
+    arguments (a, w, out, M, + keywords); fc2['a'] must be fc1['out'].  -> True when the pair was launched that way, False when the C entry does not
+    take the pair (the caller then issues the two launches).  The device-side error flag (a wait that hit its limit) is readable as ``chain_error(dev)``."""
+    f1, f2 = dict(fc1), dict(fc2)
+    p1, x31, N1, K1 = _blk_desc(f1.pop('a'), f1.pop('w'), f1.pop('out'), f1.pop('M'), **f1)
+    p2, x32, N2, K2 = _blk_desc(f2.pop('a'), f2.pop('w'), f2.pop('out'), f2.pop('M'), **f2)
+    if x31 or x32:
+        return False
+    dev = fc1['a'].device
+    sc = _CHAIN_SCRATCH.get(dev)
+    if sc is None:
+        sc = _CHAIN_SCRATCH[dev] = (torch.zeros(4096, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev))
+    if (p1.M + 319) // 320 > sc[0].numel():
+        return False
+    ev = _profile_begin()
+    rc = lib().whmr_gemm_blk_chain(C.byref(p1), C.byref(p2), sc[0].data_ptr(), sc[1].data_ptr(), _stream())
+    if rc == 1:                                  # hipErrorInvalidValue: not a pair the pilot takes, nothing was launched
+        return False
+    _check(rc, 'whmr_gemm_blk_chain')
+    if ev is not None:                           # one launch, two products: booked as two GEMM rows of half the span each
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        PROFILE.append(('gemm_bf16_chain', 2.0 * p1.M * (N1 * K1 + N2 * K2), ev, e1))
+    return True
+
+
+def chain_error(device):
+    """1 when a wait of a chained launch on ``device`` ever ran into its time limit (synchronises)"""
+    sc = _CHAIN_SCRATCH.get(device)
+    return 0 if sc is None else int(sc[1].item())
+
+
+def _blk_desc(a, w, out, M, bias=None, epi=EPI_BF16, res=None, res_rows=0, tile=0, xhat=None, stats_out=None, stats_in=None, colsum=None,
+              ln_eps=1e-6, a_lo=None, w_lo=None, out_lo=None, shift=None, shift_stats=None, shift_out=None, xhat_lo=None):
+    """-> (whmr_gemm_blk_desc, split-bf16?, N, K) for gemm_blk's arguments (shape / dtype checks included)"""
     _dev(a, w, out, bias, res)
     assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and a.is_contiguous() and w.is_contiguous() and out.is_contiguous()
     N, K = w.shape[0] * 32, w.shape[1] * 8
@@ -419,15 +471,8 @@ def gemm_blk(a, w, out, M, bias=None, epi=EPI_BF16, res=None, res_rows=0, tile=0
         if epi < 2:
             assert out_lo is not None and out_lo.shape == out.shape and out_lo.dtype == torch.bfloat16 and out_lo.is_contiguous()
             p.C_lo = out_lo.data_ptr()
-    if PROFILE is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        _check(lib().whmr_gemm_blk(C.byref(p), _stream()), 'whmr_gemm_blk')
-        e1.record()
-        PROFILE.append(('gemm_bf16x3' if x3 else 'gemm_bf16', 2.0 * M * N * K, e0, e1))
-        return out
-    _check(lib().whmr_gemm_blk(C.byref(p), _stream()), 'whmr_gemm_blk')
-    return out
+    p._keep = (a, w, out, bias, res, xhat, stats_out, stats_in, colsum, a_lo, w_lo, out_lo, shift, shift_stats, shift_out, xhat_lo)
+    return p, x3, N, K
 
 
 def layernorm_blk(x, weight, bias, out, rows, eps, out_std=False, mean_out=None):

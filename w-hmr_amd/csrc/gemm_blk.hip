@@ -62,8 +62,10 @@ extern "C" int whmr_gemm_blk_tile(const whmr_gemm_blk_desc* pp, int tile, void* 
     return blk16_launch_tile(p, tile, (hipStream_t)stream);
 }
 
+static int g_chain_lab = 0;                                 // whmr_gemm_blk_set_tile(4, v): lab switch of the chain pilot (1 = workgroup-scope fences: WRONG across XCDs, timing only)
 static int g_blk_force[4] = {0, 0, 0, 0};                   // whmr_set_option keys 110..113: tile for N = 2304 / (768, K <= 1024) / 3072 / (768, K > 1024)
 extern "C" int whmr_gemm_blk_set_tile(int slot, int tile) {
+    if (slot == 4) { g_chain_lab = tile; return 0; }
     if (slot < 0 || slot > 3) return (int)hipErrorInvalidValue;
     g_blk_force[slot] = tile;
     return 0;
@@ -90,4 +92,26 @@ extern "C" int whmr_gemm_blk(const whmr_gemm_blk_desc* pp, void* stream) {
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = (t[0] << 4) | t[1]; }
     }
     return whmr_gemm_blk_tile(pp, best, stream);
+}
+
+// fc1 (epi 1: bf16 + GELU, optionally with the folded LayerNorm) -> fc2 (epi 2: fp32 + residual, optionally emitting the next LayerNorm's operand copy and
+// statistics) as ONE persistent launch (gemm_blk16_chain_kernel, gemm_blk16_impl.h) -- the cross-launch PILOT of round 6.  Accepts exactly the pair the
+// ViT-B inference path issues on the tiles its chooser picks (fc1 320 x 256, fc2 160 x 256); anything else returns hipErrorInvalidValue and the caller
+// issues the two launches.  counters: >= ceil(M / 320) uint32 (zeroed here); err: one int32 the kernel raises when a wait ran into its 20 ms limit.
+extern "C" int whmr_gemm_blk_chain(const whmr_gemm_blk_desc* fc1, const whmr_gemm_blk_desc* fc2, void* counters, void* err, void* stream) {
+#ifdef WHMR_BLK_STAMPS
+    return (int)hipErrorInvalidValue;
+#else
+    const whmr_gemm_blk_desc &a = *fc1, &b = *fc2;
+    if (!counters || !err || a.epi != 1 || b.epi != 2 || a.M != b.M || a.M <= 0 || a.C != b.A || a.N != b.K || (a.N % 256) || (b.N % 256) || (a.K % 32) ||
+        (b.K % 32) || !b.res || a.A_lo || a.W_lo || a.C_lo || b.A_lo || b.W_lo || b.C_lo || a.xhat || (b.xhat && (!b.stats_out || b.N > 1024)) ||
+        (a.stats_in && (!a.colsum || (a.K % 256) || a.K > 1024)) || b.stats_in)
+        return (int)hipErrorInvalidValue;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) { cus = 0; return (int)hipErrorInvalidValue; }
+    }
+    return launch_blk16_chain<5, 5, 3, 2>(a, b, (unsigned*)counters, (int*)err, cus, g_chain_lab, (hipStream_t)stream);
+#endif
 }

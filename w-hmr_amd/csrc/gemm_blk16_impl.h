@@ -73,8 +73,9 @@ struct blk16_cfg {
 
 // One barrier per half tile, the two wave groups in opposite order within a slot.  (Round 3-4 also carried a two-barrier schedule and the same tile on
 // FOUR waves, one per SIMD -- tile id 0x144, bit-identical, same K slope, worse epilogue: profiles/r04_fw4_ab.txt.  Both are gone from the build.)
+// lid_in >= 0: the logical tile id is given by the caller (the persistent chain kernel below walks a tile list); < 0: one tile per workgroup, XCD-aware order
 template <int MI0, int MI1, int EPI, int SCHED, int NW>
-__device__ __forceinline__ void gemm_blk16_body(const whmr_gemm_blk_desc& p, char* smem BLK16_STAMP_PARAM) {
+__device__ __forceinline__ void gemm_blk16_body(const whmr_gemm_blk_desc& p, char* smem, int lid_in BLK16_STAMP_PARAM) {
     using cfg = blk16_cfg<MI0, MI1>;
     constexpr int MB = cfg::MB, BM = cfg::BM, BN = cfg::BN, SLOT = cfg::SLOT, HU = cfg::HU, NJ = NW == 8 ? 2 : 4, NT = NW * 64;
     constexpr int HUPW = (HU + NW - 1) / NW;             // DMA units per wave (waves >= HU % NW issue one less when HU % NW != 0)
@@ -84,7 +85,7 @@ __device__ __forceinline__ void gemm_blk16_body(const whmr_gemm_blk_desc& p, cha
     const int wm = NW == 8 ? wave >> 2 : wave >> 1, wn = NW == 8 ? wave & 3 : wave & 1;     // NW 8: wm = group
     const int l15 = lane & 15, g = lane >> 4;             // row inside a 16-row half / K chunk of the operand fragments = column group of the results
     const int tiles_n = p.N / BN, tiles_m = (p.M + BM - 1) / BM;
-    const int lid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int lid = lid_in >= 0 ? lid_in : xcd_remap(blockIdx.x, tiles_m * tiles_n);
     const int tm = lid / tiles_n, tn = lid % tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
     BLK16_STAMP(0);
@@ -419,8 +420,81 @@ __device__ __forceinline__ void gemm_blk16_body(const whmr_gemm_blk_desc& p, cha
 template <int MI0, int MI1, int EPI, int SCHED>
 __global__ __launch_bounds__(512, 2) void gemm_blk16_kernel(const whmr_gemm_blk_desc p BLK16_STAMP_PARAM) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    gemm_blk16_body<MI0, MI1, EPI, SCHED, 8>(p, smem BLK16_STAMP_PASS);
+    gemm_blk16_body<MI0, MI1, EPI, SCHED, 8>(p, smem, -1 BLK16_STAMP_PASS);
 }
+
+#ifndef WHMR_BLK_STAMPS
+// ---- PILOT (round 6; off by default, WHMR_BLK_CHAIN=1): fc1 -> fc2 of one transformer layer as ONE persistent launch.
+// grid = the CU count; workgroup w walks items w, w + grid, ... of the static list [fc1 tiles (XCD-aware order) | fc2 tiles]; an fc1 tile ARRIVES on the
+// counter of its row panel when all its stores are visible device-wide (per-thread release fence at agent scope, barrier, one atomic add); an fc2 tile
+// WAITS until the fc1 panels that hold its rows have seen all their column tiles, then takes an acquire fence (the XCD's L2 must not serve stale lines
+// of the hidden activations: the buffer is reused every layer).  Every wait targets EARLIER items of the list and a workgroup walks its items in order,
+// so the list cannot deadlock once every workgroup has started; a workgroup that has not been scheduled yet (foreign kernels on its CU) is what the
+// BOUNDED spin covers: after `spin_limit` ticks of the 100 MHz counter the waiter raises *err and goes on (wrong results, flagged -- never a hang).
+// The same tile bodies as the two launches: bit-identical outputs.
+template <int A0, int A1, int B0, int B1>
+__global__ __launch_bounds__(512, 2) void gemm_blk16_chain_kernel(const whmr_gemm_blk_desc p1, const whmr_gemm_blk_desc p2, unsigned* __restrict__ cnt,
+                                                                  int* __restrict__ err, unsigned long long spin_limit, int lab) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BM1 = (A0 + A1) * 32, BM2 = (B0 + B1) * 32;
+    const int tn1 = p1.N / 256, tm1 = (p1.M + BM1 - 1) / BM1, n1 = tn1 * tm1;
+    const int tn2 = p2.N / 256, tm2 = (p2.M + BM2 - 1) / BM2, n2 = tn2 * tm2;
+    // (two loops, not one loop with a branch: with both tile bodies inside one loop the two descriptors' ~100 scalar registers stay live together, spill to
+    //  vector lanes and push the kernel to 256 VGPRs + scratch; the walk order is the same -- every fc1 item of the list precedes every fc2 item)
+    int item = blockIdx.x;
+    for (; item < n1; item += gridDim.x) {
+        const int lid = xcd_remap(item, n1);
+        gemm_blk16_body<A0, A1, 1, 1, 8>(p1, smem, lid);
+        // (lab != 0, tools/r6_chain_ab.py only: workgroup-scope fences -- NOT correct across the XCD-private L2s; it prices the agent-scope fences)
+        if (lab) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                   // this wave's stores of the tile: complete and written back
+        __syncthreads();                                                          // (also: the next item's prologue overwrites the bias / statistics area and the ring)
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(&cnt[lid / tn1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    for (; item < n1 + n2; item += gridDim.x) {
+        const int lid = xcd_remap(item - n1, n2);
+        const int r0 = (lid / tn2) * BM2;
+        int r1 = r0 + BM2 - 1;
+        if (r1 > p2.M - 1) r1 = p2.M - 1;
+        if (threadIdx.x == 0) {
+            int bad = 0;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            for (int pn = r0 / BM1; pn <= r1 / BM1 && !bad; ++pn) {
+                while (__hip_atomic_load(&cnt[pn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)tn1) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > spin_limit) { bad = 1; break; }
+                }
+            }
+            if (bad) *err = 1;
+        }
+        __syncthreads();
+        if (lab) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        gemm_blk16_body<B0, B1, 2, 1, 8>(p2, smem, lid);
+        __syncthreads();
+    }
+}
+
+template <int A0, int A1, int B0, int B1>
+static int launch_blk16_chain(const whmr_gemm_blk_desc& p1, const whmr_gemm_blk_desc& p2, unsigned* cnt, int* err, int grid, int lab, hipStream_t st) {
+    using c1 = blk16_cfg<A0, A1>;
+    using c2 = blk16_cfg<B0, B1>;
+    constexpr int LDS = c1::LDS > c2::LDS ? c1::LDS : c2::LDS;
+    auto kern = gemm_blk16_chain_kernel<A0, A1, B0, B1>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    const int panels = (p1.M + c1::BM - 1) / c1::BM;
+    hipError_t e = hipMemsetAsync(cnt, 0, sizeof(unsigned) * panels, st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, st, p1, p2, cnt, err, 2000000ull /* 20 ms */, lab);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}
+#endif
 
 template <int MI0, int MI1, int EPI, int SCHED>
 static int launch_blk16_s(const whmr_gemm_blk_desc& p, hipStream_t st) {

@@ -19,6 +19,8 @@ kernels (same arithmetic; kept for A/B runs, the training graph and the fp32 par
 """
 import math
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -99,10 +101,10 @@ class ViT(nn.Module):
         self._wcache = {}
         self._ws = {}
         self.blocked = True                 # bf16 inference on the blocked-layout kernels when the shapes allow it
+        self.chain_mlp = os.environ.get('WHMR_BLK_CHAIN', '0') != '0'      # pilot: fc1 -> fc2 as one persistent launch (whmr_gemm_blk_chain)
         self.blocked_min_tokens = 2048      # ... and the batch has at least this many tokens (set 0 to force the blocked path)
         self.x3_min_tokens = 320            # bf16x3: below this many tokens (one 224^2 / 256x192 crop) the exact-f32 path is the faster parity-grade one
         self.ln_fold = True                 # ... with norm1 / norm2 folded into the qkv / fc1 GEMMs (no LayerNorm pass inside the blocks)
-        import os
         self.ln_fold_x3 = os.environ.get('WHMR_X3_FOLD', '1') != '0'      # the same fold in the bf16x3 pipeline (A/B: tools/r3_x3ab.sh)
 
     # ------------------------------------------------------------------ weight / workspace caches
@@ -258,14 +260,20 @@ class ViT(nn.Module):
                            stats_out=st[cur ^ 1], shift=sh[cur], shift_stats=None if bi == 0 else st[cur], shift_out=sh[cur ^ 1])
                 cur ^= 1
                 w1, s1, c1 = self._wfold(blk.mlp.fc1, blk.norm2)
-                L.gemm_blk(h, w1, hid, M, bias=c1, epi=L.EPI_BF16_GELU, stats_in=st[cur], colsum=s1, ln_eps=1e-6)
+                fc1 = dict(a=h, w=w1, out=hid, M=M, bias=c1, epi=L.EPI_BF16_GELU, stats_in=st[cur], colsum=s1, ln_eps=1e-6)
                 last = bi + 1 == nblk
                 if last:
-                    L.gemm_blk(hid, self._wblk(blk.mlp.fc2.weight), t, M, bias=blk.mlp.fc2.bias, epi=L.EPI_F32_RES, res=t)
+                    fc2 = dict(a=hid, w=self._wblk(blk.mlp.fc2.weight), out=t, M=M, bias=blk.mlp.fc2.bias, epi=L.EPI_F32_RES, res=t)
                 else:
-                    L.gemm_blk(hid, self._wblk(blk.mlp.fc2.weight), t, M, bias=blk.mlp.fc2.bias, epi=L.EPI_F32_RES, res=t, xhat=h,
+                    fc2 = dict(a=hid, w=self._wblk(blk.mlp.fc2.weight), out=t, M=M, bias=blk.mlp.fc2.bias, epi=L.EPI_F32_RES, res=t, xhat=h,
                                stats_out=st[cur ^ 1], shift=sh[cur], shift_stats=st[cur], shift_out=sh[cur ^ 1])
                     cur ^= 1
+                # (pilot, WHMR_BLK_CHAIN=1: the pair as one persistent launch with arrive counters -- same bits; off by default, DESIGN 8 item 2.
+                #  fc2 overwrites h -- fc1's A operand -- with the next LayerNorm's operand copy: safe inside the chain, because an fc2 tile starts only when
+                #  ALL fc1 column tiles of its row panel, the only readers of those rows of h, have arrived)
+                if not (self.chain_mlp and L.gemm_blk_chain(fc1, fc2)):
+                    L.gemm_blk(**fc1)
+                    L.gemm_blk(**fc2)
             out = torch.empty((M, D), dtype=f32, device=dev)
             L.layernorm_blk(t, self.last_norm.weight, self.last_norm.bias, out, M, 1e-6, out_std=True)
             return out
