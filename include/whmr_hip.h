@@ -125,7 +125,8 @@ struct whmr_gemm_blk_desc {
 };
 int whmr_gemm_blk(const struct whmr_gemm_blk_desc* p, void* stream);
 int whmr_gemm_blk_tile(const struct whmr_gemm_blk_desc* p, int tile, void* stream);
-/* A/B switch: force a tile for the ViT-B shapes (slot 0 qkv N = 2304, 1 proj, 2 fc1 N = 3072, 3 fc2); 0 = chooser. */
+/* A/B switch: force a tile for the ViT-B shapes (slot 0 qkv N = 2304, 1 proj, 2 fc1 N = 3072, 3 fc2); 0 = chooser.
+ * slot 4 (lab, tools/r6_chain_ab.py only): tile != 0 runs whmr_gemm_blk_chain with workgroup-scope fences -- NOT correct across XCDs, timing only. */
 int whmr_gemm_blk_set_tile(int slot, int tile);
 /* PILOT (round 6; off by default): fc1 (epi 1) -> fc2 (epi 2) of one transformer layer (vit.py:61-76 inside vit.py:117-140) as ONE persistent launch: grid = CU
  * count, every workgroup walks a static list [fc1 tiles | fc2 tiles], an fc2 tile waits on the arrive counters of the fc1 row panels it reads (bounded
