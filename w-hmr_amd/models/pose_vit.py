@@ -159,6 +159,17 @@ class ViT(nn.Module):
             t = self._ws[key] = torch.empty(shape, dtype=dtype, device=device)
         return t
 
+    def _pos(self, N, D, device):
+        """pos_embed[:, 1:] + pos_embed[:, :1] (vit.py:320) as an [N, D] fp32 table: a constant of the weights, so it is built once per parameter version
+        instead of by one framework launch per forward"""
+        pe = self.pos_embed
+        key = (pe._version, pe.data_ptr(), device, N, D)
+        ent = self._ws.get('pos_table')
+        if ent is None or ent[0] != key:
+            pos = torch.add(pe.detach()[0, 1:], pe.detach()[0, :1]).float().contiguous()
+            ent = self._ws['pos_table'] = (key, pos)
+        return ent[1]
+
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
     def forward_tokens(self, x):
@@ -189,8 +200,7 @@ class ViT(nn.Module):
             return self._forward_tokens_blocked(x, B, Hp, Wp), (B, Hp, Wp)
         cols = self._buf('cols', (M, Cin * P * P), dt, dev)
         L.patch_im2col(x.float(), cols, P, pad)
-        pos = self._buf('pos', (N, D), torch.float32, dev)
-        torch.add(self.pos_embed[0, 1:], self.pos_embed[0, :1], out=pos)              # vit.py:320
+        pos = self._pos(N, D, dev)                                                    # vit.py:320
         t = self._buf('t', (M, D), torch.float32, dev)
         L.gemm(cols, self._w(self.patch_embed.proj.weight, (D, Cin * P * P)), t, bias=self.patch_embed.proj.bias,
                residual=pos, res_row_mod=N)
@@ -220,8 +230,7 @@ class ViT(nn.Module):
         K0 = Cin * P * P
         cols = self._buf('cols_blk', (nb, K0 // 8, 32, 8), bf, dev)
         L.patch_im2col_blk(x.float(), cols, P, pad)
-        pos = self._buf('pos', (N, D), f32, dev)
-        torch.add(self.pos_embed[0, 1:], self.pos_embed[0, :1], out=pos)              # vit.py:320
+        pos = self._pos(N, D, dev)                                                    # vit.py:320
         t = self._buf('t_blk', (nb, D // 4, 32, 4), f32, dev)
         fold = self.ln_fold and D <= 1024
         if not fold:
@@ -329,8 +338,7 @@ class ViT(nn.Module):
         pair = lambda name, cols: (self._buf(name + '_hi', (nb, cols // 8, 32, 8), bf, dev), self._buf(name + '_lo', (nb, cols // 8, 32, 8), bf, dev))
         cols = pair('x3cols', K0)
         L.patch_im2col_blk(x.float(), cols[0], P, pad, out_lo=cols[1])
-        pos = self._buf('pos', (N, D), f32, dev)
-        torch.add(self.pos_embed[0, 1:], self.pos_embed[0, :1], out=pos)              # vit.py:320
+        pos = self._pos(N, D, dev)                                                    # vit.py:320
         t = self._buf('t_blk', (nb, D // 4, 32, 4), f32, dev)
         w = self._wblk_x3(self.patch_embed.proj.weight, (D, K0))
         L.gemm_blk(cols[0], w[0], t, M, bias=self.patch_embed.proj.bias, epi=L.EPI_F32_POS, res=pos, res_rows=N, a_lo=cols[1], w_lo=w[1])

@@ -593,6 +593,15 @@ class WHMR(nn.Module):
             self._init_cache = (key, reg.forward_init(x1, with_aux=with_aux))
         return expand(self._init_cache[1])
 
+    def _grid_points(self, B):
+        """the stage-0 sampling grid as [B, 63, 2] points (whmr.py:586-590: points_grid expanded and transposed): a constant, built once per batch size"""
+        g = self.points_grid
+        key = (B, g.device, g._version, g.data_ptr())
+        ent = self.__dict__.get('_grid_pts')
+        if ent is None or ent[0] != key:
+            ent = self.__dict__['_grid_pts'] = (key, g.expand(B, -1, -1).transpose(1, 2).contiguous())
+        return ent[1]
+
     def _tz_placeholder(self, B, dev):
         t = self._tz_ones.get((dev, B))
         if t is None:
@@ -733,7 +742,7 @@ class WHMR(nn.Module):
             ext.cam = cam
             xc = xcs[i]
             if i == 0:
-                pts = self.points_grid.expand(B, -1, -1).transpose(1, 2).contiguous()
+                pts = self._grid_points(B)
                 ext.sampling(pts, out=xc, want_point_feat=False)
             else:
                 ext(smpl_output['markers'], cam=cam, out=xc, want_point_feat=False)   # cam: a strided column slice of the state (no copy)
