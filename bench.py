@@ -51,6 +51,7 @@ def parse(argv=None):
                     help='whmr_train: the synthetic L2 loss over the 27 supervised tensors as multi-tensor launches (default) or as 27 x (pow, mean, add) '
                          'torch expressions (~190 small launches per step on the critical stream)')
     ap.add_argument('--eager', action='store_true', help='whmr: time the eager module call instead of the HIP-graph replay (default: graph)')
+    ap.add_argument('--serial', action='store_true', help='whmr: the eager call with the side streams folded into the main one (per-kernel durations without concurrency, for rocprofv3)')
     ap.add_argument('--full-x', default='hoisted', choices=('hoisted', 'per-crop', 'none'),
                     help='whmr (BASELINE configs[2]): full-frame input of cam_model -- one [1,3,600,800] frame shared by the batch (default), one frame per '
                          'crop [B,3,600,800] as demo/tester.py:161 replicates it, or none (camera rotation = identity given)')
@@ -119,6 +120,8 @@ def build_workload(args, dev):
             finally:
                 m.overlap_camera, m.overlap_tz = ov
         args.eager_step = eager_serial
+        if args.serial:
+            return eager_serial, None, inp['x'], (256, 192)
         if args.eager:
             return eager, None, inp['x'], (256, 192)
         g = GraphedForward(m, *a, **kw)
@@ -1067,7 +1070,7 @@ def main(argv=None):
             'dtype': args.numerics, 'data': 'dryrun' if dry else 'synthetic',
             'config': {'workload': ('%s (%s), %dx%d crops, batch %d per GPU, random-init weights%s'
                                     % (WORKLOAD[args.workload], args.workload, size[0], size[1], args.batch,
-                                       ('; ' + args.full_x_note + ('; eager module call' if args.eager else '; replayed from one HIP graph'))
+                                       ('; ' + args.full_x_note + ('; eager module call, side streams folded into the main one' if args.serial else '; eager module call' if args.eager else '; replayed from one HIP graph'))
                                        if args.workload == 'whmr' else
                                        ('; synthetic L2 loss over the 27 supervised tensors as %s' % ('multi-tensor launches' if args.loss == 'multi-tensor' else '27 x (pow, mean, add) expressions'))
                                        if args.workload == 'whmr_train' else '')) if not dry else 'dryrun-cpu stand-in',

@@ -52,6 +52,7 @@ prof() {  # name, description, bench args...
 prof vit224_b64 "ViT-B/16 224^2 batch 64 bf16: timed steps + warm-ups + 1 instrumented step in the trace" --no-cpu --no-secondary --steps 10 --warmup 3
 prof vit224_b64_bf16x3 "the same workload in the bf16x3 numerics" --no-cpu --no-secondary --numerics bf16x3 --steps 10 --warmup 3
 prof whmr_b64 "full W-HMR forward, batch 64 + one 600x800 frame, bf16, HIP-graph replays + one eager instrumented step" --workload whmr --no-cpu --no-parity --steps 10 --warmup 3
+prof whmr_b64_serial "the same forward with the side streams folded into the main one (eager): every kernel's duration WITHOUT concurrency" --workload whmr --serial --no-cpu --no-parity --steps 10 --warmup 3
 prof whmr_train_b64 "W-HMR training step, batch 64, bf16, Adam inside the step" --workload whmr_train --no-cpu --steps 4 --warmup 2
 # timeline of one replayed full forward (every launch with start offset / duration / HSA queue)
 rocprofv3 --kernel-trace -d $OUT/${TAG}_prof_tl -o tl -- python3 $R/bench.py --no-ceilings --workload whmr --no-cpu --no-parity --steps 10 --warmup 3 > $OUT/${TAG}_prof_tl.log 2>&1
