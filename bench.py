@@ -1139,6 +1139,21 @@ def main(argv=None):
                                            'cpu_baseline_per_crop': 1,
                                            'note': 'machine-readable form of config.workload: the GPU step runs cam_model on this many 600x800 frames per '
                                                    'batch; the CPU leg replicates the frame per crop like demo/tester.py:161 (--full-x per-crop times the GPU that way)'}
+                # the heavy chain behind the backbone, per launch, from the instrumented step (eager, side streams folded into the main one, one HIP-event pair
+                # per launch: no concurrency and no profiler in these figures) -- deconv 1 / 2 / 3 and the composed Tz convolution's GEMM by their flop counts
+                B_ = args.batch
+                marks = {'deconv1': 2.0 * 4 * B_ * 16 * 12 * 256 * 4 * 768, 'deconv2': 2.0 * 4 * B_ * 32 * 24 * 256 * 4 * 256,
+                         'deconv3': 2.0 * 4 * B_ * 64 * 48 * 256 * 4 * 256}
+                marks['tz_composed_gemm'] = 2.0 * (B_ * 22 * 16) * 128 * 9216 * (4.0 / 3.0 if x3_mode else 1.0)      # (bf16x3: N = 256, K = 18432 -> 4x; / 3 below)
+                hc = {}
+                for name, f, e0, e1 in prof:
+                    for k, fl in marks.items():
+                        if name.startswith('gemm_bf16') and abs(f / ((3.0 if x3_mode else 1.0) * fl) - 1.0) < 1e-6:
+                            us = e0.elapsed_time(e1) * 1e3
+                            hc[k] = {'us': us, 'algorithmic_TFLOPs': fl / us / 1e6, 'frac': fl / us / 1e6 / peak}
+                if hc:
+                    res['heavy_chain'] = dict(hc, note='per-launch HIP-event times of the instrumented (serial, eager) step; frac = algorithmic 2MNK flops / time / the 2.5 PF '
+                                                       'dense bf16 peak (bf16x3 issues three MFMAs per product)')
                 # the HBM-bound rows of the north star: MAF sampler and SMPL (LBS) call
                 res['hbm_rows'] = whmr_hbm_rows(args, dev)
                 att = res['roofline'].get('hbm_attainable_GBps')

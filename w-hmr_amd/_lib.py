@@ -323,7 +323,9 @@ def gemm(a, w, out, bias=None, residual=None, res_row_mod=0, act=ACT_NONE, conv=
         p.workspace, p.workspace_bytes = ws.data_ptr(), ws.numel()
     if raw_splits:                          # bf16 kernel: `out` = [raw_splits, M, N] fp32 planes of raw split-K partial sums (no finishing pass)
         assert a.dtype == torch.bfloat16 and tile is not None and out.dtype == torch.float32 and out.is_contiguous() and out.numel() == raw_splits * p.M * N
+        ev = _profile_begin()
         _check(lib().whmr_gemm_bf16_split_raw(C.byref(p), int(tile), int(raw_splits), _stream()), 'whmr_gemm_bf16_split_raw')
+        _profile_end(ev, 'gemm_bf16', 2.0 * p.M * p.N * p.K)
         return out
     if tile is not None:                    # explicit tile id (A/B tests), see gemm_bf16_big.hip
         assert a.dtype == torch.bfloat16

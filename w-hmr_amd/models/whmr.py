@@ -553,7 +553,7 @@ class WHMR(nn.Module):
         # small batches keep the chooser (it slices K itself when the grid is small)
         kw = dict(self._tz_gemm_kw)
         M = B * OHp * OWp
-        if not kw and self._dt != torch.float32 and M >= 8192:
+        if not kw and self.numerics != 'fp32' and M >= 8192:
             kw = dict(tile=192 if x3 else 64, raw_splits=2)
         ns = kw.get('raw_splits') or 1
         P = torch.empty(ns, M, g.shape[0], dtype=torch.float32, device=f_nhwc.device)
