@@ -437,6 +437,13 @@ int whmr_maf_sample_bwd(const void* fmap, int fmap_bf16, long sb, long sc, long 
                         const float* d_out, long dout_stride, void* d_fmap, int d_fmap_bf16, long gsb, long gsc, long gsy, long gsx,
                         float* XT, float* DT, long ldt, void* stream);
 
+/* The sampler's map gradient in two halves, for a map whose other consumers write their gradient first (the last feature map: Tz head and IUV head run
+ * on a side stream).  whmr_maf_sample_bwd with d_fmap_bf16 = 2 leaves, instead of scattering, a compact fp32 record d_fmap [B*P][264]: row b*P + p =
+ * 256 channel gradients of point p, its 4 texel offsets (y*W + x, int bits; -1 = outside the map) and its 4 bilinear weights.  whmr_maf_scatter adds
+ * the records to a gradient map (same strides / dtype rules as d_fmap above; d_fmap_bf16 = 0 | 1) -- 4 texels per point instead of a dense
+ * zero-filled map and a full-size add. */
+int whmr_maf_scatter(const float* rec, int B, int P, int W, void* d_fmap, int d_fmap_bf16, long gsb, long gsc, long gsy, long gsx, void* stream);
+
 /* col2im (gather form): dx [B,IH,IW,C] = fold of the column-space gradient dcol [(b,oy,ox)][(ky,kx,c)] (row stride ldcol) of a strided,
  * padded Conv2d -- the data gradient of the Tz-head convolutions (whmr.py:419-420) after dcol = dY . W on whmr_gemm_*. */
 int whmr_col2im(const void* dcol, int dcol_bf16, long ldcol, void* dx, int dx_bf16, int B, int IH, int IW, int C, int OH, int OW,

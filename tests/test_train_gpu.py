@@ -438,6 +438,55 @@ def test_maf_sampler_backward_matches_autograd(dev, map_dtype):
             assert a.grad.shape == b_.shape and _rel(a.grad.cpu(), b_) < 1e-4, (mode, a.shape, _rel(a.grad.cpu(), b_))
 
 
+@pytest.mark.parametrize('side', [False, True])
+@pytest.mark.parametrize('map_dtype', [torch.float32, torch.bfloat16])
+def test_map_fork_adds_the_sampler_records_to_the_other_consumers_gradient(dev, map_dtype, side):
+    """MapForkFn (last feature map of the training graph): the sampler leaves per-point records instead of a dense gradient map and the fork's
+    backward adds them, in place, to the gradient of the map's other consumer -- here a weighted sum, evaluated on a side stream when ``side`` -- so
+    that the map's gradient equals plain autograd fan-out (sampler's dense scatter + the other gradient) up to the bf16 accumulation order."""
+    from whmr_amd.models.maf_extractor import MAF_Extractor
+    from whmr_amd.train.maf_autograd import MAFSampleFn, MapForkFn
+    g = torch.Generator().manual_seed(11)
+    B, H, W, P = 4, 24, 18, 431
+    ext = MAF_Extractor().to(dev)
+    for p_ in ext.parameters():
+        p_.data = (torch.randn(p_.shape, generator=g) * (0.1 if p_.dim() > 1 else 0.05)).to(dev)
+    fmap = torch.randn(B, H, W, 256, generator=g).to(dev).to(map_dtype)
+    other = torch.randn(B, H, W, 256, generator=g).to(dev).to(map_dtype)
+    pts3 = (torch.randn(B, P, 3, generator=g) * 0.4).to(dev)
+    cam = torch.cat([torch.rand(B, 1, generator=g) * 0.5 + 0.7, torch.randn(B, 2, generator=g) * 0.1], 1).to(dev)
+    cot = torch.randn(B, 32 * P, generator=g).to(dev)
+    ps = [p_.detach().clone().requires_grad_(True) for p_ in ext.parameters()]
+
+    def run(fork):
+        fm = fmap.clone().requires_grad_(True)
+        for p_ in ps:
+            p_.grad = None
+        main = torch.cuda.current_stream(dev)
+        st = torch.cuda.Stream(device=dev) if side else main
+        st.wait_stream(main)
+        sink = {} if fork else None
+        with torch.cuda.stream(st):
+            fm_s, fm_c = MapForkFn.apply(fm, sink) if fork else (fm, fm)
+            other_loss = (fm_c.float() * other.float()).sum()
+        y = MAFSampleFn.apply(fm_s.permute(0, 3, 1, 2), *ps, ext, None, pts3, cam, sink)
+        main.wait_stream(st)
+        (other_loss + (y * cot).sum()).backward()
+        torch.cuda.synchronize(dev)
+        assert not sink                                                     # the records were consumed
+        return fm.grad.float().cpu(), [p_.grad.clone().cpu() for p_ in ps]
+
+    g_plain, w_plain = run(False)
+    g_fork, w_fork = run(True)
+    assert g_fork.abs().max() > 0 and (g_fork - other.float().cpu()).abs().max() > 0          # both contributions are there
+    # bf16 map: fan-out rounds (sum of the ~4 contributions a texel of this small map gets) + other once, the fork adds them to `other` one at a time
+    # -- a few bf16 ulps at the largest values (2^-5 at |g| in 4 .. 8), 2^-9-grade on the whole map
+    tol, tol_rms = (1e-6, 1e-6) if map_dtype == torch.float32 else (4e-2, 4e-3)
+    assert _rel(g_fork, g_plain) < tol and _rms(g_fork, g_plain) < tol_rms, (_rel(g_fork, g_plain), _rms(g_fork, g_plain))
+    for a, b_ in zip(w_fork, w_plain):
+        assert torch.equal(a, b_)                                           # the MLP's gradients do not pass through the map
+
+
 def _train_model(assets, state_dict, numerics, dev):
     from whmr_amd.models import whmr_net
     m = whmr_net(None, assets=assets, numerics=numerics)

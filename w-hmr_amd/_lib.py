@@ -145,6 +145,7 @@ _SIGS = {
     'whmr_smpl_skin_bwd': [C.POINTER(WhmrSmplModel), _P, _L, _P, _P, _P, _P, _I, _I, _P, _P, _P],
     'whmr_smpl_chain_bwd': [C.POINTER(WhmrSmplModel), _P, _P, _L, _P, _P, _P, _I, _P, _P, _P],
     'whmr_maf_sample_bwd': [_P, _I, _L, _L, _L, _L, _I, _I, _P, _P, _P, _L, _F, _F, _F, C.POINTER(WhmrMafWeights), _P, _P, _P, _I, _I, _P, _L, _P, _I, _L, _L, _L, _L, _P, _P, _L, _P],
+    'whmr_maf_scatter': [_P, _I, _I, _I, _P, _I, _L, _L, _L, _L, _P],
     'whmr_col2im': [_P, _I, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'whmr_csr_apply3': [_P, _P, _P, _P, _I, _P, _I, _I, _I, _P],
     'whmr_regressor_post_train': [_P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P],
@@ -1374,10 +1375,14 @@ def smpl_chain_bwd(model, rotmat, betas, dA_partial, d_posed_joints, d_pf_beta, 
            'whmr_smpl_chain_bwd')
 
 
+MAF_RECORD = 264                # floats per point of the sampler's compact gradient record (whmr_hip.h: whmr_maf_scatter)
+
+
 def maf_sample_bwd(fmap_nchw, weights, w0, w1, w2, d_out, d_fmap_nchw, XT, DT, pts2d=None, pts3d=None, cam=None, focal=1000.0, res_w=256.0,
-                   res_h=256.0):
-    """fmap / d_fmap: logical [B,256,H,W] tensors of any strides (d_fmap fp32, accumulated into; may be None)."""
-    _dev(fmap_nchw, d_out, d_fmap_nchw, XT, DT, pts2d, pts3d, cam, w0, w1, w2)
+                   res_h=256.0, record=None):
+    """fmap / d_fmap: logical [B,256,H,W] tensors of any strides (d_fmap fp32 or bf16, accumulated into; may be None).
+    ``record`` ([B*P, MAF_RECORD] fp32, instead of d_fmap): the map gradient is left as per-point records for ``maf_scatter``."""
+    _dev(fmap_nchw, d_out, d_fmap_nchw, XT, DT, pts2d, pts3d, cam, w0, w1, w2, record)
     B, _, H, W = fmap_nchw.shape
     sb, sc, sy, sx = fmap_nchw.stride()
     P = (pts2d if pts2d is not None else pts3d).shape[1]
@@ -1385,11 +1390,29 @@ def maf_sample_bwd(fmap_nchw, weights, w0, w1, w2, d_out, d_fmap_nchw, XT, DT, p
     assert XT.is_contiguous() and DT.is_contiguous() and XT.shape[1] == DT.shape[1] >= B * P
     g = (0, 0, 0, 0) if d_fmap_nchw is None else d_fmap_nchw.stride()
     assert d_fmap_nchw is None or (d_fmap_nchw.dtype in (torch.float32, torch.bfloat16) and d_fmap_nchw.shape == fmap_nchw.shape)
+    if record is not None:
+        assert d_fmap_nchw is None and record.dtype == torch.float32 and record.is_contiguous() and tuple(record.shape) == (B * P, MAF_RECORD)
+        _check(lib().whmr_maf_sample_bwd(fmap_nchw.data_ptr(), _bf(fmap_nchw), sb, sc, sy, sx, H, W, _ptr(pts2d), _ptr(pts3d), _ptr(cam),
+                                         cam.stride(0) if cam is not None else 0, focal, res_w, res_h, C.byref(weights), w0.data_ptr(),
+                                         w1.data_ptr(), w2.data_ptr(), B, P, d_out.data_ptr(), d_out.stride(0), record.data_ptr(), 2, 0, 0, 0, 0,
+                                         XT.data_ptr(), DT.data_ptr(), XT.shape[1], _stream()), 'whmr_maf_sample_bwd')
+        return
     _check(lib().whmr_maf_sample_bwd(fmap_nchw.data_ptr(), _bf(fmap_nchw), sb, sc, sy, sx, H, W, _ptr(pts2d), _ptr(pts3d), _ptr(cam),
                                      cam.stride(0) if cam is not None else 0, focal, res_w, res_h, C.byref(weights), w0.data_ptr(),
                                      w1.data_ptr(), w2.data_ptr(), B, P, d_out.data_ptr(), d_out.stride(0), _ptr(d_fmap_nchw),
                                      0 if d_fmap_nchw is None else _bf(d_fmap_nchw), g[0], g[1],
                                      g[2], g[3], XT.data_ptr(), DT.data_ptr(), XT.shape[1], _stream()), 'whmr_maf_sample_bwd')
+
+
+def maf_scatter(record, d_fmap_nchw, P):
+    """d_fmap (logical [B,256,H,W], fp32 of any strides or bf16 channels-last; written by the map's other consumers) += the sampler's records."""
+    _dev(record, d_fmap_nchw)
+    B, Cc, H, W = d_fmap_nchw.shape
+    assert Cc == 256 and record.dtype == torch.float32 and record.is_contiguous() and tuple(record.shape) == (B * P, MAF_RECORD)
+    assert d_fmap_nchw.dtype in (torch.float32, torch.bfloat16)
+    g = d_fmap_nchw.stride()
+    _check(lib().whmr_maf_scatter(record.data_ptr(), B, P, W, d_fmap_nchw.data_ptr(), _bf(d_fmap_nchw), g[0], g[1], g[2], g[3], _stream()),
+           'whmr_maf_scatter')
 
 
 def col2im(dcol, dx_nhwc, OH, OW, KH, KW, S, P):

@@ -409,6 +409,11 @@ __device__ __forceinline__ void atomic_add_bf16x2(uint32_t* addr, float lo, floa
     } while (old != assumed);
 }
 
+// TG = maf_compact: d(f) is not scattered; row b*P + p of d_fmap (fp32, MAF_ROW floats) takes the 256 channel gradients of point p, its four texel offsets
+// (y*W + x as int bits, -1 = outside) and its four bilinear weights -- whmr_maf_scatter adds the rows to a gradient map later, on any stream.
+struct maf_compact { float v; };
+#define MAF_ROW 264
+
 template <typename TF, typename TG>
 __global__ __launch_bounds__(256) void maf_sample_bwd_kernel(const TF* __restrict__ fmap, long sb, long sc, long sy, long sx, int H, int W,
                                                              const float* __restrict__ pts2d, const float* __restrict__ pts3d,
@@ -556,7 +561,14 @@ __global__ __launch_bounds__(256) void maf_sample_bwd_kernel(const TF* __restric
             for (int pp = 0; pp < PT; ++pp) acc[pp] = fmaf(w, sD0[o][pp], acc[pp]);
         }
         // scatter d(f) into the gradient map
-        if constexpr (std::is_same<TG, float>::value) {
+        if constexpr (std::is_same<TG, maf_compact>::value) {
+            float* rows = (float*)d_fmap + ((size_t)b * P + p0) * MAF_ROW;
+            for (int pp = 0; pp < np; ++pp) rows[(size_t)pp * MAF_ROW + tid] = sDF[tid][pp] + acc[pp];
+            if (tid < np * 8) {
+                const int pp = tid >> 3, t = tid & 7;
+                rows[(size_t)pp * MAF_ROW + CF + t] = t < 4 ? __int_as_float(sIdx[pp][t]) : sWgt[pp][t - 4];
+            }
+        } else if constexpr (std::is_same<TG, float>::value) {
             float* gc = d_fmap ? d_fmap + (size_t)b * gsb + (size_t)tid * gsc : nullptr;
             for (int pp = 0; pp < np; ++pp) {
                 const float df = sDF[tid][pp] + acc[pp];
@@ -597,7 +609,8 @@ __global__ __launch_bounds__(256) void maf_sample_bwd_kernel(const TF* __restric
     }
 }
 
-// d_out [B, >= 32*P rows of stride dout_stride]; d_fmap (nullable) fp32 with element strides (gsb, gsc, gsy, gsx), accumulated into;
+// d_out [B, >= 32*P rows of stride dout_stride]; d_fmap (nullable) fp32 with element strides (gsb, gsc, gsy, gsx), accumulated into
+// (d_fmap_bf16 = 2: d_fmap is the compact [B*P][MAF_ROW] fp32 record of whmr_maf_scatter instead, strides unused);
 // XT [448, ldt], DT [224, ldt] with ldt >= B*P (the caller zero-fills the padding columns once).
 extern "C" int whmr_maf_sample_bwd(const void* fmap, int fmap_bf16, long sb, long sc, long sy, long sx, int H, int W, const float* pts2d,
                                    const float* pts3d, const float* cam, long cam_ld, float focal, float res_w, float res_h,
@@ -605,16 +618,60 @@ extern "C" int whmr_maf_sample_bwd(const void* fmap, int fmap_bf16, long sb, lon
                                    const float* d_out, long dout_stride, void* d_fmap, int d_fmap_bf16, long gsb, long gsc, long gsy, long gsx,
                                    float* XT, float* DT, long ldt, void* stream) {
     if (B <= 0 || P <= 0 || (!pts2d == !pts3d) || (pts3d && !cam) || dout_stride < 32L * P || ldt < (long)B * P) return (int)hipErrorInvalidValue;
-    if (d_fmap && d_fmap_bf16 && (gsc != 1 || ((gsb | gsy | gsx) & 1) || ((uintptr_t)d_fmap & 3))) return (int)hipErrorInvalidValue;
+    if (d_fmap_bf16 == 2 && !d_fmap) return (int)hipErrorInvalidValue;
+    if (d_fmap && d_fmap_bf16 == 1 && (gsc != 1 || ((gsb | gsy | gsx) & 1) || ((uintptr_t)d_fmap & 3))) return (int)hipErrorInvalidValue;
     dim3 grid((P + PT - 1) / PT, B), block(256);
     hipStream_t st = (hipStream_t)stream;
 #define MAF_BWD(TF, TG) hipLaunchKernelGGL((maf_sample_bwd_kernel<TF, TG>), grid, block, 0, st, (const TF*)fmap, sb, sc, sy, sx, H, W, pts2d, pts3d, cam, \
                                            cam_ld, focal, res_w, res_h, *w, w0, w1, w2, P, d_out, dout_stride, (TG*)d_fmap, gsb, gsc, gsy, gsx, XT, DT, ldt)
-    if (fmap_bf16 && d_fmap_bf16) MAF_BWD(bf16_t, bf16_t);
+    if (d_fmap_bf16 == 2) { if (fmap_bf16) MAF_BWD(bf16_t, maf_compact); else MAF_BWD(float, maf_compact); }
+    else if (fmap_bf16 && d_fmap_bf16) MAF_BWD(bf16_t, bf16_t);
     else if (fmap_bf16) MAF_BWD(bf16_t, float);
     else if (!d_fmap_bf16) MAF_BWD(float, float);
     else return (int)hipErrorInvalidValue;
 #undef MAF_BWD
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+// The deferred half of the sampler's backward: rows of the compact record (maf_compact above) added to a gradient map that other consumers of the
+// feature map have already written -- 4 texels x 256 channels per point instead of a dense zero-filled map plus a full-size add.
+template <typename TG>
+__global__ __launch_bounds__(256) void maf_scatter_kernel(const float* __restrict__ rec, long n, int P, int W, TG* __restrict__ d_fmap, long gsb, long gsc,
+                                                          long gsy, long gsx) {
+    constexpr bool BF = std::is_same<TG, bf16_t>::value;
+    const int tid = threadIdx.x;
+    const long pt = BF ? (long)blockIdx.x * 2 + (tid >> 7) : (long)blockIdx.x;
+    if (pt >= n) return;
+    const float* row = rec + (size_t)pt * MAF_ROW;
+    const int b = (int)(pt / P);
+    int id[4];
+    float wg[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { id[t] = __float_as_int(row[CF + t]); wg[t] = row[CF + 4 + t]; }
+    if constexpr (BF) {
+        const int c = (tid & 127) * 2;
+        const float2 d = *(const float2*)(row + c);
+        bf16_t* gc = d_fmap + (size_t)b * gsb + c;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (id[t] >= 0) atomic_add_bf16x2((uint32_t*)(gc + (size_t)(id[t] / W) * gsy + (size_t)(id[t] % W) * gsx), d.x * wg[t], d.y * wg[t]);
+    } else {
+        const float d = row[tid];
+        float* gc = d_fmap + (size_t)b * gsb + (size_t)tid * gsc;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (id[t] >= 0) unsafeAtomicAdd(gc + (size_t)(id[t] / W) * gsy + (size_t)(id[t] % W) * gsx, d * wg[t]);
+    }
+}
+
+extern "C" int whmr_maf_scatter(const float* rec, int B, int P, int W, void* d_fmap, int d_fmap_bf16, long gsb, long gsc, long gsy, long gsx, void* stream) {
+    if (!rec || !d_fmap || B <= 0 || P <= 0 || W <= 0 || (d_fmap_bf16 != 0 && d_fmap_bf16 != 1)) return (int)hipErrorInvalidValue;
+    if (d_fmap_bf16 && (gsc != 1 || ((gsb | gsy | gsx) & 1) || ((uintptr_t)d_fmap & 3))) return (int)hipErrorInvalidValue;
+    const long n = (long)B * P;
+    hipStream_t st = (hipStream_t)stream;
+    if (d_fmap_bf16) hipLaunchKernelGGL((maf_scatter_kernel<bf16_t>), dim3((unsigned)((n + 1) / 2)), dim3(256), 0, st, rec, n, P, W, (bf16_t*)d_fmap, gsb, gsc, gsy, gsx);
+    else hipLaunchKernelGGL((maf_scatter_kernel<float>), dim3((unsigned)n), dim3(256), 0, st, rec, n, P, W, (float*)d_fmap, gsb, gsc, gsy, gsx);
     WHMR_CHECK_LAUNCH();
     return 0;
 }

@@ -36,7 +36,7 @@ from ..parallel.sync_bn import batch_norm_1d
 from .aux_supervision import IUVHeadOutput
 from .deconv_autograd import DeconvBNReLUFn
 from .heads_autograd import AttentionF32Fn, ConvNHWCFn, DownsampleFn, GeluFn, LayerNormFn, LinearFn, MatToAAFn, RegressorPostFn
-from .maf_autograd import MAFSampleFn
+from .maf_autograd import MAFSampleFn, MapForkFn
 from .smpl_autograd import SMPLFn
 
 
@@ -55,6 +55,7 @@ def _projection(joints, cam):
 
 CHAIN_GRADS = os.environ.get('WHMR_CHAIN_GRADS', '1') != '0'      # feature maps handed from consumer to consumer (A/B switch), see whmr_forward_train
 CHAIN_SAMPLER3 = os.environ.get('WHMR_CHAIN_SAMPLER3', '0') != '0'   # the stage-3 sampler behind the two heads in the last map's chain (A/B switch)
+FORK_SAMPLER3 = os.environ.get('WHMR_TRAIN_FORK3', '1') != '0'       # the stage-3 sampler's map gradient as per-point records added to the heads' gradient
 OVERLAP_HEAVY = os.environ.get('WHMR_TRAIN_OVERLAP', '1') != '0'      # deconv 2 / 3 + Tz head + IUV head on a side stream beside the regressor loop
 _STREAM_WARNING_OFF = False
 
@@ -247,7 +248,14 @@ def whmr_forward_train(model, x, center, scale, bbox_height, orig_shape, bbox_in
         # last map: Tz head -> IUV head is the chain (the IUV head's backward is ready first -- its loss needs nothing from the loop -- and the
         # Tz convolution adds to its data gradient); the stage-3 sampler stays a direct consumer: behind the heads it would hold their backward
         # back until the loop's stage-3 backward has run (A/B on one box, three runs each: chained 23.09-23.11, direct 22.99-23.03 ms per step)
-        Tz, fm_heads = tz_head(fmaps[-1])
+        # ... and its map gradient is not a dense map that autograd adds to the heads' (0.2 ms on this stream's chain): the sampler leaves per-point
+        # records and MapForkFn's backward adds them to the heads' gradient in place (maf_autograd.MapForkFn; WHMR_TRAIN_FORK3=0: plain fan-out)
+        sink3 = None
+        fm_last = fmaps[-1]
+        if FORK_SAMPLER3 and not (CHAIN_GRADS and CHAIN_SAMPLER3) and fm_last.requires_grad:
+            sink3 = {}
+            fmaps[-1], fm_last = MapForkFn.apply(fm_last, sink3)
+        Tz, fm_heads = tz_head(fm_last)
         if heavy is not None:
             tz_ready = torch.cuda.Event()
             tz_ready.record(heavy)
@@ -276,7 +284,7 @@ def whmr_forward_train(model, x, center, scale, bbox_height, orig_shape, bbox_in
             pts = model.points_grid.expand(B, -1, -1).transpose(1, 2).contiguous()
             ref = MAFSampleFn.apply(fm, *ps, ext, pts, None, None)
         else:
-            ref = MAFSampleFn.apply(fm, *ps, ext, None, markers.contiguous(), cam.contiguous())
+            ref = MAFSampleFn.apply(fm, *ps, ext, None, markers.contiguous(), cam.contiguous(), sink3 if i == 2 else None)
         smpl_output, body_feat = regressor_train(reg, ref, bbox_info, None if heavy is not None else Tz, orig_shape, center, scale, bbox_height,
                                                  pose, shp, cam, cache.setdefault(i, {}))
         outs.append(smpl_output)
