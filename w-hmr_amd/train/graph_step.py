@@ -6,6 +6,10 @@ enqueues on the current stream and allocates nothing (include/whmr_hip.h), torch
 graph's private pool, so the step is capturable as it stands.  Rules the caller keeps (the usual whole-network-capture rules):
 static input tensors (copy new batches INTO them), no host reads inside ``fn``, gradients are read from ``p.grad`` after ``replay()``
 and the optimizer runs outside the graph.
+
+While a capture is running whmr_forward_train keeps to two streams and to autograd's own order of issue: with the Tz head's tail on a third stream
+hipStreamEndCapture crashed, and with the side stream's nodes raised in the ready queue (whmr_train._backward_first) the replayed graph ran into a GPU
+memory fault (round 6, one box each, not diagnosed; both are host-side overlap measures that a replayed graph does not need -- it has no host in the loop).
 """
 import torch
 

@@ -56,6 +56,8 @@ def _projection(joints, cam):
 CHAIN_GRADS = os.environ.get('WHMR_CHAIN_GRADS', '1') != '0'      # feature maps handed from consumer to consumer (A/B switch), see whmr_forward_train
 CHAIN_SAMPLER3 = os.environ.get('WHMR_CHAIN_SAMPLER3', '0') != '0'   # the stage-3 sampler behind the two heads in the last map's chain (A/B switch)
 FORK_SAMPLER3 = os.environ.get('WHMR_TRAIN_FORK3', '1') != '0'       # the stage-3 sampler's map gradient as per-point records added to the heads' gradient
+HEAVY_FIRST = os.environ.get('WHMR_TRAIN_HEAVY_FIRST', '1') != '0'    # the side stream's nodes ahead of the loop's in autograd's ready queue (see _backward_first)
+TZ_TAIL_STREAM = os.environ.get('WHMR_TRAIN_TZ_TAIL', '1') != '0'     # the Tz head's 5-token tail (a hundred tiny launches) on a stream of its own beside the IUV head
 OVERLAP_HEAVY = os.environ.get('WHMR_TRAIN_OVERLAP', '1') != '0'      # deconv 2 / 3 + Tz head + IUV head on a side stream beside the regressor loop
 _STREAM_WARNING_OFF = False
 
@@ -92,9 +94,35 @@ def _perspective_norm(joints, cam_t, focal, cam_center):
     return torch.stack([x, y], dim=-1) / cam_center[:, None, :] - 1.0
 
 
-def tz_head_train(model, f_nhwc, passthrough=False):
+def _backward_first(roots, stop, offset=1 << 40):
+    """Raise the ready-queue priority of every autograd node between ``roots`` (tensors) and the nodes of ``stop`` (tensors; not entered).
+
+    autograd's engine thread takes, among the nodes that are ready, the one created LAST (highest sequence number).  The side stream's chain is
+    created before the regressor loop -- its kernels must be in flight while the host issues the loop -- so in the backward pass the engine would
+    issue the loop's few hundred small launches first and only then the chain's large GEMMs: the stream that bounds the step sits idle for as
+    long as the host needs for the loop (a millisecond at batch 64).  With their sequence numbers raised the chain's nodes are issued the moment
+    their gradients exist and the loop's launches follow while the GEMMs run.  Only the order of issue changes, not what is computed."""
+    seen = {t.grad_fn for t in stop if t is not None and t.grad_fn is not None}
+    todo = [t.grad_fn for t in roots if t is not None and t.grad_fn is not None]
+    while todo:
+        fn = todo.pop()
+        if fn is None or fn in seen:
+            continue
+        seen.add(fn)
+        if not hasattr(fn, '_set_sequence_nr') or type(fn).__name__ == 'AccumulateGrad':
+            continue
+        fn._set_sequence_nr(fn._sequence_nr() + offset)
+        todo.extend(f for f, _ in fn.next_functions)
+
+
+_tail_streams = {}
+
+
+def tz_head_train(model, f_nhwc, passthrough=False, tail_stream=None):
     """whmr.py:567-577 in training mode.  f_nhwc [B,128,96,256] in the compute dtype (detached by the caller when TRAIN.STAGE == 1).
-    ``passthrough``: -> (Tz, f_nhwc handed on by the first convolution's node, see ConvNHWCFn)."""
+    ``passthrough``: -> (Tz, f_nhwc handed on by the first convolution's node, see ConvNHWCFn).
+    ``tail_stream``: everything behind the two convolutions (the 5-token timm Block, est_Tz: a hundred tiny launches forward, twice that backward)
+    runs on that stream, i.e. beside the IUV head's GEMMs instead of between them and the convolutions' backward; the caller joins it."""
     dt = model._dt
     B = f_nhwc.shape[0]
     f_next = None
@@ -103,6 +131,18 @@ def tz_head_train(model, f_nhwc, passthrough=False):
     else:
         y0 = ConvNHWCFn.apply(f_nhwc, model.conv[0].weight, 3, dt)
     y1 = ConvNHWCFn.apply(y0, model.conv[1].weight, 2, dt)                            # [B, 18, 12, 5]
+    if tail_stream is not None:
+        tail_stream.wait_stream(torch.cuda.current_stream(y1.device))
+        if not torch.cuda.is_current_stream_capturing():
+            y1.record_stream(tail_stream)
+        with torch.cuda.stream(tail_stream):
+            Tz = _tz_tail(model, y1, B)
+    else:
+        Tz = _tz_tail(model, y1, B)
+    return (Tz, f_next) if passthrough else Tz
+
+
+def _tz_tail(model, y1, B):
     t = y1.float().permute(0, 3, 1, 2).reshape(B * 5, -1).contiguous()                 # == conv(...).reshape(B, 5, -1) on NCHW, whmr.py:571
     D = t.shape[-1]
     td = model.transformer_decoder                                                     # timm Block(dim 216, 2 heads, qkv_bias False)
@@ -120,8 +160,7 @@ def tz_head_train(model, f_nhwc, passthrough=False):
     e = model.est_Tz
     y = _linear(_linear(s, e[0]), e[1])
     y = batch_norm_1d(y, e[2])                                                         # BatchNorm1d(1): batch statistics in train mode (all ranks' when converted)
-    Tz = 10.0 * torch.sigmoid(y).squeeze(-1)
-    return (Tz, f_next) if passthrough else Tz
+    return 10.0 * torch.sigmoid(y).squeeze(-1)
 
 
 def dp_head_train(model, f_nhwc, passthrough=False):
@@ -219,10 +258,10 @@ def whmr_forward_train(model, x, center, scale, bbox_height, orig_shape, bbox_in
             return DeconvBNReLUFn.apply(f, ct.weight, bn.weight, bn.bias, bn, dt, True)            # (y, f handed on)
         return DeconvBNReLUFn.apply(f, ct.weight, bn.weight, bn.bias, bn, dt), f
 
-    def tz_head(fm):
+    def tz_head(fm, tail=None):
         if not tz_grad:
-            return tz_head_train(model, fm.detach()), fm
-        return tz_head_train(model, fm, True) if CHAIN_GRADS else (tz_head_train(model, fm), fm)
+            return tz_head_train(model, fm.detach(), tail_stream=tail), fm
+        return tz_head_train(model, fm, True, tail_stream=tail) if CHAIN_GRADS else (tz_head_train(model, fm, tail_stream=tail), fm)
 
     def dp_head(fm):                                                                   # whmr.py:656-658
         return dp_head_train(model, fm, True) if CHAIN_GRADS else (dp_head_train(model, fm), fm)
@@ -232,12 +271,18 @@ def whmr_forward_train(model, x, center, scale, bbox_height, orig_shape, bbox_in
     # side stream and the loop (hundreds of small launches) beside it on the main one; the Tz-dependent projections of the three stages follow
     # the join.  autograd runs every node's backward on the stream of its forward, so the backward pass overlaps the same way.
     fmaps, dp_out, map_ready = [deconv(0, f, chain=False)[0]], [], [None, None, None]
-    heavy = None
+    f_first = fmaps[0]
+    heavy = tail = None
     if OVERLAP_HEAVY:
         main = torch.cuda.current_stream(dev)
         heavy = _heavy_stream(dev)
         heavy.wait_stream(main)
         _accept_side_stream_gradients()
+        capturing = torch.cuda.is_current_stream_capturing()
+        if TZ_TAIL_STREAM and not capturing:               # (whole-step capture keeps two streams and autograd's own order: see graph_step.py)
+            tail = _tail_streams.get(dev)
+            if tail is None:
+                tail = _tail_streams[dev] = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(heavy if heavy is not None else torch.cuda.current_stream(dev)):
         for i in (1, 2):
             y, fmaps[-1] = deconv(i, fmaps[-1])
@@ -255,15 +300,17 @@ def whmr_forward_train(model, x, center, scale, bbox_height, orig_shape, bbox_in
         if FORK_SAMPLER3 and not (CHAIN_GRADS and CHAIN_SAMPLER3) and fm_last.requires_grad:
             sink3 = {}
             fmaps[-1], fm_last = MapForkFn.apply(fm_last, sink3)
-        Tz, fm_heads = tz_head(fm_last)
+        Tz, fm_heads = tz_head(fm_last, tail)
         if heavy is not None:
             tz_ready = torch.cuda.Event()
-            tz_ready.record(heavy)
+            tz_ready.record(tail if tail is not None else heavy)
         if aux:
             d, fm_heads = dp_head(fm_heads)
             dp_out = [d]
         if CHAIN_GRADS and CHAIN_SAMPLER3:
             fmaps[-1] = fm_heads
+    if heavy is not None and HEAVY_FIRST and not capturing:
+        _backward_first([Tz, fmaps[1], fmaps[2]] + [d.nhwc for d in dp_out], [f_first])
     for i in range(3):
         model.maf_extractor[i].im_feat = fmaps[i].detach().permute(0, 3, 1, 2)
 
