@@ -647,7 +647,7 @@ def gemm_source_digest():
     """sha256 over the GEMM kernel sources: profiles/*_gemm_traffic.json records the digest it was measured at"""
     import hashlib
     h = hashlib.sha256()
-    for f in ('gemm_blk.hip', 'gemm_blk16_impl.h', 'gemm_blk_impl.h', 'gemm_blk_x3.hip', 'gemm_blk.h', 'gemm_bf16_big.hip', 'gemm_bf16.hip', 'gemm_params.h', 'common.h'):
+    for f in ('gemm_blk.hip', 'gemm_blk16_impl.h', 'gemm_blk_impl.h', 'gemm_blk_x3.hip', 'gemm_blk.h', 'gemm_bf16_big.hip', 'gemm_bf16_big_body.inc', 'gemm_bf16.hip', 'gemm_params.h', 'common.h'):
         with open(os.path.join(ROOT, 'w-hmr_amd', 'csrc', f), 'rb') as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]

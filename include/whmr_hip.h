@@ -62,6 +62,12 @@ struct whmr_gemm {
                              * next to C = gelu(that value) -- the training forward of fc1 keeps both (vit.py:66-68) without a separate GELU pass */
 };
 
+/* Up to 9 gathering (a_mode 1) bf16-output GEMMs of one tile shape as ONE launch (tile 192: 192 x 256 x 64; 65: 128 x 64 x 64 for N <= 64): no
+ * activation, no split-K, no sub-pixel phases, scattered / accumulating epilogues allowed.  The S*S residue-class data gradients of a strided
+ * convolution (autograd of whmr.py:419 `nn.Conv2d(256, 64, 7, 3)`; w-hmr_amd/train/heads_autograd.py) are nine such GEMMs of under two rounds of
+ * tiles each.  Descriptors are copied into the kernel arguments: nothing of `ps` is read after the call returns. */
+int whmr_gemm_bf16_group(const struct whmr_gemm* ps, int n, int tile, void* stream);
+
 /* bf16 MFMA GEMM (v_mfma_f32_32x32x16_bf16, fp32 accumulate).  Needs K % 64 == 0 (and Cin % 64 == 0 for a_mode 1).
  * Replaces nn.Linear at vit.py:93,96 (qkv, proj), vit.py:66-68 (fc1, fc2), Conv2d at vit.py:157 (after
  * whmr_patch_im2col), ConvTranspose2d+BN+ReLU at whmr.py:488-498 and Conv2d at whmr.py:419.
@@ -198,7 +204,7 @@ int whmr_gemm_tn_bf16_group(const struct whmr_tn_item* items, int n_items, int K
  * reduction row (b, oy, ox) is img[b, oy*S + ky - P, ox*S + kx - P, c], zero outside the image.  Autograd of Conv2d (A = dY over the output
  * grid, img = X -> dW[co, (ky,kx,ci)]: whmr.py:419-420, models/iuv_predictor.py:71-91) and of ConvTranspose2d(k4, s2, p1) (A = X over the input
  * grid, img = dZ, S = 2, P = 1 -> dW[ci, (ky,kx,co)]: whmr.py:488-498) as core/trainer.py:410-470 runs them; replaces whmr_im2col_t + the operand
- * transposes + the NT GEMM.  Mo % 64 == 0, GC % 256 == 0, K % 32 == 0; zeros: >= 512 B of device zeros; db (nullable) [Mo] = column sums of A
+ * transposes + the NT GEMM.  Mo % 128 == 0 (the 64-row tile of the gathering kernel is not built: gemm_tn.hip), GC % 256 == 0, K % 32 == 0; zeros: >= 512 B of device zeros; db (nullable) [Mo] = column sums of A
  * (the convolution's bias gradient when A is dY). */
 int whmr_conv_dw_tn_bf16(const void* A, long lda, const void* img, long ldp, float* C, long ldc, int Mo, int K, int nB, int OH, int OW,
                          int IH, int IW, int GC, int KH, int KW, int S, int P, const void* zeros, int splits, void* workspace,
@@ -534,6 +540,17 @@ int whmr_mfma_ceiling(int blocks, int iters, float* sink, unsigned long long* st
 int whmr_hbm_copy(const void* src, void* dst, long bytes, void* stream);
 int whmr_clock_probe_begin(unsigned long long* state, double limit_seconds, void* stream);
 int whmr_clock_probe_end(unsigned long long* state, void* stream);
+
+/* Debug aid: `blocks` workgroups of 128 threads fill `lds_bytes` (512 .. 65536) of LDS with a pattern, idle `spins` x 64 clocks and check it.
+ * report (4 x uint32, zeroed by the caller): [0] += dwords found changed, [1] = index + 1 of one of them, [2] = value found, [3] = value expected.
+ * Detects a co-resident kernel whose LDS-DMA lands after its workgroup has gone (tools/r6_coresidency_probe.py). */
+int whmr_debug_lds_canary(int blocks, int lds_bytes, int spins, unsigned* report, void* stream);
+/* Debug aid: table[i] = i * 2654435761u (rows x ld uint32, written by the caller); every thread re-reads its column of all rows `reps` times with plain
+ * global loads and compares (report as above). */
+int whmr_debug_global_canary(const unsigned* table, int rows, int ld, int reps, unsigned* report, void* stream);
+/* Debug aid: every lane runs one multiply-add chain as v_pk_fma_f32 and as two v_fma_f32 and compares the bits; report[0] / [1] += lanes whose low /
+ * high half differs (2 x uint32, zeroed by the caller). */
+int whmr_debug_pkfma_canary(int blocks, int iters, unsigned* report, void* stream);
 
 #ifdef __cplusplus
 }

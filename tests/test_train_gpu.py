@@ -1208,6 +1208,32 @@ def test_whmr_train_step_reducer_small_buckets_with_side_stream_gradients(dev, a
         assert _rms(runs[1][k].cpu(), g.cpu()) < 2e-2, k
 
 
+@pytest.mark.parametrize('case', ['tz conv0 7x7 s3', 'tz conv1 7x7 s2'])
+def test_strided_convolution_data_gradient_grouped_launch_matches_single_launches(dev, case, monkeypatch):
+    """ConvNHWCFn.backward, stride S > 1: the S*S residue-class GEMMs as ONE grouped launch (whmr_gemm_bf16_group, tiles 192 x 256 / 128 x 64) give the
+    bits of the S*S single launches -- same tiles' K order, disjoint output pixels -- with and without a gradient already on the map."""
+    from whmr_amd.train import heads_autograd as HA
+    g = torch.Generator().manual_seed(5)
+    Cout, Cin, S, H, W = (64, 256, 3, 40, 31) if 'conv0' in case else (5, 64, 2, 42, 31)
+    w = (torch.randn(Cout, Cin, 7, 7, generator=g) * 0.02).to(dev)
+    x0 = (torch.randn(3, H, W, Cin, generator=g) * 0.5).to(dev).bfloat16()
+    gx = torch.randn(3, H, W, Cin, generator=g).to(dev)
+    res = {}
+    for grouped in (True, False):
+        monkeypatch.setattr(HA, 'GROUP_DX', grouped)
+        for pt in (False, True):
+            x = x0.clone().requires_grad_(True)
+            out = HA.ConvNHWCFn.apply(x, w, S, torch.bfloat16, 0, None, pt)
+            y, x2 = out if pt else (out, None)
+            gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(11)).to(dev)
+            loss = (y.float() * gy).sum() + ((x2.float() * gx).sum() if pt else 0.0)
+            loss.backward()
+            res[(grouped, pt)] = x.grad.clone()
+    for pt in (False, True):
+        assert res[(True, pt)].abs().max() > 0
+        assert torch.equal(res[(True, pt)], res[(False, pt)]), (case, pt, (res[(True, pt)].float() - res[(False, pt)].float()).abs().max().item())
+
+
 @pytest.mark.parametrize('dt', [torch.bfloat16, torch.float32])
 def test_passthrough_nodes_accumulate_the_data_gradient_in_place(dev, dt):
     """ConvNHWCFn / DeconvBNReLUFn with ``passthrough``: the input map is handed on as a second output, and the gradient that comes back on it

@@ -76,6 +76,7 @@ _SIGS = {
     'whmr_conv_dw_tn_bf16': [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _L, _P, _P],
     'whmr_gemm_bf16_big': [C.POINTER(WhmrGemm), _I, _P],
     'whmr_gemm_bf16_split': [C.POINTER(WhmrGemm), _I, _I, _P],
+    'whmr_gemm_bf16_group': [_P, _I, _I, _P],
     'whmr_gemm_bf16_split_raw': [C.POINTER(WhmrGemm), _I, _I, _P],
     'whmr_set_option': [_I, _I],
     'whmr_gemm_blk': [C.POINTER(WhmrGemmBlk), _P],
@@ -123,6 +124,9 @@ _SIGS = {
     'whmr_hbm_copy': [_P, _P, _L, _P],
     'whmr_clock_probe_begin': [_P, C.c_double, _P],
     'whmr_clock_probe_end': [_P, _P],
+    'whmr_debug_lds_canary': [_I, _I, _I, _P, _P],
+    'whmr_debug_global_canary': [_P, _I, _I, _I, _P, _P],
+    'whmr_debug_pkfma_canary': [_I, _I, _P, _P],
     'whmr_estimate_translation': [_P, _P, _I, _I, _I, _I, _F, _F, _F, _P, _P],
     'whmr_transpose_cast': [_P, _I, _L, _P, _I, _L, _I, _I, _I, _P],
     'whmr_colsum': [_P, _I, _L, _I, _I, _P, _I, _P, _P],
@@ -233,7 +237,7 @@ PROFILE = None        # bench.py sets this to a list: (kernel, flops, start_even
 
 def gemm(a, w, out, bias=None, residual=None, res_row_mod=0, act=ACT_NONE, conv=None, scatter=None, M=None,
          lda=None, glds=True, tile=None, phases=None, res_first=False, splits=None, row_scale=None, accumulate=False,
-         trans_a=False, trans_w=False, pre_out=None, gelu_bwd_of=None, split3_out=None, split_parts=3, raw_splits=None):
+         trans_a=False, trans_w=False, pre_out=None, gelu_bwd_of=None, split3_out=None, split_parts=3, raw_splits=None, desc_only=False):
     """out = act(a . w^T + bias) + residual.  a/w dtype selects the kernel (bf16 MFMA or exact-fp32 MFMA).
 
     conv = dict(IH, IW, Cin, OH, OW, KW, SH, SW, PH, PW): a is an NHWC image [B, IH, IW, Cin], rows are output pixels.
@@ -318,6 +322,8 @@ def gemm(a, w, out, bias=None, residual=None, res_row_mod=0, act=ACT_NONE, conv=
             setattr(p, k, scatter[k])
     else:
         p.ldc = out.stride(-2) if out.dim() >= 2 else N
+    if desc_only:                           # -> the descriptor (for gemm_group); the caller keeps the tensors alive until the launch
+        return p
     fn = lib().whmr_gemm_bf16 if a.dtype == torch.bfloat16 else lib().whmr_gemm_f32
     if scatter is None and phases is None and (a.dtype == torch.bfloat16 or conv is None):
         ws = splitk_workspace(a.device)
@@ -344,6 +350,15 @@ def gemm(a, w, out, bias=None, residual=None, res_row_mod=0, act=ACT_NONE, conv=
         return out
     _check(fn(C.byref(p), 0 if glds else 1, _stream()), 'whmr_gemm')
     return out
+
+
+def gemm_group(descs, tile=192):
+    """<= 9 gathering bf16 GEMMs (descriptors of ``gemm(..., conv=..., desc_only=True)``, bf16 output) as ONE launch of one tile shape
+    (whmr_gemm_bf16_group: 192 = 192 x 256 x 64 tiles, 65 = 128 x 64 x 64)."""
+    arr = (WhmrGemm * len(descs))(*descs)
+    ev = _profile_begin()
+    _check(lib().whmr_gemm_bf16_group(arr, len(descs), int(tile), _stream()), 'whmr_gemm_bf16_group')
+    _profile_end(ev, 'gemm_bf16', sum(2.0 * d.M * d.N * d.K for d in descs))
 
 
 # ---- blocked layouts (gemm_blk.hip): [R, C] stored as [ceil(R/32)][C/E][32][E], E = 8 (bf16) / 4 (fp32) -----------------------------
@@ -1005,7 +1020,7 @@ def gemm_tn_group(jobs):
 def conv_dw_tn_ok(a, img):
     """envelope of whmr_conv_dw_tn_bf16 for a [K, Mo] (2-D, rows dense) and an NHWC image [B, IH, IW, C]"""
     return (a.dtype == torch.bfloat16 and img.dtype == torch.bfloat16 and a.dim() == 2 and img.dim() == 4 and a.stride(1) == 1 and img.is_contiguous()
-            and a.shape[0] % 32 == 0 and a.shape[1] % 64 == 0 and img.shape[3] % 256 == 0 and a.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0
+            and a.shape[0] % 32 == 0 and a.shape[1] % 128 == 0 and img.shape[3] % 256 == 0 and a.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0
             and img.data_ptr() % 16 == 0)
 
 

@@ -18,7 +18,7 @@ def _stale(target, deps):
 def build(force=False, verbose=True):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     srcs = sorted(glob.glob(os.path.join(CSRC, '*.hip')))
-    hdrs = glob.glob(os.path.join(CSRC, '*.h'))
+    hdrs = glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(CSRC, '*.inc'))
     objdir = os.path.join(HERE, 'build')
     os.makedirs(objdir, exist_ok=True)
     jobs = []

@@ -103,3 +103,76 @@ extern "C" int whmr_clock_probe_end(unsigned long long* state, void* stream) {
     WHMR_CHECK_LAUNCH();
     return 0;
 }
+
+// LDS canary (round 6: a kernel whose late LDS-DMA lands in the LDS of the workgroup that took its place).  Every workgroup fills `words` dwords of
+// dynamic LDS with a pattern of its own, idles `spins` x 64 clocks, and checks it.  report[0] += words found changed, report[1] = LDS dword index of one
+// of them + 1, report[2] = the value found there, report[3] = the value expected.
+__global__ __launch_bounds__(128) void lds_canary_kernel(int words, int spins, unsigned* __restrict__ report) {
+    extern __shared__ unsigned canary[];
+    const unsigned tag = 0xA5000000u ^ (blockIdx.x * 2654435761u);
+    for (int i = threadIdx.x; i < words; i += 128) canary[i] = tag + (unsigned)i;
+    __syncthreads();
+    for (int s = 0; s < spins; ++s) __builtin_amdgcn_s_sleep(1);
+    __syncthreads();
+    for (int i = threadIdx.x; i < words; i += 128) {
+        const unsigned got = canary[i];
+        if (got != tag + (unsigned)i) {
+            atomicAdd(&report[0], 1u);
+            report[1] = (unsigned)i + 1u; report[2] = got; report[3] = tag + (unsigned)i;
+        }
+    }
+}
+
+extern "C" int whmr_debug_lds_canary(int blocks, int lds_bytes, int spins, unsigned* report, void* stream) {
+    if (blocks <= 0 || lds_bytes < 512 || lds_bytes > 64 * 1024 || spins < 0 || spins > (1 << 20) || !report) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(lds_canary_kernel, dim3(blocks), dim3(128), lds_bytes, (hipStream_t)stream, lds_bytes / 4, spins, report);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+// Global-read canary: table[i] = i * 2654435761u (written by the caller).  Every thread re-reads `rows` strided rows of `ld` dwords at its own column
+// `reps` times and compares; report as above ([1] = dword index + 1, [2] found, [3] expected).  Plain global loads, like a kernel reading constant tables.
+__global__ __launch_bounds__(128) void global_canary_kernel(const unsigned* __restrict__ table, int rows, int ld, int reps, unsigned* __restrict__ report) {
+    const int v = blockIdx.x * 128 + threadIdx.x;
+    if (v >= ld) return;
+    for (int r = 0; r < reps; ++r)
+        for (int k = 0; k < rows; ++k) {
+            const unsigned i = (unsigned)k * (unsigned)ld + (unsigned)v;
+            const unsigned got = table[i];
+            if (got != i * 2654435761u) {
+                atomicAdd(&report[0], 1u);
+                report[1] = i + 1u; report[2] = got; report[3] = i * 2654435761u;
+            }
+        }
+}
+
+extern "C" int whmr_debug_global_canary(const unsigned* table, int rows, int ld, int reps, unsigned* report, void* stream) {
+    if (!table || rows <= 0 || ld <= 0 || reps <= 0 || !report) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(global_canary_kernel, dim3((ld + 127) / 128), dim3(128), 0, (hipStream_t)stream, table, rows, ld, reps, report);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+// Packed-FMA canary: every lane runs the same chain twice, as v_pk_fma_f32 on a register pair and as two v_fma_f32, and compares the bits.
+// report[0] += lanes whose LOW half differs, report[1] += lanes whose HIGH half differs.
+__global__ __launch_bounds__(128) void pkfma_canary_kernel(int iters, unsigned* __restrict__ report) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const float t = (float)(threadIdx.x + 128 * (blockIdx.x & 15)) * 1e-3f;
+    f2 a = {1.0f + t, 0.5f - t}, acc = {0.1f, 0.2f};
+    float sx = 0.1f, sy = 0.2f;
+    for (int i = 0; i < iters; ++i) {
+        f2 b = {0.999f - (float)(i & 255) * 1e-5f, -0.998f + (float)(i & 127) * 1e-5f};
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+        asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(sx) : "v"(a.x), "v"(b.x));
+        asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(sy) : "v"(a.y), "v"(b.y));
+    }
+    if (__float_as_uint(acc.x) != __float_as_uint(sx)) atomicAdd(&report[0], 1u);
+    if (__float_as_uint(acc.y) != __float_as_uint(sy)) atomicAdd(&report[1], 1u);
+}
+
+extern "C" int whmr_debug_pkfma_canary(int blocks, int iters, unsigned* report, void* stream) {
+    if (blocks <= 0 || iters <= 0 || !report) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(pkfma_canary_kernel, dim3(blocks), dim3(128), 0, (hipStream_t)stream, iters, report);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}

@@ -27,6 +27,9 @@
 #ifndef TN_LAB
 #define TN_LAB 0          // tools/lab/tn_lab.hip only (timing ablations, wrong results): 1 no MFMAs, 2 no fragment reads, 4 no LDS-DMA, 8 stamps, 16 L2-hot operands (four-wave body)
 #endif
+#ifndef TN_LAB_ROW64
+#define TN_LAB_ROW64 0    // tools/r6_coresidency_probe.py only: 1 builds the 64-row tile of the gathering kernel back in (see whmr_conv_dw_tn_bf16)
+#endif
 #ifndef TN4_NS
 #define TN4_NS 4          // ring slots of the four-wave body (32 KB each)
 #endif
@@ -712,7 +715,11 @@ static int tn_run(tn_params p, int splits, void* workspace, long workspace_bytes
     p.k_per_split = sps * 32;
     p.ws = splits > 1 ? (float*)workspace : nullptr;
     int rc;
-    if (p.gather) rc = MI == 4 ? launch_tn<4, true>(p, tiles, splits, st) : MI == 2 ? launch_tn<2, true>(p, tiles, splits, st) : launch_tn<1, true>(p, tiles, splits, st);
+    // (the gathering kernel has no 64-row instantiation: whmr_conv_dw_tn_bf16 takes Mo % 128 == 0 only, see there)
+#if TN_LAB_ROW64
+    if (p.gather && MI == 1) rc = launch_tn<1, true>(p, tiles, splits, st); else
+#endif
+    if (p.gather) rc = MI == 4 ? launch_tn<4, true>(p, tiles, splits, st) : MI == 2 ? launch_tn<2, true>(p, tiles, splits, st) : (int)hipErrorInvalidValue;
     else rc = MI == 4 ? launch_tn4<4, false>(p, tiles, splits, st) : MI == 2 ? launch_tn4<2, false>(p, tiles, splits, st) : launch_tn4<1, false>(p, tiles, splits, st);
     if (rc) return rc;
     if (splits > 1) {
@@ -865,7 +872,12 @@ extern "C" int whmr_conv_dw_tn_bf16(const void* A, long lda, const void* img, lo
                                     int IH, int IW, int GC, int KH, int KW, int S, int P, const void* zeros, int splits, void* workspace,
                                     long workspace_bytes, float* db, void* stream) {
     const long No = (long)KH * KW * GC;
-    if (Mo <= 0 || K <= 0 || (Mo % 64) || (GC % 256) || GC <= 0 || (K % 32) || (lda % 8) || (ldp % 8) || (ldc % 4) || ((uintptr_t)A & 15) ||
+    // Mo % 128, not 64: the 64-row instantiation of the gathering kernel (gemm_tn_kernel<1, true, true>) computed its own product correctly but CHANGED THE
+    // RESULTS OF ANOTHER KERNEL running at the same time on another stream -- smpl_skin_bwd_kernel beside it differed from the same launch run alone in
+    // 88 of 96 launches (the c = 0 terms of its per-block sums, up to 1e-2 relative), with every input, its LDS and its global reads verified intact
+    // and only while the 64-row kernel issued MFMAs (round 6, tools/r6_coresidency_probe.py; not root-caused).  The 128- and 256-row instantiations and
+    // every other kernel of the step leave it alone, so the 64-row one is not built; callers widen dY to 128 columns (heads_autograd.TN_ROW_PAD).
+    if (Mo <= 0 || K <= 0 || (Mo % (TN_LAB_ROW64 ? 64 : 128)) || (GC % 256) || GC <= 0 || (K % 32) || (lda % 8) || (ldp % 8) || (ldc % 4) || ((uintptr_t)A & 15) ||
         ((uintptr_t)img & 15) || ((uintptr_t)C & 15) || ((uintptr_t)zeros & 15) || !zeros || lda < Mo || ldp < GC || ldc < No ||
         (long)nB * OH * OW != K || No > (1L << 30))
         return (int)hipErrorInvalidValue;

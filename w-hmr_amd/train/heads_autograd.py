@@ -165,6 +165,29 @@ def _padded_base(dy, M, npad, dt):
     return base.view(M, npad)
 
 
+# Rows the weight-gradient operand dY is widened to = the smallest row tile the gathering TN kernel is built with (whmr_conv_dw_tn_bf16: its 64-row
+# instantiation changed the results of smpl_skin_bwd_kernel running beside it on the other stream, see gemm_tn.hip, and is gone).
+TN_ROW_PAD = 128
+GROUP_DX = os.environ.get('WHMR_TRAIN_GROUP_DX', '1') != '0'        # the residue-class data gradients of a strided convolution as one grouped launch
+_residue_index = {}
+
+
+def _residue_class_index(npad, KH, KW, Cin, S, dev):
+    """-> (idx, offsets): ``wm.reshape(-1)[idx]`` = the S*S matrices w4[:, ry::S, rx::S, :].flip(1, 2).permute(3, 1, 2, 0) of ConvNHWCFn.backward, one
+    after the other (class ry*S + rx starts at offsets[ry*S + rx]); built once per geometry."""
+    key = (npad, KH, KW, Cin, S, dev)
+    hit = _residue_index.get(key)
+    if hit is None:
+        ar = torch.arange(npad * KH * KW * Cin, dtype=torch.int64).view(npad, KH, KW, Cin)
+        parts = [ar[:, ry::S, rx::S, :].flip(1, 2).permute(3, 1, 2, 0).reshape(-1) for ry in range(S) for rx in range(S)]
+        offs, o = [], 0
+        for q in parts:
+            offs.append(o)
+            o += q.numel()
+        hit = _residue_index[key] = (torch.cat(parts).to(dev), offs)
+    return hit
+
+
 class ConvNHWCFn(torch.autograd.Function):
     """y [B,OH,OW,Cout] (dt) = ConvNHWCFn.apply(x [B,IH,IW,Cin] (dt), weight [Cout,Cin,KH,KW], stride, dt, padding=0, bias=None): Conv2d on a
     channels-last map (Tz head: 7x7 s3 / s2 without bias or padding, whmr.py:419-420; IUV head: 3x3 s1 p1 with bias, iuv_predictor.py:71-91)."""
@@ -222,8 +245,8 @@ class ConvNHWCFn(torch.autograd.Function):
         same = S == 1 and OH == IH and OW == IW
         if ctx.needs_input_grad[1] and USE_TN and dt == torch.bfloat16 and Cin % 256 == 0 and M % 32 == 0 and x.is_contiguous():
             # gathering TN kernel: dW[co, (ky, kx, ci)] = sum_m dY[m, co] . X[pixel(m) + tap, ci] from dY and X as they are -- no transposed
-            # dY, no (transposed) column matrix of X.  dY is widened to a multiple of 64 columns (the kernel's smallest row tile) if need be.
-            na = (npad + 63) // 64 * 64
+            # dY, no (transposed) column matrix of X.  dY is widened to a multiple of 128 columns (the kernel's smallest row tile) if need be.
+            na = (npad + TN_ROW_PAD - 1) // TN_ROW_PAD * TN_ROW_PAD
             if na != npad:
                 dya = torch.zeros(M, na, dtype=dt, device=dev)
                 dya[:, :npad] = dyp
@@ -273,15 +296,26 @@ class ConvNHWCFn(torch.autograd.Function):
                 # (ry, rx) only ever meets the taps ky = ry + S*t, kx = rx + S*u, so its data gradient is a small stride-1 convolution of dY
                 # (ceil((KH-ry)/S) x ceil((KW-rx)/S) taps, flipped) -- S*S implicit GEMMs that scatter into the interleaved pixels, instead
                 # of a 2 GB column-space gradient plus col2im.
-                w4 = wm.view(npad, KH, KW, Cin)
+                # The S*S weight matrices (flipped taps of one class, [Cin, (t, u, co)]) are ONE gather of wm through a cached index; in bf16 the
+                # S*S GEMMs -- each under two rounds of tiles, K = 4 .. 9 taps -- are ONE grouped launch (whmr_gemm_bf16_group).
+                idx, offs = _residue_class_index(npad, KH, KW, Cin, S, dev)
+                wp_all = wm.reshape(-1).index_select(0, idx)
                 dy_img = dyp.view(B, OH, OW, npad)
+                descs = []
                 for ry in range(S):
                     for rx in range(S):
                         Ty, Tx = len(range(ry, KH, S)), len(range(rx, KW, S))
                         Jy, Jx = (IH - ry + S - 1) // S, (IW - rx + S - 1) // S
-                        wp = w4[:, ry::S, rx::S, :].flip(1, 2).permute(3, 1, 2, 0).reshape(Cin, Ty * Tx * npad).contiguous()
-                        L.gemm(dy_img, wp, dx, conv=dict(IH=OH, IW=OW, Cin=npad, OH=Jy, OW=Jx, KW=Tx, SH=1, SW=1, PH=Ty - 1, PW=Tx - 1),
-                               scatter=dict(c_off=(ry * IW + rx) * Cin, osb=IH * IW * Cin, osy=S * IW * Cin, osx=S * Cin), accumulate=acc)
+                        o = offs[ry * S + rx]
+                        wp = wp_all[o:o + Cin * Ty * Tx * npad].view(Cin, Ty * Tx * npad)
+                        kw = dict(conv=dict(IH=OH, IW=OW, Cin=npad, OH=Jy, OW=Jx, KW=Tx, SH=1, SW=1, PH=Ty - 1, PW=Tx - 1),
+                                  scatter=dict(c_off=(ry * IW + rx) * Cin, osb=IH * IW * Cin, osy=S * IW * Cin, osx=S * Cin), accumulate=acc)
+                        if GROUP_DX and dt == torch.bfloat16 and S * S <= 9:
+                            descs.append(L.gemm(dy_img, wp, dx, desc_only=True, **kw))
+                        else:
+                            L.gemm(dy_img, wp, dx, **kw)
+                if descs:
+                    L.gemm_group(descs, 192 if Cin > 64 else 65)
             else:
                 wt = L.transpose_cast(wm, dt, pad_to=1)                            # [K, npad]
                 dcol = torch.empty(M, K, dtype=dt, device=dev)
