@@ -212,6 +212,23 @@ def _dev(*ts):
 
 _zeros = {}
 _splitk_ws = {}
+_SIDE_STREAMS = {}
+
+
+def side_stream(device, slot):
+    """The package's side streams: FOUR per device, created together at the first request and shared by every user (slot 0: the heavy chain of the
+    forward / training graph, 1: camera head | Tz head's tail, 2: the ViT backward's weight-gradient stream, graph warm-ups, probes of bench.py,
+    3: ClockProbe -- nothing else, its wave spins until it is released).  torch hands every ``torch.cuda.Stream()`` another of its 32 pooled HIP
+    streams and HIP spreads those over a few hardware queues: a process that had created a dozen streams (the default bench.py run: graphs, camera
+    streams, probes) ran the training step 0.6 ms slower than a fresh one -- its side streams shared hardware queues.  Roles that share a slot never
+    run at the same time; sharing only adds ordering."""
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device('cuda', torch.cuda.current_device())
+    pool = _SIDE_STREAMS.get(device)
+    if pool is None:
+        pool = _SIDE_STREAMS[device] = [torch.cuda.Stream(device=device) for _ in range(4)]
+    return pool[slot]
 
 
 def splitk_workspace(device):
@@ -1506,7 +1523,7 @@ class ClockProbe:
     def __init__(self, device, limit_seconds=2.0):
         self.dev, self.limit = device, limit_seconds
         self.state = torch.zeros(6, dtype=torch.int64, device=device)
-        self.side = torch.cuda.Stream(device=device)
+        self.side = side_stream(device, 3)
         self.mhz = self.seconds = None
         self.timed_out = False
 

@@ -15,7 +15,8 @@ class GraphedForward:
         self.module = module
         self._args = [a.clone() if torch.is_tensor(a) else a for a in args]
         self._kwargs = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in kwargs.items()}
-        side = torch.cuda.Stream()
+        from . import _lib as L
+        side = L.side_stream(torch.cuda.current_device(), 2)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                      # warm-up: builds weight caches, workspaces, kernel attributes
             for _ in range(warmup):

@@ -610,10 +610,8 @@ class WHMR(nn.Module):
 
     @staticmethod
     def _camera_stream(dev, tag=None):
-        st = _CAM_STREAMS.get((dev, tag))          # module-level: a Stream inside the module would break copy.deepcopy(model) / pickling
-        if st is None:
-            st = _CAM_STREAMS[(dev, tag)] = torch.cuda.Stream(device=dev)        # created ON dev, whatever the current device is
-        return st
+        st = _CAM_STREAMS.get((dev, tag))          # override hook of the stream experiments (tools/r6_cu_mask_probe.py, r6_stream_priority_probe.py)
+        return st if st is not None else L.side_stream(dev, 0 if tag == 'tz' else 1)      # the package's shared pool (module-level, not in the module: deepcopy / pickling)
 
     @torch.no_grad()
     def _camera(self, full_x, cam_rotmat, B, dev):

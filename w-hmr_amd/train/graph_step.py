@@ -23,7 +23,8 @@ def capture_train_step(model, fn, warmup=3):
     GPU).  The ViT's cached bf16 weight copies are dropped so that the casts are recorded into the graph: a real run changes the weights
     between replays."""
     vit = getattr(getattr(model, 'feature_extractor', None), 'backbone', None)
-    side = torch.cuda.Stream()
+    from .. import _lib as L
+    side = L.side_stream(torch.cuda.current_device(), 2)
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         for _ in range(warmup):

@@ -152,14 +152,8 @@ USE_TN = os.environ.get('WHMR_TN_GEMM', '1') != '0'          # weight gradients 
 # the four weight gradients of a layer in ONE launch of the TN kernel (whmr_gemm_tn_bf16_group: two K slices instead of 7-28 per product, a quarter of
 # the fp32 partial-tile traffic); A/B switch
 GROUP_DW = os.environ.get('WHMR_TN_GROUP', '1') != '0'
-_side_streams = {}
-
-
 def _side_stream(dev):
-    st = _side_streams.get(dev)
-    if st is None:
-        st = _side_streams[dev] = torch.cuda.Stream(device=dev)
-    return st
+    return L.side_stream(dev, 2)
 
 
 @torch.no_grad()

@@ -76,14 +76,8 @@ def _accept_side_stream_gradients():
             fn(False)
 
 
-_heavy_streams = {}
-
-
 def _heavy_stream(dev):
-    st = _heavy_streams.get(dev)
-    if st is None:
-        st = _heavy_streams[dev] = torch.cuda.Stream(device=dev)
-    return st
+    return L.side_stream(dev, 0)
 
 
 def _perspective_norm(joints, cam_t, focal, cam_center):
@@ -113,9 +107,6 @@ def _backward_first(roots, stop, offset=1 << 40):
             continue
         fn._set_sequence_nr(fn._sequence_nr() + offset)
         todo.extend(f for f, _ in fn.next_functions)
-
-
-_tail_streams = {}
 
 
 def tz_head_train(model, f_nhwc, passthrough=False, tail_stream=None):
@@ -280,9 +271,7 @@ def whmr_forward_train(model, x, center, scale, bbox_height, orig_shape, bbox_in
         _accept_side_stream_gradients()
         capturing = torch.cuda.is_current_stream_capturing()
         if TZ_TAIL_STREAM and not capturing:               # (whole-step capture keeps two streams and autograd's own order: see graph_step.py)
-            tail = _tail_streams.get(dev)
-            if tail is None:
-                tail = _tail_streams[dev] = torch.cuda.Stream(device=dev)
+            tail = L.side_stream(dev, 1)
     with torch.cuda.stream(heavy if heavy is not None else torch.cuda.current_stream(dev)):
         for i in (1, 2):
             y, fmaps[-1] = deconv(i, fmaps[-1])
