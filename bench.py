@@ -593,7 +593,8 @@ def whmr_hbm_rows(args, dev, n=20):
                                B * 84172.0 + 19.6e6)}
         rows = {}
         for name, (fn, byt) in calls.items():
-            side = L.side_stream(torch.cuda.current_device(), 2)
+            from whmr_amd._lib import side_stream
+            side = side_stream(torch.cuda.current_device(), 2)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(3):
