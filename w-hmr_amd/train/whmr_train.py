@@ -56,7 +56,9 @@ def _projection(joints, cam):
 CHAIN_GRADS = os.environ.get('WHMR_CHAIN_GRADS', '1') != '0'      # feature maps handed from consumer to consumer (A/B switch), see whmr_forward_train
 CHAIN_SAMPLER3 = os.environ.get('WHMR_CHAIN_SAMPLER3', '0') != '0'   # the stage-3 sampler behind the two heads in the last map's chain (A/B switch)
 FORK_SAMPLER3 = os.environ.get('WHMR_TRAIN_FORK3', '1') != '0'       # the stage-3 sampler's map gradient as per-point records added to the heads' gradient
-HEAVY_FIRST = os.environ.get('WHMR_TRAIN_HEAVY_FIRST', '1') != '0'    # the side stream's nodes ahead of the loop's in autograd's ready queue (see _backward_first)
+# the side stream's nodes ahead of the loop's in autograd's ready queue (see _backward_first).  Opt-in: -0.07 ms on the single-GPU step (three A/B rounds),
+# but +2.2 ms under torch's DistributedDataParallel, whose reducer expects gradients in roughly reverse-forward order (22.7 -> 24.9 ms, one-rank RCCL group)
+HEAVY_FIRST = os.environ.get('WHMR_TRAIN_HEAVY_FIRST', '0') != '0'
 TZ_TAIL_STREAM = os.environ.get('WHMR_TRAIN_TZ_TAIL', '1') != '0'     # the Tz head's 5-token tail (a hundred tiny launches) on a stream of its own beside the IUV head
 OVERLAP_HEAVY = os.environ.get('WHMR_TRAIN_OVERLAP', '1') != '0'      # deconv 2 / 3 + Tz head + IUV head on a side stream beside the regressor loop
 _STREAM_WARNING_OFF = False
