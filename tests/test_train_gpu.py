@@ -1208,6 +1208,60 @@ def test_whmr_train_step_reducer_small_buckets_with_side_stream_gradients(dev, a
         assert _rms(runs[1][k].cpu(), g.cpu()) < 2e-2, k
 
 
+def test_smpl_skin_backward_is_not_disturbed_by_the_side_streams_kernels(dev, assets):
+    """Round 6 regression guard (profiles/r06_coresidency_probe.txt): ``smpl_skin_bwd_kernel`` gave different bits when the 64-row tile of the gathering TN
+    kernel (then the Tz head's weight gradient) ran beside it on another stream.  That tile is gone; here the SMPL skinning backward runs on the current
+    stream while the Tz head's and the IUV head's convolution nodes (forward + backward, batch 64 geometry) run on a side stream, and every launch must
+    give the bits of the launch that ran alone."""
+    from whmr_amd import _lib as L
+    from whmr_amd.models import whmr_net
+    from whmr_amd.train.heads_autograd import ConvNHWCFn
+    smpl = whmr_net(None, assets=assets, numerics='bf16').to(dev).regressor[0].smpl
+    m = smpl._model()
+    g = torch.Generator().manual_seed(0)
+    B = 64
+    f32 = dict(dtype=torch.float32, device=dev)
+    betas = (torch.randn(B, 10, generator=g) * 0.5).to(dev)
+    A = torch.randn(B, 24, 12, generator=g).to(dev)
+    pose_off = (torch.randn(B, 6890 * 3, generator=g) * 0.01).to(dev)
+    dv = torch.randn(B, 6890, 3, generator=g).to(dev)
+    dregd = torch.randn(B, 33, 3, generator=g).to(dev)
+
+    def skin():
+        dvp, dA = torch.empty(B, 6890 * 3, **f32), torch.empty(B, 54, 288, **f32)
+        L.smpl_skin_bwd(m, betas, A, pose_off, dv, dregd, dvp, dA)
+        return dvp, dA
+    ref = skin()
+    torch.cuda.synchronize()
+    x = (torch.randn(B, 128, 96, 256, generator=g) * 0.5).to(dev).bfloat16()
+    w_tz = (torch.randn(64, 256, 7, 7, generator=g) * 0.02).to(dev).requires_grad_(True)
+    w_iuv = (torch.randn(90, 256, 3, 3, generator=g) * 0.02).to(dev).requires_grad_(True)
+    b_iuv = torch.zeros(90, device=dev, requires_grad=True)
+    side = L.side_stream(dev, 0)
+    bad = 0
+    for r in range(6):
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            xx = x.clone().requires_grad_(True)
+            y = ConvNHWCFn.apply(xx, w_tz, 3, torch.bfloat16) if r % 2 == 0 else ConvNHWCFn.apply(xx, w_iuv, 1, torch.bfloat16, 1, b_iuv)
+            y.backward(torch.ones_like(y))
+        outs = [skin() for _ in range(12)]
+        torch.cuda.synchronize()
+        bad += sum(int(not (torch.equal(o[0], ref[0]) and torch.equal(o[1], ref[1]))) for o in outs)
+    assert bad == 0, '%d of 72 launches beside the side stream differ from the launch that ran alone' % bad
+
+
+def test_side_stream_pool_is_shared(dev):
+    """_lib.side_stream: four streams per device, created once; the forward's camera / Tz streams and the training graph's heavy / tail streams are those"""
+    from whmr_amd import _lib as L
+    from whmr_amd.models.whmr import WHMR
+    from whmr_amd.train import whmr_train as WT
+    pool = [L.side_stream(dev, i) for i in range(4)]
+    assert len({s_.cuda_stream for s_ in pool}) == 4 and all(L.side_stream(dev, i) is pool[i] for i in range(4))
+    assert WHMR._camera_stream(dev) is pool[1] and WHMR._camera_stream(dev, 'tz') is pool[0] and WT._heavy_stream(dev) is pool[0]
+    assert L.ClockProbe(dev).side is pool[3]
+
+
 @pytest.mark.parametrize('case', ['tz conv0 7x7 s3', 'tz conv1 7x7 s2'])
 def test_strided_convolution_data_gradient_grouped_launch_matches_single_launches(dev, case, monkeypatch):
     """ConvNHWCFn.backward, stride S > 1: the S*S residue-class GEMMs as ONE grouped launch (whmr_gemm_bf16_group, tiles 192 x 256 / 128 x 64) give the
