@@ -92,18 +92,29 @@ for kind in ('none', 'iuv', 'tz_dw', 'tz_dx'):
     r_ = rep.cpu().tolist()
     print('global-read canary (30 x 6890 table) beside %-6s: %d wrong reads; one at dword %d: found 0x%08x expected 0x%08x' % (kind, r_[0], r_[1] - 1, r_[2] & 0xffffffff, r_[3] & 0xffffffff))
 sink_, stats_ = torch.zeros(1 << 16, **f32), torch.zeros(4, dtype=torch.int64, device=dev)
-for beside in ('nothing', 'mfma ceiling kernel'):
+for beside in ('nothing', 'mfma ceiling kernel', '32x32x16 mfma stream', 'skin'):
     rep.zero_()
     for r in range(10):
         if beside != 'nothing':
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                L._check(L.lib().whmr_mfma_ceiling(512, 40000, sink_.data_ptr(), stats_.data_ptr(), L._stream()), 'ceiling')
+                if beside == 'mfma ceiling kernel':
+                    L._check(L.lib().whmr_mfma_ceiling(512, 40000, sink_.data_ptr(), stats_.data_ptr(), L._stream()), 'ceiling')
+                else:
+                    L._check(L.lib().whmr_debug_mfma32_stream(245 if beside == 'skin' else 512, 20000, sink_.data_ptr(), L._stream()), 'mfma32')
+        if beside == 'skin':                # the victim itself beside the bare 32x32x16 stream
+            outs = [skin() for _ in range(12)]
+            torch.cuda.synchronize()
+            rep[0] += sum(int(not (torch.equal(o[0], ref[0]) and torch.equal(o[1], ref[1]))) for o in outs)
+            continue
         for _ in range(8):
             L._check(L.lib().whmr_debug_pkfma_canary(3456, 2000, rep.data_ptr(), L._stream()), 'pkfma')
         torch.cuda.synchronize()
     r_ = rep.cpu().tolist()
-    print('v_pk_fma_f32 canary beside %s: %d lanes with a wrong LOW half, %d with a wrong HIGH half (of %d)' % (beside, r_[0], r_[1], 10 * 8 * 3456 * 128))
+    if beside == 'skin':
+        print('smpl_skin_bwd_kernel beside the bare 32x32x16 mfma stream (245 workgroups): %d of 120 launches differ' % r_[0])
+    else:
+        print('v_pk_fma_f32 canary beside %s: %d lanes with a wrong LOW half, %d with a wrong HIGH half (of %d)' % (beside, r_[0], r_[1], 10 * 8 * 3456 * 128))
 import ctypes as C
 # The Tz head's weight gradient called directly (no autograd) from lab builds of gemm_tn.hip that still hold the 64-row tile of the gathering kernel:
 #   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DTN_LAB_ROW64=1 [-DTN_LAB=<n>] -I include w-hmr_amd/csrc/gemm_tn.hip -o tools/lab/build/libtn_row64[_lab<n>].so

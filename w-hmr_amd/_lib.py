@@ -127,6 +127,7 @@ _SIGS = {
     'whmr_debug_lds_canary': [_I, _I, _I, _P, _P],
     'whmr_debug_global_canary': [_P, _I, _I, _I, _P, _P],
     'whmr_debug_pkfma_canary': [_I, _I, _P, _P],
+    'whmr_debug_mfma32_stream': [_I, _I, _P, _P],
     'whmr_estimate_translation': [_P, _P, _I, _I, _I, _I, _F, _F, _F, _P, _P],
     'whmr_transpose_cast': [_P, _I, _L, _P, _I, _L, _I, _I, _I, _P],
     'whmr_colsum': [_P, _I, _L, _I, _I, _P, _I, _P, _P],

@@ -170,6 +170,39 @@ __global__ __launch_bounds__(128) void pkfma_canary_kernel(int iters, unsigned* 
     if (__float_as_uint(acc.y) != __float_as_uint(sy)) atomicAdd(&report[1], 1u);
 }
 
+// A bare v_mfma_f32_32x32x16_bf16 stream (4 independent accumulators per wave): the companion of the canaries above.
+__global__ __launch_bounds__(256) void mfma32_stream_kernel(int iters, float* sink) {
+    unsigned s = 0x9e3779b9u ^ (blockIdx.x * 2654435761u) ^ (threadIdx.x * 40503u);
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (short)(((s >> 16) & 0x807f) | 0x3f80); };
+    bf16x8_t a, b;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a[e] = rnd(); b[e] = rnd(); }
+    f32x16_t acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[0]) : "v"(a), "v"(b));
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[1]) : "v"(a), "v"(b));
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[2]) : "v"(a), "v"(b));
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[3]) : "v"(a), "v"(b));
+    }
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += acc[i][r];
+    if (t == 12345.678f) sink[0] = t;
+}
+
+extern "C" int whmr_debug_mfma32_stream(int blocks, int iters, float* sink, void* stream) {
+    if (blocks <= 0 || iters <= 0 || !sink) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(mfma32_stream_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, sink);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int whmr_debug_pkfma_canary(int blocks, int iters, unsigned* report, void* stream) {
     if (blocks <= 0 || iters <= 0 || !report) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(pkfma_canary_kernel, dim3(blocks), dim3(128), 0, (hipStream_t)stream, iters, report);
