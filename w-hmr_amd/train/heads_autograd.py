@@ -188,6 +188,17 @@ def _residue_class_index(npad, KH, KW, Cin, S, dev):
     return hit
 
 
+def _flipped_taps_index(npad, KH, KW, Cin, dev):
+    """``wm.reshape(-1)[idx]`` = wm.view(npad, KH, KW, Cin).flip(1, 2).permute(3, 1, 2, 0) flattened: the weight operand [Cin, (ky, kx, co)] of a stride-1
+    'same' convolution's data gradient; built once per geometry."""
+    key = ('flip', npad, KH, KW, Cin, dev)
+    hit = _residue_index.get(key)
+    if hit is None:
+        ar = torch.arange(npad * KH * KW * Cin, dtype=torch.int64).view(npad, KH, KW, Cin)
+        hit = _residue_index[key] = ar.flip(1, 2).permute(3, 1, 2, 0).reshape(-1).to(dev)
+    return hit
+
+
 class ConvNHWCFn(torch.autograd.Function):
     """y [B,OH,OW,Cout] (dt) = ConvNHWCFn.apply(x [B,IH,IW,Cin] (dt), weight [Cout,Cin,KH,KW], stride, dt, padding=0, bias=None): Conv2d on a
     channels-last map (Tz head: 7x7 s3 / s2 without bias or padding, whmr.py:419-420; IUV head: 3x3 s1 p1 with bias, iuv_predictor.py:71-91)."""
@@ -287,8 +298,8 @@ class ConvNHWCFn(torch.autograd.Function):
             if same and npad % 64 == 0:
                 # stride 1, 'same' padding: the data gradient is itself a convolution of dY with the flipped kernel -- an implicit GEMM
                 # with the NHWC gather (K = KH*KW*npad), no column matrix at all
-                w4 = wm.float().view(npad, KH, KW, Cin).flip(1, 2).permute(3, 1, 2, 0).reshape(Cin, KH * KW * npad).contiguous()
-                w4 = L.cast_bf16(w4) if dt == torch.bfloat16 else w4
+                # (one gather of wm through a cached index instead of float / flip / copy / cast: four launches on the side stream's chain)
+                w4 = wm.reshape(-1).index_select(0, _flipped_taps_index(npad, KH, KW, Cin, dev)).view(Cin, KH * KW * npad)
                 L.gemm(dyp.view(B, OH, OW, npad), w4, dx.view(B * IH * IW, Cin), accumulate=acc,
                        conv=dict(IH=OH, IW=OW, Cin=npad, OH=IH, OW=IW, KW=KW, SH=1, SW=1, PH=KH - 1 - P, PW=KW - 1 - P))
             elif P == 0 and S > 1 and KH >= S and KW >= S and (dt == torch.float32 or npad % 64 == 0):
