@@ -209,6 +209,10 @@ int whmr_gemm_tn_bf16_group(const struct whmr_tn_item* items, int n_items, int K
 int whmr_conv_dw_tn_bf16(const void* A, long lda, const void* img, long ldp, float* C, long ldc, int Mo, int K, int nB, int OH, int OW,
                          int IH, int IW, int GC, int KH, int KW, int S, int P, const void* zeros, int splits, void* workspace,
                          long workspace_bytes, float* db, void* stream);
+/* the same with separate row / column strides of the gather (SY, SX) */
+int whmr_conv_dw_tn2_bf16(const void* A, long lda, const void* img, long ldp, float* C, long ldc, int Mo, int K, int nB, int OH, int OW,
+                          int IH, int IW, int GC, int KH, int KW, int SY, int SX, int P, const void* zeros, int splits, void* workspace,
+                          long workspace_bytes, float* db, void* stream);
 
 /* LayerNorm over the last dim (C % 4 == 0, C <= 2048), fp32 in, fp32 or bf16 out.  vit.py:125,133,212,242. */
 int whmr_layernorm(const float* x, const float* gamma, const float* beta, void* y, int rows, int C, float eps,
@@ -374,6 +378,15 @@ int whmr_tz_conv1(const void* x, int x_bf16, const float* w, float* tok, int B, 
  * (bf16x3: the W_lo product as extra output columns); nsplit partial planes split_stride floats apart are added (1 = a finished GEMM output). */
 int whmr_tz_fold(const float* P, int ldp, int halves, int nsplit, long split_stride, float* tok, int B, int OHp, int OWp, int OH, int OW,
                  void* stream);
+
+/* The composed Tz convolution in the TRAINING graph (autograd of whmr.py:567-571 through Wc = compose(w0, w1): w-hmr_amd/train/heads_autograd.py::TzComposedFn).
+ * whmr_tz_compose: T [(u, v, o) = 245][(ci, a, b) = 49 Ci] fp32 (= w1 as [(u, v, o), c1] times w0 as [c1, (ci, a, b)]) -> the space-to-depth weight matrix
+ * g [128][36 Ci] (bf16 when g_bf16, else fp32) of whmr.py:418-421 as ONE Conv2d(256, 5, k25, s6), rows (jA, jB, o), columns (q, p, ci).
+ * whmr_tz_compose_bwd: the transpose, dG [128][36 Ci] fp32 -> dT [245][49 Ci].
+ * whmr_tz_unfold: the transpose of whmr_tz_fold, dtok [B, 5, OH, OW] fp32 -> dP [B * OHp * OWp][128] bf16. */
+int whmr_tz_compose(const float* T, int Ci, void* g, int g_bf16, void* stream);
+int whmr_tz_compose_bwd(const float* dG, int Ci, float* dT, void* stream);
+int whmr_tz_unfold(const float* dtok, void* dP, int B, int OHp, int OWp, int OH, int OW, void* stream);
 
 /* estimate_translation (utils/geometry.py:344-408; trainer host stall): S [B,J,3], joints_2d [B,J,3] = (x, y, conf);
  * joints j0..j0+nj-1 enter the weighted least squares; out [B,3]. */

@@ -1208,6 +1208,38 @@ def test_whmr_train_step_reducer_small_buckets_with_side_stream_gradients(dev, a
         assert _rms(runs[1][k].cpu(), g.cpu()) < 2e-2, k
 
 
+@pytest.mark.parametrize('geom', [(2, 128, 96), (4, 64, 48)])
+def test_tz_composed_convolution_node_matches_autograd_through_the_two_convolutions(dev, geom):
+    """TzComposedFn (bf16 training numerics): tokens, data gradient (with and without a gradient already on the map) and both weight gradients of the
+    composed Conv2d(256, 5, k25, s6) against torch autograd through conv2d(conv2d(x, w0, s3), w1, s2) in fp64 on the same bf16-rounded map."""
+    import torch.nn.functional as F
+    from whmr_amd.train.heads_autograd import TzComposedFn
+    B, H, W = geom
+    g = torch.Generator().manual_seed(7)
+    assert not TzComposedFn.fits(torch.empty(3, 64, 48, 256, dtype=torch.bfloat16, device=dev))        # 264 rows: not a multiple of the TN kernel's K step
+    x = (torch.randn(B, 256, H, W, generator=g) * 0.5).bfloat16()
+    w0 = torch.randn(64, 256, 7, 7, generator=g) * 0.02
+    w1 = torch.randn(5, 64, 7, 7, generator=g) * 0.05
+    xr, w0r, w1r = x.double().requires_grad_(True), w0.double().requires_grad_(True), w1.double().requires_grad_(True)
+    yr = F.conv2d(F.conv2d(xr, w0r, stride=3), w1r, stride=2)                           # [B, 5, H2, W2]
+    cot = torch.randn(yr.shape, generator=g).double()
+    gx_extra = torch.randn(B, H, W, 256, generator=g) * 0.1
+    yr.backward(cot)
+    for pt in (False, True):
+        xd = x.permute(0, 2, 3, 1).contiguous().to(dev).requires_grad_(True)
+        w0d, w1d = w0.to(dev).requires_grad_(True), w1.to(dev).requires_grad_(True)
+        out = TzComposedFn.apply(xd, w0d, w1d, pt)
+        t, x2 = out if pt else (out, None)
+        assert t.shape == (B * 5, yr.shape[2] * yr.shape[3]) and _rel(t.view(yr.shape).cpu(), yr.detach()) < 1e-2
+        loss = (t.view(yr.shape) * cot.float().to(dev)).sum() + ((x2.float() * gx_extra.to(dev)).sum() if pt else 0.0)
+        loss.backward()
+        want_dx = xr.grad.permute(0, 2, 3, 1) + (gx_extra.double() if pt else 0.0)
+        assert _rel(xd.grad.float().cpu(), want_dx) < 2e-2, (pt, _rel(xd.grad.float().cpu(), want_dx))
+        assert _rms(xd.grad.float().cpu(), want_dx) < 1e-2
+        assert _rel(w0d.grad.cpu(), w0r.grad) < 1e-2 and _rms(w0d.grad.cpu(), w0r.grad) < 5e-3, (_rel(w0d.grad.cpu(), w0r.grad), _rms(w0d.grad.cpu(), w0r.grad))
+        assert _rel(w1d.grad.cpu(), w1r.grad) < 1e-2 and _rms(w1d.grad.cpu(), w1r.grad) < 5e-3, (_rel(w1d.grad.cpu(), w1r.grad), _rms(w1d.grad.cpu(), w1r.grad))
+
+
 def test_smpl_skin_backward_is_not_disturbed_by_the_side_streams_kernels(dev, assets):
     """Round 6 regression guard (profiles/r06_coresidency_probe.txt): ``smpl_skin_bwd_kernel`` gave different bits when the 64-row tile of the gathering TN
     kernel (then the Tz head's weight gradient) ran beside it on another stream.  That tile is gone; here the SMPL skinning backward runs on the current

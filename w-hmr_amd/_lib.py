@@ -74,6 +74,10 @@ _SIGS = {
     'whmr_gemm_tn_bf16': [_P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _I, _P, _L, _P],
     'whmr_gemm_tn_bf16_group': [C.POINTER(WhmrTnItem), _I, _I, _P, _L, _P],
     'whmr_conv_dw_tn_bf16': [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _L, _P, _P],
+    'whmr_conv_dw_tn2_bf16': [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _L, _P, _P],
+    'whmr_tz_compose': [_P, _I, _P, _I, _P],
+    'whmr_tz_compose_bwd': [_P, _I, _P, _P],
+    'whmr_tz_unfold': [_P, _P, _I, _I, _I, _I, _I, _P],
     'whmr_gemm_bf16_big': [C.POINTER(WhmrGemm), _I, _P],
     'whmr_gemm_bf16_split': [C.POINTER(WhmrGemm), _I, _I, _P],
     'whmr_gemm_bf16_group': [_P, _I, _I, _P],
@@ -1044,17 +1048,48 @@ def conv_dw_tn_ok(a, img):
 
 def conv_dw_tn(a, img, out, OH, OW, KH, KW, S, P, splits=0, db=None):
     """out [Mo, KH*KW*C] fp32 = a^T . col(img): convolution weight gradient without a column matrix (see include/whmr_hip.h).  a [B*OH*OW, Mo] bf16,
-    img [B, IH, IW, C] bf16 NHWC."""
+    img [B, IH, IW, C] bf16 NHWC.  S: the stride, or (row stride, column stride)."""
     _dev(a, img, out)
     Bn, IH, IW, Cc = img.shape
     assert conv_dw_tn_ok(a, img) and a.shape[0] == Bn * OH * OW and out.dtype == torch.float32 and out.shape == (a.shape[1], KH * KW * Cc) and out.stride(1) == 1
     ws = splitk_workspace(a.device)
     ev = _profile_begin()
-    _check(lib().whmr_conv_dw_tn_bf16(a.data_ptr(), a.stride(0), img.data_ptr(), img.stride(2), out.data_ptr(), out.stride(0), a.shape[1], a.shape[0], Bn,
-                                      OH, OW, IH, IW, Cc, KH, KW, S, P, zero_page(a.device).data_ptr(), int(splits), ws.data_ptr(), ws.numel(), _ptr(db), _stream()),
-           'whmr_conv_dw_tn_bf16')
+    if isinstance(S, (tuple, list)):
+        _check(lib().whmr_conv_dw_tn2_bf16(a.data_ptr(), a.stride(0), img.data_ptr(), img.stride(2), out.data_ptr(), out.stride(0), a.shape[1], a.shape[0], Bn,
+                                           OH, OW, IH, IW, Cc, KH, KW, int(S[0]), int(S[1]), P, zero_page(a.device).data_ptr(), int(splits), ws.data_ptr(),
+                                           ws.numel(), _ptr(db), _stream()), 'whmr_conv_dw_tn2_bf16')
+    else:
+        _check(lib().whmr_conv_dw_tn_bf16(a.data_ptr(), a.stride(0), img.data_ptr(), img.stride(2), out.data_ptr(), out.stride(0), a.shape[1], a.shape[0], Bn,
+                                          OH, OW, IH, IW, Cc, KH, KW, S, P, zero_page(a.device).data_ptr(), int(splits), ws.data_ptr(), ws.numel(), _ptr(db), _stream()),
+               'whmr_conv_dw_tn_bf16')
     _profile_end(ev, 'gemm_bf16', 2.0 * a.shape[0] * a.shape[1] * KH * KW * Cc)
     return out
+
+
+def tz_compose(T, Ci, g):
+    """T [245, 49 Ci] fp32 -> g [128, 36 Ci] (bf16 / fp32): the composed Tz convolution's space-to-depth weight matrix (whmr_tz_compose)"""
+    _dev(T, g)
+    assert T.dtype == torch.float32 and T.is_contiguous() and tuple(T.shape) == (245, 49 * Ci) and g.is_contiguous() and tuple(g.shape) == (128, 36 * Ci)
+    assert g.dtype in (torch.bfloat16, torch.float32)
+    _check(lib().whmr_tz_compose(T.data_ptr(), Ci, g.data_ptr(), _bf(g), _stream()), 'whmr_tz_compose')
+    return g
+
+
+def tz_compose_bwd(dG, Ci, dT):
+    _dev(dG, dT)
+    assert dG.dtype == torch.float32 and dG.is_contiguous() and tuple(dG.shape) == (128, 36 * Ci)
+    assert dT.dtype == torch.float32 and dT.is_contiguous() and tuple(dT.shape) == (245, 49 * Ci)
+    _check(lib().whmr_tz_compose_bwd(dG.data_ptr(), Ci, dT.data_ptr(), _stream()), 'whmr_tz_compose_bwd')
+    return dT
+
+
+def tz_unfold(dtok, dP, B, OHp, OWp, OH, OW):
+    """dtok [B * 5, OH * OW] fp32 -> dP [B * OHp * OWp, 128] bf16 (transpose of tz_fold)"""
+    _dev(dtok, dP)
+    assert dtok.dtype == torch.float32 and dtok.is_contiguous() and dtok.numel() == B * 5 * OH * OW
+    assert dP.dtype == torch.bfloat16 and dP.is_contiguous() and tuple(dP.shape) == (B * OHp * OWp, 128)
+    _check(lib().whmr_tz_unfold(dtok.data_ptr(), dP.data_ptr(), B, OHp, OWp, OH, OW, _stream()), 'whmr_tz_unfold')
+    return dP
 
 
 def gemm_f32_set_big(on):

@@ -80,6 +80,7 @@ struct tn_params {
     // (GC % 256 == 0, so a 256-column tile lies inside ONE tap): B[k][n] = img[b, oy * S + ky - P, ox * S + kx - P, c] (NHWC, pixel stride
     // ldb elements), zero outside the IH x IW image.  The rows of a tile then are 512 contiguous bytes of one source pixel -- or of `zeros`.
     int gather, OH, OW, IH, IW, GC, KW, S, P;
+    int SX;                   // column stride of the gather (S is the row stride; whmr_conv_dw_tn_bf16 sets SX = S)
     const bf16_t* zeros;      // >= 512 B of zeros
 };
 
@@ -155,7 +156,7 @@ __device__ __forceinline__ void tn_body(const tn_params& p, char* smem, int tile
             const bool isA = u < A_BYTES / 1024;
             const bf16_t* src;
             if (GATHER && !isA) {
-                const int iy = goy[i] * p.S + g_ky - p.P, ix = gox[i] * p.S + g_kx - p.P;
+                const int iy = goy[i] * p.S + g_ky - p.P, ix = gox[i] * p.SX + g_kx - p.P;
                 const bool in = (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
                 src = in ? p.B + ((size_t)(gb[i] * p.IH + iy) * p.IW + ix) * p.ldb + g_c0 + uchunk[i] * 8 : p.zeros + uchunk[i] * 8;
                 gox[i] += BK;
@@ -410,7 +411,7 @@ __device__ __forceinline__ void tn4_body(const tn_params& p, char* smem, int til
         const int ks_ = (TN_LAB & 16) ? (kt & 3) : kt < nkt ? kt : nkt - 1;      // lab 16: every step re-reads the first four steps' rows (L2-hot operands)
         const char* src;
         if (GATHER && i >= MI) {
-            const int iy = goy[i] * p.S + g_ky - p.P, ix = gox[i] * p.S + g_kx - p.P;
+            const int iy = goy[i] * p.S + g_ky - p.P, ix = gox[i] * p.SX + g_kx - p.P;
             const bool in = kt < nkt && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
             src = in ? baseB + (((size_t)(gb[i] * p.IH + iy) * p.IW + ix) * p.ldb + g_c0) * 2 + voff[i] : (const char*)p.zeros + voff[i];
             gox[i] += BK;
@@ -868,9 +869,9 @@ extern "C" int whmr_gemm_tn_bf16_group(const whmr_tn_item* items, int n_items, i
 // img[b, oy*S + ky - P, ox*S + kx - P, c] or 0 outside the image.  Covers the autograd of Conv2d (A = dY over the OUTPUT grid, img = X:
 // dW[co, (ky,kx,ci)], whmr.py:419-420, iuv_predictor.py) and of ConvTranspose2d(k4, s2, p1) (A = X over the INPUT grid, img = dZ, S = 2, P = 1:
 // dW[ci, (ky,kx,co)], whmr.py:488-498).  GC % 256 == 0, Mo % 128 == 0, K % 32 == 0; zeros: >= 512 B of zeros on the device.
-extern "C" int whmr_conv_dw_tn_bf16(const void* A, long lda, const void* img, long ldp, float* C, long ldc, int Mo, int K, int nB, int OH, int OW,
-                                    int IH, int IW, int GC, int KH, int KW, int S, int P, const void* zeros, int splits, void* workspace,
-                                    long workspace_bytes, float* db, void* stream) {
+static int conv_dw_tn_run(const void* A, long lda, const void* img, long ldp, float* C, long ldc, int Mo, int K, int nB, int OH, int OW,
+                          int IH, int IW, int GC, int KH, int KW, int S, int SX, int P, const void* zeros, int splits, void* workspace,
+                          long workspace_bytes, float* db, void* stream) {
     const long No = (long)KH * KW * GC;
     // Mo % 128, not 64: the 64-row instantiation of the gathering kernel (gemm_tn_kernel<1, true, true>) computed its own product correctly but CHANGED THE
     // RESULTS OF ANOTHER KERNEL running at the same time on another stream -- smpl_skin_bwd_kernel beside it differed from the same launch run alone in
@@ -883,6 +884,21 @@ extern "C" int whmr_conv_dw_tn_bf16(const void* A, long lda, const void* img, lo
         return (int)hipErrorInvalidValue;
     tn_params p{};
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)img; p.C = C; p.lda = lda; p.ldb = ldp; p.ldc = ldc; p.Mo = Mo; p.No = (int)No; p.K = K;
-    p.db = db; p.gather = 1; p.OH = OH; p.OW = OW; p.IH = IH; p.IW = IW; p.GC = GC; p.KW = KW; p.S = S; p.P = P; p.zeros = (const bf16_t*)zeros;
+    p.db = db; p.gather = 1; p.OH = OH; p.OW = OW; p.IH = IH; p.IW = IW; p.GC = GC; p.KW = KW; p.S = S; p.SX = SX; p.P = P; p.zeros = (const bf16_t*)zeros;
     return tn_run(p, splits, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int whmr_conv_dw_tn_bf16(const void* A, long lda, const void* img, long ldp, float* C, long ldc, int Mo, int K, int nB, int OH, int OW,
+                                    int IH, int IW, int GC, int KH, int KW, int S, int P, const void* zeros, int splits, void* workspace,
+                                    long workspace_bytes, float* db, void* stream) {
+    return conv_dw_tn_run(A, lda, img, ldp, C, ldc, Mo, K, nB, OH, OW, IH, IW, GC, KH, KW, S, S, P, zeros, splits, workspace, workspace_bytes, db, stream);
+}
+
+// the same with a row stride SY and a column stride SX of their own (the composed Tz convolution reads the map [B, H, W / 6, 6 C] with a 6 x 1 window at
+// stride 6 x 1: heads_autograd.TzComposedFn)
+extern "C" int whmr_conv_dw_tn2_bf16(const void* A, long lda, const void* img, long ldp, float* C, long ldc, int Mo, int K, int nB, int OH, int OW,
+                                     int IH, int IW, int GC, int KH, int KW, int SY, int SX, int P, const void* zeros, int splits, void* workspace,
+                                     long workspace_bytes, float* db, void* stream) {
+    if (SY <= 0 || SX <= 0) return (int)hipErrorInvalidValue;
+    return conv_dw_tn_run(A, lda, img, ldp, C, ldc, Mo, K, nB, OH, OW, IH, IW, GC, KH, KW, SY, SX, P, zeros, splits, workspace, workspace_bytes, db, stream);
 }

@@ -91,3 +91,81 @@ extern "C" int whmr_tz_fold(const float* P, int ldp, int halves, int nsplit, lon
     WHMR_CHECK_LAUNCH();
     return 0;
 }
+
+// ---- the composed convolution in the TRAINING graph (w-hmr_amd/train/heads_autograd.py::TzComposedFn): autograd of whmr.py:567-571 through
+// Wc = compose(w0, w1) instead of through the 64-channel map between the two convolutions.
+// T [(u, v, o) = 245][(ci, a, b) = Ci * 49] fp32 = w1p . w0 (one small GEMM) -> the space-to-depth weight matrix g [128][(q, p, ci) = 36 Ci] (bf16 or fp32):
+// g[(jA, jB, o)][(q, p, ci)] = Wc[o, ci, A = q + 6 jA, B = p + 6 jB] = sum_{3u + a = A, 3v + b = B} T[(u, v, o)][(ci, a, b)], zero for A, B > 24 and rows >= 125.
+__global__ __launch_bounds__(256) void tz_compose_kernel(const float* __restrict__ T, int Ci, void* __restrict__ g, int g_bf16) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int ldk = 36 * Ci;
+    if (idx >= 128L * ldk) return;
+    const int n = (int)(idx / ldk), k = (int)(idx - (long)n * ldk);
+    const int q = k / (6 * Ci), p = (k / Ci) % 6, ci = k % Ci;
+    float acc = 0.f;
+    if (n < 125) {
+        const int j = n / 5, o = n - j * 5, A = q + 6 * (j / 5), Bc = p + 6 * (j % 5);
+        if (A < 25 && Bc < 25) {
+            const int ldt = Ci * 49;
+            for (int u = (A > 6 ? (A - 4) / 3 : 0); 3 * u <= A && u < 7; ++u) {
+                const int a = A - 3 * u;
+                if (a > 6) continue;
+                for (int v = (Bc > 6 ? (Bc - 4) / 3 : 0); 3 * v <= Bc && v < 7; ++v) {
+                    const int b = Bc - 3 * v;
+                    if (b > 6) continue;
+                    acc += T[(size_t)((u * 7 + v) * 5 + o) * ldt + ci * 49 + a * 7 + b];
+                }
+            }
+        }
+    }
+    if (g_bf16) ((bf16_t*)g)[idx] = f32_to_bf16(acc); else ((float*)g)[idx] = acc;
+}
+
+// transpose of the above: dT[(u, v, o)][(ci, a, b)] = dG[(jA, jB, o)][(q, p, ci)] at A = 3u + a, B = 3v + b (a pure gather: every (A, B) <= 24 has one home)
+__global__ __launch_bounds__(256) void tz_compose_bwd_kernel(const float* __restrict__ dG, int Ci, float* __restrict__ dT) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int ldt = Ci * 49;
+    if (idx >= 245L * ldt) return;
+    const int row = (int)(idx / ldt), col = (int)(idx - (long)row * ldt);
+    const int o = row % 5, uv = row / 5, u = uv / 7, v = uv - u * 7;
+    const int ci = col / 49, ab = col - ci * 49, a = ab / 7, b = ab - a * 7;
+    const int A = 3 * u + a, Bc = 3 * v + b;
+    dT[idx] = dG[(size_t)(((A / 6) * 5 + Bc / 6) * 5 + o) * (36 * Ci) + ((A % 6) * 6 + Bc % 6) * Ci + ci];
+}
+
+// transpose of tz_fold_kernel: dP[(b, Y, m)][(jA, jB, o)] = dtok[b, o, Y - jA, m - jB] (zero outside the OH x OW token grid and in columns 125 .. 127), bf16
+__global__ __launch_bounds__(256) void tz_unfold_kernel(const float* __restrict__ dtok, bf16_t* __restrict__ dP, int B, int OHp, int OWp, int OH, int OW) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)B * OHp * OWp * 128) return;
+    const int n = (int)(idx & 127);
+    const long row = idx >> 7;
+    const int m = (int)(row % OWp), Y = (int)((row / OWp) % OHp), b = (int)(row / ((long)OWp * OHp));
+    float v = 0.f;
+    if (n < 125) {
+        const int j = n / 5, o = n - j * 5, r = Y - j / 5, s = m - j % 5;
+        if (r >= 0 && r < OH && s >= 0 && s < OW) v = dtok[(((size_t)b * 5 + o) * OH + r) * OW + s];
+    }
+    dP[idx] = f32_to_bf16(v);
+}
+
+extern "C" int whmr_tz_compose(const float* T, int Ci, void* g, int g_bf16, void* stream) {
+    if (!T || !g || Ci <= 0) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(tz_compose_kernel, dim3((unsigned)((128L * 36 * Ci + 255) / 256)), dim3(256), 0, (hipStream_t)stream, T, Ci, g, g_bf16);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int whmr_tz_compose_bwd(const float* dG, int Ci, float* dT, void* stream) {
+    if (!dG || !dT || Ci <= 0) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(tz_compose_bwd_kernel, dim3((unsigned)((245L * 49 * Ci + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dG, Ci, dT);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int whmr_tz_unfold(const float* dtok, void* dP, int B, int OHp, int OWp, int OH, int OW, void* stream) {
+    if (!dtok || !dP || B <= 0 || OH <= 0 || OW <= 0 || OH + 4 > OHp || OW + 4 > OWp) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(tz_unfold_kernel, dim3((unsigned)(((long)B * OHp * OWp * 128 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dtok, (bf16_t*)dP, B,
+                       OHp, OWp, OH, OW);
+    WHMR_CHECK_LAUNCH();
+    return 0;
+}

@@ -339,6 +339,99 @@ class ConvNHWCFn(torch.autograd.Function):
         return dx, dw, None, None, None, db, None
 
 
+class TzComposedFn(torch.autograd.Function):
+    """tokens [B * 5, OH2 * OW2] (fp32) = TzComposedFn.apply(x [B, H, W, 256] bf16, w0 [64, 256, 7, 7], w1 [5, 64, 7, 7], passthrough=False): the Tz head's
+    two bias-free convolutions (whmr.py:418-421 as applied at :567-571) as ONE Conv2d(256, 5, k25, s6) in the training graph.
+
+    The two-convolution graph pays for the 64-channel map between them three times: conv0 forward (134 GF), its weight gradient and its data gradient, all
+    at N = 64 / K = 4-9 taps where the GEMM kernels run at a third of their rate (0.35 + 0.38 + 0.46 ms at batch 64).  Through the composed weight
+    Wc = compose(w0, w1) the same function and the same gradients cost 53 GF each: with the map read as [B, H, W/6, 6 C] (every byte once),
+        forward   P = X . G^T (implicit GEMM, 6 x 1 window at stride 6 x 1; G = whmr_tz_compose(w1p . w0)), tokens = fold(P)
+        dG        = dP^T . X          (the gathering TN kernel with row / column strides 6 / 1; dP = unfold(d tokens), 128 columns)
+        dX        = dP . G            (six GEMMs of K = 128, one per window row, each writing its 1536 contiguous channels of every pixel once)
+        dw1, dw0  = two small fp32 GEMMs of dT = compose^T(dG) with w0 / w1 (chain rule through the composition).
+    bf16 numerics only (the fp32 mode keeps the two convolutions: its parity tests compare them with the reference to 1e-4)."""
+
+    @staticmethod
+    def fits(x):
+        """geometry envelope: bf16 contiguous map, W a multiple of the composed stride, whole 256-channel groups (the TN gather), B * ceil(H / 6) * W / 6
+        rows a multiple of 32 (its K step) -- 352 rows per image at 128 x 96, i.e. every batch size of the model's geometry"""
+        B, H, W, C = x.shape
+        return (x.dtype == torch.bfloat16 and x.is_contiguous() and W % 6 == 0 and C % 256 == 0 and (B * ((H + 5) // 6) * (W // 6)) % 32 == 0
+                and (H + 5) // 6 >= ((H - 7) // 3 + 1 - 7) // 2 + 5 and W // 6 >= ((W - 7) // 3 + 1 - 7) // 2 + 5)
+
+    @staticmethod
+    def forward(ctx, x, w0, w1, passthrough=False):
+        if not x.is_cuda:
+            raise RuntimeError('whmr_amd runs on a HIP device only (no CPU fallback)')
+        ctx.set_materialize_grads(False)
+        x = x.detach()
+        B, H, W, C = x.shape
+        assert TzComposedFn.fits(x) and tuple(w0.shape) == (64, C, 7, 7) and tuple(w1.shape) == (5, 64, 7, 7)
+        dev = x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        w0m = w0.detach().float().reshape(64, C * 49)
+        w1p = w1.detach().float().permute(2, 3, 0, 1).reshape(245, 64).contiguous()          # [(u, v, o), c1]
+        T = torch.empty(245, C * 49, **f32)
+        L.gemm(w1p, w0m, T, trans_w=True)
+        g = L.tz_compose(T, C, torch.empty(128, 36 * C, dtype=torch.bfloat16, device=dev))
+        H2, W2 = ((H - 7) // 3 + 1 - 7) // 2 + 1, ((W - 7) // 3 + 1 - 7) // 2 + 1
+        OHp, OWp = (H + 5) // 6, W // 6
+        assert OHp >= H2 + 4 and OWp >= W2 + 4
+        M = B * OHp * OWp
+        ns = 2 if M >= 8192 else 1
+        P = torch.empty(ns, M, 128, **f32)
+        kw = dict(tile=64, raw_splits=2) if ns == 2 else {}
+        L.gemm(x.view(B, H, OWp, 6 * C), g, P if ns > 1 else P[0], conv=dict(IH=H, IW=OWp, Cin=6 * C, OH=OHp, OW=OWp, KW=1, SH=6, SW=1, PH=0, PW=0), **kw)
+        t = torch.empty(B * 5, H2 * W2, **f32)
+        L.tz_fold(P, t, B, OHp, OWp, H2, W2, halves=1, nsplit=ns, split_stride=M * 128)
+        ctx.saved = (x, g, w0m, w1p)
+        ctx.dims = (B, H, W, C, OHp, OWp, H2, W2)
+        ctx.passthrough = passthrough
+        return (t, x.view_as(x)) if passthrough else t
+
+    @staticmethod
+    def backward(ctx, dt, dx_in=None):
+        if dt is None:
+            return dx_in, None, None, None
+        x, g, w0m, w1p = ctx.saved
+        ctx.saved = None
+        B, H, W, C, OHp, OWp, H2, W2 = ctx.dims
+        dev = x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        dP = L.tz_unfold(dt.float().contiguous(), torch.empty(B * OHp * OWp, 128, dtype=torch.bfloat16, device=dev), B, OHp, OWp, H2, W2)
+        dw0 = dw1 = dx = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dG = torch.empty(128, 36 * C, **f32)
+            L.conv_dw_tn(dP, x.view(B, H, OWp, 6 * C), dG, OHp, OWp, 6, 1, (6, 1), 0)
+            dT = L.tz_compose_bwd(dG, C, torch.empty(245, C * 49, **f32))
+            if ctx.needs_input_grad[2]:
+                dw1p = torch.empty(245, 64, **f32)
+                L.gemm(dT, w0m, dw1p)                                                  # [(u, v, o), c1] = dT . w0^T
+                dw1 = dw1p.view(7, 7, 5, 64).permute(2, 3, 0, 1)
+            if ctx.needs_input_grad[1]:
+                dw0m = torch.empty(64, C * 49, **f32)
+                L.gemm(w1p, dT, dw0m, trans_a=True, trans_w=True)                      # [c1, (ci, a, b)] = w1p^T . dT
+                dw0 = dw0m.view(64, C, 7, 7)
+        if ctx.needs_input_grad[0]:
+            acc = dx_in is not None and dx_in.dtype == torch.bfloat16 and dx_in.is_contiguous() and tuple(dx_in.shape) == (B, H, W, C)
+            dx = dx_in if acc else torch.empty(B, H, W, C, dtype=torch.bfloat16, device=dev)
+            gT = g.t().contiguous()                                                    # [(q, p, ci), 128]
+            img = dP.view(B, OHp, OWp, 128)
+            descs = []
+            for q in range(6):                                                         # window row q: map rows y = 6 Y + q < H
+                OHq = (H - 1 - q) // 6 + 1
+                descs.append(L.gemm(img, gT[q * 6 * C:(q + 1) * 6 * C], dx, desc_only=True, accumulate=acc,
+                                    conv=dict(IH=OHp, IW=OWp, Cin=128, OH=OHq, OW=OWp, KW=1, SH=1, SW=1, PH=0, PW=0),
+                                    scatter=dict(c_off=q * W * C, osb=H * W * C, osy=6 * W * C, osx=6 * C)))
+            L.gemm_group(descs, 192)
+            if dx_in is not None and not acc:
+                dx = dx + dx_in.to(dx.dtype)
+        elif dx_in is not None:
+            dx = dx_in
+        return dx, dw0, dw1, None
+
+
 def downsample_csr(d0, d1, cache):
     """CSR triples of Dmap0, Dmap1 and their transposes, rebuilt when a buffer changes (one host sync each, outside any graph capture)."""
     key = (d0.data_ptr(), d0._version, d1.data_ptr(), d1._version)

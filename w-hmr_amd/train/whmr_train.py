@@ -35,7 +35,7 @@ from ..core.constants import FOCAL_LENGTH
 from ..parallel.sync_bn import batch_norm_1d
 from .aux_supervision import IUVHeadOutput
 from .deconv_autograd import DeconvBNReLUFn
-from .heads_autograd import AttentionF32Fn, ConvNHWCFn, DownsampleFn, GeluFn, LayerNormFn, LinearFn, MatToAAFn, RegressorPostFn
+from .heads_autograd import TzComposedFn, AttentionF32Fn, ConvNHWCFn, DownsampleFn, GeluFn, LayerNormFn, LinearFn, MatToAAFn, RegressorPostFn
 from .maf_autograd import MAFSampleFn, MapForkFn
 from .smpl_autograd import SMPLFn
 
@@ -59,6 +59,7 @@ FORK_SAMPLER3 = os.environ.get('WHMR_TRAIN_FORK3', '1') != '0'       # the stage
 # the side stream's nodes ahead of the loop's in autograd's ready queue (see _backward_first).  Opt-in: -0.07 ms on the single-GPU step (three A/B rounds),
 # but +2.2 ms under torch's DistributedDataParallel, whose reducer expects gradients in roughly reverse-forward order (22.7 -> 24.9 ms, one-rank RCCL group)
 HEAVY_FIRST = os.environ.get('WHMR_TRAIN_HEAVY_FIRST', '0') != '0'
+COMPOSE_TZ = os.environ.get('WHMR_TRAIN_COMPOSE_TZ', '1') != '0'     # bf16 numerics: the Tz head's two convolutions as one composed convolution (TzComposedFn)
 TZ_TAIL_STREAM = os.environ.get('WHMR_TRAIN_TZ_TAIL', '1') != '0'     # the Tz head's 5-token tail (a hundred tiny launches) on a stream of its own beside the IUV head
 OVERLAP_HEAVY = os.environ.get('WHMR_TRAIN_OVERLAP', '1') != '0'      # deconv 2 / 3 + Tz head + IUV head on a side stream beside the regressor loop
 _STREAM_WARNING_OFF = False
@@ -119,24 +120,29 @@ def tz_head_train(model, f_nhwc, passthrough=False, tail_stream=None):
     dt = model._dt
     B = f_nhwc.shape[0]
     f_next = None
-    if passthrough:
-        y0, f_next = ConvNHWCFn.apply(f_nhwc, model.conv[0].weight, 3, dt, 0, None, True)
+    if COMPOSE_TZ and dt == torch.bfloat16 and TzComposedFn.fits(f_nhwc):
+        # both convolutions as ONE composed convolution, gradients through the composed weight (heads_autograd.TzComposedFn)
+        t = TzComposedFn.apply(f_nhwc, model.conv[0].weight, model.conv[1].weight, passthrough)
+        t, f_next = t if passthrough else (t, None)
     else:
-        y0 = ConvNHWCFn.apply(f_nhwc, model.conv[0].weight, 3, dt)
-    y1 = ConvNHWCFn.apply(y0, model.conv[1].weight, 2, dt)                            # [B, 18, 12, 5]
+        if passthrough:
+            y0, f_next = ConvNHWCFn.apply(f_nhwc, model.conv[0].weight, 3, dt, 0, None, True)
+        else:
+            y0 = ConvNHWCFn.apply(f_nhwc, model.conv[0].weight, 3, dt)
+        y1 = ConvNHWCFn.apply(y0, model.conv[1].weight, 2, dt)                        # [B, 18, 12, 5]
+        t = y1.float().permute(0, 3, 1, 2).reshape(B * 5, -1).contiguous()             # == conv(...).reshape(B, 5, -1) on NCHW, whmr.py:571
     if tail_stream is not None:
-        tail_stream.wait_stream(torch.cuda.current_stream(y1.device))
+        tail_stream.wait_stream(torch.cuda.current_stream(t.device))
         if not torch.cuda.is_current_stream_capturing():
-            y1.record_stream(tail_stream)
+            t.record_stream(tail_stream)
         with torch.cuda.stream(tail_stream):
-            Tz = _tz_tail(model, y1, B)
+            Tz = _tz_tail(model, t, B)
     else:
-        Tz = _tz_tail(model, y1, B)
+        Tz = _tz_tail(model, t, B)
     return (Tz, f_next) if passthrough else Tz
 
 
-def _tz_tail(model, y1, B):
-    t = y1.float().permute(0, 3, 1, 2).reshape(B * 5, -1).contiguous()                 # == conv(...).reshape(B, 5, -1) on NCHW, whmr.py:571
+def _tz_tail(model, t, B):
     D = t.shape[-1]
     td = model.transformer_decoder                                                     # timm Block(dim 216, 2 heads, qkv_bias False)
     nh, hd = 2, D // 2
