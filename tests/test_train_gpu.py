@@ -1208,6 +1208,29 @@ def test_whmr_train_step_reducer_small_buckets_with_side_stream_gradients(dev, a
         assert _rms(runs[1][k].cpu(), g.cpu()) < 2e-2, k
 
 
+def test_tz_compose_kernels_match_the_fp64_composition(dev):
+    """whmr_tz_compose (the per-step device composition of the training graph: T = w1p . w0, 9-term gather-sum into the space-to-depth layout) against
+    models.whmr.compose_tz_weights (fp64, the inference path's composition), and whmr_tz_compose_bwd as its exact transpose (<dG, compose(T)> = <compose_bwd(dG), T>)."""
+    from whmr_amd import _lib as L
+    from whmr_amd.models.whmr import compose_tz_weights
+    g = torch.Generator().manual_seed(2)
+    C = 256
+    w0 = (torch.randn(64, C, 7, 7, generator=g) * 0.02).to(dev)
+    w1 = (torch.randn(5, 64, 7, 7, generator=g) * 0.05).to(dev)
+    w1p = w1.permute(2, 3, 0, 1).reshape(245, 64).contiguous()
+    T = torch.empty(245, C * 49, device=dev)
+    L.gemm(w1p, w0.reshape(64, C * 49), T, trans_w=True)
+    G = L.tz_compose(T, C, torch.empty(128, 36 * C, device=dev))
+    ref = compose_tz_weights(w0, w1)
+    assert _rel(G.cpu(), ref.cpu()) < 1e-5, _rel(G.cpu(), ref.cpu())
+    Gb = L.tz_compose(T, C, torch.empty(128, 36 * C, dtype=torch.bfloat16, device=dev))
+    assert torch.equal(Gb, L.cast_bf16(G))
+    dG = torch.randn(128, 36 * C, generator=g).to(dev)
+    dT = L.tz_compose_bwd(dG, C, torch.empty(245, C * 49, device=dev))
+    lhs, rhs = (dG.double() * G.double()).sum().item(), (dT.double() * T.double()).sum().item()
+    assert abs(lhs - rhs) < 1e-6 * max(abs(lhs), 1.0), (lhs, rhs)
+
+
 @pytest.mark.parametrize('geom', [(2, 128, 96), (4, 64, 48)])
 def test_tz_composed_convolution_node_matches_autograd_through_the_two_convolutions(dev, geom):
     """TzComposedFn (bf16 training numerics): tokens, data gradient (with and without a gradient already on the map) and both weight gradients of the
