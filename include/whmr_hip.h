@@ -562,7 +562,7 @@ int whmr_debug_lds_canary(int blocks, int lds_bytes, int spins, unsigned* report
  * global loads and compares (report as above). */
 int whmr_debug_global_canary(const unsigned* table, int rows, int ld, int reps, unsigned* report, void* stream);
 /* Debug aid: every lane runs one multiply-add chain as v_pk_fma_f32 and as two v_fma_f32 and compares the bits; report[0] / [1] += lanes whose low /
- * high half differs (2 x uint32, zeroed by the caller). */
+ * high half differs; report[2] / [3]: the same for the op_sel:[0,1,0] form (4 x uint32, zeroed by the caller). */
 int whmr_debug_pkfma_canary(int blocks, int iters, unsigned* report, void* stream);
 /* Debug aid: a bare v_mfma_f32_32x32x16_bf16 stream (`blocks` workgroups of 4 waves, 4 MFMAs per wave and iteration) to run beside a canary. */
 int whmr_debug_mfma32_stream(int blocks, int iters, float* sink, void* stream);

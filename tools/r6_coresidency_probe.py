@@ -25,6 +25,9 @@ if os.environ.get('PROBE_ZERO') == 'pose':
     pose_off.zero_()
 if os.environ.get('PROBE_ZERO') == 'betas':
     betas.zero_()
+if os.environ.get('PROBE_ONEHOT') is not None:      # only beta[l0] is non-zero: the shape sum of component c then reads shapedirs row c * 10 + l0 alone
+    betas.zero_()
+    betas[:, int(os.environ['PROBE_ONEHOT'])] = 0.7
 if os.environ.get('PROBE_ZERO') == 'both':
     pose_off.zero_(); betas.zero_()
 dregd = torch.randn(B, 33, 3, generator=g).to(dev)
@@ -114,7 +117,7 @@ for beside in ('nothing', 'mfma ceiling kernel', '32x32x16 mfma stream', 'skin')
     if beside == 'skin':
         print('smpl_skin_bwd_kernel beside the bare 32x32x16 mfma stream (245 workgroups): %d of 120 launches differ' % r_[0])
     else:
-        print('v_pk_fma_f32 canary beside %s: %d lanes with a wrong LOW half, %d with a wrong HIGH half (of %d)' % (beside, r_[0], r_[1], 10 * 8 * 3456 * 128))
+        print('v_pk_fma_f32 canary beside %s: %d lanes with a wrong LOW half, %d with a wrong HIGH half; op_sel:[0,1,0] form %d / %d (of %d)' % (beside, r_[0], r_[1], r_[2], r_[3], 10 * 8 * 3456 * 128))
 import ctypes as C
 # The Tz head's weight gradient called directly (no autograd) from lab builds of gemm_tn.hip that still hold the 64-row tile of the gathering kernel:
 #   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DTN_LAB_ROW64=1 [-DTN_LAB=<n>] -I include w-hmr_amd/csrc/gemm_tn.hip -o tools/lab/build/libtn_row64[_lab<n>].so
@@ -145,6 +148,22 @@ for name, rows in (('libtn_row64.so', 64), ('libtn_row64_lab1.so', 64), ('libtn_
             tot += 1
             bad += int(not (torch.equal(dvp, ref[0]) and torch.equal(dA, ref[1])))
     print('Tz weight gradient (7x7 s3, %d-row tile of the gathering TN kernel, %s) on the other stream: %d of %d smpl_skin_bwd launches differ' % (rows, name, bad, tot))
+    if name == 'libtn_row64.so':                       # the canaries beside THIS kernel
+        rep.zero_()
+        rep2 = torch.zeros(4, dtype=torch.int32, device=dev)
+        for r in range(10):
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                ws = L.splitk_workspace(dev)
+                for _ in range(3):
+                    fn(dy_tz.data_ptr(), dy_tz.stride(0), x.data_ptr(), x.stride(2), dw_tz.data_ptr(), dw_tz.stride(0), rows, dy_tz.shape[0], B, OH, OW, 128, 96, 256,
+                       7, 7, 3, 0, L.zero_page(dev).data_ptr(), 0, ws.data_ptr(), ws.numel(), None, L._stream())
+            for _ in range(8):
+                L._check(L.lib().whmr_debug_pkfma_canary(3456, 2000, rep.data_ptr(), L._stream()), 'pkfma')
+                L._check(L.lib().whmr_debug_lds_canary(3456, 20480, 100, rep2.data_ptr(), L._stream()), 'lds')
+            torch.cuda.synchronize()
+        r_, r2_ = rep.cpu().tolist(), rep2.cpu().tolist()
+        print('   beside the %d-row tile: v_pk_fma_f32 canary %d wrong LOW halves, %d wrong HIGH halves; with op_sel:[0,1,0] %d / %d; LDS canary %d dwords changed' % (rows, r_[0], r_[1], r_[2], r_[3], r2_[0]))
 for kind in ('none', 'tz_dw', 'tz', 'iuv'):
     bad = tot = 0
     worst = 0.0

@@ -15,6 +15,17 @@ def _stale(target, deps):
     return not os.path.exists(target) or any(os.path.getmtime(d) > os.path.getmtime(target) for d in deps)
 
 
+# Round 6 (profiles/r06_coresidency_probe.txt): `v_pk_fma_f32 ... op_sel:[0,1,0]` (both lanes times the HIGH half of a register pair -- what hipcc makes of "a
+# pair times one scalar of a pair") returned wrong LOW lanes while one particular MFMA kernel of this library ran on another stream (a canary of nothing but
+# that instruction: 457 552 wrong lanes beside it, none beside anything else, none for the plain form).  That kernel is gone; the files whose kernels
+# contain the form are nevertheless built without packed-fp32 instructions -- they are memory- or latency-bound VALU kernels that run beside the GEMM
+# streams (the host pass prints "not a recognized feature" for the flag and ignores it).
+_NO_PK = ['-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']
+NO_PACKED_FP32 = {f: _NO_PK for f in ('smpl_lbs.hip', 'smpl_fused.hip', 'geometry.hip', 'iuv_loss.hip', 'maf_sampler.hip', 'rasterize.hip', 'vit_ops.hip')}
+if os.environ.get('WHMR_BUILD_PACKED_FP32', '0') == '1':                 # A/B
+    NO_PACKED_FP32 = {}
+
+
 def build(force=False, verbose=True):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     srcs = sorted(glob.glob(os.path.join(CSRC, '*.hip')))
@@ -29,7 +40,7 @@ def build(force=False, verbose=True):
 
     def cc(job):
         s, o = job
-        cmd = [hipcc] + FLAGS + ['-c', s, '-o', o]
+        cmd = [hipcc] + FLAGS + NO_PACKED_FP32.get(os.path.basename(s), []) + ['-c', s, '-o', o]
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)

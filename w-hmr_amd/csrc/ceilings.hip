@@ -154,7 +154,7 @@ extern "C" int whmr_debug_global_canary(const unsigned* table, int rows, int ld,
 }
 
 // Packed-FMA canary: every lane runs the same chain twice, as v_pk_fma_f32 on a register pair and as two v_fma_f32, and compares the bits.
-// report[0] += lanes whose LOW half differs, report[1] += lanes whose HIGH half differs.
+// report[0] += lanes whose LOW half differs, report[1] += lanes whose HIGH half differs; report[2] / [3]: the same for the op_sel:[0,1,0] form.
 __global__ __launch_bounds__(128) void pkfma_canary_kernel(int iters, unsigned* __restrict__ report) {
     typedef float f2 __attribute__((ext_vector_type(2)));
     const float t = (float)(threadIdx.x + 128 * (blockIdx.x & 15)) * 1e-3f;
@@ -168,6 +168,18 @@ __global__ __launch_bounds__(128) void pkfma_canary_kernel(int iters, unsigned* 
     }
     if (__float_as_uint(acc.x) != __float_as_uint(sx)) atomicAdd(&report[0], 1u);
     if (__float_as_uint(acc.y) != __float_as_uint(sy)) atomicAdd(&report[1], 1u);
+    // the same with op_sel:[0,1,0]: BOTH lanes multiply by the HIGH half of the second source (the form hipcc emits for "a pair times one scalar of a pair":
+    // smpl_skin_bwd_kernel's shape sum, rows 1 / 5 / 9 -- the rows that went wrong beside the 64-row TN tile)
+    f2 acc2 = {0.1f, 0.2f};
+    float tx = 0.1f, ty = 0.2f;
+    for (int i = 0; i < iters; ++i) {
+        f2 b = {0.999f - (float)(i & 255) * 1e-5f, -0.998f + (float)(i & 127) * 1e-5f};
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(acc2) : "v"(a), "v"(b));
+        asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(tx) : "v"(a.x), "v"(b.y));
+        asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(ty) : "v"(a.y), "v"(b.y));
+    }
+    if (__float_as_uint(acc2.x) != __float_as_uint(tx)) atomicAdd(&report[2], 1u);
+    if (__float_as_uint(acc2.y) != __float_as_uint(ty)) atomicAdd(&report[3], 1u);
 }
 
 // A bare v_mfma_f32_32x32x16_bf16 stream (4 independent accumulators per wave): the companion of the canaries above.

@@ -873,11 +873,11 @@ static int conv_dw_tn_run(const void* A, long lda, const void* img, long ldp, fl
                           int IH, int IW, int GC, int KH, int KW, int S, int SX, int P, const void* zeros, int splits, void* workspace,
                           long workspace_bytes, float* db, void* stream) {
     const long No = (long)KH * KW * GC;
-    // Mo % 128, not 64: the 64-row instantiation of the gathering kernel (gemm_tn_kernel<1, true, true>) computed its own product correctly but CHANGED THE
-    // RESULTS OF ANOTHER KERNEL running at the same time on another stream -- smpl_skin_bwd_kernel beside it differed from the same launch run alone in
-    // 88 of 96 launches (the c = 0 terms of its per-block sums, up to 1e-2 relative), with every input, its LDS and its global reads verified intact
-    // and only while the 64-row kernel issued MFMAs (round 6, tools/r6_coresidency_probe.py; not root-caused).  The 128- and 256-row instantiations and
-    // every other kernel of the step leave it alone, so the 64-row one is not built; callers widen dY to 128 columns (heads_autograd.TN_ROW_PAD).
+    // Mo % 128, not 64: the 64-row instantiation of the gathering kernel (gemm_tn_kernel<1, true, true>) computed its own product correctly but, while it ran,
+    // `v_pk_fma_f32 ... op_sel:[0,1,0]` returned wrong LOW lanes in kernels on OTHER streams (a canary of that one instruction: ~456 000 wrong lanes of 35 M
+    // beside it, none beside any other kernel incl. the 128- / 256-row tiles and bare MFMA streams; smpl_skin_bwd_kernel, which had three such instructions,
+    // differed in 88-112 of 96-120 launches; only while the tile issues MFMAs) -- round 6, tools/r6_coresidency_probe.py, profiles/r06_coresidency_probe.txt.
+    // The tile is not built; callers widen dY to 128 columns (heads_autograd.TN_ROW_PAD).  (The VALU files are also built without packed fp32: build.py.)
     if (Mo <= 0 || K <= 0 || (Mo % (TN_LAB_ROW64 ? 64 : 128)) || (GC % 256) || GC <= 0 || (K % 32) || (lda % 8) || (ldp % 8) || (ldc % 4) || ((uintptr_t)A & 15) ||
         ((uintptr_t)img & 15) || ((uintptr_t)C & 15) || ((uintptr_t)zeros & 15) || !zeros || lda < Mo || ldp < GC || ldc < No ||
         (long)nB * OH * OW != K || No > (1L << 30))
