@@ -23,6 +23,35 @@ def test_library_builds_and_exports_every_declared_symbol():
         assert getattr(lib, name) is not None
 
 
+def test_no_kernel_holds_the_packed_fp32_form_that_went_wrong():
+    """Round 6 (profiles/r06_coresidency_probe.txt): ``v_pk_{fma,mul,add}_f32 ... op_sel:[...]`` (a lane reading the HIGH register of a source pair) returned
+    wrong low lanes while one MFMA kernel ran on another stream.  The files whose kernels held that form are built without packed-fp32 instructions
+    (w-hmr_amd/build.py); this disassembles every built code object and finds the form nowhere but in the canary that demonstrates it (ceilings.hip)."""
+    import glob
+    import subprocess
+    import __graft_entry__ as ge
+    ge.build()
+    objdump = '/opt/rocm/lib/llvm/bin/llvm-objdump'
+    if not os.path.exists(objdump):
+        pytest.skip('no llvm-objdump in this image')
+    objs = sorted(glob.glob(os.path.join(ROOT, 'w-hmr_amd', 'build', '*.o')))
+    assert len(objs) >= 20
+    found = {}
+    for o in objs:
+        blob = open(o, 'rb').read()
+        starts = [m.start() for m in re.finditer(b'\x7fELF', blob)]
+        assert len(starts) >= 2, o                                              # host object + the embedded gfx950 code object
+        co = os.path.join(ROOT, 'w-hmr_amd', 'build', '_scan.co')
+        with open(co, 'wb') as f:
+            f.write(blob[starts[1]:])
+        text = subprocess.run([objdump, '-d', '--mcpu=gfx950', co], capture_output=True, text=True, check=True).stdout
+        os.remove(co)
+        n = len(re.findall(r'v_pk_(?:fma|mul|add)_f32[^\n]*op_sel:\[', text))
+        if n:
+            found[os.path.basename(o)] = n
+    assert found == {'ceilings.o': 1}, found
+
+
 def test_product_path_never_imports_the_oracle():
     for dp, _, files in os.walk(os.path.join(ROOT, 'w-hmr_amd')):
         for f in files:
