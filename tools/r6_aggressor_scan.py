@@ -1,0 +1,65 @@
+"""Does any kernel of the library disturb `v_pk_fma_f32 ... op_sel:[0,1,0]` on another stream the way the (removed) 64-row TN tile did?  The one-instruction
+canary (whmr_debug_pkfma_canary) runs back to back on a side stream while the main stream runs whole workloads: the ViT forward in the three numerics, the
+full W-HMR forward, the training step (forward + backward).  usage: python tools/r6_aggressor_scan.py [steps]   -> wrong lanes per workload (0 expected)"""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from oracle import synth
+from oracle import train as OT
+from whmr_amd import _lib as L
+from whmr_amd.models import whmr_net
+
+dev = torch.device('cuda:0')
+assets = synth.make_assets(0)
+sd = synth.make_state_dict(0, assets)
+B = 64
+inp = synth.make_inputs(B, 3)
+d = {k: inp[k].to(dev) for k in ('x', 'center', 'scale', 'bbox_height', 'orig_shape', 'bbox_info')}
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+side = L.side_stream(dev, 3)
+rep = torch.zeros(4, dtype=torch.int32, device=dev)
+
+
+def scan(name, fn, canaries):
+    fn()                                                     # warm-up (caches, workspaces)
+    torch.cuda.synchronize()
+    rep.zero_()
+    lanes = 0
+    for _ in range(steps):
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(canaries):
+                L._check(L.lib().whmr_debug_pkfma_canary(1024, 1500, rep.data_ptr(), L._stream()), 'pkfma')
+        lanes += canaries * 1024 * 128
+        fn()
+        torch.cuda.synchronize()
+    r = rep.cpu().tolist()
+    print('%-34s: plain form %d / %d wrong low / high lanes, op_sel:[0,1,0] form %d / %d (of %d lanes, %d canary launches beside %d steps)' % (
+        name, r[0], r[1], r[2], r[3], lanes, steps * canaries, steps))
+
+
+def train_step(m):
+    def fn():
+        for p_ in m.parameters():
+            p_.grad = None
+        out_list, _ = m(d['x'], None, d['center'], d['scale'], d['bbox_height'], d['orig_shape'], d['bbox_info'], is_train=True)
+        loss = OT.cotangent_loss(out_list['smpl_out'], dev=dev) + OT.dp_cotangent_loss(out_list['dp_out'][0], dev=dev)
+        loss.backward()
+    return fn
+
+
+for numerics in ('bf16', 'bf16x3', 'fp32'):
+    m = whmr_net(None, assets=assets, numerics=numerics)
+    m.load_state_dict(sd, strict=False)
+    m = m.to(dev).eval()
+    with torch.no_grad():
+        scan('full W-HMR forward, %s' % numerics, lambda: m(d['x'], None, d['center'], d['scale'], d['bbox_height'], d['orig_shape'], d['bbox_info']),
+             {'bf16': 120, 'bf16x3': 250, 'fp32': 600}[numerics])
+    del m
+for numerics in ('bf16', 'fp32'):
+    m = whmr_net(None, assets=assets, numerics=numerics)
+    m.load_state_dict(sd, strict=False)
+    m = m.to(dev).train()
+    scan('training step, %s' % numerics, train_step(m), {'bf16': 500, 'fp32': 2500}[numerics])
+    del m
