@@ -49,6 +49,34 @@ def train_step(m):
     return fn
 
 
+if os.environ.get('SCAN') == 'parts':        # the bf16 forward piece by piece: backbone, one sampler launch, one SMPL call (each repeated to fill the window)
+    m = whmr_net(None, assets=assets, numerics='bf16')
+    m.load_state_dict(sd, strict=False)
+    m = m.to(dev).eval()
+    with torch.no_grad():
+        out, _ = m(d['x'], None, d['center'], d['scale'], d['bbox_height'], d['orig_shape'], d['bbox_info'], view='train')
+        last = out['smpl_out'][2]
+        markers, cam = last['markers'].contiguous(), last['pred_cam'].contiguous()
+        betas, rot = last['pred_shape'].contiguous(), last['rotmat'].reshape(B, 216).contiguous()
+        ext, smpl = m.maf_extractor[2], m.regressor[2].smpl
+        xc = torch.empty(B, m.regressor[2].fc1.in_features, dtype=torch.float32, device=dev)
+        scan('ViT-B backbone (blocked bf16 kernels)', lambda: m.feature_extractor(d['x']), 80)
+        scan('sampler launch x 100', lambda: [ext(markers, cam=cam, out=xc, want_point_feat=False) for _ in range(100)], 40)
+        scan('SMPL call x 40', lambda: [smpl.run(betas, rot, gram_schmidt=True, want_aa=True, want_smpl_joints=True, want_markers=True) for _ in range(40)], 50)
+        f = m.feature_extractor(d['x']).permute(0, 2, 3, 1).contiguous().to(m._dt)
+        def heads():
+            x_, sp = f, None
+            for i in range(3):
+                x_, sp = m._deconv(i, x_, sp)
+            return x_
+        scan('three deconv stages x 1', heads, 30)
+        fm = heads()
+        scan('composed Tz convolution x 20', lambda: [m._tz_tokens_composed(fm, None) for _ in range(20)], 60)
+        t0 = m._tz_tokens_composed(fm, None)
+        g_, bn4 = m._tz_composed_operands()
+        scan('Tz tail x 40', lambda: [m._tz_tokens_tail(t0.clone(), B, dev, bn4) for _ in range(40)], 60)
+        scan('full forward again (all pieces)', lambda: m(d['x'], None, d['center'], d['scale'], d['bbox_height'], d['orig_shape'], d['bbox_info']), 120)
+    sys.exit(0)
 for numerics in ('bf16', 'bf16x3', 'fp32'):
     m = whmr_net(None, assets=assets, numerics=numerics)
     m.load_state_dict(sd, strict=False)
