@@ -76,6 +76,8 @@ if os.environ.get('SCAN') == 'parts':        # the bf16 forward piece by piece: 
         g_, bn4 = m._tz_composed_operands()
         scan('Tz tail x 40', lambda: [m._tz_tokens_tail(t0.clone(), B, dev, bn4) for _ in range(40)], 60)
         scan('full forward again (all pieces)', lambda: m(d['x'], None, d['center'], d['scale'], d['bbox_height'], d['orig_shape'], d['bbox_info']), 120)
+        m.overlap_camera = m.overlap_tz = False
+        scan('full forward, side streams folded', lambda: m(d['x'], None, d['center'], d['scale'], d['bbox_height'], d['orig_shape'], d['bbox_info']), 140)
     sys.exit(0)
 for numerics in ('bf16', 'bf16x3', 'fp32'):
     m = whmr_net(None, assets=assets, numerics=numerics)
