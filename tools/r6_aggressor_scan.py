@@ -76,6 +76,19 @@ if os.environ.get('SCAN') == 'parts':        # the bf16 forward piece by piece: 
         g_, bn4 = m._tz_composed_operands()
         scan('Tz tail x 40', lambda: [m._tz_tokens_tail(t0.clone(), B, dev, bn4) for _ in range(40)], 60)
         scan('full forward again (all pieces)', lambda: m(d['x'], None, d['center'], d['scale'], d['bbox_height'], d['orig_shape'], d['bbox_info']), 120)
+        try:                                     # one regressor stage alone (state kernel, collapsed affine map, SMPL, tail, projections of stage 3)
+            so = out['smpl_out'][2]
+            reg = m.regressor[2]
+            xc2 = torch.empty(B, reg.fc1.in_features, dtype=torch.float32, device=dev)
+            ext(markers, cam=cam, out=xc2, want_point_feat=False)
+            tz1 = torch.full((B,), 5.0, device=dev)
+            c_, s_, bh_ = d['center'].float().contiguous(), d['scale'].float(), d['bbox_height'].float().contiguous()
+            os_, bi_ = d['orig_shape'].float().contiguous(), d['bbox_info'].float().contiguous()
+            stage = lambda: [reg(None, bi_, tz1, os_, c_, s_, bh_, so['rotmat'], so['pred_shape'], so['pred_cam'], is_train=False, n_iter=1, J_regressor=None,
+                                 with_aux=False, xc=xc2, xc_next=None, state_ready=False) for _ in range(30)]
+            scan('regressor stage x 30', stage, 60)
+        except Exception as e:                   # noqa: BLE001
+            print('regressor stage scan skipped:', type(e).__name__, e)
         m.overlap_camera = m.overlap_tz = False
         scan('full forward, side streams folded', lambda: m(d['x'], None, d['center'], d['scale'], d['bbox_height'], d['orig_shape'], d['bbox_info']), 140)
     sys.exit(0)
