@@ -924,6 +924,32 @@ def test_train_step_hip_graph_replay_matches_eager(dev, assets, state_dict):
         assert worst < 1e-4, (seed, worst)
 
 
+@pytest.mark.parametrize('switch', ['FORK_SAMPLER3', 'TZ_TAIL_STREAM', 'HEAVY_FIRST', 'OVERLAP_HEAVY'])
+def test_training_overlap_switches_do_not_change_the_step(dev, assets, state_dict, switch, monkeypatch):
+    """The round-6 scheduling switches of whmr_forward_train (deferred sampler scatter, Tz tail stream, side-stream nodes first in autograd's ready queue, the
+    side stream itself) change WHEN kernels run, not what they compute: fp32 numerics, B = 2, the step with the switch flipped gives the same loss and the
+    same parameter gradients (bit for bit where no atomic accumulation order is involved; 1e-6 elsewhere)."""
+    from oracle import synth
+    from oracle import train as OT
+    from whmr_amd.train import whmr_train as WT
+    inp = synth.make_inputs(2, 0)
+    d = {k: inp[k].to(dev) for k in ('x', 'center', 'scale', 'bbox_height', 'orig_shape', 'bbox_info')}
+    res = []
+    for flip in (False, True):
+        if flip:
+            monkeypatch.setattr(WT, switch, not getattr(WT, switch))
+        m = _train_model(assets, state_dict, 'fp32', dev)
+        out_list, _ = m(d['x'], None, d['center'], d['scale'], d['bbox_height'], d['orig_shape'], d['bbox_info'], is_train=True)
+        loss = OT.cotangent_loss(out_list['smpl_out'], dev=dev) + OT.dp_cotangent_loss(out_list['dp_out'][0], dev=dev)
+        loss.backward()
+        torch.cuda.synchronize()
+        res.append((loss.item(), {k: v.grad.detach().clone() for k, v in m.named_parameters() if v.grad is not None}))
+    assert res[0][0] == res[1][0]
+    assert res[0][1].keys() == res[1][1].keys() and len(res[0][1]) > 200
+    worst = max(_rel(res[1][1][k], g_) for k, g_ in res[0][1].items() if g_.abs().max() > 1e-8)
+    assert worst < 1e-5, worst
+
+
 def test_bn_and_col2im_edge_shapes(dev):
     """BatchNorm kernels at C = 64 (32 rows per block pass) with a row count that is not a multiple of anything, fp32 and bf16 maps, running
     statistics and accumulate mode; col2im with padding against F.fold."""
