@@ -49,6 +49,15 @@ def train_step(m):
     return fn
 
 
+if os.environ.get('SCAN') == 'tiles':        # the row-major bf16 GEMM kernel tile by tile (plain operands, ResNet-like shapes), 100 launches per window
+    g = torch.Generator().manual_seed(0)
+    for tile, (M, N, K) in ((65, (30000, 64, 576)), (65, (30000, 64, 64)), (64, (30000, 128, 1152)), (128, (30000, 256, 1152)), (192, (12544, 768, 768)),
+                            (257, (12544, 2304, 768)), (256, (12544, 768, 768))):
+        a = (torch.randn(M, K, generator=g) * 0.5).to(dev).bfloat16()
+        w = (torch.randn(N, K, generator=g) * 0.05).to(dev).bfloat16()
+        o = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        scan('gemm_bf16_big tile %d, %d x %d x %d, x 100' % (tile, M, N, K), lambda: [L.gemm(a, w, o, tile=tile) for _ in range(100)], 60)
+    sys.exit(0)
 if os.environ.get('SCAN') == 'parts':        # the bf16 forward piece by piece: backbone, one sampler launch, one SMPL call (each repeated to fill the window)
     m = whmr_net(None, assets=assets, numerics='bf16')
     m.load_state_dict(sd, strict=False)
@@ -89,6 +98,8 @@ if os.environ.get('SCAN') == 'parts':        # the bf16 forward piece by piece: 
             scan('regressor stage x 30', stage, 60)
         except Exception as e:                   # noqa: BLE001
             print('regressor stage scan skipped:', type(e).__name__, e)
+        full_x = torch.randn(1, 3, 600, 800, generator=torch.Generator().manual_seed(11)).to(dev)
+        scan('camera model (ResNet-50, 600x800) x 4', lambda: [m.cam_model(full_x) for _ in range(4)], 120)
         m.overlap_camera = m.overlap_tz = False
         scan('full forward, side streams folded', lambda: m(d['x'], None, d['center'], d['scale'], d['bbox_height'], d['orig_shape'], d['bbox_info']), 140)
     sys.exit(0)
