@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 6, call 73: seven VALU files built without packed-fp32 instructions -- same-box A/B against the previous build (tools/lab/build/libwhmr_packed.so), tests
+# (tools/lab/build/libwhmr_packed.so = the library built with WHMR_BUILD_PACKED_FP32=1 python -m whmr_amd.build --force, copied aside; lab binaries are not kept in the tree)
 j() { python -c "import sys,json; [print('$1', round(json.loads(l)['ms_per_step'],3)) for l in sys.stdin if l.startswith('{')]"; }
 for r in 1 2; do
   python bench.py --no-cpu --no-secondary --no-ceilings 2>/dev/null | j "no-packed  vit224"
